@@ -1,0 +1,64 @@
+"""Seeded synthetic workloads of BASELINE.json's configs.
+
+Each builder returns (problem, P) where `problem` is an initialised single-agent
+`Point2point` (its template is shared by the whole batch) and P is a dict of
+per-agent arrays: 'p' [B, n_par] parameter vectors in the template's layout,
+'x0' [B, n_var] initial guesses (`get_init_spline_value`, hyperplanes zero).
+"""
+import numpy as np
+
+from .shapes import Circle, Square
+from .vehicles import Holonomic
+from .environment import Environment, Obstacle
+from .problems import Point2point
+
+
+def _place_obstacles(rng, n_obs, start, goal, r_lo, r_hi, box, clearance=0.3):
+    centres, radii = [], []
+    while len(centres) < n_obs:
+        r = rng.uniform(r_lo, r_hi)
+        c = rng.uniform(-box, box, size=2)
+        if np.linalg.norm(c - start) < r + clearance or np.linalg.norm(c - goal) < r + clearance:
+            continue
+        if any(np.linalg.norm(c - c2) < r + r2 + 0.05 for c2, r2 in zip(centres, radii)):
+            continue
+        centres.append(c)
+        radii.append(r)
+    return np.array(centres), np.array(radii)
+
+
+def holonomic_p2p(n_agents, knot_intervals=11, n_obs=3, seed=20240807 + 2,
+                  safety_distance=0., horizon_time=10., options=None):
+    """Config 2: batch of independent Holonomic point-to-point problems with
+    `n_obs` static circular obstacles each."""
+    rng = np.random.default_rng(seed)
+    vehicle = Holonomic(options={'safety_distance': safety_distance})
+    vehicle.define_knots(knot_intervals=knot_intervals)
+    vehicle.set_initial_conditions([-1.5, -1.5])
+    vehicle.set_terminal_conditions([1.5, 1.5])
+    environment = Environment(room={'shape': Square(5.)})
+    for l in range(n_obs):
+        environment.add_obstacle(Obstacle({'position': [0., 0.]}, shape=Circle(0.3)))
+    opts = {'horizon_time': horizon_time, 'verbose': 0}
+    opts.update(options or {})
+    problem = Point2point(vehicle, environment, options=opts)
+    problem.init()
+    tpl = problem.father.template
+    L = len(vehicle.basis)
+    p = np.zeros((n_agents, tpl.n_par))
+    x0 = np.zeros((n_agents, tpl.n_var))
+    rng_pos = rng
+    for b in range(n_agents):
+        start = rng_pos.uniform(-2., -1., size=2)
+        goal = rng_pos.uniform(1., 2., size=2)
+        centres, radii = _place_obstacles(rng_pos, n_obs, start, goal, 0.2, 0.4, 0.8)
+        lo, hi = tpl.entry_range(vehicle.label, 'state0', 'par'); p[b, lo:hi] = start
+        lo, hi = tpl.entry_range(vehicle.label, 'poseT', 'par'); p[b, lo:hi] = goal
+        for l, obs in enumerate(environment.obstacles):
+            lo, hi = tpl.entry_range(obs.label, 'x', 'par'); p[b, lo:hi] = centres[l]
+            lo, hi = tpl.entry_range(obs.label, 'rad', 'par'); p[b, lo:hi] = radii[l]
+        lo, hi = tpl.entry_range(problem.label, 'T', 'par'); p[b, lo:hi] = horizon_time
+        lo, hi = tpl.entry_range(vehicle.label, 'splines_seg0', 'var')
+        x0[b, lo:hi] = np.c_[np.linspace(start[0], goal[0], L),
+                             np.linspace(start[1], goal[1], L)].reshape(-1, order='F')
+    return problem, {'p': p, 'x0': x0}

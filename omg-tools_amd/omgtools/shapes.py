@@ -1,0 +1,156 @@
+"""Vehicle/obstacle shapes as *problem data*: checkpoints + radii, canvas
+limits, room hyperplanes.  Behavioural spec: reference `basics/shape.py`
+(Circle 49-68, Polyhedron 130-171, Rectangle 215-236, Square 239-243,
+Sphere 282-336, Polyhedron3D 339-362, Cuboid 402-438, Cube 441-444,
+Plate 447-454).  Drawing is out of the hot-path scope.
+"""
+import numpy as np
+
+
+def _rot2(theta):
+    c, s = np.cos(theta), np.sin(theta)
+    return np.array([[c, -s], [s, c]])
+
+
+def _rot3(orientation):
+    roll, pitch, yaw = orientation
+    cps, sps = np.cos(yaw), np.sin(yaw)
+    cth, sth = np.cos(pitch), np.sin(pitch)
+    cph, sph = np.cos(roll), np.sin(roll)
+    return np.array([[cth * cps, sph * sth * cps - cph * sps, cph * sth * cps + sph * sps],
+                     [cth * sps, sph * sth * sps + cph * cps, cph * sth * sps - sph * cps],
+                     [-sth, sph * cth, cph * cth]])
+
+
+class Shape(object):
+    def __init__(self, n_dim):
+        self.n_dim = n_dim
+
+    def draw(self, pose=None):
+        return [], []
+
+
+class Shape2D(Shape):
+    def __init__(self):
+        Shape.__init__(self, 2)
+
+    def rotate(self, orientation, coordinate):
+        if isinstance(orientation, np.ndarray):
+            orientation = orientation[0]
+        return _rot2(orientation).dot(coordinate)
+
+
+class Circle(Shape2D):
+    def __init__(self, radius):
+        Shape2D.__init__(self)
+        self.radius = radius
+        self.n_chck = 1
+
+    def get_checkpoints(self):
+        return [[0., 0.]], [self.radius]
+
+    def get_canvas_limits(self):
+        return [np.array([-self.radius, self.radius]),
+                np.array([-self.radius, self.radius])]
+
+
+class Polyhedron(Shape2D):
+    def __init__(self, vertices, orientation=0., radius=1e-3):
+        Shape2D.__init__(self)
+        self.n_vert = vertices.shape[1]
+        self.orientation = orientation
+        self.vertices = self.rotate(orientation, np.asarray(vertices, dtype=float))
+        self.radius = radius
+
+    def get_checkpoints(self):
+        chck = [[self.vertices[0, l], self.vertices[1, l]] for l in range(self.n_vert)]
+        return chck, [self.radius] * self.n_vert
+
+    def get_canvas_limits(self):
+        lo, hi = self.vertices.min(axis=1), self.vertices.max(axis=1)
+        return [np.array([lo[0], hi[0]]), np.array([lo[1], hi[1]])]
+
+    def get_hyperplanes(self, **kwargs):
+        pos = kwargs.get('position', [0, 0])
+        v = np.hstack((self.vertices, self.vertices[:, :1]))
+        planes = {}
+        for k in range(self.n_vert):
+            edge = v[:, k + 1] - v[:, k]
+            normal = np.array([-edge[1], edge[0]]) / np.hypot(edge[0], edge[1])
+            planes[k] = {'a': normal,
+                         'b': normal[0] * (v[0, k + 1] + pos[0]) + normal[1] * (v[1, k + 1] + pos[1])}
+        return planes
+
+
+class Rectangle(Polyhedron):
+    def __init__(self, width, height, orientation=0.):
+        self.width, self.height = width, height
+        w, h = 0.5 * width, 0.5 * height
+        # vertex order of the reference construction (`shape.py:221-236`)
+        Polyhedron.__init__(self, np.array([[w, w, -w, -w], [h, -h, -h, h]]), orientation)
+
+
+class Square(Rectangle):
+    def __init__(self, side, orientation=0.):
+        Rectangle.__init__(self, side, side, orientation)
+
+
+class Shape3D(Shape):
+    def __init__(self):
+        Shape.__init__(self, 3)
+
+    def rotate(self, orientation, coordinate):
+        if len(orientation) != 3:
+            raise ValueError('Orientation is a list with 3 elements: roll, pitch, yaw!')
+        return _rot3(orientation).dot(coordinate)
+
+
+class Sphere(Shape3D):
+    def __init__(self, radius):
+        Shape3D.__init__(self)
+        self.radius = radius
+        self.n_chck = 1
+
+    def get_checkpoints(self):
+        return [[0., 0., 0.]], [self.radius]
+
+    def get_canvas_limits(self):
+        return [np.array([-self.radius, self.radius]) for _ in range(3)]
+
+
+class Polyhedron3D(Shape3D):
+    def __init__(self, vertices, orientation=[0, 0, 0], radius=1e-3):
+        Shape3D.__init__(self)
+        self.n_vert = vertices.shape[1]
+        self.radius = radius
+        self.orientation = orientation
+        self.vertices = self.rotate(orientation, np.asarray(vertices, dtype=float))
+
+    def get_checkpoints(self):
+        chck = [[self.vertices[k, l] for k in range(3)] for l in range(self.n_vert)]
+        return chck, [self.radius] * self.n_vert
+
+    def get_canvas_limits(self):
+        lo, hi = self.vertices.min(axis=1), self.vertices.max(axis=1)
+        return [np.array([lo[k], hi[k]]) for k in range(3)]
+
+
+class Cuboid(Polyhedron3D):
+    def __init__(self, width, depth, height, orientation=[0, 0, 0]):
+        self.width, self.depth, self.height = width, depth, height
+        w, d, h = 0.5 * width, 0.5 * depth, 0.5 * height
+        xy = np.array([[w, w, -w, -w], [d, -d, -d, d]])
+        vertices = np.vstack((np.hstack((xy, xy)), np.r_[-h * np.ones(4), h * np.ones(4)]))
+        Polyhedron3D.__init__(self, vertices, orientation)
+
+
+class Cube(Cuboid):
+    def __init__(self, side, orientation=[0, 0, 0]):
+        Cuboid.__init__(self, side, side, side, orientation)
+
+
+class Plate(Polyhedron3D):
+    def __init__(self, shape2d, height, orientation=[0, 0, 0]):
+        self.shape2d = shape2d
+        vertices = np.vstack((shape2d.vertices, np.zeros((1, shape2d.vertices.shape[1]))))
+        Polyhedron3D.__init__(self, vertices, orientation, 0.5 * height)

@@ -1,0 +1,427 @@
+"""B-spline bases and splines with numeric or polynomial (`Poly`) coefficients.
+
+Host-side, construction-time spline algebra.  Behavioural spec (not code) is the
+reference's `basics/spline.py` (Basis 117-205, BSplineBasis 208-324, BSpline
+392-512) and `basics/spline_extra.py` (evalspline 28-55, integrals 58-85,
+shift matrices 107-255, knot insertion 258-305, sampling 406-410).
+
+Differences in *how* (results agree to rounding, pinned by tests/golden):
+  * basis-change and product matrices are obtained by exact least squares on
+    Chebyshev nodes of every knot span instead of collocation at the arg-max
+    of a 501-point grid (`spline.py:283-306`);
+  * the horizon-shift matrix is obtained from the polynomial continuation of
+    the last span instead of the derivative-matching construction
+    (`spline_extra.py:107-191`);
+  * coefficients may be `Poly` objects (symbolic.py) where the reference uses
+    CasADi MX.
+"""
+import numpy as np
+from collections import Counter
+
+from .symbolic import (Poly, SymbolTable, is_symbolic, matvec, as_poly_array)
+
+_TOL = 1e-10        # entries below this are structural zeros (spline.py:305)
+
+
+def _cheb_nodes(a, b, n):
+    k = np.arange(n)
+    x = np.cos((2 * k + 1) * np.pi / (2 * n))
+    return 0.5 * (a + b) + 0.5 * (b - a) * x
+
+
+class BSplineBasis(object):
+    """Knot vector + degree; evaluation follows the reference's span
+    convention: spans are (k_i, k_{i+1}] except the spans glued to the first
+    knot, which are closed on the left (`basics/spline.py:131-136`)."""
+    _cache = {}
+
+    def __new__(cls, knots, degree):
+        knots = np.asarray(knots, dtype=float)
+        key = (knots.tobytes(), int(degree))
+        inst = cls._cache.get(key)
+        if inst is None:
+            inst = object.__new__(cls)
+            inst.knots = knots.copy()
+            inst.degree = int(degree)
+            inst._memo = {}
+            cls._cache[key] = inst
+        return inst
+
+    def __len__(self):
+        return len(self.knots) - self.degree - 1
+
+    def __eq__(self, other):
+        return self is other
+
+    def __hash__(self):
+        return id(self)
+
+    def __call__(self, x):
+        return self.eval_basis(x)
+
+    # -- evaluation ----------------------------------------------------------
+    def eval_basis(self, x):
+        """Dense (len(x), len(self)) matrix of basis function values."""
+        x = np.atleast_1d(np.asarray(x, dtype=float))
+        k, d = self.knots, self.degree
+        nk = len(k)
+        lvl = np.zeros((nk - 1, x.size))
+        for i in range(nk - 1):
+            left_closed = (i < d + 1) and (k[0] == k[i])
+            lo = (x >= k[i]) if left_closed else (x > k[i])
+            lvl[i] = lo & (x <= k[i + 1])
+        for p in range(1, d + 1):
+            nxt = np.zeros((nk - p - 1, x.size))
+            for i in range(nk - p - 1):
+                den = k[i + p] - k[i]
+                if den != 0:
+                    nxt[i] += (x - k[i]) / den * lvl[i]
+                den = k[i + p + 1] - k[i + 1]
+                if den != 0:
+                    nxt[i] += (k[i + p + 1] - x) / den * lvl[i + 1]
+            lvl = nxt
+        return lvl.T.copy()
+
+    def spans(self):
+        """Distinct non-empty knot spans."""
+        u = np.unique(self.knots)
+        return list(zip(u[:-1], u[1:]))
+
+    def fit_points(self, degree=None):
+        """Chebyshev nodes on each span, enough to pin a piecewise polynomial
+        of the given degree."""
+        degree = self.degree if degree is None else degree
+        return np.concatenate([_cheb_nodes(a, b, degree + 2)
+                               for a, b in self.spans()])
+
+    def support(self):
+        d = self.degree
+        return list(zip(self.knots[:-(d + 1)], self.knots[d + 1:]))
+
+    def greville(self):
+        d = self.degree
+        return [self.knots[i + 1:i + d + 1].sum() / d for i in range(len(self))]
+
+    # -- derived bases ---------------------------------------------------------
+    def derivative(self, o=1):
+        """(basis of the o-th derivative, matrix P with c' = P c)."""
+        key = ('der', o)
+        if key not in self._memo:
+            k, d, n = self.knots, self.degree, len(self)
+            P = np.eye(n)
+            for step in range(o):
+                dd = d - step
+                kk = k[step:len(k) - step]
+                rows = n - step - 1
+                D = np.zeros((rows, rows + 1))
+                for i in range(rows):
+                    w = dd / (kk[i + dd + 1] - kk[i + 1])
+                    D[i, i], D[i, i + 1] = -w, w
+                P = D @ P
+            self._memo[key] = (BSplineBasis(k[o:len(k) - o], d - o), P)
+        return self._memo[key]
+
+    def _combine(self, other, degree):
+        cs, co = Counter(self.knots.tolist()), Counter(other.knots.tolist())
+        knots = []
+        for b in sorted(set(cs) | set(co)):
+            m = max(cs[b] + degree - self.degree if b in cs else -1,
+                    co[b] + degree - other.degree if b in co else -1)
+            knots += [b] * int(m)
+        return BSplineBasis(knots, degree)
+
+    def __add__(self, other):
+        if isinstance(other, BSplineBasis):
+            return self._combine(other, max(self.degree, other.degree))
+        return self
+
+    __radd__ = __add__
+    __sub__ = __add__
+    __rsub__ = __add__
+
+    def __mul__(self, other):
+        if isinstance(other, BSplineBasis):
+            return self._combine(other, self.degree + other.degree)
+        return self
+
+    __rmul__ = __mul__
+
+    def pairs(self, other):
+        """Index pairs (i, j) whose supports overlap (the only non-zero
+        products), in row-major order."""
+        key = ('pairs', other)
+        if key not in self._memo:
+            pi, pj = [], []
+            for i, (a0, a1) in enumerate(self.support()):
+                for j, (b0, b1) in enumerate(other.support()):
+                    if max(a0, b0) < min(a1, b1):
+                        pi.append(i)
+                        pj.append(j)
+            self._memo[key] = (np.array(pi), np.array(pj))
+        return self._memo[key]
+
+    def transform(self, other):
+        """T with  other(x) == self(x) @ T  (other's span inside self's)."""
+        key = ('tf', other)
+        if key not in self._memo:
+            x = self.fit_points()
+            T = np.linalg.lstsq(self.eval_basis(x), other.eval_basis(x),
+                                rcond=None)[0]
+            T[np.abs(T) < _TOL] = 0.
+            self._memo[key] = T
+        return self._memo[key]
+
+    def product_transform(self, a, b):
+        """T with (a-spline * b-spline) coefficients on self ==
+        T @ (ca[pi] * cb[pj]) for (pi, pj) = a.pairs(b)."""
+        key = ('ptf', a, b)
+        if key not in self._memo:
+            pi, pj = a.pairs(b)
+            x = self.fit_points()
+            prod = a.eval_basis(x)[:, pi] * b.eval_basis(x)[:, pj]
+            T = np.linalg.lstsq(self.eval_basis(x), prod, rcond=None)[0]
+            T[np.abs(T) < _TOL] = 0.
+            self._memo[key] = T
+        return self._memo[key]
+
+    def insert_knots(self, knots):
+        new = np.setdiff1d(knots, self.knots)
+        return BSplineBasis(np.sort(np.r_[self.knots, new]), self.degree)
+
+    def scale(self, factor, shift=0.):
+        return BSplineBasis(self.knots * factor + shift, self.degree)
+
+
+class BSpline(object):
+    """basis + coefficient vector (float ndarray or object ndarray of Poly)."""
+
+    def __init__(self, basis, coeffs):
+        self.basis = basis
+        if is_symbolic(coeffs):
+            self.coeffs = np.asarray(coeffs, dtype=object)
+        else:
+            self.coeffs = np.asarray(coeffs, dtype=float).reshape(-1)
+
+    def __len__(self):
+        return len(self.basis)
+
+    def __call__(self, x):
+        if isinstance(x, Poly):
+            return evalspline(self, x)
+        scalar = np.isscalar(x)
+        val = matvec(self.basis.eval_basis(x), self.coeffs)
+        return val[0] if scalar else val
+
+    def __neg__(self):
+        return BSpline(self.basis, -self.coeffs)
+
+    def __add__(self, other):
+        if isinstance(other, BSpline):
+            basis = self.basis + other.basis
+            return BSpline(basis,
+                           matvec(basis.transform(self.basis), self.coeffs) +
+                           matvec(basis.transform(other.basis), other.coeffs))
+        return BSpline(self.basis, self.coeffs + other)
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return self + (-other)
+
+    def __rsub__(self, other):
+        return (-self) + other
+
+    def __mul__(self, other):
+        if isinstance(other, BSpline):
+            basis = self.basis * other.basis
+            pi, pj = self.basis.pairs(other.basis)
+            T = basis.product_transform(self.basis, other.basis)
+            return BSpline(basis, matvec(T, self.coeffs[pi] * other.coeffs[pj]))
+        return BSpline(self.basis, self.coeffs * other)
+
+    __rmul__ = __mul__
+
+    def __pow__(self, power):
+        out = self
+        for _ in range(int(power) - 1):
+            out = out * self
+        return out
+
+    def derivative(self, o=1):
+        if o == 0:
+            return self
+        basis, P = self.basis.derivative(o)
+        return BSpline(basis, matvec(P, self.coeffs))
+
+    def integral(self):
+        k, d = self.basis.knots, self.basis.degree
+        w = (k[d + 1:] - k[:-(d + 1)]) / (d + 1)
+        return (w * self.coeffs).sum()
+
+    def insert_knots(self, knots):
+        basis = self.basis.insert_knots(knots)
+        return BSpline(basis, matvec(basis.transform(self.basis), self.coeffs))
+
+    def scale(self, factor, shift=0.):
+        return BSpline(self.basis.scale(factor, shift), self.coeffs)
+
+
+# ---------------------------------------------------------------------------
+# spline_extra equivalents
+# ---------------------------------------------------------------------------
+
+def evalspline(spline, x):
+    """Spline value at x.  For a parameter-dependent x (e.g. t/T) the basis
+    functions become derived atoms evaluated per agent on the device
+    (reference: symbolic Cox-de Boor, `spline_extra.py:28-55`)."""
+    if isinstance(x, Poly) and not x.is_constant():
+        ids = SymbolTable.current().new_bspl_atoms(
+            spline.basis.knots, spline.basis.degree, x)
+        acc = Poly()
+        for i, sym in enumerate(ids):
+            acc = acc + spline.coeffs[i] * Poly.symbol(sym)
+        return acc
+    if isinstance(x, Poly):
+        x = x.constant_value()
+    return matvec(spline.basis.eval_basis([x]), spline.coeffs)[0]
+
+
+def running_integral(spline):
+    """Antiderivative spline (value 0 at the first knot); `spline_extra.py:58-76`."""
+    k, d = spline.basis.knots, spline.basis.degree
+    basis_int = BSplineBasis(np.r_[k[0], k, k[-1]], d + 1)
+    w = (k[d + 1:] - k[:-(d + 1)]) / (d + 1)
+    if is_symbolic(spline.coeffs):
+        acc, out = Poly(), [Poly()]
+        for i in range(len(spline)):
+            acc = acc + spline.coeffs[i] * float(w[i])
+            out.append(acc)
+        coeffs = as_poly_array(out)
+    else:
+        coeffs = np.r_[0., np.cumsum(w * spline.coeffs)]
+    return BSpline(basis_int, coeffs)
+
+
+def definite_integral(spline, a, b):
+    s_int = running_integral(spline)
+    return evalspline(s_int, b) - evalspline(s_int, a)
+
+
+def _continued_basis(basis, x):
+    """Basis functions evaluated at x, where for x beyond the last knot each
+    function is the polynomial continuation of its last-span piece."""
+    x = np.asarray(x, dtype=float)
+    out = basis.eval_basis(np.minimum(x, basis.knots[-1]))
+    beyond = x > basis.knots[-1]
+    if beyond.any():
+        a, b = basis.spans()[-1]
+        nodes = _cheb_nodes(a, b, basis.degree + 1)
+        vals = basis.eval_basis(nodes)
+        # Lagrange extrapolation through the d+1 nodes (exact for degree d)
+        for r in np.nonzero(beyond)[0]:
+            lag = np.ones(len(nodes))
+            for i in range(len(nodes)):
+                for j in range(len(nodes)):
+                    if i != j:
+                        lag[i] *= (x[r] - nodes[j]) / (nodes[i] - nodes[j])
+            out[r] = lag @ vals
+    return out
+
+
+def extrapolate_T(basis, t_extra):
+    """Matrix to the basis with one extra span [k_end, k_end + t_extra] on which
+    the spline continues its last polynomial piece (`spline_extra.py:107-157`)."""
+    k, d = basis.knots, basis.degree
+    m = 1
+    while k[-d - 2 - m] >= k[-d - 2]:
+        m += 1
+    knots2 = np.r_[k[:-d - 1], k[-d - 1] * np.ones(m),
+                   (k[-1] + t_extra) * np.ones(d + 1)]
+    basis2 = BSplineBasis(knots2, d)
+    x = basis2.fit_points()
+    T = np.linalg.lstsq(basis2.eval_basis(x), _continued_basis(basis, x),
+                        rcond=None)[0]
+    T[np.abs(T) < _TOL] = 0.
+    return T
+
+
+def shiftoverknot_T(basis):
+    """Warm-start matrix when the horizon start passes the first interior knot:
+    the new coefficients describe s(tau + delta) on the same (uniform) knot
+    vector, the last span being the continuation of the old last piece
+    (`spline_extra.py:165-191`)."""
+    k, d = basis.knots, basis.degree
+    delta = k[d + 1] - k[0]
+    x = basis.fit_points()
+    T = np.linalg.lstsq(basis.eval_basis(x), _continued_basis(basis, x + delta),
+                        rcond=None)[0]
+    T[np.abs(T) < _TOL] = 0.
+    return T
+
+
+def shift_over_knot(coeffs, basis):
+    return matvec(shiftoverknot_T(basis), coeffs)
+
+
+def shiftfirstknot_T(basis, t_shift, inverse=False):
+    """Matrix re-expressing a spline on the basis whose first degree+1 knots sit
+    at t_shift (only the future part [t_shift, 1] is described); identity
+    outside the leading (d+1)x(d+1) block (`spline_extra.py:220-255`).
+    Numeric t_shift only; the per-agent device twin lives in the ADMM kernels."""
+    k, d = basis.knots.copy(), basis.degree
+    n = len(basis)
+    k2 = k.copy()
+    k2[:d + 1] = t_shift
+    basis2 = BSplineBasis(k2, d)
+    x = basis2.fit_points()
+    x = x[x >= t_shift]
+    T = np.linalg.lstsq(basis2.eval_basis(x), basis.eval_basis(x), rcond=None)[0]
+    T[np.abs(T) < _TOL] = 0.
+    T[d + 1:, :] = np.eye(n)[d + 1:, :]
+    if inverse:
+        return T, np.linalg.inv(T)
+    return T
+
+
+def shift_knot1_fwd(cfs, basis, t_shift):
+    return matvec(shiftfirstknot_T(basis, t_shift), cfs)
+
+
+def shift_knot1_bwd(cfs, basis, t_shift):
+    return matvec(shiftfirstknot_T(basis, t_shift, inverse=True)[1], cfs)
+
+
+def knot_insertion_T(basis, knots_to_insert):
+    new_knots = np.sort(np.r_[basis.knots, knots_to_insert])
+    basis2 = BSplineBasis(new_knots, basis.degree)
+    return basis2.transform(basis), new_knots.tolist()
+
+
+def crop_spline(spline, min_value, max_value):
+    """Piece of the spline on [min_value, max_value] as a clamped spline."""
+    k, d = spline.basis.knots, spline.basis.degree
+    ins = [min_value] * (d + 1 - int(np.sum(k == min_value))) + \
+          [max_value] * (d + 1 - int(np.sum(k == max_value)))
+    T, knots2 = knot_insertion_T(spline.basis, ins)
+    knots2 = np.asarray(knots2)
+    jmin = np.searchsorted(knots2, min_value, side='left')
+    jmax = np.searchsorted(knots2, max_value, side='right')
+    return BSpline(BSplineBasis(knots2[jmin:jmax], d),
+                   matvec(T[jmin:jmax - d - 1, :], spline.coeffs))
+
+
+def concat_splines(segments, segment_times, n_insert=None):
+    """Join per-segment splines (each on [0,1]) into splines on real time.
+    Single-segment problems (all FixedT point-to-point problems) reduce to a
+    rescale of the knot vector (`spline_extra.py:308-404`)."""
+    if len(segments) != 1:
+        raise NotImplementedError('multi-segment concatenation is out of the '
+                                  'hot-path scope (SURVEY.md §8)')
+    return [s.scale(segment_times[0]) for s in segments[0]]
+
+
+def sample_splines(splines, time):
+    """Host sampling helper (`spline_extra.py:406-410`); the batched device twin
+    is `omgx_batch_sample`."""
+    time = np.asarray(time, dtype=float)
+    return [matvec(s.basis.eval_basis(time), s.coeffs) for s in splines]

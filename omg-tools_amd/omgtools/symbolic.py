@@ -1,0 +1,330 @@
+"""Sparse polynomial coefficients: the numeric stand-in for CasADi MX/SX.
+
+The reference builds every constraint as a CasADi expression graph
+(`basics/optilayer.py:556-669`, `_define_mx` 610-617) and lets CasADi derive
+Jacobians/Hessians by AD.  All constraints on the hot path are *polynomial* in
+the decision variables (degree <= 3) with coefficients that
+are polynomials in the parameters and a few derived parameter quantities
+(t/T, basis functions evaluated at t/T).  So instead of a graph we carry each
+spline coefficient as an explicit sparse polynomial
+
+    sum_k  c_k * prod(atoms in A_k) * prod(variables in V_k)
+
+`Poly` implements exactly that ring.  Symbols are plain ints handed out by a
+`SymbolTable`; variable symbols and parameter ("atom") symbols live in
+disjoint id ranges so a monomial key is `(vars_tuple, atoms_tuple)`.
+
+Derived atoms (division of parameter polynomials, B-spline basis functions
+evaluated at a parameter-dependent point — the numeric twin of `evalspline`
+with a symbolic argument, `basics/spline_extra.py:28-55`) are recorded as a
+small straight-line program that the device evaluates per agent
+(csrc/omgx_kernels.hip, `eval_atoms`).
+"""
+import numpy as np
+
+VAR, ATOM = 0, 1
+_ATOM_BASE = 1 << 30          # ids >= _ATOM_BASE are atoms, below are variables
+
+
+def is_atom(sym):
+    return sym >= _ATOM_BASE
+
+
+class Poly(object):
+    """Sparse multivariate polynomial with float coefficients."""
+    __slots__ = ('terms',)
+    __array_ufunc__ = None      # make numpy defer to our reflected operators
+
+    def __init__(self, terms=None):
+        self.terms = terms if terms is not None else {}
+
+    # -- constructors ------------------------------------------------------
+    @staticmethod
+    def const(value):
+        value = float(value)
+        return Poly({((), ()): value} if value != 0.0 else {})
+
+    @staticmethod
+    def symbol(sym):
+        if is_atom(sym):
+            return Poly({((), (sym,)): 1.0})
+        return Poly({((sym,), ()): 1.0})
+
+    @staticmethod
+    def lift(value):
+        if isinstance(value, Poly):
+            return value
+        return Poly.const(value)
+
+    # -- queries -------------------------------------------------------------
+    def is_constant(self):
+        return all(k == ((), ()) for k in self.terms)
+
+    def is_param_only(self):
+        return all(len(k[0]) == 0 for k in self.terms)
+
+    def constant_value(self):
+        if not self.is_constant():
+            raise ValueError('polynomial is not constant')
+        return self.terms.get(((), ()), 0.0)
+
+    def var_degree(self):
+        return max([len(k[0]) for k in self.terms] + [0])
+
+    def variables(self):
+        out = set()
+        for k in self.terms:
+            out.update(k[0])
+        return out
+
+    def atoms(self):
+        out = set()
+        for k in self.terms:
+            out.update(k[1])
+        return out
+
+    def by_var_monomial(self):
+        """Group as {vars_tuple: Poly over atoms only}."""
+        out = {}
+        for (v, a), c in self.terms.items():
+            out.setdefault(v, {})[((), a)] = c
+        return {v: Poly(t) for v, t in out.items()}
+
+    def substitute_symbols(self, mapping):
+        """Rename symbols (int -> int); used to resolve `define_symbol`
+        placeholders (`basics/optilayer.py:209-230` translate_symbols)."""
+        out = {}
+        for (v, a), c in self.terms.items():
+            syms = [mapping.get(s, s) for s in v + a]
+            nv = tuple(sorted(s for s in syms if not is_atom(s)))
+            na = tuple(sorted(s for s in syms if is_atom(s)))
+            key = (nv, na)
+            out[key] = out.get(key, 0.0) + c
+        return Poly({k: c for k, c in out.items() if c != 0.0})
+
+    def evaluate(self, values):
+        """values: dict sym -> float (or callable sym -> float)."""
+        get = values.__getitem__ if not callable(values) else values
+        total = 0.0
+        for (v, a), c in self.terms.items():
+            m = c
+            for s in v:
+                m *= get(s)
+            for s in a:
+                m *= get(s)
+            total += m
+        return total
+
+    # -- ring operations -------------------------------------------------------
+    def _broadcast(self, other, op):
+        return np.array([op(o) for o in other.ravel()],
+                        dtype=object).reshape(other.shape)
+
+    def __add__(self, other):
+        if isinstance(other, np.ndarray):
+            return self._broadcast(other, lambda o: self + o)
+        other = Poly.lift(other)
+        out = dict(self.terms)
+        for k, c in other.terms.items():
+            nc = out.get(k, 0.0) + c
+            if nc == 0.0:
+                out.pop(k, None)
+            else:
+                out[k] = nc
+        return Poly(out)
+
+    __radd__ = __add__
+
+    def __neg__(self):
+        return Poly({k: -c for k, c in self.terms.items()})
+
+    def __sub__(self, other):
+        if isinstance(other, np.ndarray):
+            return self._broadcast(other, lambda o: self - o)
+        return self + (-Poly.lift(other))
+
+    def __rsub__(self, other):
+        if isinstance(other, np.ndarray):
+            return self._broadcast(other, lambda o: o - self)
+        return Poly.lift(other) + (-self)
+
+    def __mul__(self, other):
+        if isinstance(other, np.ndarray):
+            return self._broadcast(other, lambda o: self * o)
+        if isinstance(other, (int, float, np.floating, np.integer)):
+            other = float(other)
+            if other == 0.0:
+                return Poly()
+            return Poly({k: c * other for k, c in self.terms.items()})
+        if not isinstance(other, Poly):
+            return NotImplemented
+        out = {}
+        for (v1, a1), c1 in self.terms.items():
+            for (v2, a2), c2 in other.terms.items():
+                key = (tuple(sorted(v1 + v2)), tuple(sorted(a1 + a2)))
+                out[key] = out.get(key, 0.0) + c1 * c2
+        return Poly({k: c for k, c in out.items() if c != 0.0})
+
+    __rmul__ = __mul__
+
+    def __pow__(self, power):
+        if not isinstance(power, (int, np.integer)) or power < 0:
+            raise TypeError('exponent must be a non-negative integer')
+        out = Poly.const(1.0)
+        for _ in range(int(power)):
+            out = out * self
+        return out
+
+    def __truediv__(self, other):
+        if isinstance(other, (int, float, np.floating, np.integer)):
+            return self * (1.0 / float(other))
+        other = Poly.lift(other)
+        if other.is_constant():
+            return self * (1.0 / other.constant_value())
+        if not (self.is_param_only() and other.is_param_only()):
+            raise TypeError('division is only defined between parameter-only '
+                            'polynomials (e.g. t/T)')
+        table = SymbolTable.current()
+        return Poly.symbol(table.new_div_atom(self, other))
+
+    def __rtruediv__(self, other):
+        return Poly.lift(other) / self
+
+    def __repr__(self):
+        if not self.terms:
+            return 'Poly(0)'
+        parts = []
+        for (v, a), c in sorted(self.terms.items()):
+            parts.append('%g' % c + ''.join('*x%d' % s for s in v) +
+                         ''.join('*p%d' % (s - _ATOM_BASE) for s in a))
+        return 'Poly(' + ' + '.join(parts) + ')'
+
+
+def as_poly_array(values):
+    """1-D object array of Poly from numbers / Polys."""
+    values = list(values) if not isinstance(values, np.ndarray) else values
+    out = np.empty(len(values), dtype=object)
+    for i, v in enumerate(values):
+        out[i] = Poly.lift(v)
+    return out
+
+
+def is_symbolic(x):
+    if isinstance(x, Poly):
+        return True
+    return isinstance(x, np.ndarray) and x.dtype == object
+
+
+def vertcat(*args):
+    """Stack scalars/vectors into one coefficient vector (numeric if all
+    entries are numeric, object array of Poly otherwise)."""
+    flat = []
+    for a in args:
+        if isinstance(a, np.ndarray):
+            flat.extend(a.ravel().tolist())
+        elif isinstance(a, (list, tuple)):
+            flat.extend(a)
+        else:
+            flat.append(a)
+    if any(isinstance(f, Poly) for f in flat):
+        return as_poly_array(flat)
+    return np.array(flat, dtype=float)
+
+
+def matvec(T, coeffs):
+    """T (dense ndarray or scipy sparse) times a coefficient vector that may
+    hold Polys.  Mirrors `csr_matrix_alt.dot` (`basics/spline.py:97-114`)."""
+    if not is_symbolic(coeffs):
+        return np.asarray(T @ np.asarray(coeffs, dtype=float))
+    T = np.asarray(T.todense()) if hasattr(T, 'todense') else np.asarray(T)
+    coeffs = np.asarray(coeffs, dtype=object)
+    out = np.empty(T.shape[0], dtype=object)
+    for i in range(T.shape[0]):
+        acc = Poly()
+        for j in np.nonzero(T[i])[0]:
+            acc = acc + coeffs[j] * float(T[i, j])
+        out[i] = acc
+    return out
+
+
+class SymbolTable(object):
+    """Allocates symbol ids and records derived atoms.
+
+    atoms layout per agent at run time:  [raw parameters p | derived atoms],
+    derived atoms evaluated in creation order by a straight-line program:
+
+      ('div', num_poly, den_poly)             -> 1 atom
+      ('bspl', knots, degree, u_atom)         -> len(basis) consecutive atoms,
+                                                 B_i(u) with the reference's
+                                                 interval convention
+                                                 (`basics/spline.py:131-136`)
+    """
+    _stack = []
+
+    def __init__(self):
+        self.n_var_syms = 0
+        self.n_atoms = 0            # raw + derived, in creation order
+        self.atom_info = []         # per atom: ('raw',) | ('div', id) | ('bspl', id, i)
+        self.derived = []           # program entries
+        self._bspl_cache = {}
+        self._div_cache = {}
+
+    # context handling so Poly.__truediv__ can reach the active table
+    def __enter__(self):
+        SymbolTable._stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        SymbolTable._stack.pop()
+
+    @staticmethod
+    def current():
+        if not SymbolTable._stack:
+            raise RuntimeError('no active SymbolTable (problem not under '
+                               'construction)')
+        return SymbolTable._stack[-1]
+
+    def new_vars(self, n):
+        ids = list(range(self.n_var_syms, self.n_var_syms + n))
+        self.n_var_syms += n
+        return ids
+
+    def new_raw_atoms(self, n):
+        ids = []
+        for _ in range(n):
+            ids.append(_ATOM_BASE + self.n_atoms)
+            self.atom_info.append(('raw',))
+            self.n_atoms += 1
+        return ids
+
+    def new_div_atom(self, num, den):
+        key = (repr(num), repr(den))
+        if key in self._div_cache:
+            return self._div_cache[key]
+        sym = _ATOM_BASE + self.n_atoms
+        self.atom_info.append(('div', len(self.derived)))
+        self.derived.append(('div', num, den, sym))
+        self.n_atoms += 1
+        self._div_cache[key] = sym
+        return sym
+
+    def new_bspl_atoms(self, knots, degree, u_poly):
+        """Atoms for all basis functions of (knots, degree) evaluated at the
+        parameter-only polynomial `u_poly` (must be a single atom)."""
+        (key_u, coef), = u_poly.terms.items()
+        if coef != 1.0 or key_u[0] or len(key_u[1]) != 1:
+            raise TypeError('evaluation point must be a single atom (e.g. t/T)')
+        u_sym = key_u[1][0]
+        key = (tuple(np.asarray(knots, float).tolist()), int(degree), u_sym)
+        if key in self._bspl_cache:
+            return self._bspl_cache[key]
+        n = len(knots) - degree - 1
+        first = _ATOM_BASE + self.n_atoms
+        for i in range(n):
+            self.atom_info.append(('bspl', len(self.derived), i))
+            self.n_atoms += 1
+        ids = list(range(first, first + n))
+        self.derived.append(('bspl', np.asarray(knots, float), int(degree),
+                             u_sym, first))
+        self._bspl_cache[key] = ids
+        return ids

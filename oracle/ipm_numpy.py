@@ -1,0 +1,431 @@
+"""ORACLE (test infrastructure, never shipped or measured as product).
+
+Dense numpy statement of the primal-dual interior-point iteration that the HIP
+kernel (omg-tools_amd/csrc/omgx_kernels.hip, `ipm_solve_kernel`) runs per agent.
+It replaces -- it does not restate -- IPOPT, which is the third-party solver
+the reference calls at `problems/problem.py:113` through CasADi
+(`basics/optilayer.py:60`; casadi>=3.1.1.post3, `setup.py:29`, not vendored and
+not installable here).  PARITY UNPINNED for the solver itself: no IPOPT output is
+obtainable in this environment; results are cross-checked against scipy's
+independent SLSQP/trust-constr in tests/test_oracle_solver.py instead.
+
+The iteration (same constants as the kernel):
+  rows are classified from (lb, ub): equality (lb==ub), upper (ub finite),
+  lower (lb finite), free; h = sigma*(g - bound) <= 0 with slack s>0, h+s=0.
+  Newton on the perturbed KKT system, condensed to
+      [ H + Jh' diag(z/s) Jh + dw I    Je' ] [dx]   [ -(grad f + Jh'(mu/s + (z/s) r_p)) ]
+      [ Je                        -dc I ] [y+] = [ -r_E                             ]
+  factorised by LDL' without pivoting (quasi-definite); dw is raised until
+  all primal pivots are positive (inertia correction).  Fraction-to-boundary
+  step, l1-merit backtracking line search, monotone barrier update.
+"""
+import numpy as np
+
+DEFAULTS = dict(tol=1e-8, max_iter=200, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2,
+                theta_mu=1.5, tau_min=0.99, s_push=1.0, delta_c=1e-8, eta=1e-4,
+                rho=0.1, dw_first=1e-4, dw_inc=10.0, dw_dec=1. / 3., dw_max=1e10,
+                s_max=100.0, kappa_sigma=1e10, max_backtrack=25, max_soc=2,
+                slack_reset=True, kappa_push=1.0, nu_init=100.0, nu_max=1e8, e_push=1.0, scale_gmax=100.0, s_phi=2.3, s_theta=1.1, delta_sw=1.0,
+                gamma_theta=1e-5, gamma_phi=1e-5, filter_size=8)
+
+STATUS = {0: 'Solve_Succeeded', 1: 'Maximum_Iterations_Exceeded',
+          2: 'Infeasible_Problem_Detected', 3: 'Unsupported_Bounds',
+          4: 'Numerical_Failure'}
+
+
+def ldl_nopivot(K):
+    """In-place-style LDL' without pivoting; returns (L, d)."""
+    n = K.shape[0]
+    L = np.tril(K).astype(float)
+    d = np.zeros(n)
+    for j in range(n):
+        d[j] = L[j, j]
+        if d[j] == 0.0:
+            return L, d
+        L[j + 1:, j] /= d[j]
+        L[j, j] = 1.0
+        col = L[j + 1:, j]
+        L[j + 1:, j + 1:] -= np.tril(np.outer(col * d[j], col))
+    return L, d
+
+
+def ldl_solve(L, d, b):
+    n = len(b)
+    y = b.astype(float).copy()
+    for j in range(n):
+        y[j + 1:] -= L[j + 1:, j] * y[j]
+    y /= d
+    for j in range(n - 1, -1, -1):
+        y[j] -= L[j + 1:, j] @ y[j + 1:]
+    return y
+
+
+def solve_filter(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
+    o = dict(DEFAULTS)
+    o.update(opts or {})
+    n = nlp.n_var
+    c = nlp.term_coefs(p)
+    lb, ub = np.asarray(lb, float), np.asarray(ub, float)
+    eq = np.isfinite(lb) & (lb == ub)
+    up = np.isfinite(ub) & ~np.isfinite(lb)
+    lo = np.isfinite(lb) & ~np.isfinite(ub)
+    if np.any(np.isfinite(lb) & np.isfinite(ub) & (lb != ub)):
+        return dict(x=np.array(x0, float), lam_g=np.zeros(nlp.n_con), status=3, iters=0)
+    iE = np.nonzero(eq)[0]
+    iH = np.nonzero(up | lo)[0]
+    sig = np.where(up, 1.0, -1.0)[iH]
+    bnd = np.where(up, ub, lb)[iH]
+    mE, mH = len(iE), len(iH)
+    # gradient-based row scaling at x0 (as IPOPT's nlp_scaling_method, g_max=100)
+    J0 = nlp.jac(np.array(x0, float), c)
+    gmax = np.abs(J0[:nlp.n_con]).max(axis=1)
+    rho = np.where(gmax > o['scale_gmax'], o['scale_gmax'] / np.maximum(gmax, 1e-300), 1.0) \
+        if o['scale_gmax'] > 0 else np.ones(nlp.n_con)
+    bnd = bnd * rho[iH]
+    bE = lb[iE] * rho[iE]
+
+    def evaluate(xv):
+        fv, gv = nlp.fg(xv, c)
+        gv = gv * rho
+        return fv, sig * (gv[iH] - bnd), gv[iE] - bE
+
+    x = np.array(x0, float).copy()
+    mu = o['mu_init']
+    f, h, cE = evaluate(x)
+    s = np.maximum(-h, o['s_push'] * np.maximum(1.0, np.abs(h)))
+    z = mu / s if z0 is None else np.maximum(np.asarray(z0, float)[iH] * sig, 1e-12)
+    y = np.zeros(mE)
+    nu = 1.0
+    dw_last = 0.0
+    status, it, nfact = 1, 0, 0
+    filt = None
+    eps = np.finfo(float).eps
+
+    def kkt_error(mu_):
+        sd = max(o['s_max'], (np.abs(y).sum() + np.abs(z).sum()) / max(1, mE + mH)) / o['s_max']
+        return max(np.abs(r_d).max() / sd, np.abs(r_p).max() if mH else 0.0,
+                   np.abs(cE).max() if mE else 0.0,
+                   (np.abs(s * z - mu_).max() / sd) if mH else 0.0)
+
+    for it in range(o['max_iter'] + 1):
+        J = nlp.jac(x, c)
+        J[:nlp.n_con] *= rho[:, None]
+        gf, Jh, Je = J[nlp.n_con], sig[:, None] * J[iH], J[iE]
+        r_p = h + s
+        r_d = gf + Je.T @ y + Jh.T @ z
+        err0 = kkt_error(0.0)
+        if trace is not None:
+            trace.append(dict(it=it, f=f, mu=mu, err=err0, inf_pr=max(np.abs(r_p).max() if mH else 0,
+                              np.abs(cE).max() if mE else 0), inf_du=np.abs(r_d).max(), dw=dw_last))
+        if err0 <= o['tol']:
+            status = 0
+            break
+        if it == o['max_iter']:
+            break
+        while mu > o['tol'] / 10. and kkt_error(mu) <= o['kappa_eps'] * mu:
+            mu = max(o['tol'] / 10., min(o['kappa_mu'] * mu, mu ** o['theta_mu']))
+            if filt is not None:
+                filt = []
+        lam = np.zeros(nlp.n_con)
+        lam[iH] = sig * z
+        lam[iE] = y
+        H = nlp.hess(x, lam * rho, c)
+        Sig = z / s
+        M = H + Jh.T @ (Sig[:, None] * Jh)
+        dw, tries = 0.0, 0
+        while True:
+            K = np.zeros((n + mE, n + mE))
+            K[:n, :n] = M + dw * np.eye(n)
+            K[n:, :n] = Je
+            K[:n, n:] = Je.T
+            K[n:, n:] = -o['delta_c'] * np.eye(mE)
+            L, d = ldl_nopivot(K)
+            nfact += 1
+            if np.all(d[:n] > 0) and np.all(d[n:] < 0):
+                break
+            dw = (o['dw_first'] if dw_last == 0.0 else max(1e-10, dw_last * o['dw_dec'])) \
+                if dw == 0.0 else dw * o['dw_inc']
+            tries += 1
+            if dw > o['dw_max']:
+                status = 4
+                break
+        if status == 4:
+            break
+        if dw > 0:
+            dw_last = dw
+
+        def newton(rp_, rE_):
+            rhs = np.r_[-(gf + Jh.T @ (mu / s + Sig * rp_)), -rE_]
+            sol = ldl_solve(L, d, rhs)
+            for _ in range(o.get('n_refine', 2)):
+                res_ = rhs - K @ sol
+                res_[n:] -= o['delta_c'] * sol[n:]
+                sol += ldl_solve(L, d, res_)
+            dx_ = sol[:n]
+            return dx_, sol[n:], -rp_ - Jh @ dx_
+
+        def ftb(v, dv, tau_):
+            neg = dv < 0
+            return min(1.0, (-tau_ * v[neg] / dv[neg]).min()) if neg.any() else 1.0
+
+        dx, y_new, ds = newton(r_p, cE)
+        dz = mu / s - z - Sig * ds
+        tau = max(o['tau_min'], 1.0 - mu)
+        a_p, a_d = ftb(s, ds, tau), ftb(z, dz, tau)
+        theta0 = np.abs(r_p).sum() + np.abs(cE).sum()
+        phi0 = f - mu * np.log(s).sum()
+        dphi = gf @ dx - mu * (ds / s).sum()
+        if filt is None:
+            theta_max = 1e4 * max(1.0, theta0)
+            theta_min = 1e-4 * max(1.0, theta0)
+            filt = []
+
+        def trial(dx_, ds_, alpha_):
+            xt_ = x + alpha_ * dx_
+            st_ = s + alpha_ * ds_
+            ft_, ht_, cEt_ = evaluate(xt_)
+            if o['slack_reset']:
+                st_ = np.maximum(st_, -ht_)
+            th_ = np.abs(ht_ + st_).sum() + np.abs(cEt_).sum()
+            ph_ = ft_ - mu * np.log(st_).sum()
+            return xt_, st_, ft_, ht_, cEt_, th_, ph_
+
+        def acceptable(th_, ph_, alpha_):
+            """(accepted, f_type)"""
+            if th_ > theta_max:
+                return False, False
+            for (tj, pj) in filt:
+                if th_ >= tj and ph_ >= pj:
+                    return False, False
+            ftype = (theta0 <= theta_min and dphi < 0 and
+                     alpha_ * (-dphi) ** o['s_phi'] > o['delta_sw'] * theta0 ** o['s_theta'])
+            if ftype:
+                return ph_ <= phi0 + o['eta'] * alpha_ * dphi + 10 * eps * abs(phi0), True
+            return (th_ <= (1 - o['gamma_theta']) * theta0 or
+                    ph_ <= phi0 - o['gamma_phi'] * theta0), False
+
+        alpha, ok, nsoc, ftype = a_p, False, 0, False
+        if o.get('debug_it') == it:
+            ratio = np.where(ds < 0, -s / np.minimum(ds, -1e-300), np.inf)
+            idx = np.argsort(ratio)[:12]
+            for i in idx:
+                print('row %d s=%.3e ds=%.3e z=%.3e dz=%.3e h=%.3e r_p=%.3e ratio=%.3e Jdx=%.3e' % (iH[i], s[i], ds[i], z[i], dz[i], h[i], r_p[i], ratio[i], (Jh @ dx)[i]))
+        alpha_min = 1e-10
+        for bt in range(o['max_backtrack']):
+            xt, st, ft, ht, cEt, tht, pht = trial(dx, ds, alpha)
+            ok, ftype = acceptable(tht, pht, alpha)
+            if ok:
+                break
+            if bt == 0 and o['max_soc'] > 0 and tht >= theta0:
+                csoc_h, csoc_E, th_prev = alpha * r_p + (ht + st), alpha * cE + cEt, tht
+                for nsoc in range(1, o['max_soc'] + 1):
+                    dxs, y_s, dss = newton(csoc_h, csoc_E)
+                    a_s = ftb(s, dss, tau)
+                    xs, ss, fs, hs, cEs, ths, phs = trial(dxs, dss, a_s)
+                    ok, ftype = acceptable(ths, phs, a_s)
+                    if ok:
+                        xt, st, ft, ht, cEt, tht, pht = xs, ss, fs, hs, cEs, ths, phs
+                        alpha, y_new = a_s, y_s
+                        break
+                    if ths > 0.99 * th_prev:
+                        break
+                    th_prev = ths
+                    csoc_h, csoc_E = a_s * csoc_h + (hs + ss), a_s * csoc_E + cEs
+                if ok:
+                    break
+            alpha *= 0.5
+        if ok and not ftype:
+            filt.append(((1 - o['gamma_theta']) * theta0, phi0 - o['gamma_phi'] * theta0))
+            if len(filt) > o['filter_size']:
+                filt.pop(0)
+        nu = float(len(filt))
+        if trace is not None:
+            trace[-1].update(alpha=alpha, a_p=a_p, a_d=a_d, ok=ok, nu=nu, tries=tries, nsoc=nsoc, bt=bt)
+        x, s, f, h, cE = xt, st, ft, ht, cEt
+        z = z + a_d * dz
+        y = y + alpha * (y_new - y)
+        z = np.minimum(np.maximum(z, mu / (o['kappa_sigma'] * s)), o['kappa_sigma'] * mu / s)
+    lam = np.zeros(nlp.n_con)
+    lam[iH] = sig * z
+    lam[iE] = y
+    lam = lam * rho
+    return dict(x=x, lam_g=lam, status=status, iters=it, f=f, mu=mu, nfact=nfact)
+
+
+def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
+    """Feasible primal-dual interior point with an embedded phase I ("big-M"):
+    one extra variable t >= 0 relaxes every row that x0 does not satisfy with
+    margin,   h_i(x) - t*v_i <= 0,  c_E(x) - t*c_E(x0) = 0,  cost f + nu*t,
+    so (x0, t=1) is strictly feasible and every iterate stays strictly feasible
+    (slacks are reset to s = t*v - h after each step).  Plain Armijo on the
+    barrier function globalises it."""
+    o = dict(DEFAULTS)
+    o.update(opts or {})
+    n = nlp.n_var
+    c = nlp.term_coefs(p)
+    lb, ub = np.asarray(lb, float), np.asarray(ub, float)
+    eq = np.isfinite(lb) & (lb == ub)
+    up = np.isfinite(ub) & ~np.isfinite(lb)
+    lo = np.isfinite(lb) & ~np.isfinite(ub)
+    if np.any(np.isfinite(lb) & np.isfinite(ub) & (lb != ub)):
+        return dict(x=np.array(x0, float), lam_g=np.zeros(nlp.n_con), status=3, iters=0)
+    iE = np.nonzero(eq)[0]
+    iH = np.nonzero(up | lo)[0]
+    sig = np.where(up, 1.0, -1.0)[iH]
+    bnd = np.where(up, ub, lb)[iH]
+    mE, mH = len(iE), len(iH)
+    J0 = nlp.jac(np.array(x0, float), c)
+    gmax = np.abs(J0[:nlp.n_con]).max(axis=1)
+    rho = np.where(gmax > o['scale_gmax'], o['scale_gmax'] / np.maximum(gmax, 1e-300), 1.0) \
+        if o['scale_gmax'] > 0 else np.ones(nlp.n_con)
+    bnd = bnd * rho[iH]
+    bE = lb[iE] * rho[iE]
+
+    def evaluate(xv):
+        fv, gv = nlp.fg(xv, c)
+        gv = gv * rho
+        return fv, sig * (gv[iH] - bnd), gv[iE] - bE
+
+    x = np.array(x0, float).copy()
+    mu, nu = o['mu_init'], o['nu_init']
+    f, h, cE = evaluate(x)
+    v = np.maximum(h + o['kappa_push'], 0.0)
+    cE0 = cE.copy()
+    use_t = bool((v > 0).any() or (np.abs(cE0) > 0).any())
+    t = 1.0 if use_t else 0.0
+    s = t * v - h
+    z = mu / s
+    zt = mu / t if use_t else 0.0
+    y = np.zeros(mE)
+    dw_last = 0.0
+    status, it, nfact = 1, 0, 0
+    N = n + 1                      # (x, t)
+
+    def ftb(vv, dv, tau_):
+        neg = dv < 0
+        return min(1.0, (-tau_ * vv[neg] / dv[neg]).min()) if neg.any() else 1.0
+
+    for it in range(o['max_iter'] + 1):
+        J = nlp.jac(x, c)
+        J[:nlp.n_con] *= rho[:, None]
+        gf = np.r_[J[nlp.n_con], nu]
+        Jh = np.c_[sig[:, None] * J[iH], -v]
+        Je = np.c_[J[iE], -cE0]
+        rE = cE - t * cE0
+        r_d = gf + Je.T @ y + Jh.T @ z
+        r_d[n] -= zt
+        sd = max(o['s_max'], (np.abs(y).sum() + np.abs(z).sum()) / max(1, mE + mH)) / o['s_max']
+        viol = max(np.maximum(h, 0).max() if mH else 0.0, np.abs(cE).max() if mE else 0.0)
+
+        def kkt_error(mu_):
+            comp = np.abs(s * z - mu_).max() if mH else 0.0
+            if use_t:
+                comp = max(comp, abs(t * zt - mu_))
+            return max(np.abs(r_d).max() / sd, np.abs(rE).max() if mE else 0.0, comp / sd)
+
+        err0 = max(np.abs(r_d[:n]).max() / sd, viol, (np.abs(z * h).max() / sd) if mH else 0.0)
+        if trace is not None:
+            trace.append(dict(it=it, f=f, mu=mu, err=err0, inf_pr=viol, inf_du=np.abs(r_d).max(),
+                              dw=dw_last, nu=nu, t=t, zt=zt))
+        if err0 <= o['tol']:
+            status = 0
+            break
+        if it == o['max_iter']:
+            break
+        while mu > o['tol'] / 10. and kkt_error(mu) <= o['kappa_eps'] * mu:
+            mu = max(o['tol'] / 10., min(o['kappa_mu'] * mu, mu ** o['theta_mu']))
+        if use_t and zt < 0.1 * nu and t > o['tol'] and nu < o['nu_max'] and kkt_error(mu) <= 100 * o['kappa_eps'] * mu:
+            nu *= 10.0
+            zt += 0.9 * nu
+            continue
+        lam = np.zeros(nlp.n_con)
+        lam[iH] = sig * z
+        lam[iE] = y
+        H = np.zeros((N, N))
+        H[:n, :n] = nlp.hess(x, lam * rho, c)
+        Sig = z / s
+        M = H + Jh.T @ (Sig[:, None] * Jh)
+        if use_t:
+            M[n, n] += zt / t
+        else:
+            M[n, n] += 1.0
+        dw, tries = 0.0, 0
+        while True:
+            K = np.zeros((N + mE, N + mE))
+            K[:N, :N] = M + dw * np.eye(N)
+            K[N:, :N] = Je
+            K[:N, N:] = Je.T
+            K[N:, N:] = -o['delta_c'] * np.eye(mE)
+            L, d = ldl_nopivot(K)
+            nfact += 1
+            if np.all(d[:N] > 0) and np.all(d[N:] < 0):
+                break
+            dw = (o['dw_first'] if dw_last == 0.0 else max(1e-10, dw_last * o['dw_dec'])) \
+                if dw == 0.0 else dw * o['dw_inc']
+            tries += 1
+            if dw > o['dw_max']:
+                status = 4
+                break
+        if status == 4:
+            break
+        if dw > 0:
+            dw_last = dw
+        # r_p == 0 by construction (slack reset)
+        g_bar = gf + Jh.T @ (mu / s)
+        if use_t:
+            g_bar[n] -= mu / t
+        rhs = np.r_[-g_bar, -rE]
+        sol = ldl_solve(L, d, rhs)
+        for _ in range(o.get('n_refine', 2)):
+            res_ = rhs - K @ sol
+            res_[N:] -= o['delta_c'] * sol[N:]
+            sol += ldl_solve(L, d, res_)
+        dxt, y_new = sol[:N], sol[N:]
+        if not use_t:
+            dxt[n] = 0.0
+        ds = -Jh @ dxt
+        dz = mu / s - z - Sig * ds
+        dt = dxt[n]
+        dzt = (mu / t - zt - (zt / t) * dt) if use_t else 0.0
+        tau = max(o['tau_min'], 1.0 - mu)
+        a_p = ftb(s, ds, tau)
+        a_d = ftb(z, dz, tau)
+        if use_t:
+            if dt < 0:
+                a_p = min(a_p, -tau * t / dt)
+            if dzt < 0:
+                a_d = min(a_d, -tau * zt / dzt)
+        thE = np.abs(rE).sum()
+        nuE = 2.0 * max(1.0, np.abs(y_new).max() if mE else 0.0)
+        phi0 = f + nu * t - mu * np.log(s).sum() - (mu * np.log(t) if use_t else 0.0) + nuE * thE
+        dphi = g_bar @ dxt - nuE * thE
+        alpha, ok = a_p, False
+        for bt in range(o['max_backtrack']):
+            xt = x + alpha * dxt[:n]
+            tt = t + alpha * dt
+            ft, ht, cEt = evaluate(xt)
+            st = tt * v - ht
+            if st.min() > 0 and st.min() >= (1 - tau) * 0.0:
+                phit = ft + nu * tt - mu * np.log(st).sum() - (mu * np.log(tt) if use_t else 0.0) \
+                    + nuE * np.abs(cEt - tt * cE0).sum()
+                if phit <= phi0 + o['eta'] * alpha * dphi or phit - phi0 <= 10 * np.finfo(float).eps * abs(phi0):
+                    ok = True
+                    break
+            alpha *= 0.5
+        if trace is not None:
+            trace[-1].update(alpha=alpha, a_p=a_p, a_d=a_d, ok=ok, tries=tries, bt=bt, dphi=dphi)
+        if not ok:
+            status = 4
+            break
+        x, t, s, f, h, cE = xt, tt, st, ft, ht, cEt
+        z = z + a_d * dz
+        zt = zt + a_d * dzt
+        y = y + alpha * (y_new - y)
+        z = np.minimum(np.maximum(z, mu / (o['kappa_sigma'] * s)), o['kappa_sigma'] * mu / s)
+        if use_t:
+            zt = min(max(zt, mu / (o['kappa_sigma'] * t)), o['kappa_sigma'] * mu / t)
+    lam = np.zeros(nlp.n_con)
+    lam[iH] = sig * z
+    lam[iE] = y
+    lam = lam * rho
+    return dict(x=x, lam_g=lam, status=status, iters=it, f=f, mu=mu, nfact=nfact, nu=nu, t=t)
