@@ -1,0 +1,142 @@
+/* omgx.h -- C ABI of the MI355X-native batched spline-MPC solve path.
+ *
+ * Drop-in boundary for the one place omg-tools crosses into native numerics:
+ *   - reference `problems/problem.py:113`  result = self.problem(x0=, p=, lbg=, ubg=)
+ *     (CasADi nlpsol object built in `basics/optilayer.py:49-60`),
+ *   - reference `problems/admm.py:390` (x-update NLP), `admm.py:424,462,505`
+ *     (z / lambda / residual CasADi Functions),
+ *   - reference C++ export `omg::Point2Point::update/solve`
+ *     (`export/point2point/Point2Point.cpp:124-231`) and
+ *     `Vehicle::sampleSplines/evalSpline` (`export/vehicles/Vehicle.cpp:112-190`).
+ * The reference has no C ABI of its own (it links libcasadi from C++/Python);
+ * these entry points are what a ctypes/cgo/JNI binding of that call would bind.
+ *
+ * Conventions: every function returns 0 on success or a negative OMGX_E_* code;
+ * nothing throws across the ABI.  The caller owns every buffer it passes; the
+ * library owns only the handle and its device workspace.  All floating point is
+ * fp64.  A handle is bound to one HIP device and one stream and is not
+ * re-entrant; different handles may be driven from different threads/processes.
+ */
+#ifndef OMGX_H
+#define OMGX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMGX_VERSION 1
+
+/* error codes */
+#define OMGX_OK            0
+#define OMGX_E_INVALID    -1   /* bad argument / inconsistent template */
+#define OMGX_E_NODEVICE   -2   /* no usable HIP device */
+#define OMGX_E_HIP        -3   /* a HIP runtime call failed (see omgx_last_error) */
+#define OMGX_E_TOOLARGE   -4   /* per-agent workspace does not fit in LDS */
+
+/* per-agent solver status (mirrors IPOPT's return_status strings) */
+#define OMGX_SOLVE_SUCCEEDED        0
+#define OMGX_MAX_ITER_EXCEEDED      1
+#define OMGX_INFEASIBLE_DETECTED    2
+#define OMGX_UNSUPPORTED_BOUNDS     3
+#define OMGX_NUMERICAL_FAILURE      4
+
+/* flags for pointer arguments */
+#define OMGX_PTR_DEVICE     1   /* p/x0/x/lam_g/status/iters are device pointers */
+#define OMGX_BOUNDS_SHARED  2   /* lbg/ubg hold n_con values shared by all agents */
+#define OMGX_BOUNDS_DEVICE  4   /* lbg/ubg are device pointers */
+
+/* Flat NLP description + static solver plan (host pointers, copied by create).
+ * Produced by omgtools/template.py (NLPTemplate.flat_arrays, SolverPlan). */
+typedef struct omgx_template {
+  int32_t n_var, n_par, n_con, n_atoms, n_slots, n_terms;
+  int32_t n_prog, n_knots, n_pp, n_mono, n_matom;
+  const int32_t* prog;      /* [n_prog*6] derived-atom program */
+  const double*  knots;     /* [n_knots] */
+  const int32_t* pp_ptr;    /* [n_pp+1] */
+  const double*  pm_coef;   /* [n_mono] */
+  const int32_t* pm_ptr;    /* [n_mono+1] */
+  const int32_t* pm_atom;   /* [n_matom] */
+  const int32_t* slot_pp;   /* [n_slots] */
+  const int32_t* row_ptr;   /* [n_con+2], row n_con = objective */
+  const double*  t_coef;    /* [n_terms] */
+  const int32_t* t_slot;    /* [n_terms] */
+  const int32_t* t_var;     /* [n_terms*3], -1 = unused */
+  /* solver plan */
+  int32_t n_leaf, n_root, n_eq, nnz_j;
+  const int32_t* order;     /* [n_var+1] position -> variable (n_var = t) */
+  const int32_t* leaf_off;  /* [n_leaf+1] */
+  const int32_t* eq_rows;   /* [n_eq] */
+  const int32_t* jr_ptr;    /* [n_con+2] */
+  const int32_t* jr_pos;    /* [nnz_j] */
+  const int32_t* t_jidx;    /* [n_terms*3] */
+  const int32_t* row_leaf;  /* [n_con+1] */
+  const int32_t* jc_ptr;    /* [n_var+1] */
+  const int32_t* jc_row;    /* [nnz_j] */
+  const int32_t* jc_ent;    /* [nnz_j] */
+  const int32_t* cpl_ptr;   /* [n_leaf+1] */
+  const int32_t* cpl_idx;   /* [cpl_ptr[n_leaf]] */
+  const int32_t* cpl_map;   /* [max(n_leaf,1)*n_root] */
+} omgx_template;
+
+typedef struct omgx_options {
+  double  tol;          /* scaled KKT tolerance ('ipopt.tol') */
+  int32_t max_iter;     /* 'ipopt.max_iter' */
+  double  mu_init;      /* initial barrier parameter */
+  double  kappa_push;   /* rows within this distance of their bound are relaxed by t */
+  double  nu_init;      /* initial weight of the phase-I variable */
+  double  scale_gmax;   /* gradient-based row scaling threshold (0 = off) */
+} omgx_options;
+
+typedef struct omgx_batch omgx_batch;
+
+int  omgx_version(void);
+const char* omgx_last_error(void);
+const char* omgx_status_string(int32_t status);
+void omgx_default_options(omgx_options* o);
+
+/* Create a batch of n_agents independent problems sharing one template. */
+int  omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device,
+                       omgx_batch** out);
+void omgx_batch_destroy(omgx_batch* b);
+int  omgx_batch_set_options(omgx_batch* b, const omgx_options* o);
+/* Launch on this hipStream_t (as void*) instead of the handle's own stream. */
+int  omgx_batch_set_stream(omgx_batch* b, void* hip_stream);
+/* LDS bytes the solve kernel needs per agent (for diagnostics / DESIGN.md). */
+int  omgx_batch_lds_bytes(const omgx_batch* b);
+
+/* One MPC solve for every agent: the batched twin of
+ *   result = solver(x0=, p=, lbg=, ubg=)  ->  x, lam_g, return_status.
+ * p [B,n_par], x0 [B,n_var], lbg/ubg [B,n_con] (or [n_con] with
+ * OMGX_BOUNDS_SHARED), x [B,n_var], lam_g [B,n_con], status/iters [B].
+ * Asynchronous w.r.t. the host when OMGX_PTR_DEVICE is set; call omgx_batch_sync. */
+int  omgx_batch_solve(omgx_batch* b, const double* p, const double* x0,
+                      const double* lbg, const double* ubg,
+                      double* x, double* lam_g, int32_t* status, int32_t* iters,
+                      int32_t flags);
+int  omgx_batch_sync(omgx_batch* b);
+/* Device time (ms, HIP events on the handle's stream) of the last solve kernel. */
+int  omgx_batch_last_kernel_ms(omgx_batch* b, double* ms);
+
+/* Warm-start shift  coeffs <- T * coeffs  for the masked agents
+ * (reference `point2point.py:187-198`, `optilayer.py:470-490`,
+ * `spline_extra.py:165-191`).  entries: n_ent x {offset, rows, cols, T-offset};
+ * Tmats: concatenated row-major (rows x rows) matrices. */
+int  omgx_batch_shift(omgx_batch* b, double* x, const uint8_t* mask,
+                      const int32_t* entries, int32_t n_ent,
+                      const double* Tmats, int32_t n_tmat, int32_t flags);
+
+/* Post-solve trajectory sampling (reference `vehicle.py:250-300`,
+ * `spline_extra.py:406-410`, C++ `Vehicle::sampleSplines` Vehicle.cpp:112-129):
+ * out[b, d, k, i] = (d-th derivative of spline k of agent b)(t0[b] + i*dt), time
+ * in units of the spline domain [0,1]; coeffs [B, n_spl, L] = a slice of x.
+ * out is [B, n_der, n_spl, n_samp] fp64 (or fp32 when as_f32 != 0). */
+int  omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off,
+                       int32_t n_spl, int32_t degree, const double* knots, int32_t n_knots,
+                       int32_t n_der, const double* t0, double dt, int32_t n_samp,
+                       void* out, int32_t as_f32, int32_t flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMGX_H */

@@ -1,0 +1,426 @@
+// omgx.hip -- libomgx.so: C ABI (include/omgx.h) + gfx950 kernels.
+//
+// Kernels (all hand-written HIP for CDNA4, wave64):
+//   ipm_solve_kernel   one 256-thread workgroup per agent, whole interior-point
+//                      solve with every per-agent array resident in LDS
+//                      (<= 160 KiB / CU); only p, x0, bounds are read from HBM and
+//                      x, lam_g, status written back.
+//   sample_kernel      post-solve trajectory sampling (reference
+//                      `vehicles/vehicle.py:250-300`, `spline_extra.py:406-410`,
+//                      C++ `Vehicle::sampleSplines` Vehicle.cpp:112-129): the
+//                      HBM-write-bound stage, coalesced along the sample index.
+//   shift_kernel       warm-start shift T*coeffs (`spline_extra.py:165-191`).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/omgx.h"
+#include "omgx_core.h"
+#include "omgx_plan.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+#define HIPCHK(call)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      g_err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+      return OMGX_E_HIP;                                                          \
+    }                                                                             \
+  } while (0)
+
+constexpr int kThreads = 256;
+constexpr int kLdsLimit = 160 * 1024;
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
+                 const double* __restrict__ p, const double* __restrict__ x0,
+                 const double* __restrict__ lb, const double* __restrict__ ub, int bounds_shared,
+                 double* __restrict__ x, double* __restrict__ lam, int32_t* __restrict__ status,
+                 int32_t* __restrict__ iters, int n_agents) {
+  extern __shared__ __align__(16) double lds[];
+  const int b = blockIdx.x;
+  if (b >= n_agents) return;
+  omgx::Work w;
+  omgx::work_carve(w, lds, d, kkt_doubles);
+  omgx::Ctx c; c.red = w.red;
+  const double* lbb = lb + (bounds_shared ? 0 : (size_t)b * d.n_con);
+  const double* ubb = ub + (bounds_shared ? 0 : (size_t)b * d.n_con);
+  omgx::Result r = omgx::ipm_solve(c, d, T, o, w, p + (size_t)b * d.n_par, x0 + (size_t)b * d.n_var,
+                                   lbb, ubb, kkt_doubles);
+  __syncthreads();
+  for (int i = threadIdx.x; i < d.n_var; i += blockDim.x) x[(size_t)b * d.n_var + i] = w.x[i];
+  for (int q = threadIdx.x; q < d.n_con; q += blockDim.x)
+    lam[(size_t)b * d.n_con + q] =
+        (r.status == 3 || w.rtype[q] == omgx::ROW_FREE) ? 0.0 : w.rho[q] * w.z[q];
+  if (threadIdx.x == 0) { status[b] = r.status; iters[b] = r.iters; }
+}
+
+// out[b, o, k, i] = d^o/dt^o spline_k(t0[b] + i*dt); one block = (agent, 256-sample chunk)
+template <typename OutT>
+__global__ void __launch_bounds__(256)
+sample_kernel(const double* __restrict__ x, int x_stride, int coeff_off, int n_spl, int degree,
+              const double* __restrict__ knots, int n_knots, int n_der,
+              const double* __restrict__ t0, double dt, int n_samp, OutT* __restrict__ out) {
+  extern __shared__ __align__(16) double lds[];
+  const int L = n_knots - degree - 1;
+  double* kn = lds;                               // [n_knots]
+  double* cf = lds + n_knots;                     // [n_der][n_spl][L] derivative coefficients
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < n_knots; i += blockDim.x) kn[i] = knots[i];
+  for (int i = threadIdx.x; i < n_spl * L; i += blockDim.x)
+    cf[i] = x[(size_t)b * x_stride + coeff_off + i];
+  __syncthreads();
+  for (int o = 1; o < n_der; ++o) {               // c^(o)_i = (d-o+1) (c^(o-1)_{i+1}-c^(o-1)_i)/(k_{i+d+1}-k_{i+o})
+    const int Lo = L - o, dd = degree - o + 1;
+    for (int e = threadIdx.x; e < n_spl * Lo; e += blockDim.x) {
+      const int k = e / Lo, i = e - k * Lo;
+      const double* src = cf + ((o - 1) * n_spl + k) * L;
+      const double den = kn[i + degree + 1] - kn[i + o];
+      cf[(o * n_spl + k) * L + i] = den != 0.0 ? dd * (src[i + 1] - src[i]) / den : 0.0;
+    }
+    __syncthreads();
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_samp) return;
+  const double u = t0[b] + i * dt;
+  // span j: k_j < u <= k_{j+1} (reference convention, `basics/spline.py:131-136`)
+  int j = degree;
+  for (int q = degree + 1; q < n_knots - degree - 1; ++q) if (kn[q] < u) j = q;
+  for (int o = 0; o < n_der; ++o) {
+    const int dg = degree - o;                    // degree of the o-th derivative spline
+    // its knot vector is kn[o .. n_knots-o), coefficient i there <-> original index i
+    for (int k = 0; k < n_spl; ++k) {
+      const double* c = cf + (o * n_spl + k) * L;
+      double dbo[6];                              // de Boor triangle, degree <= 5
+      const int jo = j - o;                       // span index in the trimmed knot vector
+      for (int r = 0; r <= dg; ++r) dbo[r] = c[jo - dg + r];
+      const double* kk = kn + o;
+      for (int lev = 1; lev <= dg; ++lev)
+        for (int r = dg; r >= lev; --r) {
+          const int idx = jo - dg + r;
+          const double den = kk[idx + dg - lev + 1] - kk[idx];
+          const double a = den != 0.0 ? (u - kk[idx]) / den : 0.0;
+          dbo[r] = (1.0 - a) * dbo[r - 1] + a * dbo[r];
+        }
+      out[(((size_t)b * n_der + o) * n_spl + k) * n_samp + i] = (OutT)dbo[dg];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64)
+shift_kernel(double* __restrict__ x, int x_stride, const uint8_t* __restrict__ mask,
+             const int32_t* __restrict__ entries, int n_ent, const double* __restrict__ Tm) {
+  extern __shared__ __align__(16) double lds[];
+  const int b = blockIdx.x;
+  if (mask && !mask[b]) return;
+  for (int e = 0; e < n_ent; ++e) {
+    const int off = entries[4 * e], rows = entries[4 * e + 1], cols = entries[4 * e + 2];
+    const double* Tmat = Tm + entries[4 * e + 3];
+    double* xe = x + (size_t)b * x_stride + off;
+    for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) lds[i] = xe[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
+      const int k = i / rows, r = i - k * rows;
+      double acc = 0.0;
+      for (int q = 0; q < rows; ++q) acc += Tmat[r * rows + q] * lds[k * rows + q];
+      xe[i] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------
+struct omgx_batch {
+  int device = 0, n_agents = 0;
+  omgx::Dims dims;
+  omgx::Tables dev;               // device pointers
+  omgx::Opts opts;
+  int kkt_doubles = 0;
+  size_t lds_bytes = 0;
+  std::vector<void*> allocs;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  // staging buffers for host-pointer calls
+  double *d_p = nullptr, *d_x0 = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_x = nullptr, *d_lam = nullptr;
+  int32_t *d_status = nullptr, *d_iters = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int upload(omgx_batch* b, const T* src, size_t n, const T** dst) {
+  void* ptr = nullptr;
+  const size_t bytes = (n > 0 ? n : 1) * sizeof(T);
+  HIPCHK(hipMalloc(&ptr, bytes));
+  b->allocs.push_back(ptr);
+  if (n > 0) HIPCHK(hipMemcpy(ptr, src, n * sizeof(T), hipMemcpyHostToDevice));
+  *dst = (const T*)ptr;
+  return OMGX_OK;
+}
+
+template <typename T>
+int dalloc(omgx_batch* b, size_t n, T** dst) {
+  void* ptr = nullptr;
+  HIPCHK(hipMalloc(&ptr, (n > 0 ? n : 1) * sizeof(T)));
+  b->allocs.push_back(ptr);
+  *dst = (T*)ptr;
+  return OMGX_OK;
+}
+
+#define UP(field, count)                                             \
+  do { int rc_ = upload(b, H.field, (size_t)(count), &b->dev.field); \
+       if (rc_ != OMGX_OK) return rc_; } while (0)
+
+int build_batch(omgx_batch* b, const omgx_template* t) {
+  omgx::HostPlan plan;
+  if (!plan.build(*t)) { g_err = "inconsistent template/plan"; return OMGX_E_INVALID; }
+  b->dims = plan.dims;
+  b->kkt_doubles = plan.kkt_doubles;
+  b->lds_bytes = omgx::work_doubles(plan.dims, plan.kkt_doubles) * sizeof(double);
+  if (b->lds_bytes > (size_t)kLdsLimit) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "per-agent workspace %zu B exceeds the %d B LDS of one CU", b->lds_bytes, kLdsLimit);
+    g_err = buf;
+    return OMGX_E_TOOLARGE;
+  }
+  const omgx::Tables& H = plan.tables;
+  const omgx::Dims& d = plan.dims;
+  const int n_cpl = t->cpl_ptr[d.n_leaf];
+  UP(prog, 6 * d.n_prog); UP(knots, t->n_knots); UP(pp_ptr, t->n_pp + 1); UP(pm_coef, t->n_mono);
+  UP(pm_ptr, t->n_mono + 1); UP(pm_atom, t->n_matom); UP(slot_pp, d.n_slots);
+  UP(row_ptr, d.n_con + 2); UP(t_coef, d.n_terms); UP(t_slot, d.n_terms); UP(t_var, 3 * d.n_terms);
+  UP(order, d.N); UP(pos, d.N); UP(leaf_off, d.n_leaf + 1); UP(blk, d.N);
+  UP(eq_rows, d.n_eq); UP(eq_index, d.n_con);
+  UP(jr_ptr, d.n_con + 2); UP(jr_pos, d.nnz_j); UP(t_jidx, 3 * d.n_terms); UP(row_leaf, d.n_con + 1);
+  UP(jc_ptr, d.n_var + 1); UP(jc_row, d.nnz_j); UP(jc_ent, d.nnz_j);
+  UP(cpl_ptr, d.n_leaf + 1); UP(cpl_idx, n_cpl); UP(cpl_map, (d.n_leaf > 0 ? d.n_leaf : 1) * d.n_root);
+  UP(d_off, d.n_leaf + 1); UP(b_off, d.n_leaf > 0 ? d.n_leaf : 1);
+  return OMGX_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int omgx_version(void) { return OMGX_VERSION; }
+const char* omgx_last_error(void) { return g_err.c_str(); }
+
+const char* omgx_status_string(int32_t s) {
+  switch (s) {
+    case OMGX_SOLVE_SUCCEEDED: return "Solve_Succeeded";
+    case OMGX_MAX_ITER_EXCEEDED: return "Maximum_Iterations_Exceeded";
+    case OMGX_INFEASIBLE_DETECTED: return "Infeasible_Problem_Detected";
+    case OMGX_UNSUPPORTED_BOUNDS: return "Unsupported_Bounds";
+    case OMGX_NUMERICAL_FAILURE: return "Numerical_Failure";
+    default: return "Unknown";
+  }
+}
+
+void omgx_default_options(omgx_options* o) {
+  o->tol = 1e-3; o->max_iter = 300; o->mu_init = 0.1; o->kappa_push = 1.0;
+  o->nu_init = 100.0; o->scale_gmax = 100.0;
+}
+
+int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device, omgx_batch** out) {
+  if (!tpl || !out || n_agents <= 0) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) {
+    g_err = "no usable HIP device (the solve path has no CPU fallback)";
+    return OMGX_E_NODEVICE;
+  }
+  HIPCHK(hipSetDevice(device));
+  omgx_batch* b = new omgx_batch();
+  b->device = device; b->n_agents = n_agents;
+  omgx_options o; omgx_default_options(&o);
+  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax};
+  int rc = build_batch(b, tpl);
+  if (rc != OMGX_OK) { omgx_batch_destroy(b); return rc; }
+  const omgx::Dims& d = b->dims;
+  if ((rc = dalloc(b, (size_t)n_agents * d.n_par, &b->d_p)) || (rc = dalloc(b, (size_t)n_agents * d.n_var, &b->d_x0)) ||
+      (rc = dalloc(b, (size_t)n_agents * d.n_con, &b->d_lb)) || (rc = dalloc(b, (size_t)n_agents * d.n_con, &b->d_ub)) ||
+      (rc = dalloc(b, (size_t)n_agents * d.n_var, &b->d_x)) || (rc = dalloc(b, (size_t)n_agents * d.n_con, &b->d_lam)) ||
+      (rc = dalloc(b, (size_t)n_agents, &b->d_status)) || (rc = dalloc(b, (size_t)n_agents, &b->d_iters))) {
+    omgx_batch_destroy(b); return rc;
+  }
+  if (hipStreamCreate(&b->own_stream) != hipSuccess || hipEventCreate(&b->ev0) != hipSuccess ||
+      hipEventCreate(&b->ev1) != hipSuccess) { g_err = "stream/event creation failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
+  b->stream = b->own_stream;
+  if (hipFuncSetAttribute((const void*)ipm_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)b->lds_bytes) != hipSuccess) {
+    g_err = "cannot reserve dynamic LDS for ipm_solve_kernel"; omgx_batch_destroy(b); return OMGX_E_HIP;
+  }
+  *out = b;
+  return OMGX_OK;
+}
+
+void omgx_batch_destroy(omgx_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  for (void* p : b->allocs) (void)hipFree(p);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
+  delete b;
+}
+
+int omgx_batch_set_options(omgx_batch* b, const omgx_options* o) {
+  if (!b || !o || !(o->tol > 0) || o->max_iter < 0) { g_err = "bad options"; return OMGX_E_INVALID; }
+  b->opts = {o->tol, o->max_iter, o->mu_init, o->kappa_push, o->nu_init, o->scale_gmax};
+  return OMGX_OK;
+}
+
+int omgx_batch_set_stream(omgx_batch* b, void* s) {
+  if (!b) return OMGX_E_INVALID;
+  b->stream = s ? (hipStream_t)s : b->own_stream;
+  return OMGX_OK;
+}
+
+int omgx_batch_lds_bytes(const omgx_batch* b) { return b ? (int)b->lds_bytes : OMGX_E_INVALID; }
+
+int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const double* lbg, const double* ubg,
+                     double* x, double* lam_g, int32_t* status, int32_t* iters, int32_t flags) {
+  if (!b || !p || !x0 || !lbg || !ubg || !x || !lam_g || !status || !iters) { g_err = "null argument"; return OMGX_E_INVALID; }
+  HIPCHK(hipSetDevice(b->device));
+  const omgx::Dims& d = b->dims;
+  const int B = b->n_agents;
+  const bool dev = flags & OMGX_PTR_DEVICE, shared = flags & OMGX_BOUNDS_SHARED;
+  const bool bdev = (flags & OMGX_BOUNDS_DEVICE) != 0;
+  const size_t nb = (shared ? 1 : (size_t)B) * d.n_con;
+  const double *kp = p, *kx0 = x0, *klb = lbg, *kub = ubg;
+  double *kx = x, *klam = lam_g; int32_t *kst = status, *kit = iters;
+  if (!dev) {
+    HIPCHK(hipMemcpyAsync(b->d_p, p, (size_t)B * d.n_par * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_x0, x0, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    kp = b->d_p; kx0 = b->d_x0; kx = b->d_x; klam = b->d_lam; kst = b->d_status; kit = b->d_iters;
+  }
+  if (!bdev) {
+    HIPCHK(hipMemcpyAsync(b->d_lb, lbg, nb * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_ub, ubg, nb * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    klb = b->d_lb; kub = b->d_ub;
+  }
+  HIPCHK(hipEventRecord(b->ev0, b->stream));
+  hipLaunchKernelGGL(ipm_solve_kernel, dim3(B), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev, b->opts,
+                     b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(b->ev1, b->stream));
+  b->timed = true;
+  if (!dev) {
+    HIPCHK(hipMemcpyAsync(x, b->d_x, (size_t)B * d.n_var * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(lam_g, b->d_lam, (size_t)B * d.n_con * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(status, b->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(iters, b->d_iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+  }
+  return OMGX_OK;
+}
+
+int omgx_batch_sync(omgx_batch* b) {
+  if (!b) return OMGX_E_INVALID;
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return OMGX_OK;
+}
+
+int omgx_batch_last_kernel_ms(omgx_batch* b, double* ms) {
+  if (!b || !ms || !b->timed) { g_err = "no timed launch"; return OMGX_E_INVALID; }
+  HIPCHK(hipEventSynchronize(b->ev1));
+  float f = 0.f;
+  HIPCHK(hipEventElapsedTime(&f, b->ev0, b->ev1));
+  *ms = f;
+  return OMGX_OK;
+}
+
+int omgx_batch_shift(omgx_batch* b, double* x, const uint8_t* mask, const int32_t* entries, int32_t n_ent,
+                     const double* Tmats, int32_t n_tmat, int32_t flags) {
+  if (!b || !x || !entries || !Tmats || n_ent <= 0) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  HIPCHK(hipSetDevice(b->device));
+  const omgx::Dims& d = b->dims;
+  const int B = b->n_agents;
+  const bool dev = flags & OMGX_PTR_DEVICE;
+  int32_t* d_ent = nullptr; double* d_T = nullptr; uint8_t* d_mask = nullptr; double* d_xx = x;
+  int max_elems = 0;
+  for (int e = 0; e < n_ent; ++e) {
+    const int sz = entries[4 * e + 1] * entries[4 * e + 2];
+    if (sz > max_elems) max_elems = sz;
+  }
+  HIPCHK(hipMalloc((void**)&d_ent, 4 * n_ent * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&d_T, n_tmat * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(d_ent, entries, 4 * n_ent * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(d_T, Tmats, n_tmat * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  if (!dev) {
+    HIPCHK(hipMemcpyAsync(b->d_x, x, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    d_xx = b->d_x;
+    if (mask) {
+      HIPCHK(hipMalloc((void**)&d_mask, B));
+      HIPCHK(hipMemcpyAsync(d_mask, mask, B, hipMemcpyHostToDevice, b->stream));
+    }
+  } else {
+    d_mask = (uint8_t*)mask;
+  }
+  hipLaunchKernelGGL(shift_kernel, dim3(B), dim3(64), max_elems * sizeof(double), b->stream, d_xx, d.n_var,
+                     d_mask, d_ent, n_ent, d_T);
+  HIPCHK(hipGetLastError());
+  if (!dev) HIPCHK(hipMemcpyAsync(x, b->d_x, (size_t)B * d.n_var * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  (void)hipFree(d_ent); (void)hipFree(d_T);
+  if (!dev && d_mask) (void)hipFree(d_mask);
+  return OMGX_OK;
+}
+
+int omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off, int32_t n_spl, int32_t degree,
+                      const double* knots, int32_t n_knots, int32_t n_der, const double* t0, double dt,
+                      int32_t n_samp, void* out, int32_t as_f32, int32_t flags) {
+  if (!b || !x || !knots || !t0 || !out || degree > 5 || n_der > degree + 1 || n_samp <= 0) {
+    g_err = "bad argument"; return OMGX_E_INVALID;
+  }
+  HIPCHK(hipSetDevice(b->device));
+  const omgx::Dims& d = b->dims;
+  const int B = b->n_agents, L = n_knots - degree - 1;
+  const bool dev = flags & OMGX_PTR_DEVICE;
+  const size_t out_elems = (size_t)B * n_der * n_spl * n_samp, esz = as_f32 ? 4 : 8;
+  double* d_kn = nullptr; double* d_t0 = nullptr; void* d_out = out; const double* d_xx = x;
+  HIPCHK(hipMalloc((void**)&d_kn, n_knots * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(d_kn, knots, n_knots * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  if (!dev) {
+    HIPCHK(hipMemcpyAsync(b->d_x, x, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    d_xx = b->d_x;
+    HIPCHK(hipMalloc((void**)&d_t0, B * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(d_t0, t0, B * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMalloc(&d_out, out_elems * esz));
+  } else {
+    d_t0 = (double*)t0;
+  }
+  const dim3 grid((n_samp + 255) / 256, B), block(256);
+  const size_t lds = ((size_t)n_knots + (size_t)n_der * n_spl * L) * sizeof(double);
+  if (as_f32)
+    hipLaunchKernelGGL(sample_kernel<float>, grid, block, lds, b->stream, d_xx, d.n_var, coeff_off, n_spl, degree,
+                       d_kn, n_knots, n_der, d_t0, dt, n_samp, (float*)d_out);
+  else
+    hipLaunchKernelGGL(sample_kernel<double>, grid, block, lds, b->stream, d_xx, d.n_var, coeff_off, n_spl, degree,
+                       d_kn, n_knots, n_der, d_t0, dt, n_samp, (double*)d_out);
+  HIPCHK(hipGetLastError());
+  if (!dev) {
+    HIPCHK(hipMemcpyAsync(out, d_out, out_elems * esz, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    (void)hipFree(d_out); (void)hipFree(d_t0);
+  }
+  HIPCHK(hipStreamSynchronize(b->stream));
+  (void)hipFree(d_kn);
+  return OMGX_OK;
+}
+
+}  // extern "C"

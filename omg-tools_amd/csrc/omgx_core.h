@@ -1,0 +1,709 @@
+// omgx_core.h -- per-agent interior-point solve, written once for two targets:
+//
+//   * hipcc --offload-arch=gfx950: one 256-thread workgroup per agent, all
+//     state in LDS (omgx_kernels.hip: ipm_solve_kernel);
+//   * g++ -DOMGX_HOST_PORT: the same statements executed by one host thread
+//     (oracle/port/omgx_port.cpp) -- used ONLY as the timed CPU baseline and as
+//     a debugging aid; the product library never contains or calls it.
+//
+// What this replaces: IPOPT + MUMPS behind CasADi's nlpsol, called from
+// reference `problems/problem.py:113` (object built in `basics/optilayer.py:
+// 49-60`).  What it evaluates: the polynomial rows the front end extracted from
+// the reference's define_constraint calls.
+//
+// Algorithm (independent numpy statement in oracle/ipm_numpy.py):
+// feasible primal-dual interior point with an embedded phase I ("big-M")
+//     min f(x) + nu*t   s.t.  h_i(x) - t*v_i + s_i = 0, s>0;  c_E(x) - t*c_E(x0) = 0; t>0
+// gradient-based row scaling, exact Lagrangian Hessian with inertia correction,
+// block-arrow LDL' (leaves = hyperplane blocks, root = trajectory block + t +
+// equality multipliers), fraction-to-boundary, Armijo on the barrier function,
+// monotone barrier update.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#ifdef OMGX_HOST_PORT
+#define OMGX_FN inline
+#define OMGX_HD inline
+#else
+#define OMGX_FN __device__ __forceinline__
+#define OMGX_HD __host__ __device__ inline
+#endif
+
+namespace omgx {
+
+enum { ROW_FREE = 0, ROW_UPPER = 1, ROW_LOWER = 2, ROW_EQ = 3, ROW_BAD = 4 };
+enum { OP_DIV = 0, OP_BSPL = 1 };
+
+struct Dims {
+  int n_var, n_par, n_con, n_atoms, n_slots, n_terms, n_prog;
+  int N;        // n_var + 1 (phase-I variable t is variable index n_var)
+  int n_leaf, n_root, n_eq, nnz_j, root_off;
+  int nr;       // n_root + n_eq: order of the root block
+  int max_leaf, max_cpl;
+};
+
+struct Tables {   // read-only, shared by all agents (global memory)
+  const int32_t* prog; const double* knots;
+  const int32_t* pp_ptr; const double* pm_coef; const int32_t* pm_ptr; const int32_t* pm_atom;
+  const int32_t* slot_pp;
+  const int32_t* row_ptr; const double* t_coef; const int32_t* t_slot; const int32_t* t_var;
+  const int32_t* order; const int32_t* pos; const int32_t* leaf_off; const int32_t* blk;
+  const int32_t* eq_rows; const int32_t* eq_index;
+  const int32_t* jr_ptr; const int32_t* jr_pos; const int32_t* t_jidx; const int32_t* row_leaf;
+  const int32_t* jc_ptr; const int32_t* jc_row; const int32_t* jc_ent;
+  const int32_t* cpl_ptr; const int32_t* cpl_idx; const int32_t* cpl_map;
+  const int32_t* d_off; const int32_t* b_off;   // offsets of D_l / B_l inside the KKT store
+};
+
+struct Opts {
+  double tol; int max_iter; double mu_init, kappa_push, nu_init, scale_gmax;
+};
+
+// fixed constants of the iteration (same values in oracle/ipm_numpy.py DEFAULTS)
+#define OMGX_KAPPA_EPS   10.0
+#define OMGX_KAPPA_MU    0.2
+#define OMGX_THETA_MU    1.5
+#define OMGX_TAU_MIN     0.99
+#define OMGX_DELTA_C     1e-8
+#define OMGX_ETA         1e-4
+#define OMGX_DW_FIRST    1e-4
+#define OMGX_DW_INC      10.0
+#define OMGX_DW_DEC      (1.0 / 3.0)
+#define OMGX_DW_MAX      1e10
+#define OMGX_S_MAX       100.0
+#define OMGX_KAPPA_SIGMA 1e10
+#define OMGX_MAX_BACKTRACK 25
+#define OMGX_NU_MAX      1e8
+
+// Per-agent work arrays (LDS on the device, heap on the host port).
+struct Work {
+  double *atoms, *slots;
+  double *x, *xt;                 // [N] variable order, x[n_var] = t
+  double *hv, *ht;                // [n_con] scaled row values (h for inequality, c for equality)
+  double *bnd, *rho, *vv;         // [n_con] scaled bound, row scale (signed), phase-I weights
+  double *s, *z, *ds;             // [n_con] slack, multiplier (y for equality rows), slack step
+  double *jval;                   // [nnz_j] scaled Jacobian entries (objective row unscaled)
+  double *gbar, *sol;             // [N], [N + n_eq]   position order
+  double *kkt;                    // D_l (packed) | B_l | R (packed)
+  double *col;                    // [max(nr, max_leaf)] pivot column scratch
+  int32_t *rtype;                 // [n_con]
+  double *red;                    // reduction scratch [64]
+};
+
+OMGX_HD size_t work_doubles(const Dims& d, int kkt_doubles) {
+  size_t n = 0;
+  n += d.n_atoms + d.n_slots;
+  n += 2 * (size_t)d.N;
+  n += 8 * (size_t)d.n_con;
+  n += d.nnz_j;
+  n += d.N + (d.N + d.n_eq);
+  n += kkt_doubles;
+  n += (d.nr > d.max_leaf ? d.nr : d.max_leaf);
+  n += (d.n_con + 1) / 2;        // rtype (int32)
+  n += 64;
+  return n;
+}
+
+OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
+  double* p = base;
+  w.atoms = p; p += d.n_atoms;   w.slots = p; p += d.n_slots;
+  w.x = p; p += d.N;             w.xt = p; p += d.N;
+  w.hv = p; p += d.n_con;        w.ht = p; p += d.n_con;
+  w.bnd = p; p += d.n_con;       w.rho = p; p += d.n_con;     w.vv = p; p += d.n_con;
+  w.s = p; p += d.n_con;         w.z = p; p += d.n_con;       w.ds = p; p += d.n_con;
+  w.jval = p; p += d.nnz_j;
+  w.gbar = p; p += d.N;          w.sol = p; p += d.N + d.n_eq;
+  w.kkt = p; p += kkt_doubles;
+  w.col = p; p += (d.nr > d.max_leaf ? d.nr : d.max_leaf);
+  w.rtype = (int32_t*)p; p += (d.n_con + 1) / 2;
+  w.red = p;
+}
+
+// ---------------------------------------------------------------------------
+// execution context: thread id, barrier, reductions, LDS atomic add
+// ---------------------------------------------------------------------------
+#ifdef OMGX_HOST_PORT
+struct Ctx {
+  double* red;
+  int tid() const { return 0; }
+  int nthr() const { return 1; }
+  void sync() const {}
+  double rsum(double v) const { return v; }
+  double rmax(double v) const { return v; }
+  double rmin(double v) const { return v; }
+  void add(double* p, double v) const { *p += v; }
+};
+#else
+struct Ctx {
+  double* red;
+  __device__ int tid() const { return threadIdx.x; }
+  __device__ int nthr() const { return blockDim.x; }
+  __device__ void sync() const { __syncthreads(); }
+  template <int OP> __device__ double reduce(double v) const {
+    for (int off = 32; off > 0; off >>= 1) {
+      double o = __shfl_down(v, off, 64);
+      v = OP == 0 ? v + o : (OP == 1 ? fmax(v, o) : fmin(v, o));
+    }
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int i = 1; i < nw; ++i) r = OP == 0 ? r + red[i] : (OP == 1 ? fmax(r, red[i]) : fmin(r, red[i]));
+    __syncthreads();
+    return r;
+  }
+  __device__ double rsum(double v) const { return reduce<0>(v); }
+  __device__ double rmax(double v) const { return reduce<1>(v); }
+  __device__ double rmin(double v) const { return reduce<2>(v); }
+  __device__ void add(double* p, double v) const { atomicAdd(p, v); }   // ds_add_f64 on LDS
+};
+#endif
+
+#define OMGX_PFOR(i, n) for (int i = c.tid(); i < (n); i += c.nthr())
+
+// ---------------------------------------------------------------------------
+// parameter stage: atoms (Cox-de Boor at t/T, quotients) and coefficient slots
+// reference twin: symbolic evalspline `basics/spline_extra.py:28-55`, with the
+// span convention of `basics/spline.py:131-136`
+// ---------------------------------------------------------------------------
+OMGX_FN double pp_eval(const Tables& T, int pp, const double* a) {
+  double tot = 0.0;
+  for (int m = T.pp_ptr[pp]; m < T.pp_ptr[pp + 1]; ++m) {
+    double v = T.pm_coef[m];
+    for (int q = T.pm_ptr[m]; q < T.pm_ptr[m + 1]; ++q) v *= a[T.pm_atom[q]];
+    tot += v;
+  }
+  return tot;
+}
+
+OMGX_FN void bspl_row(const double* k, int nk, int deg, double u, double* out, double* tmp) {
+  // tmp: nk-1 doubles; out: nk-deg-1 doubles
+  for (int i = 0; i < nk - 1; ++i) {
+    bool left_closed = (i < deg + 1) && (k[0] == k[i]);
+    bool lo = left_closed ? (u >= k[i]) : (u > k[i]);
+    tmp[i] = (lo && u <= k[i + 1]) ? 1.0 : 0.0;
+  }
+  for (int d = 1; d <= deg; ++d) {
+    for (int i = 0; i < nk - d - 1; ++i) {
+      double b = 0.0;
+      double den = k[i + d] - k[i];
+      if (den != 0.0) b = (u - k[i]) * tmp[i] / den;
+      den = k[i + d + 1] - k[i + 1];
+      if (den != 0.0) b += (k[i + d + 1] - u) * tmp[i + 1] / den;
+      tmp[i] = b;
+    }
+  }
+  for (int i = 0; i < nk - deg - 1; ++i) out[i] = tmp[i];
+}
+
+template <class C>
+OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, const double* p) {
+  OMGX_PFOR(i, d.n_par) w.atoms[i] = p[i];
+  c.sync();
+  if (c.tid() == 0) {
+    for (int k = 0; k < d.n_prog; ++k) {
+      const int32_t* op = T.prog + 6 * k;
+      if (op[0] == OP_DIV) {
+        w.atoms[op[3]] = pp_eval(T, op[1], w.atoms) / pp_eval(T, op[2], w.atoms);
+      } else {
+        bspl_row(T.knots + op[1], op[2], op[3], w.atoms[op[4]], w.atoms + op[5], w.sol);
+      }
+    }
+  }
+  c.sync();
+  OMGX_PFOR(s, d.n_slots) w.slots[s] = pp_eval(T, T.slot_pp[s], w.atoms);
+  c.sync();
+}
+
+OMGX_FN double term_coef(const Tables& T, const Work& w, int t) {
+  const int sl = T.t_slot[t];
+  return sl < 0 ? T.t_coef[t] : T.t_coef[t] * w.slots[sl];
+}
+
+// value of row r (unscaled) at the variable-order point xv
+OMGX_FN double row_value(const Tables& T, const Work& w, int r, const double* xv) {
+  double g = 0.0;
+  for (int t = T.row_ptr[r]; t < T.row_ptr[r + 1]; ++t) {
+    double v = term_coef(T, w, t);
+    const int32_t* tv = T.t_var + 3 * t;
+    if (tv[0] >= 0) { v *= xv[tv[0]]; if (tv[1] >= 0) { v *= xv[tv[1]]; if (tv[2] >= 0) v *= xv[tv[2]]; } }
+    g += v;
+  }
+  return g;
+}
+
+// unscaled Jacobian entries of row r into jval[jr_ptr[r]..)
+OMGX_FN void row_jac(const Tables& T, Work& w, int r, const double* xv) {
+  for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) w.jval[e] = 0.0;
+  for (int t = T.row_ptr[r]; t < T.row_ptr[r + 1]; ++t) {
+    const double cf = term_coef(T, w, t);
+    const int32_t* tv = T.t_var + 3 * t;
+    const int32_t* je = T.t_jidx + 3 * t;
+    if (tv[0] < 0) continue;
+    if (tv[1] < 0) { w.jval[je[0]] += cf; continue; }
+    const double x0 = xv[tv[0]], x1 = xv[tv[1]];
+    if (tv[2] < 0) { w.jval[je[0]] += cf * x1; w.jval[je[1]] += cf * x0; continue; }
+    const double x2 = xv[tv[2]];
+    w.jval[je[0]] += cf * x1 * x2; w.jval[je[1]] += cf * x0 * x2; w.jval[je[2]] += cf * x0 * x1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// block-arrow KKT store
+// ---------------------------------------------------------------------------
+OMGX_FN int tri(int i, int k) { return i * (i + 1) / 2 + k; }   // packed lower, row-major, i >= k
+
+struct Kkt {
+  const Dims* d; const Tables* T; double* a;
+  OMGX_FN double* D(int l) const { return a + T->d_off[l]; }
+  OMGX_FN double* B(int l) const { return a + T->b_off[l]; }
+  OMGX_FN double* R() const { return a + T->d_off[d->n_leaf]; }
+  OMGX_FN int nl(int l) const { return T->leaf_off[l + 1] - T->leaf_off[l]; }
+  OMGX_FN int nc(int l) const { return T->cpl_ptr[l + 1] - T->cpl_ptr[l]; }
+  // address of entry (p, q), positions with p >= q, p,q < N
+  OMGX_FN double* at(int p, int q) const {
+    const int ro = d->root_off;
+    if (p < ro) { const int l = T->blk[p], o = T->leaf_off[l]; return D(l) + tri(p - o, q - o); }
+    if (q < ro) { const int l = T->blk[q]; const int arow = T->cpl_map[l * d->n_root + (p - ro)];
+                  return B(l) + arow * nl(l) + (q - T->leaf_off[l]); }
+    return R() + tri(p - ro, q - ro);
+  }
+};
+
+// LDL' without pivoting of a packed lower matrix, in place (unit L below the
+// diagonal, pivots on it).  Returns (through *bad) whether a pivot has the
+// wrong sign: the first n_pos pivots must be > 0, the rest < 0.
+template <class C>
+OMGX_FN void ldl_packed(const C& c, double* A, int n, int n_pos, double* col, int* bad) {
+  for (int j = 0; j < n; ++j) {
+    const double dj = A[tri(j, j)];
+    if ((j < n_pos) ? !(dj > 0.0) : !(dj < 0.0)) { *bad = 1; return; }   // uniform: all threads read the same value
+    OMGX_PFOR(i, n - j - 1) col[j + 1 + i] = A[tri(j + 1 + i, j)];
+    c.sync();
+    const double inv = 1.0 / dj;
+    // trailing update, 2-D thread tiling (16 x nthr/16)
+    const int si = c.nthr() >= 16 ? 16 : 1;
+    const int ti = c.tid() % si, tk = c.tid() / si, sk = c.nthr() / si;
+    for (int i = j + 1 + ti; i < n; i += si) {
+      const double li = col[i] * inv;
+      for (int k = j + 1 + tk; k <= i; k += sk) A[tri(i, k)] -= li * col[k];
+      if (tk == 0) A[tri(i, j)] = li;
+    }
+    c.sync();
+  }
+}
+
+// forward  y <- L^{-1} y ; diag  y <- y / d ; backward  y <- L^{-T} y   (packed unit-lower L)
+template <class C>
+OMGX_FN void tri_fwd(const C& c, const double* A, int n, double* y) {
+  for (int j = 0; j < n - 1; ++j) {
+    const double yj = y[j];
+    OMGX_PFOR(i, n - j - 1) y[j + 1 + i] -= A[tri(j + 1 + i, j)] * yj;
+    c.sync();
+  }
+}
+template <class C>
+OMGX_FN void tri_diag(const C& c, const double* A, int n, double* y) {
+  OMGX_PFOR(i, n) y[i] /= A[tri(i, i)];
+  c.sync();
+}
+template <class C>
+OMGX_FN void tri_bwd(const C& c, const double* A, int n, double* y) {
+  for (int j = n - 1; j > 0; --j) {
+    const double yj = y[j];
+    OMGX_PFOR(i, j) y[i] -= A[tri(j, i)] * yj;
+    c.sync();
+  }
+}
+
+// Factorise the assembled block-arrow matrix in place.  Returns 0 if the
+// inertia is (N positive, n_eq negative), 1 otherwise.
+template <class C>
+OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
+  int bad = 0;
+  for (int l = 0; l < d.n_leaf; ++l) {
+    const int n = K.nl(l), nc = K.nc(l);
+    double* D = K.D(l); double* B = K.B(l);
+    ldl_packed(c, D, n, n, w.col, &bad);
+    if (bad) return 1;
+    // B <- B L^{-T}: every coupled row solved independently
+    OMGX_PFOR(a, nc) {
+      double* b = B + a * n;
+      for (int k = 1; k < n; ++k) {
+        double acc = b[k];
+        for (int j = 0; j < k; ++j) acc -= b[j] * D[tri(k, j)];
+        b[k] = acc;
+      }
+    }
+    c.sync();
+    // R[i][k] -= sum_j Wt[a_i][j] Wt[a_k][j] / d_j   (Schur complement onto the root)
+    double* R = K.R();
+    const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
+    OMGX_PFOR(e, nc * nc) {
+      const int ai = e / nc, ak = e - ai * nc;
+      if (ak <= ai) {
+        const double* bi = B + ai * n; const double* bk = B + ak * n;
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += bi[j] * bk[j] / D[tri(j, j)];
+        R[tri(ci[ai], ci[ak])] -= acc;
+      }
+    }
+    c.sync();
+  }
+  ldl_packed(c, K.R(), d.nr, d.n_root, w.col, &bad);
+  return bad;
+}
+
+// Solve K sol = rhs in place (sol holds rhs on entry); position order + eq.
+template <class C>
+OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, double* sol) {
+  double* yr = sol + d.root_off;
+  for (int l = 0; l < d.n_leaf; ++l) {
+    const int n = K.nl(l), nc = K.nc(l);
+    double* yl = sol + K.T->leaf_off[l];
+    tri_fwd(c, K.D(l), n, yl);
+    tri_diag(c, K.D(l), n, yl);                 // yl = Delta^{-1} L^{-1} r_l
+    const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
+    const double* B = K.B(l);
+    OMGX_PFOR(a, nc) {
+      double acc = 0.0;
+      for (int j = 0; j < n; ++j) acc += B[a * n + j] * yl[j];
+      yr[ci[a]] -= acc;
+    }
+    c.sync();
+  }
+  tri_fwd(c, K.R(), d.nr, yr);
+  tri_diag(c, K.R(), d.nr, yr);
+  tri_bwd(c, K.R(), d.nr, yr);
+  for (int l = 0; l < d.n_leaf; ++l) {
+    const int n = K.nl(l), nc = K.nc(l);
+    double* yl = sol + K.T->leaf_off[l];
+    const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
+    const double* B = K.B(l); const double* D = K.D(l);
+    OMGX_PFOR(j, n) {
+      double acc = 0.0;
+      for (int a = 0; a < nc; ++a) acc += B[a * n + j] * yr[ci[a]];
+      yl[j] -= acc / D[tri(j, j)];
+    }
+    c.sync();
+    tri_bwd(c, D, n, yl);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// the solve
+// ---------------------------------------------------------------------------
+struct Result { int status, iters; double f, mu, t; };
+
+template <class C>
+OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts& o, Work& w,
+                         const double* p, const double* x0, const double* lb, const double* ub,
+                         int kkt_doubles) {
+  const int n = d.n_var, m = d.n_con, N = d.N;
+  Result res; res.status = 1; res.iters = 0; res.f = 0; res.mu = o.mu_init; res.t = 0;
+  Kkt K; K.d = &d; K.T = &T; K.a = w.kkt;
+
+  eval_params(c, d, T, w, p);
+  OMGX_PFOR(i, n) w.x[i] = x0[i];
+  if (c.tid() == 0) w.x[n] = 1.0;
+  c.sync();
+
+  // ---- row classification, gradient-based scaling, phase-I weights -----------
+  double bad_local = 0.0;
+  OMGX_PFOR(r, m) {
+    const double l = lb[r], u = ub[r];
+    const bool fl = isfinite(l), fu = isfinite(u);
+    int ty = ROW_FREE;
+    if (fl && fu) ty = (l == u) ? ROW_EQ : ROW_BAD;
+    else if (fu) ty = ROW_UPPER;
+    else if (fl) ty = ROW_LOWER;
+    if (T.eq_index[r] >= 0) { if (ty != ROW_EQ && ty != ROW_FREE) ty = ROW_BAD; }
+    else if (ty == ROW_EQ) ty = ROW_BAD;
+    if (ty == ROW_BAD) bad_local = 1.0;
+    w.rtype[r] = ty;
+    row_jac(T, w, r, w.x);
+    double gm = 0.0;
+    for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) gm = fmax(gm, fabs(w.jval[e]));
+    double rho = (o.scale_gmax > 0.0 && gm > o.scale_gmax) ? o.scale_gmax / gm : 1.0;
+    const double sg = (ty == ROW_LOWER) ? -1.0 : 1.0;
+    w.rho[r] = sg * rho;                                  // signed scale: h = rho*(g - bound)
+    w.bnd[r] = (ty == ROW_LOWER || ty == ROW_EQ) ? l : (ty == ROW_UPPER ? u : 0.0);
+    const double g = row_value(T, w, r, w.x);
+    const double h = (ty == ROW_FREE) ? 0.0 : w.rho[r] * (g - w.bnd[r]);
+    w.hv[r] = h;
+    double v = 0.0;
+    if (ty == ROW_UPPER || ty == ROW_LOWER) v = fmax(h + o.kappa_push, 0.0);
+    else if (ty == ROW_EQ) v = h;
+    w.vv[r] = v;
+  }
+  if (c.rmax(bad_local) > 0.0) { res.status = 3; return res; }
+  double any_local = 0.0;
+  OMGX_PFOR(r, m) if (w.vv[r] != 0.0) any_local = 1.0;
+  const bool use_t = c.rmax(any_local) > 0.0;
+  double mu = o.mu_init, nu = o.nu_init;
+  double t = use_t ? 1.0 : 0.0, zt = use_t ? mu / t : 0.0;
+  if (c.tid() == 0) w.x[n] = t;
+  OMGX_PFOR(r, m) {
+    const int ty = w.rtype[r];
+    if (ty == ROW_UPPER || ty == ROW_LOWER) { w.s[r] = t * w.vv[r] - w.hv[r]; w.z[r] = mu / w.s[r]; }
+    else { w.s[r] = 1.0; w.z[r] = 0.0; }
+  }
+  c.sync();
+  double f = row_value(T, w, m, w.x);
+  double dw_last = 0.0;
+  int it = 0, status = 1;
+
+  for (it = 0; it <= o.max_iter; ++it) {
+    // ---- Jacobian (scaled) -----------------------------------------------------
+    OMGX_PFOR(r, m + 1) {
+      row_jac(T, w, r, w.x);
+      if (r < m) {
+        const double sc = (w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r];
+        for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) w.jval[e] *= sc;
+      }
+    }
+    c.sync();
+    // ---- dual residual, barrier gradient (position order), error measures -------
+    double rd_max = 0.0;
+    OMGX_PFOR(q, n) {
+      double rd = 0.0, gb = 0.0;
+      for (int k = T.jc_ptr[q]; k < T.jc_ptr[q + 1]; ++k) {
+        const int r = T.jc_row[k]; const double jv = w.jval[T.jc_ent[k]];
+        if (r == m) { rd += jv; gb += jv; }
+        else {
+          const int ty = w.rtype[r];
+          if (ty == ROW_UPPER || ty == ROW_LOWER) { rd += jv * w.z[r]; gb += jv * (mu / w.s[r]); }
+          else if (ty == ROW_EQ) rd += jv * w.z[r];
+        }
+      }
+      w.gbar[q] = gb;          // refreshed below if mu changes
+      w.sol[q] = rd;
+      rd_max = fmax(rd_max, fabs(rd));
+    }
+    double viol = 0.0, zh = 0.0, rE_max = 0.0, rE_sum = 0.0, vz = 0.0, lam_sum = 0.0, cnt = 0.0;
+    OMGX_PFOR(r, m) {
+      const int ty = w.rtype[r];
+      if (ty == ROW_UPPER || ty == ROW_LOWER) {
+        cnt += 1.0; lam_sum += fabs(w.z[r]); vz += w.vv[r] * w.z[r];
+        viol = fmax(viol, w.hv[r]); zh = fmax(zh, fabs(w.z[r] * w.hv[r]));
+      } else if (ty == ROW_EQ) {
+        cnt += 1.0; lam_sum += fabs(w.z[r]); vz += w.vv[r] * w.z[r];
+        viol = fmax(viol, fabs(w.hv[r]));
+        const double re = w.hv[r] - t * w.vv[r];
+        rE_max = fmax(rE_max, fabs(re)); rE_sum += fabs(re);
+      }
+    }
+    rd_max = c.rmax(rd_max); lam_sum = c.rsum(lam_sum); vz = c.rsum(vz); cnt = c.rsum(cnt);
+    viol = c.rmax(viol); zh = c.rmax(zh); rE_max = c.rmax(rE_max); rE_sum = c.rsum(rE_sum);
+    const double sd = fmax(OMGX_S_MAX, lam_sum / fmax(1.0, cnt)) / OMGX_S_MAX;
+    const double err0 = fmax(rd_max / sd, fmax(viol, zh / sd));
+    res.f = f; res.mu = mu; res.t = t; res.iters = it;
+    if (err0 <= o.tol) { status = 0; break; }
+    if (it == o.max_iter) break;
+    // barrier-problem error at a given mu
+    for (;;) {
+      double comp = 0.0;
+      OMGX_PFOR(r, m) {
+        const int ty = w.rtype[r];
+        if (ty == ROW_UPPER || ty == ROW_LOWER) comp = fmax(comp, fabs(w.s[r] * w.z[r] - mu));
+      }
+      comp = c.rmax(comp);
+      if (use_t) comp = fmax(comp, fabs(t * zt - mu));
+      const double rd_t = use_t ? (nu - vz - zt) : 0.0;
+      const double emu = fmax(fmax(rd_max, fabs(rd_t)) / sd, fmax(rE_max, comp / sd));
+      if (mu > o.tol / 10.0 && emu <= OMGX_KAPPA_EPS * mu) {
+        mu = fmax(o.tol / 10.0, fmin(OMGX_KAPPA_MU * mu, pow(mu, OMGX_THETA_MU)));
+        continue;
+      }
+      if (use_t && zt < 0.1 * nu && t > o.tol && nu < OMGX_NU_MAX && emu <= 100.0 * OMGX_KAPPA_EPS * mu) {
+        nu *= 10.0; zt += 0.9 * nu;
+        continue;
+      }
+      break;
+    }
+    // barrier gradient with the current mu
+    OMGX_PFOR(q, n) {
+      double gb = 0.0;
+      for (int k = T.jc_ptr[q]; k < T.jc_ptr[q + 1]; ++k) {
+        const int r = T.jc_row[k]; const double jv = w.jval[T.jc_ent[k]];
+        if (r == m) gb += jv;
+        else if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) gb += jv * (mu / w.s[r]);
+      }
+      w.gbar[q] = gb;
+    }
+    double vms = 0.0;
+    OMGX_PFOR(r, m) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) vms += w.vv[r] * (mu / w.s[r]);
+    vms = c.rsum(vms);
+    const double gbar_t = use_t ? (nu - vms - mu / t) : 0.0;
+    if (c.tid() == 0) w.gbar[N - 1] = gbar_t;
+    c.sync();
+
+    // ---- assemble + factorise with inertia correction --------------------------------
+    double dw = 0.0; int failed = 0;
+    for (;;) {
+      OMGX_PFOR(i, kkt_doubles) w.kkt[i] = 0.0;
+      c.sync();
+      // J' Sigma J  (+ equality rows into the root block)
+      OMGX_PFOR(r, m) {
+        const int ty = w.rtype[r];
+        const int e0 = T.jr_ptr[r], e1 = T.jr_ptr[r + 1];
+        if (ty == ROW_UPPER || ty == ROW_LOWER) {
+          const double sg = w.z[r] / w.s[r];
+          for (int a = e0; a < e1; ++a) {
+            const double ja = sg * w.jval[a]; const int pa = T.jr_pos[a];
+            for (int b = e0; b <= a; ++b) c.add(K.at(pa, T.jr_pos[b]), ja * w.jval[b]);
+            if (use_t && w.vv[r] != 0.0) c.add(K.at(N - 1, pa), -w.vv[r] * ja);
+          }
+          if (use_t && w.vv[r] != 0.0) c.add(K.at(N - 1, N - 1), sg * w.vv[r] * w.vv[r]);
+        } else if (ty == ROW_EQ || (ty == ROW_FREE && T.eq_index[r] >= 0)) {
+          const int k = T.eq_index[r];
+          double* Rr = K.R();
+          if (ty == ROW_EQ) {
+            for (int a = e0; a < e1; ++a) Rr[tri(d.n_root + k, T.jr_pos[a] - d.root_off)] = w.jval[a];
+            if (use_t) Rr[tri(d.n_root + k, d.n_root - 1)] = -w.vv[r];
+          }
+          Rr[tri(d.n_root + k, d.n_root + k)] = -OMGX_DELTA_C;
+        }
+      }
+      // Lagrangian Hessian: terms with >= 2 variables, weight = multiplier * signed scale
+      OMGX_PFOR(r, m) {
+        const int ty = w.rtype[r];
+        if (ty == ROW_FREE) continue;
+        const double lam = w.z[r] * w.rho[r];
+        if (lam == 0.0) continue;
+        for (int tt = T.row_ptr[r]; tt < T.row_ptr[r + 1]; ++tt) {
+          const int32_t* tv = T.t_var + 3 * tt;
+          if (tv[1] < 0) continue;
+          const double cf = lam * term_coef(T, w, tt);
+          const int p0 = T.pos[tv[0]], p1 = T.pos[tv[1]];
+          if (tv[2] < 0) {
+            if (p0 == p1) c.add(K.at(p0, p0), 2.0 * cf);
+            else c.add(p0 > p1 ? K.at(p0, p1) : K.at(p1, p0), cf);
+          } else {
+            const int p2 = T.pos[tv[2]];
+            const double x0v = w.x[tv[0]], x1v = w.x[tv[1]], x2v = w.x[tv[2]];
+            // d2/(dxa dxb) of cf*x0*x1*x2, all ordered pairs, lower triangle only
+            const int pp[3] = {p0, p1, p2}; const double xv[3] = {x0v, x1v, x2v};
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
+              if (a == b) continue;
+              const double val = cf * xv[3 - a - b];
+              if (pp[a] > pp[b]) c.add(K.at(pp[a], pp[b]), val);
+              else if (pp[a] == pp[b] && a < b) c.add(K.at(pp[a], pp[a]), 2.0 * val);
+            }
+          }
+        }
+      }
+      c.sync();
+      OMGX_PFOR(q, N) {
+        double add = dw;
+        if (q == N - 1) add += use_t ? zt / t : 1.0;
+        *K.at(q, q) += add;
+      }
+      c.sync();
+      const int bad = kkt_factor(c, d, K, w);
+      if (!bad) break;
+      dw = (dw == 0.0) ? ((dw_last == 0.0) ? OMGX_DW_FIRST : fmax(1e-10, dw_last * OMGX_DW_DEC))
+                       : dw * OMGX_DW_INC;
+      if (dw > OMGX_DW_MAX) { failed = 1; break; }
+      c.sync();
+    }
+    if (failed) { status = 4; break; }
+    if (dw > 0.0) dw_last = dw;
+
+    // ---- Newton step -------------------------------------------------------------
+    OMGX_PFOR(q, N) w.sol[q] = -w.gbar[q];
+    OMGX_PFOR(k, d.n_eq) { const int r = T.eq_rows[k];
+      w.sol[N + k] = (w.rtype[r] == ROW_EQ) ? -(w.hv[r] - t * w.vv[r]) : 0.0; }
+    c.sync();
+    kkt_solve(c, d, K, w.sol);
+    if (!use_t && c.tid() == 0) w.sol[N - 1] = 0.0;
+    c.sync();
+    const double dt = w.sol[N - 1];
+    double ap_l = 1.0, ad_l = 1.0, ymax = 0.0, gdx = 0.0;
+    const double tau = fmax(OMGX_TAU_MIN, 1.0 - mu);
+    OMGX_PFOR(r, m) {
+      const int ty = w.rtype[r];
+      if (ty == ROW_UPPER || ty == ROW_LOWER) {
+        double jd = 0.0;
+        for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) jd += w.jval[e] * w.sol[T.jr_pos[e]];
+        const double dsr = -(jd - w.vv[r] * dt);
+        w.ds[r] = dsr;
+        const double dzr = mu / w.s[r] - w.z[r] - (w.z[r] / w.s[r]) * dsr;
+        if (dsr < 0.0) ap_l = fmin(ap_l, -tau * w.s[r] / dsr);
+        if (dzr < 0.0) ad_l = fmin(ad_l, -tau * w.z[r] / dzr);
+      } else if (ty == ROW_EQ) {
+        ymax = fmax(ymax, fabs(w.sol[N + T.eq_index[r]]));
+      }
+    }
+    OMGX_PFOR(q, N) gdx += w.gbar[q] * w.sol[q];
+    double a_p = c.rmin(ap_l), a_d = c.rmin(ad_l);
+    ymax = c.rmax(ymax); gdx = c.rsum(gdx);
+    double dzt = 0.0;
+    if (use_t) {
+      dzt = mu / t - zt - (zt / t) * dt;
+      if (dt < 0.0) a_p = fmin(a_p, -tau * t / dt);
+      if (dzt < 0.0) a_d = fmin(a_d, -tau * zt / dzt);
+    }
+    const double nuE = 2.0 * fmax(1.0, ymax);
+    double lns = 0.0;
+    OMGX_PFOR(r, m) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) lns += log(w.s[r]);
+    lns = c.rsum(lns);
+    const double phi0 = f + nu * t - mu * lns - (use_t ? mu * log(t) : 0.0) + nuE * rE_sum;
+    const double dphi = gdx - nuE * rE_sum;
+
+    // ---- Armijo backtracking on the barrier function, iterate stays strictly feasible ----
+    double alpha = a_p, ft = f, tt = t; int ok = 0;
+    for (int bt = 0; bt < OMGX_MAX_BACKTRACK; ++bt) {
+      OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + alpha * w.sol[q]; }
+      c.sync();
+      tt = use_t ? w.xt[n] : 0.0;
+      double smin = 1e300, lnst = 0.0, rEt = 0.0;
+      OMGX_PFOR(r, m) {
+        const int ty = w.rtype[r];
+        if (ty == ROW_FREE) { w.ht[r] = 0.0; continue; }
+        const double h = w.rho[r] * (row_value(T, w, r, w.xt) - w.bnd[r]);
+        w.ht[r] = h;
+        if (ty == ROW_EQ) rEt += fabs(h - tt * w.vv[r]);
+        else { const double st = tt * w.vv[r] - h; smin = fmin(smin, st); if (st > 0.0) lnst += log(st); }
+      }
+      smin = c.rmin(smin); lnst = c.rsum(lnst); rEt = c.rsum(rEt);
+      ft = row_value(T, w, m, w.xt);
+      if (smin > 0.0) {
+        const double phit = ft + nu * tt - mu * lnst - (use_t ? mu * log(tt) : 0.0) + nuE * rEt;
+        if (phit <= phi0 + OMGX_ETA * alpha * dphi || phit - phi0 <= 10.0 * 2.220446049250313e-16 * fabs(phi0)) { ok = 1; break; }
+      }
+      alpha *= 0.5;
+      c.sync();
+    }
+    if (!ok) { status = 4; break; }
+    // ---- accept --------------------------------------------------------------------
+    c.sync();
+    OMGX_PFOR(q, N) w.x[q] = w.xt[q];
+    t = tt; f = ft;
+    OMGX_PFOR(r, m) {
+      const int ty = w.rtype[r];
+      w.hv[r] = w.ht[r];
+      if (ty == ROW_UPPER || ty == ROW_LOWER) {
+        const double s_old = w.s[r];
+        const double dzr = mu / s_old - w.z[r] - (w.z[r] / s_old) * w.ds[r];
+        const double sn = t * w.vv[r] - w.ht[r];
+        double zn = w.z[r] + a_d * dzr;
+        zn = fmin(fmax(zn, mu / (OMGX_KAPPA_SIGMA * sn)), OMGX_KAPPA_SIGMA * mu / sn);
+        w.s[r] = sn; w.z[r] = zn;
+      } else if (ty == ROW_EQ) {
+        const double yn = w.sol[N + T.eq_index[r]];
+        w.z[r] = w.z[r] + alpha * (yn - w.z[r]);
+      }
+    }
+    if (use_t) {
+      zt = zt + a_d * dzt;
+      zt = fmin(fmax(zt, mu / (OMGX_KAPPA_SIGMA * t)), OMGX_KAPPA_SIGMA * mu / t);
+    }
+    c.sync();
+  }
+  res.status = status; res.iters = it > o.max_iter ? o.max_iter : it; res.f = f; res.mu = mu; res.t = t;
+  return res;
+}
+
+}  // namespace omgx

@@ -1,2 +1,299 @@
+"""ctypes binding of libomgx.so (include/omgx.h) and the solver objects built on it.
+
+`create_nlp` is the stand-in for the reference's solver factory
+(`basics/optilayer.py:49-104`): it returns an object with the call shape the
+reference's `Problem.solve` uses (`problems/problem.py:113-119`):
+
+    result = solver(x0=, p=, lbg=, ubg=)   ->  {'x': ..., 'lam_g': ...}
+    solver.stats()['return_status']        ->  'Solve_Succeeded' | ...
+
+There is NO CPU fallback: if libomgx.so (hand-written HIP, csrc/) cannot be
+loaded or no HIP device is present, construction raises.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from .template import SolverPlan
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libomgx.so')
+
+PTR_DEVICE, BOUNDS_SHARED, BOUNDS_DEVICE = 1, 2, 4
+
+STATUS_STRINGS = {0: 'Solve_Succeeded', 1: 'Maximum_Iterations_Exceeded',
+                  2: 'Infeasible_Problem_Detected', 3: 'Unsupported_Bounds',
+                  4: 'Numerical_Failure'}
+
+_I32P, _F64P = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+
+
+class CTemplate(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ('n_var', 'n_par', 'n_con', 'n_atoms', 'n_slots', 'n_terms',
+                 'n_prog', 'n_knots', 'n_pp', 'n_mono', 'n_matom')] + \
+               [('prog', _I32P), ('knots', _F64P), ('pp_ptr', _I32P), ('pm_coef', _F64P),
+                ('pm_ptr', _I32P), ('pm_atom', _I32P), ('slot_pp', _I32P),
+                ('row_ptr', _I32P), ('t_coef', _F64P), ('t_slot', _I32P), ('t_var', _I32P)] + \
+               [(n, C.c_int32) for n in ('n_leaf', 'n_root', 'n_eq', 'nnz_j')] + \
+               [(n, _I32P) for n in ('order', 'leaf_off', 'eq_rows', 'jr_ptr', 'jr_pos',
+                                     't_jidx', 'row_leaf', 'jc_ptr', 'jc_row', 'jc_ent',
+                                     'cpl_ptr', 'cpl_idx', 'cpl_map')]
+
+
+class COptions(C.Structure):
+    _fields_ = [('tol', C.c_double), ('max_iter', C.c_int32), ('mu_init', C.c_double),
+                ('kappa_push', C.c_double), ('nu_init', C.c_double), ('scale_gmax', C.c_double)]
+
+
+DEFAULT_OPTIONS = dict(tol=1e-3, max_iter=300, mu_init=0.1, kappa_push=1.0,
+                       nu_init=100.0, scale_gmax=100.0)
+
+
+def make_options(**kw):
+    vals = dict(DEFAULT_OPTIONS)
+    vals.update(kw)
+    return COptions(**vals)
+
+
+def options_from_problem(options):
+    """Map the reference's option names onto the HIP solver's settings
+    (`problems/problem.py:54-62`: ipopt.tol, ipopt.max_iter)."""
+    ipopt = options.get('solver_options', {}).get(options.get('solver', 'ipopt'), {})
+    kw = {}
+    if 'ipopt.tol' in ipopt:
+        kw['tol'] = float(ipopt['ipopt.tol'])
+    if 'ipopt.max_iter' in ipopt:
+        kw['max_iter'] = int(ipopt['ipopt.max_iter'])
+    kw.update(options.get('omgx', {}))
+    return kw
+
+
+def make_ctemplate(tpl, plan=None):
+    """(CTemplate, keepalive list).  `plan` defaults to SolverPlan(tpl)."""
+    plan = SolverPlan(tpl) if plan is None else plan
+    keep = []
+
+    def i32(a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        keep.append(a)
+        return a.ctypes.data_as(_I32P)
+
+    def f64(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        keep.append(a)
+        return a.ctypes.data_as(_F64P)
+
+    ct = CTemplate()
+    ct.n_var, ct.n_par, ct.n_con = tpl.n_var, tpl.n_par, tpl.n_con
+    ct.n_atoms, ct.n_slots, ct.n_terms = tpl.n_atoms, tpl.n_slots, tpl.n_terms
+    ct.n_prog, ct.n_knots = len(tpl.prog), len(tpl.knots)
+    ct.n_pp, ct.n_mono, ct.n_matom = len(tpl.pp_ptr) - 1, len(tpl.pm_coef), len(tpl.pm_atom)
+    ct.prog, ct.knots = i32(tpl.prog.reshape(-1)), f64(np.r_[tpl.knots, 0.0])
+    ct.pp_ptr, ct.pm_coef = i32(tpl.pp_ptr), f64(np.r_[tpl.pm_coef, 0.0])
+    ct.pm_ptr, ct.pm_atom = i32(tpl.pm_ptr), i32(np.r_[tpl.pm_atom, 0])
+    ct.slot_pp = i32(np.r_[tpl.slot_pp, 0])
+    ct.row_ptr, ct.t_coef = i32(tpl.row_ptr), f64(tpl.t_coef)
+    ct.t_slot, ct.t_var = i32(tpl.t_slot), i32(tpl.t_var.reshape(-1))
+    ct.n_leaf, ct.n_root, ct.n_eq, ct.nnz_j = plan.n_leaf, plan.n_root, plan.n_eq, plan.nnz_j
+    ct.order, ct.leaf_off = i32(plan.order), i32(plan.leaf_off)
+    ct.eq_rows = i32(np.r_[plan.eq_rows, 0])
+    ct.jr_ptr, ct.jr_pos = i32(plan.jr_ptr), i32(plan.jr_pos)
+    ct.t_jidx, ct.row_leaf = i32(plan.t_jidx.reshape(-1)), i32(plan.row_leaf)
+    ct.jc_ptr, ct.jc_row, ct.jc_ent = i32(plan.jc_ptr), i32(plan.jc_row), i32(plan.jc_ent)
+    ct.cpl_ptr, ct.cpl_idx = i32(plan.cpl_ptr), i32(np.r_[plan.cpl_idx, 0])
+    ct.cpl_map = i32(plan.cpl_map.reshape(-1))
+    return ct, keep
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load the HIP library; raises OSError with a build hint when missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise OSError('%s not found: build it with `python __graft_entry__.py` or '
+                      '`make -C omg-tools_amd/csrc` (hipcc, gfx950). There is no CPU '
+                      'fallback for the solve path.' % path)
+    lib = C.CDLL(path)
+    lib.omgx_version.restype = C.c_int
+    lib.omgx_last_error.restype = C.c_char_p
+    lib.omgx_status_string.restype = C.c_char_p
+    lib.omgx_status_string.argtypes = [C.c_int32]
+    lib.omgx_default_options.argtypes = [C.POINTER(COptions)]
+    lib.omgx_batch_create.argtypes = [C.POINTER(CTemplate), C.c_int32, C.c_int32,
+                                      C.POINTER(C.c_void_p)]
+    lib.omgx_batch_destroy.argtypes = [C.c_void_p]
+    lib.omgx_batch_destroy.restype = None
+    lib.omgx_batch_set_options.argtypes = [C.c_void_p, C.POINTER(COptions)]
+    lib.omgx_batch_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.omgx_batch_lds_bytes.argtypes = [C.c_void_p]
+    lib.omgx_batch_solve.argtypes = [C.c_void_p] + [C.c_void_p] * 8 + [C.c_int32]
+    lib.omgx_batch_sync.argtypes = [C.c_void_p]
+    lib.omgx_batch_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.omgx_batch_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
+    lib.omgx_batch_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_double,
+                                      C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+class OmgxError(RuntimeError):
+    pass
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise OmgxError('%s failed (%d): %s' % (what, rc, lib.omgx_last_error().decode()))
+
+
+class BatchSolver(object):
+    """Owns one `omgx_batch` handle: B agents sharing one NLP template.
+
+    Host-array interface (`solve`) for the drop-in path and the tests;
+    device-pointer interface (`solve_device`) for resident data (bench.py, the
+    batched deployer) where nothing crosses PCIe inside the timed region.
+    """
+
+    def __init__(self, template, n_agents, device=0, options=None, plan=None):
+        self.lib = load_library()
+        self.template = template
+        self.plan = SolverPlan(template) if plan is None else plan
+        self.n_agents = int(n_agents)
+        self._ct, self._keep = make_ctemplate(template, self.plan)
+        self._h = C.c_void_p()
+        _check(self.lib, self.lib.omgx_batch_create(C.byref(self._ct), self.n_agents,
+                                                    int(device), C.byref(self._h)),
+               'omgx_batch_create')
+        self.set_options(**(options or {}))
+
+    def set_options(self, **kw):
+        self.options = dict(DEFAULT_OPTIONS)
+        self.options.update(getattr(self, 'options', {}))
+        self.options.update(kw)
+        opt = COptions(**self.options)
+        _check(self.lib, self.lib.omgx_batch_set_options(self._h, C.byref(opt)),
+               'omgx_batch_set_options')
+
+    def set_stream(self, stream_ptr):
+        _check(self.lib, self.lib.omgx_batch_set_stream(self._h, C.c_void_p(stream_ptr)),
+               'omgx_batch_set_stream')
+
+    @property
+    def lds_bytes(self):
+        return self.lib.omgx_batch_lds_bytes(self._h)
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.omgx_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host arrays ----------------------------------------------------------------
+    def solve(self, p, x0, lbg=None, ubg=None):
+        t = self.template
+        B = self.n_agents
+        p = np.ascontiguousarray(np.asarray(p, float).reshape(B, t.n_par))
+        x0 = np.ascontiguousarray(np.asarray(x0, float).reshape(B, t.n_var))
+        lbg = t.lb if lbg is None else lbg
+        ubg = t.ub if ubg is None else ubg
+        lbg = np.ascontiguousarray(np.asarray(lbg, float))
+        ubg = np.ascontiguousarray(np.asarray(ubg, float))
+        shared = lbg.size == t.n_con
+        flags = BOUNDS_SHARED if shared else 0
+        if lbg.size != (t.n_con if shared else B * t.n_con) or ubg.size != lbg.size:
+            raise ValueError('lbg/ubg have the wrong size')
+        x = np.empty((B, t.n_var))
+        lam = np.empty((B, t.n_con))
+        status = np.empty(B, dtype=np.int32)
+        iters = np.empty(B, dtype=np.int32)
+        _check(self.lib, self.lib.omgx_batch_solve(
+            self._h, p.ctypes.data, x0.ctypes.data, lbg.ctypes.data, ubg.ctypes.data,
+            x.ctypes.data, lam.ctypes.data, status.ctypes.data, iters.ctypes.data, flags),
+            'omgx_batch_solve')
+        return dict(x=x, lam_g=lam, status=status, iters=iters)
+
+    # -- device pointers (torch tensors / raw ints) -------------------------------------
+    def solve_device(self, p, x0, lbg, ubg, x, lam_g, status, iters, bounds_shared=True):
+        def ptr(a):
+            return a.data_ptr() if hasattr(a, 'data_ptr') else int(a)
+        flags = PTR_DEVICE | BOUNDS_DEVICE | (BOUNDS_SHARED if bounds_shared else 0)
+        _check(self.lib, self.lib.omgx_batch_solve(
+            self._h, ptr(p), ptr(x0), ptr(lbg), ptr(ubg), ptr(x), ptr(lam_g), ptr(status),
+            ptr(iters), flags), 'omgx_batch_solve')
+
+    def sync(self):
+        _check(self.lib, self.lib.omgx_batch_sync(self._h), 'omgx_batch_sync')
+
+    def last_kernel_ms(self):
+        ms = C.c_double()
+        _check(self.lib, self.lib.omgx_batch_last_kernel_ms(self._h, C.byref(ms)),
+               'omgx_batch_last_kernel_ms')
+        return ms.value
+
+    def sample(self, x, coeff_off, n_spl, degree, knots, n_der, t0, dt, n_samp,
+               out=None, as_f32=False, device=False):
+        knots = np.ascontiguousarray(knots, dtype=np.float64)
+
+        def ptr(a):
+            return a.data_ptr() if hasattr(a, 'data_ptr') else a.ctypes.data
+        if out is None:
+            out = np.empty((self.n_agents, n_der, n_spl, n_samp),
+                           dtype=np.float32 if as_f32 else np.float64)
+        _check(self.lib, self.lib.omgx_batch_sample(
+            self._h, ptr(x), coeff_off, n_spl, degree, knots.ctypes.data, len(knots), n_der,
+            ptr(t0), float(dt), n_samp, ptr(out), int(as_f32), PTR_DEVICE if device else 0),
+            'omgx_batch_sample')
+        return out
+
+    def shift(self, x, mask, entries, tmats, device=False):
+        def ptr(a):
+            return a.data_ptr() if hasattr(a, 'data_ptr') else a.ctypes.data
+        entries = np.ascontiguousarray(entries, dtype=np.int32)
+        tmats = np.ascontiguousarray(tmats, dtype=np.float64)
+        _check(self.lib, self.lib.omgx_batch_shift(
+            self._h, ptr(x), ptr(mask), entries.ctypes.data, len(entries), tmats.ctypes.data,
+            tmats.size, PTR_DEVICE if device else 0), 'omgx_batch_shift')
+
+
+class NlpSolver(object):
+    """Single-agent solver object with the reference's `nlpsol` call shape."""
+
+    def __init__(self, template, options):
+        self.template = template
+        self.batch = BatchSolver(template, 1, options=options_from_problem(options))
+        self._stats = {'return_status': 'Not_Solved', 'iter_count': 0}
+
+    def __call__(self, x0=None, p=None, lbg=None, ubg=None, **kwargs):
+        res = self.batch.solve(np.asarray(p), np.asarray(x0), np.asarray(lbg), np.asarray(ubg))
+        self._stats = {'return_status': STATUS_STRINGS[int(res['status'][0])],
+                       'iter_count': int(res['iters'][0])}
+        return {'x': res['x'][0], 'lam_g': res['lam_g'][0]}
+
+    def stats(self):
+        return dict(self._stats)
+
+
 def create_nlp(template, options, name=''):
-    raise NotImplementedError
+    if options.get('verbose', 0) >= 1:
+        print('Building nlp ... ', end=' ')
+    t0 = time.time()
+    solver = NlpSolver(template, options)
+    dt = time.time() - t0
+    if options.get('verbose', 0) >= 1:
+        print('in %5f s' % dt)
+    return solver, dt

@@ -332,12 +332,19 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             break
         if it == o['max_iter']:
             break
-        while mu > o['tol'] / 10. and kkt_error(mu) <= o['kappa_eps'] * mu:
-            mu = max(o['tol'] / 10., min(o['kappa_mu'] * mu, mu ** o['theta_mu']))
-        if use_t and zt < 0.1 * nu and t > o['tol'] and nu < o['nu_max'] and kkt_error(mu) <= 100 * o['kappa_eps'] * mu:
-            nu *= 10.0
-            zt += 0.9 * nu
-            continue
+        while True:
+            r_d[n] = (nu - v @ z - cE0 @ y - zt) if use_t else 0.0
+            emu = kkt_error(mu)
+            if mu > o['tol'] / 10. and emu <= o['kappa_eps'] * mu:
+                mu = max(o['tol'] / 10., min(o['kappa_mu'] * mu, mu ** o['theta_mu']))
+                continue
+            if use_t and zt < 0.1 * nu and t > o['tol'] and nu < o['nu_max'] and \
+                    emu <= 100 * o['kappa_eps'] * mu:
+                nu *= 10.0
+                zt += 0.9 * nu
+                continue
+            break
+        gf[n] = nu
         lam = np.zeros(nlp.n_con)
         lam[iH] = sig * z
         lam[iE] = y
@@ -376,7 +383,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             g_bar[n] -= mu / t
         rhs = np.r_[-g_bar, -rE]
         sol = ldl_solve(L, d, rhs)
-        for _ in range(o.get('n_refine', 2)):
+        for _ in range(o.get('n_refine', 0)):
             res_ = rhs - K @ sol
             res_[N:] -= o['delta_c'] * sol[N:]
             sol += ldl_solve(L, d, res_)

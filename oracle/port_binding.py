@@ -1,0 +1,50 @@
+"""ORACLE (test infrastructure): ctypes access to oracle/_build/libomgx_port.so,
+the single-thread host build of the solver core (oracle/port/omgx_port.cpp).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+PORT_PATH = os.path.join(_DIR, '_build', 'libomgx_port.so')
+
+
+def build():
+    subprocess.check_call(['make', '-C', _DIR, '-s'])
+
+
+def load():
+    if not os.path.exists(PORT_PATH):
+        build()
+    lib = C.CDLL(PORT_PATH)
+    lib.omgx_port_solve.restype = C.c_int
+    return lib
+
+
+def solve(template, p, x0, lbg=None, ubg=None, plan=None, **options):
+    """Solve B agents on one host thread; returns dict like BatchSolver.solve."""
+    from omgtools.backend import make_ctemplate, make_options
+    lib = load()
+    ct, keep = make_ctemplate(template, plan)
+    opt = make_options(**options)
+    p = np.ascontiguousarray(np.atleast_2d(np.asarray(p, float)))
+    x0 = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, float)))
+    B = p.shape[0]
+    lbg = np.ascontiguousarray(template.lb if lbg is None else lbg, dtype=float)
+    ubg = np.ascontiguousarray(template.ub if ubg is None else ubg, dtype=float)
+    shared = int(lbg.size == template.n_con)
+    x = np.empty((B, template.n_var))
+    lam = np.empty((B, template.n_con))
+    status = np.empty(B, dtype=np.int32)
+    iters = np.empty(B, dtype=np.int32)
+    rc = lib.omgx_port_solve(C.byref(ct), C.byref(opt), C.c_int32(B),
+                             C.c_void_p(p.ctypes.data), C.c_void_p(x0.ctypes.data),
+                             C.c_void_p(lbg.ctypes.data), C.c_void_p(ubg.ctypes.data),
+                             C.c_int32(shared), C.c_void_p(x.ctypes.data),
+                             C.c_void_p(lam.ctypes.data), C.c_void_p(status.ctypes.data),
+                             C.c_void_p(iters.ctypes.data))
+    if rc != 0:
+        raise RuntimeError('omgx_port_solve failed: %d' % rc)
+    return dict(x=x, lam_g=lam, status=status, iters=iters)

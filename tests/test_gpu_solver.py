@@ -1,0 +1,46 @@
+"""Parity of the HIP solve path (through the C ABI) against the oracle:
+numpy interior point (independent statement) and the single-thread host port."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# fp64 tolerances (stated): the three implementations run the same iteration in
+# different summation orders, so iterates agree to rounding amplified by the
+# conditioning of the KKT systems.
+TOL_X = 1e-6
+
+
+def test_library_loads_and_reports_lds(cfg2_small):
+    from omgtools.backend import BatchSolver
+    problem, P = cfg2_small
+    solver = BatchSolver(problem.father.template, 8)
+    assert 0 < solver.lds_bytes <= 160 * 1024
+    solver.close()
+
+
+def test_cfg2_matches_port_and_numpy(cfg2_small):
+    from omgtools.backend import BatchSolver
+    from oracle import port_binding, ipm_numpy
+    from oracle.nlp_numpy import NumpyNLP
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    solver = BatchSolver(tpl, 8, options=dict(tol=1e-6, max_iter=200))
+    res = solver.solve(P['p'], P['x0'])
+    ref = port_binding.solve(tpl, P['p'], P['x0'], tol=1e-6, max_iter=200)
+    assert np.array_equal(res['status'], ref['status'])
+    good = res['status'] == 0
+    assert good.sum() >= 5
+    assert np.abs(res['iters'][good] - ref['iters'][good]).max() <= 2
+    assert np.abs(res['x'][good] - ref['x'][good]).max() < TOL_X
+    nlp = NumpyNLP(tpl)
+    b = int(np.nonzero(good)[0][0])
+    r_np = ipm_numpy.solve(nlp, P['x0'][b], P['p'][b], tpl.lb, tpl.ub,
+                           opts={'tol': 1e-6, 'max_iter': 200})
+    assert r_np['status'] == 0
+    assert np.abs(r_np['x'] - res['x'][b]).max() < TOL_X
+    # the solution satisfies the constraints of the reference NLP
+    c = nlp.term_coefs(P['p'][b])
+    _, g = nlp.fg(res['x'][b], c)
+    assert (g - tpl.ub).max() < 1e-6 and (tpl.lb - g).max() < 1e-6
+    solver.close()
