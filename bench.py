@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""bench.py -- MPC solves/sec of the batched spline-MPC solve path on MI355X.
+
+Workload (BASELINE.json configs[1]): 1024-agent Holonomic Point2point batch per
+GPU, degree-3 B-spline, knot_intervals=11, 3 circular obstacles, fp64; seeded
+synthetic scenarios (omgtools/scenarios.py).  One "step" = one
+batched cold solve of every agent from the reference's initial guess
+(`omgx_batch_solve` on inputs already resident in HBM), solver tolerance = the
+reference's default `ipopt.tol = 1e-3` (`problems/problem.py:57`).
+
+Launch: python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X datasheet FP64 matrix (MFMA f64) peak
+
+
+def cpu_baseline(tpl, P, opts, n_sample):
+    """Oracle CPU port (single host thread) on a bounded sample of the same workload."""
+    from oracle import port_binding
+    port_binding.load()
+    t0 = time.perf_counter()
+    res = port_binding.solve(tpl, P['p'][:n_sample], P['x0'][:n_sample], **opts)
+    dt = time.perf_counter() - t0
+    ok = int((res['status'] == 0).sum())
+    return {'value': ok / dt, 'unit': 'solves/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d agents of the same batch, cold solve, 1 thread (%.1f s; host has %d cores)'
+                      % (n_sample, dt, os.cpu_count()),
+            'mean_iters': float(res['iters'].mean())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--agents', type=int, default=1024, help='agents per GPU')
+    ap.add_argument('--tol', type=float, default=1e-3)
+    ap.add_argument('--cpu-sample', type=int, default=512)
+    ap.add_argument('--no-cpu', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    from omgtools.scenarios import holonomic_p2p
+    from omgtools.backend import BatchSolver
+    import omgtools.backend as be
+    B = args.agents
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)      # the batch solver below is the product path
+    problem, P = holonomic_p2p(B, seed=20240807 + 2 + 1000 * rank)
+    be.create_nlp = saved
+    tpl = problem.father.template
+    opts = dict(tol=args.tol, max_iter=300)
+    solver = BatchSolver(tpl, B, device=local_rank, options=opts)
+    solver.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    d = lambda a, dt=torch.float64: torch.as_tensor(a, dtype=dt, device=dev).contiguous()
+    p, x0, lb, ub = d(P['p']), d(P['x0']), d(tpl.lb), d(tpl.ub)
+    x = torch.empty((B, tpl.n_var), dtype=torch.float64, device=dev)
+    lam = torch.empty((B, tpl.n_con), dtype=torch.float64, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    iters = torch.empty(B, dtype=torch.int32, device=dev)
+
+    def step():
+        solver.solve_device(p, x0, lb, ub, x, lam, status, iters, bounds_shared=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if rank == 0 and world == 1:
+            pass
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # device time of the solve kernel (HIP events on the launch stream), re-measured
+    # over the same launches outside the wall-clock region
+    for _ in range(min(args.steps, 10)):
+        step()
+        kernel_ms.append(solver.last_kernel_ms())
+    torch.cuda.synchronize()
+    n_ok = int((status == 0).sum().item())
+    it_sum = int(iters.sum().item())
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        cc = torch.tensor([n_ok], dtype=torch.float64, device=dev)
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        n_ok_all = int(cc.item())
+    else:
+        n_ok_all = n_ok
+    if rank != 0:
+        return
+    value = n_ok_all * args.steps / elapsed
+    k_ms = float(np.mean(kernel_ms))
+    n = tpl.n_var
+    flops_per_iter = n ** 3 / 3.0 + 2.0 * n ** 2          # dense-n LDL' + 2 solves
+    achieved = it_sum * flops_per_iter / (k_ms * 1e-3) / 1e12
+    out = {
+        'metric': 'MPC solves/sec, 1024-agent Holonomic Point2point batch per GPU',
+        'value': value, 'unit': 'solves/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: %d-agent Holonomic Point2point per GPU, degree 3, '
+                               'knot_intervals=11, 3 circular obstacles, cold solve, tol=%g'
+                               % (B, args.tol),
+                   'agents_per_gpu': B, 'n_var': tpl.n_var, 'n_con': tpl.n_con,
+                   'parallelism': 'agents sharded across ranks, no collective on the solve path'},
+        'p50_batch_latency_ms': float(np.median(kernel_ms)),
+        'solved_fraction': n_ok / float(B), 'mean_iters': it_sum / float(B),
+        'lds_bytes_per_agent': solver.lds_bytes,
+        'roofline': {'bound': 'mfma', 'kernel': 'ipm_solve_kernel', 'achieved': achieved,
+                     'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
+                     'kernel_ms': k_ms,
+                     'note': 'algorithmic flops = sum(iters) x (n^3/3+2n^2), n=n_var (SURVEY 8d)'},
+    }
+    if not args.no_cpu and world == 1:
+        out['cpu_baseline'] = cpu_baseline(tpl, P, opts, min(args.cpu_sample, B))
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
