@@ -75,6 +75,7 @@ struct Opts {
 #define OMGX_KAPPA_SIGMA 1e10
 #define OMGX_MAX_BACKTRACK 25
 #define OMGX_NU_MAX      1e8
+#define OMGX_STALL_ITERS 10
 
 // Per-agent work arrays (LDS on the device, heap on the host port).
 struct Work {
@@ -451,7 +452,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   }
   c.sync();
   double f = row_value(T, w, m, w.x);
-  double dw_last = 0.0;
+  double dw_last = 0.0, t_check = t;
   int it = 0, status = 1;
 
   for (it = 0; it <= o.max_iter; ++it) {
@@ -502,6 +503,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     if (err0 <= o.tol) { status = 0; break; }
     if (it == o.max_iter) break;
     // barrier-problem error at a given mu
+    int infeasible = 0;
     for (;;) {
       double comp = 0.0;
       OMGX_PFOR(r, m) {
@@ -516,12 +518,19 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         mu = fmax(o.tol / 10.0, fmin(OMGX_KAPPA_MU * mu, pow(mu, OMGX_THETA_MU)));
         continue;
       }
-      if (use_t && zt < 0.1 * nu && t > o.tol && nu < OMGX_NU_MAX && emu <= 100.0 * OMGX_KAPPA_EPS * mu) {
+      if (use_t && zt < 0.1 * nu && t > o.tol && emu <= 100.0 * OMGX_KAPPA_EPS * mu) {
+        if (nu >= OMGX_NU_MAX) { infeasible = 1; break; }   // phase I stalls at t > 0: local infeasibility
         nu *= 10.0; zt += 0.9 * nu;
         continue;
       }
       break;
     }
+    // stall test: phase I must at least halve t every OMGX_STALL_ITERS iterations
+    if (use_t && it > 0 && it % OMGX_STALL_ITERS == 0) {
+      if (t > o.tol && t > 0.5 * t_check) infeasible = 1;
+      t_check = t;
+    }
+    if (infeasible) { status = 2; break; }
     // barrier gradient with the current mu
     OMGX_PFOR(q, n) {
       double gb = 0.0;

@@ -123,6 +123,8 @@ class Poly(object):
     def __add__(self, other):
         if isinstance(other, np.ndarray):
             return self._broadcast(other, lambda o: self + o)
+        if not isinstance(other, _SCALARS):
+            return NotImplemented
         other = Poly.lift(other)
         out = dict(self.terms)
         for k, c in other.terms.items():
@@ -141,11 +143,15 @@ class Poly(object):
     def __sub__(self, other):
         if isinstance(other, np.ndarray):
             return self._broadcast(other, lambda o: self - o)
+        if not isinstance(other, _SCALARS):
+            return NotImplemented
         return self + (-Poly.lift(other))
 
     def __rsub__(self, other):
         if isinstance(other, np.ndarray):
             return self._broadcast(other, lambda o: o - self)
+        if not isinstance(other, _SCALARS):
+            return NotImplemented
         return Poly.lift(other) + (-self)
 
     def __mul__(self, other):
@@ -198,6 +204,9 @@ class Poly(object):
             parts.append('%g' % c + ''.join('*x%d' % s for s in v) +
                          ''.join('*p%d' % (s - _ATOM_BASE) for s in a))
         return 'Poly(' + ' + '.join(parts) + ')'
+
+
+_SCALARS = (Poly, int, float, np.floating, np.integer)
 
 
 def as_poly_array(values):

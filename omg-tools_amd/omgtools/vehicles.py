@@ -76,10 +76,10 @@ class Vehicle(OptiChild, PlotLayer):
         if self.init_spline_values is not None:
             init, self.init_spline_values = self.init_spline_values, None
         else:
-            try:
-                init = self.get_init_spline_value()
-            except (AttributeError, KeyError):
-                init = [None] * n_seg
+            # as in the reference (`vehicle.py:112-115`) the construction-time value
+            # is zero unless set_init_spline_values() was called; the initial guess
+            # proper is installed by Problem.reinitialize()
+            init = [None] * n_seg
         for k in range(n_seg):
             self.splines.append(self.define_spline_variable(
                 'splines_seg' + str(k), self.n_spl, value=init[k]))

@@ -25,7 +25,7 @@ DEFAULTS = dict(tol=1e-8, max_iter=200, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.
                 theta_mu=1.5, tau_min=0.99, s_push=1.0, delta_c=1e-8, eta=1e-4,
                 rho=0.1, dw_first=1e-4, dw_inc=10.0, dw_dec=1. / 3., dw_max=1e10,
                 s_max=100.0, kappa_sigma=1e10, max_backtrack=25, max_soc=2,
-                slack_reset=True, kappa_push=1.0, nu_init=100.0, nu_max=1e8, e_push=1.0, scale_gmax=100.0, s_phi=2.3, s_theta=1.1, delta_sw=1.0,
+                slack_reset=True, kappa_push=1.0, stall_iters=10, nu_init=100.0, nu_max=1e8, e_push=1.0, scale_gmax=100.0, s_phi=2.3, s_theta=1.1, delta_sw=1.0,
                 gamma_theta=1e-5, gamma_phi=1e-5, filter_size=8)
 
 STATUS = {0: 'Solve_Succeeded', 1: 'Maximum_Iterations_Exceeded',
@@ -300,6 +300,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
     dw_last = 0.0
     status, it, nfact = 1, 0, 0
     N = n + 1                      # (x, t)
+    t_check = t
 
     def ftb(vv, dv, tau_):
         neg = dv < 0
@@ -338,11 +339,19 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             if mu > o['tol'] / 10. and emu <= o['kappa_eps'] * mu:
                 mu = max(o['tol'] / 10., min(o['kappa_mu'] * mu, mu ** o['theta_mu']))
                 continue
-            if use_t and zt < 0.1 * nu and t > o['tol'] and nu < o['nu_max'] and \
-                    emu <= 100 * o['kappa_eps'] * mu:
+            if use_t and zt < 0.1 * nu and t > o['tol'] and emu <= 100 * o['kappa_eps'] * mu:
+                if nu >= o['nu_max']:
+                    status = 2          # phase I stalls at t > 0: local infeasibility
+                    break
                 nu *= 10.0
                 zt += 0.9 * nu
                 continue
+            break
+        if use_t and it > 0 and it % o['stall_iters'] == 0:
+            if t > o['tol'] and t > 0.5 * t_check:
+                status = 2              # phase I stalls: local infeasibility
+            t_check = t
+        if status == 2:
             break
         gf[n] = nu
         lam = np.zeros(nlp.n_con)

@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""Generate golden vectors by executing the REFERENCE's own problem-construction
+code (read-only, from /root/reference) under the numeric casadi stand-in in
+tests/golden/fake_casadi.  Run in the build container only:
+
+    python tests/golden/generate_golden.py
+
+Writes tests/golden/nlp_*.npz (layout, bounds, init values, and f/g evaluated at
+seeded random points) and tests/golden/spline_kats.npz (basis/derivative/product/
+shift matrices from the reference's `basics/spline.py`, `spline_extra.py`).
+The committed .npz files are what tests/test_golden_*.py compare against; the GPU
+box never needs /root/reference.
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference/omgtools'
+sys.path.insert(0, os.path.join(HERE, 'fake_casadi'))
+
+
+def _pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path] if path else []
+    sys.modules[name] = m
+    return m
+
+
+def install_reference():
+    _pkg('omgtools', REF)
+    for sub in ('basics', 'vehicles', 'environment', 'problems'):
+        _pkg('omgtools.' + sub, os.path.join(REF, sub))
+    _pkg('omgtools.execution', None)
+    _pkg('omgtools.export', None)
+    pl = types.ModuleType('omgtools.execution.plotlayer')
+
+    class PlotLayer(object):
+        simulator = None
+        def __init__(self, *a, **k): pass
+        def update_plots(self): pass
+        def plot(self, *a, **k): pass
+    pl.PlotLayer = PlotLayer
+    pl.mix_with_white = lambda color, perc_white=80.: color
+    sys.modules['omgtools.execution.plotlayer'] = pl
+    ex = types.ModuleType('omgtools.export.export_p2p')
+    ex.ExportP2P = object
+    sys.modules['omgtools.export.export_p2p'] = ex
+    mods = {}
+    for name in ('basics.spline', 'basics.spline_extra', 'basics.shape', 'basics.optilayer',
+                 'vehicles.holonomic', 'vehicles.holonomic3d', 'vehicles.quadrotor',
+                 'environment.environment', 'environment.obstacle', 'problems.point2point'):
+        mods[name] = importlib.import_module('omgtools.' + name)
+    return mods
+
+
+def layout_of(st):
+    out = []
+    for e in st.entries:
+        if e.struct is not None:
+            for e2 in e.struct.entries:
+                off, shape = st.flat((e.name, e2.name))
+                out.append((e.name + '/' + e2.name, off, shape[0], shape[1]))
+        else:
+            off, shape = st.flat(e.name)
+            out.append((e.name, off, shape[0], shape[1]))
+    return out
+
+
+def dump(problem, tag, rng, n_pts=4):
+    father = problem.father
+    nlp = problem.problem.nlp
+    X, Pm = nlp['x'].cat, nlp['p'].cat
+    x_init = father._var_result.cat.copy()
+    problem.reinitialize()
+    x_reinit = father._var_result.cat.copy()
+    p0 = father.set_parameters(0.).cat.copy()
+    lb, ub = father._lb.cat.copy(), father._ub.cat.copy()
+    n_var, n_par = x_init.size, p0.size
+    t_idx = [off for (name, off, r, c) in layout_of(father._par_struct) if name.endswith('/t')][0]
+    knot_time = problem.knot_time
+    xs, ps, fs, gs = [], [], [], []
+    for k in range(n_pts):
+        x = x_reinit + rng.normal(scale=0.5, size=n_var) if k else x_reinit.copy()
+        p = p0.copy()
+        if k:
+            p += rng.normal(scale=0.2, size=n_par) * (np.abs(p0) > 0)
+            p[t_idx] = rng.uniform(0., 0.999 * knot_time)
+        env = {X: x.reshape(-1, 1), Pm: p.reshape(-1, 1)}
+        f = nlp['f'].eval(env) if hasattr(nlp['f'], 'eval') else np.array(nlp['f'])
+        g = nlp['g'].cat.eval(env)
+        xs.append(x); ps.append(p); fs.append(float(np.asarray(f).reshape(-1)[0])); gs.append(g.reshape(-1))
+    np.savez_compressed(
+        os.path.join(HERE, 'nlp_%s.npz' % tag), lb=lb, ub=ub, x_init=x_init, x_reinit=x_reinit, p0=p0,
+        X=np.array(xs), P=np.array(ps), F=np.array(fs), G=np.array(gs),
+        var_layout=np.array(layout_of(father._var_struct), dtype=object),
+        par_layout=np.array(layout_of(father._par_struct), dtype=object),
+        con_layout=np.array(layout_of(father._con_struct), dtype=object))
+    print(tag, 'n_var', n_var, 'n_par', n_par, 'n_con', lb.size)
+
+
+def main():
+    m = install_reference()
+    sh = m['basics.shape']
+    Holonomic = m['vehicles.holonomic'].Holonomic
+    Holonomic3D = m['vehicles.holonomic3d'].Holonomic3D
+    Quadrotor = m['vehicles.quadrotor'].Quadrotor
+    Environment = m['environment.environment'].Environment
+    Obstacle = m['environment.obstacle'].Obstacle
+    Point2point = m['problems.point2point'].Point2point
+    rng = np.random.default_rng(20240807)
+    quiet = {'verbose': 0}
+
+    # config 1: examples/p2p_holonomic.py:23-43
+    vehicle = Holonomic()
+    vehicle.set_options({'safety_distance': 0.1})
+    vehicle.set_options({'ideal_prediction': False})
+    vehicle.set_initial_conditions([-1.5, -1.5])
+    vehicle.set_terminal_conditions([2., 2.])
+    environment = Environment(room={'shape': sh.Square(5.)})
+    trajectories = {'velocity': {'time': [0., 40.], 'values': [[-0.35, 0.35], [0., 0.15]]}}
+    environment.add_obstacle(Obstacle({'position': [1.5, -1]}, shape=sh.Circle(0.5),
+                                      options={'bounce': False},
+                                      simulation={'trajectories': trajectories}))
+    problem = Point2point(vehicle, environment, options=quiet, freeT=False)
+    problem.init()
+    dump(problem, 'cfg1_p2p_holonomic', rng)
+
+    # config 2 template: Holonomic, knot_intervals=11, 3 static circles, no safety distance
+    vehicle = Holonomic()
+    vehicle.define_knots(knot_intervals=11)
+    vehicle.set_initial_conditions([-1.5, -1.2])
+    vehicle.set_terminal_conditions([1.4, 1.7])
+    environment = Environment(room={'shape': sh.Square(5.)})
+    for pos, r in (([0.1, -0.3], 0.3), ([-0.5, 0.4], 0.25), ([0.6, 0.5], 0.35)):
+        environment.add_obstacle(Obstacle({'position': pos}, shape=sh.Circle(r)))
+    problem = Point2point(vehicle, environment, options=quiet, freeT=False)
+    problem.init()
+    dump(problem, 'cfg2_holonomic_k11_o3', rng)
+
+    # rectangle obstacle + rectangular vehicle (checkpoint terms, room hyperplanes)
+    vehicle = Holonomic(shapes=sh.Rectangle(0.3, 0.2))
+    vehicle.set_initial_conditions([-1.5, -1.5])
+    vehicle.set_terminal_conditions([2., 2.])
+    environment = Environment(room={'shape': sh.Square(5.)})
+    environment.add_obstacle(Obstacle({'position': [0.2, -0.4]}, shape=sh.Rectangle(width=1., height=0.4)))
+    problem = Point2point(vehicle, environment, options=quiet, freeT=False)
+    problem.init()
+    dump(problem, 'holonomic_rectangles', rng)
+
+    # Holonomic3D (config 5 family, reduced): spheres, hard terminal constraint
+    vehicle = Holonomic3D(sh.Sphere(0.1))
+    vehicle.set_initial_conditions([-1.5, -1.5, -1.])
+    vehicle.set_terminal_conditions([1.5, 1.5, 1.])
+    environment = Environment(room={'shape': sh.Cube(5.)})
+    for pos, r in (([0.1, -0.3, 0.], 0.3), ([-0.5, 0.4, 0.2], 0.25)):
+        environment.add_obstacle(Obstacle({'position': pos}, shape=sh.Sphere(r)))
+    opts = dict(quiet); opts.update({'horizon_time': 12., 'hard_term_con': True})
+    problem = Point2point(vehicle, environment, options=opts, freeT=False)
+    problem.init()
+    dump(problem, 'holonomic3d_spheres', rng)
+
+    # Quadrotor (config 3 family, reduced): degree 4, cubic constraints, moving circles
+    vehicle = Quadrotor(0.2)
+    vehicle.define_knots(knot_intervals=13)
+    vehicle.set_initial_conditions([-4., -4.])
+    vehicle.set_terminal_conditions([4., 4.])
+    environment = Environment(room={'shape': sh.Square(10.)})
+    for pos, vel, r in (([0., -1.], [0.1, 0.05], 0.4), ([-1.5, 1.], [-0.1, 0.12], 0.3)):
+        environment.add_obstacle(Obstacle({'position': pos, 'velocity': vel}, shape=sh.Circle(r)))
+    opts = dict(quiet); opts.update({'horizon_time': 5.})
+    problem = Point2point(vehicle, environment, options=opts, freeT=False)
+    problem.init()
+    dump(problem, 'quadrotor_k13_o2', rng)
+
+    # spline known-answer matrices straight from the reference's spline algebra
+    rs, rx = m['basics.spline'], m['basics.spline_extra']
+    kats = {}
+    for d, K in ((3, 10), (3, 11), (4, 13)):
+        knots = np.r_[np.zeros(d), np.linspace(0, 1, K + 1), np.ones(d)]
+        b = rs.BSplineBasis(knots, d)
+        h = rs.BSplineBasis(np.r_[0, np.linspace(0, 1, K + 1), 1], 1)
+        o = rs.BSplineBasis([0, 0, 0, 1, 1, 1], 2)
+        x = np.linspace(0, 1, 41)
+        tag = 'd%dK%d_' % (d, K)
+        kats[tag + 'knots'] = knots
+        kats[tag + 'eval'] = b(x).toarray()
+        for od in (1, 2, 3):
+            kats[tag + 'P%d' % od] = b.derivative(od)[1].toarray()
+        kats[tag + 'shift'] = rx.shiftoverknot_T(b)
+        kats[tag + 'shift_h'] = rx.shiftoverknot_T(h)
+        for name, (b1, b2) in (('ax', (h, b)), ('ap', (h, o)), ('aa', (h, h))):
+            n1, n2 = len(b1), len(b2)
+            prod = b1 * b2
+            pairs, _ = b1.pairs(b2)
+            T = np.zeros((len(prod), len(pairs[0])))
+            for q, (i, j) in enumerate(zip(*pairs)):
+                e1, e2 = np.zeros(n1), np.zeros(n2)
+                e1[i], e2[j] = 1., 1.
+                T[:, q] = (rs.BSpline(b1, e1) * rs.BSpline(b2, e2)).coeffs
+            kats[tag + 'T_' + name] = T
+            kats[tag + 'pairs_' + name] = np.array(pairs)
+            kats[tag + 'knots_' + name] = prod.knots
+        kats[tag + 'lift_h_to_ax'] = (h * b).transform(h).toarray()
+        kats[tag + 'lift_v_to_ax'] = (h * b).transform(b).toarray()
+        for ts in (0.0, 0.031, 0.07):
+            T, Ti = rx.shiftfirstknot_T(b, ts, inverse=True)
+            kats[tag + 'fk_%g' % ts], kats[tag + 'fkinv_%g' % ts] = T, Ti
+        c = np.cos(np.arange(len(b)))
+        vals = []
+        for a_ in (0., 0.03, 0.08):
+            v = rx.definite_integral(rs.BSpline(b, c), a_, 1.)
+            vals.append(float(np.asarray(v.eval({}) if hasattr(v, 'eval') else v).reshape(-1)[0]))
+        kats[tag + 'int'] = np.array(vals)
+    np.savez_compressed(os.path.join(HERE, 'spline_kats.npz'), **kats)
+    print('spline KATs:', len(kats))
+
+
+if __name__ == '__main__':
+    main()

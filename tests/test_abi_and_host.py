@@ -1,0 +1,92 @@
+"""C-ABI surface and host-side logic (no compute on a device)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from omgtools.backend import LIB_PATH
+    header = open(os.path.join(ROOT, 'include', 'omgx.h')).read()
+    declared = set(re.findall(r'\b(omgx_[a-z_]+)\s*\(', header))
+    assert {'omgx_batch_create', 'omgx_batch_solve', 'omgx_batch_sample', 'omgx_batch_shift',
+            'omgx_batch_destroy'} <= declared
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.omgx_version.restype = ctypes.c_int
+    assert lib.omgx_version() == 1
+    lib.omgx_status_string.restype = ctypes.c_char_p
+    assert lib.omgx_status_string(0) == b'Solve_Succeeded'
+
+
+def test_no_device_is_a_loud_error(cfg2_small):
+    """Without a GPU the product path must fail, not fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from omgtools.backend import BatchSolver, OmgxError
+    problem, P = cfg2_small
+    with pytest.raises(OmgxError):
+        BatchSolver(problem.father.template, 4)
+
+
+def test_dimensions_table():
+    """SURVEY.md §8 problem sizes (K7)."""
+    import omgtools.backend as be
+    from omgtools.scenarios import holonomic_p2p
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        for sd, dims in ((0., (164, 528, 35)), (0.1, (206, 612, 35))):
+            problem, _ = holonomic_p2p(1, safety_distance=sd)
+            t = problem.father.template
+            assert (t.n_var, t.n_con, t.n_par) == dims
+    finally:
+        be.create_nlp = saved
+
+
+def test_solver_plan_is_block_arrow(cfg2_small):
+    from omgtools.template import SolverPlan
+    problem, _ = cfg2_small
+    tpl = problem.father.template
+    plan = SolverPlan(tpl)
+    assert plan.n_leaf == 3 and [len(l) for l in plan.leaves] == [36, 36, 36]
+    assert sorted(plan.order.tolist()) == list(range(tpl.n_var + 1)) and plan.order[-1] == tpl.n_var
+    assert plan.n_eq == 10
+
+
+def test_obstacle_position_spline_closed_form():
+    """K8: the obstacle's quadratic position spline equals x + v t + a t^2/2."""
+    import omgtools.backend as be
+    from omgtools import Holonomic, Environment, Obstacle, Circle, Square, Point2point
+    from omgtools.splines import BSpline
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        veh = Holonomic()
+        veh.set_initial_conditions([0., 0.]); veh.set_terminal_conditions([1., 1.])
+        env = Environment(room={'shape': Square(5.)})
+        obs = Obstacle({'position': [0.3, -0.2], 'velocity': [0.1, 0.05], 'acceleration': [0.02, -0.01]},
+                       shape=Circle(0.2))
+        env.add_obstacle(obs)
+        prob = Point2point(veh, env, options={'verbose': 0})
+        prob.init()
+        tpl = prob.father.template
+        p = prob.father.set_parameters(0.).cat.copy()
+        t_now, T = 0.37, 10.
+        lo, hi = tpl.entry_range(prob.label, 't', 'par'); p[lo:hi] = t_now
+        atoms = tpl.eval_atoms_host(p)
+        x0, v0, a0 = np.array([0.3, -0.2]), np.array([0.1, 0.05]), np.array([0.02, -0.01])
+        for k in range(2):
+            cf = [tpl.eval_poly_host(c, np.zeros(tpl.n_var), atoms) for c in obs.pos_spline[k].coeffs]
+            for tau in (0., 0.5, 1.):
+                dt_ = tau * T - t_now
+                want = x0[k] + v0[k] * dt_ + 0.5 * a0[k] * dt_**2
+                assert abs(BSpline(obs.basis, cf)(tau) - want) < 1e-12
+    finally:
+        be.create_nlp = saved

@@ -1,0 +1,70 @@
+"""Oracle solver checks (CPU): the numpy interior point, the C port of the kernel
+core, and an INDEPENDENT solver (scipy SLSQP on the same restated NLP) agree.
+IPOPT itself is unobtainable here (parity unpinned for the solver, see
+oracle/ipm_numpy.py); the stated tolerances are fp64."""
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+
+def test_port_matches_numpy_iteration_for_iteration(cfg2_small):
+    from oracle import ipm_numpy, port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    nlp = NumpyNLP(tpl)
+    ref = port_binding.solve(tpl, P['p'][:4], P['x0'][:4], tol=1e-6, max_iter=150)
+    for b in range(4):
+        r = ipm_numpy.solve(nlp, P['x0'][b], P['p'][b], tpl.lb, tpl.ub,
+                            opts={'tol': 1e-6, 'max_iter': 150})
+        assert r['status'] == ref['status'][b]
+        if r['status'] == 0:
+            assert abs(r['iters'] - ref['iters'][b]) <= 1
+            assert np.abs(r['x'] - ref['x'][b]).max() < 1e-8
+            assert np.abs(r['lam_g'] - ref['lam_g'][b]).max() < 1e-6 * (1 + np.abs(r['lam_g']).max())
+
+
+def test_kkt_conditions_and_independent_solver(cfg2_small):
+    """At the interior-point solution: constraints hold, multipliers have the
+    right sign, the Lagrangian is stationary; SLSQP started there cannot improve
+    the objective (same local minimum)."""
+    from oracle import port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    nlp = NumpyNLP(tpl)
+    ref = port_binding.solve(tpl, P['p'], P['x0'], tol=1e-7, max_iter=300)
+    b = int(np.nonzero(ref['status'] == 0)[0][0])
+    x, lam = ref['x'][b], ref['lam_g'][b]
+    c = nlp.term_coefs(P['p'][b])
+    f, g = nlp.fg(x, c)
+    J = nlp.jac(x, c)
+    assert (g - tpl.ub).max() < 1e-7 and (tpl.lb - g).max() < 1e-7
+    ineq = np.isfinite(tpl.ub) & ~np.isfinite(tpl.lb)
+    assert lam[ineq].min() > -1e-12
+    assert np.abs(lam[ineq] * (g - tpl.ub)[ineq]).max() < 1e-5
+    assert np.abs(J[-1] + J[:-1].T @ lam).max() < 1e-5
+    eq = tpl.lb == tpl.ub
+    cons = [{'type': 'eq', 'fun': lambda v: nlp.fg(v, c)[1][eq] - tpl.lb[eq],
+             'jac': lambda v: nlp.jac(v, c)[:-1][eq]},
+            {'type': 'ineq', 'fun': lambda v: (tpl.ub - nlp.fg(v, c)[1])[ineq],
+             'jac': lambda v: -nlp.jac(v, c)[:-1][ineq]}]
+    out = minimize(lambda v: nlp.fg(v, c)[0], x, jac=lambda v: nlp.jac(v, c)[-1],
+                   constraints=cons, method='SLSQP', options={'maxiter': 50, 'ftol': 1e-12})
+    assert out.fun >= f - 1e-6
+    assert abs(out.fun - f) < 1e-5
+
+
+def test_unsupported_and_free_bounds(cfg2_small):
+    from oracle import port_binding
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    lb, ub = tpl.lb.copy(), tpl.ub.copy()
+    lb[0] = -1.0                                   # two-sided row: not supported -> loud status
+    r = port_binding.solve(tpl, P['p'][:1], P['x0'][:1], lbg=lb, ubg=ub, tol=1e-3)
+    assert r['status'][0] == 3
+    lb, ub = tpl.lb.copy(), tpl.ub.copy()
+    ub[100:235] = np.inf                           # obstacle-0/1/2 vehicle rows shut down (update_bounds)
+    r = port_binding.solve(tpl, P['p'][:1], P['x0'][:1], lbg=lb, ubg=ub, tol=1e-3)
+    assert r['status'][0] == 0
+    assert np.all(r['lam_g'][0][100:235] == 0)
