@@ -45,13 +45,21 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  const double* __restrict__ p, const double* __restrict__ x0,
                  const double* __restrict__ lb, const double* __restrict__ ub, int bounds_shared,
                  double* __restrict__ x, double* __restrict__ lam, int32_t* __restrict__ status,
-                 int32_t* __restrict__ iters, int n_agents) {
+                 int32_t* __restrict__ iters, int n_agents, long long* __restrict__ prof) {
   extern __shared__ __align__(16) double lds[];
   const int b = blockIdx.x;
   if (b >= n_agents) return;
   omgx::Work w;
   omgx::work_carve(w, lds, d, kkt_doubles);
   omgx::Ctx c; c.red = w.red;
+#ifdef OMGX_PROFILE
+  __shared__ long long prof_lds[omgx::PH_COUNT];
+  c.prof = prof_lds;
+  if (threadIdx.x < omgx::PH_COUNT) prof_lds[threadIdx.x] = 0;
+  __syncthreads();
+#else
+  c.prof = nullptr;
+#endif
   const double* lbb = lb + (bounds_shared ? 0 : (size_t)b * d.n_con);
   const double* ubb = ub + (bounds_shared ? 0 : (size_t)b * d.n_con);
   omgx::Result r = omgx::ipm_solve(c, d, T, o, w, p + (size_t)b * d.n_par, x0 + (size_t)b * d.n_var,
@@ -62,6 +70,9 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
     lam[(size_t)b * d.n_con + q] =
         (r.status == 3 || w.rtype[q] == omgx::ROW_FREE) ? 0.0 : w.rho[q] * w.z[q];
   if (threadIdx.x == 0) { status[b] = r.status; iters[b] = r.iters; }
+#ifdef OMGX_PROFILE
+  if (prof && threadIdx.x < omgx::PH_COUNT) prof[(size_t)b * omgx::PH_COUNT + threadIdx.x] = prof_lds[threadIdx.x];
+#endif
 }
 
 // out[b, o, k, i] = d^o/dt^o spline_k(t0[b] + i*dt); one block = (agent, 256-sample chunk)
@@ -155,6 +166,7 @@ struct omgx_batch {
   // staging buffers for host-pointer calls
   double *d_p = nullptr, *d_x0 = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_x = nullptr, *d_lam = nullptr;
   int32_t *d_status = nullptr, *d_iters = nullptr;
+  long long* d_prof = nullptr;
 };
 
 namespace {
@@ -207,6 +219,9 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   UP(jc_ptr, d.n_var + 1); UP(jc_row, d.nnz_j); UP(jc_ent, d.nnz_j);
   UP(cpl_ptr, d.n_leaf + 1); UP(cpl_idx, n_cpl); UP(cpl_map, (d.n_leaf > 0 ? d.n_leaf : 1) * d.n_root);
   UP(d_off, d.n_leaf + 1); UP(b_off, d.n_leaf > 0 ? d.n_leaf : 1);
+  UP(pair_a, plan.pair_a.size()); UP(pair_b, plan.pair_b.size()); UP(pair_addr, plan.pair_addr.size());
+  UP(je_row, plan.je_row.size()); UP(jt_addr, plan.jt_addr.size()); UP(diag_addr, d.N);
+  UP(h_addr, plan.h_addr.size()); UP(t_row, plan.t_row.size());
   return OMGX_OK;
 }
 
@@ -254,7 +269,8 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
   if ((rc = dalloc(b, (size_t)n_agents * d.n_par, &b->d_p)) || (rc = dalloc(b, (size_t)n_agents * d.n_var, &b->d_x0)) ||
       (rc = dalloc(b, (size_t)n_agents * d.n_con, &b->d_lb)) || (rc = dalloc(b, (size_t)n_agents * d.n_con, &b->d_ub)) ||
       (rc = dalloc(b, (size_t)n_agents * d.n_var, &b->d_x)) || (rc = dalloc(b, (size_t)n_agents * d.n_con, &b->d_lam)) ||
-      (rc = dalloc(b, (size_t)n_agents, &b->d_status)) || (rc = dalloc(b, (size_t)n_agents, &b->d_iters))) {
+      (rc = dalloc(b, (size_t)n_agents, &b->d_status)) || (rc = dalloc(b, (size_t)n_agents, &b->d_iters)) ||
+      (rc = dalloc(b, (size_t)n_agents * omgx::PH_COUNT, &b->d_prof))) {
     omgx_batch_destroy(b); return rc;
   }
   if (hipStreamCreate(&b->own_stream) != hipSuccess || hipEventCreate(&b->ev0) != hipSuccess ||
@@ -315,7 +331,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   }
   HIPCHK(hipEventRecord(b->ev0, b->stream));
   hipLaunchKernelGGL(ipm_solve_kernel, dim3(B), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev, b->opts,
-                     b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B);
+                     b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   b->timed = true;
@@ -328,6 +344,14 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   }
   return OMGX_OK;
 }
+
+#ifdef OMGX_PROFILE
+int omgx_batch_phase_cycles(omgx_batch* b, long long* out) {   // profiling build only
+  HIPCHK(hipStreamSynchronize(b->stream));
+  HIPCHK(hipMemcpy(out, b->d_prof, (size_t)b->n_agents * omgx::PH_COUNT * sizeof(long long), hipMemcpyDeviceToHost));
+  return OMGX_OK;
+}
+#endif
 
 int omgx_batch_sync(omgx_batch* b) {
   if (!b) return OMGX_E_INVALID;

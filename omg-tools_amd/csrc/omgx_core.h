@@ -40,6 +40,7 @@ struct Dims {
   int N;        // n_var + 1 (phase-I variable t is variable index n_var)
   int n_leaf, n_root, n_eq, nnz_j, root_off;
   int nr;       // n_root + n_eq: order of the root block
+  int n_pairs;  // Jacobian entry pairs contributing to J' Sigma J
   int max_leaf, max_cpl;
 };
 
@@ -53,7 +54,11 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* jr_ptr; const int32_t* jr_pos; const int32_t* t_jidx; const int32_t* row_leaf;
   const int32_t* jc_ptr; const int32_t* jc_row; const int32_t* jc_ent;
   const int32_t* cpl_ptr; const int32_t* cpl_idx; const int32_t* cpl_map;
-  const int32_t* d_off; const int32_t* b_off;   // offsets of D_l / B_l inside the KKT store
+  const int32_t* d_off; const int32_t* b_off;   // panel offsets / leading dimensions inside the KKT store
+  // precomputed KKT addresses (HostPlan): Jacobian pairs, t-column, diagonal, Hessian terms
+  const int32_t* pair_a; const int32_t* pair_b; const int32_t* pair_addr;
+  const int32_t* je_row; const int32_t* jt_addr; const int32_t* diag_addr;
+  const int32_t* h_addr; const int32_t* t_row;
 };
 
 struct Opts {
@@ -71,6 +76,7 @@ struct Opts {
 #define OMGX_DW_INC      10.0
 #define OMGX_DW_DEC      (1.0 / 3.0)
 #define OMGX_DW_MAX      1e10
+#define OMGX_DW_ZERO     1e-9
 #define OMGX_S_MAX       100.0
 #define OMGX_KAPPA_SIGMA 1e10
 #define OMGX_MAX_BACKTRACK 25
@@ -87,7 +93,8 @@ struct Work {
   double *jval;                   // [nnz_j] scaled Jacobian entries (objective row unscaled)
   double *gbar, *sol;             // [N], [N + n_eq]   position order
   double *kkt;                    // D_l (packed) | B_l | R (packed)
-  double *col;                    // [max(nr, max_leaf)] pivot column scratch
+  double *col;                    // [max(nr, 16*max_leaf)] pivot column scratch (one slice per wave)
+  double *dinv;                   // [N] inverse leaf pivots
   int32_t *rtype;                 // [n_con]
   double *red;                    // reduction scratch [64]
 };
@@ -100,7 +107,7 @@ OMGX_HD size_t work_doubles(const Dims& d, int kkt_doubles) {
   n += d.nnz_j;
   n += d.N + (d.N + d.n_eq);
   n += kkt_doubles;
-  n += (d.nr > d.max_leaf ? d.nr : d.max_leaf);
+  n += (d.nr > 16 * d.max_leaf ? d.nr : 16 * d.max_leaf) + d.N;
   n += (d.n_con + 1) / 2;        // rtype (int32)
   n += 64;
   return n;
@@ -116,7 +123,8 @@ OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
   w.jval = p; p += d.nnz_j;
   w.gbar = p; p += d.N;          w.sol = p; p += d.N + d.n_eq;
   w.kkt = p; p += kkt_doubles;
-  w.col = p; p += (d.nr > d.max_leaf ? d.nr : d.max_leaf);
+  w.col = p; p += (d.nr > 16 * d.max_leaf ? d.nr : 16 * d.max_leaf);
+  w.dinv = p; p += d.N;
   w.rtype = (int32_t*)p; p += (d.n_con + 1) / 2;
   w.red = p;
 }
@@ -134,10 +142,16 @@ struct Ctx {
   double rmax(double v) const { return v; }
   double rmin(double v) const { return v; }
   void add(double* p, double v) const { *p += v; }
+  int lane() const { return 0; }
+  int nlanes() const { return 1; }
+  int wave() const { return 0; }
+  int nwaves() const { return 1; }
+  void wave_sync() const {}
 };
 #else
 struct Ctx {
   double* red;
+  long long* prof;
   __device__ int tid() const { return threadIdx.x; }
   __device__ int nthr() const { return blockDim.x; }
   __device__ void sync() const { __syncthreads(); }
@@ -158,10 +172,26 @@ struct Ctx {
   __device__ double rmax(double v) const { return reduce<1>(v); }
   __device__ double rmin(double v) const { return reduce<2>(v); }
   __device__ void add(double* p, double v) const { atomicAdd(p, v); }   // ds_add_f64 on LDS
+  __device__ int lane() const { return threadIdx.x & 63; }
+  __device__ int nlanes() const { return 64; }
+  __device__ int wave() const { return threadIdx.x >> 6; }
+  __device__ int nwaves() const { return blockDim.x >> 6; }
+  // lanes of one wave run in lockstep; this only orders their LDS traffic
+  __device__ void wave_sync() const { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 };
 #endif
 
 #define OMGX_PFOR(i, n) for (int i = c.tid(); i < (n); i += c.nthr())
+
+// optional per-phase cycle counters (profiling build only, -DOMGX_PROFILE)
+enum { PH_JAC = 0, PH_RESID, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_STEP, PH_LINESEARCH, PH_UPDATE, PH_COUNT };
+#if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
+#define OMGX_TIC() long long tic_ = (c.sync(), clock64())
+#define OMGX_TOC(k) do { c.sync(); long long now_ = clock64(); if (c.tid() == 0) c.prof[k] += now_ - tic_; tic_ = now_; } while (0)
+#else
+#define OMGX_TIC() do {} while (0)
+#define OMGX_TOC(k) do {} while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // parameter stage: atoms (Cox-de Boor at t/T, quotients) and coefficient slots
@@ -257,139 +287,189 @@ OMGX_FN int tri(int i, int k) { return i * (i + 1) / 2 + k; }   // packed lower,
 
 struct Kkt {
   const Dims* d; const Tables* T; double* a;
-  OMGX_FN double* D(int l) const { return a + T->d_off[l]; }
-  OMGX_FN double* B(int l) const { return a + T->b_off[l]; }
+  // leaf l: panel of (n_l + nc_l) rows with odd leading dimension ld_l; rows [0,n_l) hold the
+  // leaf block D_l (lower part), rows [n_l, n_l+nc_l) the coupling rows B_l (one per coupled
+  // root position).  Root block R: packed lower, row-major.
+  OMGX_FN double* P(int l) const { return a + T->d_off[l]; }
+  OMGX_FN int ld(int l) const { return T->b_off[l]; }
   OMGX_FN double* R() const { return a + T->d_off[d->n_leaf]; }
   OMGX_FN int nl(int l) const { return T->leaf_off[l + 1] - T->leaf_off[l]; }
   OMGX_FN int nc(int l) const { return T->cpl_ptr[l + 1] - T->cpl_ptr[l]; }
   // address of entry (p, q), positions with p >= q, p,q < N
   OMGX_FN double* at(int p, int q) const {
     const int ro = d->root_off;
-    if (p < ro) { const int l = T->blk[p], o = T->leaf_off[l]; return D(l) + tri(p - o, q - o); }
+    if (p < ro) { const int l = T->blk[p], o = T->leaf_off[l]; return P(l) + (p - o) * ld(l) + (q - o); }
     if (q < ro) { const int l = T->blk[q]; const int arow = T->cpl_map[l * d->n_root + (p - ro)];
-                  return B(l) + arow * nl(l) + (q - T->leaf_off[l]); }
+                  return P(l) + (nl(l) + arow) * ld(l) + (q - T->leaf_off[l]); }
     return R() + tri(p - ro, q - ro);
   }
 };
 
-// LDL' without pivoting of a packed lower matrix, in place (unit L below the
-// diagonal, pivots on it).  Returns (through *bad) whether a pivot has the
-// wrong sign: the first n_pos pivots must be > 0, the rest < 0.
+// Wave-level elimination of one leaf panel (no workgroup barrier): LDL' of the
+// leading n x n block with the nc coupling rows carried along, so that on exit
+//   rows < n :  unit-lower L below the diagonal, pivots d_j on it
+//   rows >= n:  Wt = B L^{-T}           (unscaled)
+// dinv[j] = 1/d_j.  Lanes own rows.  All pivots must be positive.
+template <class C>
+OMGX_FN void leaf_eliminate(const C& c, double* __restrict__ Pn, int n, int nc, int ld,
+                            double* __restrict__ colbuf, double* __restrict__ dinv, int* bad) {
+  const int lane = c.lane(), nl = c.nlanes();
+  const int rows = n + nc;
+  for (int j = 0; j < n; ++j) {
+    const double dj = Pn[j * ld + j];
+    if (!(dj > 0.0)) { *bad = 1; return; }                    // wave-uniform
+    const double inv = 1.0 / dj;
+    for (int r = j + 1 + lane; r < n; r += nl) colbuf[r] = Pn[r * ld + j] * inv;   // l_rj
+    c.wave_sync();
+    // lane -> row: rows beyond the lane count wrap onto the lanes owning the shortest leaf rows
+    for (int r = lane; r < rows; r += nl) {
+      if (r <= j) continue;
+      double* __restrict__ row = Pn + r * ld;
+      const double arj = row[j];
+      const int kmax = r < n ? r : n - 1;
+      int k = j + 1;
+      for (; k + 3 <= kmax; k += 4) {
+        const double c0 = colbuf[k], c1 = colbuf[k + 1], c2 = colbuf[k + 2], c3 = colbuf[k + 3];
+        double r0 = row[k], r1 = row[k + 1], r2 = row[k + 2], r3 = row[k + 3];
+        r0 -= arj * c0; r1 -= arj * c1; r2 -= arj * c2; r3 -= arj * c3;
+        row[k] = r0; row[k + 1] = r1; row[k + 2] = r2; row[k + 3] = r3;
+      }
+      for (; k <= kmax; ++k) row[k] -= arj * colbuf[k];
+      if (r < n) row[j] = arj * inv;
+    }
+    if (lane == 0) dinv[j] = inv;
+    c.wave_sync();
+  }
+}
+
+// LDL' without pivoting of a packed lower matrix, in place, by the whole
+// workgroup (unit L below the diagonal, pivots on it).  The first n_pos pivots
+// must be > 0, the rest < 0.
 template <class C>
 OMGX_FN void ldl_packed(const C& c, double* A, int n, int n_pos, double* col, int* bad) {
+  const int si = c.nthr() >= 16 ? 16 : 1;
+  const int ti = c.tid() % si, tk = c.tid() / si, sk = c.nthr() / si;
   for (int j = 0; j < n; ++j) {
     const double dj = A[tri(j, j)];
     if ((j < n_pos) ? !(dj > 0.0) : !(dj < 0.0)) { *bad = 1; return; }   // uniform: all threads read the same value
     OMGX_PFOR(i, n - j - 1) col[j + 1 + i] = A[tri(j + 1 + i, j)];
     c.sync();
     const double inv = 1.0 / dj;
-    // trailing update, 2-D thread tiling (16 x nthr/16)
-    const int si = c.nthr() >= 16 ? 16 : 1;
-    const int ti = c.tid() % si, tk = c.tid() / si, sk = c.nthr() / si;
     for (int i = j + 1 + ti; i < n; i += si) {
       const double li = col[i] * inv;
-      for (int k = j + 1 + tk; k <= i; k += sk) A[tri(i, k)] -= li * col[k];
-      if (tk == 0) A[tri(i, j)] = li;
+      double* row = A + tri(i, 0);
+      for (int k = j + 1 + tk; k <= i; k += sk) row[k] -= li * col[k];
+      if (tk == 0) row[j] = li;
     }
-    c.sync();
-  }
-}
-
-// forward  y <- L^{-1} y ; diag  y <- y / d ; backward  y <- L^{-T} y   (packed unit-lower L)
-template <class C>
-OMGX_FN void tri_fwd(const C& c, const double* A, int n, double* y) {
-  for (int j = 0; j < n - 1; ++j) {
-    const double yj = y[j];
-    OMGX_PFOR(i, n - j - 1) y[j + 1 + i] -= A[tri(j + 1 + i, j)] * yj;
-    c.sync();
-  }
-}
-template <class C>
-OMGX_FN void tri_diag(const C& c, const double* A, int n, double* y) {
-  OMGX_PFOR(i, n) y[i] /= A[tri(i, i)];
-  c.sync();
-}
-template <class C>
-OMGX_FN void tri_bwd(const C& c, const double* A, int n, double* y) {
-  for (int j = n - 1; j > 0; --j) {
-    const double yj = y[j];
-    OMGX_PFOR(i, j) y[i] -= A[tri(j, i)] * yj;
     c.sync();
   }
 }
 
 // Factorise the assembled block-arrow matrix in place.  Returns 0 if the
-// inertia is (N positive, n_eq negative), 1 otherwise.
+// inertia is (N positive, n_eq negative), 1 otherwise.  w.col: scratch of
+// max(nr, n_waves*max_leaf) doubles; w.dinv: N doubles.
 template <class C>
 OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   int bad = 0;
+  // leaves: one wave each, concurrently
+  for (int l = c.wave(); l < d.n_leaf; l += c.nwaves())
+    leaf_eliminate(c, K.P(l), K.nl(l), K.nc(l), K.ld(l), w.col + c.wave() * d.max_leaf,
+                   w.dinv + K.T->leaf_off[l], &bad);
+  if (c.rmax(bad ? 1.0 : 0.0) > 0.0) return 1;               // also the barrier after the leaf phase
+  // Schur complement onto the root:  R[ci[a]][ci[b]] -= sum_j Wt[a][j] Wt[b][j] / d_j
+  double* R = K.R();
   for (int l = 0; l < d.n_leaf; ++l) {
-    const int n = K.nl(l), nc = K.nc(l);
-    double* D = K.D(l); double* B = K.B(l);
-    ldl_packed(c, D, n, n, w.col, &bad);
-    if (bad) return 1;
-    // B <- B L^{-T}: every coupled row solved independently
-    OMGX_PFOR(a, nc) {
-      double* b = B + a * n;
-      for (int k = 1; k < n; ++k) {
-        double acc = b[k];
-        for (int j = 0; j < k; ++j) acc -= b[j] * D[tri(k, j)];
-        b[k] = acc;
-      }
-    }
-    c.sync();
-    // R[i][k] -= sum_j Wt[a_i][j] Wt[a_k][j] / d_j   (Schur complement onto the root)
-    double* R = K.R();
+    const int n = K.nl(l), nc = K.nc(l), ld = K.ld(l);
+    const double* Wt = K.P(l) + n * ld;
+    const double* di = w.dinv + K.T->leaf_off[l];
     const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
     OMGX_PFOR(e, nc * nc) {
       const int ai = e / nc, ak = e - ai * nc;
       if (ak <= ai) {
-        const double* bi = B + ai * n; const double* bk = B + ak * n;
+        const double* bi = Wt + ai * ld; const double* bk = Wt + ak * ld;
         double acc = 0.0;
-        for (int j = 0; j < n; ++j) acc += bi[j] * bk[j] / D[tri(j, j)];
+        for (int j = 0; j < n; ++j) acc += bi[j] * bk[j] * di[j];
         R[tri(ci[ai], ci[ak])] -= acc;
       }
     }
     c.sync();
   }
-  ldl_packed(c, K.R(), d.nr, d.n_root, w.col, &bad);
+  ldl_packed(c, R, d.nr, d.n_root, w.col, &bad);
   return bad;
 }
 
 // Solve K sol = rhs in place (sol holds rhs on entry); position order + eq.
 template <class C>
-OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, double* sol) {
+OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double* sol) {
   double* yr = sol + d.root_off;
-  for (int l = 0; l < d.n_leaf; ++l) {
-    const int n = K.nl(l), nc = K.nc(l);
+  const int lane = c.lane(), nln = c.nlanes();
+  // leaves (wave-parallel): y_l <- Delta^{-1} L^{-1} r_l
+  for (int l = c.wave(); l < d.n_leaf; l += c.nwaves()) {
+    const int n = K.nl(l), ld = K.ld(l);
+    const double* Pn = K.P(l);
     double* yl = sol + K.T->leaf_off[l];
-    tri_fwd(c, K.D(l), n, yl);
-    tri_diag(c, K.D(l), n, yl);                 // yl = Delta^{-1} L^{-1} r_l
-    const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
-    const double* B = K.B(l);
-    OMGX_PFOR(a, nc) {
-      double acc = 0.0;
-      for (int j = 0; j < n; ++j) acc += B[a * n + j] * yl[j];
-      yr[ci[a]] -= acc;
+    const double* di = w.dinv + K.T->leaf_off[l];
+    for (int j = 0; j < n - 1; ++j) {
+      const double yj = yl[j];
+      for (int i = j + 1 + lane; i < n; i += nln) yl[i] -= Pn[i * ld + j] * yj;
+      c.wave_sync();
     }
-    c.sync();
+    for (int i = lane; i < n; i += nln) yl[i] *= di[i];
+    c.wave_sync();
   }
-  tri_fwd(c, K.R(), d.nr, yr);
-  tri_diag(c, K.R(), d.nr, yr);
-  tri_bwd(c, K.R(), d.nr, yr);
-  for (int l = 0; l < d.n_leaf; ++l) {
-    const int n = K.nl(l), nc = K.nc(l);
+  c.sync();
+  // root rhs:  r_r -= sum_l Wt_l y_l
+  OMGX_PFOR(i, d.n_root) {
+    double acc = 0.0;
+    for (int l = 0; l < d.n_leaf; ++l) {
+      const int a = K.T->cpl_map[l * d.n_root + i];
+      if (a < 0) continue;
+      const int n = K.nl(l), ld = K.ld(l);
+      const double* wrow = K.P(l) + (n + a) * ld;
+      const double* yl = sol + K.T->leaf_off[l];
+      for (int j = 0; j < n; ++j) acc += wrow[j] * yl[j];
+    }
+    yr[i] -= acc;
+  }
+  c.sync();
+  // root solve by wave 0 (packed L)
+  if (c.wave() == 0) {
+    const double* R = K.R();
+    const int n = d.nr;
+    for (int j = 0; j < n - 1; ++j) {
+      const double yj = yr[j];
+      for (int i = j + 1 + lane; i < n; i += nln) yr[i] -= R[tri(i, j)] * yj;
+      c.wave_sync();
+    }
+    for (int i = lane; i < n; i += nln) yr[i] /= R[tri(i, i)];
+    c.wave_sync();
+    for (int j = n - 1; j > 0; --j) {
+      const double yj = yr[j];
+      for (int i = lane; i < j; i += nln) yr[i] -= R[tri(j, i)] * yj;
+      c.wave_sync();
+    }
+  }
+  c.sync();
+  // leaves: y_l <- L^{-T} (y_l - Delta^{-1} Wt' x_r)
+  for (int l = c.wave(); l < d.n_leaf; l += c.nwaves()) {
+    const int n = K.nl(l), nc = K.nc(l), ld = K.ld(l);
+    const double* Pn = K.P(l);
     double* yl = sol + K.T->leaf_off[l];
+    const double* di = w.dinv + K.T->leaf_off[l];
     const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
-    const double* B = K.B(l); const double* D = K.D(l);
-    OMGX_PFOR(j, n) {
+    for (int j = lane; j < n; j += nln) {
       double acc = 0.0;
-      for (int a = 0; a < nc; ++a) acc += B[a * n + j] * yr[ci[a]];
-      yl[j] -= acc / D[tri(j, j)];
+      for (int a = 0; a < nc; ++a) acc += Pn[(n + a) * ld + j] * yr[ci[a]];
+      yl[j] -= acc * di[j];
     }
-    c.sync();
-    tri_bwd(c, D, n, yl);
+    c.wave_sync();
+    for (int j = n - 1; j > 0; --j) {
+      const double yj = yl[j];
+      for (int i = lane; i < j; i += nln) yl[i] -= Pn[j * ld + i] * yj;
+      c.wave_sync();
+    }
   }
+  c.sync();
 }
 
 // ---------------------------------------------------------------------------
@@ -456,6 +536,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   int it = 0, status = 1;
 
   for (it = 0; it <= o.max_iter; ++it) {
+    OMGX_TIC();
     // ---- Jacobian (scaled) -----------------------------------------------------
     OMGX_PFOR(r, m + 1) {
       row_jac(T, w, r, w.x);
@@ -465,6 +546,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       }
     }
     c.sync();
+    OMGX_TOC(PH_JAC);
     // ---- dual residual, barrier gradient (position order), error measures -------
     double rd_max = 0.0;
     OMGX_PFOR(q, n) {
@@ -548,84 +630,89 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     if (c.tid() == 0) w.gbar[N - 1] = gbar_t;
     c.sync();
 
+    OMGX_TOC(PH_RESID);
     // ---- assemble + factorise with inertia correction --------------------------------
-    double dw = 0.0; int failed = 0;
+    // when the previous iteration needed dw > 0, skip the (doomed) dw = 0 attempt and decay instead
+    double dw = (dw_last < OMGX_DW_ZERO) ? 0.0 : dw_last * OMGX_DW_DEC; int failed = 0;
     for (;;) {
       OMGX_PFOR(i, kkt_doubles) w.kkt[i] = 0.0;
       c.sync();
-      // J' Sigma J  (+ equality rows into the root block)
+      // J' Sigma J over precomputed (entry, entry, address) triples; Sigma staged in w.ds
       OMGX_PFOR(r, m) {
         const int ty = w.rtype[r];
-        const int e0 = T.jr_ptr[r], e1 = T.jr_ptr[r + 1];
-        if (ty == ROW_UPPER || ty == ROW_LOWER) {
-          const double sg = w.z[r] / w.s[r];
-          for (int a = e0; a < e1; ++a) {
-            const double ja = sg * w.jval[a]; const int pa = T.jr_pos[a];
-            for (int b = e0; b <= a; ++b) c.add(K.at(pa, T.jr_pos[b]), ja * w.jval[b]);
-            if (use_t && w.vv[r] != 0.0) c.add(K.at(N - 1, pa), -w.vv[r] * ja);
-          }
-          if (use_t && w.vv[r] != 0.0) c.add(K.at(N - 1, N - 1), sg * w.vv[r] * w.vv[r]);
-        } else if (ty == ROW_EQ || (ty == ROW_FREE && T.eq_index[r] >= 0)) {
-          const int k = T.eq_index[r];
-          double* Rr = K.R();
-          if (ty == ROW_EQ) {
-            for (int a = e0; a < e1; ++a) Rr[tri(d.n_root + k, T.jr_pos[a] - d.root_off)] = w.jval[a];
-            if (use_t) Rr[tri(d.n_root + k, d.n_root - 1)] = -w.vv[r];
-          }
-          Rr[tri(d.n_root + k, d.n_root + k)] = -OMGX_DELTA_C;
+        w.ds[r] = (ty == ROW_UPPER || ty == ROW_LOWER) ? w.z[r] / w.s[r] : 0.0;
+      }
+      c.sync();
+      OMGX_PFOR(e, d.n_pairs) {
+        const int a = T.pair_a[e], b = T.pair_b[e];
+        const double sg = w.ds[T.je_row[a]];
+        if (sg != 0.0) c.add(w.kkt + T.pair_addr[e], sg * w.jval[a] * w.jval[b]);
+      }
+      double tt_acc = 0.0;
+      if (use_t) {
+        OMGX_PFOR(e, T.jr_ptr[m]) {
+          const int r = T.je_row[e];
+          const double sv = w.ds[r] * w.vv[r];
+          if (sv != 0.0) c.add(w.kkt + T.jt_addr[e], -sv * w.jval[e]);
         }
+        OMGX_PFOR(r, m) tt_acc += w.ds[r] * w.vv[r] * w.vv[r];
+      }
+      // equality rows straight into the root block
+      OMGX_PFOR(k, d.n_eq) {
+        const int r = T.eq_rows[k];
+        double* Rr = K.R();
+        if (w.rtype[r] == ROW_EQ) {
+          for (int a = T.jr_ptr[r]; a < T.jr_ptr[r + 1]; ++a)
+            Rr[tri(d.n_root + k, T.jr_pos[a] - d.root_off)] = w.jval[a];
+          if (use_t) Rr[tri(d.n_root + k, d.n_root - 1)] = -w.vv[r];
+        }
+        Rr[tri(d.n_root + k, d.n_root + k)] = -OMGX_DELTA_C;
       }
       // Lagrangian Hessian: terms with >= 2 variables, weight = multiplier * signed scale
-      OMGX_PFOR(r, m) {
-        const int ty = w.rtype[r];
-        if (ty == ROW_FREE) continue;
+      OMGX_PFOR(tt, T.row_ptr[m]) {
+        const int32_t* tv = T.t_var + 3 * tt;
+        if (tv[1] < 0) continue;
+        const int r = T.t_row[tt];
+        if (w.rtype[r] == ROW_FREE) continue;
         const double lam = w.z[r] * w.rho[r];
         if (lam == 0.0) continue;
-        for (int tt = T.row_ptr[r]; tt < T.row_ptr[r + 1]; ++tt) {
-          const int32_t* tv = T.t_var + 3 * tt;
-          if (tv[1] < 0) continue;
-          const double cf = lam * term_coef(T, w, tt);
-          const int p0 = T.pos[tv[0]], p1 = T.pos[tv[1]];
-          if (tv[2] < 0) {
-            if (p0 == p1) c.add(K.at(p0, p0), 2.0 * cf);
-            else c.add(p0 > p1 ? K.at(p0, p1) : K.at(p1, p0), cf);
-          } else {
-            const int p2 = T.pos[tv[2]];
-            const double x0v = w.x[tv[0]], x1v = w.x[tv[1]], x2v = w.x[tv[2]];
-            // d2/(dxa dxb) of cf*x0*x1*x2, all ordered pairs, lower triangle only
-            const int pp[3] = {p0, p1, p2}; const double xv[3] = {x0v, x1v, x2v};
-            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {
-              if (a == b) continue;
-              const double val = cf * xv[3 - a - b];
-              if (pp[a] > pp[b]) c.add(K.at(pp[a], pp[b]), val);
-              else if (pp[a] == pp[b] && a < b) c.add(K.at(pp[a], pp[a]), 2.0 * val);
-            }
-          }
+        const double cf = lam * term_coef(T, w, tt);
+        const int32_t* ha = T.h_addr + 3 * tt;
+        if (tv[2] < 0) {
+          c.add(w.kkt + ha[0], tv[0] == tv[1] ? 2.0 * cf : cf);
+        } else {
+          const double x0v = w.x[tv[0]], x1v = w.x[tv[1]], x2v = w.x[tv[2]];
+          c.add(w.kkt + ha[0], (tv[0] == tv[1] ? 2.0 : 1.0) * cf * x2v);   // pair (0,1)
+          c.add(w.kkt + ha[1], (tv[0] == tv[2] ? 2.0 : 1.0) * cf * x1v);   // pair (0,2)
+          c.add(w.kkt + ha[2], (tv[1] == tv[2] ? 2.0 : 1.0) * cf * x0v);   // pair (1,2)
         }
       }
+      tt_acc = use_t ? c.rsum(tt_acc) : 0.0;
       c.sync();
       OMGX_PFOR(q, N) {
         double add = dw;
-        if (q == N - 1) add += use_t ? zt / t : 1.0;
-        *K.at(q, q) += add;
+        if (q == N - 1) add += (use_t ? zt / t : 1.0) + tt_acc;
+        w.kkt[T.diag_addr[q]] += add;
       }
       c.sync();
+      OMGX_TOC(PH_ASSEMBLE);
       const int bad = kkt_factor(c, d, K, w);
+      OMGX_TOC(PH_FACTOR);
       if (!bad) break;
-      dw = (dw == 0.0) ? ((dw_last == 0.0) ? OMGX_DW_FIRST : fmax(1e-10, dw_last * OMGX_DW_DEC))
-                       : dw * OMGX_DW_INC;
+      dw = (dw == 0.0) ? OMGX_DW_FIRST : dw * OMGX_DW_INC;
       if (dw > OMGX_DW_MAX) { failed = 1; break; }
       c.sync();
     }
     if (failed) { status = 4; break; }
-    if (dw > 0.0) dw_last = dw;
+    dw_last = dw;
 
     // ---- Newton step -------------------------------------------------------------
     OMGX_PFOR(q, N) w.sol[q] = -w.gbar[q];
     OMGX_PFOR(k, d.n_eq) { const int r = T.eq_rows[k];
       w.sol[N + k] = (w.rtype[r] == ROW_EQ) ? -(w.hv[r] - t * w.vv[r]) : 0.0; }
     c.sync();
-    kkt_solve(c, d, K, w.sol);
+    kkt_solve(c, d, K, w, w.sol);
+    OMGX_TOC(PH_SOLVE);
     if (!use_t && c.tid() == 0) w.sol[N - 1] = 0.0;
     c.sync();
     const double dt = w.sol[N - 1];
@@ -661,6 +748,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     const double phi0 = f + nu * t - mu * lns - (use_t ? mu * log(t) : 0.0) + nuE * rE_sum;
     const double dphi = gdx - nuE * rE_sum;
 
+    OMGX_TOC(PH_STEP);
     // ---- Armijo backtracking on the barrier function, iterate stays strictly feasible ----
     double alpha = a_p, ft = f, tt = t; int ok = 0;
     for (int bt = 0; bt < OMGX_MAX_BACKTRACK; ++bt) {
@@ -685,6 +773,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       alpha *= 0.5;
       c.sync();
     }
+    OMGX_TOC(PH_LINESEARCH);
     if (!ok) { status = 4; break; }
     // ---- accept --------------------------------------------------------------------
     c.sync();
@@ -710,6 +799,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       zt = fmin(fmax(zt, mu / (OMGX_KAPPA_SIGMA * t)), OMGX_KAPPA_SIGMA * mu / t);
     }
     c.sync();
+    OMGX_TOC(PH_UPDATE);
   }
   res.status = status; res.iters = it > o.max_iter ? o.max_iter : it; res.f = f; res.mu = mu; res.t = t;
   return res;

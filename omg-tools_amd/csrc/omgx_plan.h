@@ -13,6 +13,7 @@ struct HostPlan {
   Tables tables;            // host pointers (into tpl and the vectors below)
   int kkt_doubles;
   std::vector<int32_t> pos, blk, eq_index, d_off, b_off;
+  std::vector<int32_t> pair_a, pair_b, pair_addr, je_row, jt_addr, diag_addr, h_addr, t_row;
 
   bool build(const omgx_template& t) {
     Dims& d = dims;
@@ -32,8 +33,8 @@ struct HostPlan {
       for (int q = t.leaf_off[l]; q < t.leaf_off[l + 1]; ++q) blk[q] = l;
       if (n > d.max_leaf) d.max_leaf = n;
       if (nc > d.max_cpl) d.max_cpl = nc;
-      d_off[l] = off; off += n * (n + 1) / 2;
-      b_off[l] = off; off += nc * n;
+      const int ld = n | 1;                        // odd leading dimension: conflict-free row-per-lane access
+      d_off[l] = off; b_off[l] = ld; off += (n + nc) * ld;
     }
     d_off[d.n_leaf] = off; off += d.nr * (d.nr + 1) / 2;
     kkt_doubles = off;
@@ -48,6 +49,61 @@ struct HostPlan {
     T.row_leaf = t.row_leaf; T.jc_ptr = t.jc_ptr; T.jc_row = t.jc_row; T.jc_ent = t.jc_ent;
     T.cpl_ptr = t.cpl_ptr; T.cpl_idx = t.cpl_idx; T.cpl_map = t.cpl_map;
     T.d_off = d_off.data(); T.b_off = b_off.data();
+    // ---- precomputed addresses -------------------------------------------------------
+    auto tri = [](int i, int k) { return i * (i + 1) / 2 + k; };
+    auto addr = [&](int p, int q) -> int32_t {               // p >= q, positions
+      const int ro = d.root_off;
+      if (p < ro) { const int l = blk[p], o = t.leaf_off[l]; return d_off[l] + (p - o) * b_off[l] + (q - o); }
+      if (q < ro) {
+        const int l = blk[q], n = t.leaf_off[l + 1] - t.leaf_off[l];
+        const int arow = t.cpl_map[l * d.n_root + (p - ro)];
+        if (arow < 0) return -1;
+        return d_off[l] + (n + arow) * b_off[l] + (q - t.leaf_off[l]);
+      }
+      return d_off[d.n_leaf] + tri(p - ro, q - ro);
+    };
+    const int m = d.n_con;
+    je_row.assign(d.nnz_j > 0 ? d.nnz_j : 1, 0);
+    jt_addr.assign(d.nnz_j > 0 ? d.nnz_j : 1, 0);
+    for (int r = 0; r <= m; ++r)
+      for (int e = t.jr_ptr[r]; e < t.jr_ptr[r + 1]; ++e) {
+        je_row[e] = r;
+        jt_addr[e] = (r < m && eq_index[r] < 0) ? addr(d.N - 1, t.jr_pos[e]) : 0;
+        if (jt_addr[e] < 0) return false;
+      }
+    pair_a.clear(); pair_b.clear(); pair_addr.clear();
+    for (int r = 0; r < m; ++r) {
+      if (eq_index[r] >= 0) continue;
+      for (int a = t.jr_ptr[r]; a < t.jr_ptr[r + 1]; ++a)
+        for (int b2 = t.jr_ptr[r]; b2 <= a; ++b2) {
+          const int32_t ad = addr(t.jr_pos[a], t.jr_pos[b2]);
+          if (ad < 0) return false;
+          pair_a.push_back(a); pair_b.push_back(b2); pair_addr.push_back(ad);
+        }
+    }
+    d.n_pairs = (int)pair_a.size();
+    if (pair_a.empty()) { pair_a.push_back(0); pair_b.push_back(0); pair_addr.push_back(0); }
+    diag_addr.assign(d.N, 0);
+    for (int q = 0; q < d.N; ++q) diag_addr[q] = addr(q, q);
+    t_row.assign(d.n_terms > 0 ? d.n_terms : 1, 0);
+    h_addr.assign(3 * (d.n_terms > 0 ? d.n_terms : 1), 0);
+    for (int r = 0; r <= m; ++r)
+      for (int tt = t.row_ptr[r]; tt < t.row_ptr[r + 1]; ++tt) {
+        t_row[tt] = r;
+        const int32_t* tv = t.t_var + 3 * tt;
+        const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+        for (int k = 0; k < 3; ++k) {
+          const int va = tv[pr[k][0]], vb = tv[pr[k][1]];
+          if (r == m || va < 0 || vb < 0) continue;
+          const int pa = pos[va], pb = pos[vb];
+          const int32_t ad = pa >= pb ? addr(pa, pb) : addr(pb, pa);
+          if (ad < 0) return false;
+          h_addr[3 * tt + k] = ad;
+        }
+      }
+    T.pair_a = pair_a.data(); T.pair_b = pair_b.data(); T.pair_addr = pair_addr.data();
+    T.je_row = je_row.data(); T.jt_addr = jt_addr.data(); T.diag_addr = diag_addr.data();
+    T.h_addr = h_addr.data(); T.t_row = t_row.data();
     return true;
   }
 };

@@ -23,7 +23,7 @@ import numpy as np
 
 DEFAULTS = dict(tol=1e-8, max_iter=200, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2,
                 theta_mu=1.5, tau_min=0.99, s_push=1.0, delta_c=1e-8, eta=1e-4,
-                rho=0.1, dw_first=1e-4, dw_inc=10.0, dw_dec=1. / 3., dw_max=1e10,
+                rho=0.1, dw_first=1e-4, dw_inc=10.0, dw_dec=1. / 3., dw_max=1e10, dw_zero=1e-9,
                 s_max=100.0, kappa_sigma=1e10, max_backtrack=25, max_soc=2,
                 slack_reset=True, kappa_push=1.0, stall_iters=10, nu_init=100.0, nu_max=1e8, e_push=1.0, scale_gmax=100.0, s_phi=2.3, s_theta=1.1, delta_sw=1.0,
                 gamma_theta=1e-5, gamma_phi=1e-5, filter_size=8)
@@ -365,7 +365,10 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             M[n, n] += zt / t
         else:
             M[n, n] += 1.0
-        dw, tries = 0.0, 0
+        # inertia correction: when the previous iteration needed dw > 0 the
+        # (doomed) dw = 0 attempt is skipped and the last value is decayed instead
+        dw = 0.0 if dw_last < o['dw_zero'] else dw_last * o['dw_dec']
+        tries = 0
         while True:
             K = np.zeros((N + mE, N + mE))
             K[:N, :N] = M + dw * np.eye(N)
@@ -376,16 +379,14 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             nfact += 1
             if np.all(d[:N] > 0) and np.all(d[N:] < 0):
                 break
-            dw = (o['dw_first'] if dw_last == 0.0 else max(1e-10, dw_last * o['dw_dec'])) \
-                if dw == 0.0 else dw * o['dw_inc']
+            dw = o['dw_first'] if dw == 0.0 else dw * o['dw_inc']
             tries += 1
             if dw > o['dw_max']:
                 status = 4
                 break
         if status == 4:
             break
-        if dw > 0:
-            dw_last = dw
+        dw_last = dw
         # r_p == 0 by construction (slack reset)
         g_bar = gf + Jh.T @ (mu / s)
         if use_t:

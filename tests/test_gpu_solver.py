@@ -19,29 +19,50 @@ def test_library_loads_and_reports_lds(cfg2_small):
     solver.close()
 
 
+def test_fixed_iteration_iterates_match_port(cfg2_small):
+    """Same number of iterations on both sides -> iterates agree to rounding."""
+    from omgtools.backend import BatchSolver
+    from oracle import port_binding
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    opts = dict(tol=1e-300, max_iter=12)
+    solver = BatchSolver(tpl, 8, options=opts)
+    res = solver.solve(P['p'], P['x0'])
+    ref = port_binding.solve(tpl, P['p'], P['x0'], **opts)
+    assert np.array_equal(res['iters'], ref['iters'])
+    assert np.abs(res['x'] - ref['x']).max() < 1e-8
+    assert np.abs(res['lam_g'] - ref['lam_g']).max() < 1e-6 * (1 + np.abs(ref['lam_g']).max())
+    solver.close()
+
+
 def test_cfg2_matches_port_and_numpy(cfg2_small):
     from omgtools.backend import BatchSolver
     from oracle import port_binding, ipm_numpy
     from oracle.nlp_numpy import NumpyNLP
     problem, P = cfg2_small
     tpl = problem.father.template
-    solver = BatchSolver(tpl, 8, options=dict(tol=1e-6, max_iter=200))
+    tol = 1e-7
+    solver = BatchSolver(tpl, 8, options=dict(tol=tol, max_iter=300))
     res = solver.solve(P['p'], P['x0'])
-    ref = port_binding.solve(tpl, P['p'], P['x0'], tol=1e-6, max_iter=200)
-    # agents on the edge of the iteration limit may land on either side of it
+    ref = port_binding.solve(tpl, P['p'], P['x0'], tol=tol, max_iter=300)
+    # agents on the edge of an iteration/stall limit may land on either side of it
     assert (res['status'] == ref['status']).sum() >= 7
     good = (res['status'] == 0) & (ref['status'] == 0)
-    assert good.sum() >= 5
-    assert np.abs(res['iters'][good] - ref['iters'][good]).max() <= 2
-    assert np.abs(res['x'][good] - ref['x'][good]).max() < TOL_X
+    assert good.sum() >= 4
+    lo, hi = tpl.entry_range(problem.vehicles[0].label, 'splines_seg0', 'var')
     nlp = NumpyNLP(tpl)
+    for b in np.nonzero(good)[0]:
+        # converged solutions: trajectory coefficients (the output the reference
+        # consumes) to 1e-5, objective to 1e-7; hyperplane variables are not unique
+        assert np.abs(res['x'][b, lo:hi] - ref['x'][b, lo:hi]).max() < 1e-5
+        c = nlp.term_coefs(P['p'][b])
+        f_gpu, g = nlp.fg(res['x'][b], c)
+        f_ref, _ = nlp.fg(ref['x'][b], c)
+        assert abs(f_gpu - f_ref) < 1e-7
+        assert (g - tpl.ub).max() < 1e-6 and (tpl.lb - g).max() < 1e-6
     b = int(np.nonzero(good)[0][0])
     r_np = ipm_numpy.solve(nlp, P['x0'][b], P['p'][b], tpl.lb, tpl.ub,
-                           opts={'tol': 1e-6, 'max_iter': 200})
+                           opts={'tol': tol, 'max_iter': 300})
     assert r_np['status'] == 0
-    assert np.abs(r_np['x'] - res['x'][b]).max() < TOL_X
-    # the solution satisfies the constraints of the reference NLP
-    c = nlp.term_coefs(P['p'][b])
-    _, g = nlp.fg(res['x'][b], c)
-    assert (g - tpl.ub).max() < 1e-6 and (tpl.lb - g).max() < 1e-6
+    assert np.abs(r_np['x'][lo:hi] - res['x'][b, lo:hi]).max() < 1e-5
     solver.close()

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Per-phase cycle breakdown of ipm_solve_kernel (profiling build libomgx_prof.so,
+`make -C omg-tools_amd/csrc libomgx_prof.so`).  Developer tool, not a test."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
+import omgtools.backend as be
+
+PHASES = ['jac', 'resid', 'assemble', 'factor', 'solve', 'step', 'linesearch', 'update']
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    be.LIB_PATH = os.path.join(ROOT, 'omg-tools_amd', 'csrc', 'libomgx_prof.so')
+    from omgtools.scenarios import holonomic_p2p
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    problem, P = holonomic_p2p(B)
+    be.create_nlp = saved
+    tpl = problem.father.template
+    solver = be.BatchSolver(tpl, B, options=dict(tol=1e-3, max_iter=300))
+    for _ in range(2):
+        res = solver.solve(P['p'], P['x0'])
+    ms = solver.last_kernel_ms()
+    prof = np.zeros((B, len(PHASES)), dtype=np.int64)
+    solver.lib.omgx_batch_phase_cycles.argtypes = [C.c_void_p, C.c_void_p]
+    solver.lib.omgx_batch_phase_cycles(solver._h, prof.ctypes.data)
+    its = res['iters'].sum()
+    tot = prof.sum()
+    out = {'agents': B, 'kernel_ms': ms, 'sum_iters': int(its),
+           'solved': int((res['status'] == 0).sum()),
+           'cycles_per_iter': {p: float(prof[:, k].sum() / its) for k, p in enumerate(PHASES)},
+           'share': {p: float(prof[:, k].sum() / tot) for k, p in enumerate(PHASES)},
+           'total_cycles_per_iter': float(tot / its)}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
