@@ -1,7 +1,7 @@
 // omgx.hip -- libomgx.so: C ABI (include/omgx.h) + gfx950 kernels.
 //
 // Kernels (all hand-written HIP for CDNA4, wave64):
-//   ipm_solve_kernel   one 256-thread workgroup per agent, whole interior-point
+//   ipm_solve_kernel   one 512-thread workgroup (8 waves) per agent, whole interior-point
 //                      solve with every per-agent array resident in LDS
 //                      (<= 160 KiB / CU); only p, x0, bounds are read from HBM and
 //                      x, lam_g, status written back.
@@ -32,7 +32,7 @@ thread_local std::string g_err;
     }                                                                             \
   } while (0)
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;
 constexpr int kLdsLimit = 160 * 1024;
 
 }  // namespace
@@ -40,7 +40,7 @@ constexpr int kLdsLimit = 160 * 1024;
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  const double* __restrict__ p, const double* __restrict__ x0,
                  const double* __restrict__ lb, const double* __restrict__ ub, int bounds_shared,

@@ -42,6 +42,7 @@ struct Dims {
   int nr;       // n_root + n_eq: order of the root block
   int n_pairs;  // Jacobian entry pairs contributing to J' Sigma J
   int max_leaf, max_cpl;
+  int col_doubles;   // scratch for the blocked LDL' (staging + panel buffers)
 };
 
 struct Tables {   // read-only, shared by all agents (global memory)
@@ -82,6 +83,8 @@ struct Opts {
 #define OMGX_MAX_BACKTRACK 25
 #define OMGX_NU_MAX      1e8
 #define OMGX_STALL_ITERS 10
+#define OMGX_MAX_LEAF    16
+#define OMGX_BMAT_DOUBLES 4      // sizeof(BMat) / 8
 
 // Per-agent work arrays (LDS on the device, heap on the host port).
 struct Work {
@@ -93,7 +96,7 @@ struct Work {
   double *jval;                   // [nnz_j] scaled Jacobian entries (objective row unscaled)
   double *gbar, *sol;             // [N], [N + n_eq]   position order
   double *kkt;                    // D_l (packed) | B_l | R (packed)
-  double *col;                    // [max(nr, 16*max_leaf)] pivot column scratch (one slice per wave)
+  double *col;                    // [col_doubles] blocked-LDL' staging + panel buffers
   double *dinv;                   // [N] inverse leaf pivots
   int32_t *rtype;                 // [n_con]
   double *red;                    // reduction scratch [64]
@@ -107,7 +110,7 @@ OMGX_HD size_t work_doubles(const Dims& d, int kkt_doubles) {
   n += d.nnz_j;
   n += d.N + (d.N + d.n_eq);
   n += kkt_doubles;
-  n += (d.nr > 16 * d.max_leaf ? d.nr : 16 * d.max_leaf) + d.N;
+  n += d.col_doubles + d.N;
   n += (d.n_con + 1) / 2;        // rtype (int32)
   n += 64;
   return n;
@@ -123,7 +126,7 @@ OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
   w.jval = p; p += d.nnz_j;
   w.gbar = p; p += d.N;          w.sol = p; p += d.N + d.n_eq;
   w.kkt = p; p += kkt_doubles;
-  w.col = p; p += (d.nr > 16 * d.max_leaf ? d.nr : 16 * d.max_leaf);
+  w.col = p; p += d.col_doubles;
   w.dinv = p; p += d.N;
   w.rtype = (int32_t*)p; p += (d.n_con + 1) / 2;
   w.red = p;
@@ -184,7 +187,7 @@ struct Ctx {
 #define OMGX_PFOR(i, n) for (int i = c.tid(); i < (n); i += c.nthr())
 
 // optional per-phase cycle counters (profiling build only, -DOMGX_PROFILE)
-enum { PH_JAC = 0, PH_RESID, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_STEP, PH_LINESEARCH, PH_UPDATE, PH_COUNT };
+enum { PH_JAC = 0, PH_RESID, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_STEP, PH_LINESEARCH, PH_UPDATE, PH_F_LEAF, PH_F_SCHUR, PH_F_ROOT, PH_LA, PH_LS, PH_LB, PH_COUNT };
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
 #define OMGX_TIC() long long tic_ = (c.sync(), clock64())
 #define OMGX_TOC(k) do { c.sync(); long long now_ = clock64(); if (c.tid() == 0) c.prof[k] += now_ - tic_; tic_ = now_; } while (0)
@@ -305,96 +308,246 @@ struct Kkt {
   }
 };
 
-// Wave-level elimination of one leaf panel (no workgroup barrier): LDL' of the
-// leading n x n block with the nc coupling rows carried along, so that on exit
-//   rows < n :  unit-lower L below the diagonal, pivots d_j on it
-//   rows >= n:  Wt = B L^{-T}           (unscaled)
-// dinv[j] = 1/d_j.  Lanes own rows.  All pivots must be positive.
-template <class C>
-OMGX_FN void leaf_eliminate(const C& c, double* __restrict__ Pn, int n, int nc, int ld,
-                            double* __restrict__ colbuf, double* __restrict__ dinv, int* bad) {
-  const int lane = c.lane(), nl = c.nlanes();
-  const int rows = n + nc;
-  for (int j = 0; j < n; ++j) {
-    const double dj = Pn[j * ld + j];
-    if (!(dj > 0.0)) { *bad = 1; return; }                    // wave-uniform
-    const double inv = 1.0 / dj;
-    for (int r = j + 1 + lane; r < n; r += nl) colbuf[r] = Pn[r * ld + j] * inv;   // l_rj
-    c.wave_sync();
-    // lane -> row: rows beyond the lane count wrap onto the lanes owning the shortest leaf rows
-    for (int r = lane; r < rows; r += nl) {
-      if (r <= j) continue;
-      double* __restrict__ row = Pn + r * ld;
-      const double arj = row[j];
-      const int kmax = r < n ? r : n - 1;
-      int k = j + 1;
-      for (; k + 3 <= kmax; k += 4) {
-        const double c0 = colbuf[k], c1 = colbuf[k + 1], c2 = colbuf[k + 2], c3 = colbuf[k + 3];
-        double r0 = row[k], r1 = row[k + 1], r2 = row[k + 2], r3 = row[k + 3];
-        r0 -= arj * c0; r1 -= arj * c1; r2 -= arj * c2; r3 -= arj * c3;
-        row[k] = r0; row[k + 1] = r1; row[k + 2] = r2; row[k + 3] = r3;
-      }
-      for (; k <= kmax; ++k) row[k] -= arj * colbuf[k];
-      if (r < n) row[j] = arj * inv;
-    }
-    if (lane == 0) dinv[j] = inv;
-    c.wave_sync();
-  }
+// ---------------------------------------------------------------------------
+// Blocked LDL' (panel width 4 = the K of v_mfma_f64_16x16x4_f64).
+//
+// A "matrix" here is a set of rows: the first nfact rows/columns form the
+// symmetric block to factorise (lower part stored), the remaining rows are
+// carried along (leaf panels carry their coupling rows B_l, which end up as
+// Wt = B L^{-T}).  Storage is either row-major with leading dimension ld or
+// packed lower (ld == 0).  Per block of 4 columns:
+//   phase A  every row solves its 4 panel entries against the 4x4 diagonal
+//            block (factorised redundantly by each thread: no extra barrier)
+//            and publishes U = a L_jj^{-T} and Lp = U Delta^{-1} in a panel buffer;
+//   phase B  trailing update  A[r][k] -= sum_q U[r][q] Lp[k][q]: one MFMA per
+//            16x16 tile on the device.
+// Two workgroup barriers per 4 columns instead of two per column.
+// ---------------------------------------------------------------------------
+// offsets (not pointers) so that every access stays a provable LDS access (ds_* instead of flat_*)
+struct BMat { int a, ld, nfact, rows, npos, dinv, pan, pad_; };   // a: offset in kkt; dinv: offset in w.dinv (-1: none); pan: offset in w.col
+static_assert(sizeof(BMat) <= 4 * sizeof(double), "BMat larger than its LDS slot");
+#define OMGX_NB 4
+#define OMGX_PAN_LD 9      // panel buffer row stride (odd: conflict-free row-per-lane access)
+
+OMGX_FN int baddr(const BMat& M, int r, int k) { return M.a + (M.ld ? r * M.ld + k : tri(r, k)); }
+
+// 4x4 (or smaller) diagonal block LDL' from the stored lower entries
+struct Blk4 { double l10, l20, l21, l30, l31, l32, d0, d1, d2, d3, i0, i1, i2, i3; };
+OMGX_FN Blk4 blk4_factor(const BMat& M, const double* A, int jb, int nb) {
+  Blk4 b; b.l10 = b.l20 = b.l21 = b.l30 = b.l31 = b.l32 = 0.0; b.d1 = b.d2 = b.d3 = 1.0;
+  // all loads first (independent), then the short dependent chain
+  double g[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int k = 0; k <= a; ++k) g[a][k] = (a < nb) ? A[baddr(M, jb + a, jb + k)] : (a == k ? 1.0 : 0.0);
+  b.d0 = g[0][0]; b.i0 = 1.0 / b.d0;
+  b.l10 = g[1][0] * b.i0; b.l20 = g[2][0] * b.i0; b.l30 = g[3][0] * b.i0;
+  b.d1 = g[1][1] - b.l10 * g[1][0]; b.i1 = 1.0 / b.d1;
+  const double w21 = g[2][1] - g[2][0] * b.l10, w31 = g[3][1] - g[3][0] * b.l10;
+  b.l21 = w21 * b.i1; b.l31 = w31 * b.i1;
+  b.d2 = g[2][2] - b.l20 * g[2][0] - b.l21 * w21; b.i2 = 1.0 / b.d2;
+  const double w32 = g[3][2] - g[3][0] * b.l20 - w31 * b.l21;
+  b.l32 = w32 * b.i2;
+  b.d3 = g[3][3] - b.l30 * g[3][0] - b.l31 * w31 - b.l32 * w32; b.i3 = 1.0 / b.d3;
+  return b;
 }
 
-// LDL' without pivoting of a packed lower matrix, in place, by the whole
-// workgroup (unit L below the diagonal, pivots on it).  The first n_pos pivots
-// must be > 0, the rest < 0.
+// Factorise `nm` matrices together (same block index for all of them).
+// Returns through *bad whether a pivot had the wrong sign.
 template <class C>
-OMGX_FN void ldl_packed(const C& c, double* A, int n, int n_pos, double* col, int* bad) {
-  const int si = c.nthr() >= 16 ? 16 : 1;
-  const int ti = c.tid() % si, tk = c.tid() / si, sk = c.nthr() / si;
-  for (int j = 0; j < n; ++j) {
-    const double dj = A[tri(j, j)];
-    if ((j < n_pos) ? !(dj > 0.0) : !(dj < 0.0)) { *bad = 1; return; }   // uniform: all threads read the same value
-    OMGX_PFOR(i, n - j - 1) col[j + 1 + i] = A[tri(j + 1 + i, j)];
-    c.sync();
-    const double inv = 1.0 / dj;
-    for (int i = j + 1 + ti; i < n; i += si) {
-      const double li = col[i] * inv;
-      double* row = A + tri(i, 0);
-      for (int k = j + 1 + tk; k <= i; k += sk) row[k] -= li * col[k];
-      if (tk == 0) row[j] = li;
+OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* dinvb, double* colb, double* stage, int* bad) {
+  int nmax = 0, total_rows = 0;
+  for (int i = 0; i < nm; ++i) { if (Ms[i].nfact > nmax) nmax = Ms[i].nfact; total_rows += Ms[i].rows; }
+  int badl = 0;
+  OMGX_TIC();
+  for (int jb = 0; jb < nmax; jb += OMGX_NB) {
+    // ---- phase A: panel ---------------------------------------------------------------
+    OMGX_PFOR(it, total_rows) {
+      int mi = 0, r = it;
+      while (r >= Ms[mi].rows) { r -= Ms[mi].rows; ++mi; }
+      const BMat M = Ms[mi];                       // by value: keep the descriptor in registers
+      if (jb >= M.nfact || r < jb) continue;
+      const int nb = (M.nfact - jb) < OMGX_NB ? (M.nfact - jb) : OMGX_NB;
+      const Blk4 B = blk4_factor(M, A, jb, nb);
+      if (r < jb + nb) {
+        // a row of the diagonal block: final values go through the staging area
+        // (other threads are still reading the original block).  No dynamically
+        // indexed local arrays here: they would live in scratch memory.
+        const int q = r - jb;
+        double* st = stage + mi * 16 + q * 4;
+        const double dq = q == 0 ? B.d0 : (q == 1 ? B.d1 : (q == 2 ? B.d2 : B.d3));
+        const double iq = q == 0 ? B.i0 : (q == 1 ? B.i1 : (q == 2 ? B.i2 : B.i3));
+        if (q == 1) { st[0] = B.l10; }
+        else if (q == 2) { st[0] = B.l20; st[1] = B.l21; }
+        else if (q == 3) { st[0] = B.l30; st[1] = B.l31; st[2] = B.l32; }
+        st[q] = dq;
+        const bool pos_ok = (jb + q < M.npos) ? (dq > 0.0) : (dq < 0.0);
+        if (!pos_ok) badl = 1;
+        if (M.dinv >= 0) dinvb[M.dinv + jb + q] = iq;
+        double* pr = colb + M.pan + r * OMGX_PAN_LD;
+        pr[0] = 0.0; pr[1] = 0.0; pr[2] = 0.0; pr[3] = 0.0; pr[4] = 0.0; pr[5] = 0.0; pr[6] = 0.0; pr[7] = 0.0;
+      } else {
+        const int base = baddr(M, r, jb);
+        const double a0 = A[base];
+        const double a1 = nb > 1 ? A[base + 1] : 0.0;
+        const double a2 = nb > 2 ? A[base + 2] : 0.0;
+        const double a3 = nb > 3 ? A[base + 3] : 0.0;
+        const double u0 = a0;
+        const double u1 = a1 - u0 * B.l10;
+        const double u2 = a2 - u0 * B.l20 - u1 * B.l21;
+        const double u3 = a3 - u0 * B.l30 - u1 * B.l31 - u2 * B.l32;
+        const double p0 = u0 * B.i0, p1 = nb > 1 ? u1 * B.i1 : 0.0, p2 = nb > 2 ? u2 * B.i2 : 0.0,
+                     p3 = nb > 3 ? u3 * B.i3 : 0.0;
+        double* pr = colb + M.pan + r * OMGX_PAN_LD;
+        pr[0] = u0; pr[1] = nb > 1 ? u1 : 0.0; pr[2] = nb > 2 ? u2 : 0.0; pr[3] = nb > 3 ? u3 : 0.0;
+        pr[4] = p0; pr[5] = p1; pr[6] = p2; pr[7] = p3;
+        const bool fact_row = r < M.nfact;
+        A[base] = fact_row ? p0 : u0;
+        if (nb > 1) A[base + 1] = fact_row ? p1 : u1;
+        if (nb > 2) A[base + 2] = fact_row ? p2 : u2;
+        if (nb > 3) A[base + 3] = fact_row ? p3 : u3;
+      }
     }
     c.sync();
+    OMGX_TOC(PH_LA);
+    // block rows: staging -> matrix
+    OMGX_PFOR(it, nm * 16) {
+      const int mi = it >> 4, q = (it >> 2) & 3, k = it & 3;
+      const BMat M = Ms[mi];
+      if (jb < M.nfact && jb + q < M.nfact && k <= q) A[baddr(M, jb + q, jb + k)] = stage[it];
+    }
+    OMGX_TOC(PH_LS);
+    // ---- phase B: trailing update, 16x16 tiles -------------------------------------------
+    int tile0 = 0;
+    for (int mi = 0; mi < nm; ++mi) {
+      const BMat M = Ms[mi];
+      const int s0 = jb + OMGX_NB;
+      if (s0 >= M.nfact) continue;
+      const int tr = (M.rows - s0 + 15) >> 4, tc = (M.nfact - s0 + 15) >> 4;
+#ifdef OMGX_HOST_PORT
+      (void)tile0; (void)tr; (void)tc;
+      for (int r = s0; r < M.rows; ++r) {
+        const int kmax = r < M.nfact ? r : M.nfact - 1;
+        for (int k = s0; k <= kmax; ++k) {
+          double acc = 0.0;
+          for (int q = 0; q < OMGX_NB; ++q) acc += colb[M.pan + r * OMGX_PAN_LD + q] * colb[M.pan + k * OMGX_PAN_LD + 4 + q];
+          A[baddr(M, r, k)] -= acc;
+        }
+      }
+#else
+      const int lane = c.lane();
+      for (int tile = c.wave() - (tile0 % c.nwaves()); tile < tr * tc; tile += c.nwaves()) {
+        if (tile < 0) continue;
+        const int ti = tile / tc, tj = tile - ti * tc;
+        const int R0 = s0 + 16 * ti, K0 = s0 + 16 * tj;
+        if (K0 > R0 + 15 && R0 + 15 < M.nfact) continue;           // tile entirely above the diagonal
+        const int ra = R0 + (lane & 15), kb = K0 + (lane & 15), q = lane >> 4;
+        const double av = (ra < M.rows) ? -colb[M.pan + ra * OMGX_PAN_LD + q] : 0.0;
+        const double bv = (kb < M.nfact) ? colb[M.pan + kb * OMGX_PAN_LD + 4 + q] : 0.0;
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        v4d acc;
+        const int col = K0 + (lane & 15);
+        int ad[4]; bool ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = R0 + (lane >> 4) + 4 * i;
+          ok[i] = row < M.rows && col < M.nfact && (row >= M.nfact || col <= row);
+          ad[i] = ok[i] ? baddr(M, row, col) : 0;
+          acc[i] = ok[i] ? A[ad[i]] : 0.0;
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (ok[i]) A[ad[i]] = acc[i];
+      }
+      tile0 += tr * tc;
+#endif
+    }
+    c.sync();
+    OMGX_TOC(PH_LB);
   }
+  *bad = c.rmax(badl ? 1.0 : 0.0) > 0.0 ? 1 : 0;
 }
 
 // Factorise the assembled block-arrow matrix in place.  Returns 0 if the
-// inertia is (N positive, n_eq negative), 1 otherwise.  w.col: scratch of
-// max(nr, n_waves*max_leaf) doubles; w.dinv: N doubles.
+// inertia is (N positive, n_eq negative), 1 otherwise.
 template <class C>
 OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   int bad = 0;
-  // leaves: one wave each, concurrently
-  for (int l = c.wave(); l < d.n_leaf; l += c.nwaves())
-    leaf_eliminate(c, K.P(l), K.nl(l), K.nc(l), K.ld(l), w.col + c.wave() * d.max_leaf,
-                   w.dinv + K.T->leaf_off[l], &bad);
-  if (c.rmax(bad ? 1.0 : 0.0) > 0.0) return 1;               // also the barrier after the leaf phase
+  OMGX_TIC();
+  // matrix descriptors live in LDS (shared by the workgroup), then staging, then panel buffers
+  BMat* Ms = (BMat*)w.col;
+  double* stage = w.col + OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1);
+  const int pan0 = (int)(stage + 16 * (OMGX_MAX_LEAF + 1) - w.col);
+  if (c.tid() == 0) {
+    int pan = pan0;
+    for (int l = 0; l < d.n_leaf; ++l) {
+      BMat& M = Ms[l];
+      M.a = K.T->d_off[l]; M.ld = K.ld(l); M.nfact = K.nl(l); M.rows = K.nl(l) + K.nc(l); M.npos = M.nfact;
+      M.dinv = K.T->leaf_off[l]; M.pan = pan; pan += OMGX_PAN_LD * M.rows;
+    }
+    BMat& Mr = Ms[d.n_leaf];
+    Mr.a = K.T->d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0;
+  }
+  c.sync();
+  if (d.n_leaf > 0) {
+    ldl_blocked(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, stage, &bad);
+    if (bad) return 1;
+  }
+  OMGX_TOC(PH_F_LEAF);
   // Schur complement onto the root:  R[ci[a]][ci[b]] -= sum_j Wt[a][j] Wt[b][j] / d_j
   double* R = K.R();
+#ifdef OMGX_HOST_PORT
   for (int l = 0; l < d.n_leaf; ++l) {
     const int n = K.nl(l), nc = K.nc(l), ld = K.ld(l);
     const double* Wt = K.P(l) + n * ld;
     const double* di = w.dinv + K.T->leaf_off[l];
     const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
-    OMGX_PFOR(e, nc * nc) {
-      const int ai = e / nc, ak = e - ai * nc;
-      if (ak <= ai) {
-        const double* bi = Wt + ai * ld; const double* bk = Wt + ak * ld;
-        double acc = 0.0;
-        for (int j = 0; j < n; ++j) acc += bi[j] * bk[j] * di[j];
-        R[tri(ci[ai], ci[ak])] -= acc;
-      }
+    for (int ai = 0; ai < nc; ++ai) for (int ak = 0; ak <= ai; ++ak) {
+      double acc = 0.0;
+      for (int j = 0; j < n; ++j) acc += Wt[ai * ld + j] * Wt[ak * ld + j] * di[j];
+      R[tri(ci[ai], ci[ak])] -= acc;
     }
-    c.sync();
   }
-  ldl_packed(c, R, d.nr, d.n_root, w.col, &bad);
+#else
+  {
+    // S = Wt Delta^{-1} Wt' per leaf as 16x16 MFMA tiles (K swept in steps of 4); leaves
+    // scatter into shared root entries, hence the LDS atomics
+    const int lane = c.lane();
+    int tile0 = 0;
+    for (int l = 0; l < d.n_leaf; ++l) {
+      const int n = K.nl(l), nc = K.nc(l), ld = K.ld(l);
+      const double* Wt = K.P(l) + n * ld;
+      const double* di = w.dinv + K.T->leaf_off[l];
+      const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
+      const int tn = (nc + 15) >> 4;
+      for (int tile = c.wave() - (tile0 % c.nwaves()); tile < tn * tn; tile += c.nwaves()) {
+        if (tile < 0) continue;
+        const int ti = tile / tn, tj = tile - ti * tn;
+        if (tj > ti) continue;
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        const int ra = 16 * ti + (lane & 15), rb = 16 * tj + (lane & 15), q = lane >> 4;
+        for (int j0 = 0; j0 < n; j0 += 4) {
+          const int j = j0 + q;
+          const double av = (ra < nc && j < n) ? Wt[ra * ld + j] * di[j] : 0.0;
+          const double bv = (rb < nc && j < n) ? Wt[rb * ld + j] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+        const int cb = 16 * tj + (lane & 15);
+        for (int i = 0; i < 4; ++i) {
+          const int ca = 16 * ti + (lane >> 4) + 4 * i;
+          if (ca < nc && cb < nc && cb <= ca) c.add(R + tri(ci[ca], ci[cb]), -acc[i]);
+        }
+      }
+      tile0 += tn * tn;
+    }
+  }
+#endif
+  c.sync();
+  OMGX_TOC(PH_F_SCHUR);
+  ldl_blocked(c, Ms + d.n_leaf, 1, w.kkt, w.dinv, w.col, stage, &bad);
+  OMGX_TOC(PH_F_ROOT);
   return bad;
 }
 

@@ -37,6 +37,13 @@ struct HostPlan {
       d_off[l] = off; b_off[l] = ld; off += (n + nc) * ld;
     }
     d_off[d.n_leaf] = off; off += d.nr * (d.nr + 1) / 2;
+    {
+      int leaf_rows = 0;
+      for (int l = 0; l < d.n_leaf; ++l) leaf_rows += (t.leaf_off[l + 1] - t.leaf_off[l]) + (t.cpl_ptr[l + 1] - t.cpl_ptr[l]);
+      const int pr = leaf_rows > d.nr ? leaf_rows : d.nr;
+      d.col_doubles = (OMGX_BMAT_DOUBLES + 16) * (OMGX_MAX_LEAF + 1) + OMGX_PAN_LD * pr;
+      if (d.n_leaf > OMGX_MAX_LEAF) return false;
+    }
     kkt_doubles = off;
     eq_index.assign(d.n_con, -1);
     for (int k = 0; k < d.n_eq; ++k) eq_index[t.eq_rows[k]] = k;

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
 import omgtools.backend as be
 
-PHASES = ['jac', 'resid', 'assemble', 'factor', 'solve', 'step', 'linesearch', 'update']
+PHASES = ['jac', 'resid', 'assemble', 'factor', 'solve', 'step', 'linesearch', 'update', 'f_leaf', 'f_schur', 'f_root', 'l_A', 'l_stage', 'l_B']
 
 
 def main():
@@ -32,7 +32,7 @@ def main():
     solver.lib.omgx_batch_phase_cycles.argtypes = [C.c_void_p, C.c_void_p]
     solver.lib.omgx_batch_phase_cycles(solver._h, prof.ctypes.data)
     its = res['iters'].sum()
-    tot = prof.sum()
+    tot = prof[:, :8].sum()
     out = {'agents': B, 'kernel_ms': ms, 'sum_iters': int(its),
            'solved': int((res['status'] == 0).sum()),
            'cycles_per_iter': {p: float(prof[:, k].sum() / its) for k, p in enumerate(PHASES)},
