@@ -27,17 +27,29 @@ import torch
 FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X datasheet FP64 matrix (MFMA f64) peak
 
 
+def measured_traffic(n_agents):
+    """HBM bytes per launch of ipm_solve_kernel from the committed PMC passes
+    (profiles/r01_pmc_hbm.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of this
+    bench at 1024 agents); None for other batch sizes."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm.json')
+    if n_agents != 1024 or not os.path.exists(path):
+        return None
+    return json.load(open(path))['hbm_bytes_per_launch']
+
+
 def cpu_baseline(tpl, P, opts, n_sample):
     """Oracle CPU port (single host thread) on a bounded sample of the same workload."""
     from oracle import port_binding
     port_binding.load()
+    B = P['p'].shape[0]
+    idx = np.arange(n_sample) % B
     t0 = time.perf_counter()
-    res = port_binding.solve(tpl, P['p'][:n_sample], P['x0'][:n_sample], **opts)
+    res = port_binding.solve(tpl, P['p'][idx], P['x0'][idx], **opts)
     dt = time.perf_counter() - t0
     ok = int((res['status'] == 0).sum())
     return {'value': ok / dt, 'unit': 'solves/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d agents of the same batch, cold solve, 1 thread (%.1f s; host has %d cores)'
-                      % (n_sample, dt, os.cpu_count()),
+            'sample': '%d agent-solves of the same batch (cold solve, same tolerance), 1 host thread, '
+                      '%.1f s; host has %d cores' % (n_sample, dt, os.cpu_count()),
             'mean_iters': float(res['iters'].mean())}
 
 
@@ -48,7 +60,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--agents', type=int, default=1024, help='agents per GPU')
     ap.add_argument('--tol', type=float, default=1e-3)
-    ap.add_argument('--cpu-sample', type=int, default=512)
+    ap.add_argument('--cpu-sample', type=int, default=2048,
+                    help='agent-solves timed on one host thread (the batch is repeated as needed)')
     ap.add_argument('--no-cpu', action='store_true')
     args = ap.parse_args()
 
@@ -140,12 +153,12 @@ def main():
         'lds_bytes_per_agent': solver.lds_bytes,
         'roofline': {'bound': 'mfma', 'kernel': 'ipm_solve_kernel', 'achieved': achieved,
                      'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
+                     'frac': achieved / FP64_MATRIX_PEAK_TFLOPS, 'traffic': measured_traffic(B),
                      'kernel_ms': k_ms,
                      'note': 'algorithmic flops = sum(iters) x (n^3/3+2n^2), n=n_var (SURVEY 8d)'},
     }
     if not args.no_cpu and world == 1:
-        out['cpu_baseline'] = cpu_baseline(tpl, P, opts, min(args.cpu_sample, B))
+        out['cpu_baseline'] = cpu_baseline(tpl, P, opts, args.cpu_sample)
     print(json.dumps(out))
 
 
