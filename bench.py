@@ -68,6 +68,7 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
@@ -121,15 +122,8 @@ def main():
     torch.cuda.synchronize()
     n_ok = int((status == 0).sum().item())
     it_sum = int(iters.sum().item())
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        cc = torch.tensor([n_ok], dtype=torch.float64, device=dev)
-        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
-        n_ok_all = int(cc.item())
-    else:
-        n_ok_all = n_ok
+    from omgtools.distributed import reduce_report
+    elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist if world > 1 else None)
     if rank != 0:
         return
     value = n_ok_all * args.steps / elapsed

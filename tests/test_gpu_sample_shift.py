@@ -1,0 +1,69 @@
+"""sample_kernel / shift_kernel against the oracle (numpy spline algebra pinned to
+the reference in tests/test_golden_splines.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _solver(cfg2_small):
+    from omgtools.backend import BatchSolver
+    problem, P = cfg2_small
+    return problem, P, BatchSolver(problem.father.template, 8)
+
+
+def test_sample_matches_numpy(cfg2_small):
+    from omgtools.splines import BSpline
+    problem, P, solver = _solver(cfg2_small)
+    tpl = problem.father.template
+    veh = problem.vehicles[0]
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(8, tpl.n_var))
+    lo, hi = tpl.entry_range(veh.label, 'splines_seg0', 'var')
+    L = len(veh.basis)
+    T = 10.0
+    knots = veh.basis.knots * T                        # real-time axis as in Vehicle.store
+    t0 = rng.uniform(0., 0.9, size=8)
+    n_samp, dt = 1001, 0.009
+    out = solver.sample(x, lo, 2, veh.degree, knots, 3, t0, dt, n_samp)
+    assert out.shape == (8, 3, 2, n_samp)
+    for b in range(8):
+        tau = t0[b] + dt * np.arange(n_samp)
+        for k in range(2):
+            s = BSpline(veh.basis.scale(T), x[b, lo + k * L: lo + (k + 1) * L])
+            for o in range(3):
+                ref = s.derivative(o)(tau)
+                assert np.abs(out[b, o, k] - ref).max() <= 1e-10 * (1 + np.abs(ref).max())
+    out32 = solver.sample(x, lo, 2, veh.degree, knots, 3, t0, dt, n_samp, as_f32=True)
+    assert out32.dtype == np.float32 and np.abs(out32 - out).max() <= 1e-5 * (1 + np.abs(out).max())
+    # end point convention: tau == last knot is inside the last span
+    t_end = np.full(8, T)
+    end = solver.sample(x, lo, 2, veh.degree, knots, 1, t_end, 0.0, 1)
+    assert np.abs(end[:, 0, :, 0] - x[:, [lo + L - 1, lo + 2 * L - 1]]).max() < 1e-12
+    solver.close()
+
+
+def test_shift_matches_matrix(cfg2_small):
+    from omgtools.splines import shiftoverknot_T, BSplineBasis
+    problem, P, solver = _solver(cfg2_small)
+    tpl = problem.father.template
+    father = problem.father
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=(8, tpl.n_var))
+    mask = np.array([1, 0, 1, 1, 0, 0, 1, 0], dtype=np.uint8)
+    entries, tmats, off = [], [], 0
+    want = x.copy()
+    for label, name, spl in father.shifted_entries():
+        lo, rows, cols = tpl.var_layout[(label, name)]
+        Tm = shiftoverknot_T(spl['basis'])
+        entries.append([lo, rows, cols, off])
+        tmats.append(Tm.reshape(-1))
+        off += Tm.size
+        for b in np.nonzero(mask)[0]:
+            blk = x[b, lo:lo + rows * cols].reshape((rows, cols), order='F')
+            want[b, lo:lo + rows * cols] = (Tm @ blk).reshape(-1, order='F')
+    assert len(entries) == 7                      # splines_seg0 + (a, b) x 3 obstacles; g* are not shifted
+    got = x.copy()
+    solver.shift(got, mask, np.array(entries), np.concatenate(tmats))
+    assert np.abs(got - want).max() < 1e-13
+    solver.close()
