@@ -136,6 +136,38 @@ int  omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off,
                        int32_t n_der, const double* t0, double dt, int32_t n_samp,
                        void* out, int32_t as_f32, int32_t flags);
 
+/* Same shift on any device-resident row-major array (stride doubles per row, n_rows rows):
+ * used for the ADMM consensus state on a knot crossing (`problems/admm.py:477-491`). */
+int  omgx_shift_rows(omgx_batch* b, double* data, int32_t stride, int32_t n_rows, const uint8_t* mask,
+                     const int32_t* entries, int32_t n_ent, const double* Tmats, int32_t n_tmat);
+
+/* ---- Formation ADMM (reference `problems/admm.py`, `problems/formation.py`) -------------
+ * Layout of one agent's consensus data inside x [B,n_var] and p [B,n_par]; shared vector
+ * x_i = fleet-centre coefficients, axis-major, ns = n_dim*L doubles. */
+typedef struct omgx_admm_layout {
+  int32_t n_dim, L, n_nghb;
+  int32_t x_spl;                    /* offset of splines_seg0 in x */
+  int32_t p_rel;                    /* rel_pos_c in p */
+  int32_t p_zi, p_zji, p_li, p_lji; /* z_i, z_ji, l_i, l_ji in p (`admm.py:68-72`) */
+} omgx_admm_layout;
+
+/* x_i[b] = splines_seg0[b] + rel_pos_c[b]   (`vehicles/vehicle.py:234-240`); x_i [B, ns]. */
+int  omgx_admm_center(omgx_batch* b, const omgx_admm_layout* lay, const double* x, const double* p,
+                      double* x_i);
+/* z-update (closed-form equality QP, `admm.py:117-168, 407-445`), lambda update (`447-466`) and
+ * residuals (`493-508`) of every local agent.  x_ext [B+halo, ns]: local agents first, then halo
+ * rows; nbr [B, n_nghb] indexes x_ext.  M, F: (n_all x n_all) row-major, n_all = (1+n_nghb)*ns
+ * (z_all = M (x_all + l_all/rho); F = forward knot transform).  z_i/l_i are read from and written
+ * to p; z_ij, l_ij [B, n_nghb, ns] are updated in place; res [B,3] = per-agent (pr, dr, cr). */
+int  omgx_admm_update(omgx_batch* b, const omgx_admm_layout* lay, const double* x_ext,
+                      const int32_t* nbr, const double* M, const double* F, double rho,
+                      double* p, double* z_ij, double* l_ij, double* res);
+/* neighbour exchange (`admm.py:468-475`): z_ji[b,k] = z_ij_ext[nbr[b,k], slot[b,k]] (same for l),
+ * written into p.  z_ij_ext / l_ij_ext [B+halo, n_nghb, ns]. */
+int  omgx_admm_communicate(omgx_batch* b, const omgx_admm_layout* lay, const int32_t* nbr,
+                           const int32_t* slot, const double* z_ij_ext, const double* l_ij_ext,
+                           double* p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,6 +149,86 @@ shift_kernel(double* __restrict__ x, int x_stride, const uint8_t* __restrict__ m
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Formation ADMM kernels (all pointers are device pointers; tiny, memory-bound)
+// ---------------------------------------------------------------------------
+__global__ void admm_center_kernel(omgx_admm_layout lay, const double* __restrict__ x, int n_var,
+                                   const double* __restrict__ p, int n_par, double* __restrict__ x_i, int B) {
+  const int ns = lay.n_dim * lay.L;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * ns) return;
+  const int b = i / ns, q = i - b * ns, k = q / lay.L;
+  x_i[i] = x[(size_t)b * n_var + lay.x_spl + q] + p[(size_t)b * n_par + lay.p_rel + k];
+}
+
+// one block per agent; thread r owns row r of the stacked vectors (n_all <= blockDim)
+__global__ void __launch_bounds__(256)
+admm_update_kernel(omgx_admm_layout lay, const double* __restrict__ x_ext, const int32_t* __restrict__ nbr,
+                   const double* __restrict__ M, const double* __restrict__ F, double rho,
+                   double* __restrict__ p, int n_par, double* __restrict__ z_ij, double* __restrict__ l_ij,
+                   double* __restrict__ res) {
+  extern __shared__ __align__(16) double lds[];
+  const int ns = lay.n_dim * lay.L, nn = lay.n_nghb, na = (1 + nn) * ns;
+  double* xa = lds; double* la = lds + na; double* zp = lds + 2 * na; double* va = lds + 3 * na;
+  double* d1 = lds + 4 * na; double* d2 = lds + 5 * na; double* red = lds + 6 * na;
+  const int b = blockIdx.x, r = threadIdx.x;
+  double* pb = p + (size_t)b * n_par;
+  if (r < na) {
+    const int blk = r / ns, q = r - blk * ns;
+    if (blk == 0) { xa[r] = x_ext[(size_t)b * ns + q]; la[r] = pb[lay.p_li + q]; zp[r] = pb[lay.p_zi + q]; }
+    else {
+      const int j = nbr[b * nn + blk - 1];
+      xa[r] = x_ext[(size_t)j * ns + q];
+      la[r] = l_ij[((size_t)b * nn + blk - 1) * ns + q];
+      zp[r] = z_ij[((size_t)b * nn + blk - 1) * ns + q];
+    }
+    va[r] = xa[r] + la[r] / rho;
+  }
+  __syncthreads();
+  double zr = 0.0, lr = 0.0;
+  if (r < na) {
+    const double* Mr = M + (size_t)r * na;
+    for (int c = 0; c < na; ++c) zr += Mr[c] * va[c];
+    lr = la[r] + rho * (xa[r] - zr);
+    d1[r] = xa[r] - zr; d2[r] = zr - zp[r];
+    const int blk = r / ns, q = r - blk * ns;
+    if (blk == 0) { pb[lay.p_zi + q] = zr; pb[lay.p_li + q] = lr; }
+    else { z_ij[((size_t)b * nn + blk - 1) * ns + q] = zr; l_ij[((size_t)b * nn + blk - 1) * ns + q] = lr; }
+  }
+  __syncthreads();
+  double pr = 0.0, dr = 0.0;
+  if (r < na) {
+    const double* Fr = F + (size_t)r * na;
+    double a1 = 0.0, a2 = 0.0;
+    for (int c = 0; c < na; ++c) { a1 += Fr[c] * d1[c]; a2 += Fr[c] * d2[c]; }
+    pr = a1 * a1; dr = a2 * a2;
+  }
+  // block sum of (pr, dr)
+  for (int off = 32; off > 0; off >>= 1) { pr += __shfl_down(pr, off, 64); dr += __shfl_down(dr, off, 64); }
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[2 * wave] = pr; red[2 * wave + 1] = dr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double P = 0.0, D = 0.0;
+    for (int w = 0; w < nw; ++w) { P += red[2 * w]; D += red[2 * w + 1]; }
+    D *= rho;
+    res[3 * b] = P; res[3 * b + 1] = D; res[3 * b + 2] = rho * P + D;
+  }
+}
+
+__global__ void admm_comm_kernel(omgx_admm_layout lay, const int32_t* __restrict__ nbr,
+                                 const int32_t* __restrict__ slot, const double* __restrict__ z_ext,
+                                 const double* __restrict__ l_ext, double* __restrict__ p, int n_par, int B) {
+  const int ns = lay.n_dim * lay.L, nn = lay.n_nghb;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nn * ns) return;
+  const int b = i / (nn * ns), rem = i - b * nn * ns, k = rem / ns, q = rem - k * ns;
+  const size_t src = ((size_t)nbr[b * nn + k] * nn + slot[b * nn + k]) * ns + q;
+  p[(size_t)b * n_par + lay.p_zji + k * ns + q] = z_ext[src];
+  p[(size_t)b * n_par + lay.p_lji + k * ns + q] = l_ext[src];
+}
+
 // ---------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------
@@ -444,6 +524,65 @@ int omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off, int32_t
   }
   HIPCHK(hipStreamSynchronize(b->stream));
   (void)hipFree(d_kn);
+  return OMGX_OK;
+}
+
+int omgx_admm_center(omgx_batch* b, const omgx_admm_layout* lay, const double* x, const double* p, double* x_i) {
+  if (!b || !lay || !x || !p || !x_i) { g_err = "null argument"; return OMGX_E_INVALID; }
+  HIPCHK(hipSetDevice(b->device));
+  const int n = b->n_agents * lay->n_dim * lay->L;
+  hipLaunchKernelGGL(admm_center_kernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, *lay, x, b->dims.n_var,
+                     p, b->dims.n_par, x_i, b->n_agents);
+  HIPCHK(hipGetLastError());
+  return OMGX_OK;
+}
+
+int omgx_admm_update(omgx_batch* b, const omgx_admm_layout* lay, const double* x_ext, const int32_t* nbr,
+                     const double* M, const double* F, double rho, double* p, double* z_ij, double* l_ij,
+                     double* res) {
+  if (!b || !lay || !x_ext || !nbr || !M || !F || !p || !z_ij || !l_ij || !res || !(rho > 0)) {
+    g_err = "bad argument"; return OMGX_E_INVALID;
+  }
+  const int na = (1 + lay->n_nghb) * lay->n_dim * lay->L;
+  if (na > 256) { g_err = "stacked consensus vector longer than 256"; return OMGX_E_TOOLARGE; }
+  HIPCHK(hipSetDevice(b->device));
+  hipLaunchKernelGGL(admm_update_kernel, dim3(b->n_agents), dim3(256), (6 * na + 16) * sizeof(double), b->stream,
+                     *lay, x_ext, nbr, M, F, rho, p, b->dims.n_par, z_ij, l_ij, res);
+  HIPCHK(hipGetLastError());
+  return OMGX_OK;
+}
+
+int omgx_admm_communicate(omgx_batch* b, const omgx_admm_layout* lay, const int32_t* nbr, const int32_t* slot,
+                          const double* z_ij_ext, const double* l_ij_ext, double* p) {
+  if (!b || !lay || !nbr || !slot || !z_ij_ext || !l_ij_ext || !p) { g_err = "null argument"; return OMGX_E_INVALID; }
+  HIPCHK(hipSetDevice(b->device));
+  const int n = b->n_agents * lay->n_nghb * lay->n_dim * lay->L;
+  hipLaunchKernelGGL(admm_comm_kernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, *lay, nbr, slot, z_ij_ext,
+                     l_ij_ext, p, b->dims.n_par, b->n_agents);
+  HIPCHK(hipGetLastError());
+  return OMGX_OK;
+}
+
+int omgx_shift_rows(omgx_batch* b, double* data, int32_t stride, int32_t n_rows, const uint8_t* mask,
+                    const int32_t* entries, int32_t n_ent, const double* Tmats, int32_t n_tmat) {
+  // device-pointer variant of omgx_batch_shift for arbitrary row-major arrays (p, z_ij, l_ij ...)
+  if (!b || !data || !entries || !Tmats || n_ent <= 0 || n_rows <= 0) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  HIPCHK(hipSetDevice(b->device));
+  int32_t* d_ent = nullptr; double* d_T = nullptr;
+  int max_elems = 0;
+  for (int e = 0; e < n_ent; ++e) {
+    const int sz = entries[4 * e + 1] * entries[4 * e + 2];
+    if (sz > max_elems) max_elems = sz;
+  }
+  HIPCHK(hipMalloc((void**)&d_ent, 4 * n_ent * sizeof(int32_t)));
+  HIPCHK(hipMalloc((void**)&d_T, n_tmat * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(d_ent, entries, 4 * n_ent * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(d_T, Tmats, n_tmat * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  hipLaunchKernelGGL(shift_kernel, dim3(n_rows), dim3(64), max_elems * sizeof(double), b->stream, data, stride,
+                     mask, d_ent, n_ent, d_T);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(b->stream));
+  (void)hipFree(d_ent); (void)hipFree(d_T);
   return OMGX_OK;
 }
 

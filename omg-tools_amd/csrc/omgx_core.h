@@ -822,12 +822,12 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         Rr[tri(d.n_root + k, d.n_root + k)] = -OMGX_DELTA_C;
       }
       // Lagrangian Hessian: terms with >= 2 variables, weight = multiplier * signed scale
-      OMGX_PFOR(tt, T.row_ptr[m]) {
+      OMGX_PFOR(tt, T.row_ptr[m + 1]) {                       // row m = objective (weight 1)
         const int32_t* tv = T.t_var + 3 * tt;
         if (tv[1] < 0) continue;
         const int r = T.t_row[tt];
-        if (w.rtype[r] == ROW_FREE) continue;
-        const double lam = w.z[r] * w.rho[r];
+        if (r < m && w.rtype[r] == ROW_FREE) continue;
+        const double lam = (r < m) ? w.z[r] * w.rho[r] : 1.0;
         if (lam == 0.0) continue;
         const double cf = lam * term_coef(T, w, tt);
         const int32_t* ha = T.h_addr + 3 * tt;

@@ -101,7 +101,7 @@ struct HostPlan {
         const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
         for (int k = 0; k < 3; ++k) {
           const int va = tv[pr[k][0]], vb = tv[pr[k][1]];
-          if (r == m || va < 0 || vb < 0) continue;
+          if (va < 0 || vb < 0) continue;
           const int pa = pos[va], pb = pos[vb];
           const int32_t ad = pa >= pb ? addr(pa, pb) : addr(pb, pa);
           if (ad < 0) return false;

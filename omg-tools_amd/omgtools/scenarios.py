@@ -62,3 +62,48 @@ def holonomic_p2p(n_agents, knot_intervals=11, n_obs=3, seed=20240807 + 2,
         x0[b, lo:hi] = np.c_[np.linspace(start[0], goal[0], L),
                              np.linspace(start[1], goal[1], L)].reshape(-1, order='F')
     return problem, {'p': p, 'x0': x0}
+
+
+def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0, horizon_time=10.,
+                        with_obstacles=True):
+    """Config 4: `n_agents` Holonomic vehicles keeping a regular-polygon formation
+    (circular interconnection), shape of `examples/formation_holonomic.py:22-57`
+    scaled to the fleet size.  Returns (problem, updater, father,
+    layout, P) with P = {'p' [B,n_par], 'x0' [B,n_var], 'nbr' [B,2]}."""
+    from .shapes import Rectangle
+    from .formation import build_updx_template, FormationLayout, circular_neighbors
+    vehicle = Holonomic()
+    vehicle.define_knots(knot_intervals=knot_intervals)
+    vehicle.set_initial_conditions([0., 0.])
+    vehicle.set_terminal_conditions([1., 1.])
+    environment = Environment(room={'shape': Square(12.)})
+    if with_obstacles:
+        rect = Rectangle(width=3., height=0.2)
+        environment.add_obstacle(Obstacle({'position': [-2.6, -1.0]}, shape=rect))
+        environment.add_obstacle(Obstacle({'position': [2.6, -1.0]}, shape=rect))
+    problem, updater, father = build_updx_template(
+        vehicle, environment, 2, {'horizon_time': horizon_time})
+    tpl = father.template
+    lay = FormationLayout(tpl, vehicle, problem, updater, 2)
+    radius = max(0.2, 0.2 * n_agents / (2 * np.pi))
+    ang = 2 * np.pi * np.arange(n_agents) / n_agents
+    config = radius * np.c_[np.cos(ang), np.sin(ang)]          # position w.r.t. the fleet centre
+    start_c, goal_c = np.array([0., -3.5]), np.array([0., 3.0])
+    L = lay.L
+    p = np.zeros((n_agents, tpl.n_par))
+    x0 = np.zeros((n_agents, tpl.n_var))
+    for l, obs in enumerate(environment.obstacles):
+        chk, rad = obs.shape.get_checkpoints()
+        lo = tpl.entry_range(obs.label, 'x', 'par')[0]; p[:, lo:lo + 2] = obs.signals['position'][:, -1]
+        lo = tpl.entry_range(obs.label, 'checkpoints', 'par')[0]; p[:, lo:lo + 2 * len(chk)] = np.reshape(chk, -1)
+        lo = tpl.entry_range(obs.label, 'rad', 'par')[0]; p[:, lo:lo + len(rad)] = rad
+    for b in range(n_agents):
+        start, goal = start_c + config[b], goal_c + config[b]
+        p[b, lay.p_rel:lay.p_rel + 2] = -config[b]                 # rel_pos_c = -configuration (fleet.py:93-98)
+        p[b, lay.p_state0:lay.p_state0 + 2] = start
+        p[b, lay.p_poseT:lay.p_poseT + 2] = goal
+        p[b, lay.p_T] = horizon_time
+        p[b, lay.p_rho] = rho
+        x0[b, lay.x_spl:lay.x_spl + 2 * L] = np.c_[np.linspace(start[0], goal[0], L),
+                                                   np.linspace(start[1], goal[1], L)].reshape(-1, order='F')
+    return problem, updater, father, lay, {'p': p, 'x0': x0, 'nbr': circular_neighbors(n_agents)}

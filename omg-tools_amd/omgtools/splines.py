@@ -383,7 +383,42 @@ def shiftfirstknot_T(basis, t_shift, inverse=False):
     return T
 
 
+def shiftfirstknot_block(basis, t_shift):
+    """Leading (d+1)x(d+1) block of `shiftfirstknot_T` for numeric OR polynomial
+    (`Poly`, e.g. t/T) t_shift, by the de Boor triangle at u = t_shift on the first
+    span: new coefficient i = d_d^{[d-i]}(t_shift), each entry a polynomial in
+    t_shift (denominators are knot differences only).  Reference: the `_t` matrix
+    chain of `spline_extra.py:220-255`."""
+    k, d = basis.knots, basis.degree
+    # rows[j] = coefficient vector (over c_0..c_d) of d_j^{[r]}
+    one = Poly.const(1.0) if isinstance(t_shift, Poly) else 1.0
+    zero = one * 0.0
+    rows = [[one if a == j else zero for a in range(d + 1)] for j in range(d + 1)]
+    out = [None] * (d + 1)
+    out[d] = rows[d]
+    for r in range(1, d + 1):
+        new = [None] * (d + 1)
+        for j in range(r, d + 1):
+            den = k[j + d - r + 1] - k[j]
+            alpha = (t_shift - k[j]) * (1.0 / den)
+            new[j] = [(one - alpha) * rows[j - 1][a] + alpha * rows[j][a] for a in range(d + 1)]
+        rows = new
+        out[d - r] = rows[d]
+    return out
+
+
 def shift_knot1_fwd(cfs, basis, t_shift):
+    if isinstance(t_shift, Poly):
+        d = basis.degree
+        blk = shiftfirstknot_block(basis, t_shift)
+        cfs = np.asarray(cfs, dtype=object)
+        out = cfs.copy()
+        for i in range(d + 1):
+            acc = Poly()
+            for a in range(d + 1):
+                acc = acc + blk[i][a] * cfs[a]
+            out[i] = acc
+        return out
     return matvec(shiftfirstknot_T(basis, t_shift), cfs)
 
 

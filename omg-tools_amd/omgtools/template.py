@@ -253,6 +253,12 @@ class SolverPlan(object):
             for t in range(tpl.row_ptr[r], tpl.row_ptr[r + 1]):
                 vs.update(int(v) for v in tpl.t_var[t] if v >= 0)
             rows_vars.append(vs)
+        # nonlinear objective terms couple their variables exactly like a constraint row
+        obj_couplings = []
+        for t in range(tpl.row_ptr[m], tpl.row_ptr[m + 1]):
+            vs = set(int(v) for v in tpl.t_var[t] if v >= 0)
+            if len(vs) > 1:
+                obj_couplings.append(vs)
         eq = np.isfinite(tpl.lb) & (tpl.lb == tpl.ub)
         self.eq_rows = np.nonzero(eq)[0].astype(np.int32)
         self.n_eq = len(self.eq_rows)
@@ -273,7 +279,7 @@ class SolverPlan(object):
                 parent[a] = parent[parent[a]]
                 a = parent[a]
             return a
-        for vs in rows_vars:
+        for vs in rows_vars + obj_couplings:
             rest = [v for v in vs if v not in root]
             for a, b in zip(rest[:-1], rest[1:]):
                 parent[find(a)] = find(b)
@@ -324,6 +330,9 @@ class SolverPlan(object):
                     if v >= 0:
                         t_jidx[t, k] = base + local[v]
             jr_ptr.append(len(jr_pos))
+        for vs in obj_couplings:
+            if len(set(int(leaf_of[v]) for v in vs if leaf_of[v] >= 0)) > 1:
+                raise ValueError('objective couples two leaves; partition invalid')
         self.jr_ptr = np.array(jr_ptr, dtype=np.int32)
         self.jr_pos = np.array(jr_pos, dtype=np.int32)
         self.t_jidx = t_jidx

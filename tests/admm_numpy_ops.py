@@ -1,0 +1,79 @@
+"""Test infrastructure: numpy `ops` backend for omgtools.admm.BatchADMM (same
+interface as HipAdmmOps) used by the CPU distributed test; x-update by the oracle
+CPU port."""
+import numpy as np
+
+
+class NumpyAdmmOps(object):
+    def __init__(self, template, layout, p, x0, tol=1e-6):
+        from oracle import port_binding
+        self.port, self.tpl, self.tol = port_binding, template, tol
+        self.p, self.x = np.array(p, float), np.array(x0, float)
+        self.B, self.ns, self.nn = self.p.shape[0], layout.ns, layout.n_nghb
+        self.z_ij = np.zeros((self.B, self.nn, self.ns))
+        self.l_ij = np.zeros((self.B, self.nn, self.ns))
+
+    def init_consensus(self, lay):
+        x_i = self.center(lay)
+        self.p[:, lay.p_zi:lay.p_zi + self.ns] = x_i
+        self.p[:, lay.p_li:lay.p_li + self.ns] = 0.
+        self.p[:, lay.p_zji:lay.p_zji + self.nn * self.ns] = np.tile(x_i, (1, self.nn))
+        self.p[:, lay.p_lji:lay.p_lji + self.nn * self.ns] = 0.
+
+    def set_time(self, lay, t_rel, rho):
+        self.p[:, lay.p_t] = t_rel
+        self.p[:, lay.p_rho] = rho
+
+    def solve(self):
+        r = self.port.solve(self.tpl, self.p, self.x, tol=self.tol, max_iter=200)
+        self.x = r['x']
+        return r['status']
+
+    def center(self, lay):
+        c = self.x[:, lay.x_spl:lay.x_spl + self.ns].reshape(self.B, lay.n_dim, lay.L)
+        return (c + self.p[:, lay.p_rel:lay.p_rel + lay.n_dim][:, :, None]).reshape(self.B, self.ns)
+
+    def update(self, lay, x_ext, nbr, M, F, rho):
+        ns, nn, p = self.ns, self.nn, self.p
+        x_all = np.concatenate([x_ext[:self.B, None, :], x_ext[nbr]], axis=1).reshape(self.B, -1)
+        l_all = np.concatenate([p[:, None, lay.p_li:lay.p_li + ns], self.l_ij], axis=1).reshape(self.B, -1)
+        z_prev = np.concatenate([p[:, None, lay.p_zi:lay.p_zi + ns], self.z_ij], axis=1).reshape(self.B, -1)
+        z_all = (x_all + l_all / rho) @ M.T
+        l_all = l_all + rho * (x_all - z_all)
+        pr = (((x_all - z_all) @ F.T) ** 2).sum(axis=1)
+        dr = rho * (((z_all - z_prev) @ F.T) ** 2).sum(axis=1)
+        z_all, l_all = z_all.reshape(self.B, 1 + nn, ns), l_all.reshape(self.B, 1 + nn, ns)
+        p[:, lay.p_zi:lay.p_zi + ns], p[:, lay.p_li:lay.p_li + ns] = z_all[:, 0], l_all[:, 0]
+        self.z_ij, self.l_ij = z_all[:, 1:].copy(), l_all[:, 1:].copy()
+        return np.stack([pr, dr, rho * pr + dr], axis=1)
+
+    def z_ij_flat(self):
+        return self.z_ij.reshape(self.B, -1)
+
+    def l_ij_flat(self):
+        return self.l_ij.reshape(self.B, -1)
+
+    def communicate(self, lay, nbr, slot, z_ext, l_ext):
+        ns, nn = self.ns, self.nn
+        z_ext, l_ext = z_ext.reshape(-1, nn, ns), l_ext.reshape(-1, nn, ns)
+        for k in range(nn):
+            self.p[:, lay.p_zji + k * ns:lay.p_zji + (k + 1) * ns] = z_ext[nbr[:, k], slot[:, k]]
+            self.p[:, lay.p_lji + k * ns:lay.p_lji + (k + 1) * ns] = l_ext[nbr[:, k], slot[:, k]]
+
+    def exchange(self, local, halo, dist):
+        import torch
+        w = local.shape[1]
+        send = torch.zeros((halo.max_pub, w), dtype=torch.float64)
+        if len(halo.publish_local):
+            send[:len(halo.publish_local)] = torch.from_numpy(local[halo.publish_local])
+        gathered = [torch.empty_like(send) for _ in range(halo.world)]
+        dist.all_gather(gathered, send)
+        allp = torch.stack(gathered).numpy()
+        return np.concatenate([local, allp[halo.src[:, 0], halo.src[:, 1]]], axis=0)
+
+    def reduce_residuals(self, res, dist):
+        import torch
+        sums = torch.from_numpy(res.sum(axis=0))
+        if dist is not None:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        return sums.numpy()

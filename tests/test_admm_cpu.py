@@ -1,0 +1,125 @@
+"""Formation ADMM on the CPU: closed-form z-update against the reference's
+formulas and against a least-squares solution of the same equality QP (K10), the
+BatchADMM driver against the monolithic oracle iteration, and world_size-2 gloo
+sharding with halo exchange against the single-process run."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scenario(n, perturb=True):
+    from omgtools.scenarios import formation_holonomic
+    problem, updater, father, lay, P = formation_holonomic(n, with_obstacles=False)
+    if perturb:                                  # break the formation so that consensus has work to do
+        rng = np.random.default_rng(7)
+        d = rng.normal(scale=0.15, size=(n, 2))
+        P['p'][:, lay.p_state0:lay.p_state0 + 2] += d
+        L = lay.L
+        for b in range(n):
+            s = P['p'][b, lay.p_state0:lay.p_state0 + 2]
+            g = P['p'][b, lay.p_poseT:lay.p_poseT + 2]
+            P['x0'][b, lay.x_spl:lay.x_spl + 2 * L] = np.c_[np.linspace(s[0], g[0], L),
+                                                            np.linspace(s[1], g[1], L)].reshape(-1, order='F')
+    return father.template, lay, P
+
+
+def test_zupdate_closed_form_is_the_qp_solution():
+    from omgtools.formation import zupdate_matrices, coupling_matrix
+    from omgtools.splines import BSplineBasis
+    K, d, nd, nn = 10, 3, 2, 2
+    basis = BSplineBasis(np.r_[np.zeros(d), np.linspace(0, 1, K + 1), np.ones(d)], d)
+    L = len(basis)
+    rng = np.random.default_rng(0)
+    x, l, rho, t0 = rng.normal(size=78), rng.normal(size=78), 1.7, 0.04
+    M, F = zupdate_matrices(basis, nd, nn, t0)
+    z = M @ (x + l / rho)
+    A = coupling_matrix(L, nd, d, nn, [basis.derivative(o)[1][-1, :] for o in range(1, d + 1)])
+    assert A.shape == (58, 78)
+    zt = F @ z
+    assert np.abs(A @ zt).max() < 1e-10                       # feasible for the coupling constraints
+    # minimiser of  -l~'z~ + rho/2 |x~ - z~|^2  s.t. A z~ = 0: gradient is in the row space of A
+    grad = -(F @ l) - rho * (F @ x - zt)
+    coef = np.linalg.lstsq(A.T, grad, rcond=None)[0]
+    assert np.abs(A.T @ coef - grad).max() < 1e-9
+
+
+def test_driver_matches_oracle_iteration():
+    from omgtools.admm import BatchADMM
+    from omgtools.formation import reverse_slots, coupling_matrix
+    from oracle import admm_numpy, port_binding
+    from admm_numpy_ops import NumpyAdmmOps
+    tpl, lay, P = _scenario(5)
+    nbr = P['nbr']
+    ops = NumpyAdmmOps(tpl, lay, P['p'], P['x0'])
+    admm = BatchADMM(lay, nbr, ops, rho=1.0)
+    admm.initialize()
+    basis = lay.basis
+    A = coupling_matrix(lay.L, 2, 3, 2, [basis.derivative(o)[1][-1, :] for o in range(1, 4)])
+    st = admm_numpy.init_state(P['x0'], P['p'], lay, nbr)
+    slot = reverse_slots(nbr)
+
+    def solve_x(p, x):
+        r = port_binding.solve(tpl, p, x, tol=1e-6, max_iter=200)
+        return r['x'], r['status']
+    for it in range(3):
+        status, (pr, dr, cr) = admm.iterate(0.0)
+        st, (pr2, dr2, cr2), _ = admm_numpy.admm_iteration(st, lay, nbr, slot, 1.0, 0.0, A, solve_x)
+        assert np.all(status == 0)
+        assert abs(pr - np.sqrt(pr2)) < 1e-8 and abs(dr - np.sqrt(dr2)) < 1e-8
+        assert np.abs(ops.x - st['x']).max() < 1e-8
+        assert np.abs(ops.z_ij - st['z_ij']).max() < 1e-9
+    assert admm.residuals[-1][0] < admm.residuals[0][0]       # consensus is being reached
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from omgtools.admm import BatchADMM
+    from omgtools.distributed import shard_range, gather_solutions
+    from admm_numpy_ops import NumpyAdmmOps
+    tpl, lay, P = _scenario(6)
+    lo, hi = shard_range(6, rank, world)
+    ops = NumpyAdmmOps(tpl, lay, P['p'][lo:hi], P['x0'][lo:hi])
+    admm = BatchADMM(lay, P['nbr'], ops, rank=rank, world=world, dist=dist, rho=1.0)
+    admm.initialize()
+    for _ in range(3):
+        admm.iterate(0.0)
+    x_all = gather_solutions(ops.x, 6, dist=dist)
+    if rank == 0:
+        q.put((admm.residuals, x_all))
+    dist.destroy_process_group()
+
+
+def test_two_rank_halo_exchange_matches_single_process():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from omgtools.admm import BatchADMM, HaloPlan
+    from admm_numpy_ops import NumpyAdmmOps
+    tpl, lay, P = _scenario(6)
+    halo = HaloPlan(P['nbr'], 1, 2)
+    assert (halo.lo, halo.hi) == (3, 6) and halo.needed == [0, 2]
+    ops = NumpyAdmmOps(tpl, lay, P['p'], P['x0'])
+    ref = BatchADMM(lay, P['nbr'], ops, rho=1.0)
+    ref.initialize()
+    for _ in range(3):
+        ref.iterate(0.0)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    residuals, x_all = q.get(timeout=240)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert np.allclose(np.array(residuals), np.array(ref.residuals), rtol=1e-9, atol=1e-12)
+    assert np.abs(x_all - ops.x).max() < 1e-9
