@@ -53,6 +53,50 @@ def cpu_baseline(tpl, P, opts, n_sample):
             'mean_iters': float(res['iters'].mean())}
 
 
+def bench_formation(args, rank, local_rank, world, dist, dev):
+    """configs[3]: FormationPoint2point ADMM, 512 Holonomic agents (fixed total: strong
+    scaling), one step = one full ADMM iteration (x-update + exchanges + z/l/residuals)."""
+    from omgtools.scenarios import formation_holonomic
+    from omgtools.backend import BatchSolver
+    from omgtools.admm import BatchADMM, HipAdmmOps
+    from omgtools.distributed import shard_range, reduce_report
+    N = 512 if args.agents == 1024 else args.agents
+    problem, updater, father, lay, P = formation_holonomic(N)
+    tpl = father.template
+    lo, hi = shard_range(N, rank, world)
+    solver = BatchSolver(tpl, hi - lo, device=local_rank, options=dict(tol=args.tol, max_iter=300))
+    ops = HipAdmmOps(solver, tpl, lay, P['p'][lo:hi], P['x0'][lo:hi], dev)
+    admm = BatchADMM(lay, P['nbr'], ops, rank=rank, world=world, dist=dist if world > 1 else None, rho=1.0)
+    admm.initialize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        admm.iterate(0.0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        status, res = admm.iterate(0.0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_ok = int((status == 0).sum().item())
+    elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist if world > 1 else None)
+    if rank != 0:
+        return
+    print(json.dumps({
+        'metric': 'ADMM agent-updates/sec, 512-agent Holonomic FormationPoint2point', 'value': n_ok_all * args.steps / elapsed,
+        'unit': 'agent-updates/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'configs[3]: FormationPoint2point ADMM, %d Holonomic agents, circular '
+                               'interconnection, knot_intervals=10, 2 rectangular obstacles, rho=1, tol=%g'
+                               % (N, args.tol), 'agents_total': N, 'n_var': tpl.n_var, 'n_con': tpl.n_con,
+                   'parallelism': 'agents sharded contiguously; halo all_gather + residual all_reduce per iteration'},
+        'solved_fraction': n_ok_all / float(N), 'residuals': list(res)}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -63,6 +107,8 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=2048,
                     help='agent-solves timed on one host thread (the batch is repeated as needed)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--workload', choices=['p2p', 'formation'], default='p2p',
+                    help="p2p = BASELINE.json configs[1] (headline); formation = configs[3], 512-agent ADMM")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -75,6 +121,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
+    if args.workload == 'formation':
+        return bench_formation(args, rank, local_rank, world, dist, dev)
     from omgtools.scenarios import holonomic_p2p
     from omgtools.backend import BatchSolver
     import omgtools.backend as be

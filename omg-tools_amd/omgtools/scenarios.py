@@ -76,7 +76,8 @@ def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0,
     vehicle.define_knots(knot_intervals=knot_intervals)
     vehicle.set_initial_conditions([0., 0.])
     vehicle.set_terminal_conditions([1., 1.])
-    environment = Environment(room={'shape': Square(12.)})
+    radius = max(0.2, 0.2 * n_agents / (2 * np.pi))
+    environment = Environment(room={'shape': Square(2. * radius + 12.)})
     if with_obstacles:
         rect = Rectangle(width=3., height=0.2)
         environment.add_obstacle(Obstacle({'position': [-2.6, -1.0]}, shape=rect))
@@ -85,7 +86,6 @@ def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0,
         vehicle, environment, 2, {'horizon_time': horizon_time})
     tpl = father.template
     lay = FormationLayout(tpl, vehicle, problem, updater, 2)
-    radius = max(0.2, 0.2 * n_agents / (2 * np.pi))
     ang = 2 * np.pi * np.arange(n_agents) / n_agents
     config = radius * np.c_[np.cos(ang), np.sin(ang)]          # position w.r.t. the fleet centre
     start_c, goal_c = np.array([0., -3.5]), np.array([0., 3.0])
