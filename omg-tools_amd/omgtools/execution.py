@@ -27,7 +27,7 @@ class Deployer(object):
 
     def _time_left(self, key):
         veh = self.problem.vehicles[0]
-        return float(getattr(veh, key)['time'][:, -1] - self.current_time)
+        return float(getattr(veh, key)['time'][0, -1] - self.current_time)
 
     def update(self, current_time, states=None, inputs=None, dinputs=None, update_time=None,
                enforce_states=False, enforce_inputs=False):
@@ -88,7 +88,7 @@ class Simulator(object):
         stop = False
         while not stop:
             stop = self.update()
-            simulated = float(self.problem.vehicles[0].signals['time'][:, -1] - self.current_time)
+            simulated = float(self.problem.vehicles[0].signals['time'][0, -1] - self.current_time)
             if (stop or self.update_time - simulated) > self.sample_time:
                 self.update_timing(max(0, simulated - self.sample_time))
             else:
@@ -99,7 +99,7 @@ class Simulator(object):
     def step(self, update_time=0.1):
         stop = self.update()
         if stop:
-            self.update_timing(float(self.problem.vehicles[0].signals['time'][:, -1] -
+            self.update_timing(float(self.problem.vehicles[0].signals['time'][0, -1] -
                                      self.current_time))
             self.problem.final()
         else:
@@ -136,7 +136,7 @@ class Simulator(object):
             return None
         self.problem.simulate(self.current_time, np.inf, self.sample_time)
         self.problem.final()
-        self.update_timing(float(self.problem.vehicles[0].signals['time'][:, -1] -
+        self.update_timing(float(self.problem.vehicles[0].signals['time'][0, -1] -
                                  self.current_time))
         if len(self.problem.vehicles) == 1:
             return self.problem.vehicles[0].trajectories
