@@ -3,10 +3,13 @@
 
 Workload (BASELINE.json configs[1]): 1024-agent Holonomic Point2point batch per
 GPU, degree-3 B-spline, knot_intervals=11, 3 circular obstacles, fp64; seeded
-synthetic scenarios (omgtools/scenarios.py).  One "step" = one
-batched cold solve of every agent from the reference's initial guess
-(`omgx_batch_solve` on inputs already resident in HBM), solver tolerance = the
-reference's default `ipopt.tol = 1e-3` (`problems/problem.py:57`).
+synthetic scenarios (omgtools/scenarios.py).  Protocol of SURVEY.md
+§8d: a cold solve of every agent from the reference's initial guess, then
+receding-horizon MPC steps (update_time 0.1 s, ideal prediction, warm start).  One
+timed "step" = one MPC step of the whole batch: prediction + horizon bookkeeping +
+`omgx_batch_solve`, everything resident in HBM.  Solver tolerance = the
+reference's default `ipopt.tol = 1e-3` (`problems/problem.py:57`).  The cold-solve
+rate is reported alongside (`cold_solve`).
 
 Launch: python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run)
 Prints ONE JSON line on rank 0.
@@ -37,20 +40,27 @@ def measured_traffic(n_agents):
     return json.load(open(path))['hbm_bytes_per_launch']
 
 
-def cpu_baseline(tpl, P, opts, n_sample):
-    """Oracle CPU port (single host thread) on a bounded sample of the same workload."""
-    from oracle import port_binding
-    port_binding.load()
-    B = P['p'].shape[0]
-    idx = np.arange(n_sample) % B
+def cpu_baseline(problem, P, opts, n_sample):
+    """Oracle CPU port (one host thread) on a bounded sample of the same workload and the
+    same protocol: cold solve, then warm-started receding-horizon steps (timed)."""
+    from omgtools.batch import BatchP2P
+    n_agents = min(64, P['p'].shape[0])
+    sub = {'p': P['p'][:n_agents], 'x0': P['x0'][:n_agents]}
+    mpc = BatchP2P(problem, sub, ops='numpy', options=opts)
+    mpc.solve_cold()
+    steps = max(1, n_sample // n_agents)
+    ok, its = 0, 0
     t0 = time.perf_counter()
-    res = port_binding.solve(tpl, P['p'][idx], P['x0'][idx], **opts)
+    for _ in range(steps):
+        mpc.step()
+        ok += int((mpc.status == 0).sum())
+        its += int(mpc.iters.sum())
     dt = time.perf_counter() - t0
-    ok = int((res['status'] == 0).sum())
     return {'value': ok / dt, 'unit': 'solves/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d agent-solves of the same batch (cold solve, same tolerance), 1 host thread, '
-                      '%.1f s; host has %d cores' % (n_sample, dt, os.cpu_count()),
-            'mean_iters': float(res['iters'].mean())}
+            'sample': '%d receding-horizon steps of the first %d agents of the same batch (same protocol '
+                      'and tolerance), 1 host thread, %.1f s; host has %d cores'
+                      % (steps, n_agents, dt, os.cpu_count()),
+            'mean_iters': its / float(steps * n_agents)}
 
 
 def bench_formation(args, rank, local_rank, world, dist, dev):
@@ -104,8 +114,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--agents', type=int, default=1024, help='agents per GPU')
     ap.add_argument('--tol', type=float, default=1e-3)
-    ap.add_argument('--cpu-sample', type=int, default=2048,
-                    help='agent-solves timed on one host thread (the batch is repeated as needed)')
+    ap.add_argument('--cpu-sample', type=int, default=12800,
+                    help='agent-solves timed on one host thread (64 agents x N receding-horizon steps)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--workload', choices=['p2p', 'formation'], default='p2p',
                     help="p2p = BASELINE.json configs[1] (headline); formation = configs[3], 512-agent ADMM")
@@ -124,61 +134,62 @@ def main():
     if args.workload == 'formation':
         return bench_formation(args, rank, local_rank, world, dist, dev)
     from omgtools.scenarios import holonomic_p2p
-    from omgtools.backend import BatchSolver
+    from omgtools.batch import BatchP2P
+    from omgtools.distributed import reduce_report
     import omgtools.backend as be
     B = args.agents
     saved = be.create_nlp
-    be.create_nlp = lambda tpl, opt, name='': (None, 0.)      # the batch solver below is the product path
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)      # BatchP2P below owns the product-path solver
     problem, P = holonomic_p2p(B, seed=20240807 + 2 + 1000 * rank)
     be.create_nlp = saved
     tpl = problem.father.template
     opts = dict(tol=args.tol, max_iter=300)
-    solver = BatchSolver(tpl, B, device=local_rank, options=opts)
-    solver.set_stream(torch.cuda.current_stream().cuda_stream)
-
-    d = lambda a, dt=torch.float64: torch.as_tensor(a, dtype=dt, device=dev).contiguous()
-    p, x0, lb, ub = d(P['p']), d(P['x0']), d(tpl.lb), d(tpl.ub)
-    x = torch.empty((B, tpl.n_var), dtype=torch.float64, device=dev)
-    lam = torch.empty((B, tpl.n_con), dtype=torch.float64, device=dev)
-    status = torch.empty(B, dtype=torch.int32, device=dev)
-    iters = torch.empty(B, dtype=torch.int32, device=dev)
-
-    def step():
-        solver.solve_device(p, x0, lb, ub, x, lam, status, iters, bounds_shared=True)
+    mpc = BatchP2P(problem, P, ops='hip', device=dev, options=opts)
+    solver = mpc.solver
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- cold solve from the reference's initial guess (reported, not the headline) ----------
+    x0_init, p_init = mpc.x.clone(), mpc.p.clone()
+    cold_ms = []
+    for _ in range(3):
+        mpc.x.copy_(x0_init)
+        mpc.p.copy_(p_init)
+        mpc.time = 0.0
+        mpc.solve_cold()
+        cold_ms.append(solver.last_kernel_ms())
+    cold_ok = int((mpc.status == 0).sum().item())
+    cold_iters = int(mpc.iters.sum().item())
+    # ---- receding-horizon steps: SURVEY.md 8d protocol (cold solve, then warm-started steps) ----
     for _ in range(args.warmup):
-        step()
+        mpc.step()
     barrier()
-    kernel_ms = []
     t0 = time.perf_counter()
+    n_ok_steps, it_sum, kernel_ms = 0, 0, []
     for _ in range(args.steps):
-        step()
-        if rank == 0 and world == 1:
-            pass
+        mpc.step()
     barrier()
     elapsed = time.perf_counter() - t0
-    # device time of the solve kernel (HIP events on the launch stream), re-measured
-    # over the same launches outside the wall-clock region
+    # per-step statistics re-measured outside the wall-clock region (device syncs)
     for _ in range(min(args.steps, 10)):
-        step()
+        mpc.step()
         kernel_ms.append(solver.last_kernel_ms())
-    torch.cuda.synchronize()
-    n_ok = int((status == 0).sum().item())
-    it_sum = int(iters.sum().item())
-    from omgtools.distributed import reduce_report
+        n_ok_steps += int((mpc.status == 0).sum().item())
+        it_sum += int(mpc.iters.sum().item())
+    n_meas = min(args.steps, 10)
+    n_ok = n_ok_steps / float(n_meas)
     elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist if world > 1 else None)
     if rank != 0:
         return
     value = n_ok_all * args.steps / elapsed
     k_ms = float(np.mean(kernel_ms))
     n = tpl.n_var
-    flops_per_iter = n ** 3 / 3.0 + 2.0 * n ** 2          # SURVEY.md §8d: dense-n LDL' + 2 solves
-    achieved = it_sum * flops_per_iter / (k_ms * 1e-3) / 1e12
+    flops_per_iter = n ** 3 / 3.0 + 2.0 * n ** 2          # SURVEY.md 8d: dense-n LDL' + 2 solves
+    achieved = (it_sum / n_meas) * flops_per_iter / (k_ms * 1e-3) / 1e12
+    cold_k = float(np.mean(cold_ms))
     out = {
         'metric': 'MPC solves/sec, 1024-agent Holonomic Point2point batch per GPU',
         'value': value, 'unit': 'solves/s', 'n_gpus': world, 'steps': args.steps,
@@ -186,12 +197,16 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'configs[1]: %d-agent Holonomic Point2point per GPU, degree 3, '
-                               'knot_intervals=11, 3 circular obstacles, cold solve, tol=%g'
-                               % (B, args.tol),
+                               'knot_intervals=11, 3 circular obstacles; one step = one receding-horizon '
+                               'MPC step of every agent (update_time 0.1 s, ideal prediction, primal-dual '
+                               'warm start) after a cold solve; tol=%g' % (B, args.tol),
                    'agents_per_gpu': B, 'n_var': tpl.n_var, 'n_con': tpl.n_con,
                    'parallelism': 'agents sharded across ranks, no collective on the solve path'},
         'p50_batch_latency_ms': float(np.median(kernel_ms)),
-        'solved_fraction': n_ok / float(B), 'mean_iters': it_sum / float(B),
+        'solved_fraction': n_ok / float(B), 'mean_iters': it_sum / float(n_meas * B),
+        'cold_solve': {'solves_per_s': cold_ok / (cold_k * 1e-3), 'kernel_ms': cold_k,
+                       'solved_fraction': cold_ok / float(B), 'mean_iters': cold_iters / float(B),
+                       'achieved_tflops': cold_iters * flops_per_iter / (cold_k * 1e-3) / 1e12},
         'lds_bytes_per_agent': solver.lds_bytes,
         'roofline': {'bound': 'mfma', 'kernel': 'ipm_solve_kernel', 'achieved': achieved,
                      'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -200,7 +215,7 @@ def main():
                      'note': 'algorithmic flops = sum(iters) x (n^3/3+2n^2), n=n_var (SURVEY 8d)'},
     }
     if not args.no_cpu and world == 1:
-        out['cpu_baseline'] = cpu_baseline(tpl, P, opts, args.cpu_sample)
+        out['cpu_baseline'] = cpu_baseline(problem, P, opts, args.cpu_sample)
     print(json.dumps(out))
 
 

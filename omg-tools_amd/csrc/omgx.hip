@@ -63,7 +63,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   const double* lbb = lb + (bounds_shared ? 0 : (size_t)b * d.n_con);
   const double* ubb = ub + (bounds_shared ? 0 : (size_t)b * d.n_con);
   omgx::Result r = omgx::ipm_solve(c, d, T, o, w, p + (size_t)b * d.n_par, x0 + (size_t)b * d.n_var,
-                                   lbb, ubb, kkt_doubles);
+                                   lbb, ubb, o.warm_start ? lam + (size_t)b * d.n_con : nullptr, kkt_doubles);
   __syncthreads();
   for (int i = threadIdx.x; i < d.n_var; i += blockDim.x) x[(size_t)b * d.n_var + i] = w.x[i];
   for (int q = threadIdx.x; q < d.n_con; q += blockDim.x)
@@ -328,7 +328,7 @@ const char* omgx_status_string(int32_t s) {
 
 void omgx_default_options(omgx_options* o) {
   o->tol = 1e-3; o->max_iter = 300; o->mu_init = 0.1; o->kappa_push = 1.0;
-  o->nu_init = 100.0; o->scale_gmax = 100.0;
+  o->nu_init = 100.0; o->scale_gmax = 100.0; o->warm_start = 0; o->kappa_warm = 1e-3;
 }
 
 int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device, omgx_batch** out) {
@@ -342,7 +342,7 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
   omgx_batch* b = new omgx_batch();
   b->device = device; b->n_agents = n_agents;
   omgx_options o; omgx_default_options(&o);
-  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax};
+  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm};
   int rc = build_batch(b, tpl);
   if (rc != OMGX_OK) { omgx_batch_destroy(b); return rc; }
   const omgx::Dims& d = b->dims;
@@ -376,7 +376,7 @@ void omgx_batch_destroy(omgx_batch* b) {
 
 int omgx_batch_set_options(omgx_batch* b, const omgx_options* o) {
   if (!b || !o || !(o->tol > 0) || o->max_iter < 0) { g_err = "bad options"; return OMGX_E_INVALID; }
-  b->opts = {o->tol, o->max_iter, o->mu_init, o->kappa_push, o->nu_init, o->scale_gmax};
+  b->opts = {o->tol, o->max_iter, o->mu_init, o->kappa_push, o->nu_init, o->scale_gmax, o->warm_start, o->kappa_warm};
   return OMGX_OK;
 }
 
@@ -402,6 +402,8 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   if (!dev) {
     HIPCHK(hipMemcpyAsync(b->d_p, p, (size_t)B * d.n_par * sizeof(double), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->d_x0, x0, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (b->opts.warm_start)
+      HIPCHK(hipMemcpyAsync(b->d_lam, lam_g, (size_t)B * d.n_con * sizeof(double), hipMemcpyHostToDevice, b->stream));
     kp = b->d_p; kx0 = b->d_x0; kx = b->d_x; klam = b->d_lam; kst = b->d_status; kit = b->d_iters;
   }
   if (!bdev) {

@@ -64,6 +64,8 @@ struct Tables {   // read-only, shared by all agents (global memory)
 
 struct Opts {
   double tol; int max_iter; double mu_init, kappa_push, nu_init, scale_gmax;
+  int warm_start;      // 1: lam0 holds the multipliers of the previous solve (primal-dual warm start)
+  double kappa_warm;   // kappa_push used for warm starts
 };
 
 // fixed constants of the iteration (same values in oracle/ipm_numpy.py DEFAULTS)
@@ -83,6 +85,7 @@ struct Opts {
 #define OMGX_MAX_BACKTRACK 25
 #define OMGX_NU_MAX      1e8
 #define OMGX_STALL_ITERS 10
+#define OMGX_WARM_ZMIN   1e-8
 #define OMGX_MAX_LEAF    16
 #define OMGX_BMAT_DOUBLES 4      // sizeof(BMat) / 8
 
@@ -633,7 +636,7 @@ struct Result { int status, iters; double f, mu, t; };
 template <class C>
 OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts& o, Work& w,
                          const double* p, const double* x0, const double* lb, const double* ub,
-                         int kkt_doubles) {
+                         const double* lam0, int kkt_doubles) {
   const int n = d.n_var, m = d.n_con, N = d.N;
   Result res; res.status = 1; res.iters = 0; res.f = 0; res.mu = o.mu_init; res.t = 0;
   Kkt K; K.d = &d; K.T = &T; K.a = w.kkt;
@@ -644,6 +647,8 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   c.sync();
 
   // ---- row classification, gradient-based scaling, phase-I weights -----------
+  const bool warm = o.warm_start && lam0 != nullptr;
+  const double kpush = warm ? o.kappa_warm : o.kappa_push;
   double bad_local = 0.0;
   OMGX_PFOR(r, m) {
     const double l = lb[r], u = ub[r];
@@ -667,7 +672,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     const double h = (ty == ROW_FREE) ? 0.0 : w.rho[r] * (g - w.bnd[r]);
     w.hv[r] = h;
     double v = 0.0;
-    if (ty == ROW_UPPER || ty == ROW_LOWER) v = fmax(h + o.kappa_push, 0.0);
+    if (ty == ROW_UPPER || ty == ROW_LOWER) v = fmax(h + kpush, 0.0);
     else if (ty == ROW_EQ) v = h;
     w.vv[r] = v;
   }
@@ -684,6 +689,23 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     else { w.s[r] = 1.0; w.z[r] = 0.0; }
   }
   c.sync();
+  if (warm) {
+    // primal-dual warm start: multipliers of the previous solve (unscaled lam_g), barrier
+    // parameter from the average complementarity
+    double sz = 0.0, cnt0 = 0.0;
+    OMGX_PFOR(r, m) {
+      const int ty = w.rtype[r];
+      if (ty == ROW_UPPER || ty == ROW_LOWER) {
+        w.z[r] = fmax(lam0[r] / w.rho[r], OMGX_WARM_ZMIN);
+        sz += w.s[r] * w.z[r]; cnt0 += 1.0;
+      } else if (ty == ROW_EQ) {
+        w.z[r] = lam0[r] / w.rho[r];
+      }
+    }
+    sz = c.rsum(sz); cnt0 = c.rsum(cnt0);
+    mu = fmin(o.mu_init, fmax(o.tol / 10.0, sz / fmax(1.0, cnt0)));
+    zt = use_t ? mu / t : 0.0;
+  }
   double f = row_value(T, w, m, w.x);
   double dw_last = 0.0, t_check = t;
   int it = 0, status = 1;

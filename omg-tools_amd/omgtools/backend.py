@@ -45,11 +45,12 @@ class CTemplate(C.Structure):
 
 class COptions(C.Structure):
     _fields_ = [('tol', C.c_double), ('max_iter', C.c_int32), ('mu_init', C.c_double),
-                ('kappa_push', C.c_double), ('nu_init', C.c_double), ('scale_gmax', C.c_double)]
+                ('kappa_push', C.c_double), ('nu_init', C.c_double), ('scale_gmax', C.c_double),
+                ('warm_start', C.c_int32), ('kappa_warm', C.c_double)]
 
 
 DEFAULT_OPTIONS = dict(tol=1e-3, max_iter=300, mu_init=0.1, kappa_push=1.0,
-                       nu_init=100.0, scale_gmax=100.0)
+                       nu_init=100.0, scale_gmax=100.0, warm_start=0, kappa_warm=1e-3)
 
 
 def make_options(**kw):
@@ -204,7 +205,8 @@ class BatchSolver(object):
             pass
 
     # -- host arrays ----------------------------------------------------------------
-    def solve(self, p, x0, lbg=None, ubg=None):
+    def solve(self, p, x0, lbg=None, ubg=None, lam_g0=None):
+        """lam_g0 is used (and required) when the option warm_start is set."""
         t = self.template
         B = self.n_agents
         p = np.ascontiguousarray(np.asarray(p, float).reshape(B, t.n_par))
@@ -218,7 +220,10 @@ class BatchSolver(object):
         if lbg.size != (t.n_con if shared else B * t.n_con) or ubg.size != lbg.size:
             raise ValueError('lbg/ubg have the wrong size')
         x = np.empty((B, t.n_var))
-        lam = np.empty((B, t.n_con))
+        lam = np.empty((B, t.n_con)) if lam_g0 is None else \
+            np.ascontiguousarray(np.asarray(lam_g0, float).reshape(B, t.n_con)).copy()
+        if self.options.get('warm_start') and lam_g0 is None:
+            raise ValueError('warm_start is set: pass lam_g0')
         status = np.empty(B, dtype=np.int32)
         iters = np.empty(B, dtype=np.int32)
         _check(self.lib, self.lib.omgx_batch_solve(

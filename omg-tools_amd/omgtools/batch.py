@@ -1,0 +1,166 @@
+"""`BatchP2P`: B independent point-to-point agents driven through the
+receding-horizon loop with everything resident on the device.
+
+The reference loops `Deployer.update` -> `problem.predict / solve / store`
+(`execution/deployer.py:43-79`) for one agent in Python.  Here one MPC step of the
+whole batch is: (1) ideal prediction -- the initial condition of the next solve is
+the current plan evaluated `update_time` ahead (`vehicles/vehicle.py:323-326`,
+C++ `Vehicle::predict` Vehicle.cpp:61-80); (2) horizon bookkeeping `t = time since
+the last knot crossing` and, on a crossing, the warm-start shift of every `seg`
+spline variable (`problems/point2point.py:187-198`, `basics/optilayer.py:470-490`)
+plus an index shift of the multipliers; (3) `omgx_batch_solve` with a primal-dual
+warm start.  The glue is a handful of tiny tensor ops on [B, *] device arrays
+(torch is only the allocator/stream here); no data leaves HBM between steps.
+
+`ops='numpy'` runs the same protocol on host arrays with the oracle CPU port as the
+solver: test infrastructure for the parity tests, never the product path.
+"""
+import numpy as np
+
+from .splines import shiftoverknot_T
+
+
+def dual_shift_perm(father):
+    """perm[r] = row whose multiplier warm-starts row r after the horizon moved by
+    one knot interval (-1: none).  Spline-valued constraint entries are indexed by
+    B-spline coefficients: moving the horizon by one interval drops the first
+    `mult` coefficients (mult = multiplicity of the interior knots of that entry's
+    basis); scalar rows keep their multiplier."""
+    tpl = father.template
+    perm = np.arange(tpl.n_con, dtype=np.int64)
+    for label, child in father.children.items():
+        for cname in child._constraints:
+            key = (label, child._add_label(cname))
+            off, rows, _ = tpl.con_layout[key]
+            if cname not in child._splines_dual:
+                continue
+            basis = child._splines_dual[cname]['basis']
+            interior = basis.knots[(basis.knots > basis.knots[0]) & (basis.knots < basis.knots[-1])]
+            if len(interior) == 0:
+                continue
+            mult = int(np.sum(interior == interior[0]))
+            idx = np.arange(rows) + mult
+            perm[off:off + rows] = np.where(idx < rows, off + idx, -1)
+    return perm
+
+
+class BatchP2P(object):
+
+    def __init__(self, problem, P, ops='hip', device=None, options=None, update_time=0.1):
+        self.problem = problem
+        father = problem.father
+        self.tpl = tpl = father.template
+        veh = problem.vehicles[0]
+        self.veh, self.basis = veh, veh.basis
+        self.L, self.n_dim = len(veh.basis), veh.n_dim
+        self.T = float(problem.options['horizon_time'])
+        self.knot_time = float(problem.knot_time)
+        self.update_time = float(update_time)
+        self.B = P['p'].shape[0]
+        self.o_spl = tpl.entry_range(veh.label, 'splines_seg0', 'var')[0]
+        self.o_state0 = tpl.entry_range(veh.label, 'state0', 'par')[0]
+        self.o_input0 = tpl.entry_range(veh.label, 'input0', 'par')[0]
+        self.o_t = tpl.entry_range(problem.label, 't', 'par')[0]
+        self.perm = dual_shift_perm(father)
+        ents, mats, off = [], [], 0
+        for label, name, spl in father.shifted_entries():
+            lo, rows, cols = tpl.var_layout[(label, name)]
+            Tm = shiftoverknot_T(spl['basis'])
+            ents.append([lo, rows, cols, off])
+            mats.append(Tm.reshape(-1))
+            off += Tm.size
+        self.shift_entries = np.array(ents, dtype=np.int32)
+        self.shift_mats = np.concatenate(mats)
+        self._shift_dense = [(e, m.reshape(e[1], e[1])) for e, m in zip(ents, mats)]
+        self.time = 0.0
+        self.opts = dict(tol=1e-3, max_iter=300)
+        self.opts.update(options or {})
+        self.kind = ops
+        if ops == 'hip':
+            import torch
+            from .backend import BatchSolver
+            self.torch = torch
+            self.dev = device if device is not None else torch.device('cuda', 0)
+            f64 = dict(dtype=torch.float64, device=self.dev)
+            self.solver = BatchSolver(tpl, self.B, device=self.dev.index or 0, options=self.opts)
+            self.solver.set_stream(torch.cuda.current_stream().cuda_stream)
+            self.p = torch.as_tensor(np.ascontiguousarray(P['p']), **f64)
+            self.x = torch.as_tensor(np.ascontiguousarray(P['x0']), **f64)
+            self.x_new = torch.empty_like(self.x)
+            self.lam = torch.zeros((self.B, tpl.n_con), **f64)
+            self.lb, self.ub = torch.as_tensor(tpl.lb, **f64), torch.as_tensor(tpl.ub, **f64)
+            self.status = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+            self.iters = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+            pm = np.maximum(self.perm, 0)
+            self._perm_idx = torch.as_tensor(pm, dtype=torch.int64, device=self.dev)
+            self._perm_ok = torch.as_tensor((self.perm >= 0).astype(np.float64), **f64)
+            self._mask = torch.ones(self.B, dtype=torch.uint8, device=self.dev)
+        else:
+            from oracle import port_binding          # test infrastructure only
+            self.port = port_binding
+            self.p, self.x = np.array(P['p'], float), np.array(P['x0'], float)
+            self.lam = np.zeros((self.B, tpl.n_con))
+            self.status = np.zeros(self.B, dtype=np.int32)
+            self.iters = np.zeros(self.B, dtype=np.int32)
+
+    # -- solves ------------------------------------------------------------------------
+    def _solve(self, warm):
+        if self.kind == 'hip':
+            self.solver.set_options(warm_start=int(warm))
+            if not warm:
+                self.lam.zero_()
+            self.solver.solve_device(self.p, self.x, self.lb, self.ub, self.x_new, self.lam,
+                                     self.status, self.iters, bounds_shared=True)
+            self.x, self.x_new = self.x_new, self.x
+        else:
+            r = self.port.solve(self.tpl, self.p, self.x, lam_g0=self.lam if warm else None,
+                                warm_start=int(warm), **self.opts)
+            self.x, self.lam, self.status, self.iters = r['x'], r['lam_g'], r['status'], r['iters']
+
+    def solve_cold(self):
+        self._solve(False)
+
+    # -- one receding-horizon step ---------------------------------------------------------
+    def step(self):
+        xp = self.torch if self.kind == 'hip' else np
+        B, L, nd = self.B, self.L, self.n_dim
+        t_prev = self.time
+        t_now = t_prev + self.update_time
+        rel_prev = np.round(t_prev, 6) % self.knot_time
+        # (1) ideal prediction on the current plan
+        tau = (rel_prev + self.update_time) / self.T
+        E = self.basis.eval_basis([tau])[0]
+        dbasis, P1 = self.basis.derivative(1)
+        Ed = dbasis.eval_basis([tau])[0] @ P1 / self.T
+        c = self.x[:, self.o_spl:self.o_spl + nd * L].reshape(B, nd, L)
+        if self.kind == 'hip':
+            Ev = xp.as_tensor(E, dtype=xp.float64, device=self.dev)
+            Edv = xp.as_tensor(Ed, dtype=xp.float64, device=self.dev)
+        else:
+            Ev, Edv = E, Ed
+        self.p[:, self.o_state0:self.o_state0 + nd] = c @ Ev
+        self.p[:, self.o_input0:self.o_input0 + nd] = c @ Edv
+        # (2) horizon bookkeeping
+        crossed = int(np.round(t_prev / self.knot_time, 6)) < int(np.round(t_now / self.knot_time, 6))
+        if crossed:
+            self._shift()
+        self.time = t_now
+        self.p[:, self.o_t] = float(np.round(t_now, 6) % self.knot_time)
+        # (3) warm-started solve
+        self._solve(True)
+        return crossed
+
+    def _shift(self):
+        if self.kind == 'hip':
+            self.solver.shift(self.x, self._mask, self.shift_entries, self.shift_mats, device=True)
+            self.lam = self.lam.index_select(1, self._perm_idx) * self._perm_ok
+        else:
+            for (lo, rows, cols, _), Tm in self._shift_dense:
+                blk = self.x[:, lo:lo + rows * cols].reshape(self.B, cols, rows)
+                self.x[:, lo:lo + rows * cols] = (blk @ Tm.T).reshape(self.B, -1)
+            self.lam = np.where(self.perm >= 0, self.lam[:, np.maximum(self.perm, 0)], 0.0)
+
+    # -- convenience -----------------------------------------------------------------------
+    def host(self, name):
+        a = getattr(self, name)
+        return a.cpu().numpy() if self.kind == 'hip' else np.asarray(a)

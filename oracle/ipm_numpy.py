@@ -25,7 +25,7 @@ DEFAULTS = dict(tol=1e-8, max_iter=200, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.
                 theta_mu=1.5, tau_min=0.99, s_push=1.0, delta_c=1e-8, eta=1e-4,
                 rho=0.1, dw_first=1e-4, dw_inc=10.0, dw_dec=1. / 3., dw_max=1e10, dw_zero=1e-9,
                 s_max=100.0, kappa_sigma=1e10, max_backtrack=25, max_soc=2,
-                slack_reset=True, kappa_push=1.0, stall_iters=10, nu_init=100.0, nu_max=1e8, e_push=1.0, scale_gmax=100.0, s_phi=2.3, s_theta=1.1, delta_sw=1.0,
+                slack_reset=True, kappa_push=1.0, stall_iters=10, warm_zmin=1e-8, nu_init=100.0, nu_max=1e8, e_push=1.0, scale_gmax=100.0, s_phi=2.3, s_theta=1.1, delta_sw=1.0,
                 gamma_theta=1e-5, gamma_phi=1e-5, filter_size=8)
 
 STATUS = {0: 'Solve_Succeeded', 1: 'Maximum_Iterations_Exceeded',
@@ -297,6 +297,14 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
     z = mu / s
     zt = mu / t if use_t else 0.0
     y = np.zeros(mE)
+    if z0 is not None:
+        # primal-dual warm start: multipliers of the previous solve (unscaled lam_g),
+        # barrier parameter from the average complementarity
+        lam0 = np.asarray(z0, float) / rho
+        z = np.maximum(sig * lam0[iH], o['warm_zmin'])
+        y = lam0[iE].copy()
+        mu = float(min(o['mu_init'], max(o['tol'] / 10., (s * z).mean())))
+        zt = mu / t if use_t else 0.0
     dw_last = 0.0
     status, it, nfact = 1, 0, 0
     N = n + 1                      # (x, t)

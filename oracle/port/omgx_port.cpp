@@ -26,6 +26,7 @@ extern "C" int omgx_port_solve(const omgx_template* tpl, const omgx_options* opt
   omgx::Opts o;
   o.tol = opt->tol; o.max_iter = opt->max_iter; o.mu_init = opt->mu_init;
   o.kappa_push = opt->kappa_push; o.nu_init = opt->nu_init; o.scale_gmax = opt->scale_gmax;
+  o.warm_start = opt->warm_start; o.kappa_warm = opt->kappa_warm;
   const omgx::Dims& d = plan.dims;
   std::vector<double> buf(omgx::work_doubles(d, plan.kkt_doubles) + 8);
   omgx::Work w;
@@ -35,7 +36,8 @@ extern "C" int omgx_port_solve(const omgx_template* tpl, const omgx_options* opt
     const double* lb = lbg + (bounds_shared ? 0 : (size_t)b * d.n_con);
     const double* ub = ubg + (bounds_shared ? 0 : (size_t)b * d.n_con);
     omgx::Result r = omgx::ipm_solve(c, d, plan.tables, o, w, p + (size_t)b * d.n_par,
-                                     x0 + (size_t)b * d.n_var, lb, ub, plan.kkt_doubles);
+                                     x0 + (size_t)b * d.n_var, lb, ub,
+                                     opt->warm_start ? lam_g + (size_t)b * d.n_con : nullptr, plan.kkt_doubles);
     for (int i = 0; i < d.n_var; ++i) x[(size_t)b * d.n_var + i] = w.x[i];
     for (int r_ = 0; r_ < d.n_con; ++r_)
       lam_g[(size_t)b * d.n_con + r_] = (r.status == 3 || w.rtype[r_] == omgx::ROW_FREE) ? 0.0 : w.rho[r_] * w.z[r_];

@@ -23,7 +23,7 @@ def load():
     return lib
 
 
-def solve(template, p, x0, lbg=None, ubg=None, plan=None, **options):
+def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, **options):
     """Solve B agents on one host thread; returns dict like BatchSolver.solve."""
     from omgtools.backend import make_ctemplate, make_options
     lib = load()
@@ -36,7 +36,8 @@ def solve(template, p, x0, lbg=None, ubg=None, plan=None, **options):
     ubg = np.ascontiguousarray(template.ub if ubg is None else ubg, dtype=float)
     shared = int(lbg.size == template.n_con)
     x = np.empty((B, template.n_var))
-    lam = np.empty((B, template.n_con))
+    lam = np.empty((B, template.n_con)) if lam_g0 is None else \
+        np.ascontiguousarray(np.atleast_2d(np.asarray(lam_g0, float))).copy()
     status = np.empty(B, dtype=np.int32)
     iters = np.empty(B, dtype=np.int32)
     rc = lib.omgx_port_solve(C.byref(ct), C.byref(opt), C.c_int32(B),

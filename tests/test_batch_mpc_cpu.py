@@ -1,0 +1,40 @@
+"""Receding-horizon protocol of BatchP2P on the host (oracle port as solver):
+warm-started steps need far fewer iterations than the cold solve, a knot crossing
+shifts the plan consistently, and the fleet makes progress to its targets."""
+import numpy as np
+
+
+def test_receding_horizon_protocol(cfg2_small):
+    from omgtools.batch import BatchP2P, dual_shift_perm
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    perm = dual_shift_perm(problem.father)
+    # velocity rows (13, simple knots) shift by 1, vehicle-hyperplane rows (45, 4 per interval) by 4
+    off = tpl.con_layout[(problem.vehicles[0].label, 'c_0_' + problem.vehicles[0].label)][0]
+    assert list(perm[off:off + 3]) == [off + 1, off + 2, off + 3] and perm[off + 12] == -1
+    off = tpl.con_layout[(problem.vehicles[0].label, 'c_8_' + problem.vehicles[0].label)][0]
+    assert perm[off] == off + 4 and perm[off + 44] == -1
+    mpc = BatchP2P(problem, P, ops='numpy', options=dict(tol=1e-3, max_iter=300))
+    mpc.solve_cold()
+    ok = mpc.status == 0
+    assert ok.sum() >= 5
+    cold_iters = mpc.iters[ok].mean()
+    lo = mpc.o_spl
+    goal = P['p'][:, tpl.entry_range(problem.vehicles[0].label, 'poseT', 'par')[0]:][:, :2]
+    d0 = np.linalg.norm(mpc.p[:, mpc.o_state0:mpc.o_state0 + 2] - goal, axis=1)
+    warm_iters, crossings = [], 0
+    for k in range(12):
+        x_before = mpc.x.copy()
+        crossed = mpc.step()
+        crossings += crossed
+        assert np.all(mpc.status[ok] == 0)
+        warm_iters.append(mpc.iters[ok].mean())
+        if not crossed:          # consecutive plans agree closely where they describe the future
+            L = mpc.L                # (the first coefficients only shape the already-travelled piece)
+            for a in range(2):
+                sl = slice(lo + a * L + 2, lo + (a + 1) * L)
+                assert np.abs(mpc.x[ok, sl] - x_before[ok, sl]).max() < 5e-2
+    assert crossings == 1                                   # t = 1.0 passes the first knot (0.909)
+    assert np.mean(warm_iters) < 0.5 * cold_iters
+    d1 = np.linalg.norm(mpc.p[:, mpc.o_state0:mpc.o_state0 + 2] - goal, axis=1)
+    assert np.all(d1[ok] < d0[ok] - 0.3)                    # 1.2 s of motion towards the goal
