@@ -86,8 +86,8 @@ typedef struct omgx_options {
   double  kappa_push;   /* rows within this distance of their bound are relaxed by t */
   double  nu_init;      /* initial weight of the phase-I variable */
   double  scale_gmax;   /* gradient-based row scaling threshold (0 = off) */
-  int32_t warm_start;   /* 1: lam_g is read as the multipliers of the previous solve (in/out) and
-                           x0 is the previous solution: primal-dual warm start for receding-horizon
+  int32_t warm_start;   /* 1: lam_g and status are in/out: an agent whose previous status was
+                           Solve_Succeeded starts from x0 with the multipliers in lam_g: primal-dual warm start for receding-horizon
                            steps (the reference warm-starts IPOPT from x0 only, `problem.py:57-60,113`) */
   double  kappa_warm;   /* kappa_push used when warm_start = 1 */
 } omgx_options;

@@ -63,7 +63,8 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   const double* lbb = lb + (bounds_shared ? 0 : (size_t)b * d.n_con);
   const double* ubb = ub + (bounds_shared ? 0 : (size_t)b * d.n_con);
   omgx::Result r = omgx::ipm_solve(c, d, T, o, w, p + (size_t)b * d.n_par, x0 + (size_t)b * d.n_var,
-                                   lbb, ubb, o.warm_start ? lam + (size_t)b * d.n_con : nullptr, kkt_doubles);
+                                   lbb, ubb, o.warm_start ? lam + (size_t)b * d.n_con : nullptr,
+                                   o.warm_start ? status[b] : 0, kkt_doubles);
   __syncthreads();
   for (int i = threadIdx.x; i < d.n_var; i += blockDim.x) x[(size_t)b * d.n_var + i] = w.x[i];
   for (int q = threadIdx.x; q < d.n_con; q += blockDim.x)
@@ -402,8 +403,10 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   if (!dev) {
     HIPCHK(hipMemcpyAsync(b->d_p, p, (size_t)B * d.n_par * sizeof(double), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->d_x0, x0, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream));
-    if (b->opts.warm_start)
+    if (b->opts.warm_start) {
       HIPCHK(hipMemcpyAsync(b->d_lam, lam_g, (size_t)B * d.n_con * sizeof(double), hipMemcpyHostToDevice, b->stream));
+      HIPCHK(hipMemcpyAsync(b->d_status, status, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+    }
     kp = b->d_p; kx0 = b->d_x0; kx = b->d_x; klam = b->d_lam; kst = b->d_status; kit = b->d_iters;
   }
   if (!bdev) {

@@ -636,7 +636,7 @@ struct Result { int status, iters; double f, mu, t; };
 template <class C>
 OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts& o, Work& w,
                          const double* p, const double* x0, const double* lb, const double* ub,
-                         const double* lam0, int kkt_doubles) {
+                         const double* lam0, int prev_status, int kkt_doubles) {
   const int n = d.n_var, m = d.n_con, N = d.N;
   Result res; res.status = 1; res.iters = 0; res.f = 0; res.mu = o.mu_init; res.t = 0;
   Kkt K; K.d = &d; K.T = &T; K.a = w.kkt;
@@ -647,7 +647,8 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   c.sync();
 
   // ---- row classification, gradient-based scaling, phase-I weights -----------
-  const bool warm = o.warm_start && lam0 != nullptr;
+  // warm start only from a converged previous solve; otherwise a cold start from x0
+  const bool warm = o.warm_start && lam0 != nullptr && prev_status == 0;
   const double kpush = warm ? o.kappa_warm : o.kappa_push;
   double bad_local = 0.0;
   OMGX_PFOR(r, m) {

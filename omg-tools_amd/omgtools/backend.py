@@ -205,7 +205,7 @@ class BatchSolver(object):
             pass
 
     # -- host arrays ----------------------------------------------------------------
-    def solve(self, p, x0, lbg=None, ubg=None, lam_g0=None):
+    def solve(self, p, x0, lbg=None, ubg=None, lam_g0=None, status0=None):
         """lam_g0 is used (and required) when the option warm_start is set."""
         t = self.template
         B = self.n_agents
@@ -224,7 +224,8 @@ class BatchSolver(object):
             np.ascontiguousarray(np.asarray(lam_g0, float).reshape(B, t.n_con)).copy()
         if self.options.get('warm_start') and lam_g0 is None:
             raise ValueError('warm_start is set: pass lam_g0')
-        status = np.empty(B, dtype=np.int32)
+        status = np.zeros(B, dtype=np.int32) if status0 is None else \
+            np.ascontiguousarray(status0, dtype=np.int32).copy()
         iters = np.empty(B, dtype=np.int32)
         _check(self.lib, self.lib.omgx_batch_solve(
             self._h, p.ctypes.data, x0.ctypes.data, lbg.ctypes.data, ubg.ctypes.data,

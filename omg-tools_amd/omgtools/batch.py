@@ -114,7 +114,7 @@ class BatchP2P(object):
             self.x, self.x_new = self.x_new, self.x
         else:
             r = self.port.solve(self.tpl, self.p, self.x, lam_g0=self.lam if warm else None,
-                                warm_start=int(warm), **self.opts)
+                                status0=self.status if warm else None, warm_start=int(warm), **self.opts)
             self.x, self.lam, self.status, self.iters = r['x'], r['lam_g'], r['status'], r['iters']
 
     def solve_cold(self):

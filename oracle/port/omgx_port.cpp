@@ -37,7 +37,8 @@ extern "C" int omgx_port_solve(const omgx_template* tpl, const omgx_options* opt
     const double* ub = ubg + (bounds_shared ? 0 : (size_t)b * d.n_con);
     omgx::Result r = omgx::ipm_solve(c, d, plan.tables, o, w, p + (size_t)b * d.n_par,
                                      x0 + (size_t)b * d.n_var, lb, ub,
-                                     opt->warm_start ? lam_g + (size_t)b * d.n_con : nullptr, plan.kkt_doubles);
+                                     opt->warm_start ? lam_g + (size_t)b * d.n_con : nullptr,
+                                     opt->warm_start ? status[b] : 0, plan.kkt_doubles);
     for (int i = 0; i < d.n_var; ++i) x[(size_t)b * d.n_var + i] = w.x[i];
     for (int r_ = 0; r_ < d.n_con; ++r_)
       lam_g[(size_t)b * d.n_con + r_] = (r.status == 3 || w.rtype[r_] == omgx::ROW_FREE) ? 0.0 : w.rho[r_] * w.z[r_];

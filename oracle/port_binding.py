@@ -23,7 +23,7 @@ def load():
     return lib
 
 
-def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, **options):
+def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, status0=None, **options):
     """Solve B agents on one host thread; returns dict like BatchSolver.solve."""
     from omgtools.backend import make_ctemplate, make_options
     lib = load()
@@ -38,7 +38,8 @@ def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, **options
     x = np.empty((B, template.n_var))
     lam = np.empty((B, template.n_con)) if lam_g0 is None else \
         np.ascontiguousarray(np.atleast_2d(np.asarray(lam_g0, float))).copy()
-    status = np.empty(B, dtype=np.int32)
+    status = np.zeros(B, dtype=np.int32) if status0 is None else \
+        np.ascontiguousarray(status0, dtype=np.int32).copy()
     iters = np.empty(B, dtype=np.int32)
     rc = lib.omgx_port_solve(C.byref(ct), C.byref(opt), C.c_int32(B),
                              C.c_void_p(p.ctypes.data), C.c_void_p(x0.ctypes.data),
