@@ -46,7 +46,10 @@ def dual_shift_perm(father):
 
 class BatchP2P(object):
 
-    def __init__(self, problem, P, ops='hip', device=None, options=None, update_time=0.1):
+    def __init__(self, problem, P, ops='hip', device=None, options=None, update_time=0.1,
+                 max_iter_step=40):
+        # max_iter_step: iteration cap of a receding-horizon step (real-time budget; an agent that
+        # hits it keeps its last strictly feasible iterate and restarts cold at the next step)
         self.problem = problem
         father = problem.father
         self.tpl = tpl = father.template
@@ -75,6 +78,7 @@ class BatchP2P(object):
         self.time = 0.0
         self.opts = dict(tol=1e-3, max_iter=300)
         self.opts.update(options or {})
+        self.max_iter_cold, self.max_iter_step = self.opts['max_iter'], int(max_iter_step)
         self.kind = ops
         if ops == 'hip':
             import torch
@@ -106,7 +110,8 @@ class BatchP2P(object):
     # -- solves ------------------------------------------------------------------------
     def _solve(self, warm):
         if self.kind == 'hip':
-            self.solver.set_options(warm_start=int(warm))
+            self.solver.set_options(warm_start=int(warm),
+                                    max_iter=self.max_iter_step if warm else self.max_iter_cold)
             if not warm:
                 self.lam.zero_()
             self.solver.solve_device(self.p, self.x, self.lb, self.ub, self.x_new, self.lam,
@@ -114,7 +119,8 @@ class BatchP2P(object):
             self.x, self.x_new = self.x_new, self.x
         else:
             r = self.port.solve(self.tpl, self.p, self.x, lam_g0=self.lam if warm else None,
-                                status0=self.status if warm else None, warm_start=int(warm), **self.opts)
+                                status0=self.status if warm else None, warm_start=int(warm),
+                                **dict(self.opts, max_iter=self.max_iter_step if warm else self.max_iter_cold))
             self.x, self.lam, self.status, self.iters = r['x'], r['lam_g'], r['status'], r['iters']
 
     def solve_cold(self):

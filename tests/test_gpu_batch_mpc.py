@@ -13,8 +13,8 @@ def test_mpc_replay_matches_port(cfg2_small):
     problem, P = cfg2_small
     tpl = problem.father.template
     opts = dict(tol=1e-6, max_iter=300)
-    gpu = BatchP2P(problem, P, ops='hip', options=opts)
-    cpu = BatchP2P(problem, P, ops='numpy', options=opts)
+    gpu = BatchP2P(problem, P, ops='hip', options=opts, max_iter_step=300)
+    cpu = BatchP2P(problem, P, ops='numpy', options=opts, max_iter_step=300)
     gpu.solve_cold()
     cpu.solve_cold()
     ok = (gpu.host('status') == 0) & (cpu.status == 0)
