@@ -178,9 +178,10 @@ class BatchSolver(object):
         self.set_options(**(options or {}))
 
     def set_options(self, **kw):
-        self.options = dict(DEFAULT_OPTIONS)
-        self.options.update(getattr(self, 'options', {}))
-        self.options.update(kw)
+        merged = dict(DEFAULT_OPTIONS)
+        merged.update(getattr(self, 'options', {}))
+        merged.update(kw)
+        self.options = merged
         opt = COptions(**self.options)
         _check(self.lib, self.lib.omgx_batch_set_options(self._h, C.byref(opt)),
                'omgx_batch_set_options')
