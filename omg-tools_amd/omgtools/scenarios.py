@@ -13,14 +13,21 @@ from .environment import Environment, Obstacle
 from .problems import Point2point
 
 
-def _place_obstacles(rng, n_obs, start, goal, r_lo, r_hi, box, clearance=0.3):
-    centres, radii = [], []
+def _place_obstacles(rng, n_obs, start, goal, r_lo, r_hi, box, clearance=0.3, gap=0.25):
+    """Rejection sampling of circular obstacles: not within `clearance` of start/goal, and any
+    two discs leave a passable gap (`gap` >= vehicle diameter 0.2 m + 5 cm).  Two discs with an
+    impassable gap across the straight start-goal line put the reference's straight-line initial
+    guess in a homotopy class no local NLP method (IPOPT included) can leave."""
+    centres, radii, tries = [], [], 0
     while len(centres) < n_obs:
+        tries += 1
+        if tries > 2000:                        # restart an unlucky draw
+            centres, radii, tries = [], [], 0
         r = rng.uniform(r_lo, r_hi)
         c = rng.uniform(-box, box, size=2)
         if np.linalg.norm(c - start) < r + clearance or np.linalg.norm(c - goal) < r + clearance:
             continue
-        if any(np.linalg.norm(c - c2) < r + r2 + 0.05 for c2, r2 in zip(centres, radii)):
+        if any(np.linalg.norm(c - c2) < r + r2 + gap for c2, r2 in zip(centres, radii)):
             continue
         centres.append(c)
         radii.append(r)
