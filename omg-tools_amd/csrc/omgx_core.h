@@ -783,9 +783,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       }
       break;
     }
-    // stall test: phase I must at least halve t every OMGX_STALL_ITERS iterations
+    // stall test: phase I must shrink t by at least 10 % every OMGX_STALL_ITERS iterations
     if (use_t && it > 0 && it % OMGX_STALL_ITERS == 0) {
-      if (t > o.tol && t > 0.5 * t_check) infeasible = 1;
+      if (t > o.tol && t > 0.9 * t_check) infeasible = 1;
       t_check = t;
     }
     if (infeasible) { status = 2; break; }

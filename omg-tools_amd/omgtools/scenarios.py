@@ -7,8 +7,8 @@ per-agent arrays: 'p' [B, n_par] parameter vectors in the template's layout,
 """
 import numpy as np
 
-from .shapes import Circle, Square
-from .vehicles import Holonomic
+from .shapes import Circle, Square, Sphere, Cube
+from .vehicles import Holonomic, Holonomic3D, Quadrotor
 from .environment import Environment, Obstacle
 from .problems import Point2point
 
@@ -68,6 +68,95 @@ def holonomic_p2p(n_agents, knot_intervals=11, n_obs=3, seed=20240807 + 2,
         lo, hi = tpl.entry_range(vehicle.label, 'splines_seg0', 'var')
         x0[b, lo:hi] = np.c_[np.linspace(start[0], goal[0], L),
                              np.linspace(start[1], goal[1], L)].reshape(-1, order='F')
+    return problem, {'p': p, 'x0': x0}
+
+
+def _set(tpl, arr, b, label, name, value, kind='par'):
+    lo, hi = tpl.entry_range(label, name, kind)
+    arr[b, lo:hi] = value
+
+
+def _straight_line(tpl, x0, b, vehicle, start, goal, clamp=0):
+    """Initial guess of the reference's `get_init_spline_value`: coefficients on the straight line
+    (`holonomic.py:107-114`); `clamp` = degree repeats the end points so that the guess starts and
+    ends at rest (`quadrotor.py:94-102`)."""
+    L = len(vehicle.basis)
+    lo, hi = tpl.entry_range(vehicle.label, 'splines_seg0', 'var')
+    x0[b, lo:hi] = np.stack([np.r_[s * np.ones(clamp), np.linspace(s, g, L - 2 * clamp), g * np.ones(clamp)]
+                             for s, g in zip(start, goal)]).reshape(-1)
+
+
+def quadrotor_p2p(n_agents, knot_intervals=13, n_obs=5, seed=20240807 + 3, horizon_time=5.,
+                  options=None):
+    """Config 3: batch of independent 2-D Quadrotor point-to-point problems (flat outputs y, z of
+    degree 4; thrust / pitch-rate rows cubic in the coefficients, `vehicles/quadrotor.py:48-62`)
+    with `n_obs` circular obstacles moving at constant velocity."""
+    rng = np.random.default_rng(seed)
+    vehicle = Quadrotor(0.2)
+    vehicle.define_knots(knot_intervals=knot_intervals)
+    vehicle.set_initial_conditions([-4., -4.])
+    vehicle.set_terminal_conditions([4., 4.])
+    environment = Environment(room={'shape': Square(10.)})
+    for l in range(n_obs):
+        environment.add_obstacle(Obstacle({'position': [0., 0.], 'velocity': [0., 0.]}, shape=Circle(0.3)))
+    opts = {'horizon_time': horizon_time, 'verbose': 0}
+    opts.update(options or {})
+    problem = Point2point(vehicle, environment, options=opts)
+    problem.init()
+    tpl = problem.father.template
+    p = np.zeros((n_agents, tpl.n_par))
+    x0 = np.zeros((n_agents, tpl.n_var))
+    for b in range(n_agents):
+        start = rng.uniform(-4.5, -3.5, size=2)
+        goal = rng.uniform(3.5, 4.5, size=2)
+        centres, radii = _place_obstacles(rng, n_obs, start, goal, 0.2, 0.5, 2.5, gap=0.45)
+        vel = rng.uniform(-0.15, 0.15, size=(n_obs, 2))
+        _set(tpl, p, b, vehicle.label, 'spl0', start)
+        _set(tpl, p, b, vehicle.label, 'poseT', goal)
+        for l, obs in enumerate(environment.obstacles):
+            _set(tpl, p, b, obs.label, 'x', centres[l])
+            _set(tpl, p, b, obs.label, 'v', vel[l])
+            _set(tpl, p, b, obs.label, 'rad', radii[l])
+        _set(tpl, p, b, problem.label, 'T', horizon_time)
+        _straight_line(tpl, x0, b, vehicle, start, goal, clamp=vehicle.degree)
+    return problem, {'p': p, 'x0': x0}
+
+
+def holonomic3d_p2p(n_agents, knot_intervals=15, n_obs=10, seed=20240807 + 5, horizon_time=12.,
+                    options=None):
+    """Config 5: batch of independent Holonomic3D(Sphere(0.1)) problems with `n_obs` static
+    spheres, `hard_term_con=True`."""
+    rng = np.random.default_rng(seed)
+    vehicle = Holonomic3D(Sphere(0.1))
+    vehicle.define_knots(knot_intervals=knot_intervals)
+    vehicle.set_initial_conditions([-1.5, -1.5, -1.5])
+    vehicle.set_terminal_conditions([1.5, 1.5, 1.5])
+    environment = Environment(room={'shape': Cube(5.)})
+    for l in range(n_obs):
+        environment.add_obstacle(Obstacle({'position': [0., 0., 0.]}, shape=Sphere(0.2)))
+    opts = {'horizon_time': horizon_time, 'hard_term_con': True, 'verbose': 0}
+    opts.update(options or {})
+    problem = Point2point(vehicle, environment, options=opts)
+    problem.init()
+    tpl = problem.father.template
+    p = np.zeros((n_agents, tpl.n_par))
+    x0 = np.zeros((n_agents, tpl.n_var))
+    for b in range(n_agents):
+        start = rng.uniform(-2., -1., size=3)
+        goal = rng.uniform(1., 2., size=3)
+        centres, radii = [], []
+        while len(centres) < n_obs:                 # spheres may overlap; they only keep clear of start/goal
+            r, c = rng.uniform(0.15, 0.3), rng.uniform(-1.5, 1.5, size=3)
+            if min(np.linalg.norm(c - start), np.linalg.norm(c - goal)) < r + 0.3:
+                continue
+            centres.append(c); radii.append(r)
+        _set(tpl, p, b, vehicle.label, 'state0', start)
+        _set(tpl, p, b, vehicle.label, 'poseT', goal)
+        for l, obs in enumerate(environment.obstacles):
+            _set(tpl, p, b, obs.label, 'x', centres[l])
+            _set(tpl, p, b, obs.label, 'rad', radii[l])
+        _set(tpl, p, b, problem.label, 'T', horizon_time)
+        _straight_line(tpl, x0, b, vehicle, start, goal)
     return problem, {'p': p, 'x0': x0}
 
 

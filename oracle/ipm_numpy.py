@@ -347,7 +347,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             if mu > o['tol'] / 10. and emu <= o['kappa_eps'] * mu:
                 mu = max(o['tol'] / 10., min(o['kappa_mu'] * mu, mu ** o['theta_mu']))
                 continue
-            if use_t and zt < 0.1 * nu and t > o['tol'] and emu <= 100 * o['kappa_eps'] * mu:
+            if use_t and zt < 0.1 * nu and t > o['tol'] and emu <= o.get('esc_factor', 100) * o['kappa_eps'] * mu:
                 if nu >= o['nu_max']:
                     status = 2          # phase I stalls at t > 0: local infeasibility
                     break
@@ -356,7 +356,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                 continue
             break
         if use_t and it > 0 and it % o['stall_iters'] == 0:
-            if t > o['tol'] and t > 0.5 * t_check:
+            if t > o['tol'] and t > o.get('stall_factor', 0.9) * t_check:
                 status = 2              # phase I stalls: local infeasibility
             t_check = t
         if status == 2:
@@ -379,7 +379,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         tries = 0
         while True:
             K = np.zeros((N + mE, N + mE))
-            K[:N, :N] = M + dw * np.eye(N)
+            K[:N, :N] = M + dw * (np.diag(np.maximum(np.abs(np.diag(M)), o.get('dw_floor', 1e-3))) if o.get('dw_scaled') else np.eye(N))
             K[N:, :N] = Je
             K[:N, N:] = Je.T
             K[N:, N:] = -o['delta_c'] * np.eye(mE)
