@@ -32,7 +32,7 @@ extern "C" {
 #define OMGX_E_INVALID    -1   /* bad argument / inconsistent template */
 #define OMGX_E_NODEVICE   -2   /* no usable HIP device */
 #define OMGX_E_HIP        -3   /* a HIP runtime call failed (see omgx_last_error) */
-#define OMGX_E_TOOLARGE   -4   /* per-agent workspace does not fit in LDS */
+#define OMGX_E_TOOLARGE   -4   /* even the O(n_var) vectors of one agent do not fit in LDS */
 
 /* per-agent solver status (mirrors IPOPT's return_status strings) */
 #define OMGX_SOLVE_SUCCEEDED        0
@@ -108,6 +108,11 @@ int  omgx_batch_set_options(omgx_batch* b, const omgx_options* o);
 int  omgx_batch_set_stream(omgx_batch* b, void* hip_stream);
 /* LDS bytes the solve kernel needs per agent (for diagnostics / DESIGN.md). */
 int  omgx_batch_lds_bytes(const omgx_batch* b);
+/* Workspace placement chosen at create: mode 0 = every per-agent array in LDS; 1 = KKT store and
+ * factorisation panels in an HBM slab; 2 = + Jacobian values; 3 = + the per-row arrays (only the
+ * O(n_var) vectors stay in LDS).  Spill modes run min(n_agents, n_slabs) persistent workgroups. */
+int  omgx_batch_workspace(const omgx_batch* b, int32_t* mode, int64_t* lds_bytes,
+                          int64_t* hbm_bytes_per_slab, int32_t* n_slabs);
 
 /* One MPC solve for every agent: the batched twin of
  *   result = solver(x0=, p=, lbg=, ubg=)  ->  x, lam_g, return_status.

@@ -40,40 +40,59 @@ constexpr int kLdsLimit = 160 * 1024;
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
+template <int MODE>
 __global__ void __launch_bounds__(512)
 ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  const double* __restrict__ p, const double* __restrict__ x0,
                  const double* __restrict__ lb, const double* __restrict__ ub, int bounds_shared,
                  double* __restrict__ x, double* __restrict__ lam, int32_t* __restrict__ status,
-                 int32_t* __restrict__ iters, int n_agents, long long* __restrict__ prof) {
+                 int32_t* __restrict__ iters, int n_agents, long long* __restrict__ prof,
+                 double* __restrict__ slabs, size_t slab_doubles) {
   extern __shared__ __align__(16) double lds[];
-  const int b = blockIdx.x;
-  if (b >= n_agents) return;
   omgx::Work w;
-  omgx::work_carve(w, lds, d, kkt_doubles);
-  omgx::Ctx c; c.red = w.red;
+  omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
+                               d, kkt_doubles);
+  omgx::CtxT<(MODE != omgx::WS_LDS)> c; c.red = w.red;
 #ifdef OMGX_PROFILE
   __shared__ long long prof_lds[omgx::PH_COUNT];
   c.prof = prof_lds;
-  if (threadIdx.x < omgx::PH_COUNT) prof_lds[threadIdx.x] = 0;
-  __syncthreads();
 #else
   c.prof = nullptr;
 #endif
-  const double* lbb = lb + (bounds_shared ? 0 : (size_t)b * d.n_con);
-  const double* ubb = ub + (bounds_shared ? 0 : (size_t)b * d.n_con);
-  omgx::Result r = omgx::ipm_solve(c, d, T, o, w, p + (size_t)b * d.n_par, x0 + (size_t)b * d.n_var,
-                                   lbb, ubb, o.warm_start ? lam + (size_t)b * d.n_con : nullptr,
-                                   o.warm_start ? status[b] : 0, kkt_doubles);
-  __syncthreads();
-  for (int i = threadIdx.x; i < d.n_var; i += blockDim.x) x[(size_t)b * d.n_var + i] = w.x[i];
-  for (int q = threadIdx.x; q < d.n_con; q += blockDim.x)
-    lam[(size_t)b * d.n_con + q] =
-        (r.status == 3 || w.rtype[q] == omgx::ROW_FREE) ? 0.0 : w.rho[q] * w.z[q];
-  if (threadIdx.x == 0) { status[b] = r.status; iters[b] = r.iters; }
+  // mode 0: one workgroup per agent.  Spill modes: the grid is capped at the number of HBM
+  // slabs and every workgroup walks over its agents.
+  for (int b = blockIdx.x; b < n_agents; b += gridDim.x) {
 #ifdef OMGX_PROFILE
-  if (prof && threadIdx.x < omgx::PH_COUNT) prof[(size_t)b * omgx::PH_COUNT + threadIdx.x] = prof_lds[threadIdx.x];
+    if (threadIdx.x < omgx::PH_COUNT) prof_lds[threadIdx.x] = 0;
+    __syncthreads();
 #endif
+    const double* lbb = lb + (bounds_shared ? 0 : (size_t)b * d.n_con);
+    const double* ubb = ub + (bounds_shared ? 0 : (size_t)b * d.n_con);
+    omgx::Result r = omgx::ipm_solve(c, d, T, o, w, p + (size_t)b * d.n_par, x0 + (size_t)b * d.n_var,
+                                     lbb, ubb, o.warm_start ? lam + (size_t)b * d.n_con : nullptr,
+                                     o.warm_start ? status[b] : 0, kkt_doubles);
+    __syncthreads();
+    for (int i = threadIdx.x; i < d.n_var; i += blockDim.x) x[(size_t)b * d.n_var + i] = w.x[i];
+    for (int q = threadIdx.x; q < d.n_con; q += blockDim.x)
+      lam[(size_t)b * d.n_con + q] =
+          (r.status == 3 || w.rtype[q] == omgx::ROW_FREE) ? 0.0 : w.rho[q] * w.z[q];
+    if (threadIdx.x == 0) { status[b] = r.status; iters[b] = r.iters; }
+#ifdef OMGX_PROFILE
+    if (prof && threadIdx.x < omgx::PH_COUNT) prof[(size_t)b * omgx::PH_COUNT + threadIdx.x] = prof_lds[threadIdx.x];
+#endif
+    __syncthreads();
+  }
+}
+
+typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
+                             const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t);
+static ipm_kernel_t ipm_kernel_for(int mode) {
+  switch (mode) {
+    case omgx::WS_LDS: return ipm_solve_kernel<omgx::WS_LDS>;
+    case omgx::WS_KKT_HBM: return ipm_solve_kernel<omgx::WS_KKT_HBM>;
+    case omgx::WS_JAC_HBM: return ipm_solve_kernel<omgx::WS_JAC_HBM>;
+    default: return ipm_solve_kernel<omgx::WS_ROWS_HBM>;
+  }
 }
 
 // out[b, o, k, i] = d^o/dt^o spline_k(t0[b] + i*dt); one block = (agent, 256-sample chunk)
@@ -240,6 +259,9 @@ struct omgx_batch {
   omgx::Opts opts;
   int kkt_doubles = 0;
   size_t lds_bytes = 0;
+  int ws_mode = 0, n_slabs = 0;        // workspace placement (omgx::WS_*), HBM slabs (= grid cap)
+  size_t slab_doubles = 0;
+  double* d_slabs = nullptr;
   std::vector<void*> allocs;
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -281,13 +303,20 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   if (!plan.build(*t)) { g_err = "inconsistent template/plan"; return OMGX_E_INVALID; }
   b->dims = plan.dims;
   b->kkt_doubles = plan.kkt_doubles;
-  b->lds_bytes = omgx::work_doubles(plan.dims, plan.kkt_doubles) * sizeof(double);
-  if (b->lds_bytes > (size_t)kLdsLimit) {
+  // smallest spill mode whose LDS part fits one CU
+  int mode = 0;
+  size_t nl = 0, ng = 0;
+  for (; mode < omgx::WS_MODES; ++mode) {
+    omgx::work_split(plan.dims, plan.kkt_doubles, mode, &nl, &ng);
+    if (nl * sizeof(double) <= (size_t)kLdsLimit) break;
+  }
+  if (mode == omgx::WS_MODES) {
     char buf[160];
-    snprintf(buf, sizeof buf, "per-agent workspace %zu B exceeds the %d B LDS of one CU", b->lds_bytes, kLdsLimit);
+    snprintf(buf, sizeof buf, "per-agent O(n_var) vectors (%zu B) exceed the %d B LDS of one CU", nl * sizeof(double), kLdsLimit);
     g_err = buf;
     return OMGX_E_TOOLARGE;
   }
+  b->ws_mode = mode; b->lds_bytes = nl * sizeof(double); b->slab_doubles = ng;
   const omgx::Tables& H = plan.tables;
   const omgx::Dims& d = plan.dims;
   const int n_cpl = t->cpl_ptr[d.n_leaf];
@@ -357,9 +386,20 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
   if (hipStreamCreate(&b->own_stream) != hipSuccess || hipEventCreate(&b->ev0) != hipSuccess ||
       hipEventCreate(&b->ev1) != hipSuccess) { g_err = "stream/event creation failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
   b->stream = b->own_stream;
-  if (hipFuncSetAttribute((const void*)ipm_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute((const void*)ipm_kernel_for(b->ws_mode), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)b->lds_bytes) != hipSuccess) {
     g_err = "cannot reserve dynamic LDS for ipm_solve_kernel"; omgx_batch_destroy(b); return OMGX_E_HIP;
+  }
+  if (b->ws_mode != omgx::WS_LDS) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_err = "hipGetDeviceProperties failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
+    const int per_cu = (int)((size_t)kLdsLimit / (b->lds_bytes > 0 ? b->lds_bytes : 1));
+    int slabs = prop.multiProcessorCount * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+    if (slabs > n_agents) slabs = n_agents;
+    b->n_slabs = slabs;
+    if ((rc = dalloc(b, (size_t)slabs * b->slab_doubles, &b->d_slabs))) { omgx_batch_destroy(b); return rc; }
+  } else {
+    b->n_slabs = n_agents;
   }
   *out = b;
   return OMGX_OK;
@@ -389,6 +429,15 @@ int omgx_batch_set_stream(omgx_batch* b, void* s) {
 
 int omgx_batch_lds_bytes(const omgx_batch* b) { return b ? (int)b->lds_bytes : OMGX_E_INVALID; }
 
+int omgx_batch_workspace(const omgx_batch* b, int32_t* mode, int64_t* lds_bytes, int64_t* hbm_bytes_per_slab, int32_t* n_slabs) {
+  if (!b) return OMGX_E_INVALID;
+  if (mode) *mode = b->ws_mode;
+  if (lds_bytes) *lds_bytes = (int64_t)b->lds_bytes;
+  if (hbm_bytes_per_slab) *hbm_bytes_per_slab = (int64_t)(b->slab_doubles * sizeof(double));
+  if (n_slabs) *n_slabs = b->n_slabs;
+  return OMGX_OK;
+}
+
 int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const double* lbg, const double* ubg,
                      double* x, double* lam_g, int32_t* status, int32_t* iters, int32_t flags) {
   if (!b || !p || !x0 || !lbg || !ubg || !x || !lam_g || !status || !iters) { g_err = "null argument"; return OMGX_E_INVALID; }
@@ -415,8 +464,9 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
     klb = b->d_lb; kub = b->d_ub;
   }
   HIPCHK(hipEventRecord(b->ev0, b->stream));
-  hipLaunchKernelGGL(ipm_solve_kernel, dim3(B), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev, b->opts,
-                     b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof);
+  hipLaunchKernelGGL(ipm_kernel_for(b->ws_mode), dim3(b->n_slabs), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev,
+                     b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
+                     b->d_slabs, b->slab_doubles);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   b->timed = true;

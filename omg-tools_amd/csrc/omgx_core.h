@@ -105,34 +105,61 @@ struct Work {
   double *red;                    // reduction scratch [64]
 };
 
+// Workspace placement.  Mode 0 keeps every array in LDS (the fast path: cfg 1/2/4).  Problems
+// whose arrays exceed the 160 KiB of one CU spill the largest ones to a per-workgroup slab in
+// HBM (L2/MALL-cached), largest first:
+//   mode 1  kkt + col            mode 2  + jval
+//   mode 3  + the eight [n_con] row arrays and rtype (only the O(n_var) vectors stay in LDS)
+enum { WS_LDS = 0, WS_KKT_HBM = 1, WS_JAC_HBM = 2, WS_ROWS_HBM = 3, WS_MODES = 4 };
+
+OMGX_HD void work_split(const Dims& d, int kkt_doubles, int mode, size_t* lds, size_t* hbm) {
+  size_t nl = 0, ng = 0;
+  nl += d.n_atoms + d.n_slots;
+  nl += 2 * (size_t)d.N;
+  nl += d.N + (d.N + d.n_eq);
+  nl += d.N;                      // dinv
+  nl += 64;                       // red
+  const size_t rows = 8 * (size_t)d.n_con + (d.n_con + 1) / 2;
+  (mode >= WS_ROWS_HBM ? ng : nl) += rows;
+  (mode >= WS_JAC_HBM ? ng : nl) += d.nnz_j;
+  (mode >= WS_KKT_HBM ? ng : nl) += (size_t)kkt_doubles + d.col_doubles;
+  *lds = nl; *hbm = ng;
+}
+
 OMGX_HD size_t work_doubles(const Dims& d, int kkt_doubles) {
-  size_t n = 0;
-  n += d.n_atoms + d.n_slots;
-  n += 2 * (size_t)d.N;
-  n += 8 * (size_t)d.n_con;
-  n += d.nnz_j;
-  n += d.N + (d.N + d.n_eq);
-  n += kkt_doubles;
-  n += d.col_doubles + d.N;
-  n += (d.n_con + 1) / 2;        // rtype (int32)
-  n += 64;
-  return n;
+  size_t nl, ng;
+  work_split(d, kkt_doubles, WS_LDS, &nl, &ng);
+  return nl;
+}
+
+// MODE is a compile-time constant so that every pointer keeps a provable address space
+template <int MODE>
+OMGX_HD void work_carve_split(Work& w, double* lds, double* hbm, const Dims& d, int kkt_doubles) {
+  double* p = lds;
+  double* g = hbm;
+  w.atoms = p; p += d.n_atoms;   w.slots = p; p += d.n_slots;
+  w.x = p; p += d.N;             w.xt = p; p += d.N;
+  w.gbar = p; p += d.N;          w.sol = p; p += d.N + d.n_eq;
+  w.dinv = p; p += d.N;
+  w.red = p; p += 64;
+  if (MODE >= WS_ROWS_HBM) {
+    w.hv = g; g += d.n_con;        w.ht = g; g += d.n_con;
+    w.bnd = g; g += d.n_con;       w.rho = g; g += d.n_con;     w.vv = g; g += d.n_con;
+    w.s = g; g += d.n_con;         w.z = g; g += d.n_con;       w.ds = g; g += d.n_con;
+    w.rtype = (int32_t*)g; g += (d.n_con + 1) / 2;
+  } else {
+    w.hv = p; p += d.n_con;        w.ht = p; p += d.n_con;
+    w.bnd = p; p += d.n_con;       w.rho = p; p += d.n_con;     w.vv = p; p += d.n_con;
+    w.s = p; p += d.n_con;         w.z = p; p += d.n_con;       w.ds = p; p += d.n_con;
+    w.rtype = (int32_t*)p; p += (d.n_con + 1) / 2;
+  }
+  if (MODE >= WS_JAC_HBM) { w.jval = g; g += d.nnz_j; } else { w.jval = p; p += d.nnz_j; }
+  if (MODE >= WS_KKT_HBM) { w.kkt = g; g += kkt_doubles; w.col = g; g += d.col_doubles; }
+  else { w.kkt = p; p += kkt_doubles; w.col = p; p += d.col_doubles; }
 }
 
 OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
-  double* p = base;
-  w.atoms = p; p += d.n_atoms;   w.slots = p; p += d.n_slots;
-  w.x = p; p += d.N;             w.xt = p; p += d.N;
-  w.hv = p; p += d.n_con;        w.ht = p; p += d.n_con;
-  w.bnd = p; p += d.n_con;       w.rho = p; p += d.n_con;     w.vv = p; p += d.n_con;
-  w.s = p; p += d.n_con;         w.z = p; p += d.n_con;       w.ds = p; p += d.n_con;
-  w.jval = p; p += d.nnz_j;
-  w.gbar = p; p += d.N;          w.sol = p; p += d.N + d.n_eq;
-  w.kkt = p; p += kkt_doubles;
-  w.col = p; p += d.col_doubles;
-  w.dinv = p; p += d.N;
-  w.rtype = (int32_t*)p; p += (d.n_con + 1) / 2;
-  w.red = p;
+  work_carve_split<WS_LDS>(w, base, nullptr, d, kkt_doubles);
 }
 
 // ---------------------------------------------------------------------------
@@ -155,7 +182,8 @@ struct Ctx {
   void wave_sync() const {}
 };
 #else
-struct Ctx {
+template <bool kHbm>
+struct CtxT {
   double* red;
   long long* prof;
   __device__ int tid() const { return threadIdx.x; }
@@ -182,9 +210,14 @@ struct Ctx {
   __device__ int nlanes() const { return 64; }
   __device__ int wave() const { return threadIdx.x >> 6; }
   __device__ int nwaves() const { return blockDim.x >> 6; }
-  // lanes of one wave run in lockstep; this only orders their LDS traffic
-  __device__ void wave_sync() const { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+  // lanes of one wave run in lockstep; this only orders their memory traffic (LDS: in-order per
+  // wave; spilled arrays in HBM: wait for the vector-memory counters as well)
+  __device__ void wave_sync() const {
+    if (kHbm) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+  }
 };
+typedef CtxT<false> Ctx;
 #endif
 
 #define OMGX_PFOR(i, n) for (int i = c.tid(); i < (n); i += c.nthr())

@@ -135,6 +135,8 @@ def load_library(path=None):
     lib.omgx_batch_set_options.argtypes = [C.c_void_p, C.POINTER(COptions)]
     lib.omgx_batch_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.omgx_batch_lds_bytes.argtypes = [C.c_void_p]
+    lib.omgx_batch_workspace.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.omgx_batch_solve.argtypes = [C.c_void_p] + [C.c_void_p] * 8 + [C.c_int32]
     lib.omgx_batch_sync.argtypes = [C.c_void_p]
     lib.omgx_batch_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -193,6 +195,15 @@ class BatchSolver(object):
     @property
     def lds_bytes(self):
         return self.lib.omgx_batch_lds_bytes(self._h)
+
+    def workspace(self):
+        """Placement chosen by the library: mode 0 = all per-agent arrays in LDS, 1..3 = KKT /
+        Jacobian / row arrays spilled to an HBM slab per persistent workgroup."""
+        mode, nslab = C.c_int32(), C.c_int32()
+        lds, hbm = C.c_int64(), C.c_int64()
+        _check(self.lib, self.lib.omgx_batch_workspace(self._h, C.byref(mode), C.byref(lds), C.byref(hbm),
+                                                       C.byref(nslab)), 'omgx_batch_workspace')
+        return dict(mode=mode.value, lds_bytes=lds.value, hbm_bytes_per_slab=hbm.value, n_slabs=nslab.value)
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
