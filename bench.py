@@ -41,26 +41,33 @@ def measured_traffic(n_agents):
 
 
 def cpu_baseline(problem, P, opts, n_sample):
-    """Oracle CPU port (one host thread) on a bounded sample of the same workload and the
-    same protocol: cold solve, then warm-started receding-horizon steps (timed)."""
+    """Oracle CPU port on a bounded sample of the same workload and the same protocol (cold solve,
+    then warm-started receding-horizon steps, timed): all host cores (one agent per thread at a
+    time) and, on a quarter of the sample, one thread."""
     from omgtools.batch import BatchP2P
-    n_agents = min(64, P['p'].shape[0])
-    sub = {'p': P['p'][:n_agents], 'x0': P['x0'][:n_agents]}
-    mpc = BatchP2P(problem, sub, ops='numpy', options=opts)
-    mpc.solve_cold()
-    steps = max(1, n_sample // n_agents)
-    ok, its = 0, 0
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        mpc.step()
-        ok += int((mpc.status == 0).sum())
-        its += int(mpc.iters.sum())
-    dt = time.perf_counter() - t0
-    return {'value': ok / dt, 'unit': 'solves/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d receding-horizon steps of the first %d agents of the same batch (same protocol '
-                      'and tolerance), 1 host thread, %.1f s; host has %d cores'
-                      % (steps, n_agents, dt, os.cpu_count()),
-            'mean_iters': its / float(steps * n_agents)}
+    cores = os.cpu_count() or 1
+    out = {}
+    for label, threads, n_agents, budget in (('all', cores, min(64 * cores, P['p'].shape[0]), n_sample),
+                                             ('one', 1, min(64, P['p'].shape[0]), n_sample // (4 * cores) + 64)):
+        sub = {'p': P['p'][:n_agents], 'x0': P['x0'][:n_agents]}
+        mpc = BatchP2P(problem, sub, ops='numpy', options=opts)
+        mpc.n_threads = threads
+        mpc.solve_cold()
+        steps = max(1, budget // n_agents)
+        ok, its = 0, 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            mpc.step()
+            ok += int((mpc.status == 0).sum())
+            its += int(mpc.iters.sum())
+        dt = time.perf_counter() - t0
+        out[label] = dict(rate=ok / dt, steps=steps, agents=n_agents, dt=dt, iters=its / float(steps * n_agents))
+    a, o = out['all'], out['one']
+    return {'value': a['rate'], 'unit': 'solves/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d receding-horizon steps of the first %d agents of the same batch (same protocol and '
+                      'tolerance) on %d host threads, %.1f s; single thread: %d steps of %d agents, %.1f s'
+                      % (a['steps'], a['agents'], cores, a['dt'], o['steps'], o['agents'], o['dt']),
+            'single_thread_value': o['rate'], 'mean_iters': a['iters']}
 
 
 def bench_formation(args, rank, local_rank, world, dist, dev):
@@ -107,6 +114,65 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
         'solved_fraction': n_ok_all / float(N), 'residuals': list(res)}))
 
 
+def bench_cold(args, rank, local_rank, world, dist, dev):
+    """configs[2] / configs[4] (parity-test configurations, not the headline): cold solves of a
+    batch of Quadrotor (K=13, 5 moving circles) or Holonomic3D (K=15, 10 spheres) agents.  Their
+    per-agent arrays exceed one CU's LDS; the library spills to HBM slabs (omgx_batch_workspace)."""
+    from omgtools import scenarios
+    from omgtools.backend import BatchSolver
+    from omgtools.distributed import reduce_report
+    import omgtools.backend as be
+    fn = {'quadrotor': scenarios.quadrotor_p2p, 'holonomic3d': scenarios.holonomic3d_p2p}[args.workload]
+    B = args.agents
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    problem, P = fn(B, seed=20240807 + (3 if args.workload == 'quadrotor' else 5) + 1000 * rank)
+    be.create_nlp = saved
+    tpl = problem.father.template
+    solver = BatchSolver(tpl, B, device=local_rank, options=dict(tol=args.tol, max_iter=300))
+    solver.set_stream(torch.cuda.current_stream().cuda_stream)
+    f64 = dict(dtype=torch.float64, device=dev)
+    p, x0 = torch.as_tensor(P['p'], **f64), torch.as_tensor(P['x0'], **f64)
+    lb, ub = torch.as_tensor(tpl.lb, **f64), torch.as_tensor(tpl.ub, **f64)
+    x, lam = torch.empty_like(x0), torch.zeros((B, tpl.n_con), **f64)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    iters = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    kernel_ms = []
+    for k in range(args.warmup + args.steps):
+        if k == args.warmup:
+            barrier()
+            t0 = time.perf_counter()
+        solver.solve_device(p, x0, lb, ub, x, lam, status, iters, bounds_shared=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms.append(solver.last_kernel_ms())
+    n_ok = int((status == 0).sum().item())
+    it_sum = int(iters.sum().item())
+    elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist if world > 1 else None)
+    if rank != 0:
+        return
+    n = tpl.n_var
+    flops = it_sum * (n ** 3 / 3.0 + 2.0 * n ** 2)
+    k_ms = float(np.mean(kernel_ms))
+    print(json.dumps({
+        'metric': 'cold MPC solves/sec, %s batch' % args.workload, 'value': n_ok_all * args.steps / elapsed,
+        'unit': 'solves/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': '%s: %d agents per GPU, cold solve from the reference initial guess, tol=%g'
+                               % (args.workload, B, args.tol), 'n_var': tpl.n_var, 'n_con': tpl.n_con},
+        'solved_fraction': n_ok / float(B), 'mean_iters': it_sum / float(B), 'workspace': solver.workspace(),
+        'roofline': {'bound': 'mfma', 'kernel': 'ipm_solve_kernel', 'achieved': flops / (k_ms * 1e-3) / 1e12,
+                     'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': flops / (k_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
+                     'kernel_ms': k_ms}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -114,10 +180,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--agents', type=int, default=1024, help='agents per GPU')
     ap.add_argument('--tol', type=float, default=1e-3)
-    ap.add_argument('--cpu-sample', type=int, default=12800,
-                    help='agent-solves timed on one host thread (64 agents x N receding-horizon steps)')
+    ap.add_argument('--cpu-sample', type=int, default=81920,
+                    help='agent-solves timed on the host cores (64 agents per core x N receding-horizon steps)')
     ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--workload', choices=['p2p', 'formation'], default='p2p',
+    ap.add_argument('--workload', choices=['p2p', 'formation', 'quadrotor', 'holonomic3d'], default='p2p',
                     help="p2p = BASELINE.json configs[1] (headline); formation = configs[3], 512-agent ADMM")
     args = ap.parse_args()
 
@@ -133,6 +199,8 @@ def main():
 
     if args.workload == 'formation':
         return bench_formation(args, rank, local_rank, world, dist, dev)
+    if args.workload in ('quadrotor', 'holonomic3d'):
+        return bench_cold(args, rank, local_rank, world, dist, dev)
     from omgtools.scenarios import holonomic_p2p
     from omgtools.batch import BatchP2P
     from omgtools.distributed import reduce_report

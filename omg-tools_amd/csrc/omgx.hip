@@ -331,7 +331,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   UP(d_off, d.n_leaf + 1); UP(b_off, d.n_leaf > 0 ? d.n_leaf : 1);
   UP(pair_a, plan.pair_a.size()); UP(pair_b, plan.pair_b.size()); UP(pair_addr, plan.pair_addr.size());
   UP(je_row, plan.je_row.size()); UP(jt_addr, plan.jt_addr.size()); UP(diag_addr, d.N);
-  UP(h_addr, plan.h_addr.size()); UP(t_row, plan.t_row.size());
+  UP(h_addr, plan.h_addr.size()); UP(t_row, plan.t_row.size()); UP(reg_w, d.N);
   return OMGX_OK;
 }
 

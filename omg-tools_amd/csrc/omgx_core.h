@@ -60,6 +60,7 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* pair_a; const int32_t* pair_b; const int32_t* pair_addr;
   const int32_t* je_row; const int32_t* jt_addr; const int32_t* diag_addr;
   const int32_t* h_addr; const int32_t* t_row;
+  const double* reg_w;   // [N] position order: weight of the inertia correction (1 nonlinear variable, OMGX_DW_LINEAR otherwise)
 };
 
 struct Opts {
@@ -80,6 +81,8 @@ struct Opts {
 #define OMGX_DW_DEC      (1.0 / 3.0)
 #define OMGX_DW_MAX      1e10
 #define OMGX_DW_ZERO     1e-9
+#define OMGX_DW_BACKOFF_MAX 8
+#define OMGX_DW_LINEAR   1e-8   // relative inertia correction of variables that only appear linearly
 #define OMGX_S_MAX       100.0
 #define OMGX_KAPPA_SIGMA 1e10
 #define OMGX_MAX_BACKTRACK 25
@@ -738,10 +741,18 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     }
     sz = c.rsum(sz); cnt0 = c.rsum(cnt0);
     mu = fmin(o.mu_init, fmax(o.tol / 10.0, sz / fmax(1.0, cnt0)));
-    zt = use_t ? mu / t : 0.0;
+    // multiplier of t >= 0: dual feasible in t (nu - v'z - zt = 0) rather than on the central path,
+    // so that the first Newton step in t is O(t) instead of O(nu t^2 / mu)
+  }
+  {
+    double vz0 = 0.0;
+    OMGX_PFOR(r, m) if (w.rtype[r] != ROW_FREE) vz0 += w.vv[r] * w.z[r];
+    vz0 = c.rsum(vz0);
+    zt = use_t ? fmax(mu / t, nu - vz0) : 0.0;
   }
   double f = row_value(T, w, m, w.x);
   double dw_last = 0.0, t_check = t;
+  int dw_hold = 0, dw_backoff = 1;   // inertia-correction tracking (see the factorisation loop)
   int it = 0, status = 1;
 
   for (it = 0; it <= o.max_iter; ++it) {
@@ -841,8 +852,17 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 
     OMGX_TOC(PH_RESID);
     // ---- assemble + factorise with inertia correction --------------------------------
-    // when the previous iteration needed dw > 0, skip the (doomed) dw = 0 attempt and decay instead
-    double dw = (dw_last < OMGX_DW_ZERO) ? 0.0 : dw_last * OMGX_DW_DEC; int failed = 0;
+    // Tracking of the inertia correction dw.  When the previous iteration needed dw > 0 the
+    // (doomed) dw = 0 attempt is skipped.  A decrease dw_last/3 is attempted only every
+    // dw_backoff-th iteration (doubling, up to OMGX_DW_BACKOFF_MAX, each time the decrease
+    // fails; reset by a success); a failed decrease falls back to the value that worked last
+    // time before escalating by OMGX_DW_INC.  Near a solution whose Lagrangian Hessian is
+    // indefinite this keeps dw within [dw*, 3 dw*] instead of cycling through [dw*/3, 10 dw*/3].
+    double dw; int decreasing = 0;
+    if (dw_last < OMGX_DW_ZERO) dw = 0.0;
+    else if (dw_hold > 0) { dw = dw_last; --dw_hold; }
+    else { dw = dw_last * OMGX_DW_DEC; decreasing = 1; }
+    int failed = 0;
     for (;;) {
       OMGX_PFOR(i, kkt_doubles) w.kkt[i] = 0.0;
       c.sync();
@@ -899,7 +919,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       tt_acc = use_t ? c.rsum(tt_acc) : 0.0;
       c.sync();
       OMGX_PFOR(q, N) {
-        double add = dw;
+        // variables without a nonlinear term have zero rows in the Lagrangian Hessian: negative
+        // curvature cannot come from them, and damping them would stall LP-like directions
+        double add = dw * T.reg_w[q];
         if (q == N - 1) add += (use_t ? zt / t : 1.0) + tt_acc;
         w.kkt[T.diag_addr[q]] += add;
       }
@@ -907,8 +929,14 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       OMGX_TOC(PH_ASSEMBLE);
       const int bad = kkt_factor(c, d, K, w);
       OMGX_TOC(PH_FACTOR);
-      if (!bad) break;
-      dw = (dw == 0.0) ? OMGX_DW_FIRST : dw * OMGX_DW_INC;
+      if (!bad) { if (decreasing) dw_backoff = 1; break; }
+      if (decreasing) {            // back to the last value that worked, try less often
+        decreasing = 0; dw = dw_last;
+        dw_backoff = dw_backoff < OMGX_DW_BACKOFF_MAX ? 2 * dw_backoff : OMGX_DW_BACKOFF_MAX;
+        dw_hold = dw_backoff;
+      } else {
+        dw = (dw == 0.0) ? OMGX_DW_FIRST : dw * OMGX_DW_INC;
+      }
       if (dw > OMGX_DW_MAX) { failed = 1; break; }
       c.sync();
     }

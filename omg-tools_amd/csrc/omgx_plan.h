@@ -14,6 +14,7 @@ struct HostPlan {
   int kkt_doubles;
   std::vector<int32_t> pos, blk, eq_index, d_off, b_off;
   std::vector<int32_t> pair_a, pair_b, pair_addr, je_row, jt_addr, diag_addr, h_addr, t_row;
+  std::vector<double> reg_w;
 
   bool build(const omgx_template& t) {
     Dims& d = dims;
@@ -111,6 +112,13 @@ struct HostPlan {
     T.pair_a = pair_a.data(); T.pair_b = pair_b.data(); T.pair_addr = pair_addr.data();
     T.je_row = je_row.data(); T.jt_addr = jt_addr.data(); T.diag_addr = diag_addr.data();
     T.h_addr = h_addr.data(); T.t_row = t_row.data();
+    reg_w.assign(d.N, OMGX_DW_LINEAR);
+    for (int tt = 0; tt < t.row_ptr[m + 1]; ++tt) {
+      const int32_t* tv = t.t_var + 3 * tt;
+      if (tv[1] < 0) continue;                                  // constant or linear term
+      for (int k = 0; k < 3; ++k) if (tv[k] >= 0) reg_w[pos[tv[k]]] = 1.0;
+    }
+    T.reg_w = reg_w.data();
     return true;
   }
 };

@@ -47,9 +47,13 @@ def dual_shift_perm(father):
 class BatchP2P(object):
 
     def __init__(self, problem, P, ops='hip', device=None, options=None, update_time=0.1,
-                 max_iter_step=40):
-        # max_iter_step: iteration cap of a receding-horizon step (real-time budget; an agent that
-        # hits it keeps its last strictly feasible iterate and restarts cold at the next step)
+                 max_iter_step=None, shift_every_spline=True):
+        # max_iter_step: iteration cap of a receding-horizon step (default: the cold-solve cap; an
+        # agent that hits it keeps its last strictly feasible iterate and restarts cold next step).
+        # shift_every_spline: on a knot crossing shift every spline variable like the generated
+        # C++ does (`export/export.py:414-439`); False = the Python rule, names containing 'seg'
+        # only (`optilayer.py:482`), which leaves the stale leading coefficient of g* / eps_* (it
+        # carries no cost just before the crossing, so the barrier parks it far from its bound).
         self.problem = problem
         father = problem.father
         self.tpl = tpl = father.template
@@ -66,7 +70,7 @@ class BatchP2P(object):
         self.o_t = tpl.entry_range(problem.label, 't', 'par')[0]
         self.perm = dual_shift_perm(father)
         ents, mats, off = [], [], 0
-        for label, name, spl in father.shifted_entries():
+        for label, name, spl in father.shifted_entries(every_spline=shift_every_spline):
             lo, rows, cols = tpl.var_layout[(label, name)]
             Tm = shiftoverknot_T(spl['basis'])
             ents.append([lo, rows, cols, off])
@@ -78,7 +82,8 @@ class BatchP2P(object):
         self.time = 0.0
         self.opts = dict(tol=1e-3, max_iter=300)
         self.opts.update(options or {})
-        self.max_iter_cold, self.max_iter_step = self.opts['max_iter'], int(max_iter_step)
+        self.max_iter_cold = self.opts['max_iter']
+        self.max_iter_step = int(max_iter_step) if max_iter_step else self.max_iter_cold
         self.kind = ops
         if ops == 'hip':
             import torch
@@ -102,6 +107,7 @@ class BatchP2P(object):
         else:
             from oracle import port_binding          # test infrastructure only
             self.port = port_binding
+            self.n_threads = 1
             self.p, self.x = np.array(P['p'], float), np.array(P['x0'], float)
             self.lam = np.zeros((self.B, tpl.n_con))
             self.status = np.zeros(self.B, dtype=np.int32)
@@ -120,6 +126,7 @@ class BatchP2P(object):
         else:
             r = self.port.solve(self.tpl, self.p, self.x, lam_g0=self.lam if warm else None,
                                 status0=self.status if warm else None, warm_start=int(warm),
+                                n_threads=self.n_threads,
                                 **dict(self.opts, max_iter=self.max_iter_step if warm else self.max_iter_cold))
             self.x, self.lam, self.status, self.iters = r['x'], r['lam_g'], r['status'], r['iters']
 

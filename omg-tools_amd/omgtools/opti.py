@@ -409,14 +409,19 @@ class OptiFather(object):
                         cache[basis] = init_primal_transform(basis)
                     spl['init'] = cache[basis]
 
-    def shifted_entries(self, seg_shift=None):
+    def shifted_entries(self, seg_shift=None, every_spline=False):
         """Variable entries that `transform_primal_splines` touches: names that
-        contain 'seg<n>' with n in seg_shift (`optilayer.py:470-490`)."""
+        contain 'seg<n>' with n in seg_shift (`optilayer.py:470-490`).  `every_spline`
+        selects the rule of the generated C++ instead, which shifts every spline
+        variable, `g*` / `eps_*` included (`export/export.py:414-439`)."""
         seg_shift = [0] if seg_shift is None else \
             (seg_shift if isinstance(seg_shift, list) else [seg_shift])
         out = []
         for label, child in self.children.items():
             for name, spl in child._splines_prim.items():
+                if every_spline and name in child._variables:
+                    out.append((label, name, spl))
+                    continue
                 if name in child._variables and 'seg' in name and \
                         int(name[name.index('seg') + 3]) in seg_shift:
                     out.append((label, name, spl))

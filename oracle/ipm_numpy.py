@@ -304,11 +304,24 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         z = np.maximum(sig * lam0[iH], o['warm_zmin'])
         y = lam0[iE].copy()
         mu = float(min(o['mu_init'], max(o['tol'] / 10., (s * z).mean())))
-        zt = mu / t if use_t else 0.0
+    # multiplier of t >= 0: dual feasible in t (nu - v'z - c0'y - zt = 0) rather than on the central
+    # path, so that the first Newton step in t is O(t) instead of O(nu t^2 / mu)
+    zt = max(mu / t, nu - v @ z - cE0 @ y) if use_t else 0.0
     dw_last = 0.0
+    dw_hold, dw_backoff = 0, 1
     status, it, nfact = 1, 0, 0
     N = n + 1                      # (x, t)
     t_check = t
+    # inertia correction acts on the variables that appear in a nonlinear term only: the rows
+    # and columns of the Lagrangian Hessian of the others are zero, so negative curvature
+    # cannot come from them (their block of J' Sigma J is positive definite)
+    tv = np.asarray(nlp.t_var).reshape(-1, 3)
+    nl = np.zeros(N, bool)
+    multi = (tv >= 0).sum(axis=1) >= 2
+    nl[np.unique(tv[multi][tv[multi] >= 0])] = True
+    if o.get('reg_t'):
+        nl[n] = True
+    reg = np.where(nl, 1.0, o.get('dw_linear', 1e-8)) if o.get('dw_selective', True) else np.ones(N)
 
     def ftb(vv, dv, tau_):
         neg = dv < 0
@@ -373,21 +386,39 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             M[n, n] += zt / t
         else:
             M[n, n] += 1.0
-        # inertia correction: when the previous iteration needed dw > 0 the
-        # (doomed) dw = 0 attempt is skipped and the last value is decayed instead
-        dw = 0.0 if dw_last < o['dw_zero'] else dw_last * o['dw_dec']
+        # inertia correction tracking (same policy as omgx_core.h): skip the doomed dw = 0 attempt
+        # when the previous iteration needed dw > 0; try dw_last/3 only every dw_backoff-th
+        # iteration (doubling on a failed decrease, reset by a success); a failed decrease falls
+        # back to the value that worked last before escalating by dw_inc
+        decreasing = False
+        if dw_last < o['dw_zero']:
+            dw = 0.0
+        elif dw_hold > 0:
+            dw = dw_last
+            dw_hold -= 1
+        else:
+            dw = dw_last * o['dw_dec']
+            decreasing = True
         tries = 0
         while True:
             K = np.zeros((N + mE, N + mE))
-            K[:N, :N] = M + dw * (np.diag(np.maximum(np.abs(np.diag(M)), o.get('dw_floor', 1e-3))) if o.get('dw_scaled') else np.eye(N))
+            K[:N, :N] = M + dw * np.diag(reg)
             K[N:, :N] = Je
             K[:N, N:] = Je.T
             K[N:, N:] = -o['delta_c'] * np.eye(mE)
             L, d = ldl_nopivot(K)
             nfact += 1
             if np.all(d[:N] > 0) and np.all(d[N:] < 0):
+                if decreasing:
+                    dw_backoff = 1
                 break
-            dw = o['dw_first'] if dw == 0.0 else dw * o['dw_inc']
+            if decreasing:
+                decreasing = False
+                dw = dw_last
+                dw_backoff = min(2 * dw_backoff, o.get('dw_backoff_max', 8))
+                dw_hold = dw_backoff
+            else:
+                dw = o['dw_first'] if dw == 0.0 else dw * o['dw_inc']
             tries += 1
             if dw > o['dw_max']:
                 status = 4

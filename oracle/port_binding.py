@@ -1,5 +1,5 @@
 """ORACLE (test infrastructure): ctypes access to oracle/_build/libomgx_port.so,
-the single-thread host build of the solver core (oracle/port/omgx_port.cpp).
+the host build of the solver core (oracle/port/omgx_port.cpp).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it."""
 import ctypes as C
 import os
@@ -20,11 +20,13 @@ def load():
         build()
     lib = C.CDLL(PORT_PATH)
     lib.omgx_port_solve.restype = C.c_int
+    lib.omgx_port_solve_mt.restype = C.c_int
     return lib
 
 
-def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, status0=None, **options):
-    """Solve B agents on one host thread; returns dict like BatchSolver.solve."""
+def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, status0=None, n_threads=1, **options):
+    """Solve B agents on `n_threads` host threads (one agent per thread at a time); returns a
+    dict like BatchSolver.solve."""
     from omgtools.backend import make_ctemplate, make_options
     lib = load()
     ct, keep = make_ctemplate(template, plan)
@@ -41,12 +43,12 @@ def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, status0=N
     status = np.zeros(B, dtype=np.int32) if status0 is None else \
         np.ascontiguousarray(status0, dtype=np.int32).copy()
     iters = np.empty(B, dtype=np.int32)
-    rc = lib.omgx_port_solve(C.byref(ct), C.byref(opt), C.c_int32(B),
+    rc = lib.omgx_port_solve_mt(C.byref(ct), C.byref(opt), C.c_int32(B),
                              C.c_void_p(p.ctypes.data), C.c_void_p(x0.ctypes.data),
                              C.c_void_p(lbg.ctypes.data), C.c_void_p(ubg.ctypes.data),
                              C.c_int32(shared), C.c_void_p(x.ctypes.data),
                              C.c_void_p(lam.ctypes.data), C.c_void_p(status.ctypes.data),
-                             C.c_void_p(iters.ctypes.data))
+                             C.c_void_p(iters.ctypes.data), C.c_int32(int(n_threads)))
     if rc != 0:
         raise RuntimeError('omgx_port_solve failed: %d' % rc)
     return dict(x=x, lam_g=lam, status=status, iters=iters)
