@@ -114,14 +114,18 @@ class BatchP2P(object):
             self.iters = np.zeros(self.B, dtype=np.int32)
 
     # -- solves ------------------------------------------------------------------------
-    def _solve(self, warm):
+    def _solve(self, warm, events=None):
         if self.kind == 'hip':
             self.solver.set_options(warm_start=int(warm),
                                     max_iter=self.max_iter_step if warm else self.max_iter_cold)
             if not warm:
                 self.lam.zero_()
+            if events is not None:                 # torch events on the launch stream (bench.py)
+                events[0].record()
             self.solver.solve_device(self.p, self.x, self.lb, self.ub, self.x_new, self.lam,
                                      self.status, self.iters, bounds_shared=True)
+            if events is not None:
+                events[1].record()
             self.x, self.x_new = self.x_new, self.x
         else:
             r = self.port.solve(self.tpl, self.p, self.x, lam_g0=self.lam if warm else None,
@@ -134,7 +138,7 @@ class BatchP2P(object):
         self._solve(False)
 
     # -- one receding-horizon step ---------------------------------------------------------
-    def step(self):
+    def step(self, events=None):
         xp = self.torch if self.kind == 'hip' else np
         B, L, nd = self.B, self.L, self.n_dim
         t_prev = self.time
@@ -160,7 +164,7 @@ class BatchP2P(object):
         self.time = t_now
         self.p[:, self.o_t] = float(np.round(t_now, 6) % self.knot_time)
         # (3) warm-started solve
-        self._solve(True)
+        self._solve(True, events)
         return crossed
 
     def _shift(self):

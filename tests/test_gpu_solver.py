@@ -59,7 +59,7 @@ def test_cfg2_matches_port_and_numpy(cfg2_small):
         f_gpu, g = nlp.fg(res['x'][b], c)
         f_ref, _ = nlp.fg(ref['x'][b], c)
         assert abs(f_gpu - f_ref) < 1e-6
-        assert (g - tpl.ub).max() < 1e-6 and (tpl.lb - g).max() < 1e-6
+        assert (g - tpl.ub).max() < 1e-5 and (tpl.lb - g).max() < 1e-5      # tol x row scaling
     # independent dense statement of the same iteration (no block structure, no MFMA): at this
     # tolerance its unpivoted dense LDL' may give up on the last ill-conditioned iterations, so
     # take the first agent it finishes
