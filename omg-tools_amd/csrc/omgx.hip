@@ -65,6 +65,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 #ifdef OMGX_PROFILE
     if (threadIdx.x < omgx::PH_COUNT) prof_lds[threadIdx.x] = 0;
     __syncthreads();
+    const long long t_begin = clock64();
 #endif
     const double* lbb = lb + (bounds_shared ? 0 : (size_t)b * d.n_con);
     const double* ubb = ub + (bounds_shared ? 0 : (size_t)b * d.n_con);
@@ -78,6 +79,9 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
           (r.status == 3 || w.rtype[q] == omgx::ROW_FREE) ? 0.0 : w.rho[q] * w.z[q];
     if (threadIdx.x == 0) { status[b] = r.status; iters[b] = r.iters; }
 #ifdef OMGX_PROFILE
+    __syncthreads();
+    if (threadIdx.x == 0) prof_lds[omgx::PH_TOTAL] = clock64() - t_begin;
+    __syncthreads();
     if (prof && threadIdx.x < omgx::PH_COUNT) prof[(size_t)b * omgx::PH_COUNT + threadIdx.x] = prof_lds[threadIdx.x];
 #endif
     __syncthreads();

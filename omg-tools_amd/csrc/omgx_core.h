@@ -226,7 +226,7 @@ typedef CtxT<false> Ctx;
 #define OMGX_PFOR(i, n) for (int i = c.tid(); i < (n); i += c.nthr())
 
 // optional per-phase cycle counters (profiling build only, -DOMGX_PROFILE)
-enum { PH_JAC = 0, PH_RESID, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_STEP, PH_LINESEARCH, PH_UPDATE, PH_F_LEAF, PH_F_SCHUR, PH_F_ROOT, PH_LA, PH_LS, PH_LB, PH_COUNT };
+enum { PH_JAC = 0, PH_RESID, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_STEP, PH_LINESEARCH, PH_UPDATE, PH_F_LEAF, PH_F_SCHUR, PH_F_ROOT, PH_LA, PH_LS, PH_LB, PH_SETUP, PH_TOTAL, PH_COUNT };
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
 #define OMGX_TIC() long long tic_ = (c.sync(), clock64())
 #define OMGX_TOC(k) do { c.sync(); long long now_ = clock64(); if (c.tid() == 0) c.prof[k] += now_ - tic_; tic_ = now_; } while (0)
@@ -250,41 +250,54 @@ OMGX_FN double pp_eval(const Tables& T, int pp, const double* a) {
   return tot;
 }
 
-OMGX_FN void bspl_row(const double* k, int nk, int deg, double u, double* out, double* tmp) {
-  // tmp: nk-1 doubles; out: nk-deg-1 doubles
-  for (int i = 0; i < nk - 1; ++i) {
-    bool left_closed = (i < deg + 1) && (k[0] == k[i]);
-    bool lo = left_closed ? (u >= k[i]) : (u > k[i]);
-    tmp[i] = (lo && u <= k[i + 1]) ? 1.0 : 0.0;
+// B_{i,deg}(u) by its own Cox-de Boor triangle (deg <= 5): every basis function is independent, so a
+// row of them is evaluated by as many threads; no dynamically indexed local array (scratch memory).
+OMGX_FN double bspl_entry(const double* k, int deg, double u, int i) {
+  double b[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int idx = i + j;
+    double v = 0.0;
+    if (j <= deg) {
+      const bool left_closed = (idx < deg + 1) && (k[0] == k[idx]);
+      const bool lo = left_closed ? (u >= k[idx]) : (u > k[idx]);
+      v = (lo && u <= k[idx + 1]) ? 1.0 : 0.0;
+    }
+    b[j] = v;
   }
-  for (int d = 1; d <= deg; ++d) {
-    for (int i = 0; i < nk - d - 1; ++i) {
-      double b = 0.0;
-      double den = k[i + d] - k[i];
-      if (den != 0.0) b = (u - k[i]) * tmp[i] / den;
-      den = k[i + d + 1] - k[i + 1];
-      if (den != 0.0) b += (k[i + d + 1] - u) * tmp[i + 1] / den;
-      tmp[i] = b;
+#pragma unroll
+  for (int r = 1; r <= 5; ++r) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (r <= deg && j <= deg - r) {
+        const int idx = i + j;
+        double v = 0.0;
+        double den = k[idx + r] - k[idx];
+        if (den != 0.0) v = (u - k[idx]) * b[j] / den;
+        den = k[idx + r + 1] - k[idx + 1];
+        if (den != 0.0) v += (k[idx + r + 1] - u) * b[j + 1] / den;
+        b[j] = v;
+      }
     }
   }
-  for (int i = 0; i < nk - deg - 1; ++i) out[i] = tmp[i];
+  return b[0];
 }
 
 template <class C>
 OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, const double* p) {
   OMGX_PFOR(i, d.n_par) w.atoms[i] = p[i];
   c.sync();
-  if (c.tid() == 0) {
-    for (int k = 0; k < d.n_prog; ++k) {
-      const int32_t* op = T.prog + 6 * k;
-      if (op[0] == OP_DIV) {
-        w.atoms[op[3]] = pp_eval(T, op[1], w.atoms) / pp_eval(T, op[2], w.atoms);
-      } else {
-        bspl_row(T.knots + op[1], op[2], op[3], w.atoms[op[4]], w.atoms + op[5], w.sol);
-      }
+  for (int k = 0; k < d.n_prog; ++k) {          // ops in order (an op may read atoms of earlier ones)
+    const int32_t* op = T.prog + 6 * k;
+    if (op[0] == OP_DIV) {
+      if (c.tid() == 0) w.atoms[op[3]] = pp_eval(T, op[1], w.atoms) / pp_eval(T, op[2], w.atoms);
+    } else {
+      const int nout = op[2] - op[3] - 1;
+      const double u = w.atoms[op[4]];
+      OMGX_PFOR(i, nout) w.atoms[op[5] + i] = bspl_entry(T.knots + op[1], op[3], u, i);
     }
+    c.sync();
   }
-  c.sync();
   OMGX_PFOR(s, d.n_slots) w.slots[s] = pp_eval(T, T.slot_pp[s], w.atoms);
   c.sync();
 }
@@ -366,7 +379,8 @@ struct Kkt {
 struct BMat { int a, ld, nfact, rows, npos, dinv, pan, pad_; };   // a: offset in kkt; dinv: offset in w.dinv (-1: none); pan: offset in w.col
 static_assert(sizeof(BMat) <= 4 * sizeof(double), "BMat larger than its LDS slot");
 #define OMGX_NB 4
-#define OMGX_PAN_LD 9      // panel buffer row stride (odd: conflict-free row-per-lane access)
+#define OMGX_PAN_LD 5      // panel buffer row stride: U[4] + pad (odd: conflict-free row-per-lane access)
+#define OMGX_STAGE_LD 20   // per matrix: 4x4 block rows [16] + inverse pivots of the block [4]
 
 OMGX_FN int baddr(const BMat& M, int r, int k) { return M.a + (M.ld ? r * M.ld + k : tri(r, k)); }
 
@@ -414,7 +428,7 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
         // (other threads are still reading the original block).  No dynamically
         // indexed local arrays here: they would live in scratch memory.
         const int q = r - jb;
-        double* st = stage + mi * 16 + q * 4;
+        double* st = stage + mi * OMGX_STAGE_LD + q * 4;
         const double dq = q == 0 ? B.d0 : (q == 1 ? B.d1 : (q == 2 ? B.d2 : B.d3));
         const double iq = q == 0 ? B.i0 : (q == 1 ? B.i1 : (q == 2 ? B.i2 : B.i3));
         if (q == 1) { st[0] = B.l10; }
@@ -424,8 +438,10 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
         const bool pos_ok = (jb + q < M.npos) ? (dq > 0.0) : (dq < 0.0);
         if (!pos_ok) badl = 1;
         if (M.dinv >= 0) dinvb[M.dinv + jb + q] = iq;
+        stage[mi * OMGX_STAGE_LD + 16 + q] = iq;
+        if (q == 0) for (int qq = nb; qq < OMGX_NB; ++qq) stage[mi * OMGX_STAGE_LD + 16 + qq] = 0.0;
         double* pr = colb + M.pan + r * OMGX_PAN_LD;
-        pr[0] = 0.0; pr[1] = 0.0; pr[2] = 0.0; pr[3] = 0.0; pr[4] = 0.0; pr[5] = 0.0; pr[6] = 0.0; pr[7] = 0.0;
+        pr[0] = 0.0; pr[1] = 0.0; pr[2] = 0.0; pr[3] = 0.0;
       } else {
         const int base = baddr(M, r, jb);
         const double a0 = A[base];
@@ -440,7 +456,6 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
                      p3 = nb > 3 ? u3 * B.i3 : 0.0;
         double* pr = colb + M.pan + r * OMGX_PAN_LD;
         pr[0] = u0; pr[1] = nb > 1 ? u1 : 0.0; pr[2] = nb > 2 ? u2 : 0.0; pr[3] = nb > 3 ? u3 : 0.0;
-        pr[4] = p0; pr[5] = p1; pr[6] = p2; pr[7] = p3;
         const bool fact_row = r < M.nfact;
         A[base] = fact_row ? p0 : u0;
         if (nb > 1) A[base + 1] = fact_row ? p1 : u1;
@@ -454,7 +469,7 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
     OMGX_PFOR(it, nm * 16) {
       const int mi = it >> 4, q = (it >> 2) & 3, k = it & 3;
       const BMat M = Ms[mi];
-      if (jb < M.nfact && jb + q < M.nfact && k <= q) A[baddr(M, jb + q, jb + k)] = stage[it];
+      if (jb < M.nfact && jb + q < M.nfact && k <= q) A[baddr(M, jb + q, jb + k)] = stage[mi * OMGX_STAGE_LD + (it & 15)];
     }
     OMGX_TOC(PH_LS);
     // ---- phase B: trailing update, 16x16 tiles -------------------------------------------
@@ -470,7 +485,8 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
         const int kmax = r < M.nfact ? r : M.nfact - 1;
         for (int k = s0; k <= kmax; ++k) {
           double acc = 0.0;
-          for (int q = 0; q < OMGX_NB; ++q) acc += colb[M.pan + r * OMGX_PAN_LD + q] * colb[M.pan + k * OMGX_PAN_LD + 4 + q];
+          for (int q = 0; q < OMGX_NB; ++q)
+            acc += colb[M.pan + r * OMGX_PAN_LD + q] * (colb[M.pan + k * OMGX_PAN_LD + q] * stage[mi * OMGX_STAGE_LD + 16 + q]);
           A[baddr(M, r, k)] -= acc;
         }
       }
@@ -483,7 +499,7 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
         if (K0 > R0 + 15 && R0 + 15 < M.nfact) continue;           // tile entirely above the diagonal
         const int ra = R0 + (lane & 15), kb = K0 + (lane & 15), q = lane >> 4;
         const double av = (ra < M.rows) ? -colb[M.pan + ra * OMGX_PAN_LD + q] : 0.0;
-        const double bv = (kb < M.nfact) ? colb[M.pan + kb * OMGX_PAN_LD + 4 + q] : 0.0;
+        const double bv = (kb < M.nfact) ? colb[M.pan + kb * OMGX_PAN_LD + q] * stage[mi * OMGX_STAGE_LD + 16 + q] : 0.0;
         typedef double v4d __attribute__((ext_vector_type(4)));
         v4d acc;
         const int col = K0 + (lane & 15);
@@ -517,7 +533,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   // matrix descriptors live in LDS (shared by the workgroup), then staging, then panel buffers
   BMat* Ms = (BMat*)w.col;
   double* stage = w.col + OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1);
-  const int pan0 = (int)(stage + 16 * (OMGX_MAX_LEAF + 1) - w.col);
+  const int pan0 = (int)(stage + OMGX_STAGE_LD * (OMGX_MAX_LEAF + 1) - w.col);
   if (c.tid() == 0) {
     int pan = pan0;
     for (int l = 0; l < d.n_leaf; ++l) {
@@ -676,6 +692,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   const int n = d.n_var, m = d.n_con, N = d.N;
   Result res; res.status = 1; res.iters = 0; res.f = 0; res.mu = o.mu_init; res.t = 0;
   Kkt K; K.d = &d; K.T = &T; K.a = w.kkt;
+  OMGX_TIC();
 
   eval_params(c, d, T, w, p);
   OMGX_PFOR(i, n) w.x[i] = x0[i];
@@ -754,6 +771,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   double dw_last = 0.0, t_check = t;
   int dw_hold = 0, dw_backoff = 1;   // inertia-correction tracking (see the factorisation loop)
   int it = 0, status = 1;
+  OMGX_TOC(PH_SETUP);
 
   for (it = 0; it <= o.max_iter; ++it) {
     OMGX_TIC();

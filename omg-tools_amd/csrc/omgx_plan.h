@@ -23,6 +23,8 @@ struct HostPlan {
     d.N = t.n_var + 1; d.n_leaf = t.n_leaf; d.n_root = t.n_root; d.n_eq = t.n_eq;
     d.nnz_j = t.nnz_j; d.root_off = t.leaf_off[t.n_leaf]; d.nr = t.n_root + t.n_eq;
     if (d.root_off + d.n_root != d.N) return false;
+    for (int k = 0; k < d.n_prog; ++k)                          // bspl_entry holds a triangle of degree <= 5
+      if (t.prog[6 * k] == OP_BSPL && (t.prog[6 * k + 3] < 0 || t.prog[6 * k + 3] > 5)) return false;
     pos.assign(d.N, -1); blk.assign(d.N, -1);
     for (int q = 0; q < d.N; ++q) { if (t.order[q] < 0 || t.order[q] >= d.N) return false; pos[t.order[q]] = q; }
     if (t.order[d.N - 1] != t.n_var) return false;       // t must be the last position
@@ -42,7 +44,7 @@ struct HostPlan {
       int leaf_rows = 0;
       for (int l = 0; l < d.n_leaf; ++l) leaf_rows += (t.leaf_off[l + 1] - t.leaf_off[l]) + (t.cpl_ptr[l + 1] - t.cpl_ptr[l]);
       const int pr = leaf_rows > d.nr ? leaf_rows : d.nr;
-      d.col_doubles = (OMGX_BMAT_DOUBLES + 16) * (OMGX_MAX_LEAF + 1) + OMGX_PAN_LD * pr;
+      d.col_doubles = (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + OMGX_PAN_LD * pr;
       if (d.n_leaf > OMGX_MAX_LEAF) return false;
     }
     kkt_doubles = off;

@@ -244,7 +244,7 @@ class SolverPlan(object):
     """
     MIN_LEAF = 8
 
-    def __init__(self, tpl, root_hint=('splines_seg',)):
+    def __init__(self, tpl, root_hint=('splines_seg',), gather_small=True):
         n, m = tpl.n_var, tpl.n_con
         self.n_var, self.n_con = n, m
         rows_vars = []
@@ -287,12 +287,20 @@ class SolverPlan(object):
         for v in range(n):
             if v not in root:
                 comps.setdefault(find(v), []).append(v)
-        leaves = []
+        # Components smaller than MIN_LEAF (e.g. every coefficient of the terminal slacks g*, which
+        # meets the rest of the problem through one trajectory coefficient only) are gathered into
+        # one extra leaf: its block is block-diagonal, and eliminating it leaf-style keeps those
+        # variables out of the dense root factorisation.
+        leaves, small = [], []
         for comp in sorted(comps.values(), key=lambda c: c[0]):
             if len(comp) < self.MIN_LEAF:
-                root.update(comp)
+                small.extend(comp)
             else:
                 leaves.append(sorted(comp))
+        if len(small) >= self.MIN_LEAF and gather_small:
+            leaves.append(sorted(small))
+        else:
+            root.update(small)
         self.leaves = leaves
         self.n_leaf = len(leaves)
         root_vars = sorted(root) + [n]                 # t last

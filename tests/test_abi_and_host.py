@@ -55,7 +55,9 @@ def test_solver_plan_is_block_arrow(cfg2_small):
     problem, _ = cfg2_small
     tpl = problem.father.template
     plan = SolverPlan(tpl)
-    assert plan.n_leaf == 3 and [len(l) for l in plan.leaves] == [36, 36, 36]
+    # three hyperplane leaves + the gathered terminal slacks g0, g1 (each coefficient a singleton)
+    assert plan.n_leaf == 4 and [len(l) for l in plan.leaves] == [36, 36, 36, 28]
+    assert plan.n_root == 28 + 1
     assert sorted(plan.order.tolist()) == list(range(tpl.n_var + 1)) and plan.order[-1] == tpl.n_var
     assert plan.n_eq == 10
 

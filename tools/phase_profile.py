@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
 import omgtools.backend as be
 
-PHASES = ['jac', 'resid', 'assemble', 'factor', 'solve', 'step', 'linesearch', 'update', 'f_leaf', 'f_schur', 'f_root', 'l_A', 'l_stage', 'l_B']
+PHASES = ['jac', 'resid', 'assemble', 'factor', 'solve', 'step', 'linesearch', 'update', 'f_leaf', 'f_schur', 'f_root', 'l_A', 'l_stage', 'l_B', 'setup', 'total']
 
 
 def main():
@@ -25,19 +25,26 @@ def main():
     be.create_nlp = saved
     tpl = problem.father.template
     solver = be.BatchSolver(tpl, B, options=dict(tol=1e-3, max_iter=300))
+    warm = len(sys.argv) > 2 and sys.argv[2] == 'warm'
     for _ in range(2):
         res = solver.solve(P['p'], P['x0'])
+    if warm:      # re-solve from the solution with its multipliers: the steady-state MPC case
+        solver.set_options(warm_start=1)
+        res = solver.solve(P['p'], res['x'], lam_g0=res['lam_g'], status0=res['status'])
     ms = solver.last_kernel_ms()
     prof = np.zeros((B, len(PHASES)), dtype=np.int64)
     solver.lib.omgx_batch_phase_cycles.argtypes = [C.c_void_p, C.c_void_p]
     solver.lib.omgx_batch_phase_cycles(solver._h, prof.ctypes.data)
-    its = res['iters'].sum()
+    its = max(1, res['iters'].sum())
     tot = prof[:, :8].sum()
     out = {'agents': B, 'kernel_ms': ms, 'sum_iters': int(its),
            'solved': int((res['status'] == 0).sum()),
            'cycles_per_iter': {p: float(prof[:, k].sum() / its) for k, p in enumerate(PHASES)},
            'share': {p: float(prof[:, k].sum() / tot) for k, p in enumerate(PHASES)},
-           'total_cycles_per_iter': float(tot / its)}
+           'total_cycles_per_iter': float(tot / its),
+           'per_agent': {'setup': float(prof[:, PHASES.index('setup')].mean()),
+                         'total': float(prof[:, PHASES.index('total')].mean()),
+                         'loop': float(prof[:, :8].sum(axis=1).mean()), 'iters': float(res['iters'].mean())}}
     print(json.dumps(out, indent=1))
 
 
