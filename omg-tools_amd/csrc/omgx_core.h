@@ -384,6 +384,19 @@ static_assert(sizeof(BMat) <= 4 * sizeof(double), "BMat larger than its LDS slot
 
 OMGX_FN int baddr(const BMat& M, int r, int k) { return M.a + (M.ld ? r * M.ld + k : tri(r, k)); }
 
+// reciprocal of a pivot: v_rcp_f64 (about 2^-29 relative) + two Newton steps instead of the
+// ~15-instruction IEEE division sequence; exact division on the host port
+#ifdef OMGX_HOST_PORT
+OMGX_FN double rcp_pivot(double d) { return 1.0 / d; }
+#else
+OMGX_FN double rcp_pivot(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  y = fma(fma(-d, y, 1.0), y, y);
+  y = fma(fma(-d, y, 1.0), y, y);
+  return y;
+}
+#endif
+
 // 4x4 (or smaller) diagonal block LDL' from the stored lower entries
 struct Blk4 { double l10, l20, l21, l30, l31, l32, d0, d1, d2, d3, i0, i1, i2, i3; };
 OMGX_FN Blk4 blk4_factor(const BMat& M, const double* A, int jb, int nb) {
@@ -394,15 +407,15 @@ OMGX_FN Blk4 blk4_factor(const BMat& M, const double* A, int jb, int nb) {
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int k = 0; k <= a; ++k) g[a][k] = (a < nb) ? A[baddr(M, jb + a, jb + k)] : (a == k ? 1.0 : 0.0);
-  b.d0 = g[0][0]; b.i0 = 1.0 / b.d0;
+  b.d0 = g[0][0]; b.i0 = rcp_pivot(b.d0);
   b.l10 = g[1][0] * b.i0; b.l20 = g[2][0] * b.i0; b.l30 = g[3][0] * b.i0;
-  b.d1 = g[1][1] - b.l10 * g[1][0]; b.i1 = 1.0 / b.d1;
+  b.d1 = g[1][1] - b.l10 * g[1][0]; b.i1 = rcp_pivot(b.d1);
   const double w21 = g[2][1] - g[2][0] * b.l10, w31 = g[3][1] - g[3][0] * b.l10;
   b.l21 = w21 * b.i1; b.l31 = w31 * b.i1;
-  b.d2 = g[2][2] - b.l20 * g[2][0] - b.l21 * w21; b.i2 = 1.0 / b.d2;
+  b.d2 = g[2][2] - b.l20 * g[2][0] - b.l21 * w21; b.i2 = rcp_pivot(b.d2);
   const double w32 = g[3][2] - g[3][0] * b.l20 - w31 * b.l21;
   b.l32 = w32 * b.i2;
-  b.d3 = g[3][3] - b.l30 * g[3][0] - b.l31 * w31 - b.l32 * w32; b.i3 = 1.0 / b.d3;
+  b.d3 = g[3][3] - b.l30 * g[3][0] - b.l31 * w31 - b.l32 * w32; b.i3 = rcp_pivot(b.d3);
   return b;
 }
 
@@ -413,13 +426,25 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
   int nmax = 0, total_rows = 0;
   for (int i = 0; i < nm; ++i) { if (Ms[i].nfact > nmax) nmax = Ms[i].nfact; total_rows += Ms[i].rows; }
   int badl = 0;
+  // row -> (matrix, local row) of this thread's first row: static over the panel loop, so the
+  // descriptor walk (dependent LDS reads) is done once, not once per panel
+  int mi_own = 0, r_own = c.tid();
+  BMat M_own = Ms[0];
+  if (c.tid() < total_rows) {
+    while (r_own >= Ms[mi_own].rows) { r_own -= Ms[mi_own].rows; ++mi_own; }
+    M_own = Ms[mi_own];
+  }
   OMGX_TIC();
   for (int jb = 0; jb < nmax; jb += OMGX_NB) {
     // ---- phase A: panel ---------------------------------------------------------------
     OMGX_PFOR(it, total_rows) {
-      int mi = 0, r = it;
-      while (r >= Ms[mi].rows) { r -= Ms[mi].rows; ++mi; }
-      const BMat M = Ms[mi];                       // by value: keep the descriptor in registers
+      int mi = mi_own, r = r_own;
+      BMat M = M_own;                              // by value: keep the descriptor in registers
+      if (it != c.tid()) {                         // more rows than threads: later passes
+        mi = 0; r = it;
+        while (r >= Ms[mi].rows) { r -= Ms[mi].rows; ++mi; }
+        M = Ms[mi];
+      }
       if (jb >= M.nfact || r < jb) continue;
       const int nb = (M.nfact - jb) < OMGX_NB ? (M.nfact - jb) : OMGX_NB;
       const Blk4 B = blk4_factor(M, A, jb, nb);
