@@ -145,6 +145,16 @@ int  omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off,
                        int32_t n_der, const double* t0, double dt, int32_t n_samp,
                        void* out, int32_t as_f32, int32_t flags);
 
+/* Ideal prediction + horizon bookkeeping of one receding-horizon step, device-resident x [B,n_var]
+ * and p [B,n_par] (reference `vehicles/vehicle.py:323-326` with `ideal_prediction`, C++
+ * `Vehicle::predict` Vehicle.cpp:61-80; `problems/point2point.py:174-198`): for every agent and
+ * spline k < n_spl,  p[p_state0+k] <- spline_k(tau),  p[p_input0+k] <- spline_k'(tau) * inv_T
+ * (tau in the spline domain [0,1], inv_T = 1/horizon_time), and p[p_t] <- t_value (p_t < 0: skip).
+ * knots: host pointer, n_knots <= 40.  Asynchronous on the handle's stream. */
+int  omgx_batch_predict(omgx_batch* b, const double* x, double* p, int32_t coeff_off, int32_t n_spl,
+                        int32_t degree, const double* knots, int32_t n_knots, double tau, double inv_T,
+                        int32_t p_state0, int32_t p_input0, int32_t p_t, double t_value);
+
 /* Same shift on any device-resident row-major array (stride doubles per row, n_rows rows):
  * used for the ADMM consensus state on a knot crossing (`problems/admm.py:477-491`). */
 int  omgx_shift_rows(omgx_batch* b, double* data, int32_t stride, int32_t n_rows, const uint8_t* mask,

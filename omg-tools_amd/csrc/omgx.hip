@@ -151,6 +151,68 @@ sample_kernel(const double* __restrict__ x, int x_stride, int coeff_off, int n_s
   }
 }
 
+// Ideal prediction of one receding-horizon step: thread (agent b, spline k) evaluates the plan and
+// its first derivative at tau by de Boor on the active span and writes them into the parameter
+// vector (state0 / input0), thread k == 0 also the time since the last knot crossing.
+struct KnotArg { double k[40]; };
+__global__ void __launch_bounds__(256)
+predict_kernel(const double* __restrict__ x, int n_var, double* __restrict__ p, int n_par, int B,
+               int coeff_off, int n_spl, int degree, KnotArg kn, int n_knots, double tau, double inv_T,
+               int p_state0, int p_input0, int p_t, double t_value) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * n_spl) return;
+  const int b = id / n_spl, k = id - b * n_spl;
+  const int L = n_knots - degree - 1;
+  const double* c = x + (size_t)b * n_var + coeff_off + k * L;
+  int j = degree;                                  // span: k_j < tau <= k_{j+1} (`basics/spline.py:131-136`)
+  for (int q = degree + 1; q < n_knots - degree - 1; ++q) if (kn.k[q] < tau) j = q;
+  double v[6], dv[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const int i = j - degree + r;
+    v[r] = (r <= degree) ? c[i] : 0.0;
+  }
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {                     // derivative coefficients c'_i, i = j-degree+1+r .. j
+    const int i = j - degree + 1 + r;
+    double den = (r < degree) ? kn.k[i + degree] - kn.k[i] : 0.0;
+    dv[r] = (r < degree && den != 0.0) ? degree * (v[r + 1] - v[r]) / den : 0.0;
+  }
+  dv[5] = 0.0;
+#pragma unroll
+  for (int lev = 1; lev <= 5; ++lev) {
+#pragma unroll
+    for (int r = 5; r >= 1; --r) {
+      if (lev <= degree && r >= lev && r <= degree) {
+        const int i = j - degree + r;
+        const double den = kn.k[i + degree - lev + 1] - kn.k[i];
+        const double a = den != 0.0 ? (tau - kn.k[i]) / den : 0.0;
+        v[r] = (1.0 - a) * v[r - 1] + a * v[r];
+      }
+    }
+  }
+  const int dg = degree - 1;                        // derivative spline: degree-1 on knots k[1 .. n_knots-1)
+#pragma unroll
+  for (int lev = 1; lev <= 4; ++lev) {
+#pragma unroll
+    for (int r = 4; r >= 1; --r) {
+      if (lev <= dg && r >= lev && r <= dg) {
+        const int i = j - degree + 1 + r;           // original index of c'_i
+        const double den = kn.k[i + dg - lev + 1] - kn.k[i];
+        const double a = den != 0.0 ? (tau - kn.k[i]) / den : 0.0;
+        dv[r] = (1.0 - a) * dv[r - 1] + a * dv[r];
+      }
+    }
+  }
+  double val = 0.0, der = 0.0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) { if (r == degree) val = v[r]; if (r == dg) der = dv[r]; }
+  double* pb = p + (size_t)b * n_par;
+  pb[p_state0 + k] = val;
+  pb[p_input0 + k] = der * inv_T;
+  if (k == 0 && p_t >= 0) pb[p_t] = t_value;
+}
+
 __global__ void __launch_bounds__(64)
 shift_kernel(double* __restrict__ x, int x_stride, const uint8_t* __restrict__ mask,
              const int32_t* __restrict__ entries, int n_ent, const double* __restrict__ Tm) {
@@ -583,6 +645,23 @@ int omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off, int32_t
   }
   HIPCHK(hipStreamSynchronize(b->stream));
   (void)hipFree(d_kn);
+  return OMGX_OK;
+}
+
+int omgx_batch_predict(omgx_batch* b, const double* x, double* p, int32_t coeff_off, int32_t n_spl, int32_t degree,
+                       const double* knots, int32_t n_knots, double tau, double inv_T, int32_t p_state0,
+                       int32_t p_input0, int32_t p_t, double t_value) {
+  if (!b || !x || !p || !knots || degree < 1 || degree > 5 || n_knots > 40 || n_knots < 2 * (degree + 1) || n_spl <= 0) {
+    g_err = "bad argument"; return OMGX_E_INVALID;
+  }
+  HIPCHK(hipSetDevice(b->device));
+  const omgx::Dims& d = b->dims;
+  KnotArg kn;
+  for (int i = 0; i < 40; ++i) kn.k[i] = i < n_knots ? knots[i] : 0.0;
+  const int n = b->n_agents * n_spl;
+  hipLaunchKernelGGL(predict_kernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, x, d.n_var, p, d.n_par,
+                     b->n_agents, coeff_off, n_spl, degree, kn, n_knots, tau, inv_T, p_state0, p_input0, p_t, t_value);
+  HIPCHK(hipGetLastError());
   return OMGX_OK;
 }
 

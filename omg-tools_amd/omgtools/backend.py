@@ -142,6 +142,9 @@ def load_library(path=None):
     lib.omgx_batch_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.omgx_batch_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
+    lib.omgx_batch_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_double]
     lib.omgx_batch_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_double,
                                       C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
@@ -262,6 +265,17 @@ class BatchSolver(object):
         _check(self.lib, self.lib.omgx_batch_last_kernel_ms(self._h, C.byref(ms)),
                'omgx_batch_last_kernel_ms')
         return ms.value
+
+    def predict(self, x, p, coeff_off, n_spl, degree, knots, tau, inv_T, p_state0, p_input0, p_t, t_value):
+        """Ideal prediction on device-resident x / p (torch tensors or raw device pointers)."""
+        knots = np.ascontiguousarray(knots, dtype=np.float64)
+
+        def ptr(a):
+            return a.data_ptr() if hasattr(a, 'data_ptr') else int(a)
+        _check(self.lib, self.lib.omgx_batch_predict(
+            self._h, ptr(x), ptr(p), int(coeff_off), int(n_spl), int(degree), knots.ctypes.data, len(knots),
+            float(tau), float(inv_T), int(p_state0), int(p_input0), int(p_t), float(t_value)),
+            'omgx_batch_predict')
 
     def sample(self, x, coeff_off, n_spl, degree, knots, n_der, t0, dt, n_samp,
                out=None, as_f32=False, device=False):

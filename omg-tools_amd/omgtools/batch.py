@@ -139,30 +139,29 @@ class BatchP2P(object):
 
     # -- one receding-horizon step ---------------------------------------------------------
     def step(self, events=None):
-        xp = self.torch if self.kind == 'hip' else np
         B, L, nd = self.B, self.L, self.n_dim
         t_prev = self.time
         t_now = t_prev + self.update_time
         rel_prev = np.round(t_prev, 6) % self.knot_time
-        # (1) ideal prediction on the current plan
+        # (1) ideal prediction on the current plan, (2) horizon bookkeeping
         tau = (rel_prev + self.update_time) / self.T
-        E = self.basis.eval_basis([tau])[0]
-        dbasis, P1 = self.basis.derivative(1)
-        Ed = dbasis.eval_basis([tau])[0] @ P1 / self.T
-        c = self.x[:, self.o_spl:self.o_spl + nd * L].reshape(B, nd, L)
-        if self.kind == 'hip':
-            Ev = xp.as_tensor(E, dtype=xp.float64, device=self.dev)
-            Edv = xp.as_tensor(Ed, dtype=xp.float64, device=self.dev)
-        else:
-            Ev, Edv = E, Ed
-        self.p[:, self.o_state0:self.o_state0 + nd] = c @ Ev
-        self.p[:, self.o_input0:self.o_input0 + nd] = c @ Edv
-        # (2) horizon bookkeeping
         crossed = int(np.round(t_prev / self.knot_time, 6)) < int(np.round(t_now / self.knot_time, 6))
+        t_rel = float(np.round(t_now, 6) % self.knot_time)
+        if self.kind == 'hip':
+            # one kernel: state0 / input0 from the plan at tau and the new t, all written into p
+            self.solver.predict(self.x, self.p, self.o_spl, nd, self.basis.degree, self.basis.knots, tau,
+                                1.0 / self.T, self.o_state0, self.o_input0, self.o_t, t_rel)
+        else:
+            E = self.basis.eval_basis([tau])[0]
+            dbasis, P1 = self.basis.derivative(1)
+            Ed = dbasis.eval_basis([tau])[0] @ P1 / self.T
+            c = self.x[:, self.o_spl:self.o_spl + nd * L].reshape(B, nd, L)
+            self.p[:, self.o_state0:self.o_state0 + nd] = c @ E
+            self.p[:, self.o_input0:self.o_input0 + nd] = c @ Ed
+            self.p[:, self.o_t] = t_rel
         if crossed:
             self._shift()
         self.time = t_now
-        self.p[:, self.o_t] = float(np.round(t_now, 6) % self.knot_time)
         # (3) warm-started solve
         self._solve(True, events)
         return crossed
