@@ -70,7 +70,9 @@ struct Opts {
 };
 
 // fixed constants of the iteration (same values in oracle/ipm_numpy.py DEFAULTS)
+#ifndef OMGX_KAPPA_EPS
 #define OMGX_KAPPA_EPS   10.0
+#endif
 #define OMGX_KAPPA_MU    0.2
 #define OMGX_THETA_MU    1.5
 #define OMGX_TAU_MIN     0.99
@@ -81,13 +83,15 @@ struct Opts {
 #define OMGX_DW_DEC      (1.0 / 3.0)
 #define OMGX_DW_MAX      1e10
 #define OMGX_DW_ZERO     1e-9
+#define OMGX_DW_HEAVY    10.0
+#define OMGX_KAPPA_EPS_HEAVY 100.0
 #define OMGX_DW_BACKOFF_MAX 8
 #define OMGX_DW_LINEAR   1e-8   // relative inertia correction of variables that only appear linearly
 #define OMGX_S_MAX       100.0
 #define OMGX_KAPPA_SIGMA 1e10
 #define OMGX_MAX_BACKTRACK 25
 #define OMGX_NU_MAX      1e8
-#define OMGX_STALL_ITERS 10
+#define OMGX_STALL_ITERS 20
 #define OMGX_WARM_ZMIN   1e-8
 #define OMGX_MAX_LEAF    16
 #define OMGX_BMAT_DOUBLES 4      // sizeof(BMat) / 8
@@ -847,7 +851,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     res.f = f; res.mu = mu; res.t = t; res.iters = it;
     if (err0 <= o.tol) { status = 0; break; }
     if (it == o.max_iter) break;
-    // barrier-problem error at a given mu
+    // barrier-problem error at a given mu.  Under a heavy inertia correction (concave rows with
+    // multipliers ~ mu/s: the negative curvature itself scales with mu) the damped Newton method
+    // crawls on the barrier subproblem, so it is solved less accurately before mu is reduced.
+    const double keps = (dw_last > OMGX_DW_HEAVY) ? OMGX_KAPPA_EPS_HEAVY : OMGX_KAPPA_EPS;
     int infeasible = 0;
     for (;;) {
       double comp = 0.0;
@@ -859,7 +866,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       if (use_t) comp = fmax(comp, fabs(t * zt - mu));
       const double rd_t = use_t ? (nu - vz - zt) : 0.0;
       const double emu = fmax(fmax(rd_max, fabs(rd_t)) / sd, fmax(rE_max, comp / sd));
-      if (mu > o.tol / 10.0 && emu <= OMGX_KAPPA_EPS * mu) {
+      if (mu > o.tol / 10.0 && emu <= keps * mu) {
         mu = fmax(o.tol / 10.0, fmin(OMGX_KAPPA_MU * mu, pow(mu, OMGX_THETA_MU)));
         continue;
       }
@@ -870,7 +877,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       }
       break;
     }
-    // stall test: phase I must shrink t by at least 10 % every OMGX_STALL_ITERS iterations
+    // stall test: phase I must shrink t by at least 10 % over OMGX_STALL_ITERS (20) iterations
     if (use_t && it > 0 && it % OMGX_STALL_ITERS == 0) {
       if (t > o.tol && t > 0.9 * t_check) infeasible = 1;
       t_check = t;
