@@ -47,7 +47,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  const double* __restrict__ lb, const double* __restrict__ ub, int bounds_shared,
                  double* __restrict__ x, double* __restrict__ lam, int32_t* __restrict__ status,
                  int32_t* __restrict__ iters, int n_agents, long long* __restrict__ prof,
-                 double* __restrict__ slabs, size_t slab_doubles) {
+                 double* __restrict__ slabs, size_t slab_doubles, double* __restrict__ dw_state) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
@@ -71,13 +71,13 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
     const double* ubb = ub + (bounds_shared ? 0 : (size_t)b * d.n_con);
     omgx::Result r = omgx::ipm_solve(c, d, T, o, w, p + (size_t)b * d.n_par, x0 + (size_t)b * d.n_var,
                                      lbb, ubb, o.warm_start ? lam + (size_t)b * d.n_con : nullptr,
-                                     o.warm_start ? status[b] : 0, kkt_doubles);
+                                     o.warm_start ? status[b] : 0, kkt_doubles, o.warm_start ? dw_state[b] : 0.0);
     __syncthreads();
     for (int i = threadIdx.x; i < d.n_var; i += blockDim.x) x[(size_t)b * d.n_var + i] = w.x[i];
     for (int q = threadIdx.x; q < d.n_con; q += blockDim.x)
       lam[(size_t)b * d.n_con + q] =
           (r.status == 3 || w.rtype[q] == omgx::ROW_FREE) ? 0.0 : w.rho[q] * w.z[q];
-    if (threadIdx.x == 0) { status[b] = r.status; iters[b] = r.iters; }
+    if (threadIdx.x == 0) { status[b] = r.status; iters[b] = r.iters; dw_state[b] = r.dw; }
 #ifdef OMGX_PROFILE
     __syncthreads();
     if (threadIdx.x == 0) prof_lds[omgx::PH_TOTAL] = clock64() - t_begin;
@@ -89,7 +89,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 }
 
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
-                             const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t);
+                             const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*);
 static ipm_kernel_t ipm_kernel_for(int mode) {
   switch (mode) {
     case omgx::WS_LDS: return ipm_solve_kernel<omgx::WS_LDS>;
@@ -328,6 +328,7 @@ struct omgx_batch {
   int ws_mode = 0, n_slabs = 0;        // workspace placement (omgx::WS_*), HBM slabs (= grid cap)
   size_t slab_doubles = 0;
   double* d_slabs = nullptr;
+  double* d_dw = nullptr;          // per-agent inertia correction carried between warm-started solves
   std::vector<void*> allocs;
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -446,12 +447,13 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
       (rc = dalloc(b, (size_t)n_agents * d.n_con, &b->d_lb)) || (rc = dalloc(b, (size_t)n_agents * d.n_con, &b->d_ub)) ||
       (rc = dalloc(b, (size_t)n_agents * d.n_var, &b->d_x)) || (rc = dalloc(b, (size_t)n_agents * d.n_con, &b->d_lam)) ||
       (rc = dalloc(b, (size_t)n_agents, &b->d_status)) || (rc = dalloc(b, (size_t)n_agents, &b->d_iters)) ||
-      (rc = dalloc(b, (size_t)n_agents * omgx::PH_COUNT, &b->d_prof))) {
+      (rc = dalloc(b, (size_t)n_agents * omgx::PH_COUNT, &b->d_prof)) || (rc = dalloc(b, (size_t)n_agents, &b->d_dw))) {
     omgx_batch_destroy(b); return rc;
   }
   if (hipStreamCreate(&b->own_stream) != hipSuccess || hipEventCreate(&b->ev0) != hipSuccess ||
       hipEventCreate(&b->ev1) != hipSuccess) { g_err = "stream/event creation failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
   b->stream = b->own_stream;
+  if (hipMemset(b->d_dw, 0, (size_t)n_agents * sizeof(double)) != hipSuccess) { g_err = "hipMemset failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
   if (hipFuncSetAttribute((const void*)ipm_kernel_for(b->ws_mode), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)b->lds_bytes) != hipSuccess) {
     g_err = "cannot reserve dynamic LDS for ipm_solve_kernel"; omgx_batch_destroy(b); return OMGX_E_HIP;
@@ -532,7 +534,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   HIPCHK(hipEventRecord(b->ev0, b->stream));
   hipLaunchKernelGGL(ipm_kernel_for(b->ws_mode), dim3(b->n_slabs), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev,
                      b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
-                     b->d_slabs, b->slab_doubles);
+                     b->d_slabs, b->slab_doubles, b->d_dw);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   b->timed = true;

@@ -30,6 +30,10 @@
 #define OMGX_HD __host__ __device__ inline
 #endif
 
+#ifdef OMGX_COUNT_FACT
+#include <atomic>
+static std::atomic<long> omgx_dbg_nfact(0);
+#endif
 namespace omgx {
 
 enum { ROW_FREE = 0, ROW_UPPER = 1, ROW_LOWER = 2, ROW_EQ = 3, ROW_BAD = 4 };
@@ -712,14 +716,14 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
 // ---------------------------------------------------------------------------
 // the solve
 // ---------------------------------------------------------------------------
-struct Result { int status, iters; double f, mu, t; };
+struct Result { int status, iters; double f, mu, t, dw; };
 
 template <class C>
 OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts& o, Work& w,
                          const double* p, const double* x0, const double* lb, const double* ub,
-                         const double* lam0, int prev_status, int kkt_doubles) {
+                         const double* lam0, int prev_status, int kkt_doubles, double dw_prev = 0.0) {
   const int n = d.n_var, m = d.n_con, N = d.N;
-  Result res; res.status = 1; res.iters = 0; res.f = 0; res.mu = o.mu_init; res.t = 0;
+  Result res; res.status = 1; res.iters = 0; res.f = 0; res.mu = o.mu_init; res.t = 0; res.dw = 0;
   Kkt K; K.d = &d; K.T = &T; K.a = w.kkt;
   OMGX_TIC();
 
@@ -797,8 +801,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     zt = use_t ? fmax(mu / t, nu - vz0) : 0.0;
   }
   double f = row_value(T, w, m, w.x);
-  double dw_last = 0.0, t_check = t;
-  int dw_hold = 0, dw_backoff = 1;   // inertia-correction tracking (see the factorisation loop)
+  // a warm start also inherits the inertia correction the previous solve of this agent ended with
+  // (first factorisation at that value instead of climbing 0, 1e-4, 1e-3, ... again)
+  double dw_last = (warm && dw_prev > 0.0) ? dw_prev : 0.0, t_check = t;
+  int dw_hold = dw_last > 0.0 ? 1 : 0, dw_backoff = 1;   // inertia-correction tracking (see the factorisation loop)
   int it = 0, status = 1;
   OMGX_TOC(PH_SETUP);
 
@@ -978,6 +984,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       c.sync();
       OMGX_TOC(PH_ASSEMBLE);
       const int bad = kkt_factor(c, d, K, w);
+#ifdef OMGX_COUNT_FACT
+      ++omgx_dbg_nfact;
+#endif
       OMGX_TOC(PH_FACTOR);
       if (!bad) { if (decreasing) dw_backoff = 1; break; }
       if (decreasing) {            // back to the last value that worked, try less often
@@ -1089,6 +1098,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     OMGX_TOC(PH_UPDATE);
   }
   res.status = status; res.iters = it > o.max_iter ? o.max_iter : it; res.f = f; res.mu = mu; res.t = t;
+  res.dw = dw_last;
   return res;
 }
 

@@ -108,6 +108,7 @@ class BatchP2P(object):
             from oracle import port_binding          # test infrastructure only
             self.port = port_binding
             self.n_threads = 1
+            self.dw = np.zeros(self.B)            # inertia correction carried between warm solves
             self.p, self.x = np.array(P['p'], float), np.array(P['x0'], float)
             self.lam = np.zeros((self.B, tpl.n_con))
             self.status = np.zeros(self.B, dtype=np.int32)
@@ -130,7 +131,7 @@ class BatchP2P(object):
         else:
             r = self.port.solve(self.tpl, self.p, self.x, lam_g0=self.lam if warm else None,
                                 status0=self.status if warm else None, warm_start=int(warm),
-                                n_threads=self.n_threads,
+                                n_threads=self.n_threads, dw_state=self.dw,
                                 **dict(self.opts, max_iter=self.max_iter_step if warm else self.max_iter_cold))
             self.x, self.lam, self.status, self.iters = r['x'], r['lam_g'], r['status'], r['iters']
 

@@ -20,10 +20,12 @@
 #include "../../omg-tools_amd/csrc/omgx_core.h"
 #include "../../omg-tools_amd/csrc/omgx_plan.h"
 
+// dw_state [n_agents] (may be null): inertia correction carried between warm-started solves, the
+// state the HIP library keeps inside its handle
 extern "C" int omgx_port_solve_mt(const omgx_template* tpl, const omgx_options* opt, int32_t n_agents,
                                   const double* p, const double* x0, const double* lbg, const double* ubg,
                                   int32_t bounds_shared, double* x, double* lam_g, int32_t* status,
-                                  int32_t* iters, int32_t n_threads) {
+                                  int32_t* iters, int32_t n_threads, double* dw_state) {
   omgx::HostPlan plan;
   if (!plan.build(*tpl)) return OMGX_E_INVALID;
   omgx::Opts o;
@@ -43,7 +45,9 @@ extern "C" int omgx_port_solve_mt(const omgx_template* tpl, const omgx_options* 
       omgx::Result r = omgx::ipm_solve(c, d, plan.tables, o, w, p + (size_t)b * d.n_par,
                                        x0 + (size_t)b * d.n_var, lb, ub,
                                        opt->warm_start ? lam_g + (size_t)b * d.n_con : nullptr,
-                                       opt->warm_start ? status[b] : 0, plan.kkt_doubles);
+                                       opt->warm_start ? status[b] : 0, plan.kkt_doubles,
+                                       (opt->warm_start && dw_state) ? dw_state[b] : 0.0);
+      if (dw_state) dw_state[b] = r.dw;
       for (int i = 0; i < d.n_var; ++i) x[(size_t)b * d.n_var + i] = w.x[i];
       for (int r_ = 0; r_ < d.n_con; ++r_)
         lam_g[(size_t)b * d.n_con + r_] = (r.status == 3 || w.rtype[r_] == omgx::ROW_FREE) ? 0.0 : w.rho[r_] * w.z[r_];
@@ -61,5 +65,9 @@ extern "C" int omgx_port_solve(const omgx_template* tpl, const omgx_options* opt
                                const double* p, const double* x0, const double* lbg, const double* ubg,
                                int32_t bounds_shared, double* x, double* lam_g, int32_t* status,
                                int32_t* iters) {
-  return omgx_port_solve_mt(tpl, opt, n_agents, p, x0, lbg, ubg, bounds_shared, x, lam_g, status, iters, 1);
+  return omgx_port_solve_mt(tpl, opt, n_agents, p, x0, lbg, ubg, bounds_shared, x, lam_g, status, iters, 1, nullptr);
 }
+
+#ifdef OMGX_COUNT_FACT
+extern "C" long omgx_port_nfact(int reset) { long v = omgx_dbg_nfact.load(); if (reset) omgx_dbg_nfact = 0; return v; }
+#endif

@@ -24,7 +24,8 @@ def load():
     return lib
 
 
-def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, status0=None, n_threads=1, **options):
+def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, status0=None, n_threads=1,
+          dw_state=None, **options):
     """Solve B agents on `n_threads` host threads (one agent per thread at a time); returns a
     dict like BatchSolver.solve."""
     from omgtools.backend import make_ctemplate, make_options
@@ -48,7 +49,8 @@ def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, status0=N
                              C.c_void_p(lbg.ctypes.data), C.c_void_p(ubg.ctypes.data),
                              C.c_int32(shared), C.c_void_p(x.ctypes.data),
                              C.c_void_p(lam.ctypes.data), C.c_void_p(status.ctypes.data),
-                             C.c_void_p(iters.ctypes.data), C.c_int32(int(n_threads)))
+                             C.c_void_p(iters.ctypes.data), C.c_int32(int(n_threads)),
+                             C.c_void_p(dw_state.ctypes.data if dw_state is not None else None))
     if rc != 0:
         raise RuntimeError('omgx_port_solve failed: %d' % rc)
     return dict(x=x, lam_g=lam, status=status, iters=iters)
