@@ -185,6 +185,7 @@ struct Ctx {
   double rsum(double v) const { return v; }
   double rmax(double v) const { return v; }
   double rmin(double v) const { return v; }
+  template <int... OPS> void reduce_ops(double (&)[sizeof...(OPS)]) const {}
   void add(double* p, double v) const { *p += v; }
   int lane() const { return 0; }
   int nlanes() const { return 1; }
@@ -212,6 +213,33 @@ struct CtxT {
     for (int i = 1; i < nw; ++i) r = OP == 0 ? r + red[i] : (OP == 1 ? fmax(r, red[i]) : fmin(r, red[i]));
     __syncthreads();
     return r;
+  }
+  // N values at once (op: 0 sum, 1 max, 2 min) for the price of one: two barriers in total.
+  // Ops are template arguments so that everything unrolls into registers (no scratch).
+  template <int OP> static __device__ __forceinline__ double comb(double a, double b) {
+    return OP == 0 ? a + b : (OP == 1 ? fmax(a, b) : fmin(a, b));
+  }
+  template <int I, int N, int OP0, int... OPS>
+  __device__ __forceinline__ void red_wave(double (&v)[N]) const {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[I] = comb<OP0>(v[I], __shfl_down(v[I], off, 64));
+    if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * N + I] = v[I];
+    if constexpr (sizeof...(OPS) > 0) red_wave<I + 1, N, OPS...>(v);
+  }
+  template <int I, int N, int OP0, int... OPS>
+  __device__ __forceinline__ void red_block(double (&v)[N]) const {
+    const int nw = (blockDim.x + 63) >> 6;
+    double r = red[I];
+    for (int k = 1; k < nw; ++k) r = comb<OP0>(r, red[k * N + I]);
+    v[I] = r;
+    if constexpr (sizeof...(OPS) > 0) red_block<I + 1, N, OPS...>(v);
+  }
+  template <int... OPS> __device__ __forceinline__ void reduce_ops(double (&v)[sizeof...(OPS)]) const {
+    static_assert(sizeof...(OPS) <= 8, "reduction scratch holds 8 values per wave");
+    red_wave<0, sizeof...(OPS), OPS...>(v);
+    __syncthreads();
+    red_block<0, sizeof...(OPS), OPS...>(v);
+    __syncthreads();
   }
   __device__ double rsum(double v) const { return reduce<0>(v); }
   __device__ double rmax(double v) const { return reduce<1>(v); }
@@ -319,6 +347,19 @@ OMGX_FN double term_coef(const Tables& T, const Work& w, int t) {
 OMGX_FN double row_value(const Tables& T, const Work& w, int r, const double* xv) {
   double g = 0.0;
   for (int t = T.row_ptr[r]; t < T.row_ptr[r + 1]; ++t) {
+    double v = term_coef(T, w, t);
+    const int32_t* tv = T.t_var + 3 * t;
+    if (tv[0] >= 0) { v *= xv[tv[0]]; if (tv[1] >= 0) { v *= xv[tv[1]]; if (tv[2] >= 0) v *= xv[tv[2]]; } }
+    g += v;
+  }
+  return g;
+}
+
+// this thread's share of row r (terms strided over the workgroup); the caller sums the shares
+template <class C>
+OMGX_FN double row_value_share(const C& c, const Tables& T, const Work& w, int r, const double* xv) {
+  double g = 0.0;
+  for (int t = T.row_ptr[r] + c.tid(); t < T.row_ptr[r + 1]; t += c.nthr()) {
     double v = term_coef(T, w, t);
     const int32_t* tv = T.t_var + 3 * t;
     if (tv[0] >= 0) { v *= xv[tv[0]]; if (tv[1] >= 0) { v *= xv[tv[1]]; if (tv[2] >= 0) v *= xv[tv[2]]; } }
@@ -794,13 +835,14 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     // multiplier of t >= 0: dual feasible in t (nu - v'z - zt = 0) rather than on the central path,
     // so that the first Newton step in t is O(t) instead of O(nu t^2 / mu)
   }
+  double f;
   {
-    double vz0 = 0.0;
-    OMGX_PFOR(r, m) if (w.rtype[r] != ROW_FREE) vz0 += w.vv[r] * w.z[r];
-    vz0 = c.rsum(vz0);
-    zt = use_t ? fmax(mu / t, nu - vz0) : 0.0;
+    double rv[2] = {0.0, row_value_share(c, T, w, m, w.x)};
+    OMGX_PFOR(r, m) if (w.rtype[r] != ROW_FREE) rv[0] += w.vv[r] * w.z[r];
+    c.template reduce_ops<0, 0>(rv);
+    zt = use_t ? fmax(mu / t, nu - rv[0]) : 0.0;
+    f = rv[1];
   }
-  double f = row_value(T, w, m, w.x);
   // a warm start also inherits the inertia correction the previous solve of this agent ended with
   // (first factorisation at that value instead of climbing 0, 1e-4, 1e-3, ... again)
   double dw_last = (warm && dw_prev > 0.0) ? dw_prev : 0.0, t_check = t;
@@ -810,33 +852,44 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 
   for (it = 0; it <= o.max_iter; ++it) {
     OMGX_TIC();
-    // ---- Jacobian (scaled) -----------------------------------------------------
-    OMGX_PFOR(r, m + 1) {
-      row_jac(T, w, r, w.x);
-      if (r < m) {
-        const double sc = (w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r];
-        for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) w.jval[e] *= sc;
-      }
+    // ---- Jacobian (scaled): one thread per term, entries accumulated with LDS atomics -------
+    OMGX_PFOR(e, T.jr_ptr[m + 1]) w.jval[e] = 0.0;
+    c.sync();
+    OMGX_PFOR(tt, T.row_ptr[m + 1]) {
+      const int32_t* tv = T.t_var + 3 * tt;
+      if (tv[0] < 0) continue;
+      const int r = T.t_row[tt];
+      const double sc = (r < m) ? ((w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r]) : 1.0;
+      if (sc == 0.0) continue;
+      const double cf = sc * term_coef(T, w, tt);
+      const int32_t* je = T.t_jidx + 3 * tt;
+      if (tv[1] < 0) { c.add(w.jval + je[0], cf); continue; }
+      const double x0 = w.x[tv[0]], x1 = w.x[tv[1]];
+      if (tv[2] < 0) { c.add(w.jval + je[0], cf * x1); c.add(w.jval + je[1], cf * x0); continue; }
+      const double x2 = w.x[tv[2]];
+      c.add(w.jval + je[0], cf * x1 * x2); c.add(w.jval + je[1], cf * x0 * x2); c.add(w.jval + je[2], cf * x0 * x1);
     }
     c.sync();
     OMGX_TOC(PH_JAC);
     // ---- dual residual, barrier gradient (position order), error measures -------
-    double rd_max = 0.0;
-    OMGX_PFOR(q, n) {
-      double rd = 0.0, gb = 0.0;
-      for (int k = T.jc_ptr[q]; k < T.jc_ptr[q + 1]; ++k) {
-        const int r = T.jc_row[k]; const double jv = w.jval[T.jc_ent[k]];
-        if (r == m) { rd += jv; gb += jv; }
-        else {
-          const int ty = w.rtype[r];
-          if (ty == ROW_UPPER || ty == ROW_LOWER) { rd += jv * w.z[r]; gb += jv * (mu / w.s[r]); }
-          else if (ty == ROW_EQ) rd += jv * w.z[r];
-        }
+    // one thread per Jacobian entry; sol <- J'z (+ grad f), gbar <- grad f, xt <- J'(1/s): the
+    // barrier gradient grad f + mu J'(1/s) is formed once mu is settled below
+    OMGX_PFOR(q, N) { w.sol[q] = 0.0; w.gbar[q] = 0.0; w.xt[q] = 0.0; }
+    c.sync();
+    OMGX_PFOR(e, T.jr_ptr[m + 1]) {
+      const int r = T.je_row[e], q = T.jr_pos[e];
+      const double jv = w.jval[e];
+      if (jv == 0.0) continue;
+      if (r == m) { c.add(w.sol + q, jv); c.add(w.gbar + q, jv); }
+      else {
+        const int ty = w.rtype[r];
+        if (ty == ROW_UPPER || ty == ROW_LOWER) { c.add(w.sol + q, jv * w.z[r]); c.add(w.xt + q, jv / w.s[r]); }
+        else if (ty == ROW_EQ) c.add(w.sol + q, jv * w.z[r]);
       }
-      w.gbar[q] = gb;          // refreshed below if mu changes
-      w.sol[q] = rd;
-      rd_max = fmax(rd_max, fabs(rd));
     }
+    c.sync();
+    double rd_max = 0.0;
+    OMGX_PFOR(q, n) rd_max = fmax(rd_max, fabs(w.sol[q]));
     double viol = 0.0, zh = 0.0, rE_max = 0.0, rE_sum = 0.0, vz = 0.0, lam_sum = 0.0, cnt = 0.0;
     OMGX_PFOR(r, m) {
       const int ty = w.rtype[r];
@@ -850,8 +903,11 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         rE_max = fmax(rE_max, fabs(re)); rE_sum += fabs(re);
       }
     }
-    rd_max = c.rmax(rd_max); lam_sum = c.rsum(lam_sum); vz = c.rsum(vz); cnt = c.rsum(cnt);
-    viol = c.rmax(viol); zh = c.rmax(zh); rE_max = c.rmax(rE_max); rE_sum = c.rsum(rE_sum);
+    {
+      double rv[8] = {rd_max, lam_sum, vz, cnt, viol, zh, rE_max, rE_sum};
+      c.template reduce_ops<1, 0, 0, 0, 1, 1, 1, 0>(rv);
+      rd_max = rv[0]; lam_sum = rv[1]; vz = rv[2]; cnt = rv[3]; viol = rv[4]; zh = rv[5]; rE_max = rv[6]; rE_sum = rv[7];
+    }
     const double sd = fmax(OMGX_S_MAX, lam_sum / fmax(1.0, cnt)) / OMGX_S_MAX;
     const double err0 = fmax(rd_max / sd, fmax(viol, zh / sd));
     res.f = f; res.mu = mu; res.t = t; res.iters = it;
@@ -890,15 +946,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     }
     if (infeasible) { status = 2; break; }
     // barrier gradient with the current mu
-    OMGX_PFOR(q, n) {
-      double gb = 0.0;
-      for (int k = T.jc_ptr[q]; k < T.jc_ptr[q + 1]; ++k) {
-        const int r = T.jc_row[k]; const double jv = w.jval[T.jc_ent[k]];
-        if (r == m) gb += jv;
-        else if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) gb += jv * (mu / w.s[r]);
-      }
-      w.gbar[q] = gb;
-    }
+    OMGX_PFOR(q, n) w.gbar[q] += mu * w.xt[q];
     double vms = 0.0;
     OMGX_PFOR(r, m) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) vms += w.vv[r] * (mu / w.s[r]);
     vms = c.rsum(vms);
@@ -1029,8 +1077,14 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       }
     }
     OMGX_PFOR(q, N) gdx += w.gbar[q] * w.sol[q];
-    double a_p = c.rmin(ap_l), a_d = c.rmin(ad_l);
-    ymax = c.rmax(ymax); gdx = c.rsum(gdx);
+    double lns = 0.0;
+    OMGX_PFOR(r, m) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) lns += log(w.s[r]);
+    double a_p, a_d;
+    {
+      double rv[5] = {ap_l, ad_l, ymax, gdx, lns};
+      c.template reduce_ops<2, 2, 1, 0, 0>(rv);
+      a_p = rv[0]; a_d = rv[1]; ymax = rv[2]; gdx = rv[3]; lns = rv[4];
+    }
     double dzt = 0.0;
     if (use_t) {
       dzt = mu / t - zt - (zt / t) * dt;
@@ -1038,9 +1092,6 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       if (dzt < 0.0) a_d = fmin(a_d, -tau * zt / dzt);
     }
     const double nuE = 2.0 * fmax(1.0, ymax);
-    double lns = 0.0;
-    OMGX_PFOR(r, m) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) lns += log(w.s[r]);
-    lns = c.rsum(lns);
     const double phi0 = f + nu * t - mu * lns - (use_t ? mu * log(t) : 0.0) + nuE * rE_sum;
     const double dphi = gdx - nuE * rE_sum;
 
@@ -1060,8 +1111,11 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         if (ty == ROW_EQ) rEt += fabs(h - tt * w.vv[r]);
         else { const double st = tt * w.vv[r] - h; smin = fmin(smin, st); if (st > 0.0) lnst += log(st); }
       }
-      smin = c.rmin(smin); lnst = c.rsum(lnst); rEt = c.rsum(rEt);
-      ft = row_value(T, w, m, w.xt);
+      {
+        double rv[4] = {smin, lnst, rEt, row_value_share(c, T, w, m, w.xt)};
+        c.template reduce_ops<2, 0, 0, 0>(rv);
+        smin = rv[0]; lnst = rv[1]; rEt = rv[2]; ft = rv[3];
+      }
       if (smin > 0.0) {
         const double phit = ft + nu * tt - mu * lnst - (use_t ? mu * log(tt) : 0.0) + nuE * rEt;
         if (phit <= phi0 + OMGX_ETA * alpha * dphi || phit - phi0 <= 10.0 * 2.220446049250313e-16 * fabs(phi0)) { ok = 1; break; }
