@@ -451,11 +451,16 @@ struct Blk4 { double l10, l20, l21, l30, l31, l32, d0, d1, d2, d3, i0, i1, i2, i
 OMGX_FN Blk4 blk4_factor(const BMat& M, const double* A, int jb, int nb) {
   Blk4 b; b.l10 = b.l20 = b.l21 = b.l30 = b.l31 = b.l32 = 0.0; b.d1 = b.d2 = b.d3 = 1.0;
   // all loads first (independent), then the short dependent chain
+  // (a partial last block reads rows past the block: still inside the workspace, then masked;
+  // unconditional loads issue back to back instead of one LDS round trip per branch)
   double g[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int k = 0; k <= a; ++k) g[a][k] = (a < nb) ? A[baddr(M, jb + a, jb + k)] : (a == k ? 1.0 : 0.0);
+    for (int k = 0; k <= a; ++k) {
+      const double v = A[baddr(M, jb + (a < nb ? a : 0), jb + (a < nb ? k : 0))];
+      g[a][k] = (a < nb) ? v : (a == k ? 1.0 : 0.0);
+    }
   b.d0 = g[0][0]; b.i0 = rcp_pivot(b.d0);
   b.l10 = g[1][0] * b.i0; b.l20 = g[2][0] * b.i0; b.l30 = g[3][0] * b.i0;
   b.d1 = g[1][1] - b.l10 * g[1][0]; b.i1 = rcp_pivot(b.d1);
@@ -519,9 +524,10 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
       } else {
         const int base = baddr(M, r, jb);
         const double a0 = A[base];
-        const double a1 = nb > 1 ? A[base + 1] : 0.0;
-        const double a2 = nb > 2 ? A[base + 2] : 0.0;
-        const double a3 = nb > 3 ? A[base + 3] : 0.0;
+        const double l1 = A[base + (nb > 1 ? 1 : 0)], l2 = A[base + (nb > 2 ? 2 : 0)], l3 = A[base + (nb > 3 ? 3 : 0)];
+        const double a1 = nb > 1 ? l1 : 0.0;
+        const double a2 = nb > 2 ? l2 : 0.0;
+        const double a3 = nb > 3 ? l3 : 0.0;
         const double u0 = a0;
         const double u1 = a1 - u0 * B.l10;
         const double u2 = a2 - u0 * B.l20 - u1 * B.l21;
@@ -565,31 +571,42 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
         }
       }
 #else
-      const int lane = c.lane();
-      for (int tile = c.wave() - (tile0 % c.nwaves()); tile < tr * tc; tile += c.nwaves()) {
-        if (tile < 0) continue;
-        const int ti = tile / tc, tj = tile - ti * tc;
-        const int R0 = s0 + 16 * ti, K0 = s0 + 16 * tj;
-        if (K0 > R0 + 15 && R0 + 15 < M.nfact) continue;           // tile entirely above the diagonal
-        const int ra = R0 + (lane & 15), kb = K0 + (lane & 15), q = lane >> 4;
-        const double av = (ra < M.rows) ? -colb[M.pan + ra * OMGX_PAN_LD + q] : 0.0;
-        const double bv = (kb < M.nfact) ? colb[M.pan + kb * OMGX_PAN_LD + q] * stage[mi * OMGX_STAGE_LD + 16 + q] : 0.0;
-        typedef double v4d __attribute__((ext_vector_type(4)));
-        v4d acc;
-        const int col = K0 + (lane & 15);
-        int ad[4]; bool ok[4];
+      // tile rows are dealt round-robin to the waves across all matrices (tile0 = running count);
+      // the wave count is a power of two, so no integer division anywhere in this loop
+      const int lane = c.lane(), nwm = c.nwaves() - 1;
+      for (int ti = (c.wave() - tile0) & nwm; ti < tr; ti += nwm + 1) {
+        const int R0 = s0 + 16 * ti;
+        for (int tj = 0; tj < tc; ++tj) {
+          const int K0 = s0 + 16 * tj;
+          if (K0 > R0 + 15 && R0 + 15 < M.nfact) break;             // rest of the row is above the diagonal
+          const int ra = R0 + (lane & 15), kb = K0 + (lane & 15), q = lane >> 4;
+          // all loads unconditional on clamped addresses, masked afterwards: one LDS round trip
+          const double av_l = colb[M.pan + (ra < M.rows ? ra : M.rows - 1) * OMGX_PAN_LD + q];
+          const double bv_l = colb[M.pan + (kb < M.nfact ? kb : M.nfact - 1) * OMGX_PAN_LD + q];
+          const double iv_l = stage[mi * OMGX_STAGE_LD + 16 + q];
+          typedef double v4d __attribute__((ext_vector_type(4)));
+          v4d acc;
+          const int col = K0 + (lane & 15);
+          int ad[4]; bool ok[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = R0 + (lane >> 4) + 4 * i;
-          ok[i] = row < M.rows && col < M.nfact && (row >= M.nfact || col <= row);
-          ad[i] = ok[i] ? baddr(M, row, col) : 0;
-          acc[i] = ok[i] ? A[ad[i]] : 0.0;
+          for (int i = 0; i < 4; ++i) {
+            const int row = R0 + (lane >> 4) + 4 * i;
+            ok[i] = row < M.rows && col < M.nfact && (row >= M.nfact || col <= row);
+            ad[i] = ok[i] ? baddr(M, row, col) : M.a;
+          }
+          double al[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) al[i] = A[ad[i]];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = ok[i] ? al[i] : 0.0;
+          const double av = (ra < M.rows) ? -av_l : 0.0;
+          const double bv = (kb < M.nfact) ? bv_l * iv_l : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) if (ok[i]) A[ad[i]] = acc[i];
         }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) if (ok[i]) A[ad[i]] = acc[i];
       }
-      tile0 += tr * tc;
+      tile0 += tr;
 #endif
     }
     c.sync();
@@ -649,18 +666,20 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
       const double* Wt = K.P(l) + n * ld;
       const double* di = w.dinv + K.T->leaf_off[l];
       const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
-      const int tn = (nc + 15) >> 4;
-      for (int tile = c.wave() - (tile0 % c.nwaves()); tile < tn * tn; tile += c.nwaves()) {
-        if (tile < 0) continue;
-        const int ti = tile / tn, tj = tile - ti * tn;
-        if (tj > ti) continue;
+      const int tn = (nc + 15) >> 4, nwm = c.nwaves() - 1;
+      // lower-triangular tile pairs (ti, tj <= ti) numbered consecutively and dealt round-robin
+      int tile = 0;
+      for (int ti = 0; ti < tn; ++ti) for (int tj = 0; tj <= ti; ++tj, ++tile) {
+        if (((tile0 + tile) & nwm) != c.wave()) continue;
         typedef double v4d __attribute__((ext_vector_type(4)));
         v4d acc = {0.0, 0.0, 0.0, 0.0};
         const int ra = 16 * ti + (lane & 15), rb = 16 * tj + (lane & 15), q = lane >> 4;
         for (int j0 = 0; j0 < n; j0 += 4) {
           const int j = j0 + q;
-          const double av = (ra < nc && j < n) ? Wt[ra * ld + j] * di[j] : 0.0;
-          const double bv = (rb < nc && j < n) ? Wt[rb * ld + j] : 0.0;
+          const int jc = j < n ? j : n - 1, rac = ra < nc ? ra : nc - 1, rbc = rb < nc ? rb : nc - 1;
+          const double wa = Wt[rac * ld + jc], wd = di[jc], wb = Wt[rbc * ld + jc];     // unconditional loads
+          const double av = (ra < nc && j < n) ? wa * wd : 0.0;
+          const double bv = (rb < nc && j < n) ? wb : 0.0;
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
         }
         const int cb = 16 * tj + (lane & 15);
@@ -669,7 +688,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
           if (ca < nc && cb < nc && cb <= ca) c.add(R + tri(ci[ca], ci[cb]), -acc[i]);
         }
       }
-      tile0 += tn * tn;
+      tile0 += tile;
     }
   }
 #endif
