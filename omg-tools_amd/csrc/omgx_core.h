@@ -796,6 +796,28 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // warm start only from a converged previous solve; otherwise a cold start from x0
   const bool warm = o.warm_start && lam0 != nullptr && prev_status == 0;
   const double kpush = warm ? o.kappa_warm : o.kappa_push;
+  // unscaled Jacobian entries and row values at x0, one thread per term (LDS atomics) ...
+  OMGX_PFOR(e, T.jr_ptr[m + 1]) w.jval[e] = 0.0;
+  OMGX_PFOR(r, m) w.hv[r] = 0.0;
+  c.sync();
+  OMGX_PFOR(tt, T.row_ptr[m]) {
+    const double cf = term_coef(T, w, tt);
+    const int32_t* tv = T.t_var + 3 * tt;
+    const int r = T.t_row[tt];
+    if (tv[0] < 0) { c.add(w.hv + r, cf); continue; }
+    const int32_t* je = T.t_jidx + 3 * tt;
+    const double x0v = w.x[tv[0]];
+    if (tv[1] < 0) { c.add(w.hv + r, cf * x0v); c.add(w.jval + je[0], cf); continue; }
+    const double x1v = w.x[tv[1]];
+    if (tv[2] < 0) {
+      c.add(w.hv + r, cf * x0v * x1v); c.add(w.jval + je[0], cf * x1v); c.add(w.jval + je[1], cf * x0v); continue;
+    }
+    const double x2v = w.x[tv[2]];
+    c.add(w.hv + r, cf * x0v * x1v * x2v);
+    c.add(w.jval + je[0], cf * x1v * x2v); c.add(w.jval + je[1], cf * x0v * x2v); c.add(w.jval + je[2], cf * x0v * x1v);
+  }
+  c.sync();
+  // ... then one thread per row: classification, gradient-based scale, phase-I weight
   double bad_local = 0.0;
   OMGX_PFOR(r, m) {
     const double l = lb[r], u = ub[r];
@@ -808,14 +830,13 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     else if (ty == ROW_EQ) ty = ROW_BAD;
     if (ty == ROW_BAD) bad_local = 1.0;
     w.rtype[r] = ty;
-    row_jac(T, w, r, w.x);
     double gm = 0.0;
     for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) gm = fmax(gm, fabs(w.jval[e]));
     double rho = (o.scale_gmax > 0.0 && gm > o.scale_gmax) ? o.scale_gmax / gm : 1.0;
     const double sg = (ty == ROW_LOWER) ? -1.0 : 1.0;
     w.rho[r] = sg * rho;                                  // signed scale: h = rho*(g - bound)
     w.bnd[r] = (ty == ROW_LOWER || ty == ROW_EQ) ? l : (ty == ROW_UPPER ? u : 0.0);
-    const double g = row_value(T, w, r, w.x);
+    const double g = w.hv[r];
     const double h = (ty == ROW_FREE) ? 0.0 : w.rho[r] * (g - w.bnd[r]);
     w.hv[r] = h;
     double v = 0.0;
@@ -1121,11 +1142,21 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + alpha * w.sol[q]; }
       c.sync();
       tt = use_t ? w.xt[n] : 0.0;
+      // row values at the trial point: one thread per term, LDS atomics into ht
+      OMGX_PFOR(r, m) w.ht[r] = 0.0;
+      c.sync();
+      OMGX_PFOR(q, T.row_ptr[m]) {
+        double v = term_coef(T, w, q);
+        const int32_t* tv = T.t_var + 3 * q;
+        if (tv[0] >= 0) { v *= w.xt[tv[0]]; if (tv[1] >= 0) { v *= w.xt[tv[1]]; if (tv[2] >= 0) v *= w.xt[tv[2]]; } }
+        c.add(w.ht + T.t_row[q], v);
+      }
+      c.sync();
       double smin = 1e300, lnst = 0.0, rEt = 0.0;
       OMGX_PFOR(r, m) {
         const int ty = w.rtype[r];
         if (ty == ROW_FREE) { w.ht[r] = 0.0; continue; }
-        const double h = w.rho[r] * (row_value(T, w, r, w.xt) - w.bnd[r]);
+        const double h = w.rho[r] * (w.ht[r] - w.bnd[r]);
         w.ht[r] = h;
         if (ty == ROW_EQ) rEt += fabs(h - tt * w.vv[r]);
         else { const double st = tt * w.vv[r] - h; smin = fmin(smin, st); if (st > 0.0) lnst += log(st); }
