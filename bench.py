@@ -43,33 +43,37 @@ def measured_traffic(n_agents):
     return warm('FETCH_SIZE') + warm('WRITE_SIZE')
 
 
-def cpu_baseline(problem, P, opts, n_sample):
-    """Oracle CPU port on a bounded sample of the same workload and the same protocol (cold solve,
-    then warm-started receding-horizon steps, timed): all host cores (one agent per thread at a
-    time) and, on a quarter of the sample, one thread."""
+def cpu_baseline(problem, P, opts, steps, warmup, budget_s):
+    """Oracle CPU port on the same workload, protocol and tolerance: cold solve, `warmup` untimed
+    receding-horizon steps, then `steps` timed ones (exactly the GPU's timed region), repeated from
+    the cold start until about `budget_s` seconds of timed CPU work are collected -- on all host
+    cores (one agent per thread at a time) and, with a 64-agent sample, on one thread."""
     from omgtools.batch import BatchP2P
     cores = os.cpu_count() or 1
     out = {}
-    for label, threads, n_agents, budget in (('all', cores, min(64 * cores, P['p'].shape[0]), n_sample),
-                                             ('one', 1, min(64, P['p'].shape[0]), n_sample // (4 * cores) + 64)):
+    for label, threads, n_agents, budget in (('all', cores, P['p'].shape[0], budget_s), ('one', 1, min(64, P['p'].shape[0]), budget_s / 4.)):
         sub = {'p': P['p'][:n_agents], 'x0': P['x0'][:n_agents]}
-        mpc = BatchP2P(problem, sub, ops='numpy', options=opts)
-        mpc.n_threads = threads
-        mpc.solve_cold()
-        steps = max(1, budget // n_agents)
-        ok, its = 0, 0
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            mpc.step()
-            ok += int((mpc.status == 0).sum())
-            its += int(mpc.iters.sum())
-        dt = time.perf_counter() - t0
-        out[label] = dict(rate=ok / dt, steps=steps, agents=n_agents, dt=dt, iters=its / float(steps * n_agents))
+        ok, its, dt, reps = 0, 0, 0.0, 0
+        while dt < budget and reps < 200:
+            mpc = BatchP2P(problem, sub, ops='numpy', options=opts)
+            mpc.n_threads = threads
+            mpc.solve_cold()
+            for _ in range(warmup):
+                mpc.step()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                mpc.step()
+                ok += int((mpc.status == 0).sum())
+                its += int(mpc.iters.sum())
+            dt += time.perf_counter() - t0
+            reps += 1
+        out[label] = dict(rate=ok / dt, reps=reps, agents=n_agents, dt=dt, iters=its / float(reps * steps * n_agents))
     a, o = out['all'], out['one']
     return {'value': a['rate'], 'unit': 'solves/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d receding-horizon steps of the first %d agents of the same batch (same protocol and '
-                      'tolerance) on %d host threads, %.1f s; single thread: %d steps of %d agents, %.1f s'
-                      % (a['steps'], a['agents'], cores, a['dt'], o['steps'], o['agents'], o['dt']),
+            'sample': '%d repetitions of the bench protocol (cold solve, %d warm-up steps untimed; %d receding-horizon '
+                      'steps timed) on all %d agents with %d host threads, %.1f s timed; single thread: %d repetitions '
+                      'on the first %d agents, %.1f s timed'
+                      % (a['reps'], warmup, steps, a['agents'], cores, a['dt'], o['reps'], o['agents'], o['dt']),
             'single_thread_value': o['rate'], 'mean_iters': a['iters']}
 
 
@@ -183,8 +187,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--agents', type=int, default=1024, help='agents per GPU')
     ap.add_argument('--tol', type=float, default=1e-3)
-    ap.add_argument('--cpu-sample', type=int, default=81920,
-                    help='agent-solves timed on the host cores (64 agents per core x N receding-horizon steps)')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0,
+                    help='seconds of timed CPU work for the cpu_baseline leg (all host cores; a quarter of it on one)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--workload', choices=['p2p', 'formation', 'quadrotor', 'holonomic3d'], default='p2p',
                     help="p2p = BASELINE.json configs[1] (headline); formation = configs[3], 512-agent ADMM")
@@ -306,7 +310,7 @@ def main():
         'step_kernel_ms': [round(v, 3) for v in kernel_ms], 'step_max_iters': it_log[W:].max(dim=1).values.tolist(),
     }
     if not args.no_cpu and world == 1:
-        out['cpu_baseline'] = cpu_baseline(problem, P, opts, args.cpu_sample)
+        out['cpu_baseline'] = cpu_baseline(problem, P, opts, args.steps, args.warmup, args.cpu_seconds)
     print(json.dumps(out))
 
 
