@@ -67,3 +67,40 @@ def test_shift_matches_matrix(cfg2_small):
     solver.shift(got, mask, np.array(entries), np.concatenate(tmats))
     assert np.abs(got - want).max() < 1e-13
     solver.close()
+
+
+def test_predict_matches_basis_evaluation(cfg2_small):
+    """`omgx_batch_predict` (ideal prediction, `vehicles/vehicle.py:323-326`): state0 = spline(tau),
+    input0 = spline'(tau)/T, t written into p -- against the host basis matrices."""
+    import torch
+    from omgtools.backend import BatchSolver
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    veh = problem.vehicles[0]
+    basis, L, nd = veh.basis, len(veh.basis), veh.n_dim
+    B = P['p'].shape[0]
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((B, tpl.n_var))
+    o_spl = tpl.entry_range(veh.label, 'splines_seg0', 'var')[0]
+    o_s0 = tpl.entry_range(veh.label, 'state0', 'par')[0]
+    o_i0 = tpl.entry_range(veh.label, 'input0', 'par')[0]
+    o_t = tpl.entry_range(problem.label, 't', 'par')[0]
+    solver = BatchSolver(tpl, B)
+    dev = torch.device('cuda', 0)
+    solver.set_stream(torch.cuda.current_stream().cuda_stream)      # same stream as the torch copies
+    for tau in (0.004, 1. / 11. - 1e-3, 0.5, 0.97):
+        xd = torch.as_tensor(x, dtype=torch.float64, device=dev)
+        pd = torch.as_tensor(P['p'], dtype=torch.float64, device=dev).clone()
+        solver.predict(xd, pd, o_spl, nd, basis.degree, basis.knots, tau, 1. / 10., o_s0, o_i0, o_t, 0.123)
+        solver.sync()
+        p = pd.cpu().numpy()
+        E = basis.eval_basis([tau])[0]
+        dbasis, P1 = basis.derivative(1)
+        Ed = dbasis.eval_basis([tau])[0] @ P1 / 10.
+        c = x[:, o_spl:o_spl + nd * L].reshape(B, nd, L)
+        assert np.abs(p[:, o_s0:o_s0 + nd] - c @ E).max() < 1e-12
+        assert np.abs(p[:, o_i0:o_i0 + nd] - c @ Ed).max() < 1e-11
+        assert np.all(p[:, o_t] == 0.123)
+        keep = np.ones(tpl.n_par, bool); keep[o_s0:o_s0 + nd] = False; keep[o_i0:o_i0 + nd] = False; keep[o_t] = False
+        assert np.array_equal(p[:, keep], P['p'][:, keep])
+    solver.close()
