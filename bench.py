@@ -136,7 +136,7 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
     problem, P = fn(B, seed=20240807 + (3 if args.workload == 'quadrotor' else 5) + 1000 * rank)
     be.create_nlp = saved
     tpl = problem.father.template
-    solver = BatchSolver(tpl, B, device=local_rank, options=dict(tol=args.tol, max_iter=300))
+    solver = BatchSolver(tpl, B, device=local_rank, options=dict(P.get('solver_options', {}), tol=args.tol, max_iter=300))
     solver.set_stream(torch.cuda.current_stream().cuda_stream)
     f64 = dict(dtype=torch.float64, device=dev)
     p, x0 = torch.as_tensor(P['p'], **f64), torch.as_tensor(P['x0'], **f64)

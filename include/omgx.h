@@ -90,6 +90,9 @@ typedef struct omgx_options {
                            Solve_Succeeded starts from x0 with the multipliers in lam_g: primal-dual warm start for receding-horizon
                            steps (the reference warm-starts IPOPT from x0 only, `problem.py:57-60,113`) */
   double  kappa_warm;   /* kappa_push used when warm_start = 1 */
+  double  dw_leaf_ratio_cold;  /* cold starts weight the inertia correction of nonlinear leaf (hyperplane)
+                           variables by this ratio and of root (trajectory) variables by its inverse;
+                           1 = symmetric (default); 0.3 suits the Quadrotor / 3-D classes */
 } omgx_options;
 
 typedef struct omgx_batch omgx_batch;

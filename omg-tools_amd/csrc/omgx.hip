@@ -426,6 +426,7 @@ const char* omgx_status_string(int32_t s) {
 void omgx_default_options(omgx_options* o) {
   o->tol = 1e-3; o->max_iter = 300; o->mu_init = 0.1; o->kappa_push = 1.0;
   o->nu_init = 100.0; o->scale_gmax = 100.0; o->warm_start = 0; o->kappa_warm = 1e-3;
+  o->dw_leaf_ratio_cold = 1.0;
 }
 
 int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device, omgx_batch** out) {
@@ -439,7 +440,7 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
   omgx_batch* b = new omgx_batch();
   b->device = device; b->n_agents = n_agents;
   omgx_options o; omgx_default_options(&o);
-  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm};
+  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm, o.dw_leaf_ratio_cold};
   int rc = build_batch(b, tpl);
   if (rc != OMGX_OK) { omgx_batch_destroy(b); return rc; }
   const omgx::Dims& d = b->dims;
@@ -485,7 +486,8 @@ void omgx_batch_destroy(omgx_batch* b) {
 
 int omgx_batch_set_options(omgx_batch* b, const omgx_options* o) {
   if (!b || !o || !(o->tol > 0) || o->max_iter < 0) { g_err = "bad options"; return OMGX_E_INVALID; }
-  b->opts = {o->tol, o->max_iter, o->mu_init, o->kappa_push, o->nu_init, o->scale_gmax, o->warm_start, o->kappa_warm};
+  b->opts = {o->tol, o->max_iter, o->mu_init, o->kappa_push, o->nu_init, o->scale_gmax, o->warm_start, o->kappa_warm,
+             o->dw_leaf_ratio_cold > 0 ? o->dw_leaf_ratio_cold : 1.0};
   return OMGX_OK;
 }
 

@@ -64,13 +64,14 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* pair_a; const int32_t* pair_b; const int32_t* pair_addr;
   const int32_t* je_row; const int32_t* jt_addr; const int32_t* diag_addr;
   const int32_t* h_addr; const int32_t* t_row;
-  const double* reg_w;   // [N] position order: weight of the inertia correction (1 nonlinear variable, OMGX_DW_LINEAR otherwise)
+  const double* reg_w;   // [N] position order: inertia-correction class (+1 nonlinear root variable, -1 nonlinear leaf variable, else the weight itself: OMGX_DW_LINEAR)
 };
 
 struct Opts {
   double tol; int max_iter; double mu_init, kappa_push, nu_init, scale_gmax;
   int warm_start;      // 1: lam0 holds the multipliers of the previous solve (primal-dual warm start)
   double kappa_warm;   // kappa_push used for warm starts
+  double dw_leaf_ratio_cold;   // cold starts: inertia-correction weight of nonlinear leaf variables (root: its inverse)
 };
 
 // fixed constants of the iteration (same values in oracle/ipm_numpy.py DEFAULTS)
@@ -887,6 +888,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // (first factorisation at that value instead of climbing 0, 1e-4, 1e-3, ... again)
   double dw_last = (warm && dw_prev > 0.0) ? dw_prev : 0.0, t_check = t;
   int dw_hold = dw_last > 0.0 ? 1 : 0, dw_backoff = 1;   // inertia-correction tracking (see the factorisation loop)
+  // cold starts may damp the leaf (hyperplane) variables less and the root (trajectory) variables more
+  // than dw (same product: the same bilinear negative curvature is covered); warm starts use dw on both
+  const double reg_leaf = warm ? 1.0 : o.dw_leaf_ratio_cold, reg_root = warm ? 1.0 : 1.0 / o.dw_leaf_ratio_cold;
   int it = 0, status = 1;
   OMGX_TOC(PH_SETUP);
 
@@ -1065,7 +1069,8 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       OMGX_PFOR(q, N) {
         // variables without a nonlinear term have zero rows in the Lagrangian Hessian: negative
         // curvature cannot come from them, and damping them would stall LP-like directions
-        double add = dw * T.reg_w[q];
+        const double wq = T.reg_w[q];
+        double add = dw * (wq == 1.0 ? reg_root : (wq == -1.0 ? reg_leaf : wq));
         if (q == N - 1) add += (use_t ? zt / t : 1.0) + tt_acc;
         w.kkt[T.diag_addr[q]] += add;
       }
@@ -1202,7 +1207,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     OMGX_TOC(PH_UPDATE);
   }
   res.status = status; res.iters = it > o.max_iter ? o.max_iter : it; res.f = f; res.mu = mu; res.t = t;
-  res.dw = dw_last;
+  res.dw = dw_last * reg_root;      // handed to the next (warm, symmetric) solve: the damping the root block had
   return res;
 }
 

@@ -118,7 +118,8 @@ struct HostPlan {
     for (int tt = 0; tt < t.row_ptr[m + 1]; ++tt) {
       const int32_t* tv = t.t_var + 3 * tt;
       if (tv[1] < 0) continue;                                  // constant or linear term
-      for (int k = 0; k < 3; ++k) if (tv[k] >= 0) reg_w[pos[tv[k]]] = 1.0;
+      // class markers, turned into weights by the kernel: -1 nonlinear leaf variable, +1 nonlinear root variable
+      for (int k = 0; k < 3; ++k) if (tv[k] >= 0) reg_w[pos[tv[k]]] = (pos[tv[k]] < d.root_off) ? -1.0 : 1.0;
     }
     T.reg_w = reg_w.data();
     return true;

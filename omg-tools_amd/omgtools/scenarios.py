@@ -3,7 +3,9 @@
 Each builder returns (problem, P) where `problem` is an initialised single-agent
 `Point2point` (its template is shared by the whole batch) and P is a dict of
 per-agent arrays: 'p' [B, n_par] parameter vectors in the template's layout,
-'x0' [B, n_var] initial guesses (`get_init_spline_value`, hyperplanes zero).
+'x0' [B, n_var] initial guesses (`get_init_spline_value`, hyperplanes zero), and for
+the Quadrotor / 3-D classes 'solver_options' (settings of the HIP solver that suit the
+class, like the per-problem `solver_options` of the reference's examples).
 """
 import numpy as np
 
@@ -119,7 +121,7 @@ def quadrotor_p2p(n_agents, knot_intervals=13, n_obs=5, seed=20240807 + 3, horiz
             _set(tpl, p, b, obs.label, 'rad', radii[l])
         _set(tpl, p, b, problem.label, 'T', horizon_time)
         _straight_line(tpl, x0, b, vehicle, start, goal, clamp=vehicle.degree)
-    return problem, {'p': p, 'x0': x0}
+    return problem, {'p': p, 'x0': x0, 'solver_options': {'dw_leaf_ratio_cold': 0.3}}
 
 
 def holonomic3d_p2p(n_agents, knot_intervals=15, n_obs=10, seed=20240807 + 5, horizon_time=12.,
@@ -157,7 +159,7 @@ def holonomic3d_p2p(n_agents, knot_intervals=15, n_obs=10, seed=20240807 + 5, ho
             _set(tpl, p, b, obs.label, 'rad', radii[l])
         _set(tpl, p, b, problem.label, 'T', horizon_time)
         _straight_line(tpl, x0, b, vehicle, start, goal)
-    return problem, {'p': p, 'x0': x0}
+    return problem, {'p': p, 'x0': x0, 'solver_options': {'dw_leaf_ratio_cold': 0.3}}
 
 
 def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0, horizon_time=10.,

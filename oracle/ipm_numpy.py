@@ -322,6 +322,12 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
     if o.get('reg_t'):
         nl[n] = True
     reg = np.where(nl, 1.0, o.get('dw_linear', 1e-8)) if o.get('dw_selective', True) else np.ones(N)
+    if z0 is None:
+        # cold start: leaf (hyperplane) variables are damped less, root variables more (same product)
+        ratio = o.get('dw_leaf_ratio_cold', 1.0)
+        is_leaf = np.zeros(N, bool)
+        is_leaf[np.asarray(getattr(nlp, 'leaf_vars', []), dtype=np.int64)] = True
+        reg = np.where(nl, np.where(is_leaf, ratio, 1.0 / ratio), reg)
 
     def ftb(vv, dv, tau_):
         neg = dv < 0
@@ -348,7 +354,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         err0 = max(np.abs(r_d[:n]).max() / sd, viol, (np.abs(z * h).max() / sd) if mH else 0.0)
         if trace is not None:
             trace.append(dict(it=it, f=f, mu=mu, err=err0, inf_pr=viol, inf_du=np.abs(r_d).max(),
-                              dw=dw_last, nu=nu, t=t, zt=zt))
+                              dw=dw_last, nu=nu, t=t, zt=zt, imax=int(np.argmax(np.abs(r_d)))))
         if err0 <= o['tol']:
             status = 0
             break

@@ -32,6 +32,7 @@ extern "C" int omgx_port_solve_mt(const omgx_template* tpl, const omgx_options* 
   o.tol = opt->tol; o.max_iter = opt->max_iter; o.mu_init = opt->mu_init;
   o.kappa_push = opt->kappa_push; o.nu_init = opt->nu_init; o.scale_gmax = opt->scale_gmax;
   o.warm_start = opt->warm_start; o.kappa_warm = opt->kappa_warm;
+  o.dw_leaf_ratio_cold = opt->dw_leaf_ratio_cold > 0 ? opt->dw_leaf_ratio_cold : 1.0;
   const omgx::Dims& d = plan.dims;
   std::atomic<int> next(0);
   auto worker = [&]() {
