@@ -96,7 +96,9 @@ struct Opts {
 #define OMGX_KAPPA_SIGMA 1e10
 #define OMGX_MAX_BACKTRACK 25
 #define OMGX_NU_MAX      1e8
+#ifndef OMGX_STALL_ITERS
 #define OMGX_STALL_ITERS 20
+#endif
 #define OMGX_WARM_ZMIN   1e-8
 #define OMGX_MAX_LEAF    16
 #define OMGX_BMAT_DOUBLES 4      // sizeof(BMat) / 8
@@ -983,9 +985,14 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       }
       break;
     }
-    // stall test: phase I must shrink t by at least 10 % over OMGX_STALL_ITERS (20) iterations
+    // phase-I progress check every OMGX_STALL_ITERS iterations: when t shrank by less than 10 % the
+    // penalty weight is raised first (at this nu the subproblem has its minimum at t > 0); only at
+    // nu_max is the problem declared locally infeasible
     if (use_t && it > 0 && it % OMGX_STALL_ITERS == 0) {
-      if (t > o.tol && t > 0.9 * t_check) infeasible = 1;
+      if (t > o.tol && t > 0.9 * t_check) {
+        if (nu >= OMGX_NU_MAX) infeasible = 1;
+        else { nu *= 10.0; zt += 0.9 * nu; }
+      }
       t_check = t;
     }
     if (infeasible) { status = 2; break; }

@@ -375,8 +375,14 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                 continue
             break
         if use_t and it > 0 and it % o['stall_iters'] == 0:
+            # phase-I progress check: raise the penalty weight first, declare local infeasibility
+            # only at nu_max
             if t > o['tol'] and t > o.get('stall_factor', 0.9) * t_check:
-                status = 2              # phase I stalls: local infeasibility
+                if nu >= o['nu_max']:
+                    status = 2
+                else:
+                    nu *= 10.0
+                    zt += 0.9 * nu
             t_check = t
         if status == 2:
             break

@@ -1,0 +1,30 @@
+"""Test helper: an `nlpsol`-shaped solver object backed by the ORACLE host port, so that the
+Python host logic (Simulator / Deployer / Problem) can be exercised in the CPU test tier.  Test
+infrastructure only -- the product path (`omgtools.backend.NlpSolver`) has no CPU fallback."""
+import time
+
+import numpy as np
+
+
+class PortNlpSolver(object):
+    def __init__(self, template, options):
+        from omgtools.backend import options_from_problem
+        self.template = template
+        self.options = options_from_problem(options)
+        self._stats = {'return_status': 'Not_Solved', 'iter_count': 0}
+
+    def __call__(self, x0=None, p=None, lbg=None, ubg=None, **kwargs):
+        from oracle import port_binding
+        from omgtools.backend import STATUS_STRINGS
+        res = port_binding.solve(self.template, np.asarray(p), np.asarray(x0), np.asarray(lbg), np.asarray(ubg),
+                                 **self.options)
+        self._stats = {'return_status': STATUS_STRINGS[int(res['status'][0])], 'iter_count': int(res['iters'][0])}
+        return {'x': res['x'][0], 'lam_g': res['lam_g'][0]}
+
+    def stats(self):
+        return dict(self._stats)
+
+
+def create_nlp(template, options, name=''):
+    t0 = time.time()
+    return PortNlpSolver(template, options), time.time() - t0
