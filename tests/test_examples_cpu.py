@@ -1,0 +1,61 @@
+"""Host logic of the drop-in surface in the CPU tier: scripts of the reference's examples run
+through `Simulator` (Deployer -> predict / solve / store / simulate, knot shifts, vehicle dynamics)
+with the ORACLE host port standing in for the HIP solver (tests/port_solver.py; the product path
+has no CPU fallback).  Shaped like the reference's `tests/test_examples.py`, which runs every
+example and asserts that it completes -- here the outcome is asserted too."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(autouse=True)
+def port_backend(monkeypatch):
+    import omgtools.backend as be
+    import port_solver
+    monkeypatch.setattr(be, 'create_nlp', port_solver.create_nlp)
+
+
+def test_p2p_quadrotor_example_reaches_target():
+    """`examples/p2p_quadrotor.py:22-43`: Quadrotor over a wall, safety distance, T = 5 s."""
+    from omgtools import Quadrotor, Environment, Obstacle, Rectangle, Square, Point2point, Simulator
+    vehicle = Quadrotor()
+    vehicle.set_options({'safety_distance': 0.1})
+    vehicle.set_initial_conditions([-4., -4., 0., 0., 0.])
+    vehicle.set_terminal_conditions([4., 4.])
+    environment = Environment(room={'shape': Square(10.)})
+    environment.add_obstacle(Obstacle({'position': [-0.6, -5.4]}, shape=Rectangle(width=0.2, height=12.)))
+    problem = Point2point(vehicle, environment, {'horizon_time': 5, 'verbose': 0})
+    problem.init()
+    simulator = Simulator(problem)
+    problem.plot('scene')
+    vehicle.plot('input', knots=True, label=['Thrust force (N/kg)', 'Pitch rate (rad/s)'])
+    trajectories, signals = simulator.run()
+    state = signals['state']
+    assert np.linalg.norm(state[:2, -1] - np.array([4., 4.])) < 2e-2
+    # never inside the wall (x in [-0.7, -0.5], y < 0.6) inflated by the vehicle radius
+    inside = (np.abs(state[0] + 0.6) < 0.1 + 0.2 - 2e-2) & (state[1] < 0.6 + 0.2 - 2e-2)
+    assert not inside.any()
+    u = signals['input']
+    assert u[0].min() > 2. - 0.3 and u[0].max() < 15. + 0.3            # thrust limits (`quadrotor.py:34-35`)
+
+
+def test_p2p_holonomic_example_reaches_target():
+    """`examples/p2p_holonomic.py:23-51` (the GPU tier runs the same script on the HIP path)."""
+    from omgtools import Holonomic, Environment, Obstacle, Circle, Square, Point2point, Simulator
+    vehicle = Holonomic()
+    vehicle.set_options({'safety_distance': 0.1})
+    vehicle.set_options({'ideal_prediction': False})
+    vehicle.set_initial_conditions([-1.5, -1.5])
+    vehicle.set_terminal_conditions([2., 2.])
+    environment = Environment(room={'shape': Square(5.)})
+    trajectories = {'velocity': {'time': [0., 40.], 'values': [[-0.35, 0.35], [0., 0.15]]}}
+    obstacle = Obstacle({'position': [1.5, -1]}, shape=Circle(0.5), options={'bounce': False},
+                        simulation={'trajectories': trajectories})
+    environment.add_obstacle(obstacle)
+    problem = Point2point(vehicle, environment, options={'verbose': 0}, freeT=False)
+    problem.init()
+    trajectories, signals = Simulator(problem).run()
+    state = signals['state']
+    assert np.linalg.norm(state[:, -1] - np.array([2., 2.])) < 1e-2
+    n = min(state.shape[1], obstacle.signals['position'].shape[1])
+    dist = np.linalg.norm(state[:, :n] - obstacle.signals['position'][:, :n], axis=0)
+    assert dist.min() >= 0.5 + 0.1 - 2e-2

@@ -35,3 +35,21 @@ def test_p2p_holonomic_example_runs_to_target():
     dist = np.linalg.norm(state[:, :n] - obstacle.signals['position'][:, :n], axis=0)
     assert dist.min() >= 0.5 + 0.1 - 2e-2                                    # never inside obstacle + vehicle radius
     assert len(problem.update_times) > 50 and signals['time'][0, -1] > 8.
+
+
+def test_p2p_quadrotor_example_runs_to_target():
+    """`examples/p2p_quadrotor.py:22-43` on the HIP path (Quadrotor over a wall, T = 5 s)."""
+    from omgtools import Quadrotor, Environment, Obstacle, Rectangle, Square, Point2point, Simulator
+    vehicle = Quadrotor()
+    vehicle.set_options({'safety_distance': 0.1})
+    vehicle.set_initial_conditions([-4., -4., 0., 0., 0.])
+    vehicle.set_terminal_conditions([4., 4.])
+    environment = Environment(room={'shape': Square(10.)})
+    environment.add_obstacle(Obstacle({'position': [-0.6, -5.4]}, shape=Rectangle(width=0.2, height=12.)))
+    problem = Point2point(vehicle, environment, {'horizon_time': 5, 'verbose': 0})
+    problem.init()
+    trajectories, signals = Simulator(problem).run()
+    state = signals['state']
+    assert np.linalg.norm(state[:2, -1] - np.array([4., 4.])) < 2e-2
+    inside = (np.abs(state[0] + 0.6) < 0.1 + 0.2 - 2e-2) & (state[1] < 0.6 + 0.2 - 2e-2)
+    assert not inside.any()

@@ -80,3 +80,27 @@ def test_more_agents_than_slabs():
         assert np.ptp(res['iters'][k::4]) <= 1
         assert np.abs(res['x'][k::4] - res['x'][k]).max() < 1e-6
     solver.close()
+
+
+def test_cfg2_safety_distance_variant():
+    """SURVEY 8d's s = 1 variant of config 2 (safety_distance > 0: n_var 206, n_con 612): does
+    not fit one CU's LDS any more, so it runs with the KKT store in HBM; converged solutions agree
+    with the port."""
+    from omgtools import scenarios
+    from omgtools.backend import BatchSolver
+    from oracle import port_binding
+    B = 16
+    problem, P = _build(lambda n: scenarios.holonomic_p2p(n, safety_distance=0.1), B)
+    tpl = problem.father.template
+    assert (tpl.n_var, tpl.n_con) == (206, 612)
+    opts = dict(tol=1e-3, max_iter=300)
+    solver = BatchSolver(tpl, B, options=opts)
+    assert solver.workspace()['mode'] >= 1
+    res = solver.solve(P['p'], P['x0'])
+    ref = port_binding.solve(tpl, P['p'], P['x0'], **opts)
+    assert (res['status'] == ref['status']).sum() >= B - 1
+    good = (res['status'] == 0) & (ref['status'] == 0)
+    assert good.sum() >= B - 3
+    lo, hi = tpl.entry_range(problem.vehicles[0].label, 'splines_seg0', 'var')
+    assert np.abs(res['x'][good][:, lo:hi] - ref['x'][good][:, lo:hi]).max() < 1e-2
+    solver.close()
