@@ -4,15 +4,16 @@
 the in-scope path (reference `omgtools/__init__.py`): vehicles, shapes,
 environment, point-to-point / formation problems, simulator and deployer.
 """
-from .shapes import (Circle, Polyhedron, Rectangle, Square, Sphere, Polyhedron3D,
+from .shapes import (Circle, Polyhedron, RegularPolyhedron, Rectangle, Square, Sphere, Polyhedron3D,
                      Cuboid, Cube, Plate)
 from .splines import BSplineBasis, BSpline
 from .vehicles import Vehicle, Holonomic, Holonomic3D, Quadrotor, Fleet
 from .environment import Environment, Obstacle
 from .problems import Problem, Point2point, FixedTPoint2point
 from .execution import Simulator, Deployer
+from .formation import FormationPoint2point
 
-__all__ = ['Circle', 'Polyhedron', 'Rectangle', 'Square', 'Sphere', 'Polyhedron3D',
+__all__ = ['Circle', 'Polyhedron', 'RegularPolyhedron', 'Rectangle', 'Square', 'Sphere', 'Polyhedron3D',
            'Cuboid', 'Cube', 'Plate', 'BSplineBasis', 'BSpline', 'Vehicle', 'Holonomic',
            'Holonomic3D', 'Quadrotor', 'Fleet', 'Environment', 'Obstacle', 'Problem',
-           'Point2point', 'FixedTPoint2point', 'Simulator', 'Deployer']
+           'Point2point', 'FixedTPoint2point', 'FormationPoint2point', 'Simulator', 'Deployer']

@@ -191,6 +191,32 @@ class HipAdmmOps(object):
             l_ext.data_ptr(), self.p.data_ptr()), 'omgx_admm_communicate')
         self._keep2 = (nbr, sl, z_ext, l_ext)
 
+    # -- host bookkeeping of the drop-in problem class (formation.FormationPoint2point) -----------
+    def upload_params(self, p_host, cols):
+        t = self.torch
+        idx = t.as_tensor(np.asarray(cols), dtype=t.int64, device=self.dev)
+        self.p[:, idx] = t.as_tensor(np.ascontiguousarray(p_host[:, cols]), dtype=t.float64, device=self.dev)
+
+    def upload_x(self, x_host):
+        self.x.copy_(self.torch.as_tensor(np.ascontiguousarray(x_host), dtype=self.torch.float64, device=self.dev))
+
+    def download_x(self):
+        return self.x.cpu().numpy()
+
+    def shift(self, shift_x, shift_p, shift_side):
+        """Knot crossing: x <- T x for every spline variable, and the same shift of the consensus
+        state z_i, l_i, z_ji, l_ji (inside p) and z_ij, l_ij (`admm.py:477-491`)."""
+        lib, h = self.solver.lib, self.solver._h
+        lib.omgx_shift_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_int32, C.c_void_p, C.c_int32]
+        for data, stride, (ents, mats) in ((self.x, self.x.shape[1], shift_x), (self.p, self.p.shape[1], shift_p),
+                                           (self.z_ij, self.nn * self.ns, shift_side),
+                                           (self.l_ij, self.nn * self.ns, shift_side)):
+            ents = np.ascontiguousarray(ents, dtype=np.int32)
+            mats = np.ascontiguousarray(mats, dtype=np.float64)
+            self._chk(lib.omgx_shift_rows(h, data.data_ptr(), int(stride), self.B, None, ents.ctypes.data,
+                                          len(ents), mats.ctypes.data, mats.size), 'omgx_shift_rows')
+
     def exchange(self, local, halo, dist):
         t = self.torch
         w = local.shape[1]

@@ -157,3 +157,209 @@ def reverse_slots(nbr):
             j = nbr[b, k]
             slot[b, k] = int(np.nonzero(nbr[j] == b)[0][0])
     return slot
+
+
+class FormationPoint2point(object):
+    """Drop-in for the reference's `FormationPoint2point` (`problems/formation.py:26-72` on top of
+    `ADMMProblem` `problems/admm.py:556-628`, `DualProblem` `problems/dualmethod.py:190-244`,
+    `DistributedProblem` `problems/distributedproblem.py:26-103`): same constructor, options
+    (`rho`, `init_iter`, `max_iter_per_update`, `horizon_time`, ...) and the methods `Simulator` /
+    `Deployer` call (`init, reinitialize, initialize, predict, solve, store, simulate,
+    stop_criterium, final`).
+
+    One sub-problem per vehicle with its own copy of the environment keeps the reference's host
+    bookkeeping (parameters from predictions, trajectory storage); all agents share ONE x-update
+    template, and a dual update = one `BatchADMM.iterate` over the whole fleet on the device
+    (`omgx_batch_solve` + `omgx_admm_*`).  `ops` selects the kernel backend: 'hip' (the product
+    path) or an object with the `HipAdmmOps` interface (tests inject the numpy oracle)."""
+
+    def __init__(self, fleet, environment, options=None, ops='hip'):
+        from .vehicles import get_fleet_vehicles
+        self.fleet, self.vehicles = get_fleet_vehicles(fleet)
+        self.environment = environment
+        self.options = {'verbose': 2, 'horizon_time': 10., 'rho': 2., 'init_iter': 5,
+                        'max_iter_per_update': 1, 'max_iter': None, 'solver': 'ipopt',
+                        'solver_options': {'ipopt': {'ipopt.tol': 1e-3}}}
+        for key, value in (options or {}).items():
+            if key == 'solver_options':
+                for k2, v2 in value.items():
+                    self.options['solver_options'].setdefault(k2, {}).update(v2)
+            else:
+                self.options[key] = value
+        self._ops_kind = ops
+        self.iteration, self.update_times = 0, []
+        self.residuals = {'primal': [], 'dual': [], 'combined': []}
+        self.start_time = 0.
+
+    # -- construction ---------------------------------------------------------------------
+    def init(self):
+        from .admm import BatchADMM
+        N = len(self.vehicles)
+        index = {veh: l for l, veh in enumerate(self.vehicles)}
+        nbr = [[index[g] for g in self.fleet.get_neighbors(veh)] for veh in self.vehicles]
+        n_nghb = len(nbr[0])
+        if any(len(r) != n_nghb for r in nbr):
+            raise ValueError('every vehicle needs the same number of neighbours (one shared x-update template)')
+        self.nbr = np.array(nbr, dtype=np.int32)
+        sub_opts = {k: v for k, v in self.options.items()
+                    if k not in ('rho', 'init_iter', 'max_iter_per_update', 'max_iter')}
+        sub_opts['verbose'] = 0
+        self.subs = []
+        for veh in self.vehicles:
+            problem, updater, father = build_updx_template(veh, self.environment.copy(), n_nghb, sub_opts)
+            veh._values['rel_pos_c'] = np.asarray(veh.rel_pos_c, dtype=float).reshape(-1, 1)
+            self.subs.append((problem, updater, father))
+        tpl = self.subs[0][2].template
+        for _, _, father in self.subs[1:]:
+            t = father.template
+            if (t.n_var, t.n_con, t.n_par, t.n_terms) != (tpl.n_var, tpl.n_con, tpl.n_par, tpl.n_terms):
+                raise ValueError('vehicles of one formation must share the x-update structure')
+        self.tpl = tpl
+        self.lay = lay = FormationLayout(tpl, self.vehicles[0], self.subs[0][0], self.subs[0][1], n_nghb)
+        self.knot_time = self.subs[0][0].knot_time
+        # parameter columns owned by the device-side consensus state (never overwritten from the host)
+        keep = np.ones(tpl.n_par, dtype=bool)
+        for off, size in ((lay.p_zi, lay.ns), (lay.p_li, lay.ns), (lay.p_zji, n_nghb * lay.ns),
+                          (lay.p_lji, n_nghb * lay.ns)):
+            keep[off:off + size] = False
+        self.host_cols = np.nonzero(keep)[0]
+        # shift tables: every spline variable of x; consensus blocks inside p; side arrays z_ij / l_ij
+        veh0, father0 = self.vehicles[0], self.subs[0][2]
+        Tm = shiftoverknot_T(veh0.basis)
+        ents, mats, off = [], [], 0
+        for label, name, spl in father0.shifted_entries(every_spline=True):
+            lo, rows, cols = tpl.var_layout[(label, name)]
+            Ts = shiftoverknot_T(spl['basis'])
+            ents.append([lo, rows, cols, off]); mats.append(Ts.reshape(-1)); off += Ts.size
+        self._shift_x = (np.array(ents, dtype=np.int32), np.concatenate(mats))
+        L, nd = lay.L, lay.n_dim
+        p_ents = [[lay.p_zi, L, nd, 0], [lay.p_li, L, nd, 0]]
+        for j in range(n_nghb):
+            p_ents += [[lay.p_zji + j * lay.ns, L, nd, 0], [lay.p_lji + j * lay.ns, L, nd, 0]]
+        self._shift_p = (np.array(p_ents, dtype=np.int32), Tm.reshape(-1).copy())
+        self._shift_side = (np.array([[j * lay.ns, L, nd, 0] for j in range(n_nghb)], dtype=np.int32),
+                            Tm.reshape(-1).copy())
+        # device state
+        p0, x0 = self._host_parameters(0.), self._host_variables()
+        if self._ops_kind == 'hip':
+            import torch
+            from .admm import HipAdmmOps
+            from .backend import BatchSolver, options_from_problem
+            opts = options_from_problem(self.options)
+            opts['tol'] = self.xupdate_tol()
+            self.solver = BatchSolver(tpl, N, options=opts)
+            self.ops = HipAdmmOps(self.solver, tpl, lay, p0, x0, torch.device('cuda', 0))
+        else:
+            self.ops = self._ops_kind(tpl, lay, p0, x0, self.xupdate_tol())
+        self.admm = BatchADMM(lay, self.nbr, self.ops, rho=self.options['rho'],
+                              horizon_time=self.options['horizon_time'])
+        return 0.
+
+    def xupdate_tol(self):
+        """Tolerance of the x-update solves: `ipopt.tol` x 1e-3.  IPOPT's last (superlinear) step
+        usually lands orders of magnitude below its tolerance while this solver stops right at it, and
+        ADMM with one iteration per update is sensitive to inexact x-updates: on
+        `examples/formation_holonomic.py` (rho = 1) the formation error in the passage between the
+        obstacles is 0.41 m with x-updates at 1e-4, 0.11 m at 1e-6; at 1e-3 the consensus even keeps
+        a residual velocity just above the vehicles' `stop_tol` and the run never ends."""
+        from .backend import options_from_problem
+        return 1e-3 * options_from_problem(self.options).get('tol', 1e-3)
+
+    def _host_parameters(self, current_time):
+        return np.stack([father.set_parameters(current_time).cat for _, _, father in self.subs])
+
+    def _host_variables(self):
+        return np.stack([np.asarray(father.get_variables()).reshape(-1) for _, _, father in self.subs])
+
+    def reinitialize(self, father=None):
+        for problem, _, fa in self.subs:
+            problem.reinitialize(father=fa)
+        self.ops.upload_x(self._host_variables())
+        self.ops.upload_params(self._host_parameters(0.), self.host_cols)
+        self.admm.initialize()
+
+    def initialize(self, current_time):
+        self.start_time = current_time
+        for problem, _, _ in self.subs:
+            problem.initialize(current_time)
+        self._time_prev = 0.
+        for _ in range(self.options['init_iter']):
+            self.solve(current_time, 0.0)
+
+    # -- the hot call --------------------------------------------------------------------------
+    def solve(self, current_time, update_time):
+        current_time -= self.start_time
+        for _ in range(self.options['max_iter_per_update']):
+            self.dual_update(current_time, update_time)
+
+    def dual_update(self, current_time, update_time):
+        import time
+        t0 = time.time()
+        # knot crossing: shift the warm start of x and the whole consensus state (`admm.py:477-491`)
+        if int(np.round(self._time_prev / self.knot_time, 6)) < int(np.round(current_time / self.knot_time, 6)):
+            self.ops.shift(self._shift_x, self._shift_p, self._shift_side)
+        self._time_prev = current_time
+        self.ops.upload_params(self._host_parameters(current_time), self.host_cols)
+        t_rel = float(np.round(current_time, 6) % self.knot_time)
+        status, (pr, dr, cr) = self.admm.iterate(t_rel)
+        x = self.ops.download_x()
+        for l, (_, _, father) in enumerate(self.subs):
+            father.set_variables(x[l])
+        self.iteration += 1
+        t_upd = time.time() - t0
+        if self.options['verbose'] >= 2:
+            if (self.iteration - 1) % 20 == 0:
+                print('----|------|----------|----------|----------')
+                print('%3s | %4s | %8s | %8s | %8s ' % ('It', 't', 'prim res', 'dual res', 't upd'))
+                print('----|------|----------|----------|----------')
+            print('%3d | %4.1f | %.2e | %.2e | %.2e ' % (self.iteration, current_time, pr, dr, t_upd))
+        for key, val in (('primal', pr), ('dual', dr), ('combined', cr)):
+            self.residuals[key].append(val)
+        self.update_times.append(t_upd)
+        self.last_status = np.asarray(status.cpu() if hasattr(status, 'cpu') else status)
+
+    # -- deployment (per-vehicle bookkeeping of the sub-problems) -----------------------------------
+    def predict(self, current_time, predict_time, sample_time, states=None, inputs=None,
+                dinputs=None, delay=0, enforce_states=False, enforce_inputs=False):
+        n = len(self.vehicles)
+        per = lambda v: [None] * n if v is None else v
+        states, inputs, dinputs = per(states), per(inputs), per(dinputs)
+        if current_time == self.start_time:
+            enforce_states = True
+        for k, vehicle in enumerate(self.vehicles):
+            vehicle.predict(current_time, predict_time, sample_time, states[k], inputs[k], dinputs[k],
+                            delay, enforce_states, enforce_inputs)
+
+    def store(self, current_time, update_time, sample_time):
+        for problem, _, _ in self.subs:
+            problem.store(current_time, update_time, sample_time)
+
+    def simulate(self, current_time, simulation_time, sample_time):
+        horizon_time = self.options['horizon_time']
+        rel = np.round(current_time - self.start_time, 6) % self.knot_time
+        simulation_time = min(simulation_time, horizon_time - rel)
+        for vehicle in self.vehicles:
+            vehicle.simulate(simulation_time, sample_time)
+        self.environment.simulate(simulation_time, sample_time)
+        for problem, _, _ in self.subs:
+            problem.environment.simulate(simulation_time, sample_time)
+
+    def stop_criterium(self, current_time, update_time):
+        if self.options['max_iter'] and self.iteration > self.options['max_iter']:
+            return True
+        return all(vehicle.check_terminal_conditions() for vehicle in self.vehicles)
+
+    def final(self):
+        if self.options['verbose'] >= 1:
+            print('\nWe reached our target!')
+            print('%-18s %6g ms' % ('Max update time:', max(self.update_times) * 1000.))
+            print('%-18s %6g ms' % ('Av update time:', sum(self.update_times) * 1000. / len(self.update_times)))
+
+    def get_interaction_error(self):
+        """Average deviation of the agents' fleet centres from their mean (`formation.py:79-100`)."""
+        x_i = np.asarray(self.ops.center(self.lay).cpu() if hasattr(self.ops.center(self.lay), 'cpu')
+                         else self.ops.center(self.lay))
+        return float(np.abs(x_i - x_i.mean(axis=0)).mean())
+
+    def plot(self, *args, **kwargs):
+        pass

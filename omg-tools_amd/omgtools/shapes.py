@@ -82,6 +82,20 @@ class Polyhedron(Shape2D):
         return planes
 
 
+class RegularPolyhedron(Polyhedron):
+    """Regular polygon with `n_vert` vertices on a circle of `radius` (`shape.py:191-212`: vertex l is
+    the intersection of the edge lines with normals at l*dth and (l+1)*dth from the y axis, i.e. the
+    point at angle (l + 1/2) dth)."""
+
+    def __init__(self, radius, n_vert, orientation=0.):
+        self.n_vert = n_vert
+        dth = 2. * np.pi / n_vert
+        ang = (np.arange(n_vert) + 0.5) * dth
+        vertices = radius * np.vstack((np.sin(ang), np.cos(ang)))
+        Polyhedron.__init__(self, vertices, orientation)
+        self.radius_polygon = radius
+
+
 class Rectangle(Polyhedron):
     def __init__(self, width, height, orientation=0.):
         self.width, self.height = width, height

@@ -47,6 +47,27 @@ class NumpyAdmmOps(object):
         self.z_ij, self.l_ij = z_all[:, 1:].copy(), l_all[:, 1:].copy()
         return np.stack([pr, dr, rho * pr + dr], axis=1)
 
+    def upload_params(self, p_host, cols):
+        self.p[:, cols] = p_host[:, cols]
+
+    def upload_x(self, x_host):
+        self.x = np.array(x_host, float)
+
+    def download_x(self):
+        return self.x.copy()
+
+    def shift(self, shift_x, shift_p, shift_side):
+        def apply(arr, ents, mats):
+            for lo, rows, cols, off in ents:
+                Tm = mats[off:off + rows * rows].reshape(rows, rows)
+                blk = arr[:, lo:lo + rows * cols].reshape(arr.shape[0], cols, rows)
+                arr[:, lo:lo + rows * cols] = (blk @ Tm.T).reshape(arr.shape[0], -1)
+        apply(self.x, *shift_x)
+        apply(self.p, *shift_p)
+        for side in (self.z_ij, self.l_ij):
+            flat = side.reshape(self.B, -1)
+            apply(flat, *shift_side)
+
     def z_ij_flat(self):
         return self.z_ij.reshape(self.B, -1)
 
