@@ -116,8 +116,11 @@ class HipAdmmOps(object):
         self.x_new = torch.empty_like(self.x)
         self.lb = torch.as_tensor(template.lb, **f64)
         self.ub = torch.as_tensor(template.ub, **f64)
-        self.lam = torch.empty((B, template.n_con), **f64)
-        self.status = torch.empty(B, dtype=torch.int32, device=device)
+        # consecutive x-updates are neighbouring problems: primal-dual warm start from the previous
+        # one (status 1 everywhere = the first solve is cold)
+        self.lam = torch.zeros((B, template.n_con), **f64)
+        self.status = torch.ones(B, dtype=torch.int32, device=device)
+        solver.set_options(warm_start=1)
         self.iters = torch.empty(B, dtype=torch.int32, device=device)
         self.x_i = torch.empty((B, self.ns), **f64)
         self.z_ij = torch.zeros((B, self.nn, self.ns), **f64)

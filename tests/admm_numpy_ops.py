@@ -5,7 +5,8 @@ import numpy as np
 
 
 class NumpyAdmmOps(object):
-    def __init__(self, template, layout, p, x0, tol=1e-6):
+    def __init__(self, template, layout, p, x0, tol=1e-6, warm=True):
+        self.warm = warm
         from oracle import port_binding
         self.port, self.tpl, self.tol = port_binding, template, tol
         self.p, self.x = np.array(p, float), np.array(x0, float)
@@ -25,8 +26,17 @@ class NumpyAdmmOps(object):
         self.p[:, lay.p_rho] = rho
 
     def solve(self):
-        r = self.port.solve(self.tpl, self.p, self.x, tol=self.tol, max_iter=200)
-        self.x = r['x']
+        # consecutive x-updates are neighbouring problems: primal-dual warm start from the previous
+        # one (first call: status 1 everywhere = cold), like HipAdmmOps
+        if not hasattr(self, 'lam'):
+            self.lam = np.zeros((self.B, self.tpl.n_con))
+            self.status = np.ones(self.B, dtype=np.int32)
+            self.dw = np.zeros(self.B)
+        if not self.warm:
+            self.status[:] = 1
+        r = self.port.solve(self.tpl, self.p, self.x, tol=self.tol, max_iter=300, warm_start=1,
+                            lam_g0=self.lam, status0=self.status, dw_state=self.dw)
+        self.x, self.lam, self.status = r['x'], r['lam_g'], r['status']
         return r['status']
 
     def center(self, lay):

@@ -55,7 +55,7 @@ def test_driver_matches_oracle_iteration():
     from admm_numpy_ops import NumpyAdmmOps
     tpl, lay, P = _scenario(5)
     nbr = P['nbr']
-    ops = NumpyAdmmOps(tpl, lay, P['p'], P['x0'])
+    ops = NumpyAdmmOps(tpl, lay, P['p'], P['x0'], warm=False)     # cold x-updates like the oracle's solve_x below
     admm = BatchADMM(lay, nbr, ops, rho=1.0)
     admm.initialize()
     basis = lay.basis
@@ -64,7 +64,7 @@ def test_driver_matches_oracle_iteration():
     slot = reverse_slots(nbr)
 
     def solve_x(p, x):
-        r = port_binding.solve(tpl, p, x, tol=1e-6, max_iter=200)
+        r = port_binding.solve(tpl, p, x, tol=1e-6, max_iter=300)
         return r['x'], r['status']
     for it in range(3):
         status, (pr, dr, cr) = admm.iterate(0.0)

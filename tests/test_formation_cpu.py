@@ -31,7 +31,7 @@ def formation_example(ops, n=4, verbose=0, extra={}):
     return problem, vehicles, terminal_positions, configuration
 
 
-def check_formation_run(problem, vehicles, terminal_positions, configuration, max_dev=0.3, mean_dev=0.04):
+def check_formation_run(problem, vehicles, terminal_positions, configuration, max_dev=0.15, mean_dev=0.02):
     t_end = vehicles[0].signals['time'][0, -1]
     assert 8. < t_end < 40.
     for veh, target in zip(vehicles, terminal_positions):
@@ -57,4 +57,4 @@ def test_formation_holonomic_example_cpu():
 def test_formation_tight_with_larger_rho():
     from admm_numpy_ops import NumpyAdmmOps
     out = formation_example(lambda tpl, lay, p, x0, tol: NumpyAdmmOps(tpl, lay, p, x0, tol=tol), extra={'rho': 5.})
-    check_formation_run(*out, max_dev=0.05, mean_dev=0.01)
+    check_formation_run(*out, max_dev=0.1, mean_dev=0.01)
