@@ -95,7 +95,6 @@ struct Opts {
 #define OMGX_S_MAX       100.0
 #define OMGX_KAPPA_SIGMA 1e10
 #define OMGX_MAX_BACKTRACK 25
-#define OMGX_MAX_LS_FAIL 3
 #define OMGX_NU_MAX      1e8
 #ifndef OMGX_STALL_ITERS
 #define OMGX_STALL_ITERS 20
@@ -894,7 +893,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // cold starts may damp the leaf (hyperplane) variables less and the root (trajectory) variables more
   // than dw (same product: the same bilinear negative curvature is covered); warm starts use dw on both
   const double reg_leaf = warm ? 1.0 : o.dw_leaf_ratio_cold, reg_root = warm ? 1.0 : 1.0 / o.dw_leaf_ratio_cold;
-  int it = 0, status = 1, ls_fail = 0;
+  int it = 0, status = 1;
   OMGX_TOC(PH_SETUP);
 
   for (it = 0; it <= o.max_iter; ++it) {
@@ -1187,12 +1186,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       c.sync();
     }
     OMGX_TOC(PH_LINESEARCH);
-    if (!ok) {
-      // no acceptable step along this direction: damp harder and try again from the same point
-      // before giving up (the direction of a barely positive definite system can be useless)
-      if (ls_fail < OMGX_MAX_LS_FAIL) { ++ls_fail; dw_last = fmax(100.0 * dw_last, 1e-2); dw_hold = 2; continue; }
-      status = 4; break;
-    }
+    if (!ok) { status = 4; break; }
     // ---- accept --------------------------------------------------------------------
     c.sync();
     OMGX_PFOR(q, N) w.x[q] = w.xt[q];

@@ -309,7 +309,6 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
     zt = max(mu / t, nu - v @ z - cE0 @ y) if use_t else 0.0
     dw_last = 0.0
     dw_hold, dw_backoff = 0, 1
-    ls_fail = 0
     status, it, nfact = 1, 0, 0
     N = n + 1                      # (x, t)
     t_check = t
@@ -484,12 +483,6 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         if trace is not None:
             trace[-1].update(alpha=alpha, a_p=a_p, a_d=a_d, ok=ok, tries=tries, bt=bt, dphi=dphi)
         if not ok:
-            # no acceptable step: damp harder and retry from the same point before giving up
-            if ls_fail < o.get('max_ls_fail', 3):
-                ls_fail += 1
-                dw_last = max(100.0 * dw_last, 1e-2)
-                dw_hold = 2
-                continue
             status = 4
             break
         x, t, s, f, h, cE = xt, tt, st, ft, ht, cEt
