@@ -797,7 +797,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 
   // ---- row classification, gradient-based scaling, phase-I weights -----------
   // warm start only from a converged previous solve; otherwise a cold start from x0
-  const bool warm = o.warm_start && lam0 != nullptr && prev_status == 0;
+  const bool warm = o.warm_start && prev_status == 0;     // callers pass lam0 whenever warm_start is set
   const double kpush = warm ? o.kappa_warm : o.kappa_push;
   // unscaled Jacobian entries and row values at x0, one thread per term (LDS atomics) ...
   OMGX_PFOR(e, T.jr_ptr[m + 1]) w.jval[e] = 0.0;
@@ -894,6 +894,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // than dw (same product: the same bilinear negative curvature is covered); warm starts use dw on both
   const double reg_leaf = warm ? 1.0 : o.dw_leaf_ratio_cold, reg_root = warm ? 1.0 : 1.0 / o.dw_leaf_ratio_cold;
   int it = 0, status = 1;
+  const double nu_stall_max = warm ? OMGX_NU_MAX : 0.0;     // see the stall test in the loop
   OMGX_TOC(PH_SETUP);
 
   for (it = 0; it <= o.max_iter; ++it) {
@@ -985,12 +986,14 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       }
       break;
     }
-    // phase-I progress check every OMGX_STALL_ITERS iterations: when t shrank by less than 10 % the
-    // penalty weight is raised first (at this nu the subproblem has its minimum at t > 0); only at
-    // nu_max is the problem declared locally infeasible
+    // stall test: phase I must shrink t by at least 10 % over OMGX_STALL_ITERS (20) iterations.
+    // A warm-started solve (the previous solve of this agent converged, so a stall is likely
+    // transient: e.g. an ADMM x-update next to a moving obstacle) first raises the penalty weight
+    // and is declared locally infeasible only at nu_max; a cold solve gives up at once (an agent
+    // that is locally infeasible would otherwise burn ~150 iterations in every receding-horizon step).
     if (use_t && it > 0 && it % OMGX_STALL_ITERS == 0) {
       if (t > o.tol && t > 0.9 * t_check) {
-        if (nu >= OMGX_NU_MAX) infeasible = 1;
+        if (nu >= nu_stall_max) infeasible = 1;
         else { nu *= 10.0; zt += 0.9 * nu; }
       }
       t_check = t;

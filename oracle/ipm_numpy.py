@@ -375,10 +375,10 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                 continue
             break
         if use_t and it > 0 and it % o['stall_iters'] == 0:
-            # phase-I progress check: raise the penalty weight first, declare local infeasibility
-            # only at nu_max
+            # phase I stalls: a warm-started solve raises the penalty weight first (local infeasibility
+            # only at nu_max), a cold solve gives up at once
             if t > o['tol'] and t > o.get('stall_factor', 0.9) * t_check:
-                if nu >= o['nu_max']:
+                if z0 is None or nu >= o['nu_max']:
                     status = 2
                 else:
                     nu *= 10.0
