@@ -109,6 +109,11 @@ void omgx_batch_destroy(omgx_batch* b);
 int  omgx_batch_set_options(omgx_batch* b, const omgx_options* o);
 /* Launch on this hipStream_t (as void*) instead of the handle's own stream. */
 int  omgx_batch_set_stream(omgx_batch* b, void* hip_stream);
+/* Optional launch order for the following solves: order_device [n_agents] (device pointer, a
+ * permutation of the agent indices, owned by the caller; NULL = identity).  Workgroups are handed
+ * out in this order, so a caller that knows its likely stragglers (e.g. the agents that needed
+ * most iterations in the previous receding-horizon step) can start them first. */
+int  omgx_batch_set_order(omgx_batch* b, const int32_t* order_device);
 /* LDS bytes the solve kernel needs per agent (for diagnostics / DESIGN.md). */
 int  omgx_batch_lds_bytes(const omgx_batch* b);
 /* Workspace placement chosen at create: mode 0 = every per-agent array in LDS; 1 = KKT store and

@@ -47,7 +47,8 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  const double* __restrict__ lb, const double* __restrict__ ub, int bounds_shared,
                  double* __restrict__ x, double* __restrict__ lam, int32_t* __restrict__ status,
                  int32_t* __restrict__ iters, int n_agents, long long* __restrict__ prof,
-                 double* __restrict__ slabs, size_t slab_doubles, double* __restrict__ dw_state) {
+                 double* __restrict__ slabs, size_t slab_doubles, double* __restrict__ dw_state,
+                 const int32_t* __restrict__ order) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
@@ -61,7 +62,10 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 #endif
   // mode 0: one workgroup per agent.  Spill modes: the grid is capped at the number of HBM
   // slabs and every workgroup walks over its agents.
-  for (int b = blockIdx.x; b < n_agents; b += gridDim.x) {
+  // `order` (optional) maps launch slots to agents: the host can put expected stragglers first so
+  // that their long solves overlap the rest of the batch instead of trailing it
+  for (int slot = blockIdx.x; slot < n_agents; slot += gridDim.x) {
+    const int b = order ? order[slot] : slot;
 #ifdef OMGX_PROFILE
     if (threadIdx.x < omgx::PH_COUNT) prof_lds[threadIdx.x] = 0;
     __syncthreads();
@@ -89,7 +93,8 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 }
 
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
-                             const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*);
+                             const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
+                             const int32_t*);
 static ipm_kernel_t ipm_kernel_for(int mode) {
   switch (mode) {
     case omgx::WS_LDS: return ipm_solve_kernel<omgx::WS_LDS>;
@@ -329,6 +334,7 @@ struct omgx_batch {
   size_t slab_doubles = 0;
   double* d_slabs = nullptr;
   double* d_dw = nullptr;          // per-agent inertia correction carried between warm-started solves
+  const int32_t* d_order = nullptr; // optional launch order (device pointer owned by the caller)
   std::vector<void*> allocs;
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -497,6 +503,12 @@ int omgx_batch_set_stream(omgx_batch* b, void* s) {
   return OMGX_OK;
 }
 
+int omgx_batch_set_order(omgx_batch* b, const int32_t* order_device) {
+  if (!b) return OMGX_E_INVALID;
+  b->d_order = order_device;
+  return OMGX_OK;
+}
+
 int omgx_batch_lds_bytes(const omgx_batch* b) { return b ? (int)b->lds_bytes : OMGX_E_INVALID; }
 
 int omgx_batch_workspace(const omgx_batch* b, int32_t* mode, int64_t* lds_bytes, int64_t* hbm_bytes_per_slab, int32_t* n_slabs) {
@@ -536,7 +548,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   HIPCHK(hipEventRecord(b->ev0, b->stream));
   hipLaunchKernelGGL(ipm_kernel_for(b->ws_mode), dim3(b->n_slabs), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev,
                      b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
-                     b->d_slabs, b->slab_doubles, b->d_dw);
+                     b->d_slabs, b->slab_doubles, b->d_dw, b->d_order);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   b->timed = true;

@@ -47,7 +47,7 @@ def dual_shift_perm(father):
 class BatchP2P(object):
 
     def __init__(self, problem, P, ops='hip', device=None, options=None, update_time=0.1,
-                 max_iter_step=None, shift_every_spline=True):
+                 max_iter_step=None, shift_every_spline=True, straggler_first=True):
         # max_iter_step: iteration cap of a receding-horizon step (default: the cold-solve cap; an
         # agent that hits it keeps its last strictly feasible iterate and restarts cold next step).
         # shift_every_spline: on a knot crossing shift every spline variable like the generated
@@ -85,6 +85,7 @@ class BatchP2P(object):
         self.max_iter_cold = self.opts['max_iter']
         self.max_iter_step = int(max_iter_step) if max_iter_step else self.max_iter_cold
         self.kind = ops
+        self.straggler_first = bool(straggler_first)
         if ops == 'hip':
             import torch
             from .backend import BatchSolver
@@ -121,6 +122,10 @@ class BatchP2P(object):
                                     max_iter=self.max_iter_step if warm else self.max_iter_cold)
             if not warm:
                 self.lam.zero_()
+            if warm and self.straggler_first:
+                # agents that needed most iterations last time are launched first
+                self._order = self.torch.argsort(self.iters, descending=True).to(self.torch.int32)
+                self.solver.set_order(self._order)
             if events is not None:                 # torch events on the launch stream (bench.py)
                 events[0].record()
             self.solver.solve_device(self.p, self.x, self.lb, self.ub, self.x_new, self.lam,
