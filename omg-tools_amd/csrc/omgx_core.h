@@ -451,8 +451,22 @@ OMGX_FN double rcp_pivot(double d) {
 
 // 4x4 (or smaller) diagonal block LDL' from the stored lower entries
 struct Blk4 { double l10, l20, l21, l30, l31, l32, d0, d1, d2, d3, i0, i1, i2, i3; };
+OMGX_FN Blk4 blk4_from(double g00, double g10, double g11, double g20, double g21, double g22,
+                       double g30, double g31, double g32, double g33) {
+  Blk4 b;
+  b.d0 = g00; b.i0 = rcp_pivot(b.d0);
+  b.l10 = g10 * b.i0; b.l20 = g20 * b.i0; b.l30 = g30 * b.i0;
+  b.d1 = g11 - b.l10 * g10; b.i1 = rcp_pivot(b.d1);
+  const double w21 = g21 - g20 * b.l10, w31 = g31 - g30 * b.l10;
+  b.l21 = w21 * b.i1; b.l31 = w31 * b.i1;
+  b.d2 = g22 - b.l20 * g20 - b.l21 * w21; b.i2 = rcp_pivot(b.d2);
+  const double w32 = g32 - g30 * b.l20 - w31 * b.l21;
+  b.l32 = w32 * b.i2;
+  b.d3 = g33 - b.l30 * g30 - b.l31 * w31 - b.l32 * w32; b.i3 = rcp_pivot(b.d3);
+  return b;
+}
+
 OMGX_FN Blk4 blk4_factor(const BMat& M, const double* A, int jb, int nb) {
-  Blk4 b; b.l10 = b.l20 = b.l21 = b.l30 = b.l31 = b.l32 = 0.0; b.d1 = b.d2 = b.d3 = 1.0;
   // all loads first (independent), then the short dependent chain
   // (a partial last block reads rows past the block: still inside the workspace, then masked;
   // unconditional loads issue back to back instead of one LDS round trip per branch)
@@ -464,16 +478,105 @@ OMGX_FN Blk4 blk4_factor(const BMat& M, const double* A, int jb, int nb) {
       const double v = A[baddr(M, jb + (a < nb ? a : 0), jb + (a < nb ? k : 0))];
       g[a][k] = (a < nb) ? v : (a == k ? 1.0 : 0.0);
     }
-  b.d0 = g[0][0]; b.i0 = rcp_pivot(b.d0);
-  b.l10 = g[1][0] * b.i0; b.l20 = g[2][0] * b.i0; b.l30 = g[3][0] * b.i0;
-  b.d1 = g[1][1] - b.l10 * g[1][0]; b.i1 = rcp_pivot(b.d1);
-  const double w21 = g[2][1] - g[2][0] * b.l10, w31 = g[3][1] - g[3][0] * b.l10;
-  b.l21 = w21 * b.i1; b.l31 = w31 * b.i1;
-  b.d2 = g[2][2] - b.l20 * g[2][0] - b.l21 * w21; b.i2 = rcp_pivot(b.d2);
-  const double w32 = g[3][2] - g[3][0] * b.l20 - w31 * b.l21;
-  b.l32 = w32 * b.i2;
-  b.d3 = g[3][3] - b.l30 * g[3][0] - b.l31 * w31 - b.l32 * w32; b.i3 = rcp_pivot(b.d3);
-  return b;
+  return blk4_from(g[0][0], g[1][0], g[1][1], g[2][0], g[2][1], g[2][2], g[3][0], g[3][1], g[3][2], g[3][3]);
+}
+
+// ---------------------------------------------------------------------------
+// Left-looking blocked LDL' for small matrices (order <~ 64), one thread per row, ONE barrier per
+// block of 4 columns.  Every thread forms its own 4 entries of the block column AND (redundantly,
+// it reads those rows anyway) the 4x4 diagonal block,
+//     v_rc = a_rc - sum_{k<jb} U_rk U_ck / d_k ,
+// factorises the block in registers and solves its row against it.  During the sweep all rows
+// hold U = L D (for the carried rows that is the final Wt = B L^{-T}); the original diagonal blocks
+// are parked in a side buffer first, because their matrix slots receive U while other threads
+// still need the originals.  A last pass scales the factorised rows to L.  Same output layout as
+// ldl_blocked.  Latency: 2-3 dependent LDS round trips and one barrier per block instead of ~6 and
+// two; the dot products are independent loads the compiler can keep in flight.
+// ---------------------------------------------------------------------------
+template <class C>
+OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* dinvb, double* colb, int* bad) {
+  int nmax = 0, total_rows = 0, total_blocks = 0;
+  for (int i = 0; i < nm; ++i) {
+    if (Ms[i].nfact > nmax) nmax = Ms[i].nfact;
+    total_rows += Ms[i].rows; total_blocks += (Ms[i].nfact + 3) >> 2;
+  }
+  // park the original diagonal blocks: 10 doubles per block behind the inverse pivots of the matrix
+  OMGX_PFOR(it, total_blocks * 10) {
+    int mi = 0, blk = it / 10; const int e = it - 10 * blk;
+    while (blk >= ((Ms[mi].nfact + 3) >> 2)) { blk -= (Ms[mi].nfact + 3) >> 2; ++mi; }
+    const BMat M = Ms[mi];
+    const int a = e < 1 ? 0 : (e < 3 ? 1 : (e < 6 ? 2 : 3)), k = e - ((a * (a + 1)) >> 1);
+    const int ra = 4 * blk + a, ck = 4 * blk + k;
+    colb[M.pan + M.nfact + 10 * blk + e] = (ra < M.nfact) ? A[baddr(M, ra, ck)] : (a == k ? 1.0 : 0.0);
+  }
+  c.sync();
+  int badl = 0;
+  for (int jb = 0; jb < nmax; jb += OMGX_NB) {
+    OMGX_PFOR(it, total_rows) {
+      int mi = 0, r = it;
+      while (r >= Ms[mi].rows) { r -= Ms[mi].rows; ++mi; }
+      const BMat M = Ms[mi];
+      if (jb >= M.nfact || r < jb) continue;
+      const int nb = (M.nfact - jb) < OMGX_NB ? (M.nfact - jb) : OMGX_NB;
+      double* iv = (M.dinv >= 0) ? dinvb + M.dinv : colb + M.pan;       // inverse pivots of this matrix
+      const double* db = colb + M.pan + M.nfact + 10 * (jb >> 2);
+      const bool diag_row = r < jb + nb;
+      // block rows (clamped for a partial last block: their products are masked below)
+      const int q1 = nb > 1 ? 1 : 0, q2 = nb > 2 ? 2 : 0, q3 = nb > 3 ? 3 : 0;
+      const int b0 = baddr(M, jb, 0), b1 = baddr(M, jb + q1, 0), b2 = baddr(M, jb + q2, 0), b3 = baddr(M, jb + q3, 0);
+      const int br = baddr(M, r, 0);
+      double g00 = db[0], g10 = db[1], g11 = db[2], g20 = db[3], g21 = db[4], g22 = db[5],
+             g30 = db[6], g31 = db[7], g32 = db[8], g33 = db[9];
+      double v0 = A[br + jb], v1 = A[br + jb + q1], v2 = A[br + jb + q2], v3 = A[br + jb + q3];
+      const double m1 = nb > 1 ? 1.0 : 0.0, m2 = nb > 2 ? 1.0 : 0.0, m3 = nb > 3 ? 1.0 : 0.0;
+#pragma unroll 4
+      for (int k = 0; k < jb; ++k) {
+        const double tk = iv[k];
+        const double u0 = A[b0 + k], u1 = m1 * A[b1 + k], u2 = m2 * A[b2 + k], u3 = m3 * A[b3 + k], ur = A[br + k];
+        const double t0 = u0 * tk, t1 = u1 * tk, t2 = u2 * tk, t3 = u3 * tk;
+        g00 -= u0 * t0;
+        g10 -= u1 * t0; g11 -= u1 * t1;
+        g20 -= u2 * t0; g21 -= u2 * t1; g22 -= u2 * t2;
+        g30 -= u3 * t0; g31 -= u3 * t1; g32 -= u3 * t2; g33 -= u3 * t3;
+        v0 -= ur * t0; v1 -= ur * t1; v2 -= ur * t2; v3 -= ur * t3;
+      }
+      const Blk4 B = blk4_from(g00, g10, g11, g20, g21, g22, g30, g31, g32, g33);
+      if (diag_row) {
+        const int q = r - jb;
+        const double dq = q == 0 ? B.d0 : (q == 1 ? B.d1 : (q == 2 ? B.d2 : B.d3));
+        const double iq = q == 0 ? B.i0 : (q == 1 ? B.i1 : (q == 2 ? B.i2 : B.i3));
+        const bool pos_ok = (jb + q < M.npos) ? (dq > 0.0) : (dq < 0.0);
+        if (!pos_ok) badl = 1;
+        iv[jb + q] = iq;
+        // U = L D inside the block, the pivot itself on the diagonal
+        if (q == 1) { A[br + jb] = B.l10 * B.d0; }
+        else if (q == 2) { A[br + jb] = B.l20 * B.d0; A[br + jb + 1] = B.l21 * B.d1; }
+        else if (q == 3) { A[br + jb] = B.l30 * B.d0; A[br + jb + 1] = B.l31 * B.d1; A[br + jb + 2] = B.l32 * B.d2; }
+        A[br + jb + q] = dq;
+      } else {
+        const double u0 = v0;
+        const double u1 = v1 - u0 * B.l10;
+        const double u2 = v2 - u0 * B.l20 - u1 * B.l21;
+        const double u3 = v3 - u0 * B.l30 - u1 * B.l31 - u2 * B.l32;
+        A[br + jb] = u0;
+        if (nb > 1) A[br + jb + 1] = u1;
+        if (nb > 2) A[br + jb + 2] = u2;
+        if (nb > 3) A[br + jb + 3] = u3;
+      }
+    }
+    c.sync();
+  }
+  // factorised rows: U -> L
+  OMGX_PFOR(it, total_rows) {
+    int mi = 0, r = it;
+    while (r >= Ms[mi].rows) { r -= Ms[mi].rows; ++mi; }
+    const BMat M = Ms[mi];
+    if (r >= M.nfact) continue;
+    const double* iv = (M.dinv >= 0) ? dinvb + M.dinv : colb + M.pan;
+    const int br = baddr(M, r, 0);
+    for (int k = 0; k < r; ++k) A[br + k] *= iv[k];
+  }
+  *bad = c.rmax(badl ? 1.0 : 0.0) > 0.0 ? 1 : 0;
 }
 
 // Factorise `nm` matrices together (same block index for all of them).
@@ -640,7 +743,11 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   }
   c.sync();
   if (d.n_leaf > 0) {
+#ifdef OMGX_LDL_MFMA
     ldl_blocked(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, stage, &bad);
+#else
+    ldl_left4(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad);
+#endif
     if (bad) return 1;
   }
   OMGX_TOC(PH_F_LEAF);
@@ -697,6 +804,9 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
 #endif
   c.sync();
   OMGX_TOC(PH_F_SCHUR);
+  // the root is one matrix of a few dozen rows (a single wave): the two-phase MFMA routine spreads its
+  // trailing tiles over all waves and wins there; the leaves (several matrices, many rows) are faster
+  // with the one-barrier left-looking sweep
   ldl_blocked(c, Ms + d.n_leaf, 1, w.kkt, w.dinv, w.col, stage, &bad);
   OMGX_TOC(PH_F_ROOT);
   return bad;
