@@ -114,6 +114,10 @@ int  omgx_batch_set_stream(omgx_batch* b, void* hip_stream);
  * out in this order, so a caller that knows its likely stragglers (e.g. the agents that needed
  * most iterations in the previous receding-horizon step) can start them first. */
 int  omgx_batch_set_order(omgx_batch* b, const int32_t* order_device);
+/* Fill order_device [n_agents] from the iteration counts of the previous solve (iters_device, as
+ * written by omgx_batch_solve), largest first, on the handle's stream, and install it as the
+ * launch order (the receding-horizon loop calls this before every warm-started solve). */
+int  omgx_batch_order_by_iters(omgx_batch* b, const int32_t* iters_device, int32_t* order_device);
 /* LDS bytes the solve kernel needs per agent (for diagnostics / DESIGN.md). */
 int  omgx_batch_lds_bytes(const omgx_batch* b);
 /* Workspace placement chosen at create: mode 0 = every per-agent array in LDS; 1 = KKT store and

@@ -218,6 +218,27 @@ predict_kernel(const double* __restrict__ x, int n_var, double* __restrict__ p, 
   if (k == 0 && p_t >= 0) pb[p_t] = t_value;
 }
 
+// Launch order for the next solve: agents bucketed by the iteration count of their previous solve,
+// largest first (64 buckets, counting sort in LDS by one workgroup; the order inside a bucket is
+// arbitrary).  Replaces a device-wide sort: this is ~10 us.
+__global__ void __launch_bounds__(1024)
+order_kernel(const int32_t* __restrict__ iters, int32_t* __restrict__ order, int B) {
+  __shared__ int cnt[64], off[64];
+  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int it = iters[b];
+    atomicAdd(&cnt[63 - (it < 0 ? 0 : (it > 63 ? 63 : it))], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { int a = 0; for (int k = 0; k < 64; ++k) { off[k] = a; a += cnt[k]; } }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int it = iters[b];
+    order[atomicAdd(&off[63 - (it < 0 ? 0 : (it > 63 ? 63 : it))], 1)] = b;
+  }
+}
+
 __global__ void __launch_bounds__(64)
 shift_kernel(double* __restrict__ x, int x_stride, const uint8_t* __restrict__ mask,
              const int32_t* __restrict__ entries, int n_ent, const double* __restrict__ Tm) {
@@ -505,6 +526,15 @@ int omgx_batch_set_stream(omgx_batch* b, void* s) {
 
 int omgx_batch_set_order(omgx_batch* b, const int32_t* order_device) {
   if (!b) return OMGX_E_INVALID;
+  b->d_order = order_device;
+  return OMGX_OK;
+}
+
+int omgx_batch_order_by_iters(omgx_batch* b, const int32_t* iters_device, int32_t* order_device) {
+  if (!b || !iters_device || !order_device) { g_err = "null argument"; return OMGX_E_INVALID; }
+  HIPCHK(hipSetDevice(b->device));
+  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, b->stream, iters_device, order_device, b->n_agents);
+  HIPCHK(hipGetLastError());
   b->d_order = order_device;
   return OMGX_OK;
 }

@@ -138,6 +138,7 @@ def load_library(path=None):
     lib.omgx_batch_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.omgx_batch_lds_bytes.argtypes = [C.c_void_p]
     lib.omgx_batch_set_order.argtypes = [C.c_void_p, C.c_void_p]
+    lib.omgx_batch_order_by_iters.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.omgx_batch_workspace.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                          C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.omgx_batch_solve.argtypes = [C.c_void_p] + [C.c_void_p] * 8 + [C.c_int32]
@@ -207,6 +208,12 @@ class BatchSolver(object):
         ptr = None if order is None else (order.data_ptr() if hasattr(order, 'data_ptr') else int(order))
         self._order_keep = order
         _check(self.lib, self.lib.omgx_batch_set_order(self._h, ptr), 'omgx_batch_set_order')
+
+    def order_by_iters(self, iters, order):
+        """order <- agents sorted by their previous iteration count (largest first); becomes the launch order."""
+        self._order_keep = order
+        _check(self.lib, self.lib.omgx_batch_order_by_iters(self._h, iters.data_ptr(), order.data_ptr()),
+               'omgx_batch_order_by_iters')
 
     def workspace(self):
         """Placement chosen by the library: mode 0 = all per-agent arrays in LDS, 1..3 = KKT /

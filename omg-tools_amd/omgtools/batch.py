@@ -105,6 +105,7 @@ class BatchP2P(object):
             self._perm_idx = torch.as_tensor(pm, dtype=torch.int64, device=self.dev)
             self._perm_ok = torch.as_tensor((self.perm >= 0).astype(np.float64), **f64)
             self._mask = torch.ones(self.B, dtype=torch.uint8, device=self.dev)
+            self._order = torch.arange(self.B, dtype=torch.int32, device=self.dev)
         else:
             from oracle import port_binding          # test infrastructure only
             self.port = port_binding
@@ -124,8 +125,7 @@ class BatchP2P(object):
                 self.lam.zero_()
             if warm and self.straggler_first:
                 # agents that needed most iterations last time are launched first
-                self._order = self.torch.argsort(self.iters, descending=True).to(self.torch.int32)
-                self.solver.set_order(self._order)
+                self.solver.order_by_iters(self.iters, self._order)
             if events is not None:                 # torch events on the launch stream (bench.py)
                 events[0].record()
             self.solver.solve_device(self.p, self.x, self.lb, self.ub, self.x_new, self.lam,
