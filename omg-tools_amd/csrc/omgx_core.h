@@ -61,7 +61,7 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* cpl_ptr; const int32_t* cpl_idx; const int32_t* cpl_map;
   const int32_t* d_off; const int32_t* b_off;   // panel offsets / leading dimensions inside the KKT store
   // precomputed KKT addresses (HostPlan): Jacobian pairs, t-column, diagonal, Hessian terms
-  const int32_t* pair_a; const int32_t* pair_b; const int32_t* pair_addr;
+  const int32_t* pair4;     // [n_pairs][4] = {Jacobian entry a, entry b, KKT address, row}: one 16-byte record per pair
   const int32_t* je_row; const int32_t* jt_addr; const int32_t* diag_addr;
   const int32_t* h_addr; const int32_t* t_row;
   const double* reg_w;   // [N] position order: inertia-correction class (+1 nonlinear root variable, -1 nonlinear leaf variable, else the weight itself: OMGX_DW_LINEAR)
@@ -263,6 +263,7 @@ typedef CtxT<false> Ctx;
 #endif
 
 #define OMGX_PFOR(i, n) for (int i = c.tid(); i < (n); i += c.nthr())
+#define OMGX_PFOR_U4(i, n) _Pragma("unroll 4") for (int i = c.tid(); i < (n); i += c.nthr())
 
 // optional per-phase cycle counters (profiling build only, -DOMGX_PROFILE)
 enum { PH_JAC = 0, PH_RESID, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_STEP, PH_LINESEARCH, PH_UPDATE, PH_F_LEAF, PH_F_SCHUR, PH_F_ROOT, PH_LA, PH_LS, PH_LB, PH_SETUP, PH_TOTAL, PH_COUNT };
@@ -1140,10 +1141,12 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         w.ds[r] = (ty == ROW_UPPER || ty == ROW_LOWER) ? w.z[r] / w.s[r] : 0.0;
       }
       c.sync();
-      OMGX_PFOR(e, d.n_pairs) {
-        const int a = T.pair_a[e], b = T.pair_b[e];
-        const double sg = w.ds[T.je_row[a]];
-        if (sg != 0.0) c.add(w.kkt + T.pair_addr[e], sg * w.jval[a] * w.jval[b]);
+      OMGX_PFOR_U4(e, d.n_pairs) {
+        // one packed record per pair (a single 16-byte load, no dependent table look-ups) and an
+        // unconditional add: nothing to wait for between pairs, the loads of several pairs overlap
+        const int32_t* q = T.pair4 + 4 * e;
+        const int a = q[0], b = q[1], ad = q[2], r = q[3];
+        c.add(w.kkt + ad, w.ds[r] * w.jval[a] * w.jval[b]);
       }
       double tt_acc = 0.0;
       if (use_t) {

@@ -13,7 +13,7 @@ struct HostPlan {
   Tables tables;            // host pointers (into tpl and the vectors below)
   int kkt_doubles;
   std::vector<int32_t> pos, blk, eq_index, d_off, b_off;
-  std::vector<int32_t> pair_a, pair_b, pair_addr, je_row, jt_addr, diag_addr, h_addr, t_row;
+  std::vector<int32_t> pair4, je_row, jt_addr, diag_addr, h_addr, t_row;
   std::vector<double> reg_w;
 
   bool build(const omgx_template& t) {
@@ -81,18 +81,18 @@ struct HostPlan {
         jt_addr[e] = (r < m && eq_index[r] < 0) ? addr(d.N - 1, t.jr_pos[e]) : 0;
         if (jt_addr[e] < 0) return false;
       }
-    pair_a.clear(); pair_b.clear(); pair_addr.clear();
+    pair4.clear();
     for (int r = 0; r < m; ++r) {
       if (eq_index[r] >= 0) continue;
       for (int a = t.jr_ptr[r]; a < t.jr_ptr[r + 1]; ++a)
         for (int b2 = t.jr_ptr[r]; b2 <= a; ++b2) {
           const int32_t ad = addr(t.jr_pos[a], t.jr_pos[b2]);
           if (ad < 0) return false;
-          pair_a.push_back(a); pair_b.push_back(b2); pair_addr.push_back(ad);
+          pair4.push_back(a); pair4.push_back(b2); pair4.push_back(ad); pair4.push_back(r);
         }
     }
-    d.n_pairs = (int)pair_a.size();
-    if (pair_a.empty()) { pair_a.push_back(0); pair_b.push_back(0); pair_addr.push_back(0); }
+    d.n_pairs = (int)pair4.size() / 4;
+    if (pair4.empty()) pair4.assign(4, 0);
     diag_addr.assign(d.N, 0);
     for (int q = 0; q < d.N; ++q) diag_addr[q] = addr(q, q);
     t_row.assign(d.n_terms > 0 ? d.n_terms : 1, 0);
@@ -111,7 +111,7 @@ struct HostPlan {
           h_addr[3 * tt + k] = ad;
         }
       }
-    T.pair_a = pair_a.data(); T.pair_b = pair_b.data(); T.pair_addr = pair_addr.data();
+    T.pair4 = pair4.data();
     T.je_row = je_row.data(); T.jt_addr = jt_addr.data(); T.diag_addr = diag_addr.data();
     T.h_addr = h_addr.data(); T.t_row = t_row.data();
     reg_w.assign(d.N, OMGX_DW_LINEAR);
