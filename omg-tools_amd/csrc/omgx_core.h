@@ -429,7 +429,7 @@ struct Kkt {
 // Two workgroup barriers per 4 columns instead of two per column.
 // ---------------------------------------------------------------------------
 // offsets (not pointers) so that every access stays a provable LDS access (ds_* instead of flat_*)
-struct BMat { int a, ld, nfact, rows, npos, dinv, pan, pad_; };   // a: offset in kkt; dinv: offset in w.dinv (-1: none); pan: offset in w.col
+struct BMat { int a, ld, nfact, rows, npos, dinv, pan, cpl; };   // cpl: offset of the leaf's coupling index list (cpl_ptr[l])   // a: offset in kkt; dinv: offset in w.dinv (-1: none); pan: offset in w.col
 static_assert(sizeof(BMat) <= 4 * sizeof(double), "BMat larger than its LDS slot");
 #define OMGX_NB 4
 #define OMGX_PAN_LD 5      // panel buffer row stride: U[4] + pad (odd: conflict-free row-per-lane access)
@@ -737,7 +737,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
     for (int l = 0; l < d.n_leaf; ++l) {
       BMat& M = Ms[l];
       M.a = K.T->d_off[l]; M.ld = K.ld(l); M.nfact = K.nl(l); M.rows = K.nl(l) + K.nc(l); M.npos = M.nfact;
-      M.dinv = K.T->leaf_off[l]; M.pan = pan; pan += OMGX_PAN_LD * M.rows;
+      M.dinv = K.T->leaf_off[l]; M.pan = pan; pan += OMGX_PAN_LD * M.rows; M.cpl = K.T->cpl_ptr[l];
     }
     BMat& Mr = Ms[d.n_leaf];
     Mr.a = K.T->d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0;
@@ -773,10 +773,11 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
     const int lane = c.lane();
     int tile0 = 0;
     for (int l = 0; l < d.n_leaf; ++l) {
-      const int n = K.nl(l), nc = K.nc(l), ld = K.ld(l);
-      const double* Wt = K.P(l) + n * ld;
-      const double* di = w.dinv + K.T->leaf_off[l];
-      const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
+      const BMat M = Ms[l];                       // dimensions from LDS, not from the global plan tables
+      const int n = M.nfact, nc = M.rows - M.nfact, ld = M.ld;
+      const double* Wt = w.kkt + M.a + n * ld;
+      const double* di = w.dinv + M.dinv;
+      const int32_t* ci = K.T->cpl_idx + M.cpl;
       const int tn = (nc + 15) >> 4, nwm = c.nwaves() - 1;
       // lower-triangular tile pairs (ti, tj <= ti) numbered consecutively and dealt round-robin
       int tile = 0;
@@ -813,76 +814,142 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   return bad;
 }
 
+// Unit-lower triangular solves in blocks of 4 columns, executed by ONE wave (lanes = rows): every
+// lane reads the 4 right-hand-side entries and the 6 sub-diagonal entries of the block, finishes
+// the block redundantly in registers, then updates its own row with 4 multiply-adds -- n/4
+// wave-synchronised steps instead of n.  `L(i, j)` returns the offset of entry (i, j), i > j.
+template <class C, class Addr>
+OMGX_FN void trsv_fwd4(const C& c, const double* A, Addr L, int n, double* y) {
+  const int lane = c.lane(), nln = c.nlanes();
+  for (int jb = 0; jb < n; jb += 4) {
+    const int nb = (n - jb) < 4 ? (n - jb) : 4;
+    const int q1 = nb > 1 ? 1 : 0, q2 = nb > 2 ? 2 : 0, q3 = nb > 3 ? 3 : 0;
+    const double m1 = nb > 1 ? 1.0 : 0.0, m2 = nb > 2 ? 1.0 : 0.0, m3 = nb > 3 ? 1.0 : 0.0;
+    const double r0 = y[jb], r1 = y[jb + q1], r2 = y[jb + q2], r3 = y[jb + q3];
+    // (masked entries of a partial last block read the diagonal entry (jb, jb): finite, times 0)
+    const double l10 = m1 * A[L(jb + q1, jb)];
+    const double l20 = m2 * A[L(jb + q2, jb)], l21 = m2 * A[L(jb + q2, jb + (q2 ? 1 : 0))];
+    const double l30 = m3 * A[L(jb + q3, jb)], l31 = m3 * A[L(jb + q3, jb + (q3 ? 1 : 0))],
+                 l32 = m3 * A[L(jb + q3, jb + (q3 ? 2 : 0))];
+    const double y0 = r0, y1 = r1 - l10 * y0, y2 = r2 - l20 * y0 - l21 * y1, y3 = r3 - l30 * y0 - l31 * y1 - l32 * y2;
+    for (int i = jb + lane; i < n; i += nln) {
+      if (i >= jb + nb) {
+        const int o = L(i, jb);
+        y[i] -= A[o] * y0 + m1 * A[o + q1] * y1 + m2 * A[o + q2] * y2 + m3 * A[o + q3] * y3;
+      } else {
+        const int q = i - jb;
+        y[i] = q == 0 ? y0 : (q == 1 ? y1 : (q == 2 ? y2 : y3));
+      }
+    }
+    c.wave_sync();
+  }
+}
+
+// x <- L^{-T} y for the same storage (entry (i, j) of L, i > j, multiplies x_i into row j)
+template <class C, class Addr>
+OMGX_FN void trsv_bwd4(const C& c, const double* A, Addr L, int n, double* y) {
+  const int lane = c.lane(), nln = c.nlanes();
+  const int nblk = (n + 3) >> 2;
+  for (int bk = nblk - 1; bk >= 0; --bk) {
+    const int jb = 4 * bk;
+    const int nb = (n - jb) < 4 ? (n - jb) : 4;
+    const int q1 = nb > 1 ? 1 : 0, q2 = nb > 2 ? 2 : 0, q3 = nb > 3 ? 3 : 0;
+    const double m1 = nb > 1 ? 1.0 : 0.0, m2 = nb > 2 ? 1.0 : 0.0, m3 = nb > 3 ? 1.0 : 0.0;
+    const double r0 = y[jb], r1 = m1 * y[jb + q1], r2 = m2 * y[jb + q2], r3 = m3 * y[jb + q3];
+    const double l10 = m1 * A[L(jb + q1, jb)];
+    const double l20 = m2 * A[L(jb + q2, jb)], l21 = m2 * A[L(jb + q2, jb + (q2 ? 1 : 0))];
+    const double l30 = m3 * A[L(jb + q3, jb)], l31 = m3 * A[L(jb + q3, jb + (q3 ? 1 : 0))],
+                 l32 = m3 * A[L(jb + q3, jb + (q3 ? 2 : 0))];
+    const double x3 = r3, x2 = r2 - l32 * x3, x1 = r1 - l21 * x2 - l31 * x3, x0 = r0 - l10 * x1 - l20 * x2 - l30 * x3;
+    for (int i = lane; i < jb + nb; i += nln) {
+      if (i < jb) {
+        y[i] -= A[L(jb, i)] * x0 + m1 * A[L(jb + q1, i)] * x1 + m2 * A[L(jb + q2, i)] * x2 + m3 * A[L(jb + q3, i)] * x3;
+      } else {
+        const int q = i - jb;
+        y[i] = q == 0 ? x0 : (q == 1 ? x1 : (q == 2 ? x2 : x3));
+      }
+    }
+    c.wave_sync();
+  }
+}
+
 // Solve K sol = rhs in place (sol holds rhs on entry); position order + eq.
 template <class C>
 OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double* sol) {
   double* yr = sol + d.root_off;
   const int lane = c.lane(), nln = c.nlanes();
+  // leaf dimensions from the matrix descriptors kkt_factor left in LDS (not from the global plan
+  // tables: every look-up there is a dependent global load)
+  const BMat* Ms = (const BMat*)w.col;
   // leaves (wave-parallel): y_l <- Delta^{-1} L^{-1} r_l
   for (int l = c.wave(); l < d.n_leaf; l += c.nwaves()) {
-    const int n = K.nl(l), ld = K.ld(l);
-    const double* Pn = K.P(l);
-    double* yl = sol + K.T->leaf_off[l];
-    const double* di = w.dinv + K.T->leaf_off[l];
-    for (int j = 0; j < n - 1; ++j) {
-      const double yj = yl[j];
-      for (int i = j + 1 + lane; i < n; i += nln) yl[i] -= Pn[i * ld + j] * yj;
-      c.wave_sync();
-    }
+    const BMat M = Ms[l];
+    const int n = M.nfact, ld = M.ld, base = M.a;
+    double* yl = sol + M.dinv;
+    const double* di = w.dinv + M.dinv;
+    trsv_fwd4(c, w.kkt, [=](int i, int j) { return base + i * ld + j; }, n, yl);
     for (int i = lane; i < n; i += nln) yl[i] *= di[i];
     c.wave_sync();
   }
   c.sync();
-  // root rhs:  r_r -= sum_l Wt_l y_l
-  OMGX_PFOR(i, d.n_root) {
-    double acc = 0.0;
-    for (int l = 0; l < d.n_leaf; ++l) {
-      const int a = K.T->cpl_map[l * d.n_root + i];
-      if (a < 0) continue;
-      const int n = K.nl(l), ld = K.ld(l);
-      const double* wrow = K.P(l) + (n + a) * ld;
-      const double* yl = sol + K.T->leaf_off[l];
-      for (int j = 0; j < n; ++j) acc += wrow[j] * yl[j];
+  // root rhs:  r_r -= sum_l Wt_l y_l, spread over the whole workgroup: one item = (leaf, coupling
+  // row, chunk of 8 leaf columns), partial sums added with LDS atomics
+  {
+    int items = 0;
+    for (int l = 0; l < d.n_leaf; ++l) items += (Ms[l].rows - Ms[l].nfact) * ((Ms[l].nfact + 7) >> 3);
+    OMGX_PFOR(it, items) {
+      int l = 0, e = it;
+      for (;; ++l) { const int cnt = (Ms[l].rows - Ms[l].nfact) * ((Ms[l].nfact + 7) >> 3); if (e < cnt) break; e -= cnt; }
+      const BMat M = Ms[l];
+      const int n = M.nfact, ld = M.ld, nch = (n + 7) >> 3;
+      const int a = e / nch, j0 = 8 * (e - a * nch);
+      const double* wrow = w.kkt + M.a + (n + a) * ld;
+      const double* yl = sol + M.dinv;
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int j = j0 + q < n ? j0 + q : n - 1; acc += (j0 + q < n ? 1.0 : 0.0) * wrow[j] * yl[j]; }
+      c.add(yr + K.T->cpl_idx[M.cpl + a], -acc);
     }
-    yr[i] -= acc;
   }
   c.sync();
   // root solve by wave 0 (packed L)
   if (c.wave() == 0) {
-    const double* R = K.R();
-    const int n = d.nr;
-    for (int j = 0; j < n - 1; ++j) {
-      const double yj = yr[j];
-      for (int i = j + 1 + lane; i < n; i += nln) yr[i] -= R[tri(i, j)] * yj;
-      c.wave_sync();
-    }
-    for (int i = lane; i < n; i += nln) yr[i] /= R[tri(i, i)];
+    const int n = d.nr, rbase = Ms[d.n_leaf].a;
+    auto Lr = [=](int i, int j) { return rbase + tri(i, j); };
+    trsv_fwd4(c, w.kkt, Lr, n, yr);
+    for (int i = lane; i < n; i += nln) yr[i] /= w.kkt[rbase + tri(i, i)];
     c.wave_sync();
-    for (int j = n - 1; j > 0; --j) {
-      const double yj = yr[j];
-      for (int i = lane; i < j; i += nln) yr[i] -= R[tri(j, i)] * yj;
-      c.wave_sync();
+    trsv_bwd4(c, w.kkt, Lr, n, yr);
+  }
+  c.sync();
+  // leaves: y_l <- L^{-T} (y_l - Delta^{-1} Wt' x_r); the correction term again item-parallel over
+  // (leaf, leaf column, chunk of 8 coupling rows)
+  {
+    int items = 0;
+    for (int l = 0; l < d.n_leaf; ++l) items += Ms[l].nfact * ((Ms[l].rows - Ms[l].nfact + 7) >> 3);
+    OMGX_PFOR(it, items) {
+      int l = 0, e = it;
+      for (;; ++l) { const int cnt = Ms[l].nfact * ((Ms[l].rows - Ms[l].nfact + 7) >> 3); if (e < cnt) break; e -= cnt; }
+      const BMat M = Ms[l];
+      const int n = M.nfact, nc = M.rows - M.nfact, ld = M.ld;
+      const int ch = e / n, j = e - ch * n, a0 = 8 * ch;
+      const double* Pn = w.kkt + M.a;
+      const int32_t* ci = K.T->cpl_idx + M.cpl;
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int a = a0 + q < nc ? a0 + q : nc - 1;
+        acc += (a0 + q < nc ? 1.0 : 0.0) * Pn[(n + a) * ld + j] * yr[ci[a]];
+      }
+      c.add(sol + M.dinv + j, -acc * w.dinv[M.dinv + j]);
     }
   }
   c.sync();
-  // leaves: y_l <- L^{-T} (y_l - Delta^{-1} Wt' x_r)
   for (int l = c.wave(); l < d.n_leaf; l += c.nwaves()) {
-    const int n = K.nl(l), nc = K.nc(l), ld = K.ld(l);
-    const double* Pn = K.P(l);
-    double* yl = sol + K.T->leaf_off[l];
-    const double* di = w.dinv + K.T->leaf_off[l];
-    const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
-    for (int j = lane; j < n; j += nln) {
-      double acc = 0.0;
-      for (int a = 0; a < nc; ++a) acc += Pn[(n + a) * ld + j] * yr[ci[a]];
-      yl[j] -= acc * di[j];
-    }
-    c.wave_sync();
-    for (int j = n - 1; j > 0; --j) {
-      const double yj = yl[j];
-      for (int i = lane; i < j; i += nln) yl[i] -= Pn[j * ld + i] * yj;
-      c.wave_sync();
-    }
+    const BMat M = Ms[l];
+    const int n = M.nfact, ld = M.ld, base = M.a;
+    double* yl = sol + M.dinv;
+    trsv_bwd4(c, w.kkt, [=](int i, int j) { return base + i * ld + j; }, n, yl);
   }
   c.sync();
 }
