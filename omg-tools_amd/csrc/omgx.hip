@@ -423,7 +423,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   UP(jc_ptr, d.n_var + 1); UP(jc_row, d.nnz_j); UP(jc_ent, d.nnz_j);
   UP(cpl_ptr, d.n_leaf + 1); UP(cpl_idx, n_cpl); UP(cpl_map, (d.n_leaf > 0 ? d.n_leaf : 1) * d.n_root);
   UP(d_off, d.n_leaf + 1); UP(b_off, d.n_leaf > 0 ? d.n_leaf : 1);
-  UP(pair4, plan.pair4.size());
+  UP(pair4, plan.pair4.size()); UP(eqe3, plan.eqe3.size());
   UP(je_row, plan.je_row.size()); UP(jt_addr, plan.jt_addr.size()); UP(diag_addr, d.N);
   UP(h_addr, plan.h_addr.size()); UP(t_row, plan.t_row.size()); UP(reg_w, d.N);
   return OMGX_OK;

@@ -45,6 +45,7 @@ struct Dims {
   int n_leaf, n_root, n_eq, nnz_j, root_off;
   int nr;       // n_root + n_eq: order of the root block
   int n_pairs;  // Jacobian entry pairs contributing to J' Sigma J
+  int n_eqe;    // Jacobian entries of the equality rows
   int max_leaf, max_cpl;
   int col_doubles;   // scratch for the blocked LDL' (staging + panel buffers)
 };
@@ -61,6 +62,7 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* cpl_ptr; const int32_t* cpl_idx; const int32_t* cpl_map;
   const int32_t* d_off; const int32_t* b_off;   // panel offsets / leading dimensions inside the KKT store
   // precomputed KKT addresses (HostPlan): Jacobian pairs, t-column, diagonal, Hessian terms
+  const int32_t* eqe3;      // [n_eqe][3] = {Jacobian entry, KKT address, row} of the equality-row entries
   const int32_t* pair4;     // [n_pairs][4] = {Jacobian entry a, entry b, KKT address, row}: one 16-byte record per pair
   const int32_t* je_row; const int32_t* jt_addr; const int32_t* diag_addr;
   const int32_t* h_addr; const int32_t* t_row;
@@ -722,13 +724,11 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
   *bad = c.rmax(badl ? 1.0 : 0.0) > 0.0 ? 1 : 0;
 }
 
-// Factorise the assembled block-arrow matrix in place.  Returns 0 if the
-// inertia is (N positive, n_eq negative), 1 otherwise.
+// Matrix descriptors of the block-arrow store: written once per solve at the head of w.col (shared
+// by the workgroup; the plan tables they come from are global memory, i.e. a chain of dependent
+// loads per look-up), followed by the staging area and the panel buffers.
 template <class C>
-OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
-  int bad = 0;
-  OMGX_TIC();
-  // matrix descriptors live in LDS (shared by the workgroup), then staging, then panel buffers
+OMGX_FN void kkt_describe(const C& c, const Dims& d, const Kkt& K, Work& w) {
   BMat* Ms = (BMat*)w.col;
   double* stage = w.col + OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1);
   const int pan0 = (int)(stage + OMGX_STAGE_LD * (OMGX_MAX_LEAF + 1) - w.col);
@@ -743,6 +743,16 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
     Mr.a = K.T->d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0;
   }
   c.sync();
+}
+
+// Factorise the assembled block-arrow matrix in place.  Returns 0 if the
+// inertia is (N positive, n_eq negative), 1 otherwise.
+template <class C>
+OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
+  int bad = 0;
+  OMGX_TIC();
+  BMat* Ms = (BMat*)w.col;
+  double* stage = w.col + OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1);
   if (d.n_leaf > 0) {
 #ifdef OMGX_LDL_MFMA
     ldl_blocked(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, stage, &bad);
@@ -967,6 +977,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   Result res; res.status = 1; res.iters = 0; res.f = 0; res.mu = o.mu_init; res.t = 0; res.dw = 0;
   Kkt K; K.d = &d; K.T = &T; K.a = w.kkt;
   OMGX_TIC();
+  kkt_describe(c, d, K, w);
 
   eval_params(c, d, T, w, p);
   OMGX_PFOR(i, n) w.x[i] = x0[i];
@@ -1225,14 +1236,14 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         OMGX_PFOR(r, m) tt_acc += w.ds[r] * w.vv[r] * w.vv[r];
       }
       // equality rows straight into the root block
+      OMGX_PFOR(i, d.n_eqe) {                                   // one thread per equality-row entry
+        const int32_t* q = T.eqe3 + 3 * i;                     // {Jacobian entry, KKT address, row}
+        if (w.rtype[q[2]] == ROW_EQ) w.kkt[q[1]] = w.jval[q[0]];
+      }
       OMGX_PFOR(k, d.n_eq) {
         const int r = T.eq_rows[k];
         double* Rr = K.R();
-        if (w.rtype[r] == ROW_EQ) {
-          for (int a = T.jr_ptr[r]; a < T.jr_ptr[r + 1]; ++a)
-            Rr[tri(d.n_root + k, T.jr_pos[a] - d.root_off)] = w.jval[a];
-          if (use_t) Rr[tri(d.n_root + k, d.n_root - 1)] = -w.vv[r];
-        }
+        if (use_t && w.rtype[r] == ROW_EQ) Rr[tri(d.n_root + k, d.n_root - 1)] = -w.vv[r];
         Rr[tri(d.n_root + k, d.n_root + k)] = -OMGX_DELTA_C;
       }
       // Lagrangian Hessian: terms with >= 2 variables, weight = multiplier * signed scale

@@ -13,7 +13,7 @@ struct HostPlan {
   Tables tables;            // host pointers (into tpl and the vectors below)
   int kkt_doubles;
   std::vector<int32_t> pos, blk, eq_index, d_off, b_off;
-  std::vector<int32_t> pair4, je_row, jt_addr, diag_addr, h_addr, t_row;
+  std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, h_addr, t_row;
   std::vector<double> reg_w;
 
   bool build(const omgx_template& t) {
@@ -91,6 +91,15 @@ struct HostPlan {
           pair4.push_back(a); pair4.push_back(b2); pair4.push_back(ad); pair4.push_back(r);
         }
     }
+    eqe3.clear();
+    for (int k = 0; k < d.n_eq; ++k) {
+      const int r = t.eq_rows[k];
+      for (int a = t.jr_ptr[r]; a < t.jr_ptr[r + 1]; ++a) {
+        eqe3.push_back(a); eqe3.push_back(d_off[d.n_leaf] + tri(d.n_root + k, t.jr_pos[a] - d.root_off)); eqe3.push_back(r);
+      }
+    }
+    d.n_eqe = (int)eqe3.size() / 3;
+    if (eqe3.empty()) eqe3.assign(3, 0);
     d.n_pairs = (int)pair4.size() / 4;
     if (pair4.empty()) pair4.assign(4, 0);
     diag_addr.assign(d.N, 0);
@@ -111,7 +120,7 @@ struct HostPlan {
           h_addr[3 * tt + k] = ad;
         }
       }
-    T.pair4 = pair4.data();
+    T.pair4 = pair4.data(); T.eqe3 = eqe3.data();
     T.je_row = je_row.data(); T.jt_addr = jt_addr.data(); T.diag_addr = diag_addr.data();
     T.h_addr = h_addr.data(); T.t_row = t_row.data();
     reg_w.assign(d.N, OMGX_DW_LINEAR);
