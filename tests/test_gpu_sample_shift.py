@@ -104,3 +104,31 @@ def test_predict_matches_basis_evaluation(cfg2_small):
         keep = np.ones(tpl.n_par, bool); keep[o_s0:o_s0 + nd] = False; keep[o_i0:o_i0 + nd] = False; keep[o_t] = False
         assert np.array_equal(p[:, keep], P['p'][:, keep])
     solver.close()
+
+
+def test_order_by_iters_is_a_bucketed_permutation(cfg2_small):
+    """`omgx_batch_order_by_iters`: a permutation of the agents, iteration counts (clamped to 63)
+    non-increasing along it; installing it as the launch order does not change any result."""
+    import torch
+    from omgtools.backend import BatchSolver
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    B = 64
+    p = np.tile(P['p'], (B // 8, 1)); x0 = np.tile(P['x0'], (B // 8, 1))
+    solver = BatchSolver(tpl, B)
+    dev = torch.device('cuda', 0)
+    solver.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(3)
+    iters = torch.as_tensor(rng.integers(0, 120, size=B).astype(np.int32), device=dev)
+    order = torch.zeros(B, dtype=torch.int32, device=dev)
+    solver.order_by_iters(iters, order)
+    solver.sync()
+    o = order.cpu().numpy(); it = np.minimum(iters.cpu().numpy(), 63)
+    assert sorted(o.tolist()) == list(range(B))
+    assert np.all(np.diff(it[o]) <= 0)
+    res = solver.solve(p, x0)                       # launched in that order
+    solver.set_order(None)
+    ref = solver.solve(p, x0)
+    assert np.array_equal(res['status'], ref['status']) and np.ptp(res['iters'] - ref['iters']) <= 1
+    assert np.abs(res['x'] - ref['x']).max() < 1e-6
+    solver.close()
