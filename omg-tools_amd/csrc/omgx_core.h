@@ -1181,7 +1181,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     // and is declared locally infeasible only at nu_max; a cold solve gives up at once (an agent
     // that is locally infeasible would otherwise burn ~150 iterations in every receding-horizon step).
     if (use_t && it > 0 && it % OMGX_STALL_ITERS == 0) {
-      if (t > o.tol && t > 0.9 * t_check) {
+      // (t sits at mu / z_t ~ mu / nu on the central path of a feasible problem: only a t well above
+      // that counts as phase I not finishing)
+      if (t > fmax(o.tol, 10.0 * mu / nu) && t > 0.9 * t_check) {
         if (nu >= nu_stall_max) infeasible = 1;
         else { nu *= 10.0; zt += 0.9 * nu; }
       }

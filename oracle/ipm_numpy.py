@@ -377,7 +377,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         if use_t and it > 0 and it % o['stall_iters'] == 0:
             # phase I stalls: a warm-started solve raises the penalty weight first (local infeasibility
             # only at nu_max), a cold solve gives up at once
-            if t > o['tol'] and t > o.get('stall_factor', 0.9) * t_check:
+            if t > max(o['tol'], 10.0 * mu / nu) and t > o.get('stall_factor', 0.9) * t_check:
                 if z0 is None or nu >= o['nu_max']:
                     status = 2
                 else:

@@ -1,0 +1,21 @@
+"""Test helper: an INDEPENDENT solver (scipy SLSQP, dense SQP with its own QP solver and line
+search) on the restated NLP (oracle/nlp_numpy.py) -- the stand-in SURVEY.md 8c prescribes for the
+unobtainable CasADi/IPOPT outputs.  From the same initial guess it must reach the same local
+minimum as the interior-point path."""
+import numpy as np
+from scipy.optimize import minimize
+
+
+def solve_slsqp(nlp, tpl, x0, p, maxiter=400):
+    c = nlp.term_coefs(p)
+    eq = tpl.lb == tpl.ub
+    ineq = np.isfinite(tpl.ub) & ~eq
+    lo = np.isfinite(tpl.lb) & ~eq
+    assert not lo.any()                      # in-scope rows are g <= ub or g == b
+    cons = [{'type': 'eq', 'fun': lambda v: nlp.fg(v, c)[1][eq] - tpl.lb[eq], 'jac': lambda v: nlp.jac(v, c)[:-1][eq]},
+            {'type': 'ineq', 'fun': lambda v: (tpl.ub - nlp.fg(v, c)[1])[ineq], 'jac': lambda v: -nlp.jac(v, c)[:-1][ineq]}]
+    out = minimize(lambda v: nlp.fg(v, c)[0], x0, jac=lambda v: nlp.jac(v, c)[-1], constraints=cons,
+                   method='SLSQP', options={'maxiter': maxiter, 'ftol': 1e-12})
+    g = nlp.fg(out.x, c)[1]
+    viol = max((g - tpl.ub)[ineq].max(), np.abs(g[eq] - tpl.lb[eq]).max())
+    return out.x, float(out.fun), bool(out.status == 0 and viol < 1e-8)

@@ -74,3 +74,16 @@ def test_cfg2_matches_port_and_numpy(cfg2_small):
         break
     assert checked == 1
     solver.close()
+
+
+def test_hip_reaches_the_slsqp_minimum():
+    """Independent-solver parity (tests/test_independent_solver.py) on the HIP path."""
+    from omgtools.backend import BatchSolver
+    from test_independent_solver import slsqp_cases, check_against_slsqp
+
+    def solve(tpl, p, x0):
+        solver = BatchSolver(tpl, 1, options=dict(tol=1e-6, max_iter=500))
+        res = solver.solve(p[None], x0[None])
+        solver.close()
+        return res
+    check_against_slsqp(slsqp_cases(), solve)
