@@ -92,3 +92,34 @@ def test_obstacle_position_spline_closed_form():
                 assert abs(BSpline(obs.basis, cf)(tau) - want) < 1e-12
     finally:
         be.create_nlp = saved
+
+
+def test_bad_arguments_return_error_codes(cfg2_small):
+    """Error behaviour of the C ABI: negative codes + `omgx_last_error`, nothing throws; argument
+    checks come before any device work, so they are testable without a GPU."""
+    import ctypes as C
+    import omgtools.backend as be
+    problem, _ = cfg2_small
+    lib = be.load_library()
+    ct, keep = be.make_ctemplate(problem.father.template)
+    h = C.c_void_p()
+    assert lib.omgx_batch_create(C.byref(ct), 0, 0, C.byref(h)) == -1            # OMGX_E_INVALID: empty batch
+    assert b'bad argument' in lib.omgx_last_error()
+    assert lib.omgx_batch_create(None, 4, 0, C.byref(h)) == -1
+    assert lib.omgx_batch_create(C.byref(ct), 4, 0, None) == -1
+    lib.omgx_batch_solve.restype = C.c_int
+    assert lib.omgx_batch_solve(None, None, None, None, None, None, None, None, None, 0) == -1
+    assert lib.omgx_batch_set_options(None, None) == -1
+    assert lib.omgx_batch_sync(None) == -1
+    lib.omgx_batch_destroy(None)                                                  # no-op
+    for code, name in ((0, b'Solve_Succeeded'), (1, b'Maximum_Iterations_Exceeded'),
+                       (2, b'Infeasible_Problem_Detected'), (3, b'Unsupported_Bounds'),
+                       (4, b'Numerical_Failure'), (99, b'Unknown')):
+        assert lib.omgx_status_string(code) == name
+    opt = be.COptions()
+    lib.omgx_default_options(C.byref(opt))
+    assert (opt.tol, opt.max_iter, opt.warm_start) == (1e-3, 300, 0) and opt.dw_leaf_ratio_cold == 1.0
+    # a template whose plan is inconsistent is rejected, not executed
+    ct2, keep2 = be.make_ctemplate(problem.father.template)
+    ct2.n_root = ct2.n_root + 1
+    assert lib.omgx_batch_create(C.byref(ct2), 4, 0, C.byref(h)) in (-1, -2)      # invalid (or no device first)

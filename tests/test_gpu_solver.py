@@ -87,3 +87,37 @@ def test_hip_reaches_the_slsqp_minimum():
         solver.close()
         return res
     check_against_slsqp(slsqp_cases(), solve)
+
+
+def test_ragged_batch_and_masked_shift(cfg2_small):
+    """Batch sizes that are not a multiple of anything (1, 7, 130 agents) give the same per-agent
+    results; a masked warm-start shift leaves the unmasked agents untouched."""
+    from omgtools.backend import BatchSolver
+    from omgtools.splines import shiftoverknot_T
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    ref = None
+    for B in (1, 7, 130):
+        idx = np.arange(B) % 8
+        solver = BatchSolver(tpl, B, options=dict(tol=1e-3, max_iter=300))
+        res = solver.solve(P['p'][idx], P['x0'][idx])
+        if ref is None:
+            ref = res
+        assert np.array_equal(res['status'][:1], ref['status'][:1])
+        assert np.abs(res['x'][0] - ref['x'][0]).max() < 1e-6
+        for b in range(B):
+            assert np.abs(res['x'][b] - res['x'][idx[b]]).max() < 1e-6
+        if B == 7:
+            veh = problem.vehicles[0]
+            lo, rows, cols = tpl.var_layout[(veh.label, 'splines_seg0')]
+            Tm = shiftoverknot_T(veh.basis)
+            x = res['x'].copy()
+            mask = np.array([1, 0, 1, 0, 0, 1, 0], dtype=np.uint8)
+            out = np.ascontiguousarray(x.copy())
+            solver.shift(out, mask, np.array([[lo, rows, cols, 0]], dtype=np.int32), Tm.reshape(-1))      # in place
+            want = x.copy()
+            blk = x[:, lo:lo + rows * cols].reshape(B, cols, rows)
+            want[:, lo:lo + rows * cols] = np.where(mask[:, None].astype(bool), (blk @ Tm.T).reshape(B, -1),
+                                                    x[:, lo:lo + rows * cols])
+            assert np.abs(out - want).max() < 1e-12
+        solver.close()
