@@ -164,13 +164,11 @@ class Problem(OptiChild, PlotLayer):
 
 
 class Point2point(object):
-    """Factory selecting fixed-T vs free-T (`point2point.py:28-35`); free-T is
-    listed under SURVEY.md §8f 'next' and not built yet."""
+    """Factory selecting fixed-T vs free-T (`point2point.py:28-35`)."""
 
     def __new__(cls, fleet, environment, options=None, freeT=False):
         if freeT:
-            raise NotImplementedError('FreeTPoint2point is outside the current hot-path '
-                                      'scope (SURVEY.md §8f rank 2)')
+            return FreeTPoint2point(fleet, environment, options)
         return FixedTPoint2point(fleet, environment, options)
 
 
@@ -185,9 +183,13 @@ class Point2pointProblem(Problem):
         Problem.set_default_options(self)
         self.options['inter_vehicle_avoidance'] = False
 
-    def construct(self):
+    def define_time(self):
+        """T, t and t0 = t/T (`point2point.py:53-55`); FreeT overrides."""
         self.T, self.t = self.define_parameter('T'), self.define_parameter('t')
         self.t0 = self.t / self.T
+
+    def construct(self):
+        self.define_time()
         Problem.construct(self)
         for vehicle in self.vehicles:
             splines = vehicle.define_splines(n_seg=1)
@@ -347,4 +349,96 @@ class FixedTPoint2point(Point2pointProblem):
                     g = self.father.get_variables(self, 'g' + str(k))[0]
                     obj += self.options['horizon_time'] * g.integral()
             return obj
+        return self.objective
+
+
+class FreeTPoint2point(Point2pointProblem):
+    """Free end time (`point2point.py:269-369`): the motion time T is a variable and the
+    objective; hard terminal constraints; after every update the spline is re-expressed on the
+    remaining horizon (`shift_spline`) and T reduced by the update time.
+
+    The reference resolves symbols by name, so that the parameter `T` the base class defines first
+    ends up unused (every `T` becomes the variable) but stays in the parameter vector; that
+    layout is kept.  Its `t` is always 0 for this problem class (the time axis resets every
+    update, `point2point.py:299-306`), so t0 = t/T is the constant 0 here; `set_init_time` is not
+    supported for free-T problems."""
+
+    def __init__(self, fleet, environment, options):
+        Point2pointProblem.__init__(self, fleet, environment, options)
+        self.objective = 0.
+
+    def define_time(self):
+        self.define_parameter('T')                       # kept for the reference's parameter layout
+        self.t = self.define_parameter('t')
+        self.T = self.define_variable('T', value=10.)
+        self.t0 = 0.
+
+    def construct(self):
+        Point2pointProblem.construct(self)
+        self.define_objective(self.T)
+        self.define_constraint(-self.T, -inf, 0.)          # positive motion time
+        self.define_init_constraints()
+        self.define_terminal_constraints()
+
+    def define_terminal_constraints(self):
+        for vehicle in self.vehicles:
+            term_con, term_con_der = vehicle.get_terminal_constraints(vehicle.splines[0])
+            if self.options.get('no_term_con_der'):
+                term_con_der = []
+            for spline, condition in term_con + term_con_der:
+                self.define_constraint(spline(1.) - condition, 0., 0.)
+
+    def set_parameters(self, current_time):
+        if self.init_time is not None:
+            raise NotImplementedError('set_init_time is not supported for free-T problems')
+        return {self: {'t': 0.}}
+
+    # -- deployment --------------------------------------------------------------------
+    def horizon(self):
+        return float(np.asarray(self.father.get_variables(self, 'T')).reshape(-1)[0])
+
+    def init_step(self, current_time, update_time):
+        if (current_time - self.start_time) > 0:
+            T = self.horizon()
+            if T < 2 * update_time:            # almost arrived: lower the update time
+                update_time = T - update_time
+                target_time = T
+            else:
+                target_time = T - update_time
+            from .splines import shift_spline_T
+            cache = {}
+
+            def shift(coeffs, basis, _T=None):
+                key = id(basis)
+                if key not in cache:
+                    cache[key] = shift_spline_T(basis, update_time / target_time)
+                return cache[key].dot(coeffs)
+            self.father.transform_primal_splines(shift)
+            self.father.set_variables(target_time, self, 'T')
+
+    def store(self, current_time, update_time, sample_time):
+        horizon_time = self.horizon()
+        if horizon_time < sample_time:
+            return
+        for vehicle in self.vehicles:
+            n_samp = int(round(horizon_time / sample_time, 6)) + 1
+            time_axis = np.linspace(0., (n_samp - 1) * sample_time, n_samp)
+            segments = [self.father.get_variables(vehicle, 'splines_seg' + str(k))
+                        for k in range(vehicle.n_seg)]
+            vehicle.store(current_time, sample_time, segments, horizon_time, time_axis)
+
+    def simulate(self, current_time, simulation_time, sample_time):
+        horizon_time = self.horizon()
+        if horizon_time < sample_time:
+            return
+        simulation_time = min(simulation_time, horizon_time)
+        self.objective = current_time + simulation_time - self.start_time
+        Problem.simulate(self, current_time, simulation_time, sample_time)
+
+    def stop_criterium(self, current_time, update_time):
+        if self.horizon() < update_time:
+            return True
+        return Point2pointProblem.stop_criterium(self, current_time, update_time)
+
+    def compute_objective(self):
         return self.objective

@@ -363,6 +363,17 @@ def shift_over_knot(coeffs, basis):
     return matvec(shiftoverknot_T(basis), coeffs)
 
 
+def shift_spline_T(basis, t_shift):
+    """Matrix of the free-T warm-start shift (`spline_extra.py:88-99`): the piece of the spline on
+    [t_shift, 1] re-expressed on a basis with equidistant knots on that interval (same number of
+    knots, so the approximation is not exact -- it is an initial guess)."""
+    d = basis.degree
+    n_knots = len(basis) - d + 1
+    knots2 = np.r_[t_shift * np.ones(d), np.linspace(t_shift, basis.knots[-1], n_knots),
+                   basis.knots[-1] * np.ones(d)]
+    return BSplineBasis(knots2, d).transform(basis)
+
+
 def shiftfirstknot_T(basis, t_shift, inverse=False):
     """Matrix re-expressing a spline on the basis whose first degree+1 knots sit
     at t_shift (only the future part [t_shift, 1] is described); identity

@@ -81,14 +81,14 @@ def dump(problem, tag, rng, n_pts=4):
     lb, ub = father._lb.cat.copy(), father._ub.cat.copy()
     n_var, n_par = x_init.size, p0.size
     t_idx = [off for (name, off, r, c) in layout_of(father._par_struct) if name.endswith('/t')][0]
-    knot_time = problem.knot_time
+    knot_time = getattr(problem, 'knot_time', None)       # FreeT: no knot time, t is always 0
     xs, ps, fs, gs = [], [], [], []
     for k in range(n_pts):
         x = x_reinit + rng.normal(scale=0.5, size=n_var) if k else x_reinit.copy()
         p = p0.copy()
         if k:
             p += rng.normal(scale=0.2, size=n_par) * (np.abs(p0) > 0)
-            p[t_idx] = rng.uniform(0., 0.999 * knot_time)
+            p[t_idx] = rng.uniform(0., 0.999 * knot_time) if knot_time else 0.
         env = {X: x.reshape(-1, 1), Pm: p.reshape(-1, 1)}
         f = nlp['f'].eval(env) if hasattr(nlp['f'], 'eval') else np.array(nlp['f'])
         g = nlp['g'].cat.eval(env)
@@ -175,6 +175,17 @@ def main():
     problem = Point2point(vehicle, environment, options=opts, freeT=False)
     problem.init()
     dump(problem, 'quadrotor_k13_o2', rng)
+
+    # free end time (`point2point.py:269-369`): T is a variable, objective T, hard terminal constraints
+    vehicle = Holonomic()
+    vehicle.set_initial_conditions([-1.5, -1.5])
+    vehicle.set_terminal_conditions([2., 2.])
+    environment = Environment(room={'shape': sh.Square(5.)})
+    environment.add_obstacle(Obstacle({'position': [0.2, -0.4]}, shape=sh.Circle(0.4)))
+    environment.add_obstacle(Obstacle({'position': [1.0, 1.2], 'velocity': [-0.1, 0.05]}, shape=sh.Circle(0.3)))
+    problem = Point2point(vehicle, environment, options=quiet, freeT=True)
+    problem.init()
+    dump(problem, 'freeT_holonomic', rng)
 
     # spline known-answer matrices straight from the reference's spline algebra
     rs, rx = m['basics.spline'], m['basics.spline_extra']

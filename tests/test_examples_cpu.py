@@ -59,3 +59,37 @@ def test_p2p_holonomic_example_reaches_target():
     n = min(state.shape[1], obstacle.signals['position'].shape[1])
     dist = np.linalg.norm(state[:, :n] - obstacle.signals['position'][:, :n], axis=0)
     assert dist.min() >= 0.5 + 0.1 - 2e-2
+
+
+def _free_T_run():
+    from omgtools import Holonomic, Environment, Obstacle, Circle, Square, Point2point, Simulator
+    vehicle = Holonomic()
+    vehicle.set_initial_conditions([-1.5, -1.5])
+    vehicle.set_terminal_conditions([2., 2.])
+    environment = Environment(room={'shape': Square(5.)})
+    environment.add_obstacle(Obstacle({'position': [0.2, -0.4]}, shape=Circle(0.4)))
+    moving = Obstacle({'position': [1.0, 1.2], 'velocity': [-0.1, 0.05]}, shape=Circle(0.3))
+    environment.add_obstacle(moving)
+    problem = Point2point(vehicle, environment, options={'verbose': 0}, freeT=True)
+    problem.init()
+    trajectories, signals = Simulator(problem).run()
+    return problem, signals, moving
+
+
+def check_free_T_run(problem, signals, moving):
+    state = signals['state']
+    assert np.linalg.norm(state[:, -1] - np.array([2., 2.])) < 1e-2
+    assert np.abs(signals['input']).max() <= 0.5 + 1e-3
+    # free end time: close to the time-optimal transfer (4.95 m at |v|_inf <= 0.5: >= 7 s), and the
+    # objective is the elapsed motion time (`point2point.py:361-365`)
+    t_end = signals['time'][0, -1]
+    assert 7.0 < t_end < 9.5 and abs(problem.compute_objective() - t_end) < 0.11
+    assert np.linalg.norm(state - np.array([[0.2], [-0.4]]), axis=0).min() >= 0.4 + 0.1 - 2e-2
+    n = min(state.shape[1], moving.signals['position'].shape[1])
+    assert np.linalg.norm(state[:, :n] - moving.signals['position'][:, :n], axis=0).min() >= 0.3 + 0.1 - 2e-2
+
+
+def test_free_T_point2point_reaches_target():
+    """`FreeTPoint2point` (`point2point.py:269-369`): T is a variable and the objective; the NLP
+    itself is pinned against the reference in tests/test_golden_nlp.py (freeT_holonomic)."""
+    check_free_T_run(*_free_T_run())

@@ -80,12 +80,20 @@ def build(tag):
         opts = dict(quiet)
         opts.update({'horizon_time': 5.})
         problem = Point2point(vehicle, environment, options=opts, freeT=False)
+    elif tag == 'freeT_holonomic':
+        vehicle = Holonomic()
+        vehicle.set_initial_conditions([-1.5, -1.5])
+        vehicle.set_terminal_conditions([2., 2.])
+        environment = Environment(room={'shape': Square(5.)})
+        environment.add_obstacle(Obstacle({'position': [0.2, -0.4]}, shape=Circle(0.4)))
+        environment.add_obstacle(Obstacle({'position': [1.0, 1.2], 'velocity': [-0.1, 0.05]}, shape=Circle(0.3)))
+        problem = Point2point(vehicle, environment, options=quiet, freeT=True)
     problem.init()
     return problem
 
 
 TAGS = ['cfg1_p2p_holonomic', 'cfg2_holonomic_k11_o3', 'holonomic_rectangles',
-        'holonomic3d_spheres', 'quadrotor_k13_o2']
+        'holonomic3d_spheres', 'quadrotor_k13_o2', 'freeT_holonomic']
 
 
 @pytest.mark.parametrize('tag', TAGS)

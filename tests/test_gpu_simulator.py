@@ -53,3 +53,9 @@ def test_p2p_quadrotor_example_runs_to_target():
     assert np.linalg.norm(state[:2, -1] - np.array([4., 4.])) < 2e-2
     inside = (np.abs(state[0] + 0.6) < 0.1 + 0.2 - 2e-2) & (state[1] < 0.6 + 0.2 - 2e-2)
     assert not inside.any()
+
+
+def test_free_T_point2point_runs_to_target():
+    """Free end time problem (`point2point.py:269-369`) through Simulator on the HIP path."""
+    from test_examples_cpu import _free_T_run, check_free_T_run
+    check_free_T_run(*_free_T_run())
