@@ -315,4 +315,10 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    finally:
+        if int(os.environ.get('WORLD_SIZE', 1)) > 1:
+            import torch.distributed as _dist
+            if _dist.is_initialized():
+                _dist.destroy_process_group()
