@@ -309,7 +309,7 @@ def main():
                              'rocprofv3 --stats averages)'},
         'step_kernel_ms': [round(v, 3) for v in kernel_ms], 'step_max_iters': it_log[W:].max(dim=1).values.tolist(),
     }
-    if not args.no_cpu and world == 1:
+    if not args.no_cpu and args.cpu_seconds > 0 and world == 1:
         out['cpu_baseline'] = cpu_baseline(problem, P, opts, args.steps, args.warmup, args.cpu_seconds)
     print(json.dumps(out))
 
