@@ -425,7 +425,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   UP(d_off, d.n_leaf + 1); UP(b_off, d.n_leaf > 0 ? d.n_leaf : 1);
   UP(pair4, plan.pair4.size()); UP(eqe3, plan.eqe3.size());
   UP(je_row, plan.je_row.size()); UP(jt_addr, plan.jt_addr.size()); UP(diag_addr, d.N);
-  UP(h_addr, plan.h_addr.size()); UP(t_row, plan.t_row.size()); UP(reg_w, d.N);
+  UP(h_addr, plan.h_addr.size()); UP(t_row, plan.t_row.size()); UP(t_pos, plan.t_pos.size()); UP(reg_w, d.N);
   return OMGX_OK;
 }
 

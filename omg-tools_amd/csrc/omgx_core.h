@@ -66,6 +66,7 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* pair4;     // [n_pairs][4] = {Jacobian entry a, entry b, KKT address, row}: one 16-byte record per pair
   const int32_t* je_row; const int32_t* jt_addr; const int32_t* diag_addr;
   const int32_t* h_addr; const int32_t* t_row;
+  const int32_t* t_pos;     // [n_terms][3] positions of the term's variables (-1: none)
   const double* reg_w;   // [N] position order: inertia-correction class (+1 nonlinear root variable, -1 nonlinear leaf variable, else the weight itself: OMGX_DW_LINEAR)
 };
 
@@ -93,6 +94,7 @@ struct Opts {
 #define OMGX_DW_HEAVY    10.0
 #define OMGX_KAPPA_EPS_HEAVY 100.0
 #define OMGX_DW_BACKOFF_MAX 8
+#define OMGX_DW_CAP_FLOOR 0.03  // share of dw every nonlinear variable keeps under the Gershgorin cap
 #define OMGX_DW_LINEAR   1e-8   // relative inertia correction of variables that only appear linearly
 #define OMGX_S_MAX       100.0
 #define OMGX_KAPPA_SIGMA 1e10
@@ -1081,7 +1083,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   int dw_hold = dw_last > 0.0 ? 1 : 0, dw_backoff = 1;   // inertia-correction tracking (see the factorisation loop)
   // cold starts may damp the leaf (hyperplane) variables less and the root (trajectory) variables more
   // than dw (same product: the same bilinear negative curvature is covered); warm starts use dw on both
-  const double reg_leaf = warm ? 1.0 : o.dw_leaf_ratio_cold, reg_root = warm ? 1.0 : 1.0 / o.dw_leaf_ratio_cold;
+    const double reg_leaf = warm ? 1.0 : o.dw_leaf_ratio_cold, reg_root = warm ? 1.0 : 1.0 / o.dw_leaf_ratio_cold;
   int it = 0, status = 1;
   const double nu_stall_max = warm ? OMGX_NU_MAX : 0.0;     // see the stall test in the loop
   OMGX_TOC(PH_SETUP);
@@ -1212,6 +1214,13 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     else if (dw_hold > 0) { dw = dw_last; --dw_hold; }
     else { dw = dw_last * OMGX_DW_DEC; decreasing = 1; }
     int failed = 0;
+    // Gershgorin row sums g_q of the Lagrangian Hessian (term by term, position order; w.xt is free
+    // until the line search): H + diag(g) is diagonally dominant, so no variable ever needs more
+    // damping than g_q -- the inertia correction of variable q is min(dw * weight, g_q + 0.03 dw).  A
+    // trajectory coefficient whose bilinear rows are all inactive (multipliers ~ mu / s) is then
+    // practically undamped even while dw covers the active hyperplane rows elsewhere.
+    int first_trial = 1;
+    OMGX_PFOR(q, N) w.xt[q] = 0.0;
     for (;;) {
       OMGX_PFOR(i, kkt_doubles) w.kkt[i] = 0.0;
       c.sync();
@@ -1260,11 +1269,26 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         const int32_t* ha = T.h_addr + 3 * tt;
         if (tv[2] < 0) {
           c.add(w.kkt + ha[0], tv[0] == tv[1] ? 2.0 * cf : cf);
+          if (first_trial) {
+            const int32_t* tp = T.t_pos + 3 * tt;
+            if (tv[0] == tv[1]) { if (cf < 0.0) c.add(w.xt + tp[0], -2.0 * cf); }
+            else { c.add(w.xt + tp[0], fabs(cf)); c.add(w.xt + tp[1], fabs(cf)); }
+          }
         } else {
           const double x0v = w.x[tv[0]], x1v = w.x[tv[1]], x2v = w.x[tv[2]];
           c.add(w.kkt + ha[0], (tv[0] == tv[1] ? 2.0 : 1.0) * cf * x2v);   // pair (0,1)
           c.add(w.kkt + ha[1], (tv[0] == tv[2] ? 2.0 : 1.0) * cf * x1v);   // pair (0,2)
           c.add(w.kkt + ha[2], (tv[1] == tv[2] ? 2.0 : 1.0) * cf * x0v);   // pair (1,2)
+          if (first_trial) {
+            const int32_t* tp = T.t_pos + 3 * tt;
+            const double h01 = cf * x2v, h02 = cf * x1v, h12 = cf * x0v;
+            if (tv[0] == tv[1]) { if (h01 < 0.0) c.add(w.xt + tp[0], -2.0 * h01); }
+            else { c.add(w.xt + tp[0], fabs(h01)); c.add(w.xt + tp[1], fabs(h01)); }
+            if (tv[0] == tv[2]) { if (h02 < 0.0) c.add(w.xt + tp[0], -2.0 * h02); }
+            else { c.add(w.xt + tp[0], fabs(h02)); c.add(w.xt + tp[2], fabs(h02)); }
+            if (tv[1] == tv[2]) { if (h12 < 0.0) c.add(w.xt + tp[1], -2.0 * h12); }
+            else { c.add(w.xt + tp[1], fabs(h12)); c.add(w.xt + tp[2], fabs(h12)); }
+          }
         }
       }
       tt_acc = use_t ? c.rsum(tt_acc) : 0.0;
@@ -1274,6 +1298,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         // curvature cannot come from them, and damping them would stall LP-like directions
         const double wq = T.reg_w[q];
         double add = dw * (wq == 1.0 ? reg_root : (wq == -1.0 ? reg_leaf : wq));
+        // never (much) more than diagonal dominance needs; the small share of dw that stays keeps the
+        // step of a practically free variable inside the range of the quadratic model
+        if (wq == 1.0 || wq == -1.0) add = fmin(add, w.xt[q] + OMGX_DW_CAP_FLOOR * dw);
         if (q == N - 1) add += (use_t ? zt / t : 1.0) + tt_acc;
         w.kkt[T.diag_addr[q]] += add;
       }
@@ -1284,6 +1311,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       ++omgx_dbg_nfact;
 #endif
       OMGX_TOC(PH_FACTOR);
+      first_trial = 0;
       if (!bad) { if (decreasing) dw_backoff = 1; break; }
       if (decreasing) {            // back to the last value that worked, try less often
         decreasing = 0; dw = dw_last;
@@ -1394,7 +1422,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         const double s_old = w.s[r];
         const double dzr = mu / s_old - w.z[r] - (w.z[r] / s_old) * w.ds[r];
         const double sn = t * w.vv[r] - w.ht[r];
-        double zn = w.z[r] + a_d * dzr;
+        // warm starts take the dual step component-wise (full Newton step, each multiplier clipped by
+        // its own fraction-to-boundary rule): one multiplier on its way to zero -- a row the moving
+        // horizon releases -- does not scale down the step of all the others
+        double zn = warm ? fmax(w.z[r] + dzr, (1.0 - tau) * w.z[r]) : w.z[r] + a_d * dzr;
         zn = fmin(fmax(zn, mu / (OMGX_KAPPA_SIGMA * sn)), OMGX_KAPPA_SIGMA * mu / sn);
         w.s[r] = sn; w.z[r] = zn;
       } else if (ty == ROW_EQ) {
@@ -1403,7 +1434,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       }
     }
     if (use_t) {
-      zt = zt + a_d * dzt;
+      zt = warm ? fmax(zt + dzt, (1.0 - tau) * zt) : zt + a_d * dzt;
       zt = fmin(fmax(zt, mu / (OMGX_KAPPA_SIGMA * t)), OMGX_KAPPA_SIGMA * mu / t);
     }
     c.sync();

@@ -13,7 +13,7 @@ struct HostPlan {
   Tables tables;            // host pointers (into tpl and the vectors below)
   int kkt_doubles;
   std::vector<int32_t> pos, blk, eq_index, d_off, b_off;
-  std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, h_addr, t_row;
+  std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, h_addr, t_row, t_pos;
   std::vector<double> reg_w;
 
   bool build(const omgx_template& t) {
@@ -106,6 +106,9 @@ struct HostPlan {
     for (int q = 0; q < d.N; ++q) diag_addr[q] = addr(q, q);
     t_row.assign(d.n_terms > 0 ? d.n_terms : 1, 0);
     h_addr.assign(3 * (d.n_terms > 0 ? d.n_terms : 1), 0);
+    t_pos.assign(3 * (d.n_terms > 0 ? d.n_terms : 1), -1);
+    for (int tt = 0; tt < d.n_terms; ++tt)
+      for (int k = 0; k < 3; ++k) if (t.t_var[3 * tt + k] >= 0) t_pos[3 * tt + k] = pos[t.t_var[3 * tt + k]];
     for (int r = 0; r <= m; ++r)
       for (int tt = t.row_ptr[r]; tt < t.row_ptr[r + 1]; ++tt) {
         t_row[tt] = r;
@@ -122,7 +125,7 @@ struct HostPlan {
       }
     T.pair4 = pair4.data(); T.eqe3 = eqe3.data();
     T.je_row = je_row.data(); T.jt_addr = jt_addr.data(); T.diag_addr = diag_addr.data();
-    T.h_addr = h_addr.data(); T.t_row = t_row.data();
+    T.h_addr = h_addr.data(); T.t_row = t_row.data(); T.t_pos = t_pos.data();
     reg_w.assign(d.N, OMGX_DW_LINEAR);
     for (int tt = 0; tt < t.row_ptr[m + 1]; ++tt) {
       const int32_t* tv = t.t_var + 3 * tt;

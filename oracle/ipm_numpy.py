@@ -21,7 +21,7 @@ The iteration (same constants as the kernel):
 """
 import numpy as np
 
-DEFAULTS = dict(tol=1e-8, max_iter=200, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2,
+DEFAULTS = dict(dw_cap_floor=0.03, tol=1e-8, max_iter=200, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2,
                 theta_mu=1.5, tau_min=0.99, s_push=1.0, delta_c=1e-8, eta=1e-4,
                 rho=0.1, dw_first=1e-4, dw_inc=10.0, dw_dec=1. / 3., dw_max=1e10, dw_zero=1e-9, dw_heavy=10.0, kappa_eps_heavy=100.0,
                 s_max=100.0, kappa_sigma=1e10, max_backtrack=25, max_soc=2,
@@ -355,6 +355,9 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         if trace is not None:
             trace.append(dict(it=it, f=f, mu=mu, err=err0, inf_pr=viol, inf_du=np.abs(r_d).max(),
                               dw=dw_last, nu=nu, t=t, zt=zt, imax=int(np.argmax(np.abs(r_d)))))
+            if o.get('trace_full'):
+                trace[-1].update(r_d=r_d.copy(), y=y.copy(), z=z.copy(), s=s.copy(), x=x.copy(), iH=iH, iE=iE,
+                                 Jh=Jh.copy(), Je=Je.copy())
         if err0 <= o['tol']:
             status = 0
             break
@@ -392,6 +395,8 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         lam[iE] = y
         H = np.zeros((N, N))
         H[:n, :n] = nlp.hess(x, lam * rho, c)
+        # no variable is damped more than diagonal dominance of the Lagrangian Hessian needs
+        gersh = np.r_[nlp.hess_gershgorin(x, lam * rho, c), 0.0]
         Sig = z / s
         M = H + Jh.T @ (Sig[:, None] * Jh)
         if use_t:
@@ -414,7 +419,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         tries = 0
         while True:
             K = np.zeros((N + mE, N + mE))
-            K[:N, :N] = M + dw * np.diag(reg)
+            K[:N, :N] = M + np.diag(np.where(nl, np.minimum(dw * reg, gersh + o['dw_cap_floor'] * dw), dw * reg))
             K[N:, :N] = Je
             K[:N, N:] = Je.T
             K[N:, N:] = -o['delta_c'] * np.eye(mE)
@@ -486,8 +491,15 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             status = 4
             break
         x, t, s, f, h, cE = xt, tt, st, ft, ht, cEt
-        z = z + a_d * dz
-        zt = zt + a_d * dzt
+        if z0 is not None:
+            # component-wise dual step: every multiplier takes its full Newton step, clipped at the
+            # fraction-to-boundary rule on its own (one multiplier on its way to zero does not hold
+            # back the others)
+            z = np.maximum(z + dz, (1.0 - tau) * z)
+            zt = max(zt + dzt, (1.0 - tau) * zt)
+        else:
+            z = z + a_d * dz
+            zt = zt + a_d * dzt
         y = y + alpha * (y_new - y)
         z = np.minimum(np.maximum(z, mu / (o['kappa_sigma'] * s)), o['kappa_sigma'] * mu / s)
         if use_t:

@@ -13,15 +13,26 @@ def test_port_matches_numpy_iteration_for_iteration(cfg2_small):
     problem, P = cfg2_small
     tpl = problem.father.template
     nlp = NumpyNLP(tpl)
+    # same iterates: after 30 iterations (all four agents still iterating) the two statements agree
+    # to rounding ...
+    ref = port_binding.solve(tpl, P['p'][:4], P['x0'][:4], tol=1e-6, max_iter=30)
+    for b in range(4):
+        r = ipm_numpy.solve(nlp, P['x0'][b], P['p'][b], tpl.lb, tpl.ub,
+                            opts={'tol': 1e-6, 'max_iter': 30})
+        assert r['iters'] == ref['iters'][b] == 30
+        assert np.abs(r['x'] - ref['x'][b]).max() < 1e-9
+        assert np.abs(r['lam_g'] - ref['lam_g'][b]).max() < 1e-9 * (1 + np.abs(r['lam_g']).max())
+    # ... and they stop at the same point (rounding differences grow in the last iterations, where the
+    # barrier parameter is ~1e-7: the count may differ by a few)
     ref = port_binding.solve(tpl, P['p'][:4], P['x0'][:4], tol=1e-6, max_iter=150)
     for b in range(4):
         r = ipm_numpy.solve(nlp, P['x0'][b], P['p'][b], tpl.lb, tpl.ub,
                             opts={'tol': 1e-6, 'max_iter': 150})
         assert r['status'] == ref['status'][b]
         if r['status'] == 0:
-            assert abs(r['iters'] - ref['iters'][b]) <= 1
-            assert np.abs(r['x'] - ref['x'][b]).max() < 1e-8
-            assert np.abs(r['lam_g'] - ref['lam_g'][b]).max() < 1e-6 * (1 + np.abs(r['lam_g']).max())
+            assert abs(r['iters'] - ref['iters'][b]) <= 3
+            assert np.abs(r['x'] - ref['x'][b]).max() < 1e-6
+            assert np.abs(r['lam_g'] - ref['lam_g'][b]).max() < 1e-5 * (1 + np.abs(r['lam_g']).max())
 
 
 def test_kkt_conditions_and_independent_solver(cfg2_small):
