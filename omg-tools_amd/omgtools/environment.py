@@ -275,8 +275,35 @@ class Environment(OptiChild, PlotLayer):
             vehicle.define_collision_constraints(hyp_veh, room, splines[idx], horizon_times[idx])
 
     def define_intervehicle_collision_constraints(self, vehicles, horizon_times):
-        raise NotImplementedError('inter-vehicle avoidance is outside the hot-path scope '
-                                  '(SURVEY.md §8f rank 2)')
+        """One separating hyperplane per pair of vehicle shapes, seen with opposite signs by the two
+        vehicles (`environment/environment.py:148-176`)."""
+        horizon_times = horizon_times if isinstance(horizon_times, list) else [horizon_times]
+        for idx in range(vehicles[0].n_seg):
+            hyp_veh = {veh: {sh: [] for sh in veh.shapes} for veh in vehicles}
+            for k in range(len(vehicles)):
+                for l in range(k + 1, len(vehicles)):
+                    veh1, veh2 = vehicles[k], vehicles[l]
+                    if veh1 is veh2:
+                        continue
+                    if veh1.n_dim != veh2.n_dim:
+                        raise ValueError('Not possible to combine %dD and %dD vehicle.' % (veh1.n_dim, veh2.n_dim))
+                    knots = np.r_[0., np.union1d(veh1.knots[veh1.degree:-veh1.degree],
+                                                 veh2.knots[veh2.degree:-veh2.degree]), 1.]
+                    basis = BSplineBasis(knots, 1)
+                    for kk, shape1 in enumerate(veh1.shapes):
+                        for ll, shape2 in enumerate(veh2.shapes):
+                            tag = '_%s_seg%d_%d_%s_%d' % (veh1.label, idx, kk, veh2.label, ll)
+                            a = self.define_spline_variable('a' + tag, self.n_dim, basis=basis)
+                            b = self.define_spline_variable('b' + tag, 1, basis=basis)[0]
+                            norm2 = a[0] * a[0]
+                            for p in range(1, self.n_dim):
+                                norm2 = norm2 + a[p] * a[p]
+                            self.define_constraint(norm2 - 1, -inf, 0.)
+                            hyp_veh[veh1][shape1].append({'a': a, 'b': b})
+                            hyp_veh[veh2][shape2].append({'a': [-a_i for a_i in a], 'b': -b})
+            for vehicle in vehicles:
+                vehicle.define_collision_constraints(hyp_veh[vehicle], self.room[idx], vehicle.splines[idx],
+                                                     horizon_times[idx])
 
     def init(self, horizon_times=None):
         for obstacle in self.obstacles:

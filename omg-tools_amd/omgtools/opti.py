@@ -132,9 +132,16 @@ class OptiChild(object):
     def _define(self, name, size0, size1, store, value, kind):
         table = self._table()
         n = size0 * size1
-        ids = table.new_vars(n) if kind == 'var' else table.new_raw_atoms(n)
-        ids = np.array(ids, dtype=np.int64).reshape((size0, size1), order='F')
-        store[name] = ids
+        if name in store and store[name].shape == (size0, size1):
+            # A name defined twice by one object is ONE entry of the reference's flat vectors: its
+            # expressions are translated by symbol name (`optilayer.py:198-224, 595-602`), so both
+            # definitions address the same variable -- e.g. the terminal slacks g0, g1 of a
+            # multi-vehicle FixedTPoint2point (`point2point.py:160-163`) are shared by the vehicles.
+            ids = store[name]
+        else:
+            ids = table.new_vars(n) if kind == 'var' else table.new_raw_atoms(n)
+            ids = np.array(ids, dtype=np.int64).reshape((size0, size1), order='F')
+            store[name] = ids
         if value is None:
             self._values[name] = np.zeros((size0, size1))
         else:

@@ -187,6 +187,19 @@ def main():
     problem.init()
     dump(problem, 'freeT_holonomic', rng)
 
+    # two vehicles in one problem with inter-vehicle avoidance (`examples/p2p_holonomic_interveh_avoidance.py`,
+    # `environment.py:148-176`) and one obstacle; note that the vehicles share the terminal slacks g0, g1
+    vehicles = [Holonomic() for k in range(2)]
+    for k, vehicle in enumerate(vehicles):
+        vehicle.set_initial_conditions([1.5 * np.cos(k * np.pi), 1.5 * np.sin(k * np.pi) + 0.1 * k])
+        vehicle.set_terminal_conditions([-1.5 * np.cos(k * np.pi), -1.5 * np.sin(k * np.pi)])
+    environment = Environment(room={'shape': sh.Square(5.)})
+    environment.add_obstacle(Obstacle({'position': [0.1, 0.9]}, shape=sh.Circle(0.3)))
+    problem = Point2point(vehicles, environment, options=quiet, freeT=False)
+    problem.set_options({'inter_vehicle_avoidance': True})
+    problem.init()
+    dump(problem, 'interveh_holonomic', rng)
+
     # spline known-answer matrices straight from the reference's spline algebra
     rs, rx = m['basics.spline'], m['basics.spline_extra']
     kats = {}

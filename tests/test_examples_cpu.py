@@ -93,3 +93,37 @@ def test_free_T_point2point_reaches_target():
     """`FreeTPoint2point` (`point2point.py:269-369`): T is a variable and the objective; the NLP
     itself is pinned against the reference in tests/test_golden_nlp.py (freeT_holonomic)."""
     check_free_T_run(*_free_T_run())
+
+
+def _interveh_run(N=2):
+    """`examples/p2p_holonomic_interveh_avoidance.py:22-48`: vehicles swap places through the centre."""
+    from omgtools import Holonomic, Environment, Square, Point2point, Simulator
+    vehicles = [Holonomic() for k in range(N)]
+    for k, vehicle in enumerate(vehicles):
+        vehicle.set_initial_conditions([1.5 * np.cos((k * 2. * np.pi) / N), 1.5 * np.sin((k * 2. * np.pi) / N)])
+        vehicle.set_terminal_conditions([-1.5 * np.cos((k * 2. * np.pi) / N), -1.5 * np.sin((k * 2. * np.pi) / N)])
+    environment = Environment(room={'shape': Square(5.)})
+    problem = Point2point(vehicles, environment, freeT=False)
+    problem.set_options({'inter_vehicle_avoidance': True, 'verbose': 0})
+    problem.init()
+    Simulator(problem).run()
+    return vehicles
+
+
+def check_interveh_run(vehicles):
+    N = len(vehicles)
+    n = min(v.signals['state'].shape[1] for v in vehicles)
+    for k, v in enumerate(vehicles):
+        goal = np.array([-1.5 * np.cos((k * 2. * np.pi) / N), -1.5 * np.sin((k * 2. * np.pi) / N)])
+        assert np.linalg.norm(v.signals['state'][:2, -1] - goal) < 1e-2
+        assert np.abs(v.signals['input']).max() <= 0.5 + 1e-3
+    for k in range(N):
+        for l in range(k + 1, N):
+            d = np.linalg.norm(vehicles[k].signals['state'][:2, :n] - vehicles[l].signals['state'][:2, :n], axis=0)
+            assert d.min() >= 0.1 + 0.1 - 2e-2        # two Circle(0.1) vehicles never overlap
+
+
+def test_intervehicle_avoidance_example():
+    """Two vehicles in ONE problem with separating hyperplanes between them (`environment.py:148-176`);
+    the NLP is pinned against the reference in tests/test_golden_nlp.py (interveh_holonomic)."""
+    check_interveh_run(_interveh_run())

@@ -88,12 +88,21 @@ def build(tag):
         environment.add_obstacle(Obstacle({'position': [0.2, -0.4]}, shape=Circle(0.4)))
         environment.add_obstacle(Obstacle({'position': [1.0, 1.2], 'velocity': [-0.1, 0.05]}, shape=Circle(0.3)))
         problem = Point2point(vehicle, environment, options=quiet, freeT=True)
+    elif tag == 'interveh_holonomic':
+        vehicles = [Holonomic() for k in range(2)]
+        for k, vehicle in enumerate(vehicles):
+            vehicle.set_initial_conditions([1.5 * np.cos(k * np.pi), 1.5 * np.sin(k * np.pi) + 0.1 * k])
+            vehicle.set_terminal_conditions([-1.5 * np.cos(k * np.pi), -1.5 * np.sin(k * np.pi)])
+        environment = Environment(room={'shape': Square(5.)})
+        environment.add_obstacle(Obstacle({'position': [0.1, 0.9]}, shape=Circle(0.3)))
+        problem = Point2point(vehicles, environment, options=quiet, freeT=False)
+        problem.set_options({'inter_vehicle_avoidance': True})
     problem.init()
     return problem
 
 
 TAGS = ['cfg1_p2p_holonomic', 'cfg2_holonomic_k11_o3', 'holonomic_rectangles',
-        'holonomic3d_spheres', 'quadrotor_k13_o2', 'freeT_holonomic']
+        'holonomic3d_spheres', 'quadrotor_k13_o2', 'freeT_holonomic', 'interveh_holonomic']
 
 
 @pytest.mark.parametrize('tag', TAGS)

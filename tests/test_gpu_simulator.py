@@ -59,3 +59,9 @@ def test_free_T_point2point_runs_to_target():
     """Free end time problem (`point2point.py:269-369`) through Simulator on the HIP path."""
     from test_examples_cpu import _free_T_run, check_free_T_run
     check_free_T_run(*_free_T_run())
+
+
+def test_intervehicle_avoidance_example_runs_to_target():
+    """`examples/p2p_holonomic_interveh_avoidance.py` on the HIP path."""
+    from test_examples_cpu import _interveh_run, check_interveh_run
+    check_interveh_run(_interveh_run())
