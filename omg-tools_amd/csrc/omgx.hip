@@ -415,7 +415,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   const omgx::Dims& d = plan.dims;
   const int n_cpl = t->cpl_ptr[d.n_leaf];
   UP(prog, 6 * d.n_prog); UP(knots, t->n_knots); UP(pp_ptr, t->n_pp + 1); UP(pm_coef, t->n_mono);
-  UP(pm_ptr, t->n_mono + 1); UP(pm_atom, t->n_matom); UP(slot_pp, d.n_slots);
+  UP(pm_ptr, t->n_mono + 1); UP(pm_atom, t->n_matom); UP(slot_pp, d.n_slots); UP(pm_rec, plan.pm_rec.size());
   UP(row_ptr, d.n_con + 2); UP(t_coef, d.n_terms); UP(t_slot, d.n_terms); UP(t_var, 3 * d.n_terms);
   UP(order, d.N); UP(pos, d.N); UP(leaf_off, d.n_leaf + 1); UP(blk, d.N);
   UP(eq_rows, d.n_eq); UP(eq_index, d.n_con);

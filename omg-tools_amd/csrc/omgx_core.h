@@ -48,12 +48,18 @@ struct Dims {
   int n_eqe;    // Jacobian entries of the equality rows
   int max_leaf, max_cpl;
   int col_doubles;   // scratch for the blocked LDL' (staging + panel buffers)
+  int mono_packed;   // 1: every parameter monomial has <= 4 atoms, Tables::pm_rec is valid
 };
+
+// one parameter monomial coef * prod atoms[a_k] as a single 16-byte record (a_k = -1: unused): one
+// load per monomial instead of the pointer chase pm_ptr -> pm_atom -> atoms of the CSR form
+struct MonoRec { double coef; int16_t a0, a1, a2, a3; };
 
 struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* prog; const double* knots;
   const int32_t* pp_ptr; const double* pm_coef; const int32_t* pm_ptr; const int32_t* pm_atom;
   const int32_t* slot_pp;
+  const MonoRec* pm_rec;    // [n_mono] packed form of (pm_coef, pm_ptr, pm_atom); valid if Dims::mono_packed
   const int32_t* row_ptr; const double* t_coef; const int32_t* t_slot; const int32_t* t_var;
   const int32_t* order; const int32_t* pos; const int32_t* leaf_off; const int32_t* blk;
   const int32_t* eq_rows; const int32_t* eq_index;
@@ -270,7 +276,10 @@ typedef CtxT<false> Ctx;
 #define OMGX_PFOR_U4(i, n) _Pragma("unroll 4") for (int i = c.tid(); i < (n); i += c.nthr())
 
 // optional per-phase cycle counters (profiling build only, -DOMGX_PROFILE)
-enum { PH_JAC = 0, PH_RESID, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_STEP, PH_LINESEARCH, PH_UPDATE, PH_F_LEAF, PH_F_SCHUR, PH_F_ROOT, PH_LA, PH_LS, PH_LB, PH_SETUP, PH_TOTAL, PH_COUNT };
+enum { PH_JAC = 0, PH_RESID, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_STEP, PH_LINESEARCH, PH_UPDATE, PH_F_LEAF, PH_F_SCHUR, PH_F_ROOT, PH_LA, PH_LS, PH_LB, PH_SETUP, PH_TOTAL,
+       PH_S_DESC, PH_S_PARAMS, PH_S_JAC0, PH_S_CLASS, PH_S_INIT, PH_A_ZERO, PH_A_PAIRS, PH_A_REST, PH_A_DIAG,
+       PH_K_FWD, PH_K_ROOTRHS, PH_K_ROOT, PH_K_LEAFRHS, PH_K_BWD, PH_L_TERMS, PH_L_ROWS,
+       PH_F_PARK, PH_F_SWEEP, PH_F_SCALE, PH_A_TCOL, PH_A_HESS, PH_COUNT };
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
 #define OMGX_TIC() long long tic_ = (c.sync(), clock64())
 #define OMGX_TOC(k) do { c.sync(); long long now_ = clock64(); if (c.tid() == 0) c.prof[k] += now_ - tic_; tic_ = now_; } while (0)
@@ -289,6 +298,21 @@ OMGX_FN double pp_eval(const Tables& T, int pp, const double* a) {
   for (int m = T.pp_ptr[pp]; m < T.pp_ptr[pp + 1]; ++m) {
     double v = T.pm_coef[m];
     for (int q = T.pm_ptr[m]; q < T.pm_ptr[m + 1]; ++q) v *= a[T.pm_atom[q]];
+    tot += v;
+  }
+  return tot;
+}
+
+// the same sum, same order of operations, from the packed records: the record loads do not depend on
+// each other (the CSR form chains three global loads per monomial)
+OMGX_FN double pp_eval_packed(const Tables& T, int pp, const double* a) {
+  double tot = 0.0;
+  const int m0 = T.pp_ptr[pp], m1 = T.pp_ptr[pp + 1];
+#pragma unroll 4
+  for (int m = m0; m < m1; ++m) {
+    const MonoRec r = T.pm_rec[m];
+    double v = r.coef;
+    if (r.a0 >= 0) { v *= a[r.a0]; if (r.a1 >= 0) { v *= a[r.a1]; if (r.a2 >= 0) { v *= a[r.a2]; if (r.a3 >= 0) v *= a[r.a3]; } } }
     tot += v;
   }
   return tot;
@@ -331,18 +355,30 @@ template <class C>
 OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, const double* p) {
   OMGX_PFOR(i, d.n_par) w.atoms[i] = p[i];
   c.sync();
-  for (int k = 0; k < d.n_prog; ++k) {          // ops in order (an op may read atoms of earlier ones)
+  for (int k = 0; k < d.n_prog;) {              // ops in order (an op may read atoms of earlier ones)
     const int32_t* op = T.prog + 6 * k;
     if (op[0] == OP_DIV) {
-      if (c.tid() == 0) w.atoms[op[3]] = pp_eval(T, op[1], w.atoms) / pp_eval(T, op[2], w.atoms);
+      if (c.tid() == 0)
+        w.atoms[op[3]] = d.mono_packed ? pp_eval_packed(T, op[1], w.atoms) / pp_eval_packed(T, op[2], w.atoms)
+                                       : pp_eval(T, op[1], w.atoms) / pp_eval(T, op[2], w.atoms);
+      ++k;
     } else {
-      const int nout = op[2] - op[3] - 1;
-      const double u = w.atoms[op[4]];
-      OMGX_PFOR(i, nout) w.atoms[op[5] + i] = bspl_entry(T.knots + op[1], op[3], u, i);
+      // a run of consecutive basis-row ops is one parallel pass: their arguments are raw parameters
+      // or quotients (never the output of another basis row), so they do not depend on each other
+      int k2 = k, total = 0;
+      while (k2 < d.n_prog && T.prog[6 * k2] == OP_BSPL) { total += T.prog[6 * k2 + 2] - T.prog[6 * k2 + 3] - 1; ++k2; }
+      OMGX_PFOR(it, total) {
+        int kk = k, i = it;
+        for (;; ++kk) { const int nout = T.prog[6 * kk + 2] - T.prog[6 * kk + 3] - 1; if (i < nout) break; i -= nout; }
+        const int32_t* oq = T.prog + 6 * kk;
+        w.atoms[oq[5] + i] = bspl_entry(T.knots + oq[1], oq[3], w.atoms[oq[4]], i);
+      }
+      k = k2;
     }
     c.sync();
   }
-  OMGX_PFOR(s, d.n_slots) w.slots[s] = pp_eval(T, T.slot_pp[s], w.atoms);
+  if (d.mono_packed) { OMGX_PFOR(s, d.n_slots) w.slots[s] = pp_eval_packed(T, T.slot_pp[s], w.atoms); }
+  else { OMGX_PFOR(s, d.n_slots) w.slots[s] = pp_eval(T, T.slot_pp[s], w.atoms); }
   c.sync();
 }
 
@@ -439,7 +475,10 @@ static_assert(sizeof(BMat) <= 4 * sizeof(double), "BMat larger than its LDS slot
 #define OMGX_PAN_LD 5      // panel buffer row stride: U[4] + pad (odd: conflict-free row-per-lane access)
 #define OMGX_STAGE_LD 20   // per matrix: 4x4 block rows [16] + inverse pivots of the block [4]
 
-OMGX_FN int baddr(const BMat& M, int r, int k) { return M.a + (M.ld ? r * M.ld + k : tri(r, k)); }
+// (branch-free on purpose: with `ld ? row-major : packed` as a conditional the compiler sinks the
+// LDS load that uses the address into the two branches, and a sequence of such loads -- the ten
+// entries of a diagonal block -- becomes ten serialised round trips)
+OMGX_FN int baddr(const BMat& M, int r, int k) { return M.a + r * M.ld + (M.ld == 0 ? 1 : 0) * ((r * (r + 1)) >> 1) + k; }
 
 // reciprocal of a pivot: v_rcp_f64 (about 2^-29 relative) + two Newton steps instead of the
 // ~15-instruction IEEE division sequence; exact division on the host port
@@ -505,6 +544,7 @@ OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* di
     if (Ms[i].nfact > nmax) nmax = Ms[i].nfact;
     total_rows += Ms[i].rows; total_blocks += (Ms[i].nfact + 3) >> 2;
   }
+  OMGX_TIC();
   // park the original diagonal blocks: 10 doubles per block behind the inverse pivots of the matrix
   OMGX_PFOR(it, total_blocks * 10) {
     int mi = 0, blk = it / 10; const int e = it - 10 * blk;
@@ -515,6 +555,7 @@ OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* di
     colb[M.pan + M.nfact + 10 * blk + e] = (ra < M.nfact) ? A[baddr(M, ra, ck)] : (a == k ? 1.0 : 0.0);
   }
   c.sync();
+  OMGX_TOC(PH_F_PARK);
   int badl = 0;
   for (int jb = 0; jb < nmax; jb += OMGX_NB) {
     OMGX_PFOR(it, total_rows) {
@@ -571,6 +612,7 @@ OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* di
     }
     c.sync();
   }
+  OMGX_TOC(PH_F_SWEEP);
   // factorised rows: U -> L
   OMGX_PFOR(it, total_rows) {
     int mi = 0, r = it;
@@ -582,6 +624,7 @@ OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* di
     for (int k = 0; k < r; ++k) A[br + k] *= iv[k];
   }
   *bad = c.rmax(badl ? 1.0 : 0.0) > 0.0 ? 1 : 0;
+  OMGX_TOC(PH_F_SCALE);
 }
 
 // Factorise `nm` matrices together (same block index for all of them).
@@ -893,6 +936,7 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
   // leaf dimensions from the matrix descriptors kkt_factor left in LDS (not from the global plan
   // tables: every look-up there is a dependent global load)
   const BMat* Ms = (const BMat*)w.col;
+  OMGX_TIC();
   // leaves (wave-parallel): y_l <- Delta^{-1} L^{-1} r_l
   for (int l = c.wave(); l < d.n_leaf; l += c.nwaves()) {
     const BMat M = Ms[l];
@@ -904,6 +948,7 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
     c.wave_sync();
   }
   c.sync();
+  OMGX_TOC(PH_K_FWD);
   // root rhs:  r_r -= sum_l Wt_l y_l, spread over the whole workgroup: one item = (leaf, coupling
   // row, chunk of 8 leaf columns), partial sums added with LDS atomics
   {
@@ -924,6 +969,7 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
     }
   }
   c.sync();
+  OMGX_TOC(PH_K_ROOTRHS);
   // root solve by wave 0 (packed L)
   if (c.wave() == 0) {
     const int n = d.nr, rbase = Ms[d.n_leaf].a;
@@ -934,6 +980,7 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
     trsv_bwd4(c, w.kkt, Lr, n, yr);
   }
   c.sync();
+  OMGX_TOC(PH_K_ROOT);
   // leaves: y_l <- L^{-T} (y_l - Delta^{-1} Wt' x_r); the correction term again item-parallel over
   // (leaf, leaf column, chunk of 8 coupling rows)
   {
@@ -957,6 +1004,7 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
     }
   }
   c.sync();
+  OMGX_TOC(PH_K_LEAFRHS);
   for (int l = c.wave(); l < d.n_leaf; l += c.nwaves()) {
     const BMat M = Ms[l];
     const int n = M.nfact, ld = M.ld, base = M.a;
@@ -964,6 +1012,7 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
     trsv_bwd4(c, w.kkt, [=](int i, int j) { return base + i * ld + j; }, n, yl);
   }
   c.sync();
+  OMGX_TOC(PH_K_BWD);
 }
 
 // ---------------------------------------------------------------------------
@@ -980,8 +1029,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   Kkt K; K.d = &d; K.T = &T; K.a = w.kkt;
   OMGX_TIC();
   kkt_describe(c, d, K, w);
+  OMGX_TOC(PH_S_DESC);
 
   eval_params(c, d, T, w, p);
+  OMGX_TOC(PH_S_PARAMS);
   OMGX_PFOR(i, n) w.x[i] = x0[i];
   if (c.tid() == 0) w.x[n] = 1.0;
   c.sync();
@@ -1011,6 +1062,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     c.add(w.jval + je[0], cf * x1v * x2v); c.add(w.jval + je[1], cf * x0v * x2v); c.add(w.jval + je[2], cf * x0v * x1v);
   }
   c.sync();
+  OMGX_TOC(PH_S_JAC0);
   // ... then one thread per row: classification, gradient-based scale, phase-I weight
   double bad_local = 0.0;
   OMGX_PFOR(r, m) {
@@ -1039,6 +1091,22 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     w.vv[r] = v;
   }
   if (c.rmax(bad_local) > 0.0) { res.status = 3; return res; }
+  // the Jacobian the first iteration needs is this one with the rows scaled, plus the objective row
+  // (its entries are still zero): no second pass over the constraint terms at x0
+  OMGX_PFOR(e, T.jr_ptr[m]) { const int r = T.je_row[e]; w.jval[e] *= (w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r]; }
+  OMGX_PFOR(q, T.row_ptr[m + 1] - T.row_ptr[m]) {
+    const int tt = T.row_ptr[m] + q;
+    const int32_t* tv = T.t_var + 3 * tt;
+    if (tv[0] < 0) continue;
+    const double cf = term_coef(T, w, tt);
+    const int32_t* je = T.t_jidx + 3 * tt;
+    if (tv[1] < 0) { c.add(w.jval + je[0], cf); continue; }
+    const double x0v = w.x[tv[0]], x1v = w.x[tv[1]];
+    if (tv[2] < 0) { c.add(w.jval + je[0], cf * x1v); c.add(w.jval + je[1], cf * x0v); continue; }
+    const double x2v = w.x[tv[2]];
+    c.add(w.jval + je[0], cf * x1v * x2v); c.add(w.jval + je[1], cf * x0v * x2v); c.add(w.jval + je[2], cf * x0v * x1v);
+  }
+  OMGX_TOC(PH_S_CLASS);
   double any_local = 0.0;
   OMGX_PFOR(r, m) if (w.vv[r] != 0.0) any_local = 1.0;
   const bool use_t = c.rmax(any_local) > 0.0;
@@ -1064,7 +1132,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         w.z[r] = lam0[r] / w.rho[r];
       }
     }
-    sz = c.rsum(sz); cnt0 = c.rsum(cnt0);
+    { double rv[2] = {sz, cnt0}; c.template reduce_ops<0, 0>(rv); sz = rv[0]; cnt0 = rv[1]; }
     mu = fmin(o.mu_init, fmax(o.tol / 10.0, sz / fmax(1.0, cnt0)));
     // multiplier of t >= 0: dual feasible in t (nu - v'z - zt = 0) rather than on the central path,
     // so that the first Newton step in t is O(t) instead of O(nu t^2 / mu)
@@ -1086,11 +1154,15 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     const double reg_leaf = warm ? 1.0 : o.dw_leaf_ratio_cold, reg_root = warm ? 1.0 : 1.0 / o.dw_leaf_ratio_cold;
   int it = 0, status = 1;
   const double nu_stall_max = warm ? OMGX_NU_MAX : 0.0;     // see the stall test in the loop
-  OMGX_TOC(PH_SETUP);
+  OMGX_TOC(PH_S_INIT);
+#if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
+  if (c.tid() == 0) c.prof[PH_SETUP] += c.prof[PH_S_DESC] + c.prof[PH_S_PARAMS] + c.prof[PH_S_JAC0] + c.prof[PH_S_CLASS] + c.prof[PH_S_INIT];
+#endif
 
   for (it = 0; it <= o.max_iter; ++it) {
     OMGX_TIC();
     // ---- Jacobian (scaled): one thread per term, entries accumulated with LDS atomics -------
+    if (it > 0) {        // (iteration 0: left by the setup)
     OMGX_PFOR(e, T.jr_ptr[m + 1]) w.jval[e] = 0.0;
     c.sync();
     OMGX_PFOR(tt, T.row_ptr[m + 1]) {
@@ -1108,6 +1180,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       c.add(w.jval + je[0], cf * x1 * x2); c.add(w.jval + je[1], cf * x0 * x2); c.add(w.jval + je[2], cf * x0 * x1);
     }
     c.sync();
+    }
     OMGX_TOC(PH_JAC);
     // ---- dual residual, barrier gradient (position order), error measures -------
     // one thread per Jacobian entry; sol <- J'z (+ grad f), gbar <- grad f, xt <- J'(1/s): the
@@ -1224,6 +1297,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     for (;;) {
       OMGX_PFOR(i, kkt_doubles) w.kkt[i] = 0.0;
       c.sync();
+      OMGX_TOC(PH_A_ZERO);
       // J' Sigma J over precomputed (entry, entry, address) triples; Sigma staged in w.ds
       OMGX_PFOR(r, m) {
         const int ty = w.rtype[r];
@@ -1237,6 +1311,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         const int a = q[0], b = q[1], ad = q[2], r = q[3];
         c.add(w.kkt + ad, w.ds[r] * w.jval[a] * w.jval[b]);
       }
+      OMGX_TOC(PH_A_PAIRS);
       double tt_acc = 0.0;
       if (use_t) {
         OMGX_PFOR(e, T.jr_ptr[m]) {
@@ -1246,6 +1321,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         }
         OMGX_PFOR(r, m) tt_acc += w.ds[r] * w.vv[r] * w.vv[r];
       }
+      OMGX_TOC(PH_A_TCOL);
       // equality rows straight into the root block
       OMGX_PFOR(i, d.n_eqe) {                                   // one thread per equality-row entry
         const int32_t* q = T.eqe3 + 3 * i;                     // {Jacobian entry, KKT address, row}
@@ -1291,8 +1367,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
           }
         }
       }
+      OMGX_TOC(PH_A_HESS);
       tt_acc = use_t ? c.rsum(tt_acc) : 0.0;
       c.sync();
+      OMGX_TOC(PH_A_REST);
       OMGX_PFOR(q, N) {
         // variables without a nonlinear term have zero rows in the Lagrangian Hessian: negative
         // curvature cannot come from them, and damping them would stall LP-like directions
@@ -1305,7 +1383,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         w.kkt[T.diag_addr[q]] += add;
       }
       c.sync();
-      OMGX_TOC(PH_ASSEMBLE);
+      OMGX_TOC(PH_A_DIAG);
+#if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
+      if (c.tid() == 0) c.prof[PH_ASSEMBLE] = c.prof[PH_A_ZERO] + c.prof[PH_A_PAIRS] + c.prof[PH_A_TCOL] + c.prof[PH_A_HESS] + c.prof[PH_A_REST] + c.prof[PH_A_DIAG];
+#endif
       const int bad = kkt_factor(c, d, K, w);
 #ifdef OMGX_COUNT_FACT
       ++omgx_dbg_nfact;
@@ -1388,6 +1469,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         c.add(w.ht + T.t_row[q], v);
       }
       c.sync();
+      OMGX_TOC(PH_L_TERMS);
       double smin = 1e300, lnst = 0.0, rEt = 0.0;
       OMGX_PFOR(r, m) {
         const int ty = w.rtype[r];
@@ -1409,7 +1491,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       alpha *= 0.5;
       c.sync();
     }
-    OMGX_TOC(PH_LINESEARCH);
+    OMGX_TOC(PH_L_ROWS);
+#if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
+    if (c.tid() == 0) c.prof[PH_LINESEARCH] = c.prof[PH_L_TERMS] + c.prof[PH_L_ROWS];
+#endif
     if (!ok) { status = 4; break; }
     // ---- accept --------------------------------------------------------------------
     c.sync();

@@ -15,6 +15,7 @@ struct HostPlan {
   std::vector<int32_t> pos, blk, eq_index, d_off, b_off;
   std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, h_addr, t_row, t_pos;
   std::vector<double> reg_w;
+  std::vector<MonoRec> pm_rec;
 
   bool build(const omgx_template& t) {
     Dims& d = dims;
@@ -48,6 +49,19 @@ struct HostPlan {
       if (d.n_leaf > OMGX_MAX_LEAF) return false;
     }
     kkt_doubles = off;
+    // packed parameter monomials
+    d.mono_packed = (d.n_atoms < 32768) ? 1 : 0;
+    pm_rec.assign(t.n_mono > 0 ? t.n_mono : 1, MonoRec{0.0, -1, -1, -1, -1});
+    for (int mm = 0; mm < t.n_mono; ++mm) {
+      const int q0 = t.pm_ptr[mm], nq = t.pm_ptr[mm + 1] - q0;
+      if (nq > 4) { d.mono_packed = 0; break; }
+      MonoRec& r = pm_rec[mm];
+      r.coef = t.pm_coef[mm];
+      if (nq > 0) r.a0 = (int16_t)t.pm_atom[q0];
+      if (nq > 1) r.a1 = (int16_t)t.pm_atom[q0 + 1];
+      if (nq > 2) r.a2 = (int16_t)t.pm_atom[q0 + 2];
+      if (nq > 3) r.a3 = (int16_t)t.pm_atom[q0 + 3];
+    }
     eq_index.assign(d.n_con, -1);
     for (int k = 0; k < d.n_eq; ++k) eq_index[t.eq_rows[k]] = k;
     Tables& T = tables;
@@ -125,7 +139,7 @@ struct HostPlan {
       }
     T.pair4 = pair4.data(); T.eqe3 = eqe3.data();
     T.je_row = je_row.data(); T.jt_addr = jt_addr.data(); T.diag_addr = diag_addr.data();
-    T.h_addr = h_addr.data(); T.t_row = t_row.data(); T.t_pos = t_pos.data();
+    T.h_addr = h_addr.data(); T.t_row = t_row.data(); T.t_pos = t_pos.data(); T.pm_rec = pm_rec.data();
     reg_w.assign(d.N, OMGX_DW_LINEAR);
     for (int tt = 0; tt < t.row_ptr[m + 1]; ++tt) {
       const int32_t* tv = t.t_var + 3 * tt;

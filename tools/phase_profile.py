@@ -12,12 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
 import omgtools.backend as be
 
-PHASES = ['jac', 'resid', 'assemble', 'factor', 'solve', 'step', 'linesearch', 'update', 'f_leaf', 'f_schur', 'f_root', 'l_A', 'l_stage', 'l_B', 'setup', 'total']
+PHASES = ['jac', 'resid', 'assemble', 'factor', 'solve', 'step', 'linesearch', 'update', 'f_leaf', 'f_schur', 'f_root', 'l_A', 'l_stage', 'l_B', 'setup', 'total',
+          's_desc', 's_params', 's_jac0', 's_class', 's_init', 'a_zero', 'a_pairs', 'a_rest', 'a_diag',
+          'k_fwd', 'k_rootrhs', 'k_root', 'k_leafrhs', 'k_bwd', 'l_terms', 'l_rows',
+          'f_park', 'f_sweep', 'f_scale', 'a_tcol', 'a_hess']
 
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    be.LIB_PATH = os.path.join(ROOT, 'omg-tools_amd', 'csrc', 'libomgx_prof.so')
+    be.LIB_PATH = os.environ.get('OMGX_PROF_LIB', os.path.join(ROOT, 'omg-tools_amd', 'csrc', 'libomgx_prof.so'))
     from omgtools.scenarios import holonomic_p2p
     saved = be.create_nlp
     be.create_nlp = lambda tpl, opt, name='': (None, 0.)
