@@ -4,8 +4,10 @@
 the in-scope path (reference `omgtools/__init__.py`): vehicles, shapes,
 environment, point-to-point / formation problems, simulator and deployer.
 """
+import numpy as np          # the reference's package namespace carries numpy as `np` (its examples rely on it)
+
 from .shapes import (Circle, Polyhedron, RegularPolyhedron, Rectangle, Square, Sphere, Polyhedron3D,
-                     Cuboid, Cube, Plate)
+                     RegularPrisma, Cuboid, Cube, Plate)
 from .splines import BSplineBasis, BSpline
 from .vehicles import Vehicle, Holonomic, Holonomic3D, Quadrotor, Fleet
 from .environment import Environment, Obstacle
@@ -13,7 +15,7 @@ from .problems import Problem, Point2point, FixedTPoint2point, FreeTPoint2point
 from .execution import Simulator, Deployer
 from .formation import FormationPoint2point
 
-__all__ = ['Circle', 'Polyhedron', 'RegularPolyhedron', 'Rectangle', 'Square', 'Sphere', 'Polyhedron3D',
+__all__ = ['np', 'RegularPrisma', 'Circle', 'Polyhedron', 'RegularPolyhedron', 'Rectangle', 'Square', 'Sphere', 'Polyhedron3D',
            'Cuboid', 'Cube', 'Plate', 'BSplineBasis', 'BSpline', 'Vehicle', 'Holonomic',
            'Holonomic3D', 'Quadrotor', 'Fleet', 'Environment', 'Obstacle', 'Problem',
            'Point2point', 'FixedTPoint2point', 'FreeTPoint2point', 'FormationPoint2point', 'Simulator', 'Deployer']

@@ -149,6 +149,27 @@ class Polyhedron3D(Shape3D):
         return [np.array([lo[k], hi[k]]) for k in range(3)]
 
 
+class RegularPrisma(Polyhedron3D):
+    """Right prism over a regular n-gon (`basics/shape.py:364-399`): `radius` is that of the circle
+    through the vertices of the base."""
+
+    def __init__(self, radius, height, n_faces, orientation=[0, 0, 0]):
+        self.height, self.n_faces = height, n_faces
+        dth = 2 * np.pi / n_faces
+        normals = np.array([[np.sin(l * dth), np.cos(l * dth)] for l in range(n_faces)])
+        apothem = radius * np.cos(np.pi / n_faces)
+        vertices = np.zeros((3, 2 * n_faces))
+        for l in range(n_faces):
+            # vertex l = intersection of the side faces l and l+1
+            a = np.vstack((normals[l], normals[(l + 1) % n_faces]))
+            vertices[:2, l] = np.linalg.solve(a, np.array([apothem, apothem]))
+            vertices[2, l] = -0.5 * height
+            vertices[:2, l + n_faces] = vertices[:2, l]
+            vertices[2, l + n_faces] = 0.5 * height
+        Polyhedron3D.__init__(self, vertices, orientation)
+        self.radius_outer = radius
+
+
 class Cuboid(Polyhedron3D):
     def __init__(self, width, depth, height, orientation=[0, 0, 0]):
         self.width, self.depth, self.height = width, depth, height
