@@ -20,12 +20,17 @@ import numpy as np
 from .splines import shiftoverknot_T
 
 
-def dual_shift_perm(father):
+def dual_shift_perm(father, extrapolate=True):
     """perm[r] = row whose multiplier warm-starts row r after the horizon moved by
     one knot interval (-1: none).  Spline-valued constraint entries are indexed by
     B-spline coefficients: moving the horizon by one interval drops the first
     `mult` coefficients (mult = multiplicity of the interior knots of that entry's
-    basis); scalar rows keep their multiplier."""
+    basis); scalar rows keep their multiplier.  The rows that enter at the end of the horizon
+    have no predecessor: with `extrapolate` they start from the multiplier of the last row that has
+    one (for the terminal-slack rows that is the right magnitude: the objective weight of the last
+    coefficients), otherwise from zero (-1) -- a zero multiplier on a row that is active at the
+    solution removes that row's curvature from the first Newton system, and the first step of the
+    crossing solve is cut to ~1e-6 by the fraction-to-boundary rule."""
     tpl = father.template
     perm = np.arange(tpl.n_con, dtype=np.int64)
     for label, child in father.children.items():
@@ -40,7 +45,7 @@ def dual_shift_perm(father):
                 continue
             mult = int(np.sum(interior == interior[0]))
             idx = np.arange(rows) + mult
-            perm[off:off + rows] = np.where(idx < rows, off + idx, -1)
+            perm[off:off + rows] = off + np.minimum(idx, rows - 1) if extrapolate else np.where(idx < rows, off + idx, -1)
     return perm
 
 

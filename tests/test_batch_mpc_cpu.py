@@ -8,12 +8,15 @@ def test_receding_horizon_protocol(cfg2_small):
     from omgtools.batch import BatchP2P, dual_shift_perm
     problem, P = cfg2_small
     tpl = problem.father.template
-    perm = dual_shift_perm(problem.father)
+    perm = dual_shift_perm(problem.father, extrapolate=False)
     # velocity rows (13, simple knots) shift by 1, vehicle-hyperplane rows (45, 4 per interval) by 4
     off = tpl.con_layout[(problem.vehicles[0].label, 'c_0_' + problem.vehicles[0].label)][0]
     assert list(perm[off:off + 3]) == [off + 1, off + 2, off + 3] and perm[off + 12] == -1
     off = tpl.con_layout[(problem.vehicles[0].label, 'c_8_' + problem.vehicles[0].label)][0]
     assert perm[off] == off + 4 and perm[off + 44] == -1
+    # default: rows entering at the end of the horizon start from the last multiplier that has a predecessor
+    perm_x = dual_shift_perm(problem.father)
+    assert perm_x[off] == off + 4 and list(perm_x[off + 41:off + 45]) == [off + 44] * 4 and perm_x.min() >= 0
     mpc = BatchP2P(problem, P, ops='numpy', options=dict(tol=1e-3, max_iter=300))
     mpc.solve_cold()
     ok = mpc.status == 0
