@@ -28,6 +28,38 @@ import numpy as np
 import torch
 
 FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X datasheet FP64 matrix (MFMA f64) peak
+HBM_PEAK_GBPS = 8000.0             # MI355X HBM3E (MI355X_MICROARCH.md)
+
+
+def sample_roofline(torch, tpl, veh, dev, n_agents, horizon_time, reps=20):
+    """Second roofline of SURVEY 8d: post-solve trajectory sampling (A11, `sample_kernel`) against HBM
+    bandwidth.  Algorithmic bytes per agent = 8 n_spl L (coefficients in) + 8 n_der n_spl n_samp (samples
+    out), n_samp = 1001, fp64.  Timed with events on the launch stream; outside the headline's timed
+    region."""
+    from omgtools.backend import BatchSolver
+    sol = BatchSolver(tpl, n_agents, device=dev.index or 0, options=dict(tol=1e-3, max_iter=1))
+    sol.set_stream(torch.cuda.current_stream().cuda_stream)
+    n_spl, L, n_der, n_samp = veh.n_spl, len(veh.basis), 3, 1001
+    lo = tpl.entry_range(veh.label, 'splines_seg0', 'var')[0]
+    x = torch.randn((n_agents, tpl.n_var), dtype=torch.float64, device=dev)
+    t0 = torch.zeros(n_agents, dtype=torch.float64, device=dev)
+    out = torch.empty((n_agents, n_der, n_spl, n_samp), dtype=torch.float64, device=dev)
+    knots = veh.basis.knots * horizon_time
+    dt = horizon_time / (n_samp - 1)
+    for _ in range(3):
+        sol.sample(x, lo, n_spl, veh.degree, knots, n_der, t0, dt, n_samp, out=out, device=True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        sol.sample(x, lo, n_spl, veh.degree, knots, n_der, t0, dt, n_samp, out=out, device=True)
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    nbytes = n_agents * 8.0 * (n_spl * L + n_der * n_spl * n_samp)
+    sol.close()
+    return {'bound': 'hbm', 'kernel': 'sample_kernel', 'agents': n_agents, 'achieved': nbytes / (ms * 1e-3) / 1e9,
+            'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            'bytes_per_launch': nbytes, 'kernel_ms': ms}
 
 
 def measured_traffic(n_agents):
@@ -309,6 +341,12 @@ def main():
                              'rocprofv3 --stats averages)'},
         'step_kernel_ms': [round(v, 3) for v in kernel_ms], 'step_max_iters': it_log[W:].max(dim=1).values.tolist(),
     }
+    if world == 1:
+        # trajectory extraction (A11) against the HBM roofline, at the workload's batch and at 16x (the
+        # 49 MB of one 1024-agent launch last ~10 us: launch-latency bound)
+        veh = problem.vehicles[0]
+        out['roofline_sample'] = [sample_roofline(torch, tpl, veh, dev, nb, float(problem.options['horizon_time']))
+                                  for nb in (B, 16 * B)]
     if not args.no_cpu and args.cpu_seconds > 0 and world == 1:
         out['cpu_baseline'] = cpu_baseline(problem, P, opts, args.steps, args.warmup, args.cpu_seconds)
     print(json.dumps(out))

@@ -151,7 +151,8 @@ int  omgx_batch_shift(omgx_batch* b, double* x, const uint8_t* mask,
  * `spline_extra.py:406-410`, C++ `Vehicle::sampleSplines` Vehicle.cpp:112-129):
  * out[b, d, k, i] = (d-th derivative of spline k of agent b)(t0[b] + i*dt), time
  * in units of the spline domain [0,1]; coeffs [B, n_spl, L] = a slice of x.
- * out is [B, n_der, n_spl, n_samp] fp64 (or fp32 when as_f32 != 0). */
+ * out is [B, n_der, n_spl, n_samp] fp64 (or fp32 when as_f32 != 0).  knots: host pointer, n_knots <= 40.
+ * With OMGX_PTR_DEVICE the call is asynchronous on the handle's stream (omgx_batch_sync to wait). */
 int  omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off,
                        int32_t n_spl, int32_t degree, const double* knots, int32_t n_knots,
                        int32_t n_der, const double* t0, double dt, int32_t n_samp,

@@ -104,22 +104,50 @@ static ipm_kernel_t ipm_kernel_for(int mode) {
   }
 }
 
-// out[b, o, k, i] = d^o/dt^o spline_k(t0[b] + i*dt); one block = (agent, 256-sample chunk)
+// out[b, o, k, i] = d^o/dt^o spline_k(t0[b] + i*dt); one block = (agent, 1024-sample chunk).
+//
+// Bound: HBM writes (8 n_der n_spl bytes per sample).  The de Boor recursion per sample (about 20
+// fp64 divisions for 3 derivative orders of 2 cubic splines) kept the first version at 20 % of the HBM
+// roofline, so the recursion is run once per knot span instead of once per sample: every block turns
+// its agent's splines into local power series  p_{o,k,j}(h) = sum_m S_k^{(o+m)}(k_j+) / m!  h^m  around
+// the left knot of each span j (a few dozen small de Boor evaluations, spread over the block) and a
+// sample is a span look-up plus one Horner evaluation per output value.
+struct KnotArg { double k[40]; };
+#define OMGX_SAMPLE_CHUNK 1024      // samples per block: the per-block set-up is amortised over 4 samples per thread
+
+// value at u of the spline with coefficients c on the knot vector kk (degree dg), inside span jo
+__device__ __forceinline__ double deboor_at(const double* c, const double* kk, int dg, int jo, double u) {
+  double dbo[6];                                  // de Boor triangle, degree <= 5
+  for (int r = 0; r <= dg; ++r) dbo[r] = c[jo - dg + r];
+  for (int lev = 1; lev <= dg; ++lev)
+    for (int r = dg; r >= lev; --r) {
+      const int idx = jo - dg + r;
+      const double den = kk[idx + dg - lev + 1] - kk[idx];
+      const double a = den != 0.0 ? (u - kk[idx]) / den : 0.0;
+      dbo[r] = (1.0 - a) * dbo[r - 1] + a * dbo[r];
+    }
+  return dbo[dg];
+}
+
 template <typename OutT>
 __global__ void __launch_bounds__(256)
 sample_kernel(const double* __restrict__ x, int x_stride, int coeff_off, int n_spl, int degree,
-              const double* __restrict__ knots, int n_knots, int n_der,
+              KnotArg knots, int n_knots, int n_der,
               const double* __restrict__ t0, double dt, int n_samp, OutT* __restrict__ out) {
   extern __shared__ __align__(16) double lds[];
   const int L = n_knots - degree - 1;
+  const int n_span = n_knots - 2 * degree - 1;    // spans j = degree .. degree + n_span - 1
+  const int D1 = degree + 1;
   double* kn = lds;                               // [n_knots]
-  double* cf = lds + n_knots;                     // [n_der][n_spl][L] derivative coefficients
+  double* cf = kn + n_knots;                      // [D1][n_spl][L]      coefficients of every derivative order
+  double* val = cf + D1 * n_spl * L;              // [D1][n_spl][n_span] S^{(q)}(k_j+)
+  double* pw = val + D1 * n_spl * n_span;         // [n_der][n_spl][n_span][D1] local power series
   const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < n_knots; i += blockDim.x) kn[i] = knots[i];
+  for (int i = threadIdx.x; i < n_knots; i += blockDim.x) kn[i] = knots.k[i];
   for (int i = threadIdx.x; i < n_spl * L; i += blockDim.x)
     cf[i] = x[(size_t)b * x_stride + coeff_off + i];
   __syncthreads();
-  for (int o = 1; o < n_der; ++o) {               // c^(o)_i = (d-o+1) (c^(o-1)_{i+1}-c^(o-1)_i)/(k_{i+d+1}-k_{i+o})
+  for (int o = 1; o <= degree; ++o) {             // c^(o)_i = (d-o+1) (c^(o-1)_{i+1}-c^(o-1)_i)/(k_{i+d+1}-k_{i+o})
     const int Lo = L - o, dd = degree - o + 1;
     for (int e = threadIdx.x; e < n_spl * Lo; e += blockDim.x) {
       const int k = e / Lo, i = e - k * Lo;
@@ -129,29 +157,39 @@ sample_kernel(const double* __restrict__ x, int x_stride, int coeff_off, int n_s
     }
     __syncthreads();
   }
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_samp) return;
-  const double u = t0[b] + i * dt;
-  // span j: k_j < u <= k_{j+1} (reference convention, `basics/spline.py:131-136`)
-  int j = degree;
-  for (int q = degree + 1; q < n_knots - degree - 1; ++q) if (kn[q] < u) j = q;
-  for (int o = 0; o < n_der; ++o) {
-    const int dg = degree - o;                    // degree of the o-th derivative spline
-    // its knot vector is kn[o .. n_knots-o), coefficient i there <-> original index i
-    for (int k = 0; k < n_spl; ++k) {
-      const double* c = cf + (o * n_spl + k) * L;
-      double dbo[6];                              // de Boor triangle, degree <= 5
-      const int jo = j - o;                       // span index in the trimmed knot vector
-      for (int r = 0; r <= dg; ++r) dbo[r] = c[jo - dg + r];
-      const double* kk = kn + o;
-      for (int lev = 1; lev <= dg; ++lev)
-        for (int r = dg; r >= lev; --r) {
-          const int idx = jo - dg + r;
-          const double den = kk[idx + dg - lev + 1] - kk[idx];
-          const double a = den != 0.0 ? (u - kk[idx]) / den : 0.0;
-          dbo[r] = (1.0 - a) * dbo[r - 1] + a * dbo[r];
-        }
-      out[(((size_t)b * n_der + o) * n_spl + k) * n_samp + i] = (OutT)dbo[dg];
+  // right-hand limits of every derivative order at the left knot of every span
+  for (int e = threadIdx.x; e < D1 * n_spl * n_span; e += blockDim.x) {
+    const int q = e / (n_spl * n_span), r = e - q * n_spl * n_span, k = r / n_span, sp = r - k * n_span;
+    const int j = degree + sp;
+    // the q-th derivative lives on the knot vector kn[q .. n_knots-q), its span index there is j - q
+    val[e] = deboor_at(cf + (q * n_spl + k) * L, kn + q, degree - q, j - q, kn[j]);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n_der * n_spl * n_span * D1; e += blockDim.x) {
+    const int m = e % D1, r = e / D1;             // r = (o, k, sp)
+    const int o = r / (n_spl * n_span), ks = r - o * n_spl * n_span;
+    double f = 1.0;
+    for (int q = 2; q <= m; ++q) f *= q;
+    pw[e] = (o + m <= degree) ? val[(o + m) * n_spl * n_span + ks] / f : 0.0;
+  }
+  __syncthreads();
+  const double tb = t0[b];
+  const int i_end = min(n_samp, (int)(blockIdx.x + 1) * OMGX_SAMPLE_CHUNK);
+  for (int i = blockIdx.x * OMGX_SAMPLE_CHUNK + threadIdx.x; i < i_end; i += blockDim.x) {
+    const double u = tb + i * dt;
+    // span j: k_j < u <= k_{j+1} (reference convention, `basics/spline.py:131-136`)
+    int j = degree;
+    for (int q = degree + 1; q < n_knots - degree - 1; ++q) if (kn[q] < u) j = q;
+    const double h = u - kn[j];
+    const int sp = j - degree;
+    for (int o = 0; o < n_der; ++o) {
+      const int dg = degree - o;
+      for (int k = 0; k < n_spl; ++k) {
+        const double* c = pw + (((o * n_spl + k) * n_span) + sp) * D1;
+        double v = c[dg];
+        for (int m = dg - 1; m >= 0; --m) v = fma(v, h, c[m]);
+        out[(((size_t)b * n_der + o) * n_spl + k) * n_samp + i] = (OutT)v;
+      }
     }
   }
 }
@@ -159,7 +197,6 @@ sample_kernel(const double* __restrict__ x, int x_stride, int coeff_off, int n_s
 // Ideal prediction of one receding-horizon step: thread (agent b, spline k) evaluates the plan and
 // its first derivative at tau by de Boor on the active span and writes them into the parameter
 // vector (state0 / input0), thread k == 0 also the time since the last knot crossing.
-struct KnotArg { double k[40]; };
 __global__ void __launch_bounds__(256)
 predict_kernel(const double* __restrict__ x, int n_var, double* __restrict__ p, int n_par, int B,
                int coeff_off, int n_spl, int degree, KnotArg kn, int n_knots, double tau, double inv_T,
@@ -663,9 +700,10 @@ int omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off, int32_t
   const int B = b->n_agents, L = n_knots - degree - 1;
   const bool dev = flags & OMGX_PTR_DEVICE;
   const size_t out_elems = (size_t)B * n_der * n_spl * n_samp, esz = as_f32 ? 4 : 8;
-  double* d_kn = nullptr; double* d_t0 = nullptr; void* d_out = out; const double* d_xx = x;
-  HIPCHK(hipMalloc((void**)&d_kn, n_knots * sizeof(double)));
-  HIPCHK(hipMemcpyAsync(d_kn, knots, n_knots * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  if (n_knots > 40) { g_err = "knot vector longer than 40"; return OMGX_E_INVALID; }
+  KnotArg kn;
+  for (int i = 0; i < 40; ++i) kn.k[i] = i < n_knots ? knots[i] : 0.0;
+  double* d_t0 = nullptr; void* d_out = out; const double* d_xx = x;
   if (!dev) {
     HIPCHK(hipMemcpyAsync(b->d_x, x, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream));
     d_xx = b->d_x;
@@ -675,23 +713,23 @@ int omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off, int32_t
   } else {
     d_t0 = (double*)t0;
   }
-  const dim3 grid((n_samp + 255) / 256, B), block(256);
-  const size_t lds = ((size_t)n_knots + (size_t)n_der * n_spl * L) * sizeof(double);
+  const dim3 grid((n_samp + OMGX_SAMPLE_CHUNK - 1) / OMGX_SAMPLE_CHUNK, B), block(256);
+  const int n_span = n_knots - 2 * degree - 1, D1 = degree + 1;
+  const size_t lds = ((size_t)n_knots + (size_t)D1 * n_spl * L + (size_t)D1 * n_spl * n_span +
+                      (size_t)n_der * n_spl * n_span * D1) * sizeof(double);
   if (as_f32)
     hipLaunchKernelGGL(sample_kernel<float>, grid, block, lds, b->stream, d_xx, d.n_var, coeff_off, n_spl, degree,
-                       d_kn, n_knots, n_der, d_t0, dt, n_samp, (float*)d_out);
+                       kn, n_knots, n_der, d_t0, dt, n_samp, (float*)d_out);
   else
     hipLaunchKernelGGL(sample_kernel<double>, grid, block, lds, b->stream, d_xx, d.n_var, coeff_off, n_spl, degree,
-                       d_kn, n_knots, n_der, d_t0, dt, n_samp, (double*)d_out);
+                       kn, n_knots, n_der, d_t0, dt, n_samp, (double*)d_out);
   HIPCHK(hipGetLastError());
   if (!dev) {
     HIPCHK(hipMemcpyAsync(out, d_out, out_elems * esz, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     (void)hipFree(d_out); (void)hipFree(d_t0);
   }
-  HIPCHK(hipStreamSynchronize(b->stream));
-  (void)hipFree(d_kn);
-  return OMGX_OK;
+  return OMGX_OK;      // device pointers: stream-ordered, the caller synchronises (omgx_batch_sync)
 }
 
 int omgx_batch_predict(omgx_batch* b, const double* x, double* p, int32_t coeff_off, int32_t n_spl, int32_t degree,

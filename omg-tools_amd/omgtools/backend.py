@@ -124,6 +124,14 @@ def load_library(path=None):
         raise OSError('%s not found: build it with `python __graft_entry__.py` or '
                       '`make -C omg-tools_amd/csrc` (hipcc, gfx950). There is no CPU '
                       'fallback for the solve path.' % path)
+    # One ROCm runtime per process: torch ships its own libamdhip64, and whichever copy initialises the
+    # device second reports "No HIP GPUs are available".  Importing torch first makes the loader bind
+    # libomgx.so to the copy torch uses (torch is the allocator / stream / RCCL host of this package
+    # anyway); without torch the library stands alone on /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     lib.omgx_version.restype = C.c_int
     lib.omgx_last_error.restype = C.c_char_p

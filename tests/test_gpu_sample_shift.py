@@ -43,6 +43,42 @@ def test_sample_matches_numpy(cfg2_small):
     solver.close()
 
 
+def test_sample_all_orders_nonuniform_knots_device_pointers(cfg2_small):
+    """Degree 4, every derivative order, non-uniform breakpoints, device
+    pointers (asynchronous on the handle's stream): the per-span power series equal scipy-free
+    de Boor evaluation (`omgtools.splines`, pinned to the reference in tests/test_golden_splines.py)."""
+    import torch
+    from omgtools.splines import BSpline, BSplineBasis
+    dev = torch.device('cuda', 0)
+    torch.zeros(1, device=dev)                           # torch initialises the HIP runtime first (as in BatchP2P)
+    problem, P, solver = _solver(cfg2_small)
+    tpl = problem.father.template
+    rng = np.random.default_rng(11)
+    deg = 4
+    brk = np.r_[0., np.sort(rng.uniform(0.05, 0.95, size=6)), 1.]
+    knots = np.r_[np.zeros(deg), brk, np.ones(deg)]
+    basis = BSplineBasis(knots, deg)
+    L, n_spl, n_der, n_samp = len(basis), 3, deg + 1, 777
+    assert n_spl * L <= tpl.n_var
+    x = rng.normal(size=(8, tpl.n_var))
+    t0 = rng.uniform(0., 0.2, size=8)
+    dt = 0.8 / (n_samp - 1)
+    xd = torch.as_tensor(x, device=dev)
+    td = torch.as_tensor(t0, device=dev)
+    out = torch.empty((8, n_der, n_spl, n_samp), dtype=torch.float64, device=dev)
+    solver.sample(xd, 5, n_spl, deg, knots, n_der, td, dt, n_samp, out=out, device=True)
+    solver.sync()
+    out = out.cpu().numpy()
+    for b in range(8):
+        tau = t0[b] + dt * np.arange(n_samp)
+        for k in range(n_spl):
+            s = BSpline(basis, x[b, 5 + k * L: 5 + (k + 1) * L])
+            for o in range(n_der):
+                ref = s.derivative(o)(tau)
+                assert np.abs(out[b, o, k] - ref).max() <= 1e-9 * (1 + np.abs(ref).max()), (b, k, o)
+    solver.close()
+
+
 def test_shift_matches_matrix(cfg2_small):
     from omgtools.splines import shiftoverknot_T, BSplineBasis
     problem, P, solver = _solver(cfg2_small)
