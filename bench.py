@@ -56,10 +56,18 @@ def sample_roofline(torch, tpl, veh, dev, n_agents, horizon_time, reps=20):
     torch.cuda.synchronize()
     ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
     nbytes = n_agents * 8.0 * (n_spl * L + n_der * n_spl * n_samp)
+    # calibration: a plain fill of the same output buffer (what a pure write stream reaches on this box)
+    for a, b in ev:
+        a.record()
+        out.fill_(1.0)
+        b.record()
+    torch.cuda.synchronize()
+    fill_ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
     sol.close()
     return {'bound': 'hbm', 'kernel': 'sample_kernel', 'agents': n_agents, 'achieved': nbytes / (ms * 1e-3) / 1e9,
             'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            'bytes_per_launch': nbytes, 'kernel_ms': ms}
+            'bytes_per_launch': nbytes, 'kernel_ms': ms,
+            'fill_same_buffer_GBps': out.numel() * 8.0 / (fill_ms * 1e-3) / 1e9}
 
 
 def measured_traffic(n_agents):

@@ -115,18 +115,26 @@ static ipm_kernel_t ipm_kernel_for(int mode) {
 struct KnotArg { double k[40]; };
 #define OMGX_SAMPLE_CHUNK 1024      // samples per block: the per-block set-up is amortised over 4 samples per thread
 
-// value at u of the spline with coefficients c on the knot vector kk (degree dg), inside span jo
+// value at u of the spline with coefficients c on the knot vector kk (degree dg <= 5), inside span jo.
+// Fully unrolled triangle with compile-time indices: a dynamically indexed local array would live in
+// scratch (global) memory.
 __device__ __forceinline__ double deboor_at(const double* c, const double* kk, int dg, int jo, double u) {
-  double dbo[6];                                  // de Boor triangle, degree <= 5
-  for (int r = 0; r <= dg; ++r) dbo[r] = c[jo - dg + r];
-  for (int lev = 1; lev <= dg; ++lev)
-    for (int r = dg; r >= lev; --r) {
-      const int idx = jo - dg + r;
-      const double den = kk[idx + dg - lev + 1] - kk[idx];
-      const double a = den != 0.0 ? (u - kk[idx]) / den : 0.0;
-      dbo[r] = (1.0 - a) * dbo[r - 1] + a * dbo[r];
+  double dbo[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) dbo[r] = (r <= dg) ? c[jo - dg + r] : 0.0;
+#pragma unroll
+  for (int lev = 1; lev <= 5; ++lev) {
+#pragma unroll
+    for (int r = 5; r >= 1; --r) {
+      if (lev <= dg && r >= lev && r <= dg) {
+        const int idx = jo - dg + r;
+        const double den = kk[idx + dg - lev + 1] - kk[idx];
+        const double a = den != 0.0 ? (u - kk[idx]) / den : 0.0;
+        dbo[r] = (1.0 - a) * dbo[r - 1] + a * dbo[r];
+      }
     }
-  return dbo[dg];
+  }
+  return dg == 0 ? dbo[0] : (dg == 1 ? dbo[1] : (dg == 2 ? dbo[2] : (dg == 3 ? dbo[3] : (dg == 4 ? dbo[4] : dbo[5]))));
 }
 
 template <typename OutT>
