@@ -1,0 +1,159 @@
+"""BASELINE.json's configurations at their FULL batch sizes on the HIP path, checked through
+size-independent properties (the oracle solves a handful of agents in seconds, not thousands):
+
+* optimality conditions of every converged agent, evaluated with the oracle's numpy restatement of
+  the NLP (`oracle/nlp_numpy.py`, pinned to the reference's construct code by tests/golden): primal
+  feasibility, multiplier signs, complementarity, stationarity of the Lagrangian -- at the tolerance
+  the solver was asked for (`ipopt.tol = 1e-3` on gradient-scaled rows, `problems/problem.py:57`);
+* independence of the agents: a permuted batch gives the permuted result, and an agent solved alone
+  equals the same agent inside the batch (LDS atomics reorder sums: 1e-8, not bitwise);
+* the receding-horizon step keeps every plan feasible and consistent with the prediction.
+
+Config 2: 1024 x Holonomic (K=11, 3 circles); config 3: 4096 x Quadrotor (K=13, 5 moving circles, HBM
+spill mode 1); config 5: 8192 x Holonomic3D (K=15, 10 spheres, spill mode 3) on ONE GPU here (the
+8-GPU split of BASELINE.json shards agents without any exchange)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+def _build(fn, B, **kw):
+    import omgtools.backend as be
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        return fn(B, **kw)
+    finally:
+        be.create_nlp = saved
+
+
+def kkt_report(nlp, tpl, p, x, lam):
+    """(max violation, min multiplier sign, max |lam * slack|, max |grad L|) of one agent, rows scaled
+    like the solver scales them (gradient-based, g_max = 100)."""
+    c = nlp.term_coefs(p)
+    f, g = nlp.fg(x, c)
+    J = nlp.jac(x, c)
+    gmax = np.abs(J[:-1]).max(axis=1)
+    rho = np.where(gmax > 100., 100. / np.maximum(gmax, 1e-300), 1.0)
+    up, lo = np.isfinite(tpl.ub), np.isfinite(tpl.lb)
+    viol = max(((g - tpl.ub) * rho)[up].max(initial=0.), ((tpl.lb - g) * rho)[lo].max(initial=0.))
+    ineq_up, ineq_lo = up & ~lo, lo & ~up
+    sign = min(lam[ineq_up].min(initial=0.), (-lam[ineq_lo]).min(initial=0.))
+    slack = np.where(ineq_up, tpl.ub - g, np.where(ineq_lo, g - tpl.lb, 0.0))
+    comp = np.abs(lam * slack).max()
+    sd = max(100., np.abs(lam / rho).mean()) / 100.
+    stat = np.abs(J[-1] + J[:-1].T @ lam).max() / sd
+    return viol, sign, comp / sd, stat
+
+
+def check_optimality(tpl, P, res, agents):
+    from oracle.nlp_numpy import NumpyNLP
+    nlp = NumpyNLP(tpl)
+    worst = np.zeros(4)
+    for b in agents:
+        viol, sign, comp, stat = kkt_report(nlp, tpl, P['p'][b], res['x'][b], res['lam_g'][b])
+        worst = np.maximum(worst, [viol, -sign, comp, stat])
+        assert viol < 2 * TOL, (b, viol)                # h <= t v with t at the phase-I floor
+        assert sign > -1e-12, (b, sign)
+        assert comp < 3 * TOL, (b, comp)                # s z ~ mu <= kappa_eps * tol / 10 ... tol
+        assert stat < 1.5 * TOL, (b, stat)
+    return worst
+
+
+def test_config2_full_batch_optimality_and_independence():
+    from omgtools.scenarios import holonomic_p2p
+    from omgtools.backend import BatchSolver
+    B = 1024
+    problem, P = _build(holonomic_p2p, B)
+    tpl = problem.father.template
+    solver = BatchSolver(tpl, B, options=dict(tol=TOL, max_iter=300))
+    res = solver.solve(P['p'], P['x0'])
+    ok = res['status'] == 0
+    assert ok.mean() >= 0.998
+    check_optimality(tpl, P, res, np.nonzero(ok)[0])            # every converged agent
+    # permutation of the batch -> permutation of the result
+    perm = np.random.default_rng(5).permutation(B)
+    res_p = solver.solve(P['p'][perm], P['x0'][perm])
+    assert np.array_equal(res_p['status'], res['status'][perm])
+    assert np.array_equal(res_p['iters'], res['iters'][perm])
+    assert np.abs(res_p['x'] - res['x'][perm]).max() < 1e-8 * (1 + np.abs(res['x']).max())
+    solver.close()
+    # an agent alone == the same agent in the batch
+    single = BatchSolver(tpl, 1, options=dict(tol=TOL, max_iter=300))
+    for b in (0, 511, 1023):
+        r1 = single.solve(P['p'][b:b + 1], P['x0'][b:b + 1])
+        assert r1['status'][0] == res['status'][b] and r1['iters'][0] == res['iters'][b]
+        assert np.abs(r1['x'][0] - res['x'][b]).max() < 1e-8 * (1 + np.abs(res['x'][b]).max())
+    single.close()
+
+
+def test_config2_full_batch_receding_horizon_properties():
+    """Twelve receding-horizon steps of the 1024-agent batch (one knot crossing): every step converges for
+    every agent, the new plan starts at the predicted state (the init rows `B(t0) c = state0`,
+    `holonomic.py:87-96`), its velocity / acceleration coefficients respect the limits
+    (`holonomic.py:62-85`), and the fleet advances."""
+    import torch
+    from omgtools.scenarios import holonomic_p2p
+    from omgtools.batch import BatchP2P
+    B = 1024
+    problem, P = _build(holonomic_p2p, B)
+    tpl = problem.father.template
+    veh = problem.vehicles[0]
+    mpc = BatchP2P(problem, P, ops='hip', device=torch.device('cuda', 0), options=dict(tol=TOL, max_iter=300))
+    mpc.solve_cold()
+    assert (mpc.host('status') == 0).mean() >= 0.998
+    basis, L, T = veh.basis, len(veh.basis), mpc.T
+    d1, P1 = basis.derivative(1)
+    d2, P2 = basis.derivative(2)
+    goal = P['p'][:, tpl.entry_range(veh.label, 'poseT', 'par')[0]:][:, :2]
+    start = P['p'][:, tpl.entry_range(veh.label, 'state0', 'par')[0]:][:, :2].copy()
+    crossings = 0
+    for k in range(12):
+        crossings += mpc.step()
+        st = mpc.host('status')
+        assert (st == 0).mean() >= 0.998, (k, np.bincount(st))
+        x, p = mpc.host('x'), mpc.host('p')
+        c = x[:, mpc.o_spl:mpc.o_spl + 2 * L].reshape(B, 2, L)
+        t0 = p[0, mpc.o_t] / T
+        E = basis.eval_basis([t0])[0]
+        good = st == 0
+        assert np.abs(c[good] @ E - p[good, mpc.o_state0:mpc.o_state0 + 2]).max() < 1e-6
+        assert (np.abs(c[good] @ P1.T) / T).max() <= 0.5 + 2e-3          # vmax = 0.5 (`holonomic.py:40-41`)
+        assert (np.abs(c[good] @ P2.T) / T ** 2).max() <= 1.0 + 5e-3     # amax = 1
+    assert crossings == 1
+    now = mpc.host('p')[:, mpc.o_state0:mpc.o_state0 + 2]
+    gain = (np.linalg.norm(start - goal, axis=1) - np.linalg.norm(now - goal, axis=1))[good]
+    assert gain.min() > 0.1 and gain.mean() > 0.4               # 1.2 s from rest at amax 1, vmax 0.5 (detours included)
+
+
+@pytest.mark.parametrize('name,B,min_ok,n_check', [('quadrotor_p2p', 4096, 0.93, 48), ('holonomic3d_p2p', 8192, 0.99, 24)])
+def test_config3_and_5_full_batch(name, B, min_ok, n_check):
+    from omgtools import scenarios
+    from omgtools.backend import BatchSolver
+    problem, P = _build(getattr(scenarios, name), B)
+    tpl = problem.father.template
+    solver = BatchSolver(tpl, B, options=dict(P.get('solver_options', {}), tol=TOL, max_iter=300))
+    assert solver.workspace()['mode'] >= 1                        # HBM spill mode
+    res = solver.solve(P['p'], P['x0'])
+    ok = res['status'] == 0
+    assert ok.mean() >= min_ok, ok.mean()
+    assert set(np.unique(res['status'])) <= {0, 1, 2}             # never a numerical failure / bad bounds
+    rng = np.random.default_rng(7)
+    agents = rng.choice(np.nonzero(ok)[0], size=n_check, replace=False)
+    check_optimality(tpl, P, res, agents)
+    # permuted second half of the batch: same results for the same agents
+    half = np.arange(B // 2, B)
+    perm = np.r_[np.arange(B // 2), rng.permutation(half)]
+    res_p = solver.solve(P['p'][perm], P['x0'][perm])
+    assert np.array_equal(res_p['status'], res['status'][perm])
+    # LDS atomics reorder sums from run to run; over a long ill-conditioned solve (> 100 iterations) that
+    # rounding noise can grow to the solver tolerance, so: (nearly) all agents agree to rounding, all
+    # of them to the accuracy the tolerance buys
+    diff = np.abs(res_p['x'][ok[perm]] - res['x'][perm][ok[perm]]).max(axis=1)
+    assert (diff < 1e-7 * (1 + np.abs(res['x'][ok]).max())).mean() >= 0.99
+    lo, hi = tpl.entry_range(problem.vehicles[0].label, 'splines_seg0', 'var')     # the output the reference consumes
+    assert np.abs(res_p['x'][ok[perm], lo:hi] - res['x'][perm][ok[perm], lo:hi]).max() < 5e-2
+    solver.close()
