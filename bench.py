@@ -89,13 +89,14 @@ def cpu_baseline(problem, P, opts, steps, warmup, budget_s):
     the cold start until about `budget_s` seconds of timed CPU work are collected -- on all host
     cores (one agent per thread at a time) and, with a 64-agent sample, on one thread."""
     from omgtools.batch import BatchP2P
+    from oracle import port_binding            # the checker, timed as the reported CPU baseline
     cores = os.cpu_count() or 1
     out = {}
     for label, threads, n_agents, budget in (('all', cores, P['p'].shape[0], budget_s), ('one', 1, min(64, P['p'].shape[0]), budget_s / 4.)):
         sub = {'p': P['p'][:n_agents], 'x0': P['x0'][:n_agents]}
         ok, its, dt, reps = 0, 0, 0.0, 0
         while dt < budget and reps < 200:
-            mpc = BatchP2P(problem, sub, ops='numpy', options=opts)
+            mpc = BatchP2P(problem, sub, ops=port_binding, options=opts)
             mpc.n_threads = threads
             mpc.solve_cold()
             for _ in range(warmup):

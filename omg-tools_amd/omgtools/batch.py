@@ -12,8 +12,10 @@ plus an index shift of the multipliers; (3) `omgx_batch_solve` with a primal-dua
 warm start.  The glue is a handful of tiny tensor ops on [B, *] device arrays
 (torch is only the allocator/stream here); no data leaves HBM between steps.
 
-`ops='numpy'` runs the same protocol on host arrays with the oracle CPU port as the
-solver: test infrastructure for the parity tests, never the product path.
+Passing a host solver object as `ops` (anything with the `solve(template, p, x0, ...)` signature of
+the tests' oracle port binding) runs the same protocol on host arrays instead: that is how the
+parity tests and the CPU baseline of bench.py replay the loop.  This package itself never imports
+the oracle; the default `ops='hip'` is the only product path.
 """
 import numpy as np
 
@@ -89,7 +91,7 @@ class BatchP2P(object):
         self.opts.update(options or {})
         self.max_iter_cold = self.opts['max_iter']
         self.max_iter_step = int(max_iter_step) if max_iter_step else self.max_iter_cold
-        self.kind = ops
+        self.kind = 'hip' if ops == 'hip' else 'host'
         self.straggler_first = bool(straggler_first)
         if ops == 'hip':
             import torch
@@ -112,8 +114,9 @@ class BatchP2P(object):
             self._mask = torch.ones(self.B, dtype=torch.uint8, device=self.dev)
             self._order = torch.arange(self.B, dtype=torch.int32, device=self.dev)
         else:
-            from oracle import port_binding          # test infrastructure only
-            self.port = port_binding
+            if isinstance(ops, str):
+                raise ValueError("ops must be 'hip' or an injected host solver object (tests / CPU baseline)")
+            self.port = ops                          # injected by tests / bench.py's cpu_baseline leg
             self.n_threads = 1
             self.dw = np.zeros(self.B)            # inertia correction carried between warm solves
             self.p, self.x = np.array(P['p'], float), np.array(P['x0'], float)

@@ -123,3 +123,19 @@ def test_bad_arguments_return_error_codes(cfg2_small):
     ct2, keep2 = be.make_ctemplate(problem.father.template)
     ct2.n_root = ct2.n_root + 1
     assert lib.omgx_batch_create(C.byref(ct2), 4, 0, C.byref(h)) in (-1, -2)      # invalid (or no device first)
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under omg-tools_amd/ may import or include it (host
+    solvers for the CPU tier are injected by the tests)."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'omg-tools_amd')
+    py = re.compile(r'^\s*(from|import)\s+oracle\b', re.M)
+    inc = re.compile(r'#include\s+"[^"]*oracle/')
+    hits = []
+    for d, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                txt = open(os.path.join(d, f), errors='ignore').read()
+                if py.search(txt) or inc.search(txt):
+                    hits.append(os.path.join(d, f))
+    assert not hits, hits

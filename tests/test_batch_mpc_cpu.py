@@ -6,6 +6,7 @@ import numpy as np
 
 def test_receding_horizon_protocol(cfg2_small):
     from omgtools.batch import BatchP2P, dual_shift_perm
+    from oracle import port_binding
     problem, P = cfg2_small
     tpl = problem.father.template
     perm = dual_shift_perm(problem.father, extrapolate=False)
@@ -17,7 +18,7 @@ def test_receding_horizon_protocol(cfg2_small):
     # default: rows entering at the end of the horizon start from the last multiplier that has a predecessor
     perm_x = dual_shift_perm(problem.father)
     assert perm_x[off] == off + 4 and list(perm_x[off + 41:off + 45]) == [off + 44] * 4 and perm_x.min() >= 0
-    mpc = BatchP2P(problem, P, ops='numpy', options=dict(tol=1e-3, max_iter=300))
+    mpc = BatchP2P(problem, P, ops=port_binding, options=dict(tol=1e-3, max_iter=300))
     mpc.solve_cold()
     ok = mpc.status == 0
     assert ok.sum() >= 5

@@ -10,13 +10,14 @@ pytestmark = pytest.mark.gpu
 
 def test_mpc_replay_matches_port(cfg2_small):
     from omgtools.batch import BatchP2P
+    from oracle import port_binding
     problem, P = cfg2_small
     tpl = problem.father.template
     from oracle.nlp_numpy import NumpyNLP
     nlp = NumpyNLP(tpl)
     opts = dict(tol=1e-5, max_iter=300)
     gpu = BatchP2P(problem, P, ops='hip', options=opts, max_iter_step=300)
-    cpu = BatchP2P(problem, P, ops='numpy', options=opts, max_iter_step=300)
+    cpu = BatchP2P(problem, P, ops=port_binding, options=opts, max_iter_step=300)
     gpu.solve_cold()
     cpu.solve_cold()
     ok = (gpu.host('status') == 0) & (cpu.status == 0)
