@@ -435,9 +435,11 @@ OMGX_FN int tri(int i, int k) { return i * (i + 1) / 2 + k; }   // packed lower,
 
 struct Kkt {
   const Dims* d; const Tables* T; double* a;
-  // leaf l: panel of (n_l + nc_l) rows with odd leading dimension ld_l; rows [0,n_l) hold the
+  // leaf l: panel of (n_l + nc_l + 1) rows with odd leading dimension ld_l; rows [0,n_l) hold the
   // leaf block D_l (lower part), rows [n_l, n_l+nc_l) the coupling rows B_l (one per coupled
-  // root position).  Root block R: packed lower, row-major.
+  // root position), row n_l+nc_l the right-hand side of the leaf.  Root block R: packed lower,
+  // row-major, nr rows + one more for its right-hand side.  The right-hand sides are carried through
+  // the factorisation like coupling rows, so the forward substitutions L^{-1} r come out of it.
   OMGX_FN double* P(int l) const { return a + T->d_off[l]; }
   OMGX_FN int ld(int l) const { return T->b_off[l]; }
   OMGX_FN double* R() const { return a + T->d_off[d->n_leaf]; }
@@ -781,11 +783,11 @@ OMGX_FN void kkt_describe(const C& c, const Dims& d, const Kkt& K, Work& w) {
     int pan = pan0;
     for (int l = 0; l < d.n_leaf; ++l) {
       BMat& M = Ms[l];
-      M.a = K.T->d_off[l]; M.ld = K.ld(l); M.nfact = K.nl(l); M.rows = K.nl(l) + K.nc(l); M.npos = M.nfact;
+      M.a = K.T->d_off[l]; M.ld = K.ld(l); M.nfact = K.nl(l); M.rows = K.nl(l) + K.nc(l) + 1; M.npos = M.nfact;   // + the rhs row
       M.dinv = K.T->leaf_off[l]; M.pan = pan; pan += OMGX_PAN_LD * M.rows; M.cpl = K.T->cpl_ptr[l];
     }
     BMat& Mr = Ms[d.n_leaf];
-    Mr.a = K.T->d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0;
+    Mr.a = K.T->d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr + 1; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0;
   }
   c.sync();
 }
@@ -815,10 +817,12 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
     const double* Wt = K.P(l) + n * ld;
     const double* di = w.dinv + K.T->leaf_off[l];
     const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
-    for (int ai = 0; ai < nc; ++ai) for (int ak = 0; ak <= ai; ++ak) {
+    // carried rows 0..nc-1 are coupling rows (root position ci[a]), row nc the leaf's right-hand side,
+    // which lands in the root's right-hand-side row (index nr):  r_r -= Wt D^{-1} (L^{-1} r_l)
+    for (int ai = 0; ai <= nc; ++ai) for (int ak = 0; ak <= ai && ak < nc; ++ak) {
       double acc = 0.0;
       for (int j = 0; j < n; ++j) acc += Wt[ai * ld + j] * Wt[ak * ld + j] * di[j];
-      R[tri(ci[ai], ci[ak])] -= acc;
+      R[tri(ai < nc ? ci[ai] : d.nr, ci[ak])] -= acc;
     }
   }
 #else
@@ -829,6 +833,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
     int tile0 = 0;
     for (int l = 0; l < d.n_leaf; ++l) {
       const BMat M = Ms[l];                       // dimensions from LDS, not from the global plan tables
+      // carried rows: nc - 1 coupling rows + the right-hand-side row (last), which maps to row nr of the root
       const int n = M.nfact, nc = M.rows - M.nfact, ld = M.ld;
       const double* Wt = w.kkt + M.a + n * ld;
       const double* di = w.dinv + M.dinv;
@@ -852,7 +857,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
         const int cb = 16 * tj + (lane & 15);
         for (int i = 0; i < 4; ++i) {
           const int ca = 16 * ti + (lane >> 4) + 4 * i;
-          if (ca < nc && cb < nc && cb <= ca) c.add(R + tri(ci[ca], ci[cb]), -acc[i]);
+          if (ca < nc && cb < nc - 1 && cb <= ca) c.add(R + tri(ca < nc - 1 ? ci[ca] : d.nr, ci[cb]), -acc[i]);
         }
       }
       tile0 += tile;
@@ -928,69 +933,49 @@ OMGX_FN void trsv_bwd4(const C& c, const double* A, Addr L, int n, double* y) {
   }
 }
 
-// Solve K sol = rhs in place (sol holds rhs on entry); position order + eq.
+// Finish the solve of K sol = rhs.  The right-hand side went through the factorisation as the carried
+// last row of every leaf panel and of the root (kkt_rhs wrote it there), so the forward substitutions
+// are done: the rows hold L^{-1} r.  What is left: scale by the inverse pivots, the root's backward
+// substitution, the leaves' correction by the root solution and their backward substitutions.
+// sol: position order + equality multipliers.
 template <class C>
 OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double* sol) {
   double* yr = sol + d.root_off;
-  const int lane = c.lane(), nln = c.nlanes();
   // leaf dimensions from the matrix descriptors kkt_factor left in LDS (not from the global plan
   // tables: every look-up there is a dependent global load)
   const BMat* Ms = (const BMat*)w.col;
   OMGX_TIC();
-  // leaves (wave-parallel): y_l <- Delta^{-1} L^{-1} r_l
-  for (int l = c.wave(); l < d.n_leaf; l += c.nwaves()) {
+  // leaves: y_l <- Delta^{-1} (L^{-1} r_l), root: y_r <- D^{-1} (L^{-1} r_r)
+  OMGX_PFOR(q, d.root_off) {
+    int l = 0;
+    while (q >= Ms[l].dinv + Ms[l].nfact) ++l;
     const BMat M = Ms[l];
-    const int n = M.nfact, ld = M.ld, base = M.a;
-    double* yl = sol + M.dinv;
-    const double* di = w.dinv + M.dinv;
-    trsv_fwd4(c, w.kkt, [=](int i, int j) { return base + i * ld + j; }, n, yl);
-    for (int i = lane; i < n; i += nln) yl[i] *= di[i];
-    c.wave_sync();
+    sol[q] = w.kkt[M.a + (M.rows - 1) * M.ld + (q - M.dinv)] * w.dinv[q];
+  }
+  {
+    const int rbase = Ms[d.n_leaf].a, nr = d.nr;
+    OMGX_PFOR(k, nr) yr[k] = w.kkt[rbase + tri(nr, k)] / w.kkt[rbase + tri(k, k)];
   }
   c.sync();
   OMGX_TOC(PH_K_FWD);
-  // root rhs:  r_r -= sum_l Wt_l y_l, spread over the whole workgroup: one item = (leaf, coupling
-  // row, chunk of 8 leaf columns), partial sums added with LDS atomics
-  {
-    int items = 0;
-    for (int l = 0; l < d.n_leaf; ++l) items += (Ms[l].rows - Ms[l].nfact) * ((Ms[l].nfact + 7) >> 3);
-    OMGX_PFOR(it, items) {
-      int l = 0, e = it;
-      for (;; ++l) { const int cnt = (Ms[l].rows - Ms[l].nfact) * ((Ms[l].nfact + 7) >> 3); if (e < cnt) break; e -= cnt; }
-      const BMat M = Ms[l];
-      const int n = M.nfact, ld = M.ld, nch = (n + 7) >> 3;
-      const int a = e / nch, j0 = 8 * (e - a * nch);
-      const double* wrow = w.kkt + M.a + (n + a) * ld;
-      const double* yl = sol + M.dinv;
-      double acc = 0.0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { const int j = j0 + q < n ? j0 + q : n - 1; acc += (j0 + q < n ? 1.0 : 0.0) * wrow[j] * yl[j]; }
-      c.add(yr + K.T->cpl_idx[M.cpl + a], -acc);
-    }
-  }
-  c.sync();
-  OMGX_TOC(PH_K_ROOTRHS);
-  // root solve by wave 0 (packed L)
+  // root backward substitution by wave 0 (packed L)
   if (c.wave() == 0) {
     const int n = d.nr, rbase = Ms[d.n_leaf].a;
     auto Lr = [=](int i, int j) { return rbase + tri(i, j); };
-    trsv_fwd4(c, w.kkt, Lr, n, yr);
-    for (int i = lane; i < n; i += nln) yr[i] /= w.kkt[rbase + tri(i, i)];
-    c.wave_sync();
     trsv_bwd4(c, w.kkt, Lr, n, yr);
   }
   c.sync();
   OMGX_TOC(PH_K_ROOT);
-  // leaves: y_l <- L^{-T} (y_l - Delta^{-1} Wt' x_r); the correction term again item-parallel over
+  // leaves: y_l <- L^{-T} (y_l - Delta^{-1} Wt' x_r); the correction term item-parallel over
   // (leaf, leaf column, chunk of 8 coupling rows)
   {
     int items = 0;
-    for (int l = 0; l < d.n_leaf; ++l) items += Ms[l].nfact * ((Ms[l].rows - Ms[l].nfact + 7) >> 3);
+    for (int l = 0; l < d.n_leaf; ++l) items += Ms[l].nfact * ((Ms[l].rows - 1 - Ms[l].nfact + 7) >> 3);
     OMGX_PFOR(it, items) {
       int l = 0, e = it;
-      for (;; ++l) { const int cnt = Ms[l].nfact * ((Ms[l].rows - Ms[l].nfact + 7) >> 3); if (e < cnt) break; e -= cnt; }
+      for (;; ++l) { const int cnt = Ms[l].nfact * ((Ms[l].rows - 1 - Ms[l].nfact + 7) >> 3); if (e < cnt) break; e -= cnt; }
       const BMat M = Ms[l];
-      const int n = M.nfact, nc = M.rows - M.nfact, ld = M.ld;
+      const int n = M.nfact, nc = M.rows - 1 - M.nfact, ld = M.ld;
       const int ch = e / n, j = e - ch * n, a0 = 8 * ch;
       const double* Pn = w.kkt + M.a;
       const int32_t* ci = K.T->cpl_idx + M.cpl;
@@ -1013,6 +998,27 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
   }
   c.sync();
   OMGX_TOC(PH_K_BWD);
+}
+
+// Right-hand side of the Newton system into the carried rows of the block-arrow store (after the
+// store was zeroed, before the factorisation): leaf l gets -gbar of its variables, the root
+// -gbar of the root variables and the equality residuals.
+template <class C>
+OMGX_FN void kkt_rhs(const C& c, const Dims& d, const Tables& T, Work& w, double t) {
+  const BMat* Ms = (const BMat*)w.col;
+  OMGX_PFOR(q, d.root_off) {
+    int l = 0;
+    while (q >= Ms[l].dinv + Ms[l].nfact) ++l;
+    const BMat M = Ms[l];
+    w.kkt[M.a + (M.rows - 1) * M.ld + (q - M.dinv)] = -w.gbar[q];
+  }
+  const int rbase = Ms[d.n_leaf].a, nr = d.nr;
+  OMGX_PFOR(k, nr) {
+    double v;
+    if (k < d.n_root) v = -w.gbar[d.root_off + k];
+    else { const int r = T.eq_rows[k - d.n_root]; v = (w.rtype[r] == ROW_EQ) ? -(w.hv[r] - t * w.vv[r]) : 0.0; }
+    w.kkt[rbase + tri(nr, k)] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1368,6 +1374,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         }
       }
       OMGX_TOC(PH_A_HESS);
+      kkt_rhs(c, d, T, w, t);
       tt_acc = use_t ? c.rsum(tt_acc) : 0.0;
       c.sync();
       OMGX_TOC(PH_A_REST);
@@ -1408,10 +1415,6 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     dw_last = dw;
 
     // ---- Newton step -------------------------------------------------------------
-    OMGX_PFOR(q, N) w.sol[q] = -w.gbar[q];
-    OMGX_PFOR(k, d.n_eq) { const int r = T.eq_rows[k];
-      w.sol[N + k] = (w.rtype[r] == ROW_EQ) ? -(w.hv[r] - t * w.vv[r]) : 0.0; }
-    c.sync();
     kkt_solve(c, d, K, w, w.sol);
     OMGX_TOC(PH_SOLVE);
     if (!use_t && c.tid() == 0) w.sol[N - 1] = 0.0;

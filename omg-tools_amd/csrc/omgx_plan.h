@@ -38,13 +38,15 @@ struct HostPlan {
       if (n > d.max_leaf) d.max_leaf = n;
       if (nc > d.max_cpl) d.max_cpl = nc;
       const int ld = n | 1;                        // odd leading dimension: conflict-free row-per-lane access
-      d_off[l] = off; b_off[l] = ld; off += (n + nc) * ld;
+      // rows [0,n): D_l, rows [n,n+nc): coupling rows B_l, row n+nc: the right-hand side of the leaf
+      // (carried through the factorisation like a coupling row: it comes out as L^{-1} r)
+      d_off[l] = off; b_off[l] = ld; off += (n + nc + 1) * ld;
     }
-    d_off[d.n_leaf] = off; off += d.nr * (d.nr + 1) / 2;
+    d_off[d.n_leaf] = off; off += (d.nr + 1) * (d.nr + 2) / 2;      // packed root + its right-hand-side row
     {
       int leaf_rows = 0;
-      for (int l = 0; l < d.n_leaf; ++l) leaf_rows += (t.leaf_off[l + 1] - t.leaf_off[l]) + (t.cpl_ptr[l + 1] - t.cpl_ptr[l]);
-      const int pr = leaf_rows > d.nr ? leaf_rows : d.nr;
+      for (int l = 0; l < d.n_leaf; ++l) leaf_rows += (t.leaf_off[l + 1] - t.leaf_off[l]) + (t.cpl_ptr[l + 1] - t.cpl_ptr[l]) + 1;
+      const int pr = leaf_rows > d.nr + 1 ? leaf_rows : d.nr + 1;
       d.col_doubles = (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + OMGX_PAN_LD * pr;
       if (d.n_leaf > OMGX_MAX_LEAF) return false;
     }
