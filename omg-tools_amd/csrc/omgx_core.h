@@ -535,8 +535,8 @@ OMGX_FN Blk4 blk4_factor(const BMat& M, const double* A, int jb, int nb) {
 // factorises the block in registers and solves its row against it.  During the sweep all rows
 // hold U = L D (for the carried rows that is the final Wt = B L^{-T}); the original diagonal blocks
 // are parked in a side buffer first, because their matrix slots receive U while other threads
-// still need the originals.  A last pass scales the factorised rows to L.  Same output layout as
-// ldl_blocked.  Latency: 2-3 dependent LDS round trips and one barrier per block instead of ~6 and
+// still need the originals.  Output: factorised rows hold U = L D (pivots on the diagonal, inverse
+// pivots in the side array), carried rows U = a L^{-T} as in ldl_blocked.  Latency: 2-3 dependent LDS round trips and one barrier per block instead of ~6 and
 // two; the dot products are independent loads the compiler can keep in flight.
 // ---------------------------------------------------------------------------
 template <class C>
@@ -615,16 +615,8 @@ OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* di
     c.sync();
   }
   OMGX_TOC(PH_F_SWEEP);
-  // factorised rows: U -> L
-  OMGX_PFOR(it, total_rows) {
-    int mi = 0, r = it;
-    while (r >= Ms[mi].rows) { r -= Ms[mi].rows; ++mi; }
-    const BMat M = Ms[mi];
-    if (r >= M.nfact) continue;
-    const double* iv = (M.dinv >= 0) ? dinvb + M.dinv : colb + M.pan;
-    const int br = baddr(M, r, 0);
-    for (int k = 0; k < r; ++k) A[br + k] *= iv[k];
-  }
+  // (the factorised rows stay in the form U = L D: the only reader, the leaves' backward
+  // substitution, applies the inverse pivots on the fly -- no scaling pass over the panels)
   *bad = c.rmax(badl ? 1.0 : 0.0) > 0.0 ? 1 : 0;
   OMGX_TOC(PH_F_SCALE);
 }
@@ -905,9 +897,11 @@ OMGX_FN void trsv_fwd4(const C& c, const double* A, Addr L, int n, double* y) {
   }
 }
 
-// x <- L^{-T} y for the same storage (entry (i, j) of L, i > j, multiplies x_i into row j)
+// x <- L^{-T} y for the same storage (entry (i, j) of L, i > j, multiplies x_i into row j).  With
+// `iv` (inverse pivots) the storage holds U = L D instead of L (the leaf panels after ldl_left4):
+// L_ij = U_ij iv_j, applied on the fly.
 template <class C, class Addr>
-OMGX_FN void trsv_bwd4(const C& c, const double* A, Addr L, int n, double* y) {
+OMGX_FN void trsv_bwd4(const C& c, const double* A, Addr L, int n, double* y, const double* iv = nullptr) {
   const int lane = c.lane(), nln = c.nlanes();
   const int nblk = (n + 3) >> 2;
   for (int bk = nblk - 1; bk >= 0; --bk) {
@@ -916,14 +910,16 @@ OMGX_FN void trsv_bwd4(const C& c, const double* A, Addr L, int n, double* y) {
     const int q1 = nb > 1 ? 1 : 0, q2 = nb > 2 ? 2 : 0, q3 = nb > 3 ? 3 : 0;
     const double m1 = nb > 1 ? 1.0 : 0.0, m2 = nb > 2 ? 1.0 : 0.0, m3 = nb > 3 ? 1.0 : 0.0;
     const double r0 = y[jb], r1 = m1 * y[jb + q1], r2 = m2 * y[jb + q2], r3 = m3 * y[jb + q3];
-    const double l10 = m1 * A[L(jb + q1, jb)];
-    const double l20 = m2 * A[L(jb + q2, jb)], l21 = m2 * A[L(jb + q2, jb + (q2 ? 1 : 0))];
-    const double l30 = m3 * A[L(jb + q3, jb)], l31 = m3 * A[L(jb + q3, jb + (q3 ? 1 : 0))],
-                 l32 = m3 * A[L(jb + q3, jb + (q3 ? 2 : 0))];
+    const double s0 = iv ? iv[jb] : 1.0, s1 = iv ? iv[jb + q1] : 1.0, s2 = iv ? iv[jb + q2] : 1.0;
+    const double l10 = m1 * A[L(jb + q1, jb)] * s0;
+    const double l20 = m2 * A[L(jb + q2, jb)] * s0, l21 = m2 * A[L(jb + q2, jb + (q2 ? 1 : 0))] * s1;
+    const double l30 = m3 * A[L(jb + q3, jb)] * s0, l31 = m3 * A[L(jb + q3, jb + (q3 ? 1 : 0))] * s1,
+                 l32 = m3 * A[L(jb + q3, jb + (q3 ? 2 : 0))] * s2;
     const double x3 = r3, x2 = r2 - l32 * x3, x1 = r1 - l21 * x2 - l31 * x3, x0 = r0 - l10 * x1 - l20 * x2 - l30 * x3;
     for (int i = lane; i < jb + nb; i += nln) {
       if (i < jb) {
-        y[i] -= A[L(jb, i)] * x0 + m1 * A[L(jb + q1, i)] * x1 + m2 * A[L(jb + q2, i)] * x2 + m3 * A[L(jb + q3, i)] * x3;
+        const double si = iv ? iv[i] : 1.0;
+        y[i] -= si * (A[L(jb, i)] * x0 + m1 * A[L(jb + q1, i)] * x1 + m2 * A[L(jb + q2, i)] * x2 + m3 * A[L(jb + q3, i)] * x3);
       } else {
         const int q = i - jb;
         y[i] = q == 0 ? x0 : (q == 1 ? x1 : (q == 2 ? x2 : x3));
@@ -994,7 +990,7 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
     const BMat M = Ms[l];
     const int n = M.nfact, ld = M.ld, base = M.a;
     double* yl = sol + M.dinv;
-    trsv_bwd4(c, w.kkt, [=](int i, int j) { return base + i * ld + j; }, n, yl);
+    trsv_bwd4(c, w.kkt, [=](int i, int j) { return base + i * ld + j; }, n, yl, w.dinv + M.dinv);   // panels hold U = L D
   }
   c.sync();
   OMGX_TOC(PH_K_BWD);

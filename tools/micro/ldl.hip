@@ -66,8 +66,7 @@ int main() {
   }
   // compare the lower parts / carried rows and the inverse pivots
   double md = 0.0, mx = 0.0;
-  for (int l = 0; l < 4; ++l) for (int r = 0; r < 65; ++r) for (int k = 0; k < 36; ++k) {
-    if (r < 36 && k > r) continue;
+  for (int l = 0; l < 4; ++l) for (int r = 36; r < 65; ++r) for (int k = 0; k < 36; ++k) {      // carried rows (the factorised rows are L in one routine, U = L D in the other)
     const int i = l * 65 * 37 + r * 37 + k;
     md = fmax(md, fabs(res[0][i] - res[1][i])); mx = fmax(mx, fabs(res[0][i]));
   }
