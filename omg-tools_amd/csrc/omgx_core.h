@@ -49,11 +49,19 @@ struct Dims {
   int max_leaf, max_cpl;
   int col_doubles;   // scratch for the blocked LDL' (staging + panel buffers)
   int mono_packed;   // 1: every parameter monomial has <= 4 atoms, Tables::pm_rec is valid
+  int n_hess;        // number of HessRec records
 };
 
 // one parameter monomial coef * prod atoms[a_k] as a single 16-byte record (a_k = -1: unused): one
 // load per monomial instead of the pointer chase pm_ptr -> pm_atom -> atoms of the CSR form
 struct MonoRec { double coef; int16_t a0, a1, a2, a3; };
+
+// One polynomial term coef * slot * x_v0 x_v1 x_v2 as a single 40-byte record (v_k = -1: unused) with
+// its row and the Jacobian entries it feeds: one sequence of wide loads per term instead of nine
+// loads from five tables.  HessRec: the same for the terms with two or more variables (the only ones
+// the Lagrangian Hessian sees), with their KKT addresses and variable positions.
+struct TermRec { double coef; int32_t slot, row, j0, j1, j2; int16_t v0, v1, v2, pad; };
+struct HessRec { double coef; int32_t slot, row, ha0, ha1, ha2; int16_t v0, v1, v2, p0, p1, p2; };
 
 struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* prog; const double* knots;
@@ -73,6 +81,8 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* je_row; const int32_t* jt_addr; const int32_t* diag_addr;
   const int32_t* h_addr; const int32_t* t_row;
   const int32_t* t_pos;     // [n_terms][3] positions of the term's variables (-1: none)
+  const TermRec* trec;      // [n_terms] packed terms (rows 0..m-1 first, then the objective row m)
+  const HessRec* hrec;      // [n_hess] packed terms with >= 2 variables
   const double* reg_w;   // [N] position order: inertia-correction class (+1 nonlinear root variable, -1 nonlinear leaf variable, else the weight itself: OMGX_DW_LINEAR)
 };
 
@@ -386,6 +396,8 @@ OMGX_FN double term_coef(const Tables& T, const Work& w, int t) {
   const int sl = T.t_slot[t];
   return sl < 0 ? T.t_coef[t] : T.t_coef[t] * w.slots[sl];
 }
+
+OMGX_FN double rec_coef(const Work& w, double coef, int slot) { return slot < 0 ? coef : coef * w.slots[slot]; }
 
 // value of row r (unscaled) at the variable-order point xv
 OMGX_FN double row_value(const Tables& T, const Work& w, int r, const double* xv) {
@@ -1047,21 +1059,20 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   OMGX_PFOR(e, T.jr_ptr[m + 1]) w.jval[e] = 0.0;
   OMGX_PFOR(r, m) w.hv[r] = 0.0;
   c.sync();
-  OMGX_PFOR(tt, T.row_ptr[m]) {
-    const double cf = term_coef(T, w, tt);
-    const int32_t* tv = T.t_var + 3 * tt;
-    const int r = T.t_row[tt];
-    if (tv[0] < 0) { c.add(w.hv + r, cf); continue; }
-    const int32_t* je = T.t_jidx + 3 * tt;
-    const double x0v = w.x[tv[0]];
-    if (tv[1] < 0) { c.add(w.hv + r, cf * x0v); c.add(w.jval + je[0], cf); continue; }
-    const double x1v = w.x[tv[1]];
-    if (tv[2] < 0) {
-      c.add(w.hv + r, cf * x0v * x1v); c.add(w.jval + je[0], cf * x1v); c.add(w.jval + je[1], cf * x0v); continue;
+  OMGX_PFOR_U4(tt, T.row_ptr[m]) {
+    const TermRec q = T.trec[tt];
+    const double cf = rec_coef(w, q.coef, q.slot);
+    const int r = q.row;
+    if (q.v0 < 0) { c.add(w.hv + r, cf); continue; }
+    const double x0v = w.x[q.v0];
+    if (q.v1 < 0) { c.add(w.hv + r, cf * x0v); c.add(w.jval + q.j0, cf); continue; }
+    const double x1v = w.x[q.v1];
+    if (q.v2 < 0) {
+      c.add(w.hv + r, cf * x0v * x1v); c.add(w.jval + q.j0, cf * x1v); c.add(w.jval + q.j1, cf * x0v); continue;
     }
-    const double x2v = w.x[tv[2]];
+    const double x2v = w.x[q.v2];
     c.add(w.hv + r, cf * x0v * x1v * x2v);
-    c.add(w.jval + je[0], cf * x1v * x2v); c.add(w.jval + je[1], cf * x0v * x2v); c.add(w.jval + je[2], cf * x0v * x1v);
+    c.add(w.jval + q.j0, cf * x1v * x2v); c.add(w.jval + q.j1, cf * x0v * x2v); c.add(w.jval + q.j2, cf * x0v * x1v);
   }
   c.sync();
   OMGX_TOC(PH_S_JAC0);
@@ -1167,19 +1178,18 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     if (it > 0) {        // (iteration 0: left by the setup)
     OMGX_PFOR(e, T.jr_ptr[m + 1]) w.jval[e] = 0.0;
     c.sync();
-    OMGX_PFOR(tt, T.row_ptr[m + 1]) {
-      const int32_t* tv = T.t_var + 3 * tt;
-      if (tv[0] < 0) continue;
-      const int r = T.t_row[tt];
+    OMGX_PFOR_U4(tt, T.row_ptr[m + 1]) {
+      const TermRec q = T.trec[tt];
+      if (q.v0 < 0) continue;
+      const int r = q.row;
       const double sc = (r < m) ? ((w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r]) : 1.0;
       if (sc == 0.0) continue;
-      const double cf = sc * term_coef(T, w, tt);
-      const int32_t* je = T.t_jidx + 3 * tt;
-      if (tv[1] < 0) { c.add(w.jval + je[0], cf); continue; }
-      const double x0 = w.x[tv[0]], x1 = w.x[tv[1]];
-      if (tv[2] < 0) { c.add(w.jval + je[0], cf * x1); c.add(w.jval + je[1], cf * x0); continue; }
-      const double x2 = w.x[tv[2]];
-      c.add(w.jval + je[0], cf * x1 * x2); c.add(w.jval + je[1], cf * x0 * x2); c.add(w.jval + je[2], cf * x0 * x1);
+      const double cf = sc * rec_coef(w, q.coef, q.slot);
+      if (q.v1 < 0) { c.add(w.jval + q.j0, cf); continue; }
+      const double x0 = w.x[q.v0], x1 = w.x[q.v1];
+      if (q.v2 < 0) { c.add(w.jval + q.j0, cf * x1); c.add(w.jval + q.j1, cf * x0); continue; }
+      const double x2 = w.x[q.v2];
+      c.add(w.jval + q.j0, cf * x1 * x2); c.add(w.jval + q.j1, cf * x0 * x2); c.add(w.jval + q.j2, cf * x0 * x1);
     }
     c.sync();
     }
@@ -1336,36 +1346,32 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         Rr[tri(d.n_root + k, d.n_root + k)] = -OMGX_DELTA_C;
       }
       // Lagrangian Hessian: terms with >= 2 variables, weight = multiplier * signed scale
-      OMGX_PFOR(tt, T.row_ptr[m + 1]) {                       // row m = objective (weight 1)
-        const int32_t* tv = T.t_var + 3 * tt;
-        if (tv[1] < 0) continue;
-        const int r = T.t_row[tt];
+      OMGX_PFOR_U4(i, d.n_hess) {                              // (row m = objective: weight 1)
+        const HessRec q = T.hrec[i];
+        const int r = q.row;
         if (r < m && w.rtype[r] == ROW_FREE) continue;
         const double lam = (r < m) ? w.z[r] * w.rho[r] : 1.0;
         if (lam == 0.0) continue;
-        const double cf = lam * term_coef(T, w, tt);
-        const int32_t* ha = T.h_addr + 3 * tt;
-        if (tv[2] < 0) {
-          c.add(w.kkt + ha[0], tv[0] == tv[1] ? 2.0 * cf : cf);
+        const double cf = lam * rec_coef(w, q.coef, q.slot);
+        if (q.v2 < 0) {
+          c.add(w.kkt + q.ha0, q.v0 == q.v1 ? 2.0 * cf : cf);
           if (first_trial) {
-            const int32_t* tp = T.t_pos + 3 * tt;
-            if (tv[0] == tv[1]) { if (cf < 0.0) c.add(w.xt + tp[0], -2.0 * cf); }
-            else { c.add(w.xt + tp[0], fabs(cf)); c.add(w.xt + tp[1], fabs(cf)); }
+            if (q.v0 == q.v1) { if (cf < 0.0) c.add(w.xt + q.p0, -2.0 * cf); }
+            else { c.add(w.xt + q.p0, fabs(cf)); c.add(w.xt + q.p1, fabs(cf)); }
           }
         } else {
-          const double x0v = w.x[tv[0]], x1v = w.x[tv[1]], x2v = w.x[tv[2]];
-          c.add(w.kkt + ha[0], (tv[0] == tv[1] ? 2.0 : 1.0) * cf * x2v);   // pair (0,1)
-          c.add(w.kkt + ha[1], (tv[0] == tv[2] ? 2.0 : 1.0) * cf * x1v);   // pair (0,2)
-          c.add(w.kkt + ha[2], (tv[1] == tv[2] ? 2.0 : 1.0) * cf * x0v);   // pair (1,2)
+          const double x0v = w.x[q.v0], x1v = w.x[q.v1], x2v = w.x[q.v2];
+          c.add(w.kkt + q.ha0, (q.v0 == q.v1 ? 2.0 : 1.0) * cf * x2v);   // pair (0,1)
+          c.add(w.kkt + q.ha1, (q.v0 == q.v2 ? 2.0 : 1.0) * cf * x1v);   // pair (0,2)
+          c.add(w.kkt + q.ha2, (q.v1 == q.v2 ? 2.0 : 1.0) * cf * x0v);   // pair (1,2)
           if (first_trial) {
-            const int32_t* tp = T.t_pos + 3 * tt;
             const double h01 = cf * x2v, h02 = cf * x1v, h12 = cf * x0v;
-            if (tv[0] == tv[1]) { if (h01 < 0.0) c.add(w.xt + tp[0], -2.0 * h01); }
-            else { c.add(w.xt + tp[0], fabs(h01)); c.add(w.xt + tp[1], fabs(h01)); }
-            if (tv[0] == tv[2]) { if (h02 < 0.0) c.add(w.xt + tp[0], -2.0 * h02); }
-            else { c.add(w.xt + tp[0], fabs(h02)); c.add(w.xt + tp[2], fabs(h02)); }
-            if (tv[1] == tv[2]) { if (h12 < 0.0) c.add(w.xt + tp[1], -2.0 * h12); }
-            else { c.add(w.xt + tp[1], fabs(h12)); c.add(w.xt + tp[2], fabs(h12)); }
+            if (q.v0 == q.v1) { if (h01 < 0.0) c.add(w.xt + q.p0, -2.0 * h01); }
+            else { c.add(w.xt + q.p0, fabs(h01)); c.add(w.xt + q.p1, fabs(h01)); }
+            if (q.v0 == q.v2) { if (h02 < 0.0) c.add(w.xt + q.p0, -2.0 * h02); }
+            else { c.add(w.xt + q.p0, fabs(h02)); c.add(w.xt + q.p2, fabs(h02)); }
+            if (q.v1 == q.v2) { if (h12 < 0.0) c.add(w.xt + q.p1, -2.0 * h12); }
+            else { c.add(w.xt + q.p1, fabs(h12)); c.add(w.xt + q.p2, fabs(h12)); }
           }
         }
       }
@@ -1461,11 +1467,11 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       // row values at the trial point: one thread per term, LDS atomics into ht
       OMGX_PFOR(r, m) w.ht[r] = 0.0;
       c.sync();
-      OMGX_PFOR(q, T.row_ptr[m]) {
-        double v = term_coef(T, w, q);
-        const int32_t* tv = T.t_var + 3 * q;
-        if (tv[0] >= 0) { v *= w.xt[tv[0]]; if (tv[1] >= 0) { v *= w.xt[tv[1]]; if (tv[2] >= 0) v *= w.xt[tv[2]]; } }
-        c.add(w.ht + T.t_row[q], v);
+      OMGX_PFOR_U4(tq, T.row_ptr[m]) {
+        const TermRec q = T.trec[tq];
+        double v = rec_coef(w, q.coef, q.slot);
+        if (q.v0 >= 0) { v *= w.xt[q.v0]; if (q.v1 >= 0) { v *= w.xt[q.v1]; if (q.v2 >= 0) v *= w.xt[q.v2]; } }
+        c.add(w.ht + q.row, v);
       }
       c.sync();
       OMGX_TOC(PH_L_TERMS);

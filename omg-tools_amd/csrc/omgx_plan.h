@@ -16,6 +16,8 @@ struct HostPlan {
   std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, h_addr, t_row, t_pos;
   std::vector<double> reg_w;
   std::vector<MonoRec> pm_rec;
+  std::vector<TermRec> trec;
+  std::vector<HessRec> hrec;
 
   bool build(const omgx_template& t) {
     Dims& d = dims;
@@ -139,6 +141,29 @@ struct HostPlan {
           h_addr[3 * tt + k] = ad;
         }
       }
+    // packed term records
+    if (d.n_var >= 32767) return false;
+    trec.assign(d.n_terms > 0 ? d.n_terms : 1, TermRec{0.0, -1, 0, 0, 0, 0, -1, -1, -1, 0});
+    hrec.clear();
+    for (int tt = 0; tt < d.n_terms; ++tt) {
+      const int32_t* tv = t.t_var + 3 * tt;
+      const int32_t* je = t.t_jidx + 3 * tt;
+      TermRec& q = trec[tt];
+      q.coef = t.t_coef[tt]; q.slot = t.t_slot[tt]; q.row = t_row[tt];
+      q.j0 = je[0] < 0 ? 0 : je[0]; q.j1 = je[1] < 0 ? 0 : je[1]; q.j2 = je[2] < 0 ? 0 : je[2];
+      q.v0 = (int16_t)tv[0]; q.v1 = (int16_t)tv[1]; q.v2 = (int16_t)tv[2];
+      if (tv[1] >= 0) {
+        HessRec h;
+        h.coef = q.coef; h.slot = q.slot; h.row = q.row;
+        h.ha0 = h_addr[3 * tt]; h.ha1 = h_addr[3 * tt + 1]; h.ha2 = h_addr[3 * tt + 2];
+        h.v0 = q.v0; h.v1 = q.v1; h.v2 = q.v2;
+        h.p0 = (int16_t)t_pos[3 * tt]; h.p1 = (int16_t)t_pos[3 * tt + 1]; h.p2 = (int16_t)(tv[2] >= 0 ? t_pos[3 * tt + 2] : 0);
+        hrec.push_back(h);
+      }
+    }
+    d.n_hess = (int)hrec.size();
+    if (hrec.empty()) hrec.push_back(HessRec{0.0, -1, 0, 0, 0, 0, -1, -1, -1, 0, 0, 0});
+    T.trec = trec.data(); T.hrec = hrec.data();
     T.pair4 = pair4.data(); T.eqe3 = eqe3.data();
     T.je_row = je_row.data(); T.jt_addr = jt_addr.data(); T.diag_addr = diag_addr.data();
     T.h_addr = h_addr.data(); T.t_row = t_row.data(); T.t_pos = t_pos.data(); T.pm_rec = pm_rec.data();
