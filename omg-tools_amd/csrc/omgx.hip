@@ -471,7 +471,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   UP(pair4, plan.pair4.size()); UP(eqe3, plan.eqe3.size());
   UP(je_row, plan.je_row.size()); UP(jt_addr, plan.jt_addr.size()); UP(diag_addr, d.N);
   UP(h_addr, plan.h_addr.size()); UP(t_row, plan.t_row.size()); UP(t_pos, plan.t_pos.size()); UP(reg_w, d.N);
-  UP(trec, plan.trec.size()); UP(hrec, plan.hrec.size());
+  UP(trec, plan.trec.size()); UP(hrec, plan.hrec.size()); UP(je_rp, plan.je_rp.size());
   return OMGX_OK;
 }
 

@@ -50,6 +50,8 @@ struct Dims {
   int col_doubles;   // scratch for the blocked LDL' (staging + panel buffers)
   int mono_packed;   // 1: every parameter monomial has <= 4 atoms, Tables::pm_rec is valid
   int n_hess;        // number of HessRec records
+  int rp_packed;     // 1: rows and positions fit 16 bits each, Tables::je_rp is valid
+  int n_knots;       // total length of the knot vectors of the atoms program (copied to LDS per solve)
 };
 
 // one parameter monomial coef * prod atoms[a_k] as a single 16-byte record (a_k = -1: unused): one
@@ -81,6 +83,7 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* je_row; const int32_t* jt_addr; const int32_t* diag_addr;
   const int32_t* h_addr; const int32_t* t_row;
   const int32_t* t_pos;     // [n_terms][3] positions of the term's variables (-1: none)
+  const int32_t* je_rp;     // [nnz_j] (row << 16) | position of every Jacobian entry (valid if Dims::rp_packed)
   const TermRec* trec;      // [n_terms] packed terms (rows 0..m-1 first, then the objective row m)
   const HessRec* hrec;      // [n_hess] packed terms with >= 2 variables
   const double* reg_w;   // [N] position order: inertia-correction class (+1 nonlinear root variable, -1 nonlinear leaf variable, else the weight itself: OMGX_DW_LINEAR)
@@ -125,7 +128,7 @@ struct Opts {
 
 // Per-agent work arrays (LDS on the device, heap on the host port).
 struct Work {
-  double *atoms, *slots;
+  double *atoms, *slots, *knots;
   double *x, *xt;                 // [N] variable order, x[n_var] = t
   double *hv, *ht;                // [n_con] scaled row values (h for inequality, c for equality)
   double *bnd, *rho, *vv;         // [n_con] scaled bound, row scale (signed), phase-I weights
@@ -148,7 +151,7 @@ enum { WS_LDS = 0, WS_KKT_HBM = 1, WS_JAC_HBM = 2, WS_ROWS_HBM = 3, WS_MODES = 4
 
 OMGX_HD void work_split(const Dims& d, int kkt_doubles, int mode, size_t* lds, size_t* hbm) {
   size_t nl = 0, ng = 0;
-  nl += d.n_atoms + d.n_slots;
+  nl += d.n_atoms + d.n_slots + d.n_knots;
   nl += 2 * (size_t)d.N;
   nl += d.N + (d.N + d.n_eq);
   nl += d.N;                      // dinv
@@ -171,7 +174,7 @@ template <int MODE>
 OMGX_HD void work_carve_split(Work& w, double* lds, double* hbm, const Dims& d, int kkt_doubles) {
   double* p = lds;
   double* g = hbm;
-  w.atoms = p; p += d.n_atoms;   w.slots = p; p += d.n_slots;
+  w.atoms = p; p += d.n_atoms;   w.slots = p; p += d.n_slots;   w.knots = p; p += d.n_knots;
   w.x = p; p += d.N;             w.xt = p; p += d.N;
   w.gbar = p; p += d.N;          w.sol = p; p += d.N + d.n_eq;
   w.dinv = p; p += d.N;
@@ -364,6 +367,7 @@ OMGX_FN double bspl_entry(const double* k, int deg, double u, int i) {
 template <class C>
 OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, const double* p) {
   OMGX_PFOR(i, d.n_par) w.atoms[i] = p[i];
+  OMGX_PFOR(i, d.n_knots) w.knots[i] = T.knots[i];     // the Cox-de Boor triangles read them dozens of times
   c.sync();
   for (int k = 0; k < d.n_prog;) {              // ops in order (an op may read atoms of earlier ones)
     const int32_t* op = T.prog + 6 * k;
@@ -381,7 +385,7 @@ OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, co
         int kk = k, i = it;
         for (;; ++kk) { const int nout = T.prog[6 * kk + 2] - T.prog[6 * kk + 3] - 1; if (i < nout) break; i -= nout; }
         const int32_t* oq = T.prog + 6 * kk;
-        w.atoms[oq[5] + i] = bspl_entry(T.knots + oq[1], oq[3], w.atoms[oq[4]], i);
+        w.atoms[oq[5] + i] = bspl_entry(w.knots + oq[1], oq[3], w.atoms[oq[4]], i);
       }
       k = k2;
     }
@@ -1199,8 +1203,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     // barrier gradient grad f + mu J'(1/s) is formed once mu is settled below
     OMGX_PFOR(q, N) { w.sol[q] = 0.0; w.gbar[q] = 0.0; w.xt[q] = 0.0; }
     c.sync();
-    OMGX_PFOR(e, T.jr_ptr[m + 1]) {
-      const int r = T.je_row[e], q = T.jr_pos[e];
+    OMGX_PFOR_U4(e, T.jr_ptr[m + 1]) {
+      int r, q;
+      if (d.rp_packed) { const int32_t rp = T.je_rp[e]; r = (int)((uint32_t)rp >> 16); q = rp & 0xffff; }
+      else { r = T.je_row[e]; q = T.jr_pos[e]; }
       const double jv = w.jval[e];
       if (jv == 0.0) continue;
       if (r == m) { c.add(w.sol + q, jv); c.add(w.gbar + q, jv); }
@@ -1427,6 +1433,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     OMGX_PFOR(r, m) {
       const int ty = w.rtype[r];
       if (ty == ROW_UPPER || ty == ROW_LOWER) {
+        // (measured: spreading J dx over the entries with LDS atomics is slower than one thread per row)
         double jd = 0.0;
         for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) jd += w.jval[e] * w.sol[T.jr_pos[e]];
         const double dsr = -(jd - w.vv[r] * dt);

@@ -16,6 +16,7 @@ struct HostPlan {
   std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, h_addr, t_row, t_pos;
   std::vector<double> reg_w;
   std::vector<MonoRec> pm_rec;
+  std::vector<int32_t> je_rp;
   std::vector<TermRec> trec;
   std::vector<HessRec> hrec;
 
@@ -24,7 +25,7 @@ struct HostPlan {
     d.n_var = t.n_var; d.n_par = t.n_par; d.n_con = t.n_con; d.n_atoms = t.n_atoms;
     d.n_slots = t.n_slots; d.n_terms = t.n_terms; d.n_prog = t.n_prog;
     d.N = t.n_var + 1; d.n_leaf = t.n_leaf; d.n_root = t.n_root; d.n_eq = t.n_eq;
-    d.nnz_j = t.nnz_j; d.root_off = t.leaf_off[t.n_leaf]; d.nr = t.n_root + t.n_eq;
+    d.nnz_j = t.nnz_j; d.root_off = t.leaf_off[t.n_leaf]; d.nr = t.n_root + t.n_eq; d.n_knots = t.n_knots;
     if (d.root_off + d.n_root != d.N) return false;
     for (int k = 0; k < d.n_prog; ++k)                          // bspl_entry holds a triangle of degree <= 5
       if (t.prog[6 * k] == OP_BSPL && (t.prog[6 * k + 3] < 0 || t.prog[6 * k + 3] > 5)) return false;
@@ -141,6 +142,12 @@ struct HostPlan {
           h_addr[3 * tt + k] = ad;
         }
       }
+    // packed (row, position) of the Jacobian entries
+    d.rp_packed = (m < 65535 && d.N < 65536) ? 1 : 0;
+    je_rp.assign(d.nnz_j > 0 ? d.nnz_j : 1, 0);
+    if (d.rp_packed)
+      for (int e = 0; e < d.nnz_j; ++e) je_rp[e] = (int32_t)(((uint32_t)je_row[e] << 16) | (uint32_t)t.jr_pos[e]);
+    T.je_rp = je_rp.data();
     // packed term records
     if (d.n_var >= 32767) return false;
     trec.assign(d.n_terms > 0 ? d.n_terms : 1, TermRec{0.0, -1, 0, 0, 0, 0, -1, -1, -1, 0});
