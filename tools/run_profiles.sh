@@ -10,3 +10,8 @@ python bench.py --workload formation --no-cpu > gpurun_out/bench_formation.json 
 python bench.py --workload quadrotor --agents 1024 --steps 2 --warmup 1 --no-cpu > gpurun_out/bench_quadrotor.json 2> gpurun_out/bench_quadrotor.err
 python bench.py --workload holonomic3d --agents 1024 --steps 2 --warmup 1 --no-cpu > gpurun_out/bench_holonomic3d.json 2> gpurun_out/bench_holonomic3d.err
 ls -R gpurun_out/prof | head -40
+python tools/phase_profile.py 1024 > gpurun_out/phase_cold_final.json 2> gpurun_out/phase_final.err
+python tools/phase_profile.py 1024 warm > gpurun_out/phase_warm_final.json 2>> gpurun_out/phase_final.err
+./tools/micro/lat > gpurun_out/micro_latency.txt 2>&1
+./tools/micro/ldl > gpurun_out/micro_ldl.txt 2>&1
+python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
