@@ -11,11 +11,11 @@ from .shapes import (Circle, Polyhedron, RegularPolyhedron, Rectangle, Square, S
 from .splines import BSplineBasis, BSpline
 from .vehicles import Vehicle, Holonomic, Holonomic3D, Quadrotor, Fleet
 from .environment import Environment, Obstacle
-from .problems import Problem, Point2point, FixedTPoint2point, FreeTPoint2point
+from .problems import Problem, Point2point, FixedTPoint2point, FreeTPoint2point, FreeEndPoint2point
 from .execution import Simulator, Deployer
 from .formation import FormationPoint2point
 
 __all__ = ['np', 'RegularPrisma', 'Circle', 'Polyhedron', 'RegularPolyhedron', 'Rectangle', 'Square', 'Sphere', 'Polyhedron3D',
            'Cuboid', 'Cube', 'Plate', 'BSplineBasis', 'BSpline', 'Vehicle', 'Holonomic',
            'Holonomic3D', 'Quadrotor', 'Fleet', 'Environment', 'Obstacle', 'Problem',
-           'Point2point', 'FixedTPoint2point', 'FreeTPoint2point', 'FormationPoint2point', 'Simulator', 'Deployer']
+           'Point2point', 'FixedTPoint2point', 'FreeTPoint2point', 'FreeEndPoint2point', 'FormationPoint2point', 'Simulator', 'Deployer']

@@ -352,6 +352,49 @@ class FixedTPoint2point(Point2pointProblem):
         return self.objective
 
 
+class FreeEndPoint2point(FixedTPoint2point):
+    """Fixed horizon, free end point (`problems/point2point.py:376-418`): the terminal conditions
+    listed in `free_ind[vehicle]` become the variable `conT<l>`; the building block of the
+    reference's RendezVous problem (`problems/rendezvous.py:29-35`)."""
+
+    def __init__(self, fleet, environment, options, free_ind=None):
+        FixedTPoint2point.__init__(self, fleet, environment, options)
+        self.free_ind = free_ind
+
+    def construct(self):
+        if self.free_ind is None:
+            self.free_ind = {}
+            for vehicle in self.vehicles:
+                term_con = vehicle.get_terminal_constraints(vehicle.splines[0])
+                self.free_ind[vehicle] = list(range(len(term_con)))
+        FixedTPoint2point.construct(self)
+
+    def define_terminal_constraints(self):
+        objective = 0.
+        self.term_con_len = []
+        for l, vehicle in enumerate(self.vehicles):
+            term_con, term_con_der = vehicle.get_terminal_constraints(vehicle.splines[0])
+            conditions = np.atleast_1d(self.define_variable('conT' + str(l), len(self.free_ind[vehicle])))
+            cnt = 0
+            self.term_con_len.append(len(term_con))
+            for k, con in enumerate(term_con):
+                if k in self.free_ind[vehicle]:
+                    spline, condition = con[0], conditions[cnt]
+                    cnt += 1
+                else:
+                    spline, condition = con[0], con[1]
+                g = self.define_spline_variable('g' + str(k), 1, basis=spline.basis)[0]
+                objective = objective + definite_integral(g, self.t0, 1.)
+                self.define_constraint(spline - condition - g, -inf, 0.)
+                self.define_constraint(-spline + condition - g, -inf, 0.)
+            # as in the reference (`point2point.py:416-417`): the loop over the derivative conditions
+            # re-uses `spline, condition` of the last position condition, i.e. it pins the end point of
+            # the LAST position spline len(term_con_der) times -- kept, the NLP has to be the same
+            for con in term_con_der:
+                self.define_constraint(spline(1.) - condition, 0., 0.)
+        self.define_objective(objective)
+
+
 class FreeTPoint2point(Point2pointProblem):
     """Free end time (`point2point.py:269-369`): the motion time T is a variable and the
     objective; hard terminal constraints; after every update the spline is re-expressed on the

@@ -200,6 +200,18 @@ def main():
     problem.init()
     dump(problem, 'interveh_holonomic', rng)
 
+    # free end point (`point2point.py:376-418`, the sub-problem of RendezVous): the x target is the
+    # variable conT0, the y target stays a parameter
+    FreeEnd = m['problems.point2point'].FreeEndPoint2point
+    vehicle = Holonomic()
+    vehicle.set_initial_conditions([-1.5, -1.5])
+    vehicle.set_terminal_conditions([2., 2.])
+    environment = Environment(room={'shape': sh.Square(5.)})
+    environment.add_obstacle(Obstacle({'position': [0.2, -0.4]}, shape=sh.Circle(0.4)))
+    problem = FreeEnd(vehicle, environment, quiet, {vehicle: [0]})
+    problem.init()
+    dump(problem, 'freeend_holonomic', rng)
+
     # spline known-answer matrices straight from the reference's spline algebra
     rs, rx = m['basics.spline'], m['basics.spline_extra']
     kats = {}

@@ -127,3 +127,35 @@ def test_intervehicle_avoidance_example():
     """Two vehicles in ONE problem with separating hyperplanes between them (`environment.py:148-176`);
     the NLP is pinned against the reference in tests/test_golden_nlp.py (interveh_holonomic)."""
     check_interveh_run(_interveh_run())
+
+
+def _free_end_solve():
+    """`FreeEndPoint2point` (`point2point.py:376-418`) with a free x target: the plan keeps x and
+    moves y to the target (the NLP is pinned in tests/test_golden_nlp.py: freeend_holonomic)."""
+    from omgtools import Holonomic, Environment, Obstacle, Circle, Square, FreeEndPoint2point
+    vehicle = Holonomic()
+    vehicle.set_initial_conditions([-1.5, -1.5])
+    vehicle.set_terminal_conditions([2., 2.])
+    environment = Environment(room={'shape': Square(5.)})
+    environment.add_obstacle(Obstacle({'position': [0.2, -0.4]}, shape=Circle(0.4)))
+    problem = FreeEndPoint2point(vehicle, environment, {'verbose': 0}, {vehicle: [0]})
+    problem.init()
+    problem.reinitialize()
+    problem.solve(0., 0.1)
+    return problem, vehicle
+
+
+def check_free_end(problem, vehicle):
+    assert problem.problem.stats()['return_status'] == 'Solve_Succeeded'
+    tpl = problem.father.template
+    x = problem.father.get_variables().cat
+    lo, hi = tpl.entry_range(problem.label, 'conT0', 'var')
+    conT = x[lo:hi]
+    lo, hi = tpl.entry_range(vehicle.label, 'splines_seg0', 'var')
+    c = x[lo:hi].reshape(2, -1)
+    assert abs(conT[0] + 1.5) < 1e-2                      # the free x target settles at the start
+    assert abs(c[0, -1] - conT[0]) < 1e-2 and abs(c[1, -1] - 2.) < 1e-6   # end point: (conT, fixed y target)
+
+
+def test_free_end_point2point_solves():
+    check_free_end(*_free_end_solve())

@@ -97,12 +97,20 @@ def build(tag):
         environment.add_obstacle(Obstacle({'position': [0.1, 0.9]}, shape=Circle(0.3)))
         problem = Point2point(vehicles, environment, options=quiet, freeT=False)
         problem.set_options({'inter_vehicle_avoidance': True})
+    elif tag == 'freeend_holonomic':
+        from omgtools import FreeEndPoint2point
+        vehicle = Holonomic()
+        vehicle.set_initial_conditions([-1.5, -1.5])
+        vehicle.set_terminal_conditions([2., 2.])
+        environment = Environment(room={'shape': Square(5.)})
+        environment.add_obstacle(Obstacle({'position': [0.2, -0.4]}, shape=Circle(0.4)))
+        problem = FreeEndPoint2point(vehicle, environment, quiet, {vehicle: [0]})
     problem.init()
     return problem
 
 
 TAGS = ['cfg1_p2p_holonomic', 'cfg2_holonomic_k11_o3', 'holonomic_rectangles',
-        'holonomic3d_spheres', 'quadrotor_k13_o2', 'freeT_holonomic', 'interveh_holonomic']
+        'holonomic3d_spheres', 'quadrotor_k13_o2', 'freeT_holonomic', 'interveh_holonomic', 'freeend_holonomic']
 
 
 @pytest.mark.parametrize('tag', TAGS)

@@ -65,3 +65,9 @@ def test_intervehicle_avoidance_example_runs_to_target():
     """`examples/p2p_holonomic_interveh_avoidance.py` on the HIP path."""
     from test_examples_cpu import _interveh_run, check_interveh_run
     check_interveh_run(_interveh_run())
+
+
+def test_free_end_point2point_solves_on_hip():
+    """`FreeEndPoint2point` (duplicate terminal equality rows of the reference included) on the HIP path."""
+    from test_examples_cpu import _free_end_solve, check_free_end
+    check_free_end(*_free_end_solve())
