@@ -1049,11 +1049,15 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   kkt_describe(c, d, K, w);
   OMGX_TOC(PH_S_DESC);
 
+  // the per-agent inputs come from HBM (~1 us each if loaded where they are first needed): all of
+  // them are requested here, so that their latencies overlap with each other and with the parameter
+  // stage (p is loaded by eval_params; the multipliers wait in w.ds, which is free until the assembly)
+  const bool warm_in = o.warm_start && prev_status == 0;
+  OMGX_PFOR(i, n) w.x[i] = x0[i];
+  if (warm_in) { OMGX_PFOR(r, m) w.ds[r] = lam0[r]; }
+  if (c.tid() == 0) w.x[n] = 1.0;
   eval_params(c, d, T, w, p);
   OMGX_TOC(PH_S_PARAMS);
-  OMGX_PFOR(i, n) w.x[i] = x0[i];
-  if (c.tid() == 0) w.x[n] = 1.0;
-  c.sync();
 
   // ---- row classification, gradient-based scaling, phase-I weights -----------
   // warm start only from a converged previous solve; otherwise a cold start from x0
@@ -1143,10 +1147,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     OMGX_PFOR(r, m) {
       const int ty = w.rtype[r];
       if (ty == ROW_UPPER || ty == ROW_LOWER) {
-        w.z[r] = fmax(lam0[r] / w.rho[r], OMGX_WARM_ZMIN);
+        w.z[r] = fmax(w.ds[r] / w.rho[r], OMGX_WARM_ZMIN);
         sz += w.s[r] * w.z[r]; cnt0 += 1.0;
       } else if (ty == ROW_EQ) {
-        w.z[r] = lam0[r] / w.rho[r];
+        w.z[r] = w.ds[r] / w.rho[r];
       }
     }
     { double rv[2] = {sz, cnt0}; c.template reduce_ops<0, 0>(rv); sz = rv[0]; cnt0 = rv[1]; }
