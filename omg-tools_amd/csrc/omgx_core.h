@@ -637,6 +637,122 @@ OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* di
   OMGX_TOC(PH_F_SCALE);
 }
 
+#ifndef OMGX_HOST_PORT
+// ---------------------------------------------------------------------------
+// Cooperative form of ldl_left4 for the case that the workgroup has a spare wave per matrix (config 2:
+// 4 leaves, 256 rows = 4 row waves + 4 block waves).  In ldl_left4 every row recomputes the 4x4
+// diagonal block (14 of the 21 fp64 operations per row and finished column) because handing it over
+// would cost a barrier -- but a barrier costs 15 cycles here, the redundant arithmetic thousands.  So:
+//   block wave of matrix l:  S = U_blk diag(1/d) U_blk' over the finished columns on the matrix pipe
+//                            (one v_mfma_f64_16x16x4 per 4 columns), G = A_blk - S, 4x4 LDL' of G,
+//                            result (14 doubles) and the new inverse pivots to LDS;
+//   row waves, meanwhile:    v_rq = a_rq - sum_k U_rk (U_{jb+q,k} / d_k), 8 operations per column;
+//   barrier; every row reads the block factor and finishes its four entries; barrier.
+// Same storage convention and (up to summation order) the same numbers as ldl_left4.
+// ---------------------------------------------------------------------------
+template <class C>
+OMGX_FN void ldl_left4_coop(const C& c, const BMat* Ms, int nm, double* A, double* dinvb, double* colb, int* bad,
+                            int total_rows, int nmax) {
+  const int lane = c.lane(), wave = c.wave();
+  const int row_waves = (total_rows + 63) >> 6;
+  const bool is_row = c.tid() < total_rows;
+  const bool is_blk = wave >= row_waves && wave < row_waves + nm;
+  int r = c.tid();
+  BMat M = Ms[0];
+  if (is_row) { int mi = 0; while (r >= Ms[mi].rows) { r -= Ms[mi].rows; ++mi; } M = Ms[mi]; }
+  else if (is_blk) { M = Ms[wave - row_waves]; r = -1; }
+  double* iv = (M.dinv >= 0) ? dinvb + M.dinv : colb + M.pan;          // inverse pivots of this matrix
+  double* gb = colb + M.pan + M.nfact;                                // [16] G staging, [16..30) block factor
+  double* bb = gb + 16;
+  const int br = baddr(M, r > 0 ? r : 0, 0);
+  int badl = 0;
+  for (int jb = 0; jb < nmax; jb += OMGX_NB) {
+    const bool live = (is_row || is_blk) && jb < M.nfact;
+    const int nb = (M.nfact - jb) < OMGX_NB ? (M.nfact - jb) : OMGX_NB;
+    const int q1 = nb > 1 ? 1 : 0, q2 = nb > 2 ? 2 : 0, q3 = nb > 3 ? 3 : 0;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    if (live && is_blk) {
+      // ---- block wave: G = A_blk - U_blk diag(1/d) U_blk' ---------------------------------
+      const int a = lane & 15, kq = lane >> 4;
+      const bool in_blk = a < nb;
+      const int ra = baddr(M, jb + (in_blk ? a : 0), 0);
+      typedef double v4d __attribute__((ext_vector_type(4)));
+      v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+      int k0 = 0;
+      for (; k0 + 8 <= jb; k0 += 8) {
+        const double u_a = A[ra + k0 + kq], t_a = iv[k0 + kq], u_b = A[ra + k0 + 4 + kq], t_b = iv[k0 + 4 + kq];
+        const double ua = in_blk ? u_a : 0.0, ub = in_blk ? u_b : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ua * t_a, ua, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ub * t_b, ub, acc2, 0, 0, 0);
+      }
+      for (; k0 < jb; k0 += 4) {
+        const double u_a = A[ra + k0 + kq], t_a = iv[k0 + kq];
+        const double ua = in_blk ? u_a : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ua * t_a, ua, acc, 0, 0, 0);
+      }
+      acc += acc2;
+      // acc[0] of lane (row = lane >> 4, col = lane & 15) is S[row][col], rows and columns 0..3
+      {
+        const int gr = lane >> 4, gc = lane & 15;
+        if (gc <= gr) {                                           // lower part (gr < 4 always)
+          const bool ok = gr < nb && gc < nb;
+          const double orig = A[baddr(M, jb + (ok ? gr : 0), jb + (ok ? gc : 0))];
+          gb[gr * 4 + gc] = ok ? orig - acc[0] : (gr == gc ? 1.0 : 0.0);
+        }
+      }
+      c.wave_sync();
+      const Blk4 B = blk4_from(gb[0], gb[4], gb[5], gb[8], gb[9], gb[10], gb[12], gb[13], gb[14], gb[15]);
+      if (lane == 0) {
+        bb[0] = B.l10; bb[1] = B.l20; bb[2] = B.l21; bb[3] = B.l30; bb[4] = B.l31; bb[5] = B.l32;
+        bb[6] = B.d0; bb[7] = B.d1; bb[8] = B.d2; bb[9] = B.d3;
+      }
+      if (lane < nb) {
+        const double dq = lane == 0 ? B.d0 : (lane == 1 ? B.d1 : (lane == 2 ? B.d2 : B.d3));
+        const double iq = lane == 0 ? B.i0 : (lane == 1 ? B.i1 : (lane == 2 ? B.i2 : B.i3));
+        const bool pos_ok = (jb + lane < M.npos) ? (dq > 0.0) : (dq < 0.0);
+        if (!pos_ok) badl = 1;
+        bb[10 + lane] = iq;                                       // published to iv after the barrier
+      }
+    } else if (live && r >= jb + nb) {
+      // ---- row waves: the four entries of this row against the finished columns ------------
+      const int b0 = baddr(M, jb, 0), b1 = baddr(M, jb + q1, 0), b2 = baddr(M, jb + q2, 0), b3 = baddr(M, jb + q3, 0);
+      v0 = A[br + jb]; v1 = A[br + jb + q1]; v2 = A[br + jb + q2]; v3 = A[br + jb + q3];
+#pragma unroll 4
+      for (int k = 0; k < jb; ++k) {
+        const double tk = iv[k], ur = A[br + k];
+        const double w = ur * tk;
+        v0 -= w * A[b0 + k]; v1 -= w * A[b1 + k]; v2 -= w * A[b2 + k]; v3 -= w * A[b3 + k];
+      }
+    }
+    c.sync();
+    if (live && is_row && r >= jb) {
+      const double l10 = bb[0], l20 = bb[1], l21 = bb[2], l30 = bb[3], l31 = bb[4], l32 = bb[5];
+      const double d0 = bb[6], d1 = bb[7], d2 = bb[8], d3 = bb[9];
+      if (r < jb + nb) {
+        const int q = r - jb;
+        iv[jb + q] = bb[10 + q];
+        // U = L D inside the block, the pivot itself on the diagonal
+        if (q == 1) { A[br + jb] = l10 * d0; }
+        else if (q == 2) { A[br + jb] = l20 * d0; A[br + jb + 1] = l21 * d1; }
+        else if (q == 3) { A[br + jb] = l30 * d0; A[br + jb + 1] = l31 * d1; A[br + jb + 2] = l32 * d2; }
+        A[br + jb + q] = q == 0 ? d0 : (q == 1 ? d1 : (q == 2 ? d2 : d3));
+      } else {
+        const double u0 = v0;
+        const double u1 = v1 - u0 * l10;
+        const double u2 = v2 - u0 * l20 - u1 * l21;
+        const double u3 = v3 - u0 * l30 - u1 * l31 - u2 * l32;
+        A[br + jb] = u0;
+        if (nb > 1) A[br + jb + 1] = u1;
+        if (nb > 2) A[br + jb + 2] = u2;
+        if (nb > 3) A[br + jb + 3] = u3;
+      }
+    }
+    c.sync();
+  }
+  *bad = c.rmax(badl ? 1.0 : 0.0) > 0.0 ? 1 : 0;
+}
+#endif
+
 // Factorise `nm` matrices together (same block index for all of them).
 // Returns through *bad whether a pivot had the wrong sign.
 template <class C>
@@ -812,7 +928,21 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
 #ifdef OMGX_LDL_MFMA
     ldl_blocked(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, stage, &bad);
 #else
+#ifdef OMGX_HOST_PORT
     ldl_left4(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad);
+#else
+    {
+      int total_rows = 0, nmax = 0; bool room = true;
+      for (int l = 0; l < d.n_leaf; ++l) {
+        total_rows += Ms[l].rows; if (Ms[l].nfact > nmax) nmax = Ms[l].nfact;
+        if (Ms[l].nfact + 30 > OMGX_PAN_LD * Ms[l].rows) room = false;     // staging behind the inverse-pivot slot
+      }
+      // a spare wave per leaf next to the row waves
+      const bool coop = room && ((total_rows + 63) >> 6) + d.n_leaf <= c.nwaves();
+      if (coop) ldl_left4_coop(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad, total_rows, nmax);
+      else ldl_left4(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad);
+    }
+#endif
 #endif
     if (bad) return 1;
   }
