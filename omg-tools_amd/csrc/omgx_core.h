@@ -497,6 +497,12 @@ static_assert(sizeof(BMat) <= 4 * sizeof(double), "BMat larger than its LDS slot
 // LDS load that uses the address into the two branches, and a sequence of such loads -- the ten
 // entries of a diagonal block -- becomes ten serialised round trips)
 OMGX_FN int baddr(const BMat& M, int r, int k) { return M.a + r * M.ld + (M.ld == 0 ? 1 : 0) * ((r * (r + 1)) >> 1) + k; }
+// storage kind known at compile time (one multiply instead of two and a select per address):
+// KIND 0 generic, 1 row-major (leaf panels), 2 packed lower (root)
+template <int KIND>
+OMGX_FN int baddr_k(const BMat& M, int r, int k) {
+  return KIND == 1 ? M.a + r * M.ld + k : (KIND == 2 ? M.a + ((r * (r + 1)) >> 1) + k : baddr(M, r, k));
+}
 
 // reciprocal of a pivot: v_rcp_f64 (about 2^-29 relative) + two Newton steps instead of the
 // ~15-instruction IEEE division sequence; exact division on the host port
@@ -528,6 +534,7 @@ OMGX_FN Blk4 blk4_from(double g00, double g10, double g11, double g20, double g2
   return b;
 }
 
+template <int KIND>
 OMGX_FN Blk4 blk4_factor(const BMat& M, const double* A, int jb, int nb) {
   // all loads first (independent), then the short dependent chain
   // (a partial last block reads rows past the block: still inside the workspace, then masked;
@@ -537,7 +544,7 @@ OMGX_FN Blk4 blk4_factor(const BMat& M, const double* A, int jb, int nb) {
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int k = 0; k <= a; ++k) {
-      const double v = A[baddr(M, jb + (a < nb ? a : 0), jb + (a < nb ? k : 0))];
+      const double v = A[baddr_k<KIND>(M, jb + (a < nb ? a : 0), jb + (a < nb ? k : 0))];
       g[a][k] = (a < nb) ? v : (a == k ? 1.0 : 0.0);
     }
   return blk4_from(g[0][0], g[1][0], g[1][1], g[2][0], g[2][1], g[2][2], g[3][0], g[3][1], g[3][2], g[3][3]);
@@ -664,7 +671,7 @@ OMGX_FN void ldl_left4_coop(const C& c, const BMat* Ms, int nm, double* A, doubl
   double* iv = (M.dinv >= 0) ? dinvb + M.dinv : colb + M.pan;          // inverse pivots of this matrix
   double* gb = colb + M.pan + M.nfact;                                // [16] G staging, [16..30) block factor
   double* bb = gb + 16;
-  const int br = baddr(M, r > 0 ? r : 0, 0);
+  const int br = baddr_k<1>(M, r > 0 ? r : 0, 0);
   int badl = 0;
   for (int jb = 0; jb < nmax; jb += OMGX_NB) {
     const bool live = (is_row || is_blk) && jb < M.nfact;
@@ -675,7 +682,7 @@ OMGX_FN void ldl_left4_coop(const C& c, const BMat* Ms, int nm, double* A, doubl
       // ---- block wave: G = A_blk - U_blk diag(1/d) U_blk' ---------------------------------
       const int a = lane & 15, kq = lane >> 4;
       const bool in_blk = a < nb;
-      const int ra = baddr(M, jb + (in_blk ? a : 0), 0);
+      const int ra = baddr_k<1>(M, jb + (in_blk ? a : 0), 0);
       typedef double v4d __attribute__((ext_vector_type(4)));
       v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
       int k0 = 0;
@@ -696,7 +703,7 @@ OMGX_FN void ldl_left4_coop(const C& c, const BMat* Ms, int nm, double* A, doubl
         const int gr = lane >> 4, gc = lane & 15;
         if (gc <= gr) {                                           // lower part (gr < 4 always)
           const bool ok = gr < nb && gc < nb;
-          const double orig = A[baddr(M, jb + (ok ? gr : 0), jb + (ok ? gc : 0))];
+          const double orig = A[baddr_k<1>(M, jb + (ok ? gr : 0), jb + (ok ? gc : 0))];
           gb[gr * 4 + gc] = ok ? orig - acc[0] : (gr == gc ? 1.0 : 0.0);
         }
       }
@@ -715,7 +722,7 @@ OMGX_FN void ldl_left4_coop(const C& c, const BMat* Ms, int nm, double* A, doubl
       }
     } else if (live && r >= jb + nb) {
       // ---- row waves: the four entries of this row against the finished columns ------------
-      const int b0 = baddr(M, jb, 0), b1 = baddr(M, jb + q1, 0), b2 = baddr(M, jb + q2, 0), b3 = baddr(M, jb + q3, 0);
+      const int b0 = baddr_k<1>(M, jb, 0), b1 = baddr_k<1>(M, jb + q1, 0), b2 = baddr_k<1>(M, jb + q2, 0), b3 = baddr_k<1>(M, jb + q3, 0);
       v0 = A[br + jb]; v1 = A[br + jb + q1]; v2 = A[br + jb + q2]; v3 = A[br + jb + q3];
 #pragma unroll 4
       for (int k = 0; k < jb; ++k) {
@@ -755,7 +762,7 @@ OMGX_FN void ldl_left4_coop(const C& c, const BMat* Ms, int nm, double* A, doubl
 
 // Factorise `nm` matrices together (same block index for all of them).
 // Returns through *bad whether a pivot had the wrong sign.
-template <class C>
+template <int KIND, class C>
 OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* dinvb, double* colb, double* stage, int* bad) {
   int nmax = 0, total_rows = 0;
   for (int i = 0; i < nm; ++i) { if (Ms[i].nfact > nmax) nmax = Ms[i].nfact; total_rows += Ms[i].rows; }
@@ -781,7 +788,7 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
       }
       if (jb >= M.nfact || r < jb) continue;
       const int nb = (M.nfact - jb) < OMGX_NB ? (M.nfact - jb) : OMGX_NB;
-      const Blk4 B = blk4_factor(M, A, jb, nb);
+      const Blk4 B = blk4_factor<KIND>(M, A, jb, nb);
       if (r < jb + nb) {
         // a row of the diagonal block: final values go through the staging area
         // (other threads are still reading the original block).  No dynamically
@@ -802,7 +809,7 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
         double* pr = colb + M.pan + r * OMGX_PAN_LD;
         pr[0] = 0.0; pr[1] = 0.0; pr[2] = 0.0; pr[3] = 0.0;
       } else {
-        const int base = baddr(M, r, jb);
+        const int base = baddr_k<KIND>(M, r, jb);
         const double a0 = A[base];
         const double l1 = A[base + (nb > 1 ? 1 : 0)], l2 = A[base + (nb > 2 ? 2 : 0)], l3 = A[base + (nb > 3 ? 3 : 0)];
         const double a1 = nb > 1 ? l1 : 0.0;
@@ -829,7 +836,7 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
     OMGX_PFOR(it, nm * 16) {
       const int mi = it >> 4, q = (it >> 2) & 3, k = it & 3;
       const BMat M = Ms[mi];
-      if (jb < M.nfact && jb + q < M.nfact && k <= q) A[baddr(M, jb + q, jb + k)] = stage[mi * OMGX_STAGE_LD + (it & 15)];
+      if (jb < M.nfact && jb + q < M.nfact && k <= q) A[baddr_k<KIND>(M, jb + q, jb + k)] = stage[mi * OMGX_STAGE_LD + (it & 15)];
     }
     OMGX_TOC(PH_LS);
     // ---- phase B: trailing update, 16x16 tiles -------------------------------------------
@@ -847,7 +854,7 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
           double acc = 0.0;
           for (int q = 0; q < OMGX_NB; ++q)
             acc += colb[M.pan + r * OMGX_PAN_LD + q] * (colb[M.pan + k * OMGX_PAN_LD + q] * stage[mi * OMGX_STAGE_LD + 16 + q]);
-          A[baddr(M, r, k)] -= acc;
+          A[baddr_k<KIND>(M, r, k)] -= acc;
         }
       }
 #else
@@ -872,7 +879,7 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
           for (int i = 0; i < 4; ++i) {
             const int row = R0 + (lane >> 4) + 4 * i;
             ok[i] = row < M.rows && col < M.nfact && (row >= M.nfact || col <= row);
-            ad[i] = ok[i] ? baddr(M, row, col) : M.a;
+            ad[i] = ok[i] ? baddr_k<KIND>(M, row, col) : M.a;
           }
           double al[4];
 #pragma unroll
@@ -926,7 +933,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   double* stage = w.col + OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1);
   if (d.n_leaf > 0) {
 #ifdef OMGX_LDL_MFMA
-    ldl_blocked(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, stage, &bad);
+    ldl_blocked<1>(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, stage, &bad);
 #else
 #ifdef OMGX_HOST_PORT
     ldl_left4(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad);
@@ -938,7 +945,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
         if (Ms[l].nfact + 30 > OMGX_PAN_LD * Ms[l].rows) room = false;     // staging behind the inverse-pivot slot
       }
       // a spare wave per leaf next to the row waves
-      const bool coop = room && ((total_rows + 63) >> 6) + d.n_leaf <= c.nwaves();
+      const bool coop = room && ((total_rows + 63) >> 6) + d.n_leaf <= c.nwaves();       // (leaf panels are row-major: baddr_k<1>)
       if (coop) ldl_left4_coop(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad, total_rows, nmax);
       else ldl_left4(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad);
     }
@@ -1007,7 +1014,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   // the root is one matrix of a few dozen rows (a single wave): the two-phase MFMA routine spreads its
   // trailing tiles over all waves and wins there; the leaves (several matrices, many rows) are faster
   // with the one-barrier left-looking sweep
-  ldl_blocked(c, Ms + d.n_leaf, 1, w.kkt, w.dinv, w.col, stage, &bad);
+  ldl_blocked<2>(c, Ms + d.n_leaf, 1, w.kkt, w.dinv, w.col, stage, &bad);
   OMGX_TOC(PH_F_ROOT);
   return bad;
 }

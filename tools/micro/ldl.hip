@@ -35,10 +35,10 @@ __global__ __launch_bounds__(512) void ldl_kernel(long long* out, double* dout, 
     for (int i = threadIdx.x; i < nr; i += 512) kkt[nl * (n + nc) * ld + tri(i, i)] = 50.0 + i;
     __syncthreads();
     long long t0 = clock64();
-    if (variant == 0) ldl_left4(c, Ms, nl, kkt, dinv, col, &bad); else ldl_blocked(c, Ms, nl, kkt, dinv, col, stage, &bad);
+    if (variant == 0) ldl_left4(c, Ms, nl, kkt, dinv, col, &bad); else ldl_blocked<1>(c, Ms, nl, kkt, dinv, col, stage, &bad);
     __syncthreads();
     long long t1 = clock64();
-    if (variant == 0) ldl_blocked(c, Ms + nl, 1, kkt, dinv, col, stage, &bad); else ldl_left4(c, Ms + nl, 1, kkt, dinv, col, &bad);
+    if (variant == 0) ldl_blocked<2>(c, Ms + nl, 1, kkt, dinv, col, stage, &bad); else ldl_left4(c, Ms + nl, 1, kkt, dinv, col, &bad);
     __syncthreads();
     long long t2 = clock64();
     if (rep >= 4) { tl += t1 - t0; tr += t2 - t1; }
