@@ -9,7 +9,7 @@ __global__ __launch_bounds__(512) void ldl_kernel(long long* out, double* dout, 
   extern __shared__ double lds[];
   Ctx c; c.red = lds; c.prof = nullptr;
   double* kkt = lds + 64;
-  const int n = 36, nc = 29, ld = 37, nl = 4, nr = 39;
+  const int n = 36, nc = 28, ld = 37, nl = 4, nr = 39;      // 64 rows per leaf: 4 row waves + 4 block waves
   const int kkt_doubles = nl * (n + nc) * ld + nr * (nr + 1) / 2;
   double* dinv = kkt + kkt_doubles;
   double* col = dinv + 256;
@@ -35,10 +35,10 @@ __global__ __launch_bounds__(512) void ldl_kernel(long long* out, double* dout, 
     for (int i = threadIdx.x; i < nr; i += 512) kkt[nl * (n + nc) * ld + tri(i, i)] = 50.0 + i;
     __syncthreads();
     long long t0 = clock64();
-    if (variant == 0) ldl_left4(c, Ms, nl, kkt, dinv, col, &bad); else ldl_blocked<1>(c, Ms, nl, kkt, dinv, col, stage, &bad);
+    if (variant == 0) ldl_left4(c, Ms, nl, kkt, dinv, col, &bad); else if (variant == 1) ldl_blocked<1>(c, Ms, nl, kkt, dinv, col, stage, &bad); else ldl_left4_coop(c, Ms, nl, kkt, dinv, col, &bad, nl * (n + nc), n);
     __syncthreads();
     long long t1 = clock64();
-    if (variant == 0) ldl_blocked<2>(c, Ms + nl, 1, kkt, dinv, col, stage, &bad); else ldl_left4(c, Ms + nl, 1, kkt, dinv, col, &bad);
+    if (variant != 1) ldl_blocked<2>(c, Ms + nl, 1, kkt, dinv, col, stage, &bad); else ldl_left4(c, Ms + nl, 1, kkt, dinv, col, &bad);
     __syncthreads();
     long long t2 = clock64();
     if (rep >= 4) { tl += t1 - t0; tr += t2 - t1; }
@@ -49,28 +49,28 @@ __global__ __launch_bounds__(512) void ldl_kernel(long long* out, double* dout, 
 
 int main() {
   long long* d_out; double* d_d;
-  const int nb = 256, nd = 4 * 65 * 37 + 780 + 257;
+  const int nb = 256, nd = 4 * 64 * 37 + 780 + 257;
   hipMalloc(&d_out, nb * 2 * sizeof(long long));
   hipMalloc(&d_d, nd * sizeof(double));
   hipFuncSetAttribute((const void*)ldl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  static double res[2][4 * 65 * 37 + 780 + 257];
-  for (int variant = 0; variant < 2; ++variant) {
+  static double res[3][4 * 64 * 37 + 780 + 257];
+  for (int variant = 0; variant < 3; ++variant) {
     hipLaunchKernelGGL(ldl_kernel, dim3(nb), dim3(512), 150 * 1024, 0, d_out, d_d, variant);
     hipDeviceSynchronize();
     long long ho[512];
     hipMemcpy(ho, d_out, sizeof(ho), hipMemcpyDeviceToHost);
     hipMemcpy(res[variant], d_d, nd * sizeof(double), hipMemcpyDeviceToHost);
     double a = 0, b = 0; for (int i = 0; i < nb; ++i) { a += ho[2 * i]; b += ho[2 * i + 1]; }
-    printf("variant %d (%s): 4 leaves (36 + 29 carried rows) %.0f cycles;  root 39: %.0f cycles  bad=%g [%s]\n", variant,
-           variant ? "leaves ldl_blocked / root ldl_left4" : "leaves ldl_left4 / root ldl_blocked (shipped)", a / nb, b / nb, res[variant][nd - 1], hipGetErrorString(hipGetLastError()));
+    printf("variant %d (%s): 4 leaves (36 + 28 carried rows) %.0f cycles;  root 39: %.0f cycles  bad=%g [%s]\n", variant,
+           variant == 0 ? "leaves ldl_left4 / root ldl_blocked" : (variant == 1 ? "leaves ldl_blocked / root ldl_left4" : "leaves ldl_left4_coop / root ldl_blocked (shipped for config 2)"), a / nb, b / nb, res[variant][nd - 1], hipGetErrorString(hipGetLastError()));
   }
   // compare the lower parts / carried rows and the inverse pivots
   double md = 0.0, mx = 0.0;
-  for (int l = 0; l < 4; ++l) for (int r = 36; r < 65; ++r) for (int k = 0; k < 36; ++k) {      // carried rows (the factorised rows are L in one routine, U = L D in the other)
-    const int i = l * 65 * 37 + r * 37 + k;
-    md = fmax(md, fabs(res[0][i] - res[1][i])); mx = fmax(mx, fabs(res[0][i]));
+  for (int l = 0; l < 4; ++l) for (int r = 36; r < 64; ++r) for (int k = 0; k < 36; ++k) {      // carried rows (the factorised rows are L in one routine, U = L D in the other)
+    const int i = l * 64 * 37 + r * 37 + k;
+    md = fmax(md, fabs(res[0][i] - res[2][i])); mx = fmax(mx, fabs(res[0][i]));
   }
-  for (int i = 4 * 65 * 37 + 780; i < 4 * 65 * 37 + 780 + 144; ++i) { md = fmax(md, fabs(res[0][i] - res[1][i])); mx = fmax(mx, fabs(res[0][i])); }
-  printf("carried rows and inverse pivots of the leaves, routine vs routine: max |difference| = %.3e (max |entry| %.3e)\n", md, mx);
+  for (int i = 4 * 64 * 37 + 780; i < 4 * 64 * 37 + 780 + 144; ++i) { md = fmax(md, fabs(res[0][i] - res[2][i])); mx = fmax(mx, fabs(res[0][i])); }
+  printf("carried rows and inverse pivots of the leaves, ldl_left4 vs ldl_left4_coop: max |difference| = %.3e (max |entry| %.3e)\n", md, mx);
   return 0;
 }
