@@ -657,7 +657,7 @@ OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* di
 //   barrier; every row reads the block factor and finishes its four entries; barrier.
 // Same storage convention and (up to summation order) the same numbers as ldl_left4.
 // ---------------------------------------------------------------------------
-template <class C>
+template <int KIND, class C>
 OMGX_FN void ldl_left4_coop(const C& c, const BMat* Ms, int nm, double* A, double* dinvb, double* colb, int* bad,
                             int total_rows, int nmax) {
   const int lane = c.lane(), wave = c.wave();
@@ -671,7 +671,7 @@ OMGX_FN void ldl_left4_coop(const C& c, const BMat* Ms, int nm, double* A, doubl
   double* iv = (M.dinv >= 0) ? dinvb + M.dinv : colb + M.pan;          // inverse pivots of this matrix
   double* gb = colb + M.pan + M.nfact;                                // [16] G staging, [16..30) block factor
   double* bb = gb + 16;
-  const int br = baddr_k<1>(M, r > 0 ? r : 0, 0);
+  const int br = baddr_k<KIND>(M, r > 0 ? r : 0, 0);
   int badl = 0;
   for (int jb = 0; jb < nmax; jb += OMGX_NB) {
     const bool live = (is_row || is_blk) && jb < M.nfact;
@@ -682,7 +682,7 @@ OMGX_FN void ldl_left4_coop(const C& c, const BMat* Ms, int nm, double* A, doubl
       // ---- block wave: G = A_blk - U_blk diag(1/d) U_blk' ---------------------------------
       const int a = lane & 15, kq = lane >> 4;
       const bool in_blk = a < nb;
-      const int ra = baddr_k<1>(M, jb + (in_blk ? a : 0), 0);
+      const int ra = baddr_k<KIND>(M, jb + (in_blk ? a : 0), 0);
       typedef double v4d __attribute__((ext_vector_type(4)));
       v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
       int k0 = 0;
@@ -703,7 +703,7 @@ OMGX_FN void ldl_left4_coop(const C& c, const BMat* Ms, int nm, double* A, doubl
         const int gr = lane >> 4, gc = lane & 15;
         if (gc <= gr) {                                           // lower part (gr < 4 always)
           const bool ok = gr < nb && gc < nb;
-          const double orig = A[baddr_k<1>(M, jb + (ok ? gr : 0), jb + (ok ? gc : 0))];
+          const double orig = A[baddr_k<KIND>(M, jb + (ok ? gr : 0), jb + (ok ? gc : 0))];
           gb[gr * 4 + gc] = ok ? orig - acc[0] : (gr == gc ? 1.0 : 0.0);
         }
       }
@@ -722,7 +722,7 @@ OMGX_FN void ldl_left4_coop(const C& c, const BMat* Ms, int nm, double* A, doubl
       }
     } else if (live && r >= jb + nb) {
       // ---- row waves: the four entries of this row against the finished columns ------------
-      const int b0 = baddr_k<1>(M, jb, 0), b1 = baddr_k<1>(M, jb + q1, 0), b2 = baddr_k<1>(M, jb + q2, 0), b3 = baddr_k<1>(M, jb + q3, 0);
+      const int b0 = baddr_k<KIND>(M, jb, 0), b1 = baddr_k<KIND>(M, jb + q1, 0), b2 = baddr_k<KIND>(M, jb + q2, 0), b3 = baddr_k<KIND>(M, jb + q3, 0);
       v0 = A[br + jb]; v1 = A[br + jb + q1]; v2 = A[br + jb + q2]; v3 = A[br + jb + q3];
 #pragma unroll 4
       for (int k = 0; k < jb; ++k) {
@@ -946,7 +946,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
       }
       // a spare wave per leaf next to the row waves
       const bool coop = room && ((total_rows + 63) >> 6) + d.n_leaf <= c.nwaves();       // (leaf panels are row-major: baddr_k<1>)
-      if (coop) ldl_left4_coop(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad, total_rows, nmax);
+      if (coop) ldl_left4_coop<1>(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad, total_rows, nmax);
       else ldl_left4(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad);
     }
 #endif
@@ -1014,6 +1014,8 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   // the root is one matrix of a few dozen rows (a single wave): the two-phase MFMA routine spreads its
   // trailing tiles over all waves and wins there; the leaves (several matrices, many rows) are faster
   // with the one-barrier left-looking sweep
+  // (the cooperative routine was tried for the root as well -- one row wave + one block wave: 31 k against
+  // 43 k cycles standalone, but 1.5 % slower inside the fused kernel in an A/B of three bench runs each)
   ldl_blocked<2>(c, Ms + d.n_leaf, 1, w.kkt, w.dinv, w.col, stage, &bad);
   OMGX_TOC(PH_F_ROOT);
   return bad;

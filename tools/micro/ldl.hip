@@ -35,10 +35,10 @@ __global__ __launch_bounds__(512) void ldl_kernel(long long* out, double* dout, 
     for (int i = threadIdx.x; i < nr; i += 512) kkt[nl * (n + nc) * ld + tri(i, i)] = 50.0 + i;
     __syncthreads();
     long long t0 = clock64();
-    if (variant == 0) ldl_left4(c, Ms, nl, kkt, dinv, col, &bad); else if (variant == 1) ldl_blocked<1>(c, Ms, nl, kkt, dinv, col, stage, &bad); else ldl_left4_coop(c, Ms, nl, kkt, dinv, col, &bad, nl * (n + nc), n);
+    if (variant == 0) ldl_left4(c, Ms, nl, kkt, dinv, col, &bad); else if (variant == 1) ldl_blocked<1>(c, Ms, nl, kkt, dinv, col, stage, &bad); else ldl_left4_coop<1>(c, Ms, nl, kkt, dinv, col, &bad, nl * (n + nc), n);
     __syncthreads();
     long long t1 = clock64();
-    if (variant != 1) ldl_blocked<2>(c, Ms + nl, 1, kkt, dinv, col, stage, &bad); else ldl_left4(c, Ms + nl, 1, kkt, dinv, col, &bad);
+    if (variant == 3) ldl_left4_coop<2>(c, Ms + nl, 1, kkt, dinv, col, &bad, nr, nr); else if (variant != 1) ldl_blocked<2>(c, Ms + nl, 1, kkt, dinv, col, stage, &bad); else ldl_left4(c, Ms + nl, 1, kkt, dinv, col, &bad);
     __syncthreads();
     long long t2 = clock64();
     if (rep >= 4) { tl += t1 - t0; tr += t2 - t1; }
@@ -53,8 +53,8 @@ int main() {
   hipMalloc(&d_out, nb * 2 * sizeof(long long));
   hipMalloc(&d_d, nd * sizeof(double));
   hipFuncSetAttribute((const void*)ldl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  static double res[3][4 * 64 * 37 + 780 + 257];
-  for (int variant = 0; variant < 3; ++variant) {
+  static double res[4][4 * 64 * 37 + 780 + 257];
+  for (int variant = 0; variant < 4; ++variant) {
     hipLaunchKernelGGL(ldl_kernel, dim3(nb), dim3(512), 150 * 1024, 0, d_out, d_d, variant);
     hipDeviceSynchronize();
     long long ho[512];
@@ -62,7 +62,7 @@ int main() {
     hipMemcpy(res[variant], d_d, nd * sizeof(double), hipMemcpyDeviceToHost);
     double a = 0, b = 0; for (int i = 0; i < nb; ++i) { a += ho[2 * i]; b += ho[2 * i + 1]; }
     printf("variant %d (%s): 4 leaves (36 + 28 carried rows) %.0f cycles;  root 39: %.0f cycles  bad=%g [%s]\n", variant,
-           variant == 0 ? "leaves ldl_left4 / root ldl_blocked" : (variant == 1 ? "leaves ldl_blocked / root ldl_left4" : "leaves ldl_left4_coop / root ldl_blocked (shipped for config 2)"), a / nb, b / nb, res[variant][nd - 1], hipGetErrorString(hipGetLastError()));
+           variant == 0 ? "leaves ldl_left4 / root ldl_blocked" : (variant == 1 ? "leaves ldl_blocked / root ldl_left4" : (variant == 2 ? "leaves ldl_left4_coop / root ldl_blocked" : "leaves ldl_left4_coop / root ldl_left4_coop")), a / nb, b / nb, res[variant][nd - 1], hipGetErrorString(hipGetLastError()));
   }
   // compare the lower parts / carried rows and the inverse pivots
   double md = 0.0, mx = 0.0;
