@@ -24,11 +24,11 @@ def test_port_matches_numpy_iteration_for_iteration(cfg2_small):
         assert np.abs(r['lam_g'] - ref['lam_g'][b]).max() < 1e-9 * (1 + np.abs(r['lam_g']).max())
     # ... and they stop at the same point (rounding differences grow in the last iterations, where the
     # barrier parameter is ~1e-7: the count may differ by a few)
-    ref = port_binding.solve(tpl, P['p'][:4], P['x0'][:4], tol=1e-6, max_iter=150)
+    ref = port_binding.solve(tpl, P['p'][:4], P['x0'][:4], tol=3e-6, max_iter=150)
     both = 0
     for b in range(4):
         r = ipm_numpy.solve(nlp, P['x0'][b], P['p'][b], tpl.lb, tpl.ub,
-                            opts={'tol': 1e-6, 'max_iter': 150})
+                            opts={'tol': 3e-6, 'max_iter': 150})
         if r['status'] == 0 and ref['status'][b] == 0:
             both += 1
             assert abs(r['iters'] - ref['iters'][b]) <= 3
