@@ -1249,11 +1249,12 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     if (ty == ROW_UPPER || ty == ROW_LOWER) v = fmax(h + kpush, 0.0);
     else if (ty == ROW_EQ) v = h;
     w.vv[r] = v;
+    // the Jacobian the first iteration needs is this one with the rows scaled (plus the objective row,
+    // below): no second pass over the constraint terms at x0; the row's entries are in flight anyway
+    const double sc = (ty == ROW_FREE) ? 0.0 : w.rho[r];
+    for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) w.jval[e] *= sc;
   }
   if (c.rmax(bad_local) > 0.0) { res.status = 3; return res; }
-  // the Jacobian the first iteration needs is this one with the rows scaled, plus the objective row
-  // (its entries are still zero): no second pass over the constraint terms at x0
-  OMGX_PFOR(e, T.jr_ptr[m]) { const int r = T.je_row[e]; w.jval[e] *= (w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r]; }
   OMGX_PFOR(q, T.row_ptr[m + 1] - T.row_ptr[m]) {
     const int tt = T.row_ptr[m] + q;
     const int32_t* tv = T.t_var + 3 * tt;
