@@ -51,6 +51,7 @@ struct Dims {
   int mono_packed;   // 1: every parameter monomial has <= 4 atoms, Tables::pm_rec is valid
   int n_hess;        // number of HessRec records
   int rp_packed;     // 1: rows and positions fit 16 bits each, Tables::je_rp is valid
+  int n_bspl;        // number of basis-function atoms (records in Tables::bspl_items)
   int n_knots;       // total length of the knot vectors of the atoms program (copied to LDS per solve)
 };
 
@@ -70,6 +71,8 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* pp_ptr; const double* pm_coef; const int32_t* pm_ptr; const int32_t* pm_atom;
   const int32_t* slot_pp;
   const MonoRec* pm_rec;    // [n_mono] packed form of (pm_coef, pm_ptr, pm_atom); valid if Dims::mono_packed
+  const int32_t* slot_rng;  // [n_slots][2] monomial range of every slot (= pp_ptr[slot_pp[s]], pp_ptr[slot_pp[s] + 1])
+  const int32_t* bspl_items;// [n_bspl][6] one record per basis-function atom: {knot offset, degree, input atom, i, output atom, op index}
   const int32_t* row_ptr; const double* t_coef; const int32_t* t_slot; const int32_t* t_var;
   const int32_t* order; const int32_t* pos; const int32_t* leaf_off; const int32_t* blk;
   const int32_t* eq_rows; const int32_t* eq_index;
@@ -316,6 +319,19 @@ OMGX_FN double pp_eval(const Tables& T, int pp, const double* a) {
   return tot;
 }
 
+// (range form: the caller already knows the monomial range)
+OMGX_FN double mono_range_eval(const Tables& T, int m0, int m1, const double* a) {
+  double tot = 0.0;
+#pragma unroll 4
+  for (int m = m0; m < m1; ++m) {
+    const MonoRec r = T.pm_rec[m];
+    double v = r.coef;
+    if (r.a0 >= 0) { v *= a[r.a0]; if (r.a1 >= 0) { v *= a[r.a1]; if (r.a2 >= 0) { v *= a[r.a2]; if (r.a3 >= 0) v *= a[r.a3]; } } }
+    tot += v;
+  }
+  return tot;
+}
+
 // the same sum, same order of operations, from the packed records: the record loads do not depend on
 // each other (the CSR form chains three global loads per monomial)
 OMGX_FN double pp_eval_packed(const Tables& T, int pp, const double* a) {
@@ -379,19 +395,18 @@ OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, co
     } else {
       // a run of consecutive basis-row ops is one parallel pass: their arguments are raw parameters
       // or quotients (never the output of another basis row), so they do not depend on each other
-      int k2 = k, total = 0;
-      while (k2 < d.n_prog && T.prog[6 * k2] == OP_BSPL) { total += T.prog[6 * k2 + 2] - T.prog[6 * k2 + 3] - 1; ++k2; }
-      OMGX_PFOR(it, total) {
-        int kk = k, i = it;
-        for (;; ++kk) { const int nout = T.prog[6 * kk + 2] - T.prog[6 * kk + 3] - 1; if (i < nout) break; i -= nout; }
-        const int32_t* oq = T.prog + 6 * kk;
-        w.atoms[oq[5] + i] = bspl_entry(w.knots + oq[1], oq[3], w.atoms[oq[4]], i);
+      int k2 = k;
+      while (k2 < d.n_prog && T.prog[6 * k2] == OP_BSPL) ++k2;
+      // one record per basis-function atom (no walk over the ops): those of the ops [k, k2)
+      OMGX_PFOR(it, d.n_bspl) {
+        const int32_t* q = T.bspl_items + 6 * it;
+        if (q[5] >= k && q[5] < k2) w.atoms[q[4]] = bspl_entry(w.knots + q[0], q[1], w.atoms[q[2]], q[3]);
       }
       k = k2;
     }
     c.sync();
   }
-  if (d.mono_packed) { OMGX_PFOR(s, d.n_slots) w.slots[s] = pp_eval_packed(T, T.slot_pp[s], w.atoms); }
+  if (d.mono_packed) { OMGX_PFOR(s, d.n_slots) w.slots[s] = mono_range_eval(T, T.slot_rng[2 * s], T.slot_rng[2 * s + 1], w.atoms); }
   else { OMGX_PFOR(s, d.n_slots) w.slots[s] = pp_eval(T, T.slot_pp[s], w.atoms); }
   c.sync();
 }
