@@ -472,7 +472,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   UP(je_row, plan.je_row.size()); UP(jt_addr, plan.jt_addr.size()); UP(diag_addr, d.N);
   UP(h_addr, plan.h_addr.size()); UP(t_row, plan.t_row.size()); UP(t_pos, plan.t_pos.size()); UP(reg_w, d.N);
   UP(trec, plan.trec.size()); UP(hrec, plan.hrec.size()); UP(je_rp, plan.je_rp.size());
-  UP(slot_rng, plan.slot_rng.size()); UP(bspl_items, plan.bspl_items.size());
+  UP(slot_rng, plan.slot_rng.size());
   return OMGX_OK;
 }
 

@@ -51,7 +51,6 @@ struct Dims {
   int mono_packed;   // 1: every parameter monomial has <= 4 atoms, Tables::pm_rec is valid
   int n_hess;        // number of HessRec records
   int rp_packed;     // 1: rows and positions fit 16 bits each, Tables::je_rp is valid
-  int n_bspl;        // number of basis-function atoms (records in Tables::bspl_items)
   int n_knots;       // total length of the knot vectors of the atoms program (copied to LDS per solve)
 };
 
@@ -72,7 +71,6 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* slot_pp;
   const MonoRec* pm_rec;    // [n_mono] packed form of (pm_coef, pm_ptr, pm_atom); valid if Dims::mono_packed
   const int32_t* slot_rng;  // [n_slots][2] monomial range of every slot (= pp_ptr[slot_pp[s]], pp_ptr[slot_pp[s] + 1])
-  const int32_t* bspl_items;// [n_bspl][6] one record per basis-function atom: {knot offset, degree, input atom, i, output atom, op index}
   const int32_t* row_ptr; const double* t_coef; const int32_t* t_slot; const int32_t* t_var;
   const int32_t* order; const int32_t* pos; const int32_t* leaf_off; const int32_t* blk;
   const int32_t* eq_rows; const int32_t* eq_index;
@@ -295,7 +293,7 @@ typedef CtxT<false> Ctx;
 enum { PH_JAC = 0, PH_RESID, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_STEP, PH_LINESEARCH, PH_UPDATE, PH_F_LEAF, PH_F_SCHUR, PH_F_ROOT, PH_LA, PH_LS, PH_LB, PH_SETUP, PH_TOTAL,
        PH_S_DESC, PH_S_PARAMS, PH_S_JAC0, PH_S_CLASS, PH_S_INIT, PH_A_ZERO, PH_A_PAIRS, PH_A_REST, PH_A_DIAG,
        PH_K_FWD, PH_K_ROOTRHS, PH_K_ROOT, PH_K_LEAFRHS, PH_K_BWD, PH_L_TERMS, PH_L_ROWS,
-       PH_F_PARK, PH_F_SWEEP, PH_F_SCALE, PH_A_TCOL, PH_A_HESS, PH_COUNT };
+       PH_F_PARK, PH_F_SWEEP, PH_F_SCALE, PH_A_TCOL, PH_A_HESS, PH_P_LOAD, PH_P_DIV, PH_P_BSPL, PH_P_SLOTS, PH_COUNT };
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
 #define OMGX_TIC() long long tic_ = (c.sync(), clock64())
 #define OMGX_TOC(k) do { c.sync(); long long now_ = clock64(); if (c.tid() == 0) c.prof[k] += now_ - tic_; tic_ = now_; } while (0)
@@ -380,11 +378,50 @@ OMGX_FN double bspl_entry(const double* k, int deg, double u, int i) {
   return b[0];
 }
 
+// All basis functions of one basis row at u by the span algorithm (The NURBS Book A2.2, O(deg^2) with
+// deg (deg + 1) / 2 divisions) instead of one Cox-de Boor triangle per function: the deg + 1 functions of
+// the active span are computed together, the others are zero.  Span convention of the reference
+// (`basics/spline.py:131-136`): k_j < u <= k_{j+1}, closed on the left at the first knot.  Fully unrolled
+// with compile-time indices (no scratch).  out[0 .. n_fun) receives the row.
+OMGX_FN void bspl_row(const double* k, int n_knots, int deg, double u, double* out) {
+  const int n_fun = n_knots - deg - 1;
+  int j = deg;                                               // first non-degenerate span
+  for (int q = deg + 1; q < n_fun; ++q) if (k[q] < u) j = q;
+  double N[6], left[6], right[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) { N[r] = 0.0; left[r] = 0.0; right[r] = 0.0; }
+  N[0] = 1.0;
+  const bool inside = (u >= k[0]) && (u <= k[n_knots - 1]);
+#pragma unroll
+  for (int r = 1; r <= 5; ++r) {
+    if (r <= deg) {
+      left[r] = u - k[j + 1 - r];
+      right[r] = k[j + r] - u;
+      double saved = 0.0;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        if (q < r) {
+          const double den = right[q + 1] + left[r - q];
+          const double temp = den != 0.0 ? N[q] / den : 0.0;
+          N[q] = saved + right[q + 1] * temp;
+          saved = left[r - q] * temp;
+        }
+      }
+      N[r] = saved;
+    }
+  }
+  for (int i = 0; i < n_fun; ++i) out[i] = 0.0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) if (r <= deg && inside) out[j - deg + r] = N[r];
+}
+
 template <class C>
 OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, const double* p) {
   OMGX_PFOR(i, d.n_par) w.atoms[i] = p[i];
+  OMGX_TIC();
   OMGX_PFOR(i, d.n_knots) w.knots[i] = T.knots[i];     // the Cox-de Boor triangles read them dozens of times
   c.sync();
+  OMGX_TOC(PH_P_LOAD);
   for (int k = 0; k < d.n_prog;) {              // ops in order (an op may read atoms of earlier ones)
     const int32_t* op = T.prog + 6 * k;
     if (op[0] == OP_DIV) {
@@ -392,23 +429,28 @@ OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, co
         w.atoms[op[3]] = d.mono_packed ? pp_eval_packed(T, op[1], w.atoms) / pp_eval_packed(T, op[2], w.atoms)
                                        : pp_eval(T, op[1], w.atoms) / pp_eval(T, op[2], w.atoms);
       ++k;
+      c.sync();
+      OMGX_TOC(PH_P_DIV);
+      continue;
     } else {
       // a run of consecutive basis-row ops is one parallel pass: their arguments are raw parameters
       // or quotients (never the output of another basis row), so they do not depend on each other
       int k2 = k;
       while (k2 < d.n_prog && T.prog[6 * k2] == OP_BSPL) ++k2;
-      // one record per basis-function atom (no walk over the ops): those of the ops [k, k2)
-      OMGX_PFOR(it, d.n_bspl) {
-        const int32_t* q = T.bspl_items + 6 * it;
-        if (q[5] >= k && q[5] < k2) w.atoms[q[4]] = bspl_entry(w.knots + q[0], q[1], w.atoms[q[2]], q[3]);
+      // one thread per basis row: the deg + 1 functions of the active span together (bspl_row)
+      OMGX_PFOR(it, k2 - k) {
+        const int32_t* oq = T.prog + 6 * (k + it);
+        bspl_row(w.knots + oq[1], oq[2], oq[3], w.atoms[oq[4]], w.atoms + oq[5]);
       }
       k = k2;
     }
     c.sync();
+    OMGX_TOC(PH_P_BSPL);
   }
   if (d.mono_packed) { OMGX_PFOR(s, d.n_slots) w.slots[s] = mono_range_eval(T, T.slot_rng[2 * s], T.slot_rng[2 * s + 1], w.atoms); }
   else { OMGX_PFOR(s, d.n_slots) w.slots[s] = pp_eval(T, T.slot_pp[s], w.atoms); }
   c.sync();
+  OMGX_TOC(PH_P_SLOTS);
 }
 
 OMGX_FN double term_coef(const Tables& T, const Work& w, int t) {

@@ -16,7 +16,7 @@ struct HostPlan {
   std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, h_addr, t_row, t_pos;
   std::vector<double> reg_w;
   std::vector<MonoRec> pm_rec;
-  std::vector<int32_t> je_rp, slot_rng, bspl_items;
+  std::vector<int32_t> je_rp, slot_rng;
   std::vector<TermRec> trec;
   std::vector<HessRec> hrec;
 
@@ -145,16 +145,7 @@ struct HostPlan {
     // flat tables of the parameter stage
     slot_rng.assign(2 * (d.n_slots > 0 ? d.n_slots : 1), 0);
     for (int sl = 0; sl < d.n_slots; ++sl) { slot_rng[2 * sl] = t.pp_ptr[t.slot_pp[sl]]; slot_rng[2 * sl + 1] = t.pp_ptr[t.slot_pp[sl] + 1]; }
-    bspl_items.clear();
-    for (int k = 0; k < d.n_prog; ++k) {
-      const int32_t* op = t.prog + 6 * k;
-      if (op[0] != OP_BSPL) continue;
-      const int nout = op[2] - op[3] - 1;
-      for (int i = 0; i < nout; ++i) { const int32_t rec[6] = {op[1], op[3], op[4], i, op[5] + i, k}; bspl_items.insert(bspl_items.end(), rec, rec + 6); }
-    }
-    d.n_bspl = (int)bspl_items.size() / 6;
-    if (bspl_items.empty()) bspl_items.assign(6, 0);
-    T.slot_rng = slot_rng.data(); T.bspl_items = bspl_items.data();
+    T.slot_rng = slot_rng.data();
     // packed (row, position) of the Jacobian entries
     d.rp_packed = (m < 65535 && d.N < 65536) ? 1 : 0;
     je_rp.assign(d.nnz_j > 0 ? d.nnz_j : 1, 0);

@@ -15,7 +15,7 @@ import omgtools.backend as be
 PHASES = ['jac', 'resid', 'assemble', 'factor', 'solve', 'step', 'linesearch', 'update', 'f_leaf', 'f_schur', 'f_root', 'l_A', 'l_stage', 'l_B', 'setup', 'total',
           's_desc', 's_params', 's_jac0', 's_class', 's_init', 'a_zero', 'a_pairs', 'a_rest', 'a_diag',
           'k_fwd', 'k_rootrhs', 'k_root', 'k_leafrhs', 'k_bwd', 'l_terms', 'l_rows',
-          'f_park', 'f_sweep', 'f_scale', 'a_tcol', 'a_hess']
+          'f_park', 'f_sweep', 'f_scale', 'a_tcol', 'a_hess', 's_p_load', 's_p_div', 's_p_bspl', 's_p_slots']
 
 
 def main():
