@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define OMGX_VERSION 1
+#define OMGX_VERSION 2
 
 /* error codes */
 #define OMGX_OK            0
@@ -46,8 +46,12 @@ extern "C" {
 #define OMGX_BOUNDS_SHARED  2   /* lbg/ubg hold n_con values shared by all agents */
 #define OMGX_BOUNDS_DEVICE  4   /* lbg/ubg are device pointers */
 
-/* Flat NLP description + static solver plan (host pointers, copied by create).
- * Produced by omgtools/template.py (NLPTemplate.flat_arrays, SolverPlan). */
+/* Flat NLP description (host pointers, copied by create): what the reference hands to
+ * `nlpsol('solver', 'ipopt', {x, p, f, g}, ...)` (`basics/optilayer.py:54-60`) as CasADi graphs, here as
+ * polynomial term lists (omgtools/template.py NLPTemplate.flat_arrays; INTEGRATION.md shows how the
+ * reference's own construct code produces them).  The solver's static plan (which variables form
+ * the leaves / the root of the block-arrow KKT matrix, Jacobian structure, assembly tables) is derived
+ * inside the library (csrc/omgx_plan.h); `omgx_plan_describe` reports it. */
 typedef struct omgx_template {
   int32_t n_var, n_par, n_con, n_atoms, n_slots, n_terms;
   int32_t n_prog, n_knots, n_pp, n_mono, n_matom;
@@ -62,22 +66,26 @@ typedef struct omgx_template {
   const double*  t_coef;    /* [n_terms] */
   const int32_t* t_slot;    /* [n_terms] */
   const int32_t* t_var;     /* [n_terms*3], -1 = unused */
-  /* solver plan */
-  int32_t n_leaf, n_root, n_eq, nnz_j;
-  const int32_t* order;     /* [n_var+1] position -> variable (n_var = t) */
-  const int32_t* leaf_off;  /* [n_leaf+1] */
+  /* row kinds: the rows with lbg == ubg (reference `optilayer.py:263-272`) */
+  int32_t n_eq;
   const int32_t* eq_rows;   /* [n_eq] */
-  const int32_t* jr_ptr;    /* [n_con+2] */
-  const int32_t* jr_pos;    /* [nnz_j] */
-  const int32_t* t_jidx;    /* [n_terms*3] */
-  const int32_t* row_leaf;  /* [n_con+1] */
-  const int32_t* jc_ptr;    /* [n_var+1] */
-  const int32_t* jc_row;    /* [nnz_j] */
-  const int32_t* jc_ent;    /* [nnz_j] */
-  const int32_t* cpl_ptr;   /* [n_leaf+1] */
-  const int32_t* cpl_idx;   /* [cpl_ptr[n_leaf]] */
-  const int32_t* cpl_map;   /* [max(n_leaf,1)*n_root] */
+  /* optional structure hint: variables that belong to the root of the block-arrow KKT matrix (the
+   * vehicle's spline coefficients, `vehicles/vehicle.py:105-120`); n_root_vars = 0: chosen automatically */
+  int32_t n_root_vars;
+  const int32_t* root_vars; /* [n_root_vars] */
 } omgx_template;
+
+/* What the library derived from a template (host only, needs no device). */
+#define OMGX_PLAN_MAX_LEAF 16
+typedef struct omgx_plan_info {
+  int32_t n_leaf, n_root, n_eq, nnz_j;       /* n_root includes the phase-I variable t */
+  int32_t kkt_doubles;                       /* size of the block-arrow store */
+  int32_t wave_path;                         /* 1: register-resident wave-level factorisation applies */
+  int32_t ws_mode;                           /* workspace placement that would be chosen (omgx_batch_workspace) */
+  int64_t lds_bytes;
+  int32_t leaf_size[OMGX_PLAN_MAX_LEAF], leaf_bw[OMGX_PLAN_MAX_LEAF], leaf_cpl[OMGX_PLAN_MAX_LEAF];
+  int32_t n_pairs, ka_len, kh_len, kg_len;   /* assembly: Jacobian pairs; records per owner thread (pairs / Hessian / Gershgorin) */
+} omgx_plan_info;
 
 typedef struct omgx_options {
   double  tol;          /* scaled KKT tolerance ('ipopt.tol') */
@@ -101,6 +109,10 @@ int  omgx_version(void);
 const char* omgx_last_error(void);
 const char* omgx_status_string(int32_t status);
 void omgx_default_options(omgx_options* o);
+
+/* Derive the solver plan of a template without creating a batch (host only).  order [n_var+1]
+ * (position -> variable, n_var = the phase-I variable) may be NULL. */
+int  omgx_plan_describe(const omgx_template* tpl, omgx_plan_info* info, int32_t* order);
 
 /* Create a batch of n_agents independent problems sharing one template. */
 int  omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device,

@@ -437,18 +437,30 @@ int dalloc(omgx_batch* b, size_t n, T** dst) {
   do { int rc_ = upload(b, H.field, (size_t)(count), &b->dev.field); \
        if (rc_ != OMGX_OK) return rc_; } while (0)
 
+// smallest spill mode whose LDS part fits one CU (WS_MODES: none does)
+int pick_mode(const omgx::Dims& d, int kkt_doubles, size_t* lds_doubles, size_t* hbm_doubles) {
+  int mode = 0;
+  for (; mode < omgx::WS_MODES; ++mode) {
+    omgx::work_split(d, kkt_doubles, mode, lds_doubles, hbm_doubles);
+    if (*lds_doubles * sizeof(double) <= (size_t)kLdsLimit) break;
+  }
+  return mode;
+}
+
+int check_template(const omgx_template* t) {
+  if (!t || t->n_var <= 0 || t->n_par < 0 || t->n_con < 0 || t->n_terms < 0 || t->n_eq < 0 || t->n_root_vars < 0 ||
+      !t->row_ptr || (t->n_terms > 0 && (!t->t_coef || !t->t_slot || !t->t_var)) || (t->n_eq > 0 && !t->eq_rows) ||
+      (t->n_root_vars > 0 && !t->root_vars)) { g_err = "bad template"; return OMGX_E_INVALID; }
+  return OMGX_OK;
+}
+
 int build_batch(omgx_batch* b, const omgx_template* t) {
   omgx::HostPlan plan;
-  if (!plan.build(*t)) { g_err = "inconsistent template/plan"; return OMGX_E_INVALID; }
+  if (!plan.build(*t)) { g_err = "inconsistent template: " + plan.error; return OMGX_E_INVALID; }
   b->dims = plan.dims;
   b->kkt_doubles = plan.kkt_doubles;
-  // smallest spill mode whose LDS part fits one CU
-  int mode = 0;
   size_t nl = 0, ng = 0;
-  for (; mode < omgx::WS_MODES; ++mode) {
-    omgx::work_split(plan.dims, plan.kkt_doubles, mode, &nl, &ng);
-    if (nl * sizeof(double) <= (size_t)kLdsLimit) break;
-  }
+  const int mode = pick_mode(plan.dims, plan.kkt_doubles, &nl, &ng);
   if (mode == omgx::WS_MODES) {
     char buf[160];
     snprintf(buf, sizeof buf, "per-agent O(n_var) vectors (%zu B) exceed the %d B LDS of one CU", nl * sizeof(double), kLdsLimit);
@@ -456,23 +468,27 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
     return OMGX_E_TOOLARGE;
   }
   b->ws_mode = mode; b->lds_bytes = nl * sizeof(double); b->slab_doubles = ng;
+  if (mode != omgx::WS_LDS) b->dims.wave_ok = 0;      // the wave-level routines address the KKT store as LDS
   const omgx::Tables& H = plan.tables;
   const omgx::Dims& d = plan.dims;
-  const int n_cpl = t->cpl_ptr[d.n_leaf];
   UP(prog, 6 * d.n_prog); UP(knots, t->n_knots); UP(pp_ptr, t->n_pp + 1); UP(pm_coef, t->n_mono);
   UP(pm_ptr, t->n_mono + 1); UP(pm_atom, t->n_matom); UP(slot_pp, d.n_slots); UP(pm_rec, plan.pm_rec.size());
   UP(row_ptr, d.n_con + 2); UP(t_coef, d.n_terms); UP(t_slot, d.n_terms); UP(t_var, 3 * d.n_terms);
-  UP(order, d.N); UP(pos, d.N); UP(leaf_off, d.n_leaf + 1); UP(blk, d.N);
+  UP(order, d.N); UP(pos, d.N); UP(leaf_off, d.n_leaf + 1); UP(leaf_bw, plan.leaf_bw.size()); UP(blk, d.N);
   UP(eq_rows, d.n_eq); UP(eq_index, d.n_con);
-  UP(jr_ptr, d.n_con + 2); UP(jr_pos, d.nnz_j); UP(t_jidx, 3 * d.n_terms); UP(row_leaf, d.n_con + 1);
-  UP(jc_ptr, d.n_var + 1); UP(jc_row, d.nnz_j); UP(jc_ent, d.nnz_j);
-  UP(cpl_ptr, d.n_leaf + 1); UP(cpl_idx, n_cpl); UP(cpl_map, (d.n_leaf > 0 ? d.n_leaf : 1) * d.n_root);
-  UP(d_off, d.n_leaf + 1); UP(b_off, d.n_leaf > 0 ? d.n_leaf : 1);
+  UP(jr_ptr, d.n_con + 2); UP(jr_pos, d.nnz_j); UP(t_jidx, plan.t_jidx.size()); UP(row_leaf, d.n_con + 1);
+  UP(cpl_ptr, d.n_leaf + 1); UP(cpl_idx, plan.cpl_idx.size()); UP(cpl_map, plan.cpl_map.size());
+  UP(d_off, d.n_leaf + 1); UP(b_off, plan.b_off.size());
   UP(pair4, plan.pair4.size()); UP(eqe3, plan.eqe3.size());
-  UP(je_row, plan.je_row.size()); UP(jt_addr, plan.jt_addr.size()); UP(diag_addr, d.N);
+  UP(je_row, plan.je_row.size()); UP(jt_addr, plan.jt_addr.size()); UP(diag_addr, d.N); UP(tq_addr, plan.tq_addr.size());
   UP(h_addr, plan.h_addr.size()); UP(t_row, plan.t_row.size()); UP(t_pos, plan.t_pos.size()); UP(reg_w, d.N);
   UP(trec, plan.trec.size()); UP(hrec, plan.hrec.size()); UP(je_rp, plan.je_rp.size());
   UP(slot_rng, plan.slot_rng.size());
+  UP(je_ptr, plan.je_ptr.size()); UP(je_item, plan.je_item.size()); UP(jv_list, plan.jv_list.size());
+  UP(row_perm, plan.row_perm.size()); UP(cs_ptr, plan.cs_ptr.size()); UP(cs_rec, plan.cs_rec.size());
+  UP(obj_ent, plan.obj_ent.size());
+  UP(ka_rec, plan.ka_rec.size()); UP(kh_rec, plan.kh_rec.size()); UP(kg_rec, plan.kg_rec.size());
+  UP(ka_fix, plan.ka_fix.size()); UP(kg_fix, plan.kg_fix.size());
   return OMGX_OK;
 }
 
@@ -497,6 +513,29 @@ const char* omgx_status_string(int32_t s) {
   }
 }
 
+int omgx_plan_describe(const omgx_template* tpl, omgx_plan_info* info, int32_t* order) {
+  if (!info) { g_err = "null argument"; return OMGX_E_INVALID; }
+  int rc = check_template(tpl);
+  if (rc != OMGX_OK) return rc;
+  omgx::HostPlan plan;
+  if (!plan.build(*tpl)) { g_err = "inconsistent template: " + plan.error; return OMGX_E_INVALID; }
+  const omgx::Dims& d = plan.dims;
+  memset(info, 0, sizeof *info);
+  info->n_leaf = d.n_leaf; info->n_root = d.n_root; info->n_eq = d.n_eq; info->nnz_j = d.nnz_j;
+  info->kkt_doubles = plan.kkt_doubles; info->wave_path = d.wave_ok;
+  size_t nl = 0, ng = 0;
+  info->ws_mode = pick_mode(d, plan.kkt_doubles, &nl, &ng);
+  info->lds_bytes = (int64_t)(nl * sizeof(double));
+  for (int l = 0; l < d.n_leaf && l < OMGX_PLAN_MAX_LEAF; ++l) {
+    info->leaf_size[l] = plan.leaf_off[l + 1] - plan.leaf_off[l];
+    info->leaf_bw[l] = plan.leaf_bw[l];
+    info->leaf_cpl[l] = plan.cpl_ptr[l + 1] - plan.cpl_ptr[l];
+  }
+  info->n_pairs = d.n_pairs; info->ka_len = d.ka_len; info->kh_len = d.kh_len; info->kg_len = d.kg_len;
+  if (order) for (int q = 0; q < d.N; ++q) order[q] = plan.order[q];
+  return OMGX_OK;
+}
+
 void omgx_default_options(omgx_options* o) {
   o->tol = 1e-3; o->max_iter = 300; o->mu_init = 0.1; o->kappa_push = 1.0;
   o->nu_init = 100.0; o->scale_gmax = 100.0; o->warm_start = 0; o->kappa_warm = 1e-3;
@@ -504,7 +543,8 @@ void omgx_default_options(omgx_options* o) {
 }
 
 int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device, omgx_batch** out) {
-  if (!tpl || !out || n_agents <= 0) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  if (!tpl || !out || n_agents <= 0 || device < 0) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  { const int rc0 = check_template(tpl); if (rc0 != OMGX_OK) return rc0; }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) {
     g_err = "no usable HIP device (the solve path has no CPU fallback)";

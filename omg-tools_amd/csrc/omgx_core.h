@@ -52,6 +52,12 @@ struct Dims {
   int n_hess;        // number of HessRec records
   int rp_packed;     // 1: rows and positions fit 16 bits each, Tables::je_rp is valid
   int n_knots;       // total length of the knot vectors of the atoms program (copied to LDS per solve)
+  int wave_ok;       // 1: every panel of the KKT store fits one wave (register-resident factorisation, omgx_wave.h)
+  int n_jv;          // Jacobian entries whose value depends on x (the others are constant over a solve)
+  int ka_len, kh_len, kg_len;   // records per owner bin (longest bin) of the pair / Hessian / Gershgorin passes
+  int n_kafix, n_kgfix;         // targets whose run was cut (fix-up records)
+  int side_off, dump_off;       // side slots / per-lane dump slots behind the KKT store
+  int cs_parts;      // threads per column in the column sums J'w
 };
 
 // one parameter monomial coef * prod atoms[a_k] as a single 16-byte record (a_k = -1: unused): one
@@ -65,6 +71,13 @@ struct MonoRec { double coef; int16_t a0, a1, a2, a3; };
 struct TermRec { double coef; int32_t slot, row, j0, j1, j2; int16_t v0, v1, v2, pad; };
 struct HessRec { double coef; int32_t slot, row, ha0, ha1, ha2; int16_t v0, v1, v2, p0, p1, p2; };
 
+// Owner-computes records (omgx_plan.h): every sum of the solve has one owner thread and a fixed order.
+// JItem: one contribution coef * slot * x[va] * x[vb] (v = -1: factor 1) to a Jacobian entry.
+// HItem: one contribution of a nonlinear term to a KKT address (or, for the Gershgorin sums, to a
+// position): h = lambda_row * coef * slot * x[vthird]; kind 1 = both variables of the pair coincide.
+struct JItem { double coef; int32_t slot; int16_t va, vb; };
+struct HItem { double coef; int32_t slot, row, target; int16_t vthird, kind; };
+
 struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* prog; const double* knots;
   const int32_t* pp_ptr; const double* pm_coef; const int32_t* pm_ptr; const int32_t* pm_atom;
@@ -75,7 +88,6 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* order; const int32_t* pos; const int32_t* leaf_off; const int32_t* blk;
   const int32_t* eq_rows; const int32_t* eq_index;
   const int32_t* jr_ptr; const int32_t* jr_pos; const int32_t* t_jidx; const int32_t* row_leaf;
-  const int32_t* jc_ptr; const int32_t* jc_row; const int32_t* jc_ent;
   const int32_t* cpl_ptr; const int32_t* cpl_idx; const int32_t* cpl_map;
   const int32_t* d_off; const int32_t* b_off;   // panel offsets / leading dimensions inside the KKT store
   // precomputed KKT addresses (HostPlan): Jacobian pairs, t-column, diagonal, Hessian terms
@@ -88,6 +100,24 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const TermRec* trec;      // [n_terms] packed terms (rows 0..m-1 first, then the objective row m)
   const HessRec* hrec;      // [n_hess] packed terms with >= 2 variables
   const double* reg_w;   // [N] position order: inertia-correction class (+1 nonlinear root variable, -1 nonlinear leaf variable, else the weight itself: OMGX_DW_LINEAR)
+  const int32_t* leaf_bw;   // [n_leaf] half bandwidth of the leaf block in its (reverse Cuthill-McKee) order
+  const int32_t* tq_addr;   // [n_var] KKT address of (t, q)
+  // owner-computes tables
+  const int32_t* je_ptr;    // [nnz_j + 1] items of every Jacobian entry
+  const JItem* je_item;
+  const int32_t* jv_list;   // [n_jv] entries that depend on x
+  const int32_t* row_perm;  // [n_con] rows, longest term list first
+  const int32_t* cs_ptr;    // [n_var + 1] column (position) -> its entries, row order
+  const int32_t* cs_rec;    // [.][2] {Jacobian entry, row}
+  const int32_t* obj_ent;   // [n_var] objective-row entry of the position (-1: none)
+  // ELL layout: record r of owner bin b at index r * OMGX_NBIN + b (coalesced across the lanes), a bin's
+  // records sorted by target; the target is stored only in the last record of its run (-1 in the others
+  // and in the padding): the owner adds every record to a running sum and stores / restarts where it sees one
+  const int32_t* ka_rec;    // [ka_len][OMGX_NBIN][4] pair records {entry a, entry b, KKT address, row}
+  const HItem* kh_rec;      // [kh_len][OMGX_NBIN] Hessian items (target = KKT address)
+  const HItem* kg_rec;      // [kg_len][OMGX_NBIN] Gershgorin items (target = position, N + k = side slot k)
+  const int32_t* ka_fix;    // [n_kafix][3] {KKT address, first side slot, number of side slots}: address += the slots, in order
+  const int32_t* kg_fix;    // [n_kgfix][3] the same for the Gershgorin sums (position)
 };
 
 struct Opts {
@@ -125,7 +155,13 @@ struct Opts {
 #endif
 #define OMGX_WARM_ZMIN   1e-8
 #define OMGX_MAX_LEAF    16
-#define OMGX_BMAT_DOUBLES 4      // sizeof(BMat) / 8
+#define OMGX_BMAT_DOUBLES 5      // sizeof(BMat) / 8
+#define OMGX_MIN_LEAF    8       // smaller components are gathered into one leaf
+#define OMGX_NBIN        512     // owner bins of the assembly passes (= threads of the solve workgroup)
+#define OMGX_REC_BATCH   8       // records an owner loads at a time (all in flight together)
+#define OMGX_RUN_CAP     16      // longest run of records summed by one owner (longer runs are cut, see omgx_plan.h)
+#define OMGX_WAVE_ROWS   64      // register rows of a panel the wave-level routines take (lanes)
+#define OMGX_WAVE_COLS   40      // columns (registers per lane)
 
 // Per-agent work arrays (LDS on the device, heap on the host port).
 struct Work {
@@ -274,7 +310,7 @@ struct CtxT {
   __device__ void add(double* p, double v) const { atomicAdd(p, v); }   // ds_add_f64 on LDS
   __device__ int lane() const { return threadIdx.x & 63; }
   __device__ int nlanes() const { return 64; }
-  __device__ int wave() const { return threadIdx.x >> 6; }
+  __device__ int wave() const { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }     // (provably wave-uniform: scalar branches)
   __device__ int nwaves() const { return blockDim.x >> 6; }
   // lanes of one wave run in lockstep; this only orders their memory traffic (LDS: in-order per
   // wave; spilled arrays in HBM: wait for the vector-memory counters as well)
@@ -460,6 +496,32 @@ OMGX_FN double term_coef(const Tables& T, const Work& w, int t) {
 
 OMGX_FN double rec_coef(const Work& w, double coef, int slot) { return slot < 0 ? coef : coef * w.slots[slot]; }
 
+// unscaled value of Jacobian entry e at xv: the sum of its items in table order (owner-computes: one
+// thread per entry, no atomics, the same rounding in every run)
+OMGX_FN double jac_entry(const Tables& T, const Work& w, int e, const double* xv) {
+  double s = 0.0;
+  for (int i = T.je_ptr[e]; i < T.je_ptr[e + 1]; ++i) {
+    const JItem q = T.je_item[i];
+    // (selects on clamped indices instead of branches: the loads of the items stay in flight together)
+    const double xs = w.slots[q.slot < 0 ? 0 : q.slot], xa = xv[q.va < 0 ? 0 : q.va], xb = xv[q.vb < 0 ? 0 : q.vb];
+    s += q.coef * (q.slot < 0 ? 1.0 : xs) * (q.va < 0 ? 1.0 : xa) * (q.vb < 0 ? 1.0 : xb);
+  }
+  return s;
+}
+
+// unscaled value of row r (r < m) at xv from the packed term records, term order
+OMGX_FN double row_value_rec(const Tables& T, const Work& w, int r, const double* xv) {
+  double g = 0.0;
+#pragma unroll 4
+  for (int t = T.row_ptr[r]; t < T.row_ptr[r + 1]; ++t) {
+    const TermRec q = T.trec[t];
+    const double xs = w.slots[q.slot < 0 ? 0 : q.slot];
+    const double x0 = xv[q.v0 < 0 ? 0 : q.v0], x1 = xv[q.v1 < 0 ? 0 : q.v1], x2 = xv[q.v2 < 0 ? 0 : q.v2];
+    g += q.coef * (q.slot < 0 ? 1.0 : xs) * (q.v0 < 0 ? 1.0 : x0) * (q.v1 < 0 ? 1.0 : x1) * (q.v2 < 0 ? 1.0 : x2);
+  }
+  return g;
+}
+
 // value of row r (unscaled) at the variable-order point xv
 OMGX_FN double row_value(const Tables& T, const Work& w, int r, const double* xv) {
   double g = 0.0;
@@ -544,8 +606,8 @@ struct Kkt {
 // Two workgroup barriers per 4 columns instead of two per column.
 // ---------------------------------------------------------------------------
 // offsets (not pointers) so that every access stays a provable LDS access (ds_* instead of flat_*)
-struct BMat { int a, ld, nfact, rows, npos, dinv, pan, cpl; };   // cpl: offset of the leaf's coupling index list (cpl_ptr[l])   // a: offset in kkt; dinv: offset in w.dinv (-1: none); pan: offset in w.col
-static_assert(sizeof(BMat) <= 4 * sizeof(double), "BMat larger than its LDS slot");
+struct BMat { int a, ld, nfact, rows, npos, dinv, pan, cpl, bw, pad_; };   // cpl: offset of the leaf's coupling index list (cpl_ptr[l])   // a: offset in kkt; dinv: offset in w.dinv (-1: none); pan: offset in w.col
+static_assert(sizeof(BMat) <= OMGX_BMAT_DOUBLES * sizeof(double), "BMat larger than its LDS slot");
 #define OMGX_NB 4
 #define OMGX_PAN_LD 5      // panel buffer row stride: U[4] + pad (odd: conflict-free row-per-lane access)
 #define OMGX_STAGE_LD 20   // per matrix: 4x4 block rows [16] + inverse pivots of the block [4]
@@ -573,6 +635,12 @@ OMGX_FN double rcp_pivot(double d) {
   return y;
 }
 #endif
+
+}  // namespace omgx
+#ifndef OMGX_HOST_PORT
+#include "omgx_wave.h"      // register-resident wave-level LDL' (device only)
+#endif
+namespace omgx {
 
 // 4x4 (or smaller) diagonal block LDL' from the stored lower entries
 struct Blk4 { double l10, l20, l21, l30, l31, l32, d0, d1, d2, d3, i0, i1, i2, i3; };
@@ -972,18 +1040,173 @@ OMGX_FN void kkt_describe(const C& c, const Dims& d, const Kkt& K, Work& w) {
     for (int l = 0; l < d.n_leaf; ++l) {
       BMat& M = Ms[l];
       M.a = K.T->d_off[l]; M.ld = K.ld(l); M.nfact = K.nl(l); M.rows = K.nl(l) + K.nc(l) + 1; M.npos = M.nfact;   // + the rhs row
-      M.dinv = K.T->leaf_off[l]; M.pan = pan; pan += OMGX_PAN_LD * M.rows; M.cpl = K.T->cpl_ptr[l];
+      M.dinv = K.T->leaf_off[l]; M.pan = pan; pan += OMGX_PAN_LD * M.rows; M.cpl = K.T->cpl_ptr[l]; M.bw = K.T->leaf_bw[l];
     }
     BMat& Mr = Ms[d.n_leaf];
-    Mr.a = K.T->d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr + 1; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0;
+    Mr.a = K.T->d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr + 1; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0; Mr.cpl = 0; Mr.bw = d.nr;
   }
   c.sync();
 }
+
+#ifndef OMGX_HOST_PORT
+// ---------------------------------------------------------------------------
+// Wave path (every panel of the store fits one wave, Dims::wave_ok): register-resident factorisation
+// (omgx_wave.h).  Leaf l is factorised by wave l % nwaves -- all leaves at once, no workgroup barrier inside
+// --, its Schur complement S_l = Wt Delta^{-1} Wt' is formed by the same wave on the matrix pipe
+// (16x16x4 fp64 MFMA tiles) and subtracted from the root in leaf order (one leaf per barrier-separated
+// round: fixed order of the sums); the root is factorised by wave 0.
+// ---------------------------------------------------------------------------
+OMGX_FN WPanel wpanel_leaf(const BMat& M) {
+  WPanel P; P.base = M.a; P.ld = M.ld; P.packed = 0; P.n = M.nfact; P.nreg = M.rows - 2; P.nvec = 2; P.npos = M.nfact; P.bw = M.bw;
+  return P;
+}
+OMGX_FN WPanel wpanel_root(const BMat& M, int n_root) {
+  WPanel P; P.base = M.a; P.ld = 0; P.packed = 1; P.n = M.nfact; P.nreg = M.nfact; P.nvec = 1; P.npos = n_root; P.bw = M.nfact;
+  return P;
+}
+
+template <class C>
+OMGX_FN int kkt_factor_wave(const C& c, const Dims& d, const Kkt& K, Work& w) {
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  const BMat* Ms = (const BMat*)w.col;
+  const int lane = c.lane(), wave = c.wave(), nw = c.nwaves();
+  const int koff = (int)(w.kkt - omgx_lds);            // the out-of-line wave routines address the LDS by offset
+  OMGX_TIC();
+  int badl = 0;
+#ifdef OMGX_PROFILE
+  const long long tw0_ = clock64();
+#endif
+  for (int l = wave; l < d.n_leaf; l += nw) {
+    const WPanel P = wpanel_leaf(Ms[l]);
+    // hyperplane leaves are banded (half bandwidth 5 in reverse Cuthill-McKee order): compile-time band of 8
+    badl |= (P.bw <= 8) ? wave_ldl<OMGX_WAVE_COLS, 8>(koff, P) : wave_ldl<OMGX_WAVE_COLS, OMGX_WAVE_COLS>(koff, P);
+    wave_fence();
+    const double dl = wave_dinv(w.kkt, P);
+    if (lane < P.n) w.dinv[Ms[l].dinv + lane] = dl;
+  }
+#ifdef OMGX_PROFILE
+  if (c.tid() == 0) { c.prof[PH_F_SCALE] += clock64() - tw0_; c.prof[PH_F_PARK] += 1; }      // raw leaf time of wave 0, number of factorisations
+#endif
+  if (c.rmax(badl ? 1.0 : 0.0) > 0.0) return 1;       // (two barriers: the panels and inverse pivots are visible)
+  OMGX_TOC(PH_F_LEAF);
+  double* R = K.R();
+  for (int base = 0; base < d.n_leaf; base += nw) {
+    const int l = base + wave;
+    v4d acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = acc00, acc11 = acc00;
+    int nc1 = 0, ci_b0 = 0, ci_b1 = 0, ci_a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ci_a[i] = 0;
+    if (l < d.n_leaf) {
+      const BMat M = Ms[l];
+      const int n = __builtin_amdgcn_readfirstlane(M.nfact), ld = __builtin_amdgcn_readfirstlane(M.ld);
+      nc1 = __builtin_amdgcn_readfirstlane(M.rows) - n;            // coupling rows + the right-hand-side row (last)
+      const double* Wt = w.kkt + __builtin_amdgcn_readfirstlane(M.a) + n * ld;
+      const double* di = w.dinv + __builtin_amdgcn_readfirstlane(M.dinv);
+      const int32_t* ci = K.T->cpl_idx + __builtin_amdgcn_readfirstlane(M.cpl);
+      // root positions of this lane's rows / columns (global table: requested before the MFMA loop)
+      const int cb0 = lane & 15, cb1 = 16 + (lane & 15);
+      ci_b0 = ci[cb0 < nc1 - 1 ? cb0 : 0]; ci_b1 = ci[cb1 < nc1 - 1 ? cb1 : 0];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ca = 16 * (i >> 2) + (lane >> 4) + 4 * (i & 3);
+        ci_a[i] = ca < nc1 - 1 ? ci[ca] : d.nr;
+      }
+      const int r0 = lane & 15, r1 = 16 + (lane & 15), q = lane >> 4;
+      const int r0c = r0 < nc1 ? r0 : nc1 - 1, r1c = r1 < nc1 ? r1 : nc1 - 1;
+      const bool two = nc1 > 16;
+      for (int j0 = 0; j0 < n; j0 += 4) {
+        const int j = j0 + q, jc = j < n ? j : n - 1;
+        const double w0 = Wt[r0c * ld + jc], w1 = Wt[r1c * ld + jc], dj = di[jc];       // unconditional loads
+        const double b0 = (r0 < nc1 && j < n) ? w0 : 0.0, b1 = (r1 < nc1 && j < n) ? w1 : 0.0;
+        acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(b0 * dj, b0, acc00, 0, 0, 0);
+        if (two) {
+          acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1 * dj, b0, acc10, 0, 0, 0);
+          acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1 * dj, b1, acc11, 0, 0, 0);
+        }
+      }
+    }
+    // subtract from the root, one leaf per round
+    const int lend = base + nw < d.n_leaf ? base + nw : d.n_leaf;
+    for (int lr = base; lr < lend; ++lr) {
+      if (l == lr) {
+        const int cb0 = lane & 15, cb1 = 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ca0 = (lane >> 4) + 4 * i, ca1 = 16 + ca0;
+          if (ca0 < nc1 && cb0 < nc1 - 1 && cb0 <= ca0) R[tri(ci_a[i], ci_b0)] -= acc00[i];
+          if (ca1 < nc1 && cb0 < nc1 - 1) R[tri(ci_a[4 + i], ci_b0)] -= acc10[i];
+          if (ca1 < nc1 && cb1 < nc1 - 1 && cb1 <= ca1) R[tri(ci_a[4 + i], ci_b1)] -= acc11[i];
+        }
+      }
+      c.sync();
+    }
+  }
+  OMGX_TOC(PH_F_SCHUR);
+  int badr = 0;
+  if (wave == 0) {
+    const WPanel P = wpanel_root(Ms[d.n_leaf], d.n_root);
+#ifdef OMGX_PROFILE
+    const long long tr0_ = clock64();
+#endif
+    badr = wave_ldl<OMGX_WAVE_COLS, OMGX_WAVE_COLS>(koff, P);
+#ifdef OMGX_PROFILE
+    if (c.tid() == 0) c.prof[PH_F_SWEEP] += clock64() - tr0_;      // raw root time
+#endif
+  }
+  const int bad = c.rmax(badr ? 1.0 : 0.0) > 0.0 ? 1 : 0;
+  OMGX_TOC(PH_F_ROOT);
+  return bad;
+}
+
+// the solve that goes with kkt_factor_wave: root backward substitution by wave 0, then every leaf wave
+// corrects its right-hand side by the root solution and substitutes backwards -- no workgroup barrier
+// inside a leaf, no atomics
+template <class C>
+OMGX_FN void kkt_solve_wave(const C& c, const Dims& d, const Kkt& K, Work& w, double* sol) {
+  const BMat* Ms = (const BMat*)w.col;
+  const int lane = c.lane(), wave = c.wave(), nw = c.nwaves();
+  const int koff = (int)(w.kkt - omgx_lds);
+  OMGX_TIC();
+  if (wave == 0) {
+    const WPanel P = wpanel_root(Ms[d.n_leaf], d.n_root);
+    const double dl = wave_dinv(w.kkt, P);
+    const double y = w.kkt[wrow(P, P.n) + (lane < P.n ? lane : 0)];           // L^{-1} r: the carried vector row
+    const double x = wave_bwd<OMGX_WAVE_COLS>(koff, P, dl, y * dl);
+    if (lane < P.n) sol[d.root_off + lane] = x;
+  }
+  c.sync();
+  OMGX_TOC(PH_K_ROOT);
+  double* xg = w.col + OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1) + wave * 64;      // gathered root solution of this wave's leaf
+  for (int l = wave; l < d.n_leaf; l += nw) {
+    const BMat M = Ms[l];
+    const WPanel P = wpanel_uniform(wpanel_leaf(M));
+    const int n = P.n, nc = P.nreg + 1 - P.n, ld = P.ld;          // (wave-uniform values: scalar loop bounds)
+    const int32_t* ci = K.T->cpl_idx + __builtin_amdgcn_readfirstlane(M.cpl);
+    if (lane < nc) xg[lane] = sol[d.root_off + ci[lane]];
+    wave_fence();
+    const int j = lane < n ? lane : 0;
+    const double* Wt = w.kkt + P.base + n * ld + j;
+    double acc = Wt[nc * ld];                          // L^{-1} r_l
+#pragma unroll 4
+    for (int a = 0; a < nc; ++a) acc = fma(-Wt[a * ld], xg[a], acc);
+    const int dv = __builtin_amdgcn_readfirstlane(M.dinv);
+    const double dl = w.dinv[dv + j];
+    const double x = wave_bwd<OMGX_WAVE_COLS>(koff, P, dl, acc * dl);
+    if (lane < n) sol[dv + lane] = x;
+    wave_fence();
+  }
+  c.sync();
+  OMGX_TOC(PH_K_BWD);
+}
+#endif
 
 // Factorise the assembled block-arrow matrix in place.  Returns 0 if the
 // inertia is (N positive, n_eq negative), 1 otherwise.
 template <class C>
 OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
+#ifndef OMGX_HOST_PORT
+  if (d.wave_ok) return kkt_factor_wave(c, d, K, w);
+#endif
   int bad = 0;
   OMGX_TIC();
   BMat* Ms = (BMat*)w.col;
@@ -1029,10 +1252,10 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   }
 #else
   {
-    // S = Wt Delta^{-1} Wt' per leaf as 16x16 MFMA tiles (K swept in steps of 4); leaves
-    // scatter into shared root entries, hence the LDS atomics
+    // S = Wt Delta^{-1} Wt' per leaf as 16x16 MFMA tiles (K swept in steps of 4), the tiles of one leaf
+    // dealt round-robin to the waves.  Different leaves add into the same root entries, so the leaves
+    // take turns (one barrier per leaf): plain read-modify-write, fixed order of the sums, no atomics.
     const int lane = c.lane();
-    int tile0 = 0;
     for (int l = 0; l < d.n_leaf; ++l) {
       const BMat M = Ms[l];                       // dimensions from LDS, not from the global plan tables
       // carried rows: nc - 1 coupling rows + the right-hand-side row (last), which maps to row nr of the root
@@ -1041,10 +1264,9 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
       const double* di = w.dinv + M.dinv;
       const int32_t* ci = K.T->cpl_idx + M.cpl;
       const int tn = (nc + 15) >> 4, nwm = c.nwaves() - 1;
-      // lower-triangular tile pairs (ti, tj <= ti) numbered consecutively and dealt round-robin
       int tile = 0;
       for (int ti = 0; ti < tn; ++ti) for (int tj = 0; tj <= ti; ++tj, ++tile) {
-        if (((tile0 + tile) & nwm) != c.wave()) continue;
+        if ((tile & nwm) != c.wave()) continue;
         typedef double v4d __attribute__((ext_vector_type(4)));
         v4d acc = {0.0, 0.0, 0.0, 0.0};
         const int ra = 16 * ti + (lane & 15), rb = 16 * tj + (lane & 15), q = lane >> 4;
@@ -1059,10 +1281,10 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
         const int cb = 16 * tj + (lane & 15);
         for (int i = 0; i < 4; ++i) {
           const int ca = 16 * ti + (lane >> 4) + 4 * i;
-          if (ca < nc && cb < nc - 1 && cb <= ca) c.add(R + tri(ca < nc - 1 ? ci[ca] : d.nr, ci[cb]), -acc[i]);
+          if (ca < nc && cb < nc - 1 && cb <= ca) R[tri(ca < nc - 1 ? ci[ca] : d.nr, ci[cb])] -= acc[i];
         }
       }
-      tile0 += tile;
+      c.sync();
     }
   }
 #endif
@@ -1148,6 +1370,9 @@ OMGX_FN void trsv_bwd4(const C& c, const double* A, Addr L, int n, double* y, co
 // sol: position order + equality multipliers.
 template <class C>
 OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double* sol) {
+#ifndef OMGX_HOST_PORT
+  if (d.wave_ok) { kkt_solve_wave(c, d, K, w, sol); return; }
+#endif
   double* yr = sol + d.root_off;
   // leaf dimensions from the matrix descriptors kkt_factor left in LDS (not from the global plan
   // tables: every look-up there is a dependent global load)
@@ -1174,27 +1399,19 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
   }
   c.sync();
   OMGX_TOC(PH_K_ROOT);
-  // leaves: y_l <- L^{-T} (y_l - Delta^{-1} Wt' x_r); the correction term item-parallel over
-  // (leaf, leaf column, chunk of 8 coupling rows)
-  {
-    int items = 0;
-    for (int l = 0; l < d.n_leaf; ++l) items += Ms[l].nfact * ((Ms[l].rows - 1 - Ms[l].nfact + 7) >> 3);
-    OMGX_PFOR(it, items) {
-      int l = 0, e = it;
-      for (;; ++l) { const int cnt = Ms[l].nfact * ((Ms[l].rows - 1 - Ms[l].nfact + 7) >> 3); if (e < cnt) break; e -= cnt; }
-      const BMat M = Ms[l];
-      const int n = M.nfact, nc = M.rows - 1 - M.nfact, ld = M.ld;
-      const int ch = e / n, j = e - ch * n, a0 = 8 * ch;
-      const double* Pn = w.kkt + M.a;
-      const int32_t* ci = K.T->cpl_idx + M.cpl;
-      double acc = 0.0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int a = a0 + q < nc ? a0 + q : nc - 1;
-        acc += (a0 + q < nc ? 1.0 : 0.0) * Pn[(n + a) * ld + j] * yr[ci[a]];
-      }
-      c.add(sol + M.dinv + j, -acc * w.dinv[M.dinv + j]);
-    }
+  // leaves: y_l <- L^{-T} (y_l - Delta^{-1} Wt' x_r); the correction term by one thread per leaf column
+  // (coupling rows in order: a fixed-order sum)
+  OMGX_PFOR(q, d.root_off) {
+    int l = 0;
+    while (q >= Ms[l].dinv + Ms[l].nfact) ++l;
+    const BMat M = Ms[l];
+    const int n = M.nfact, nc = M.rows - 1 - M.nfact, ld = M.ld, j = q - M.dinv;
+    const double* Pn = w.kkt + M.a + n * ld + j;
+    const int32_t* ci = K.T->cpl_idx + M.cpl;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int a = 0; a < nc; ++a) acc += Pn[a * ld] * yr[ci[a]];
+    sol[q] -= acc * w.dinv[q];
   }
   c.sync();
   OMGX_TOC(PH_K_LEAFRHS);
@@ -1259,25 +1476,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // warm start only from a converged previous solve; otherwise a cold start from x0
   const bool warm = o.warm_start && prev_status == 0;     // callers pass lam0 whenever warm_start is set
   const double kpush = warm ? o.kappa_warm : o.kappa_push;
-  // unscaled Jacobian entries and row values at x0, one thread per term (LDS atomics) ...
-  OMGX_PFOR(e, T.jr_ptr[m + 1]) w.jval[e] = 0.0;
-  OMGX_PFOR(r, m) w.hv[r] = 0.0;
-  c.sync();
-  OMGX_PFOR_U4(tt, T.row_ptr[m]) {
-    const TermRec q = T.trec[tt];
-    const double cf = rec_coef(w, q.coef, q.slot);
-    const int r = q.row;
-    if (q.v0 < 0) { c.add(w.hv + r, cf); continue; }
-    const double x0v = w.x[q.v0];
-    if (q.v1 < 0) { c.add(w.hv + r, cf * x0v); c.add(w.jval + q.j0, cf); continue; }
-    const double x1v = w.x[q.v1];
-    if (q.v2 < 0) {
-      c.add(w.hv + r, cf * x0v * x1v); c.add(w.jval + q.j0, cf * x1v); c.add(w.jval + q.j1, cf * x0v); continue;
-    }
-    const double x2v = w.x[q.v2];
-    c.add(w.hv + r, cf * x0v * x1v * x2v);
-    c.add(w.jval + q.j0, cf * x1v * x2v); c.add(w.jval + q.j1, cf * x0v * x2v); c.add(w.jval + q.j2, cf * x0v * x1v);
-  }
+  // unscaled Jacobian entries (one thread per entry) and row values (one thread per row) at x0 ...
+  OMGX_PFOR_U4(e, T.jr_ptr[m + 1]) w.jval[e] = jac_entry(T, w, e, w.x);
+  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_rec(T, w, r, w.x); }
   c.sync();
   OMGX_TOC(PH_S_JAC0);
   // ... then one thread per row: classification, gradient-based scale, phase-I weight
@@ -1312,18 +1513,6 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) w.jval[e] *= sc;
   }
   if (c.rmax(bad_local) > 0.0) { res.status = 3; return res; }
-  OMGX_PFOR(q, T.row_ptr[m + 1] - T.row_ptr[m]) {
-    const int tt = T.row_ptr[m] + q;
-    const int32_t* tv = T.t_var + 3 * tt;
-    if (tv[0] < 0) continue;
-    const double cf = term_coef(T, w, tt);
-    const int32_t* je = T.t_jidx + 3 * tt;
-    if (tv[1] < 0) { c.add(w.jval + je[0], cf); continue; }
-    const double x0v = w.x[tv[0]], x1v = w.x[tv[1]];
-    if (tv[2] < 0) { c.add(w.jval + je[0], cf * x1v); c.add(w.jval + je[1], cf * x0v); continue; }
-    const double x2v = w.x[tv[2]];
-    c.add(w.jval + je[0], cf * x1v * x2v); c.add(w.jval + je[1], cf * x0v * x2v); c.add(w.jval + je[2], cf * x0v * x1v);
-  }
   OMGX_TOC(PH_S_CLASS);
   double any_local = 0.0;
   OMGX_PFOR(r, m) if (w.vv[r] != 0.0) any_local = 1.0;
@@ -1379,47 +1568,66 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 
   for (it = 0; it <= o.max_iter; ++it) {
     OMGX_TIC();
-    // ---- Jacobian (scaled): one thread per term, entries accumulated with LDS atomics -------
+    // ---- Jacobian (scaled): one thread per entry; only the entries that depend on x ------------
     if (it > 0) {        // (iteration 0: left by the setup)
-    OMGX_PFOR(e, T.jr_ptr[m + 1]) w.jval[e] = 0.0;
-    c.sync();
-    OMGX_PFOR_U4(tt, T.row_ptr[m + 1]) {
-      const TermRec q = T.trec[tt];
-      if (q.v0 < 0) continue;
-      const int r = q.row;
-      const double sc = (r < m) ? ((w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r]) : 1.0;
-      if (sc == 0.0) continue;
-      const double cf = sc * rec_coef(w, q.coef, q.slot);
-      if (q.v1 < 0) { c.add(w.jval + q.j0, cf); continue; }
-      const double x0 = w.x[q.v0], x1 = w.x[q.v1];
-      if (q.v2 < 0) { c.add(w.jval + q.j0, cf * x1); c.add(w.jval + q.j1, cf * x0); continue; }
-      const double x2 = w.x[q.v2];
-      c.add(w.jval + q.j0, cf * x1 * x2); c.add(w.jval + q.j1, cf * x0 * x2); c.add(w.jval + q.j2, cf * x0 * x1);
+      OMGX_PFOR_U4(i, d.n_jv) {
+        const int e = T.jv_list[i];
+        const int r = d.rp_packed ? (int)((uint32_t)T.je_rp[e] >> 16) : T.je_row[e];
+        const double sc = (r < m) ? ((w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r]) : 1.0;
+        w.jval[e] = sc * jac_entry(T, w, e, w.x);
+      }
+    }
+    // per row: 1/s (-> ht) and Sigma = z/s (-> ds; stays there for the assembly)
+    OMGX_PFOR(r, m) {
+      const int ty = w.rtype[r];
+      const bool ineq = (ty == ROW_UPPER || ty == ROW_LOWER);
+      const double is = ineq ? 1.0 / w.s[r] : 0.0;
+      w.ht[r] = is; w.ds[r] = ineq ? w.z[r] * is : 0.0;
     }
     c.sync();
-    }
     OMGX_TOC(PH_JAC);
     // ---- dual residual, barrier gradient (position order), error measures -------
-    // one thread per Jacobian entry; sol <- J'z (+ grad f), gbar <- grad f, xt <- J'(1/s): the
-    // barrier gradient grad f + mu J'(1/s) is formed once mu is settled below
-    OMGX_PFOR(q, N) { w.sol[q] = 0.0; w.gbar[q] = 0.0; w.xt[q] = 0.0; }
-    c.sync();
-    OMGX_PFOR_U4(e, T.jr_ptr[m + 1]) {
-      int r, q;
-      if (d.rp_packed) { const int32_t rp = T.je_rp[e]; r = (int)((uint32_t)rp >> 16); q = rp & 0xffff; }
-      else { r = T.je_row[e]; q = T.jr_pos[e]; }
-      const double jv = w.jval[e];
-      if (jv == 0.0) continue;
-      if (r == m) { c.add(w.sol + q, jv); c.add(w.gbar + q, jv); }
-      else {
-        const int ty = w.rtype[r];
-        if (ty == ROW_UPPER || ty == ROW_LOWER) { c.add(w.sol + q, jv * w.z[r]); c.add(w.xt + q, jv / w.s[r]); }
-        else if (ty == ROW_EQ) c.add(w.sol + q, jv * w.z[r]);
+    // Column sums over the Jacobian, cs_parts threads per column, each over a strided share of the
+    // column's entries in row order; the shares are combined in part order (fixed-order sums):
+    //   dinv <- grad f + J'z (the dual residual; w.dinv is free until the factorisation),  gbar <- grad f,
+    //   xt <- J'(1/s),  sol <- J'(Sigma v) (the phase-I column of the KKT matrix; w.sol is free until the
+    //   Newton system is solved, also across the retries of the inertia correction)
+    // the barrier gradient grad f + mu J'(1/s) is formed once mu is settled below
+    {
+      const int parts = d.cs_parts;
+      double* part = w.kkt;                               // [n * parts][3] staging (the KKT store is idle here)
+      OMGX_PFOR(it2, n * parts) {
+        const int q = it2 / parts, k = it2 - q * parts;
+        double a_z = 0.0, a_s = 0.0, a_t = 0.0;
+#pragma unroll 2
+        for (int i = T.cs_ptr[q] + k; i < T.cs_ptr[q + 1]; i += parts) {
+          const int e = T.cs_rec[2 * i], r = T.cs_rec[2 * i + 1];
+          const double jv = w.jval[e];
+          a_z += jv * w.z[r]; a_s += jv * w.ht[r]; a_t += jv * (w.ds[r] * w.vv[r]);
+        }
+        if (parts == 1) {
+          const int eo = T.obj_ent[q];
+          const double gf = eo >= 0 ? w.jval[eo] : 0.0;
+          w.dinv[q] = gf + a_z; w.gbar[q] = gf; w.xt[q] = a_s; w.sol[q] = a_t;
+        } else {
+          part[3 * it2] = a_z; part[3 * it2 + 1] = a_s; part[3 * it2 + 2] = a_t;
+        }
       }
+      if (parts > 1) {
+        c.sync();
+        OMGX_PFOR(q, n) {
+          double a_z = 0.0, a_s = 0.0, a_t = 0.0;
+          for (int k = 0; k < parts; ++k) { const double* pp = part + 3 * (q * parts + k); a_z += pp[0]; a_s += pp[1]; a_t += pp[2]; }
+          const int eo = T.obj_ent[q];
+          const double gf = eo >= 0 ? w.jval[eo] : 0.0;
+          w.dinv[q] = gf + a_z; w.gbar[q] = gf; w.xt[q] = a_s; w.sol[q] = a_t;
+        }
+      }
+      if (c.tid() == 0) { w.gbar[N - 1] = 0.0; w.xt[N - 1] = 0.0; }
     }
     c.sync();
     double rd_max = 0.0;
-    OMGX_PFOR(q, n) rd_max = fmax(rd_max, fabs(w.sol[q]));
+    OMGX_PFOR(q, n) rd_max = fmax(rd_max, fabs(w.dinv[q]));
     double viol = 0.0, zh = 0.0, rE_max = 0.0, rE_sum = 0.0, vz = 0.0, lam_sum = 0.0, cnt = 0.0;
     OMGX_PFOR(r, m) {
       const int ty = w.rtype[r];
@@ -1517,30 +1725,48 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       OMGX_PFOR(i, kkt_doubles) w.kkt[i] = 0.0;
       c.sync();
       OMGX_TOC(PH_A_ZERO);
-      // J' Sigma J over precomputed (entry, entry, address) triples; Sigma staged in w.ds
-      OMGX_PFOR(r, m) {
-        const int ty = w.rtype[r];
-        w.ds[r] = (ty == ROW_UPPER || ty == ROW_LOWER) ? w.z[r] / w.s[r] : 0.0;
+      // J' Sigma J + Lagrangian Hessian, owner-computes: every KKT address belongs to one of OMGX_NBIN
+      // bins; a bin's pair records {entry a, entry b, address, row} and Hessian items are sorted by
+      // address, the owner sums each run in table order and stores it (Sigma = w.ds, set with the
+      // residuals).  No atomics: the same bits in every run, for every batch composition.
+      // (branch-free loop bodies -- the store of a record that does not end a segment goes to a dump slot
+      // behind the store -- and the records of a batch loaded first, all in flight together: left to itself
+      // the compiler issues every load right before its use, behind the previous LDS store, ~1000 cycles each)
+      for (int bin = c.tid(); bin < OMGX_NBIN; bin += c.nthr()) {
+        const int dump = d.dump_off + (bin & 63);       // (a slot per lane behind the store: nothing lives there)
+        struct PairRec { int32_t a, b, ad, r; };
+        const PairRec* recs = (const PairRec*)T.ka_rec;
+        double acc = 0.0;
+        for (int r0 = 0; r0 < d.ka_len; r0 += OMGX_REC_BATCH) {
+          PairRec q[OMGX_REC_BATCH];
+#pragma unroll
+          for (int i = 0; i < OMGX_REC_BATCH; ++i) q[i] = recs[(r0 + i) * OMGX_NBIN + bin];
+          double v[OMGX_REC_BATCH];
+#pragma unroll
+          for (int i = 0; i < OMGX_REC_BATCH; ++i) v[i] = w.ds[q[i].r] * w.jval[q[i].a] * w.jval[q[i].b];
+#pragma unroll
+          for (int i = 0; i < OMGX_REC_BATCH; ++i) {
+            acc += v[i];
+            w.kkt[q[i].ad >= 0 ? q[i].ad : dump] = acc;
+            acc = q[i].ad >= 0 ? 0.0 : acc;
+          }
+        }
       }
       c.sync();
-      OMGX_PFOR_U4(e, d.n_pairs) {
-        // one packed record per pair (a single 16-byte load, no dependent table look-ups) and an
-        // unconditional add: nothing to wait for between pairs, the loads of several pairs overlap
-        const int32_t* q = T.pair4 + 4 * e;
-        const int a = q[0], b = q[1], ad = q[2], r = q[3];
-        c.add(w.kkt + ad, w.ds[r] * w.jval[a] * w.jval[b]);
-      }
       OMGX_TOC(PH_A_PAIRS);
+      // cut runs: the side slots are added to their address, in order
+      OMGX_PFOR(i, d.n_kafix) {
+        const int32_t* f = T.ka_fix + 3 * i;
+        double a = w.kkt[f[0]];
+        for (int k = 0; k < f[2]; ++k) a += w.kkt[d.side_off + f[1] + k];
+        w.kkt[f[0]] = a;
+      }
+      // phase-I column: -J'(Sigma v) from the column sums, its diagonal from the rows
       double tt_acc = 0.0;
       if (use_t) {
-        OMGX_PFOR(e, T.jr_ptr[m]) {
-          const int r = T.je_row[e];
-          const double sv = w.ds[r] * w.vv[r];
-          if (sv != 0.0) c.add(w.kkt + T.jt_addr[e], -sv * w.jval[e]);
-        }
+        OMGX_PFOR(q, n) w.kkt[T.tq_addr[q]] = -w.sol[q];
         OMGX_PFOR(r, m) tt_acc += w.ds[r] * w.vv[r] * w.vv[r];
       }
-      OMGX_TOC(PH_A_TCOL);
       // equality rows straight into the root block
       OMGX_PFOR(i, d.n_eqe) {                                   // one thread per equality-row entry
         const int32_t* q = T.eqe3 + 3 * i;                     // {Jacobian entry, KKT address, row}
@@ -1552,33 +1778,57 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         if (use_t && w.rtype[r] == ROW_EQ) Rr[tri(d.n_root + k, d.n_root - 1)] = -w.vv[r];
         Rr[tri(d.n_root + k, d.n_root + k)] = -OMGX_DELTA_C;
       }
-      // Lagrangian Hessian: terms with >= 2 variables, weight = multiplier * signed scale
-      OMGX_PFOR_U4(i, d.n_hess) {                              // (row m = objective: weight 1)
-        const HessRec q = T.hrec[i];
-        const int r = q.row;
-        if (r < m && w.rtype[r] == ROW_FREE) continue;
-        const double lam = (r < m) ? w.z[r] * w.rho[r] : 1.0;
-        if (lam == 0.0) continue;
-        const double cf = lam * rec_coef(w, q.coef, q.slot);
-        if (q.v2 < 0) {
-          c.add(w.kkt + q.ha0, q.v0 == q.v1 ? 2.0 * cf : cf);
-          if (first_trial) {
-            if (q.v0 == q.v1) { if (cf < 0.0) c.add(w.xt + q.p0, -2.0 * cf); }
-            else { c.add(w.xt + q.p0, fabs(cf)); c.add(w.xt + q.p1, fabs(cf)); }
+      c.sync();
+      OMGX_TOC(PH_A_TCOL);
+      for (int bin = c.tid(); bin < OMGX_NBIN; bin += c.nthr()) {
+        const int dump = d.dump_off + (bin & 63);
+        {
+          // Lagrangian Hessian: terms with >= 2 variables, weight = multiplier * signed scale (row m = objective: 1)
+          double acc = 0.0;
+          for (int e0 = 0; e0 < d.kh_len; e0 += OMGX_REC_BATCH) {
+            HItem q[OMGX_REC_BATCH];
+#pragma unroll
+            for (int i = 0; i < OMGX_REC_BATCH; ++i) q[i] = T.kh_rec[(e0 + i) * OMGX_NBIN + bin];
+            double h[OMGX_REC_BATCH];
+#pragma unroll
+            for (int i = 0; i < OMGX_REC_BATCH; ++i) {
+              const int r = q[i].row < m ? q[i].row : 0;
+              const double lam = (q[i].row < m) ? ((w.rtype[r] != ROW_FREE) ? w.z[r] * w.rho[r] : 0.0) : 1.0;
+              const double xs = w.slots[q[i].slot < 0 ? 0 : q[i].slot], x3 = w.x[q[i].vthird < 0 ? 0 : q[i].vthird];
+              h[i] = (q[i].kind ? 2.0 : 1.0) * lam * q[i].coef * (q[i].slot < 0 ? 1.0 : xs) * (q[i].vthird < 0 ? 1.0 : x3);
+            }
+#pragma unroll
+            for (int i = 0; i < OMGX_REC_BATCH; ++i) {
+              acc += h[i];
+              const int st = q[i].target >= 0 ? q[i].target : dump;
+              w.kkt[st] += acc;
+              acc = q[i].target >= 0 ? 0.0 : acc;
+            }
           }
-        } else {
-          const double x0v = w.x[q.v0], x1v = w.x[q.v1], x2v = w.x[q.v2];
-          c.add(w.kkt + q.ha0, (q.v0 == q.v1 ? 2.0 : 1.0) * cf * x2v);   // pair (0,1)
-          c.add(w.kkt + q.ha1, (q.v0 == q.v2 ? 2.0 : 1.0) * cf * x1v);   // pair (0,2)
-          c.add(w.kkt + q.ha2, (q.v1 == q.v2 ? 2.0 : 1.0) * cf * x0v);   // pair (1,2)
-          if (first_trial) {
-            const double h01 = cf * x2v, h02 = cf * x1v, h12 = cf * x0v;
-            if (q.v0 == q.v1) { if (h01 < 0.0) c.add(w.xt + q.p0, -2.0 * h01); }
-            else { c.add(w.xt + q.p0, fabs(h01)); c.add(w.xt + q.p1, fabs(h01)); }
-            if (q.v0 == q.v2) { if (h02 < 0.0) c.add(w.xt + q.p0, -2.0 * h02); }
-            else { c.add(w.xt + q.p0, fabs(h02)); c.add(w.xt + q.p2, fabs(h02)); }
-            if (q.v1 == q.v2) { if (h12 < 0.0) c.add(w.xt + q.p1, -2.0 * h12); }
-            else { c.add(w.xt + q.p1, fabs(h12)); c.add(w.xt + q.p2, fabs(h12)); }
+        }
+        if (first_trial) {
+          // Gershgorin row sums of the Hessian, term by term (no cancellation), owner = position
+          double acc = 0.0;
+          for (int e0 = 0; e0 < d.kg_len; e0 += OMGX_REC_BATCH) {
+            HItem q[OMGX_REC_BATCH];
+#pragma unroll
+            for (int i = 0; i < OMGX_REC_BATCH; ++i) q[i] = T.kg_rec[(e0 + i) * OMGX_NBIN + bin];
+            double g[OMGX_REC_BATCH];
+#pragma unroll
+            for (int i = 0; i < OMGX_REC_BATCH; ++i) {
+              const int r = q[i].row < m ? q[i].row : 0;
+              const double lam = (q[i].row < m) ? ((w.rtype[r] != ROW_FREE) ? w.z[r] * w.rho[r] : 0.0) : 1.0;
+              const double xs = w.slots[q[i].slot < 0 ? 0 : q[i].slot], x3 = w.x[q[i].vthird < 0 ? 0 : q[i].vthird];
+              const double h = lam * q[i].coef * (q[i].slot < 0 ? 1.0 : xs) * (q[i].vthird < 0 ? 1.0 : x3);
+              g[i] = q[i].kind ? (h < 0.0 ? -2.0 * h : 0.0) : fabs(h);
+            }
+#pragma unroll
+            for (int i = 0; i < OMGX_REC_BATCH; ++i) {
+              acc += g[i];
+              const int tg = q[i].target;
+              if (tg >= N) w.kkt[d.side_off + (tg - N)] = acc; else if (tg >= 0) w.xt[tg] = acc;
+              acc = tg >= 0 ? 0.0 : acc;
+            }
           }
         }
       }
@@ -1586,6 +1836,15 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       kkt_rhs(c, d, T, w, t);
       tt_acc = use_t ? c.rsum(tt_acc) : 0.0;
       c.sync();
+      if (first_trial) {
+        OMGX_PFOR(i, d.n_kgfix) {
+          const int32_t* f = T.kg_fix + 3 * i;
+          double a = w.xt[f[0]];
+          for (int k = 0; k < f[2]; ++k) a += w.kkt[d.side_off + f[1] + k];
+          w.xt[f[0]] = a;
+        }
+        c.sync();
+      }
       OMGX_TOC(PH_A_REST);
       OMGX_PFOR(q, N) {
         // variables without a nonlinear term have zero rows in the Lagrangian Hessian: negative
@@ -1631,10 +1890,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     const double dt = w.sol[N - 1];
     double ap_l = 1.0, ad_l = 1.0, ymax = 0.0, gdx = 0.0;
     const double tau = fmax(OMGX_TAU_MIN, 1.0 - mu);
-    OMGX_PFOR(r, m) {
+    OMGX_PFOR(ir, m) {
+      const int r = T.row_perm[ir];
       const int ty = w.rtype[r];
       if (ty == ROW_UPPER || ty == ROW_LOWER) {
-        // (measured: spreading J dx over the entries with LDS atomics is slower than one thread per row)
         double jd = 0.0;
         for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) jd += w.jval[e] * w.sol[T.jr_pos[e]];
         const double dsr = -(jd - w.vv[r] * dt);
@@ -1672,26 +1931,18 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + alpha * w.sol[q]; }
       c.sync();
       tt = use_t ? w.xt[n] : 0.0;
-      // row values at the trial point: one thread per term, LDS atomics into ht
-      OMGX_PFOR(r, m) w.ht[r] = 0.0;
-      c.sync();
-      OMGX_PFOR_U4(tq, T.row_ptr[m]) {
-        const TermRec q = T.trec[tq];
-        double v = rec_coef(w, q.coef, q.slot);
-        if (q.v0 >= 0) { v *= w.xt[q.v0]; if (q.v1 >= 0) { v *= w.xt[q.v1]; if (q.v2 >= 0) v *= w.xt[q.v2]; } }
-        c.add(w.ht + q.row, v);
-      }
-      c.sync();
-      OMGX_TOC(PH_L_TERMS);
+      // row values at the trial point: one thread per row (long rows first), terms in table order
       double smin = 1e300, lnst = 0.0, rEt = 0.0;
-      OMGX_PFOR(r, m) {
+      OMGX_PFOR(i, m) {
+        const int r = T.row_perm[i];
         const int ty = w.rtype[r];
         if (ty == ROW_FREE) { w.ht[r] = 0.0; continue; }
-        const double h = w.rho[r] * (w.ht[r] - w.bnd[r]);
+        const double h = w.rho[r] * (row_value_rec(T, w, r, w.xt) - w.bnd[r]);
         w.ht[r] = h;
         if (ty == ROW_EQ) rEt += fabs(h - tt * w.vv[r]);
         else { const double st = tt * w.vv[r] - h; smin = fmin(smin, st); if (st > 0.0) lnst += log(st); }
       }
+      OMGX_TOC(PH_L_TERMS);
       {
         double rv[4] = {smin, lnst, rEt, row_value_share(c, T, w, m, w.xt)};
         c.template reduce_ops<2, 0, 0, 0>(rv);

@@ -1,7 +1,19 @@
-// omgx_plan.h -- turn an omgx_template (host pointers) into Dims + derived
-// tables (position maps, KKT block offsets).  Host-side only; shared by the HIP
-// library (which then uploads the tables) and by the CPU port.
+// omgx_plan.h -- from the flat NLP (omgx_template, host pointers) to everything the solve kernel works
+// from: the static block-arrow structure of the KKT matrix (which variables form leaves, which the
+// root), the permuted Jacobian structure, KKT addresses, and the owner-computes tables that make every
+// sum of the solve a fixed-order sum (no floating-point atomics anywhere).  Host-side only; shared by
+// the HIP library (which uploads the tables) and by the CPU port of the oracle.
+//
+// What it replaces in the reference: nothing one-to-one -- CasADi derives the sparsity of the
+// Lagrangian Hessian / constraint Jacobian (`basics/optilayer.py:49-60`, `expand=True`) and MUMPS does its
+// own symbolic analysis; this is the symbolic phase of the hand-written solver.
 #pragma once
+#include <algorithm>
+#include <functional>
+#include <numeric>
+#include <queue>
+#include <set>
+#include <string>
 #include <vector>
 #include "../../include/omgx.h"
 #include "omgx_core.h"
@@ -12,32 +24,199 @@ struct HostPlan {
   Dims dims;
   Tables tables;            // host pointers (into tpl and the vectors below)
   int kkt_doubles;
-  std::vector<int32_t> pos, blk, eq_index, d_off, b_off;
-  std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, h_addr, t_row, t_pos;
+  // ---- structure (built here; a caller-provided plan is not needed) ----------------------------
+  std::vector<int32_t> order, pos, blk, leaf_off, leaf_bw, eq_rows, eq_index;
+  std::vector<int32_t> jr_ptr, jr_pos, t_jidx, row_leaf, cpl_ptr, cpl_idx, cpl_map;
+  std::vector<int32_t> d_off, b_off;
+  // ---- addresses and packed records ---------------------------------------------------------------
+  std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, h_addr, t_row, t_pos, tq_addr;
   std::vector<double> reg_w;
   std::vector<MonoRec> pm_rec;
   std::vector<int32_t> je_rp, slot_rng;
   std::vector<TermRec> trec;
   std::vector<HessRec> hrec;
+  // ---- owner-computes tables ----------------------------------------------------------------------
+  std::vector<int32_t> je_ptr, jv_list, row_perm, cs_ptr, cs_rec, obj_ent;
+  std::vector<JItem> je_item;
+  std::vector<int32_t> ka_rec, ka_fix, kg_fix;
+  std::vector<HItem> kh_rec, kg_rec;
+  std::string error;
+
+  bool fail(const char* msg) { error = msg; return false; }
+
+  // ------------------------------------------------------------------------------------------------
+  // Block-arrow structure.  Variables are permuted into [leaf_0 | leaf_1 | ... | root | t]: no constraint
+  // row couples two different leaves (each obstacle's hyperplane variables form a leaf, the
+  // trajectory coefficients the root), so the condensed KKT matrix is block-arrow.  Root = variables of
+  // the equality rows + the caller's hint (`root_vars`: e.g. the vehicle's spline coefficients); without
+  // a hint, the highest-degree variables are moved to the root until every component fits one wave.
+  // Components smaller than 8 variables (every coefficient of the terminal slacks g*, which meets the rest
+  // of the problem through one trajectory coefficient only) are gathered into one extra leaf.  Inside a
+  // leaf the variables are ordered by reverse Cuthill-McKee: the hyperplane block of an obstacle is block
+  // tridiagonal by knot (degree-1 splines), its factor keeps that band and the factorisation skips
+  // everything outside it.
+  // ------------------------------------------------------------------------------------------------
+  bool build_structure(const omgx_template& t) {
+    const int n = t.n_var, m = t.n_con;
+    std::vector<std::vector<int>> rows_vars(m + 1);
+    for (int r = 0; r <= m; ++r) {
+      std::set<int> s;
+      for (int tt = t.row_ptr[r]; tt < t.row_ptr[r + 1]; ++tt)
+        for (int k = 0; k < 3; ++k) { const int v = t.t_var[3 * tt + k]; if (v >= n) return fail("term variable out of range"); if (v >= 0) s.insert(v); }
+      rows_vars[r].assign(s.begin(), s.end());
+    }
+    std::vector<std::vector<int>> obj_cpl;       // nonlinear objective terms couple their variables like a row
+    for (int tt = t.row_ptr[m]; tt < t.row_ptr[m + 1]; ++tt) {
+      std::set<int> s;
+      for (int k = 0; k < 3; ++k) if (t.t_var[3 * tt + k] >= 0) s.insert(t.t_var[3 * tt + k]);
+      if (s.size() > 1) obj_cpl.emplace_back(s.begin(), s.end());
+    }
+    eq_rows.assign(t.eq_rows, t.eq_rows + t.n_eq);
+    eq_index.assign(m, -1);
+    for (int k = 0; k < t.n_eq; ++k) { if (eq_rows[k] < 0 || eq_rows[k] >= m) return fail("equality row out of range"); eq_index[eq_rows[k]] = k; }
+    std::vector<char> in_root(n, 0);
+    for (int r : eq_rows) for (int v : rows_vars[r]) in_root[v] = 1;
+    for (int i = 0; i < t.n_root_vars; ++i) { const int v = t.root_vars[i]; if (v < 0 || v >= n) return fail("root hint out of range"); in_root[v] = 1; }
+    // adjacency of the variables (same row or same nonlinear objective term)
+    std::vector<std::set<int>> adj(n);
+    auto couple = [&](const std::vector<int>& vs) { for (int a : vs) for (int b : vs) if (a != b) adj[a].insert(b); };
+    for (int r = 0; r < m; ++r) couple(rows_vars[r]);
+    for (auto& vs : obj_cpl) couple(vs);
+    auto components = [&]() {
+      std::vector<int> comp(n, -1); std::vector<std::vector<int>> out;
+      for (int v = 0; v < n; ++v) {
+        if (in_root[v] || comp[v] >= 0) continue;
+        std::vector<int> cur; std::queue<int> q; q.push(v); comp[v] = (int)out.size();
+        while (!q.empty()) { const int a = q.front(); q.pop(); cur.push_back(a);
+          for (int b : adj[a]) if (!in_root[b] && comp[b] < 0) { comp[b] = (int)out.size(); q.push(b); } }
+        std::sort(cur.begin(), cur.end());
+        out.push_back(cur);
+      }
+      return out;
+    };
+    std::vector<std::vector<int>> comps = components();
+    if (t.n_root_vars == 0) {
+      // no hint: vertex separator by greedy removal of the highest-degree variable of an oversized component
+      for (;;) {
+        int big = -1;
+        for (size_t c = 0; c < comps.size(); ++c) if ((int)comps[c].size() > OMGX_WAVE_ROWS && (big < 0 || comps[c].size() > comps[big].size())) big = (int)c;
+        if (big < 0) break;
+        int best = -1, bdeg = -1;
+        for (int v : comps[big]) { int deg = 0; for (int b : adj[v]) if (!in_root[b]) ++deg; if (deg > bdeg) { bdeg = deg; best = v; } }
+        in_root[best] = 1;
+        comps = components();
+      }
+    }
+    std::vector<std::vector<int>> leaves; std::vector<int> small;
+    for (auto& c : comps) { if ((int)c.size() < OMGX_MIN_LEAF) small.insert(small.end(), c.begin(), c.end()); else leaves.push_back(c); }
+    std::sort(small.begin(), small.end());
+    if ((int)small.size() >= OMGX_MIN_LEAF) leaves.push_back(small); else for (int v : small) in_root[v] = 1;
+    if ((int)leaves.size() > OMGX_MAX_LEAF) return fail("more leaves than OMGX_MAX_LEAF");
+    // reverse Cuthill-McKee inside each leaf (restricted to the leaf's own variables)
+    leaf_bw.assign(leaves.size(), 0);
+    for (size_t l = 0; l < leaves.size(); ++l) {
+      std::vector<int>& lv = leaves[l];
+      std::set<int> inl(lv.begin(), lv.end());
+      auto deg = [&](int v) { int dg = 0; for (int b : adj[v]) if (inl.count(b)) ++dg; return dg; };
+      std::vector<int> out; std::set<int> seen;
+      while (out.size() < lv.size()) {
+        int start = -1;
+        for (int v : lv) if (!seen.count(v) && (start < 0 || deg(v) < deg(start))) start = v;
+        std::queue<int> q; q.push(start); seen.insert(start);
+        while (!q.empty()) {
+          const int a = q.front(); q.pop(); out.push_back(a);
+          std::vector<int> nb;
+          for (int b : adj[a]) if (inl.count(b) && !seen.count(b)) nb.push_back(b);
+          std::sort(nb.begin(), nb.end(), [&](int x, int y) { const int dx = deg(x), dy = deg(y); return dx != dy ? dx < dy : x < y; });
+          for (int b : nb) { seen.insert(b); q.push(b); }
+        }
+      }
+      std::reverse(out.begin(), out.end());
+      std::vector<int> where(n, -1);
+      for (size_t i = 0; i < out.size(); ++i) where[out[i]] = (int)i;
+      int bw = 0;
+      for (int v : out) for (int b : adj[v]) if (where[b] >= 0) bw = std::max(bw, std::abs(where[v] - where[b]));
+      lv = out; leaf_bw[l] = bw;
+    }
+    // order / positions
+    order.clear();
+    leaf_off.assign(1, 0);
+    for (auto& lv : leaves) { order.insert(order.end(), lv.begin(), lv.end()); leaf_off.push_back((int)order.size()); }
+    for (int v = 0; v < n; ++v) if (in_root[v]) order.push_back(v);
+    order.push_back(n);                               // t last
+    Dims& d = dims;
+    d.n_leaf = (int)leaves.size(); d.root_off = leaf_off.back(); d.n_root = n + 1 - d.root_off;
+    pos.assign(n + 1, -1);
+    for (int q = 0; q <= n; ++q) pos[order[q]] = q;
+    std::vector<int> leaf_of(n + 1, -1);
+    for (size_t l = 0; l < leaves.size(); ++l) for (int v : leaves[l]) leaf_of[v] = (int)l;
+    // per-row Jacobian structure in position order, term -> entry index
+    jr_ptr.assign(1, 0); jr_pos.clear(); t_jidx.assign(3 * (size_t)std::max(1, t.n_terms), -1); row_leaf.assign(m + 1, -1);
+    for (int r = 0; r <= m; ++r) {
+      std::vector<int> vs = rows_vars[r];
+      std::sort(vs.begin(), vs.end(), [&](int a, int b) { return pos[a] < pos[b]; });
+      std::set<int> ls;
+      for (int v : vs) if (leaf_of[v] >= 0) ls.insert(leaf_of[v]);
+      if (r < m && ls.size() > 1) return fail("a constraint row couples two leaves");
+      if (r < m && eq_index[r] >= 0 && !ls.empty()) return fail("an equality row touches a leaf variable");
+      row_leaf[r] = (r < m && !ls.empty()) ? *ls.begin() : -1;
+      const int base = (int)jr_pos.size();
+      for (int v : vs) jr_pos.push_back(pos[v]);
+      for (int tt = t.row_ptr[r]; tt < t.row_ptr[r + 1]; ++tt)
+        for (int k = 0; k < 3; ++k) {
+          const int v = t.t_var[3 * tt + k];
+          if (v >= 0) t_jidx[3 * tt + k] = base + (int)(std::find(vs.begin(), vs.end(), v) - vs.begin());
+        }
+      jr_ptr.push_back((int)jr_pos.size());
+    }
+    for (auto& vs : obj_cpl) { std::set<int> ls; for (int v : vs) if (leaf_of[v] >= 0) ls.insert(leaf_of[v]); if (ls.size() > 1) return fail("the objective couples two leaves"); }
+    d.nnz_j = (int)jr_pos.size();
+    // root positions coupled to each leaf (rows of the B_l blocks); t always
+    cpl_ptr.assign(1, 0); cpl_idx.clear();
+    cpl_map.assign((size_t)std::max(1, d.n_leaf) * d.n_root, -1);
+    for (int l = 0; l < d.n_leaf; ++l) {
+      std::set<int> s;
+      for (int r = 0; r < m; ++r) if (row_leaf[r] == l) for (int v : rows_vars[r]) if (leaf_of[v] < 0) s.insert(pos[v] - d.root_off);
+      for (auto& vs : obj_cpl) { bool mine = false; for (int v : vs) if (leaf_of[v] == l) mine = true; if (mine) for (int v : vs) if (leaf_of[v] < 0) s.insert(pos[v] - d.root_off); }
+      s.insert(d.n_root - 1);
+      int k = 0;
+      for (int i : s) { cpl_map[(size_t)l * d.n_root + i] = k++; cpl_idx.push_back(i); }
+      cpl_ptr.push_back((int)cpl_idx.size());
+    }
+    return true;
+  }
+
+  // LPT assignment of weighted items to OMGX_NBIN bins (heaviest first, to the lightest bin)
+  static std::vector<int> lpt_bins(const std::vector<int>& weight) {
+    std::vector<int> idx(weight.size()), bin(weight.size(), 0);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return weight[a] > weight[b]; });
+    typedef std::pair<long, int> LB;     // (load, bin)
+    std::priority_queue<LB, std::vector<LB>, std::greater<LB>> heap;
+    for (int b = 0; b < OMGX_NBIN; ++b) heap.push(LB(0, b));
+    for (int i : idx) { LB lb = heap.top(); heap.pop(); bin[i] = lb.second; lb.first += weight[i]; heap.push(lb); }
+    return bin;
+  }
 
   bool build(const omgx_template& t) {
     Dims& d = dims;
+    d = Dims();
     d.n_var = t.n_var; d.n_par = t.n_par; d.n_con = t.n_con; d.n_atoms = t.n_atoms;
     d.n_slots = t.n_slots; d.n_terms = t.n_terms; d.n_prog = t.n_prog;
-    d.N = t.n_var + 1; d.n_leaf = t.n_leaf; d.n_root = t.n_root; d.n_eq = t.n_eq;
-    d.nnz_j = t.nnz_j; d.root_off = t.leaf_off[t.n_leaf]; d.nr = t.n_root + t.n_eq; d.n_knots = t.n_knots;
-    if (d.root_off + d.n_root != d.N) return false;
-    for (int k = 0; k < d.n_prog; ++k)                          // bspl_entry holds a triangle of degree <= 5
-      if (t.prog[6 * k] == OP_BSPL && (t.prog[6 * k + 3] < 0 || t.prog[6 * k + 3] > 5)) return false;
-    pos.assign(d.N, -1); blk.assign(d.N, -1);
-    for (int q = 0; q < d.N; ++q) { if (t.order[q] < 0 || t.order[q] >= d.N) return false; pos[t.order[q]] = q; }
-    if (t.order[d.N - 1] != t.n_var) return false;       // t must be the last position
+    d.N = t.n_var + 1; d.n_eq = t.n_eq; d.n_knots = t.n_knots;
+    if (t.n_var <= 0 || t.n_con < 0 || t.n_terms < 0 || t.n_var >= 32767) return fail("bad dimensions");
+    if (t.row_ptr[t.n_con + 1] != t.n_terms) return fail("row_ptr does not cover the terms");
+    for (int k = 0; k < d.n_prog; ++k)                          // bspl_row holds a triangle of degree <= 5
+      if (t.prog[6 * k] == OP_BSPL && (t.prog[6 * k + 3] < 0 || t.prog[6 * k + 3] > 5)) return fail("basis degree > 5");
+    if (!build_structure(t)) return false;
+    d.nr = d.n_root + d.n_eq;
+    blk.assign(d.N, -1);
     d.max_leaf = 0; d.max_cpl = 0;
     d_off.assign(d.n_leaf + 1, 0); b_off.assign(d.n_leaf > 0 ? d.n_leaf : 1, 0);
     int off = 0;
     for (int l = 0; l < d.n_leaf; ++l) {
-      const int n = t.leaf_off[l + 1] - t.leaf_off[l], nc = t.cpl_ptr[l + 1] - t.cpl_ptr[l];
-      for (int q = t.leaf_off[l]; q < t.leaf_off[l + 1]; ++q) blk[q] = l;
+      const int n = leaf_off[l + 1] - leaf_off[l], nc = cpl_ptr[l + 1] - cpl_ptr[l];
+      for (int q = leaf_off[l]; q < leaf_off[l + 1]; ++q) blk[q] = l;
       if (n > d.max_leaf) d.max_leaf = n;
       if (nc > d.max_cpl) d.max_cpl = nc;
       const int ld = n | 1;                        // odd leading dimension: conflict-free row-per-lane access
@@ -48,12 +227,19 @@ struct HostPlan {
     d_off[d.n_leaf] = off; off += (d.nr + 1) * (d.nr + 2) / 2;      // packed root + its right-hand-side row
     {
       int leaf_rows = 0;
-      for (int l = 0; l < d.n_leaf; ++l) leaf_rows += (t.leaf_off[l + 1] - t.leaf_off[l]) + (t.cpl_ptr[l + 1] - t.cpl_ptr[l]) + 1;
+      for (int l = 0; l < d.n_leaf; ++l) leaf_rows += (leaf_off[l + 1] - leaf_off[l]) + (cpl_ptr[l + 1] - cpl_ptr[l]) + 1;
       const int pr = leaf_rows > d.nr + 1 ? leaf_rows : d.nr + 1;
       d.col_doubles = (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + OMGX_PAN_LD * pr;
-      if (d.n_leaf > OMGX_MAX_LEAF) return false;
+      const int wave_scratch = OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1) + 16 * 64;      // kkt_solve_wave: 64 doubles per wave
+      if (d.col_doubles < wave_scratch) d.col_doubles = wave_scratch;
     }
-    kkt_doubles = off;
+    kkt_doubles = off;                           // (side and dump slots of the assembly are appended below)
+    // the wave-level register routines apply when every panel fits one wave
+    d.wave_ok = d.nr <= OMGX_WAVE_COLS ? 1 : 0;
+    for (int l = 0; l < d.n_leaf; ++l) {
+      const int n = leaf_off[l + 1] - leaf_off[l], nc = cpl_ptr[l + 1] - cpl_ptr[l];
+      if (n > OMGX_WAVE_COLS || n + nc - 1 > OMGX_WAVE_ROWS || nc + 1 > 32) d.wave_ok = 0;
+    }
     // packed parameter monomials
     d.mono_packed = (d.n_atoms < 32768) ? 1 : 0;
     pm_rec.assign(t.n_mono > 0 ? t.n_mono : 1, MonoRec{0.0, -1, -1, -1, -1});
@@ -67,65 +253,65 @@ struct HostPlan {
       if (nq > 2) r.a2 = (int16_t)t.pm_atom[q0 + 2];
       if (nq > 3) r.a3 = (int16_t)t.pm_atom[q0 + 3];
     }
-    eq_index.assign(d.n_con, -1);
-    for (int k = 0; k < d.n_eq; ++k) eq_index[t.eq_rows[k]] = k;
     Tables& T = tables;
+    T = Tables();
     T.prog = t.prog; T.knots = t.knots; T.pp_ptr = t.pp_ptr; T.pm_coef = t.pm_coef;
     T.pm_ptr = t.pm_ptr; T.pm_atom = t.pm_atom; T.slot_pp = t.slot_pp; T.row_ptr = t.row_ptr;
-    T.t_coef = t.t_coef; T.t_slot = t.t_slot; T.t_var = t.t_var; T.order = t.order;
-    T.pos = pos.data(); T.leaf_off = t.leaf_off; T.blk = blk.data(); T.eq_rows = t.eq_rows;
-    T.eq_index = eq_index.data(); T.jr_ptr = t.jr_ptr; T.jr_pos = t.jr_pos; T.t_jidx = t.t_jidx;
-    T.row_leaf = t.row_leaf; T.jc_ptr = t.jc_ptr; T.jc_row = t.jc_row; T.jc_ent = t.jc_ent;
-    T.cpl_ptr = t.cpl_ptr; T.cpl_idx = t.cpl_idx; T.cpl_map = t.cpl_map;
+    T.t_coef = t.t_coef; T.t_slot = t.t_slot; T.t_var = t.t_var; T.order = order.data();
+    T.pos = pos.data(); T.leaf_off = leaf_off.data(); T.leaf_bw = leaf_bw.data(); T.blk = blk.data(); T.eq_rows = eq_rows.data();
+    T.eq_index = eq_index.data(); T.jr_ptr = jr_ptr.data(); T.jr_pos = jr_pos.data(); T.t_jidx = t_jidx.data();
+    T.row_leaf = row_leaf.data();
+    T.cpl_ptr = cpl_ptr.data(); T.cpl_idx = cpl_idx.data(); T.cpl_map = cpl_map.data();
     T.d_off = d_off.data(); T.b_off = b_off.data();
     // ---- precomputed addresses -------------------------------------------------------
     auto tri = [](int i, int k) { return i * (i + 1) / 2 + k; };
     auto addr = [&](int p, int q) -> int32_t {               // p >= q, positions
       const int ro = d.root_off;
-      if (p < ro) { const int l = blk[p], o = t.leaf_off[l]; return d_off[l] + (p - o) * b_off[l] + (q - o); }
+      if (p < ro) { const int l = blk[p], o = leaf_off[l]; if (blk[q] != l) return -1; return d_off[l] + (p - o) * b_off[l] + (q - o); }
       if (q < ro) {
-        const int l = blk[q], n = t.leaf_off[l + 1] - t.leaf_off[l];
-        const int arow = t.cpl_map[l * d.n_root + (p - ro)];
+        const int l = blk[q], n = leaf_off[l + 1] - leaf_off[l];
+        const int arow = cpl_map[(size_t)l * d.n_root + (p - ro)];
         if (arow < 0) return -1;
-        return d_off[l] + (n + arow) * b_off[l] + (q - t.leaf_off[l]);
+        return d_off[l] + (n + arow) * b_off[l] + (q - leaf_off[l]);
       }
       return d_off[d.n_leaf] + tri(p - ro, q - ro);
     };
-    const int m = d.n_con;
+    const int m = d.n_con, n = d.n_var;
     je_row.assign(d.nnz_j > 0 ? d.nnz_j : 1, 0);
     jt_addr.assign(d.nnz_j > 0 ? d.nnz_j : 1, 0);
     for (int r = 0; r <= m; ++r)
-      for (int e = t.jr_ptr[r]; e < t.jr_ptr[r + 1]; ++e) {
+      for (int e = jr_ptr[r]; e < jr_ptr[r + 1]; ++e) {
         je_row[e] = r;
-        jt_addr[e] = (r < m && eq_index[r] < 0) ? addr(d.N - 1, t.jr_pos[e]) : 0;
-        if (jt_addr[e] < 0) return false;
+        jt_addr[e] = (r < m && eq_index[r] < 0) ? addr(d.N - 1, jr_pos[e]) : 0;
+        if (jt_addr[e] < 0) return fail("no slot for a phase-I column entry");
       }
+    tq_addr.assign(n, 0);
+    for (int q = 0; q < n; ++q) { tq_addr[q] = addr(d.N - 1, q); if (tq_addr[q] < 0) return fail("no slot for (t, q)"); }
     pair4.clear();
     for (int r = 0; r < m; ++r) {
       if (eq_index[r] >= 0) continue;
-      for (int a = t.jr_ptr[r]; a < t.jr_ptr[r + 1]; ++a)
-        for (int b2 = t.jr_ptr[r]; b2 <= a; ++b2) {
-          const int32_t ad = addr(t.jr_pos[a], t.jr_pos[b2]);
-          if (ad < 0) return false;
+      for (int a = jr_ptr[r]; a < jr_ptr[r + 1]; ++a)
+        for (int b2 = jr_ptr[r]; b2 <= a; ++b2) {
+          const int32_t ad = addr(jr_pos[a], jr_pos[b2]);
+          if (ad < 0) return fail("no slot for a Jacobian pair");
           pair4.push_back(a); pair4.push_back(b2); pair4.push_back(ad); pair4.push_back(r);
         }
     }
     eqe3.clear();
     for (int k = 0; k < d.n_eq; ++k) {
-      const int r = t.eq_rows[k];
-      for (int a = t.jr_ptr[r]; a < t.jr_ptr[r + 1]; ++a) {
-        eqe3.push_back(a); eqe3.push_back(d_off[d.n_leaf] + tri(d.n_root + k, t.jr_pos[a] - d.root_off)); eqe3.push_back(r);
+      const int r = eq_rows[k];
+      for (int a = jr_ptr[r]; a < jr_ptr[r + 1]; ++a) {
+        eqe3.push_back(a); eqe3.push_back(d_off[d.n_leaf] + tri(d.n_root + k, jr_pos[a] - d.root_off)); eqe3.push_back(r);
       }
     }
     d.n_eqe = (int)eqe3.size() / 3;
     if (eqe3.empty()) eqe3.assign(3, 0);
     d.n_pairs = (int)pair4.size() / 4;
-    if (pair4.empty()) pair4.assign(4, 0);
     diag_addr.assign(d.N, 0);
     for (int q = 0; q < d.N; ++q) diag_addr[q] = addr(q, q);
     t_row.assign(d.n_terms > 0 ? d.n_terms : 1, 0);
-    h_addr.assign(3 * (d.n_terms > 0 ? d.n_terms : 1), 0);
-    t_pos.assign(3 * (d.n_terms > 0 ? d.n_terms : 1), -1);
+    h_addr.assign(3 * (size_t)(d.n_terms > 0 ? d.n_terms : 1), 0);
+    t_pos.assign(3 * (size_t)(d.n_terms > 0 ? d.n_terms : 1), -1);
     for (int tt = 0; tt < d.n_terms; ++tt)
       for (int k = 0; k < 3; ++k) if (t.t_var[3 * tt + k] >= 0) t_pos[3 * tt + k] = pos[t.t_var[3 * tt + k]];
     for (int r = 0; r <= m; ++r)
@@ -138,27 +324,26 @@ struct HostPlan {
           if (va < 0 || vb < 0) continue;
           const int pa = pos[va], pb = pos[vb];
           const int32_t ad = pa >= pb ? addr(pa, pb) : addr(pb, pa);
-          if (ad < 0) return false;
+          if (ad < 0) return fail("no slot for a Hessian entry");
           h_addr[3 * tt + k] = ad;
         }
       }
     // flat tables of the parameter stage
-    slot_rng.assign(2 * (d.n_slots > 0 ? d.n_slots : 1), 0);
+    slot_rng.assign(2 * (size_t)(d.n_slots > 0 ? d.n_slots : 1), 0);
     for (int sl = 0; sl < d.n_slots; ++sl) { slot_rng[2 * sl] = t.pp_ptr[t.slot_pp[sl]]; slot_rng[2 * sl + 1] = t.pp_ptr[t.slot_pp[sl] + 1]; }
     T.slot_rng = slot_rng.data();
     // packed (row, position) of the Jacobian entries
     d.rp_packed = (m < 65535 && d.N < 65536) ? 1 : 0;
     je_rp.assign(d.nnz_j > 0 ? d.nnz_j : 1, 0);
     if (d.rp_packed)
-      for (int e = 0; e < d.nnz_j; ++e) je_rp[e] = (int32_t)(((uint32_t)je_row[e] << 16) | (uint32_t)t.jr_pos[e]);
+      for (int e = 0; e < d.nnz_j; ++e) je_rp[e] = (int32_t)(((uint32_t)je_row[e] << 16) | (uint32_t)jr_pos[e]);
     T.je_rp = je_rp.data();
     // packed term records
-    if (d.n_var >= 32767) return false;
     trec.assign(d.n_terms > 0 ? d.n_terms : 1, TermRec{0.0, -1, 0, 0, 0, 0, -1, -1, -1, 0});
     hrec.clear();
     for (int tt = 0; tt < d.n_terms; ++tt) {
       const int32_t* tv = t.t_var + 3 * tt;
-      const int32_t* je = t.t_jidx + 3 * tt;
+      const int32_t* je = t_jidx.data() + 3 * tt;
       TermRec& q = trec[tt];
       q.coef = t.t_coef[tt]; q.slot = t.t_slot[tt]; q.row = t_row[tt];
       q.j0 = je[0] < 0 ? 0 : je[0]; q.j1 = je[1] < 0 ? 0 : je[1]; q.j2 = je[2] < 0 ? 0 : je[2];
@@ -175,8 +360,8 @@ struct HostPlan {
     d.n_hess = (int)hrec.size();
     if (hrec.empty()) hrec.push_back(HessRec{0.0, -1, 0, 0, 0, 0, -1, -1, -1, 0, 0, 0});
     T.trec = trec.data(); T.hrec = hrec.data();
-    T.pair4 = pair4.data(); T.eqe3 = eqe3.data();
-    T.je_row = je_row.data(); T.jt_addr = jt_addr.data(); T.diag_addr = diag_addr.data();
+    T.eqe3 = eqe3.data();
+    T.je_row = je_row.data(); T.jt_addr = jt_addr.data(); T.diag_addr = diag_addr.data(); T.tq_addr = tq_addr.data();
     T.h_addr = h_addr.data(); T.t_row = t_row.data(); T.t_pos = t_pos.data(); T.pm_rec = pm_rec.data();
     reg_w.assign(d.N, OMGX_DW_LINEAR);
     for (int tt = 0; tt < t.row_ptr[m + 1]; ++tt) {
@@ -186,6 +371,197 @@ struct HostPlan {
       for (int k = 0; k < 3; ++k) if (tv[k] >= 0) reg_w[pos[tv[k]]] = (pos[tv[k]] < d.root_off) ? -1.0 : 1.0;
     }
     T.reg_w = reg_w.data();
+
+    // ---- owner-computes tables: every sum of the solve has one owner and a fixed order ---------------
+    // (1) Jacobian entries: entry e = sum of its items coef * slot * x[va] * x[vb] (term order)
+    {
+      std::vector<std::vector<JItem>> items(d.nnz_j > 0 ? d.nnz_j : 1);
+      for (int tt = 0; tt < d.n_terms; ++tt) {
+        const int32_t* tv = t.t_var + 3 * tt;
+        int nv = 0; while (nv < 3 && tv[nv] >= 0) ++nv;
+        for (int k = 0; k < nv; ++k) {
+          JItem it; it.coef = t.t_coef[tt]; it.slot = t.t_slot[tt]; it.va = -1; it.vb = -1;
+          int o = 0;
+          for (int k2 = 0; k2 < nv; ++k2) if (k2 != k) { (o == 0 ? it.va : it.vb) = (int16_t)tv[k2]; ++o; }
+          items[t_jidx[3 * tt + k]].push_back(it);
+        }
+      }
+      je_ptr.assign(1, 0); je_item.clear(); jv_list.clear();
+      for (int e = 0; e < d.nnz_j; ++e) {
+        bool varying = false;
+        for (auto& it : items[e]) { je_item.push_back(it); if (it.va >= 0) varying = true; }
+        je_ptr.push_back((int)je_item.size());
+        if (varying) jv_list.push_back(e);
+      }
+      d.n_jv = (int)jv_list.size();
+      if (je_item.empty()) je_item.push_back(JItem{0.0, -1, -1, -1});
+      if (jv_list.empty()) jv_list.push_back(0);
+      T.je_ptr = je_ptr.data(); T.je_item = je_item.data(); T.jv_list = jv_list.data();
+    }
+    // (2) rows by decreasing term count: the threads of the first pass get the long rows
+    {
+      row_perm.resize(m > 0 ? m : 1, 0);
+      std::iota(row_perm.begin(), row_perm.end(), 0);
+      std::stable_sort(row_perm.begin(), row_perm.begin() + m, [&](int a, int b) {
+        return (t.row_ptr[a + 1] - t.row_ptr[a]) > (t.row_ptr[b + 1] - t.row_ptr[b]); });
+      T.row_perm = row_perm.data();
+    }
+    // (3) column sums J'w: entries of every column (position) in row order, objective entry apart
+    {
+      std::vector<std::vector<std::pair<int, int>>> cols(n);
+      obj_ent.assign(n, -1);
+      for (int r = 0; r <= m; ++r)
+        for (int e = jr_ptr[r]; e < jr_ptr[r + 1]; ++e) {
+          const int q = jr_pos[e];
+          if (q >= n) return fail("Jacobian entry in the phase-I column");
+          if (r == m) obj_ent[q] = e; else cols[q].push_back(std::make_pair(e, r));
+        }
+      cs_ptr.assign(1, 0); cs_rec.clear();
+      for (int q = 0; q < n; ++q) { for (auto& er : cols[q]) { cs_rec.push_back(er.first); cs_rec.push_back(er.second); } cs_ptr.push_back((int)cs_rec.size() / 2); }
+      if (cs_rec.empty()) cs_rec.assign(2, 0);
+      int parts = OMGX_NBIN / (n > 0 ? n : 1);
+      if (parts < 1) parts = 1;
+      if (parts > 4) parts = 4;
+      while (parts > 1 && (size_t)4 * n * parts > (size_t)kkt_doubles) --parts;      // the partial sums are staged in the (idle) KKT store
+      d.cs_parts = parts;
+      T.cs_ptr = cs_ptr.data(); T.cs_rec = cs_rec.data(); T.obj_ent = obj_ent.data();
+    }
+    // (4) KKT assembly.  Every target (a KKT address; for the Gershgorin sums a position) has its records
+    // summed in table order.  A long run (the diagonal entry of a trajectory coefficient collects 47 pairs,
+    // the average owner has 21 records) is cut into segments of at most OMGX_RUN_CAP records; the first
+    // segment goes to the target, the others to side slots behind the store, and a fix-up list says which
+    // slots to add to which target, in order: still one fixed order per sum, but the longest owner loop is
+    // ~24 records instead of 47.  Segments are dealt to the OMGX_NBIN owners by LPT; an owner's records are
+    // stored "transposed" (ELL layout): record r of owner b sits at index r * OMGX_NBIN + b, so that thread b
+    // = lane b reads next to its neighbours; owners shorter than the longest are padded with null records.
+    // The target is stored only in the last record of a segment (-1 elsewhere): the owner adds every record
+    // to a running sum and stores / restarts where it sees one.
+    {
+      struct Seg { int target; std::vector<int> items; };
+      // items of one target in table order -> segments, side slots and fix-ups
+      auto cut = [&](const std::vector<std::pair<int, std::vector<int>>>& runs, std::vector<Seg>& segs, std::vector<int32_t>& fix, int& n_side) {
+        for (auto& run : runs) {
+          const std::vector<int>& it = run.second;
+          const int nseg = ((int)it.size() + OMGX_RUN_CAP - 1) / OMGX_RUN_CAP;
+          if (nseg > 1) { fix.push_back(run.first); fix.push_back(n_side); fix.push_back(nseg - 1); }
+          for (int sg = 0; sg < nseg; ++sg) {
+            Seg g; g.target = sg == 0 ? run.first : -2 - (n_side++);       // (-2 - k: side slot k)
+            const int lo = sg * (int)it.size() / nseg, hi = (sg + 1) * (int)it.size() / nseg;
+            g.items.assign(it.begin() + lo, it.begin() + hi);
+            segs.push_back(g);
+          }
+        }
+      };
+      auto deal = [&](const std::vector<Seg>& segs, std::vector<std::vector<std::pair<int, int>>>& per) {   // per[bin] = (item, target or -1)
+        std::vector<int> wgt(segs.size());
+        for (size_t i = 0; i < segs.size(); ++i) wgt[i] = (int)segs[i].items.size();
+        std::vector<int> bin = lpt_bins(wgt);
+        per.assign(OMGX_NBIN, {});
+        for (size_t i = 0; i < segs.size(); ++i)
+          for (size_t k = 0; k < segs[i].items.size(); ++k)
+            per[bin[i]].push_back(std::make_pair(segs[i].items[k], k + 1 == segs[i].items.size() ? segs[i].target : -1));
+      };
+      auto ell_len = [&](const std::vector<std::vector<std::pair<int, int>>>& per) {
+        size_t len = 0; for (auto& v : per) len = std::max(len, v.size());
+        return (int)((len + OMGX_REC_BATCH - 1) / OMGX_REC_BATCH * OMGX_REC_BATCH);      // (owner loops load OMGX_REC_BATCH records at a time)
+      };
+      const int side0 = kkt_doubles;                  // side slots start here; the store grows by them below
+      int n_side = 0;
+      // ---- pairs of J' Sigma J
+      {
+        std::vector<int> ord(d.n_pairs);
+        std::iota(ord.begin(), ord.end(), 0);
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return pair4[4 * x + 2] < pair4[4 * y + 2]; });
+        std::vector<std::pair<int, std::vector<int>>> runs;
+        for (int e : ord) { const int ad = pair4[4 * e + 2]; if (runs.empty() || runs.back().first != ad) runs.push_back(std::make_pair(ad, std::vector<int>())); runs.back().second.push_back(e); }
+        std::vector<Seg> segs; cut(runs, segs, ka_fix, n_side);
+        std::vector<std::vector<std::pair<int, int>>> per; deal(segs, per);
+        d.ka_len = ell_len(per);
+        ka_rec.assign((size_t)4 * OMGX_NBIN * std::max(1, d.ka_len), 0);
+        for (int bb = 0; bb < OMGX_NBIN; ++bb)
+          for (int r = 0; r < d.ka_len; ++r) {
+            int32_t* q = ka_rec.data() + 4 * ((size_t)r * OMGX_NBIN + bb);
+            q[0] = 0; q[1] = 0; q[2] = -1; q[3] = 0;
+            if (r < (int)per[bb].size()) {
+              const int e = per[bb][r].first, tg = per[bb][r].second;
+              q[0] = pair4[4 * e]; q[1] = pair4[4 * e + 1]; q[3] = pair4[4 * e + 3];
+              q[2] = tg <= -2 ? side0 + (-2 - tg) : tg;
+            }
+          }
+      }
+      // ---- Hessian items: one per (nonlinear term, variable pair), added to the store after the pairs
+      struct HI { HItem it; int pa, pb; };
+      std::vector<HI> his;
+      for (const HessRec& h : hrec) {
+        if (h.v0 < 0) continue;
+        const int16_t v[3] = {h.v0, h.v1, h.v2}, pp[3] = {h.p0, h.p1, h.p2};
+        const int32_t ha[3] = {h.ha0, h.ha1, h.ha2};
+        const int pr[3][3] = {{0, 1, 2}, {0, 2, 1}, {1, 2, 0}};
+        const int npair = h.v2 < 0 ? 1 : 3;
+        for (int k = 0; k < npair; ++k) {
+          HI x; x.it.coef = h.coef; x.it.slot = h.slot; x.it.row = h.row; x.it.target = ha[k];
+          x.it.vthird = h.v2 < 0 ? (int16_t)-1 : v[pr[k][2]];
+          x.it.kind = (v[pr[k][0]] == v[pr[k][1]]) ? 1 : 0;
+          x.pa = pp[pr[k][0]]; x.pb = pp[pr[k][1]];
+          his.push_back(x);
+        }
+      }
+      {
+        std::vector<int> oh(his.size());
+        std::iota(oh.begin(), oh.end(), 0);
+        std::stable_sort(oh.begin(), oh.end(), [&](int x, int y) { return his[x].it.target < his[y].it.target; });
+        std::vector<std::pair<int, std::vector<int>>> runs;
+        for (int i : oh) { const int ad = his[i].it.target; if (runs.empty() || runs.back().first != ad) runs.push_back(std::make_pair(ad, std::vector<int>())); runs.back().second.push_back(i); }
+        // (no cutting here: at most a handful of terms meet in one Hessian entry; a cut run would need its own fix-up)
+        std::vector<Seg> segs;
+        for (auto& run : runs) { Seg g; g.target = run.first; g.items = run.second; segs.push_back(g); }
+        std::vector<std::vector<std::pair<int, int>>> per; deal(segs, per);
+        d.kh_len = ell_len(per);
+        kh_rec.assign((size_t)OMGX_NBIN * std::max(1, d.kh_len), HItem{0.0, -1, 0, -1, -1, 0});
+        for (int bb = 0; bb < OMGX_NBIN; ++bb) for (size_t r = 0; r < per[bb].size(); ++r) {
+          HItem it = his[per[bb][r].first].it; it.target = per[bb][r].second;
+          kh_rec[r * OMGX_NBIN + bb] = it;
+        }
+      }
+      // ---- Gershgorin row sums: target = position (w.xt), side slots shared with the pairs' (the pass runs
+      // after the pair fix-up has consumed them)
+      {
+        struct GI { HItem it; int p; };
+        std::vector<GI> gis;
+        for (auto& x : his) {
+          GI g; g.it = x.it; g.p = x.pa; gis.push_back(g);
+          if (!x.it.kind) { g.p = x.pb; gis.push_back(g); }
+        }
+        std::vector<int> og(gis.size());
+        std::iota(og.begin(), og.end(), 0);
+        std::stable_sort(og.begin(), og.end(), [&](int x, int y) { return gis[x].p < gis[y].p; });
+        std::vector<std::pair<int, std::vector<int>>> runs;
+        for (int i : og) { const int q = gis[i].p; if (runs.empty() || runs.back().first != q) runs.push_back(std::make_pair(q, std::vector<int>())); runs.back().second.push_back(i); }
+        int n_side_g = 0;
+        std::vector<Seg> segs; cut(runs, segs, kg_fix, n_side_g);
+        if (n_side_g > n_side) n_side = n_side_g;
+        std::vector<std::vector<std::pair<int, int>>> per; deal(segs, per);
+        d.kg_len = ell_len(per);
+        kg_rec.assign((size_t)OMGX_NBIN * std::max(1, d.kg_len), HItem{0.0, -1, 0, -1, -1, 0});
+        for (int bb = 0; bb < OMGX_NBIN; ++bb) for (size_t r = 0; r < per[bb].size(); ++r) {
+          HItem it = gis[per[bb][r].first].it;
+          const int tg = per[bb][r].second;
+          it.target = tg <= -2 ? d.N + (-2 - tg) : tg;             // side slot k is encoded as N + k
+          kg_rec[r * OMGX_NBIN + bb] = it;
+        }
+      }
+      d.n_kafix = (int)ka_fix.size() / 3; d.n_kgfix = (int)kg_fix.size() / 3;
+      if (ka_fix.empty()) ka_fix.assign(3, 0);
+      if (kg_fix.empty()) kg_fix.assign(3, 0);
+      d.side_off = side0;
+      kkt_doubles = side0 + n_side + 64;              // + side slots + one dump slot per lane (owner passes store there
+                                                      //   whatever is not the end of a segment; distinct banks)
+      d.dump_off = side0 + n_side;
+      T.ka_rec = ka_rec.data(); T.kh_rec = kh_rec.data(); T.kg_rec = kg_rec.data();
+      T.ka_fix = ka_fix.data(); T.kg_fix = kg_fix.data();
+    }
+    if (pair4.empty()) pair4.assign(4, 0);
+    T.pair4 = pair4.data();
     return true;
   }
 };

@@ -1,0 +1,181 @@
+// omgx_wave.h -- wave-level, register-resident linear algebra for the block-arrow KKT solve (gfx950 only).
+//
+// One wave owns one small symmetric matrix (a leaf panel or the root block of the KKT store): lane i
+// holds row i in registers, a column is a register index.  The right-looking LDL' needs, per pair
+// (j, k > j), the entry u_kj of the pivot column in every lane -- a v_readlane broadcast from lane k --
+// and one fp64 FMA on the whole wave; there is no LDS traffic and no barrier inside the factorisation
+// (the LDS-resident routines it replaces, ldl_left4 / ldl_blocked, re-read every operand from LDS for
+// every block step and were bound by LDS issue: 61 k + 69 k cycles for four 36-column leaves and the
+// 39-column root of config 2).  All register indices are compile-time constants (full unrolling), the
+// run-time order n only cuts the loops short through wave-uniform branches.
+//
+// Storage convention (same as the routines replaced): factorised rows hold U = L D
+// (u_ij = l_ij d_j, the pivot d_i on the diagonal), carried rows hold W = B L^{-T}, inverse pivots in a
+// side array.  "Vector rows" are carried rows kept as one value per lane (lane k = column k) instead of
+// one row per lane: the phase-I coupling row and the right-hand side of a leaf, the right-hand side of
+// the root -- so that config 2's 36 + 28 register rows fill the 64 lanes exactly.
+#pragma once
+
+namespace omgx {
+
+// (lane: any wave-uniform value)
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A panel of the KKT store as one wave sees it.  Rows [0, n): the symmetric block (lower part stored);
+// rows [n, nreg): carried rows held one per lane; rows [nreg, nreg + nvec): carried rows held as lane
+// vectors.  Row r starts at base + r * ld + packed * r (r + 1) / 2 (row-major leaf panels: packed = 0;
+// packed lower root: ld = 0, packed = 1).  Pivots j < npos must be positive, the others negative.
+struct WPanel { int base, ld, packed, n, nreg, nvec, npos, bw; };    // bw: half bandwidth of the symmetric block (n - 1: dense)
+
+// The descriptor fields are the same in every lane but come from LDS (per-lane loads): without this the
+// compiler has to treat every loop bound of the routines below as divergent (exec-masked regions
+// instead of scalar branches, broadcast values spilled across them).
+__device__ __forceinline__ WPanel wpanel_uniform(const WPanel& Q) {
+  WPanel P;
+  P.base = __builtin_amdgcn_readfirstlane(Q.base); P.ld = __builtin_amdgcn_readfirstlane(Q.ld);
+  P.packed = __builtin_amdgcn_readfirstlane(Q.packed); P.n = __builtin_amdgcn_readfirstlane(Q.n);
+  P.nreg = __builtin_amdgcn_readfirstlane(Q.nreg); P.nvec = __builtin_amdgcn_readfirstlane(Q.nvec);
+  P.npos = __builtin_amdgcn_readfirstlane(Q.npos); P.bw = __builtin_amdgcn_readfirstlane(Q.bw);
+  return P;
+}
+
+__device__ __forceinline__ int wrow(const WPanel& P, int r) { return P.base + r * P.ld + P.packed * ((r * (r + 1)) >> 1); }
+
+// All dynamic LDS of the workgroup (HIP: every `extern __shared__` array starts at the same address): the
+// out-of-line routines below take offsets into it, so that their accesses stay ds_* instructions (a
+// pointer argument would be a generic pointer: flat_* instructions).
+extern __shared__ double omgx_lds[];
+
+// In-place LDL' of a panel by one wave, the matrix in registers: lane i holds row i, a[k] = A[i][k].
+// Straight-line code: all NC columns are processed whatever the order n is (the columns >= n work on
+// garbage that is never stored and raise no flag), the half bandwidth BW is a compile-time bound (columns further than
+// BW right of the pivot are skipped: u_kj = 0 there, nothing to subtract from any row), so all register
+// indices and all broadcast lanes are constants and there is no branch inside the factorisation --
+// every run-time loop bound tried (uniform scalar branches per chunk, rolled block loops with a shifting
+// register window and run-time broadcast lanes) made the compiler hoist, spill or relocate the chunks,
+// at 30-40 cycles per broadcast-and-FMA instead of the 12 of this form (tools/micro/bcast.hip: two
+// v_readlane + one fp64 FMA).  Details that matter (each measured on the device):
+//   * the descriptor must be provably wave-uniform (wpanel_uniform);
+//   * the four FMAs of a chunk are pinned behind their broadcasts by an empty volatile asm: without it
+//     the compiler issues the broadcasts of a whole column first and spills their SGPRs (v_writelane);
+//   * lane masks are formed from a laundered lane id where they are used, otherwise all NC of them are
+//     hoisted to the top and spilled;
+//   * a pivot of the wrong sign is only recorded; the caller looks at the flag at the end (the panel is
+//     garbage then, but nothing traps).
+// On return the panel holds U = L D (rows < n, lower part and diagonal) / W = B L^{-T} (carried rows), the
+// vector rows are stored forward-substituted.  Returns 1 if a pivot had the wrong sign.  `off`: offset of
+// the KKT store in the dynamic LDS (doubles).
+template <int NC, int BW>
+__device__ __forceinline__ int wave_ldl(int off, const WPanel Pin) {
+  double* A = omgx_lds + off;
+  const WPanel P = wpanel_uniform(Pin);
+  const int lane = threadIdx.x & 63;
+  const int n = P.n;
+  const bool has_row = lane < P.nreg;
+  const bool sym_row = lane < n;                       // a row of the symmetric block: only its lower part is stored
+  const int ra = wrow(P, has_row ? lane : 0);
+  double a[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {                       // unconditional loads (all in flight), masked afterwards
+    const double v = A[ra + (k < n ? k : n - 1)];
+    a[k] = (has_row && k < n) ? v : 0.0;
+  }
+  double yv0, yv1;
+  {
+    const int c = sym_row ? lane : 0;
+    const double v0 = A[wrow(P, P.nreg) + c], v1 = A[wrow(P, P.nreg + (P.nvec > 1 ? 1 : 0)) + c];
+    yv0 = (P.nvec > 0 && sym_row) ? v0 : 0.0;
+    yv1 = (P.nvec > 1 && sym_row) ? v1 : 0.0;
+  }
+  int bad = 0;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const double dj = readlane_d(a[j], j);
+    const bool okp = (j < P.npos) ? (dj > 0.0) : (dj < 0.0);
+    bad |= (j < n && !okp) ? 1 : 0;                    // (columns >= n: padding, whatever they compute is never stored)
+    const double inv = rcp_pivot(dj);
+    const double li = a[j] * inv;                      // l_ij of every row i > j (lanes <= j: unused upper part)
+    {
+      // the vector rows live on the lanes of the block rows: only rows below the pivot take part
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const double lm = ln > j ? li : 0.0;
+      // (columns >= n broadcast zero: their garbage may hold NaN, and 0 * NaN would reach the real lanes)
+      const double y0j = readlane_d(yv0, j), y1j = readlane_d(yv1, j);
+      yv0 = fma(-lm, j < n ? y0j : 0.0, yv0);
+      yv1 = fma(-lm, j < n ? y1j : 0.0, yv1);
+    }
+#pragma unroll
+    for (int c = j / 4; c < NC / 4; ++c) {             // columns in chunks of four
+      if (4 * c > j + BW) continue;                    // (compile time)
+      double s[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] = readlane_d(a[j], 4 * c + q);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = 4 * c + q;
+        if (k > j && k <= j + BW) a[k] = fma(-li, s[q], a[k]);
+      }
+      asm volatile("" : "+v"(a[4 * c]), "+v"(a[4 * c + 1]), "+v"(a[4 * c + 2]), "+v"(a[4 * c + 3]));
+    }
+  }
+  if (!bad) {
+    if (has_row) {
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        if (k < n && (!sym_row || k <= ln)) A[ra + k] = a[k];
+      }
+    }
+    if (sym_row) {
+      if (P.nvec > 0) A[wrow(P, P.nreg) + lane] = yv0;
+      if (P.nvec > 1) A[wrow(P, P.nreg + 1) + lane] = yv1;
+    }
+  }
+  return bad;
+}
+
+// inverse pivot of column `lane`, read back from the stored diagonal (after wave_ldl + wave_fence)
+__device__ __forceinline__ double wave_dinv(const double* A, const WPanel P) {
+  const int lane = threadIdx.x & 63;
+  const int c = lane < P.n ? lane : 0;
+  const double d = A[wrow(P, c) + c];
+  return lane < P.n ? rcp_pivot(d) : 0.0;
+}
+
+// x <- L^{-T} z for the factor stored in the panel (U = L D in LDS, left by wave_ldl): lane j reads
+// column j (u_ij, i > j), scales it by its own inverse pivot and the wave substitutes backwards with one
+// broadcast per row.  z: component `lane` (lanes >= n ignored); returns x_lane.
+template <int NC>
+__device__ __forceinline__ double wave_bwd(int off, const WPanel Pin, double dinvl, double z) {
+  const double* A = omgx_lds + off;
+  const WPanel P = wpanel_uniform(Pin);
+  const int lane = threadIdx.x & 63;
+  const int n = P.n;
+  double lt[NC];
+  const int c = lane < n ? lane : 0;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const double v = A[wrow(P, i < n ? i : n - 1) + c];
+    lt[i] = (i < n && lane < i) ? v * dinvl : 0.0;
+  }
+  double x = lane < n ? z : 0.0;
+#pragma unroll
+  for (int i = NC - 1; i >= 1; --i) {
+    if (i < n) x = fma(-lt[i], readlane_d(x, i), x);
+  }
+  return x;
+}
+
+}  // namespace omgx

@@ -16,7 +16,6 @@ import time
 
 import numpy as np
 
-from .template import SolverPlan
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libomgx.so')
@@ -31,16 +30,23 @@ _I32P, _F64P = C.POINTER(C.c_int32), C.POINTER(C.c_double)
 
 
 class CTemplate(C.Structure):
+    """`omgx_template` (include/omgx.h): the flat NLP; the solver plan is derived inside the library."""
     _fields_ = [(n, C.c_int32) for n in
                 ('n_var', 'n_par', 'n_con', 'n_atoms', 'n_slots', 'n_terms',
                  'n_prog', 'n_knots', 'n_pp', 'n_mono', 'n_matom')] + \
                [('prog', _I32P), ('knots', _F64P), ('pp_ptr', _I32P), ('pm_coef', _F64P),
                 ('pm_ptr', _I32P), ('pm_atom', _I32P), ('slot_pp', _I32P),
                 ('row_ptr', _I32P), ('t_coef', _F64P), ('t_slot', _I32P), ('t_var', _I32P)] + \
-               [(n, C.c_int32) for n in ('n_leaf', 'n_root', 'n_eq', 'nnz_j')] + \
-               [(n, _I32P) for n in ('order', 'leaf_off', 'eq_rows', 'jr_ptr', 'jr_pos',
-                                     't_jidx', 'row_leaf', 'jc_ptr', 'jc_row', 'jc_ent',
-                                     'cpl_ptr', 'cpl_idx', 'cpl_map')]
+               [('n_eq', C.c_int32), ('eq_rows', _I32P), ('n_root_vars', C.c_int32), ('root_vars', _I32P)]
+
+
+class CPlanInfo(C.Structure):
+    """`omgx_plan_info` (include/omgx.h)."""
+    _fields_ = [(n, C.c_int32) for n in ('n_leaf', 'n_root', 'n_eq', 'nnz_j', 'kkt_doubles',
+                                         'wave_path', 'ws_mode')] + \
+               [('lds_bytes', C.c_int64)] + \
+               [(n, C.c_int32 * 16) for n in ('leaf_size', 'leaf_bw', 'leaf_cpl')] + \
+               [(n, C.c_int32) for n in ('n_pairs', 'ka_len', 'kh_len', 'kg_len')]
 
 
 class COptions(C.Structure):
@@ -74,9 +80,23 @@ def options_from_problem(options):
     return kw
 
 
+ROOT_HINT = ('splines_seg',)
+
+
+def root_hint_vars(tpl, root_hint=ROOT_HINT):
+    """Variables handed to the library as the root of the block-arrow KKT matrix: the vehicle's spline
+    coefficients (`vehicles/vehicle.py:105-120`); every other variable meets the rest of the problem
+    through them."""
+    idx = []
+    for (label, name), (off, r, c) in tpl.var_layout.items():
+        if any(name.startswith(h) for h in root_hint):
+            idx.extend(range(off, off + r * c))
+    return np.array(idx, dtype=np.int32)
+
+
 def make_ctemplate(tpl, plan=None):
-    """(CTemplate, keepalive list).  `plan` defaults to SolverPlan(tpl)."""
-    plan = SolverPlan(tpl) if plan is None else plan
+    """(CTemplate, keepalive list).  `plan` is accepted for backward compatibility and ignored: the
+    solver plan is derived inside the library (csrc/omgx_plan.h)."""
     keep = []
 
     def i32(a):
@@ -98,17 +118,30 @@ def make_ctemplate(tpl, plan=None):
     ct.pp_ptr, ct.pm_coef = i32(tpl.pp_ptr), f64(np.r_[tpl.pm_coef, 0.0])
     ct.pm_ptr, ct.pm_atom = i32(tpl.pm_ptr), i32(np.r_[tpl.pm_atom, 0])
     ct.slot_pp = i32(np.r_[tpl.slot_pp, 0])
-    ct.row_ptr, ct.t_coef = i32(tpl.row_ptr), f64(tpl.t_coef)
-    ct.t_slot, ct.t_var = i32(tpl.t_slot), i32(tpl.t_var.reshape(-1))
-    ct.n_leaf, ct.n_root, ct.n_eq, ct.nnz_j = plan.n_leaf, plan.n_root, plan.n_eq, plan.nnz_j
-    ct.order, ct.leaf_off = i32(plan.order), i32(plan.leaf_off)
-    ct.eq_rows = i32(np.r_[plan.eq_rows, 0])
-    ct.jr_ptr, ct.jr_pos = i32(plan.jr_ptr), i32(plan.jr_pos)
-    ct.t_jidx, ct.row_leaf = i32(plan.t_jidx.reshape(-1)), i32(plan.row_leaf)
-    ct.jc_ptr, ct.jc_row, ct.jc_ent = i32(plan.jc_ptr), i32(plan.jc_row), i32(plan.jc_ent)
-    ct.cpl_ptr, ct.cpl_idx = i32(plan.cpl_ptr), i32(np.r_[plan.cpl_idx, 0])
-    ct.cpl_map = i32(plan.cpl_map.reshape(-1))
+    ct.row_ptr, ct.t_coef = i32(tpl.row_ptr), f64(np.r_[tpl.t_coef, 0.0])
+    ct.t_slot, ct.t_var = i32(np.r_[tpl.t_slot, 0]), i32(np.r_[tpl.t_var.reshape(-1), 0])
+    eq_rows = np.nonzero(np.isfinite(tpl.lb) & (tpl.lb == tpl.ub))[0]
+    ct.n_eq, ct.eq_rows = len(eq_rows), i32(np.r_[eq_rows, 0])
+    root = root_hint_vars(tpl)
+    ct.n_root_vars, ct.root_vars = len(root), i32(np.r_[root, 0])
     return ct, keep
+
+
+def describe_plan(tpl, lib=None):
+    """What the library derives from the template (host only, no device needed): dict with the leaf
+    sizes / bandwidths / coupling counts, the root size and `order` (position -> variable)."""
+    lib = lib or load_library()
+    ct, keep = make_ctemplate(tpl)
+    info = CPlanInfo()
+    order = np.zeros(tpl.n_var + 1, dtype=np.int32)
+    lib.omgx_plan_describe.argtypes = [C.POINTER(CTemplate), C.POINTER(CPlanInfo), C.c_void_p]
+    _check(lib, lib.omgx_plan_describe(C.byref(ct), C.byref(info), order.ctypes.data), 'omgx_plan_describe')
+    nl = info.n_leaf
+    return dict(n_leaf=nl, n_root=info.n_root, n_eq=info.n_eq, nnz_j=info.nnz_j, kkt_doubles=info.kkt_doubles,
+                wave_path=info.wave_path, ws_mode=info.ws_mode, lds_bytes=info.lds_bytes,
+                leaf_sizes=list(info.leaf_size[:nl]), leaf_bw=list(info.leaf_bw[:nl]),
+                leaf_cpl=list(info.leaf_cpl[:nl]), order=order, n_pairs=info.n_pairs,
+                ka_len=info.ka_len, kh_len=info.kh_len, kg_len=info.kg_len)
 
 
 _lib = None
@@ -185,9 +218,8 @@ class BatchSolver(object):
     def __init__(self, template, n_agents, device=0, options=None, plan=None):
         self.lib = load_library()
         self.template = template
-        self.plan = SolverPlan(template) if plan is None else plan
         self.n_agents = int(n_agents)
-        self._ct, self._keep = make_ctemplate(template, self.plan)
+        self._ct, self._keep = make_ctemplate(template)
         self._h = C.c_void_p()
         _check(self.lib, self.lib.omgx_batch_create(C.byref(self._ct), self.n_agents,
                                                     int(device), C.byref(self._h)),

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.omgx_version.restype = ctypes.c_int
-    assert lib.omgx_version() == 1
+    assert lib.omgx_version() == 2
     lib.omgx_status_string.restype = ctypes.c_char_p
     assert lib.omgx_status_string(0) == b'Solve_Succeeded'
 
@@ -51,15 +51,36 @@ def test_dimensions_table():
 
 
 def test_solver_plan_is_block_arrow(cfg2_small):
-    from omgtools.template import SolverPlan
+    """The plan is derived inside the library from the flat NLP (`omgx_plan_describe`, host only)."""
+    from omgtools.backend import describe_plan
     problem, _ = cfg2_small
     tpl = problem.father.template
-    plan = SolverPlan(tpl)
+    plan = describe_plan(tpl)
     # three hyperplane leaves + the gathered terminal slacks g0, g1 (each coefficient a singleton)
-    assert plan.n_leaf == 4 and [len(l) for l in plan.leaves] == [36, 36, 36, 28]
-    assert plan.n_root == 28 + 1
-    assert sorted(plan.order.tolist()) == list(range(tpl.n_var + 1)) and plan.order[-1] == tpl.n_var
-    assert plan.n_eq == 10
+    assert plan['n_leaf'] == 4 and plan['leaf_sizes'] == [36, 36, 36, 28]
+    assert plan['n_root'] == 28 + 1 and plan['n_eq'] == 10
+    order = plan['order']
+    assert sorted(order.tolist()) == list(range(tpl.n_var + 1)) and order[-1] == tpl.n_var
+    # hyperplane blocks of degree-1 splines are block tridiagonal by knot: (a0, a1, b) of neighbouring knots
+    assert plan['leaf_bw'][:3] == [5, 5, 5] and plan['leaf_bw'][3] == 0
+    assert plan['leaf_cpl'] == [29, 29, 29, 29]
+    assert plan['wave_path'] == 1 and plan['ws_mode'] == 0
+
+
+def test_plan_without_root_hint_finds_a_separator(cfg2_small):
+    """No structure hint from the caller: the library picks the root itself (highest-degree variables
+    first) and still gets leaves that fit one wave."""
+    import ctypes as C
+    import omgtools.backend as be
+    problem, _ = cfg2_small
+    tpl = problem.father.template
+    lib = be.load_library()
+    ct, keep = be.make_ctemplate(tpl)
+    ct.n_root_vars = 0
+    info = be.CPlanInfo()
+    lib.omgx_plan_describe.argtypes = [C.POINTER(be.CTemplate), C.POINTER(be.CPlanInfo), C.c_void_p]
+    assert lib.omgx_plan_describe(C.byref(ct), C.byref(info), None) == 0
+    assert info.n_leaf >= 3 and max(info.leaf_size[:info.n_leaf]) <= 64
 
 
 def test_obstacle_position_spline_closed_form():
@@ -119,10 +140,17 @@ def test_bad_arguments_return_error_codes(cfg2_small):
     opt = be.COptions()
     lib.omgx_default_options(C.byref(opt))
     assert (opt.tol, opt.max_iter, opt.warm_start) == (1e-3, 300, 0) and opt.dw_leaf_ratio_cold == 1.0
-    # a template whose plan is inconsistent is rejected, not executed
+    # an inconsistent template is rejected, not executed
     ct2, keep2 = be.make_ctemplate(problem.father.template)
-    ct2.n_root = ct2.n_root + 1
-    assert lib.omgx_batch_create(C.byref(ct2), 4, 0, C.byref(h)) in (-1, -2)      # invalid (or no device first)
+    ct2.n_var = -3
+    assert lib.omgx_batch_create(C.byref(ct2), 4, 0, C.byref(h)) == -1
+    info = be.CPlanInfo()
+    lib.omgx_plan_describe.argtypes = [C.POINTER(be.CTemplate), C.POINTER(be.CPlanInfo), C.c_void_p]
+    ct3, keep3 = be.make_ctemplate(problem.father.template)
+    bad_eq = np.array([10 ** 6], dtype=np.int32)
+    ct3.n_eq, ct3.eq_rows = 1, bad_eq.ctypes.data_as(C.POINTER(C.c_int32))
+    assert lib.omgx_plan_describe(C.byref(ct3), C.byref(info), None) == -1
+    assert b'equality row' in lib.omgx_last_error()
 
 
 def test_product_package_never_imports_the_oracle():
