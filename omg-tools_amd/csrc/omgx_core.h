@@ -76,6 +76,8 @@ struct HessRec { double coef; int32_t slot, row, ha0, ha1, ha2; int16_t v0, v1, 
 // HItem: one contribution of a nonlinear term to a KKT address (or, for the Gershgorin sums, to a
 // position): h = lambda_row * coef * slot * x[vthird]; kind 1 = both variables of the pair coincide.
 struct JItem { double coef; int32_t slot; int16_t va, vb; };
+// one term of a row for the row-value passes (24 bytes; padding records have coef 0)
+struct RowTerm { double coef; int32_t slot; int16_t v0, v1, v2, pad; };
 struct HItem { double coef; int32_t slot, row, target; int16_t vthird, kind; };
 
 struct Tables {   // read-only, shared by all agents (global memory)
@@ -107,6 +109,24 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const JItem* je_item;
   const int32_t* jv_list;   // [n_jv] entries that depend on x
   const int32_t* row_perm;  // [n_con] rows, longest term list first
+  // ELL tables of the row / column / entry owners: record `step` of owner i at index step * n_owner + i
+  // (coalesced across the lanes), padded with null records; *_glen[i >> 6] = steps the 64 owners of a
+  // group need (rounded up to the batch the loops load at a time)
+  const RowTerm* rt_ell;    // [rt_steps][n_con] terms of row row_perm[i]
+  const int32_t* rt_glen;
+  const int32_t* jp_ell;    // [jp_steps][n_con][2] {Jacobian entry, position} of row row_perm[i] (padding: entry nnz_j = 0.0)
+  const int32_t* jp_glen;
+  const int32_t* cs_ell;    // [cs_steps][n_var * cs_parts][2] {Jacobian entry, row} of column-sum owner o = j * cs_parts + k
+  const int32_t* cs_glen;
+  const int32_t* cs_col;    // [n_var] column (position) of slot j (columns by decreasing length)
+  const JItem* jv_ell;      // [jv_steps][n_jv] items of entry jv_list[i] (entries by decreasing item count)
+  const int32_t* jv_glen;
+  const int32_t* ja_list;   // [nnz_j] all entries by decreasing item count (the setup evaluates every entry once)
+  const JItem* ja_ell;      // [ja_steps][nnz_j]
+  const int32_t* ja_glen;
+  const int32_t* sl_list;   // [n_slots] slots by decreasing monomial count
+  const MonoRec* sl_ell;    // [sl_steps][n_slots] monomials of slot sl_list[i] (padding: coef 0)
+  const int32_t* sl_glen;
   const int32_t* cs_ptr;    // [n_var + 1] column (position) -> its entries, row order
   const int32_t* cs_rec;    // [.][2] {Jacobian entry, row}
   const int32_t* obj_ent;   // [n_var] objective-row entry of the position (-1: none)
@@ -195,7 +215,7 @@ OMGX_HD void work_split(const Dims& d, int kkt_doubles, int mode, size_t* lds, s
   nl += 64;                       // red
   const size_t rows = 8 * (size_t)d.n_con + (d.n_con + 1) / 2;
   (mode >= WS_ROWS_HBM ? ng : nl) += rows;
-  (mode >= WS_JAC_HBM ? ng : nl) += d.nnz_j;
+  (mode >= WS_JAC_HBM ? ng : nl) += d.nnz_j + 1;      // + one slot that stays 0.0 (padding records point at it)
   (mode >= WS_KKT_HBM ? ng : nl) += (size_t)kkt_doubles + d.col_doubles;
   *lds = nl; *hbm = ng;
 }
@@ -227,7 +247,7 @@ OMGX_HD void work_carve_split(Work& w, double* lds, double* hbm, const Dims& d, 
     w.s = p; p += d.n_con;         w.z = p; p += d.n_con;       w.ds = p; p += d.n_con;
     w.rtype = (int32_t*)p; p += (d.n_con + 1) / 2;
   }
-  if (MODE >= WS_JAC_HBM) { w.jval = g; g += d.nnz_j; } else { w.jval = p; p += d.nnz_j; }
+  if (MODE >= WS_JAC_HBM) { w.jval = g; g += d.nnz_j + 1; } else { w.jval = p; p += d.nnz_j + 1; }
   if (MODE >= WS_KKT_HBM) { w.kkt = g; g += kkt_doubles; w.col = g; g += d.col_doubles; }
   else { w.kkt = p; p += kkt_doubles; w.col = p; p += d.col_doubles; }
 }
@@ -483,8 +503,28 @@ OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, co
     c.sync();
     OMGX_TOC(PH_P_BSPL);
   }
-  if (d.mono_packed) { OMGX_PFOR(s, d.n_slots) w.slots[s] = mono_range_eval(T, T.slot_rng[2 * s], T.slot_rng[2 * s + 1], w.atoms); }
-  else { OMGX_PFOR(s, d.n_slots) w.slots[s] = pp_eval(T, T.slot_pp[s], w.atoms); }
+  if (d.mono_packed) {
+    // monomials of every slot from the ELL table, four at a time (all loads in flight), summed in table order
+    OMGX_PFOR(i, d.n_slots) {
+      const int L = T.sl_glen[i >> 6];
+      double tot = 0.0;
+      for (int s0 = 0; s0 < L; s0 += 4) {
+        MonoRec q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = T.sl_ell[(s0 + k) * d.n_slots + i];
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double a0 = w.atoms[q[k].a0 < 0 ? 0 : q[k].a0], a1 = w.atoms[q[k].a1 < 0 ? 0 : q[k].a1];
+          const double a2 = w.atoms[q[k].a2 < 0 ? 0 : q[k].a2], a3 = w.atoms[q[k].a3 < 0 ? 0 : q[k].a3];
+          v[k] = q[k].coef * (q[k].a0 < 0 ? 1.0 : a0) * (q[k].a1 < 0 ? 1.0 : a1) * (q[k].a2 < 0 ? 1.0 : a2) * (q[k].a3 < 0 ? 1.0 : a3);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tot += v[k];
+      }
+      w.slots[T.sl_list[i]] = tot;
+    }
+  } else { OMGX_PFOR(s, d.n_slots) w.slots[s] = pp_eval(T, T.slot_pp[s], w.atoms); }
   c.sync();
   OMGX_TOC(PH_P_SLOTS);
 }
@@ -507,6 +547,49 @@ OMGX_FN double jac_entry(const Tables& T, const Work& w, int e, const double* xv
     s += q.coef * (q.slot < 0 ? 1.0 : xs) * (q.va < 0 ? 1.0 : xa) * (q.vb < 0 ? 1.0 : xb);
   }
   return s;
+}
+
+// sum of the items of the entry in slot i of an ELL item table (four at a time, all loads in flight)
+OMGX_FN double jac_entry_ell(const JItem* ell, const int32_t* glen, int n_owner, const Work& w, int i, const double* xv) {
+  const int L = glen[i >> 6];
+  double sj = 0.0;
+  for (int s0 = 0; s0 < L; s0 += 4) {
+    JItem q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = ell[(s0 + k) * n_owner + i];
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double xs = w.slots[q[k].slot < 0 ? 0 : q[k].slot], xa = xv[q[k].va < 0 ? 0 : q[k].va], xb = xv[q[k].vb < 0 ? 0 : q[k].vb];
+      v[k] = q[k].coef * (q[k].slot < 0 ? 1.0 : xs) * (q[k].va < 0 ? 1.0 : xa) * (q[k].vb < 0 ? 1.0 : xb);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sj += v[k];
+  }
+  return sj;
+}
+
+// unscaled value of the row in slot i (row T.row_perm[i]) at xv: its terms from the ELL table, eight at a
+// time (all loads in flight together), summed in term order
+#define OMGX_ROW_BATCH 8
+OMGX_FN double row_value_ell(const Tables& T, const Work& w, int i, int m, const double* xv) {
+  const int L = T.rt_glen[i >> 6];
+  double g = 0.0;
+  for (int s0 = 0; s0 < L; s0 += OMGX_ROW_BATCH) {
+    RowTerm q[OMGX_ROW_BATCH];
+#pragma unroll
+    for (int k = 0; k < OMGX_ROW_BATCH; ++k) q[k] = T.rt_ell[(s0 + k) * m + i];
+    double v[OMGX_ROW_BATCH];
+#pragma unroll
+    for (int k = 0; k < OMGX_ROW_BATCH; ++k) {
+      const double xs = w.slots[q[k].slot < 0 ? 0 : q[k].slot];
+      const double x0 = xv[q[k].v0 < 0 ? 0 : q[k].v0], x1 = xv[q[k].v1 < 0 ? 0 : q[k].v1], x2 = xv[q[k].v2 < 0 ? 0 : q[k].v2];
+      v[k] = q[k].coef * (q[k].slot < 0 ? 1.0 : xs) * (q[k].v0 < 0 ? 1.0 : x0) * (q[k].v1 < 0 ? 1.0 : x1) * (q[k].v2 < 0 ? 1.0 : x2);
+    }
+#pragma unroll
+    for (int k = 0; k < OMGX_ROW_BATCH; ++k) g += v[k];
+  }
+  return g;
 }
 
 // unscaled value of row r (r < m) at xv from the packed term records, term order
@@ -1477,8 +1560,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   const bool warm = o.warm_start && prev_status == 0;     // callers pass lam0 whenever warm_start is set
   const double kpush = warm ? o.kappa_warm : o.kappa_push;
   // unscaled Jacobian entries (one thread per entry) and row values (one thread per row) at x0 ...
-  OMGX_PFOR_U4(e, T.jr_ptr[m + 1]) w.jval[e] = jac_entry(T, w, e, w.x);
-  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_rec(T, w, r, w.x); }
+  OMGX_PFOR(i, d.nnz_j) w.jval[T.ja_list[i]] = jac_entry_ell(T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
+  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell(T, w, i, m, w.x); }
+  if (c.tid() == 0) w.jval[d.nnz_j] = 0.0;               // the slot padding records point at
   c.sync();
   OMGX_TOC(PH_S_JAC0);
   // ... then one thread per row: classification, gradient-based scale, phase-I weight
@@ -1570,11 +1654,12 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     OMGX_TIC();
     // ---- Jacobian (scaled): one thread per entry; only the entries that depend on x ------------
     if (it > 0) {        // (iteration 0: left by the setup)
-      OMGX_PFOR_U4(i, d.n_jv) {
+      OMGX_PFOR(i, d.n_jv) {
         const int e = T.jv_list[i];
         const int r = d.rp_packed ? (int)((uint32_t)T.je_rp[e] >> 16) : T.je_row[e];
         const double sc = (r < m) ? ((w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r]) : 1.0;
-        w.jval[e] = sc * jac_entry(T, w, e, w.x);
+        const double sj = jac_entry_ell(T.jv_ell, T.jv_glen, d.n_jv, w, i, w.x);
+        w.jval[e] = sc * sj;
       }
     }
     // per row: 1/s (-> ht) and Sigma = z/s (-> ds; stays there for the assembly)
@@ -1596,32 +1681,29 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     {
       const int parts = d.cs_parts;
       double* part = w.kkt;                               // [n * parts][3] staging (the KKT store is idle here)
-      OMGX_PFOR(it2, n * parts) {
-        const int q = it2 / parts, k = it2 - q * parts;
+      OMGX_PFOR(o, n * parts) {                           // owner o = slot j * parts + part k
+        const int L = T.cs_glen[o >> 6];
         double a_z = 0.0, a_s = 0.0, a_t = 0.0;
-#pragma unroll 2
-        for (int i = T.cs_ptr[q] + k; i < T.cs_ptr[q + 1]; i += parts) {
-          const int e = T.cs_rec[2 * i], r = T.cs_rec[2 * i + 1];
-          const double jv = w.jval[e];
-          a_z += jv * w.z[r]; a_s += jv * w.ht[r]; a_t += jv * (w.ds[r] * w.vv[r]);
+        for (int s0 = 0; s0 < L; s0 += 8) {               // eight {entry, row} records at a time
+          int32_t e[8], r[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { const int32_t* q = T.cs_ell + 2 * ((s0 + k) * (n * parts) + o); e[k] = q[0]; r[k] = q[1]; }
+          double jv[8], vz[8], vs[8], vt[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { jv[k] = w.jval[e[k]]; vz[k] = w.z[r[k]]; vs[k] = w.ht[r[k]]; vt[k] = w.ds[r[k]] * w.vv[r[k]]; }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { a_z += jv[k] * vz[k]; a_s += jv[k] * vs[k]; a_t += jv[k] * vt[k]; }
         }
-        if (parts == 1) {
-          const int eo = T.obj_ent[q];
-          const double gf = eo >= 0 ? w.jval[eo] : 0.0;
-          w.dinv[q] = gf + a_z; w.gbar[q] = gf; w.xt[q] = a_s; w.sol[q] = a_t;
-        } else {
-          part[3 * it2] = a_z; part[3 * it2 + 1] = a_s; part[3 * it2 + 2] = a_t;
-        }
+        part[3 * o] = a_z; part[3 * o + 1] = a_s; part[3 * o + 2] = a_t;
       }
-      if (parts > 1) {
-        c.sync();
-        OMGX_PFOR(q, n) {
-          double a_z = 0.0, a_s = 0.0, a_t = 0.0;
-          for (int k = 0; k < parts; ++k) { const double* pp = part + 3 * (q * parts + k); a_z += pp[0]; a_s += pp[1]; a_t += pp[2]; }
-          const int eo = T.obj_ent[q];
-          const double gf = eo >= 0 ? w.jval[eo] : 0.0;
-          w.dinv[q] = gf + a_z; w.gbar[q] = gf; w.xt[q] = a_s; w.sol[q] = a_t;
-        }
+      c.sync();
+      OMGX_PFOR(j, n) {
+        double a_z = 0.0, a_s = 0.0, a_t = 0.0;
+        for (int k = 0; k < parts; ++k) { const double* pp = part + 3 * (j * parts + k); a_z += pp[0]; a_s += pp[1]; a_t += pp[2]; }
+        const int q = T.cs_col[j];
+        const int eo = T.obj_ent[q];
+        const double gf = eo >= 0 ? w.jval[eo] : 0.0;
+        w.dinv[q] = gf + a_z; w.gbar[q] = gf; w.xt[q] = a_s; w.sol[q] = a_t;
       }
       if (c.tid() == 0) { w.gbar[N - 1] = 0.0; w.xt[N - 1] = 0.0; }
     }
@@ -1797,11 +1879,15 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
               const double xs = w.slots[q[i].slot < 0 ? 0 : q[i].slot], x3 = w.x[q[i].vthird < 0 ? 0 : q[i].vthird];
               h[i] = (q[i].kind ? 2.0 : 1.0) * lam * q[i].coef * (q[i].slot < 0 ? 1.0 : xs) * (q[i].vthird < 0 ? 1.0 : x3);
             }
+            // (the old values are read first, together: a thread's targets are distinct, only the dump
+            // slot repeats, and what ends up there does not matter)
+            double old[OMGX_REC_BATCH];
+#pragma unroll
+            for (int i = 0; i < OMGX_REC_BATCH; ++i) old[i] = w.kkt[q[i].target >= 0 ? q[i].target : dump];
 #pragma unroll
             for (int i = 0; i < OMGX_REC_BATCH; ++i) {
               acc += h[i];
-              const int st = q[i].target >= 0 ? q[i].target : dump;
-              w.kkt[st] += acc;
+              w.kkt[q[i].target >= 0 ? q[i].target : dump] = old[i] + acc;
               acc = q[i].target >= 0 ? 0.0 : acc;
             }
           }
@@ -1826,7 +1912,8 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
             for (int i = 0; i < OMGX_REC_BATCH; ++i) {
               acc += g[i];
               const int tg = q[i].target;
-              if (tg >= N) w.kkt[d.side_off + (tg - N)] = acc; else if (tg >= 0) w.xt[tg] = acc;
+              double* dst = tg >= N ? w.kkt + d.side_off + (tg - N) : (tg >= 0 ? w.xt + tg : w.kkt + dump);
+              *dst = acc;
               acc = tg >= 0 ? 0.0 : acc;
             }
           }
@@ -1895,7 +1982,19 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       const int ty = w.rtype[r];
       if (ty == ROW_UPPER || ty == ROW_LOWER) {
         double jd = 0.0;
-        for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) jd += w.jval[e] * w.sol[T.jr_pos[e]];
+        {
+          const int L = T.jp_glen[ir >> 6];
+          for (int s0 = 0; s0 < L; s0 += 8) {
+            int32_t e[8], ps[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int32_t* q = T.jp_ell + 2 * ((s0 + k) * m + ir); e[k] = q[0]; ps[k] = q[1]; }
+            double jv[8], dx[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { jv[k] = w.jval[e[k]]; dx[k] = w.sol[ps[k]]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) jd += jv[k] * dx[k];
+          }
+        }
         const double dsr = -(jd - w.vv[r] * dt);
         w.ds[r] = dsr;
         const double dzr = mu / w.s[r] - w.z[r] - (w.z[r] / w.s[r]) * dsr;
@@ -1936,8 +2035,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       OMGX_PFOR(i, m) {
         const int r = T.row_perm[i];
         const int ty = w.rtype[r];
+        const double gv = row_value_ell(T, w, i, m, w.xt);      // (also for free rows: the loop bound is per wave)
         if (ty == ROW_FREE) { w.ht[r] = 0.0; continue; }
-        const double h = w.rho[r] * (row_value_rec(T, w, r, w.xt) - w.bnd[r]);
+        const double h = w.rho[r] * (gv - w.bnd[r]);
         w.ht[r] = h;
         if (ty == ROW_EQ) rEt += fabs(h - tt * w.vv[r]);
         else { const double st = tt * w.vv[r] - h; smin = fmin(smin, st); if (st > 0.0) lnst += log(st); }

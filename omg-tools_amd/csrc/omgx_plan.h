@@ -39,6 +39,11 @@ struct HostPlan {
   std::vector<int32_t> je_ptr, jv_list, row_perm, cs_ptr, cs_rec, obj_ent;
   std::vector<JItem> je_item;
   std::vector<int32_t> ka_rec, ka_fix, kg_fix;
+  std::vector<RowTerm> rt_ell;
+  std::vector<JItem> jv_ell, ja_ell;
+  std::vector<MonoRec> sl_ell;
+  std::vector<int32_t> ja_list, ja_glen, sl_list, sl_glen;
+  std::vector<int32_t> rt_glen, jp_ell, jp_glen, cs_ell, cs_glen, cs_col, jv_glen;
   std::vector<HItem> kh_rec, kg_rec;
   std::string error;
 
@@ -332,6 +337,21 @@ struct HostPlan {
     slot_rng.assign(2 * (size_t)(d.n_slots > 0 ? d.n_slots : 1), 0);
     for (int sl = 0; sl < d.n_slots; ++sl) { slot_rng[2 * sl] = t.pp_ptr[t.slot_pp[sl]]; slot_rng[2 * sl + 1] = t.pp_ptr[t.slot_pp[sl] + 1]; }
     T.slot_rng = slot_rng.data();
+    {
+      // monomials of the slots in ELL form (setup pass), slots by decreasing monomial count
+      const int no = d.n_slots;
+      sl_list.resize(std::max(1, no));
+      std::iota(sl_list.begin(), sl_list.end(), 0);
+      auto cnt = [&](int sl) { return slot_rng[2 * sl + 1] - slot_rng[2 * sl]; };
+      std::stable_sort(sl_list.begin(), sl_list.begin() + no, [&](int x, int y) { return cnt(x) > cnt(y); });
+      sl_glen.assign((no + 63) / 64 + 1, 0);
+      int steps = 0;
+      for (int i = 0; i < no; ++i) { const int len = (cnt(sl_list[i]) + 3) / 4 * 4; sl_glen[i >> 6] = std::max(sl_glen[i >> 6], len); steps = std::max(steps, len); }
+      sl_ell.assign((size_t)std::max(1, steps) * std::max(1, no), MonoRec{0.0, -1, -1, -1, -1});
+      if (d.mono_packed)
+        for (int i = 0; i < no; ++i) for (int k = slot_rng[2 * sl_list[i]]; k < slot_rng[2 * sl_list[i] + 1]; ++k) sl_ell[(size_t)(k - slot_rng[2 * sl_list[i]]) * no + i] = pm_rec[k];
+      T.sl_list = sl_list.data(); T.sl_ell = sl_ell.data(); T.sl_glen = sl_glen.data();
+    }
     // packed (row, position) of the Jacobian entries
     d.rp_packed = (m < 65535 && d.N < 65536) ? 1 : 0;
     je_rp.assign(d.nnz_j > 0 ? d.nnz_j : 1, 0);
@@ -394,6 +414,30 @@ struct HostPlan {
         if (varying) jv_list.push_back(e);
       }
       d.n_jv = (int)jv_list.size();
+      // x-dependent entries by decreasing item count (homogeneous groups of 64 owners), their items in ELL form
+      std::stable_sort(jv_list.begin(), jv_list.end(), [&](int x, int y) { return (je_ptr[x + 1] - je_ptr[x]) > (je_ptr[y + 1] - je_ptr[y]); });
+      {
+        const int no = d.n_jv;
+        jv_glen.assign((no + 63) / 64 + 1, 0);
+        int steps = 0;
+        for (int i = 0; i < no; ++i) { const int len = (je_ptr[jv_list[i] + 1] - je_ptr[jv_list[i]] + 3) / 4 * 4; jv_glen[i >> 6] = std::max(jv_glen[i >> 6], len); steps = std::max(steps, len); }
+        jv_ell.assign((size_t)std::max(1, steps) * std::max(1, no), JItem{0.0, -1, -1, -1});
+        for (int i = 0; i < no; ++i) for (int k = je_ptr[jv_list[i]]; k < je_ptr[jv_list[i] + 1]; ++k) jv_ell[(size_t)(k - je_ptr[jv_list[i]]) * no + i] = je_item[k];
+        T.jv_ell = jv_ell.data(); T.jv_glen = jv_glen.data();
+      }
+      {
+        // the same for all entries (setup pass)
+        const int no = d.nnz_j;
+        ja_list.resize(std::max(1, no));
+        std::iota(ja_list.begin(), ja_list.end(), 0);
+        std::stable_sort(ja_list.begin(), ja_list.begin() + no, [&](int x, int y) { return (je_ptr[x + 1] - je_ptr[x]) > (je_ptr[y + 1] - je_ptr[y]); });
+        ja_glen.assign((no + 63) / 64 + 1, 0);
+        int steps = 0;
+        for (int i = 0; i < no; ++i) { const int len = (je_ptr[ja_list[i] + 1] - je_ptr[ja_list[i]] + 3) / 4 * 4; ja_glen[i >> 6] = std::max(ja_glen[i >> 6], len); steps = std::max(steps, len); }
+        ja_ell.assign((size_t)std::max(1, steps) * std::max(1, no), JItem{0.0, -1, -1, -1});
+        for (int i = 0; i < no; ++i) for (int k = je_ptr[ja_list[i]]; k < je_ptr[ja_list[i] + 1]; ++k) ja_ell[(size_t)(k - je_ptr[ja_list[i]]) * no + i] = je_item[k];
+        T.ja_list = ja_list.data(); T.ja_ell = ja_ell.data(); T.ja_glen = ja_glen.data();
+      }
       if (je_item.empty()) je_item.push_back(JItem{0.0, -1, -1, -1});
       if (jv_list.empty()) jv_list.push_back(0);
       T.je_ptr = je_ptr.data(); T.je_item = je_item.data(); T.jv_list = jv_list.data();
@@ -405,6 +449,36 @@ struct HostPlan {
       std::stable_sort(row_perm.begin(), row_perm.begin() + m, [&](int a, int b) {
         return (t.row_ptr[a + 1] - t.row_ptr[a]) > (t.row_ptr[b + 1] - t.row_ptr[b]); });
       T.row_perm = row_perm.data();
+      // terms of every row (slot i = row row_perm[i]) in ELL form, eight per step
+      {
+        rt_glen.assign((m + 63) / 64 + 1, 0);
+        int steps = 0;
+        for (int i = 0; i < m; ++i) { const int r = row_perm[i]; const int len = (t.row_ptr[r + 1] - t.row_ptr[r] + 7) / 8 * 8; rt_glen[i >> 6] = std::max(rt_glen[i >> 6], len); steps = std::max(steps, len); }
+        rt_ell.assign((size_t)std::max(1, steps) * std::max(1, m), RowTerm{0.0, -1, -1, -1, -1, 0});
+        for (int i = 0; i < m; ++i) {
+          const int r = row_perm[i];
+          for (int tt = t.row_ptr[r]; tt < t.row_ptr[r + 1]; ++tt) {
+            RowTerm q; q.coef = t.t_coef[tt]; q.slot = t.t_slot[tt]; q.pad = 0;
+            q.v0 = (int16_t)t.t_var[3 * tt]; q.v1 = (int16_t)t.t_var[3 * tt + 1]; q.v2 = (int16_t)t.t_var[3 * tt + 2];
+            rt_ell[(size_t)(tt - t.row_ptr[r]) * m + i] = q;
+          }
+        }
+        T.rt_ell = rt_ell.data(); T.rt_glen = rt_glen.data();
+        // {Jacobian entry, position} of every row for J dx; padding points at the zero slot jval[nnz_j]
+        jp_glen.assign((m + 63) / 64 + 1, 0);
+        steps = 0;
+        for (int i = 0; i < m; ++i) { const int r = row_perm[i]; const int len = (jr_ptr[r + 1] - jr_ptr[r] + 7) / 8 * 8; jp_glen[i >> 6] = std::max(jp_glen[i >> 6], len); steps = std::max(steps, len); }
+        jp_ell.assign((size_t)2 * std::max(1, steps) * std::max(1, m), 0);
+        for (int i = 0; i < m; ++i) {
+          const int r = row_perm[i];
+          for (int st = 0; st < steps; ++st) {
+            int32_t* q = jp_ell.data() + 2 * ((size_t)st * m + i);
+            const int e = jr_ptr[r] + st;
+            if (e < jr_ptr[r + 1]) { q[0] = e; q[1] = jr_pos[e]; } else { q[0] = d.nnz_j; q[1] = 0; }
+          }
+        }
+        T.jp_ell = jp_ell.data(); T.jp_glen = jp_glen.data();
+      }
     }
     // (3) column sums J'w: entries of every column (position) in row order, objective entry apart
     {
@@ -425,6 +499,24 @@ struct HostPlan {
       while (parts > 1 && (size_t)4 * n * parts > (size_t)kkt_doubles) --parts;      // the partial sums are staged in the (idle) KKT store
       d.cs_parts = parts;
       T.cs_ptr = cs_ptr.data(); T.cs_rec = cs_rec.data(); T.obj_ent = obj_ent.data();
+      // owners o = slot j * parts + k (columns by decreasing length in the slots), records in ELL form
+      {
+        cs_col.resize(n);
+        std::iota(cs_col.begin(), cs_col.end(), 0);
+        std::stable_sort(cs_col.begin(), cs_col.end(), [&](int x, int y) { return (cs_ptr[x + 1] - cs_ptr[x]) > (cs_ptr[y + 1] - cs_ptr[y]); });
+        const int no = n * parts;
+        cs_glen.assign((no + 63) / 64 + 1, 0);
+        std::vector<std::vector<std::pair<int, int>>> own(no);
+        for (int j = 0; j < n; ++j) { const int q = cs_col[j]; for (int i = cs_ptr[q]; i < cs_ptr[q + 1]; ++i) own[j * parts + (i - cs_ptr[q]) % parts].push_back(std::make_pair(cs_rec[2 * i], cs_rec[2 * i + 1])); }
+        int steps = 0;
+        for (int o = 0; o < no; ++o) { const int len = ((int)own[o].size() + 7) / 8 * 8; cs_glen[o >> 6] = std::max(cs_glen[o >> 6], len); steps = std::max(steps, len); }
+        cs_ell.assign((size_t)2 * std::max(1, steps) * std::max(1, no), 0);
+        for (int o = 0; o < no; ++o) for (int st = 0; st < steps; ++st) {
+          int32_t* q = cs_ell.data() + 2 * ((size_t)st * no + o);
+          if (st < (int)own[o].size()) { q[0] = own[o][st].first; q[1] = own[o][st].second; } else { q[0] = d.nnz_j; q[1] = 0; }
+        }
+        T.cs_ell = cs_ell.data(); T.cs_glen = cs_glen.data(); T.cs_col = cs_col.data();
+      }
     }
     // (4) KKT assembly.  Every target (a KKT address; for the Gershgorin sums a position) has its records
     // summed in table order.  A long run (the diagonal entry of a trajectory coefficient collects 47 pairs,
