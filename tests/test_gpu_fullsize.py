@@ -6,7 +6,7 @@ size-independent properties (the oracle solves a handful of agents in seconds, n
   feasibility, multiplier signs, complementarity, stationarity of the Lagrangian -- at the tolerance
   the solver was asked for (`ipopt.tol = 1e-3` on gradient-scaled rows, `problems/problem.py:57`);
 * independence of the agents: a permuted batch gives the permuted result, and an agent solved alone
-  equals the same agent inside the batch (LDS atomics reorder sums: 1e-8, not bitwise);
+  equals the same agent inside the batch, bit for bit (every sum of the kernel has a fixed order);
 * the receding-horizon step keeps every plan feasible and consistent with the prediction.
 
 Config 2: 1024 x Holonomic (K=11, 3 circles); config 3: 4096 x Quadrotor (K=13, 5 moving circles, HBM
@@ -77,22 +77,20 @@ def test_config2_full_batch_optimality_and_independence():
     # permutation of the batch -> permutation of the result
     perm = np.random.default_rng(5).permutation(B)
     res_p = solver.solve(P['p'][perm], P['x0'][perm])
-    # (LDS atomics reorder sums from run to run: an agent on the edge of a decision may take one iteration
-    # more or less; all but a handful must agree to rounding, all of them to what the tolerance buys)
-    same = (res_p['status'] == res['status'][perm]) & (res_p['iters'] == res['iters'][perm])
-    assert same.mean() >= 0.99
-    d = np.abs(res_p['x'] - res['x'][perm]).max(axis=1)
-    assert (d[same] < 1e-8 * (1 + np.abs(res['x']).max())).mean() >= 0.99
+    # every sum of the kernel has a fixed order (owner-computes, no floating-point atomics) and an agent's
+    # arithmetic does not depend on where in the batch it sits: identical bits
+    assert np.array_equal(res_p['status'], res['status'][perm]) and np.array_equal(res_p['iters'], res['iters'][perm])
+    assert np.array_equal(res_p['x'], res['x'][perm]) and np.array_equal(res_p['lam_g'], res['lam_g'][perm])
+    res_again = solver.solve(P['p'], P['x0'])                     # and the same bits from run to run
+    assert np.array_equal(res_again['x'], res['x']) and np.array_equal(res_again['iters'], res['iters'])
     lo_s, hi_s = tpl.entry_range(problem.vehicles[0].label, 'splines_seg0', 'var')
-    both = (res_p['status'] == 0) & (res['status'][perm] == 0)
-    assert np.abs(res_p['x'][both, lo_s:hi_s] - res['x'][perm][both, lo_s:hi_s]).max() < 5e-2
     solver.close()
     # an agent alone == the same agent in the batch
     single = BatchSolver(tpl, 1, options=dict(tol=TOL, max_iter=300))
     for b in (0, 511, 1023):
         r1 = single.solve(P['p'][b:b + 1], P['x0'][b:b + 1])
-        assert r1['status'][0] == res['status'][b] and abs(int(r1['iters'][0]) - int(res['iters'][b])) <= 1
-        assert np.abs(r1['x'][0, lo_s:hi_s] - res['x'][b, lo_s:hi_s]).max() < 1e-3
+        assert r1['status'][0] == res['status'][b] and int(r1['iters'][0]) == int(res['iters'][b])
+        assert np.array_equal(r1['x'][0], res['x'][b])
     single.close()
 
 
@@ -154,13 +152,7 @@ def test_config3_and_5_full_batch(name, B, min_ok, n_check):
     half = np.arange(B // 2, B)
     perm = np.r_[np.arange(B // 2), rng.permutation(half)]
     res_p = solver.solve(P['p'][perm], P['x0'][perm])
-    assert (res_p['status'] == res['status'][perm]).mean() >= 0.995
-    # LDS atomics reorder sums from run to run; over a long ill-conditioned solve (> 100 iterations) that
-    # rounding noise can grow to the solver tolerance, so: (nearly) all agents agree to rounding, all
-    # of them to the accuracy the tolerance buys
-    both = ok[perm] & (res_p['status'] == 0)
-    diff = np.abs(res_p['x'][both] - res['x'][perm][both]).max(axis=1)
-    assert (diff < 1e-7 * (1 + np.abs(res['x'][ok]).max())).mean() >= 0.98
-    lo, hi = tpl.entry_range(problem.vehicles[0].label, 'splines_seg0', 'var')     # the output the reference consumes
-    assert np.abs(res_p['x'][both, lo:hi] - res['x'][perm][both, lo:hi]).max() < 5e-2
+    # fixed-order sums in the spill modes as well: identical bits for the same agent
+    assert np.array_equal(res_p['status'], res['status'][perm]) and np.array_equal(res_p['iters'], res['iters'][perm])
+    assert np.array_equal(res_p['x'], res['x'][perm])
     solver.close()

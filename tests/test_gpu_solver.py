@@ -41,17 +41,20 @@ def test_cfg2_matches_port_and_numpy(cfg2_small):
     from oracle.nlp_numpy import NumpyNLP
     problem, P = cfg2_small
     tpl = problem.father.template
-    tol = 3e-6      # (at 1e-6 the last barrier problem, mu = 1e-7, sits in the rounding noise of the LDS atomic sums)
+    tol = 1e-6
     solver = BatchSolver(tpl, 8, options=dict(tol=tol, max_iter=300))
     res = solver.solve(P['p'], P['x0'])
+    # every sum of the kernel has a fixed order (owner-computes, no floating-point atomics): a second run
+    # returns the same bits
+    res2 = solver.solve(P['p'], P['x0'])
+    assert np.array_equal(res['x'], res2['x']) and np.array_equal(res['lam_g'], res2['lam_g'])
+    assert np.array_equal(res['status'], res2['status']) and np.array_equal(res['iters'], res2['iters'])
     ref = port_binding.solve(tpl, P['p'], P['x0'], tol=tol, max_iter=300)
-    # agents on the edge of an iteration/stall limit may land on either side of it, and at this tolerance
-    # (barrier parameter down to 1e-7) a solve can end in the rounding noise of its last iterations
-    # (status 4); which ones depends on the order of the LDS atomic sums, i.e. varies from run to run
-    assert (res['status'] == ref['status']).sum() >= 6
-    assert set(np.unique(res['status'])) <= {0, 1, 2, 4}
+    # same-source check: the kernel and its host build take the same decisions on all 8 agents
+    assert np.array_equal(res['status'], ref['status'])
+    assert set(np.unique(res['status'])) <= {0, 1, 2}            # never a numerical failure
     good = (res['status'] == 0) & (ref['status'] == 0)
-    assert good.sum() >= 4
+    assert good.sum() >= 6
     lo, hi = tpl.entry_range(problem.vehicles[0].label, 'splines_seg0', 'var')
     nlp = NumpyNLP(tpl)
     for b in np.nonzero(good)[0]:
@@ -61,7 +64,7 @@ def test_cfg2_matches_port_and_numpy(cfg2_small):
         c = nlp.term_coefs(P['p'][b])
         f_gpu, g = nlp.fg(res['x'][b], c)
         f_ref, _ = nlp.fg(ref['x'][b], c)
-        assert abs(f_gpu - f_ref) < 3e-6
+        assert abs(f_gpu - f_ref) < 1e-6
         assert (g - tpl.ub).max() < 1e-5 and (tpl.lb - g).max() < 1e-5      # tol x row scaling
     # independent dense statement of the same iteration (no block structure, no MFMA): at this
     # tolerance its unpivoted dense LDL' may give up on the last ill-conditioned iterations, so
