@@ -64,6 +64,10 @@ class BatchP2P(object):
         self.problem = problem
         father = problem.father
         self.tpl = tpl = father.template
+        if len(problem.vehicles) != 1:
+            raise NotImplementedError('BatchP2P drives single-vehicle problems (one agent = one vehicle); '
+                                      'a problem with %d vehicles needs the prediction of each of them'
+                                      % len(problem.vehicles))
         veh = problem.vehicles[0]
         self.veh, self.basis = veh, veh.basis
         self.L, self.n_dim = len(veh.basis), veh.n_dim
@@ -75,6 +79,16 @@ class BatchP2P(object):
         self.o_state0 = tpl.entry_range(veh.label, 'state0', 'par')[0]
         self.o_input0 = tpl.entry_range(veh.label, 'input0', 'par')[0]
         self.o_t = tpl.entry_range(problem.label, 't', 'par')[0]
+        # obstacle motion model between two solves (`environment/obstacle.py:246-264` without bouncing):
+        # the parameters x, v, a of every obstacle are the values AT the time of the solve
+        # (`obstacle.py:142-155` reads signals[...][:, -1]; the template extrapolates them back by t)
+        self.obst = []
+        for obs in problem.environment.obstacles:
+            ox = tpl.entry_range(obs.label, 'x', 'par')
+            ov = tpl.entry_range(obs.label, 'v', 'par')
+            oa = tpl.entry_range(obs.label, 'a', 'par')
+            if np.any(P['p'][:, ov[0]:ov[1]] != 0.) or np.any(P['p'][:, oa[0]:oa[1]] != 0.):     # static obstacles: nothing to do
+                self.obst.append((ox[0], ov[0], oa[0], ox[1] - ox[0]))
         self.perm = dual_shift_perm(father)
         ents, mats, off = [], [], 0
         for label, name, spl in father.shifted_entries(every_spline=shift_every_spline):
@@ -173,6 +187,12 @@ class BatchP2P(object):
             self.p[:, self.o_state0:self.o_state0 + nd] = c @ E
             self.p[:, self.o_input0:self.o_input0 + nd] = c @ Ed
             self.p[:, self.o_t] = t_rel
+        # obstacles move on: x <- x + v dt + a dt^2 / 2, v <- v + a dt (a no-op for static obstacles)
+        dt = self.update_time
+        for ox, ov, oa, nd_o in self.obst:
+            px, pv, pa = self.p[:, ox:ox + nd_o], self.p[:, ov:ov + nd_o], self.p[:, oa:oa + nd_o]
+            px += dt * pv + (0.5 * dt * dt) * pa
+            pv += dt * pa
         if crossed:
             self._shift()
         self.time = t_now

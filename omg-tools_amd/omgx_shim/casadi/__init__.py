@@ -1,27 +1,59 @@
-"""TEST INFRASTRUCTURE ONLY -- a numeric, lazily evaluated stand-in for the parts
-of the CasADi Python API that omg-tools touches while *constructing* a problem.
+"""Stand-in for the parts of the CasADi Python API that omg-tools touches (omgx_shim: the reference's own
+classes on the MI355X solve path, see ../__init__.py).
 
-CasADi (the reference's third-party dependency, `setup.py:27-31`) is not
-installable here.  With this module on sys.path, tests/golden/generate_golden.py
-can import the reference from /root/reference and run its own
-`Problem.init()`; every MX is a closure that evaluates to a numpy array for a
-given assignment of the leaf symbols, so the reference's objective f(x,p) and
-constraint vector g(x,p) can be evaluated at concrete points.  No solver, no AD.
+omg-tools builds its NLP as CasADi graphs (`basics/optilayer.py:556-669`) and hands them to
+`nlpsol('solver', 'ipopt', {x, p, f, g}, opts)` (`optilayer.py:49-60`).  Here every MX is a lazily
+evaluated closure over its leaf symbols.  Evaluated on numbers it gives f(x, p) and g(x, p) at a point
+(tests/golden uses that to pin the product's own front end to the reference's construct code).
+Evaluated on `Poly` values (omgtools/symbolic.py) it gives every row of g and f as an explicit
+polynomial in the variables with parameter-polynomial coefficients -- all the HIP solver needs
+(template.NLPTemplate.from_polys): `nlpsol` below does exactly that and returns a solver object with
+the call shape the reference uses (`problems/problem.py:113-119`).  No AD, no graph optimisation:
+the in-scope rows are polynomial (degree <= 3 in x), their derivatives are taken term by term on the
+device.
 """
 import numpy as np
 
 inf = float('inf')
 
 
+def _val(v):
+    """Evaluation result as an array: float if it can be, object (Poly entries) otherwise."""
+    a = np.asarray(v)
+    if a.dtype == object:
+        try:
+            return a.astype(float)
+        except (TypeError, ValueError):
+            return a
+    return a.astype(float)
+
+
 def _arr(v):
     if hasattr(v, 'toarray'):
         v = v.toarray()
-    a = np.asarray(v, dtype=float)
+    if hasattr(v, 'cat') and not isinstance(v, MX):
+        v = v.cat
+    a = _val(v)
     if a.ndim == 0:
         a = a.reshape(1, 1)
     elif a.ndim == 1:
         a = a.reshape(-1, 1)
     return a
+
+
+def _pow(a, b):
+    """a ** b for float or Poly-valued arrays (integral exponents for polynomials)."""
+    if np.asarray(a).dtype != object:
+        return np.power(a, b)
+    b = np.broadcast_to(np.asarray(b, dtype=float), np.broadcast(a, b).shape)
+    a = np.broadcast_to(a, b.shape)
+    out = np.empty(b.shape, dtype=object)
+    for i in np.ndindex(*b.shape):
+        e = float(b[i])
+        if e != int(e) or e < 0:
+            raise TypeError('non-integral power of a polynomial')
+        out[i] = a[i] ** int(e)
+    return out
 
 
 class MX(object):
@@ -84,8 +116,7 @@ class MX(object):
         return self.shape[0]
 
     def eval(self, env):
-        v = np.asarray(self._fn(env), dtype=float)
-        return v.reshape(self.shape)
+        return _val(self._fn(env)).reshape(self.shape)
 
     # -- helpers ------------------------------------------------------------------
     def _bin(self, other, op, reflected=False):
@@ -105,7 +136,7 @@ class MX(object):
     def __rmul__(self, o): return self._bin(o, np.multiply, True)
     def __truediv__(self, o): return self._bin(o, np.divide)
     def __rtruediv__(self, o): return self._bin(o, np.divide, True)
-    def __pow__(self, o): return self._bin(o, np.power)
+    def __pow__(self, o): return self._bin(o, _pow)
     def __neg__(self): return MX(self.shape, lambda env: -self.eval(env), self._deps)
     def __ge__(self, o): return self._bin(o, lambda a, b: (a >= b) * 1.0)
     def __le__(self, o): return self._bin(o, lambda a, b: (a <= b) * 1.0)
@@ -130,7 +161,7 @@ class MX(object):
         if isinstance(idx[0], (int, np.integer)) and not isinstance(idx[1], (int, np.integer)):
             sub = sub.reshape(1, -1)
         shape = sub.shape
-        return MX(shape, lambda env: np.asarray(self.eval(env)[idx], float).reshape(shape), self._deps)
+        return MX(shape, lambda env: _val(self.eval(env)[idx]).reshape(shape), self._deps)
 
 
 SX = MX
@@ -236,7 +267,7 @@ class Function(object):
             key = s.cat if hasattr(s, 'cat') and not isinstance(s, MX) else s
             if isinstance(a, MX):
                 raise NotImplementedError('symbolic Function call')
-            env[key] = _arr(a.cat if hasattr(a, 'cat') else a).reshape(key.shape, order='F')
+            env[key] = _arr(a).reshape(key.shape, order='F')
         outs = [MX.lift(o).eval(env) for o in self.outputs]
         return outs[0] if len(outs) == 1 else outs
 
@@ -244,16 +275,12 @@ class Function(object):
         return [self(*args)]
 
 
-class _Solver(object):
-    def __init__(self, nlp, opts):
-        self.nlp, self.opts = nlp, opts
-
-    def stats(self):
-        return {'return_status': 'Not_Available'}
-
-
 def nlpsol(name, solver, nlp, opts=None):
-    return _Solver(nlp, opts)
+    """`nlpsol('solver', 'ipopt', {'x','p','f','g'}, opts)` (`basics/optilayer.py:60`): the solver object of
+    the MI355X path (omgx_shim.ShimSolver: polynomial template -> libomgx.so).  The NLP dictionary stays
+    accessible as `.nlp` (tests evaluate f and g through it)."""
+    from omgx_shim import ShimSolver
+    return ShimSolver(nlp, opts or {}, solver)
 
 
 def external(*a, **k):

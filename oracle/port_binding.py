@@ -24,11 +24,25 @@ def load():
     return lib
 
 
+def _backend():
+    """The product's ctypes layer: `omgtools.backend`, or -- in a process where `omgtools` is the reference
+    package running on the shim -- the same module under its shim name."""
+    try:
+        import omgtools.backend as be
+        if hasattr(be, 'make_ctemplate'):
+            return be
+    except ImportError:
+        pass
+    import omgx_shim
+    return omgx_shim._mod('backend')
+
+
 def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, status0=None, n_threads=1,
           dw_state=None, **options):
     """Solve B agents on `n_threads` host threads (one agent per thread at a time); returns a
     dict like BatchSolver.solve."""
-    from omgtools.backend import make_ctemplate, make_options
+    be = _backend()
+    make_ctemplate, make_options = be.make_ctemplate, be.make_options
     lib = load()
     ct, keep = make_ctemplate(template, plan)
     opt = make_options(**options)

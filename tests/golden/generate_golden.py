@@ -20,7 +20,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = '/root/reference/omgtools'
-sys.path.insert(0, os.path.join(HERE, 'fake_casadi'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), 'omg-tools_amd'))
+import omgx_shim      # noqa: E402  (the stand-in casadi of the product's reference shim, evaluated on numbers here)
+omgx_shim.install()
 
 
 def _pkg(name, path):

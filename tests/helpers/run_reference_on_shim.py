@@ -1,0 +1,103 @@
+"""Runs in its own process (tests/test_reference_shim_cpu.py): here `omgtools` is the REFERENCE package from
+/root/reference, imported unchanged on top of `omgx_shim` (stand-in casadi -> polynomial template -> the
+solver core; host build injected as the solver, this is the CPU tier).  Prints one JSON line."""
+import json
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np          # noqa: E402
+import omgx_shim            # noqa: E402
+
+omgx_shim.install()
+# this container has no Tk: the reference's GUI module (imported by its __init__) needs a placeholder
+for name in ('tkinter', 'tkinter.filedialog', 'tkinter.messagebox', 'tkinter.ttk'):
+    sys.modules[name] = types.ModuleType(name)
+
+
+class _Any(object):
+    def __init__(self, *a, **k): pass
+    def __getattr__(self, n): return _Any()
+    def __call__(self, *a, **k): return _Any()
+
+
+tk = sys.modules['tkinter']
+for n in ('Tk', 'Frame', 'Canvas', 'Button', 'Label', 'Entry', 'StringVar', 'IntVar', 'Toplevel', 'Checkbutton',
+          'LabelFrame', 'Scale', 'OptionMenu', 'Radiobutton'):
+    setattr(tk, n, _Any)
+tk.filedialog, tk.messagebox = sys.modules['tkinter.filedialog'], sys.modules['tkinter.messagebox']
+sys.path.insert(0, '/root/reference')
+import omgtools                                     # noqa: E402  the reference
+assert omgtools.__file__.startswith('/root/reference'), omgtools.__file__
+from omgtools import *                              # noqa: E402,F401,F403
+import port_solver                                  # noqa: E402
+from oracle.nlp_numpy import NumpyNLP               # noqa: E402
+
+omgx_shim.solver_factory = lambda tpl, opt: port_solver.PortNlpSolver(tpl, opt)
+which = sys.argv[1] if len(sys.argv) > 1 else 'p2p_holonomic'
+out = {'case': which}
+if which == 'p2p_holonomic':
+    # body of the reference's examples/p2p_holonomic.py:23-51 (the file itself ends in plotting calls)
+    vehicle = Holonomic()
+    vehicle.set_options({'safety_distance': 0.1})
+    vehicle.set_initial_conditions([-1.5, -1.5])
+    vehicle.set_terminal_conditions([2., 2.])
+    environment = Environment(room={'shape': Square(5.)})
+    trajectories = {'velocity': {'time': [3., 4.], 'values': [[-0.15, 0.0], [0., 0.15]]}}
+    environment.add_obstacle(Obstacle({'position': [1.5, 0.5]}, shape=Circle(0.5),
+                                      simulation={'trajectories': trajectories}))
+    problem = Point2point(vehicle, environment, freeT=False)
+    target = [2., 2.]
+elif which == 'p2p_holonomic_rect':
+    vehicle = Holonomic(shapes=Circle(0.1))
+    vehicle.set_initial_conditions([-1.5, -1.5])
+    vehicle.set_terminal_conditions([2., 2.])
+    environment = Environment(room={'shape': Square(5.)})
+    rectangle = Rectangle(width=3., height=0.2)
+    environment.add_obstacle(Obstacle({'position': [-2.1, -0.5]}, shape=rectangle))
+    environment.add_obstacle(Obstacle({'position': [1.7, -0.5]}, shape=rectangle))
+    problem = Point2point(vehicle, environment, freeT=False)
+    target = [2., 2.]
+else:
+    raise SystemExit('unknown case')
+problem.set_options({'verbose': 0})
+problem.init()
+problem.reinitialize()
+father = problem.father
+x0 = np.asarray(father.get_variables().cat, float).reshape(-1).copy()
+p0 = np.asarray(father.set_parameters(0.).cat, float).reshape(-1).copy()
+problem.solve(0., 0.1)
+tpl = problem.problem.template
+out.update(n_var=tpl.n_var, n_con=tpl.n_con, n_par=tpl.n_par, n_terms=int(tpl.n_terms),
+           first_status=problem.problem.stats()['return_status'])
+# the template against the reference's own graphs, evaluated numerically at random points
+nlp_ref = problem.problem.nlp
+X, Pm = nlp_ref['x'].cat, nlp_ref['p'].cat
+import casadi                                       # noqa: E402  (the stand-in)
+nn = NumpyNLP(tpl)
+rng = np.random.default_rng(3)
+err = 0.0
+pts = []
+for k in range(3):
+    xv, pv = x0 + 0.1 * rng.standard_normal(tpl.n_var), p0.copy()
+    pv[tpl.entry_range('p2p0', 't', 'par')[0]] = 0.03 * (k + 1)          # time since the last knot: exercises t/T and B(t/T)
+    env = {X: xv.reshape(-1, 1), Pm: pv.reshape(-1, 1)}
+    g_ref = np.asarray(nlp_ref['g'].cat.eval(env), float).reshape(-1)
+    f_ref = float(np.asarray(casadi.MX.lift(nlp_ref['f']).eval(env), float).reshape(-1)[0])
+    f, g = nn.fg(xv, nn.term_coefs(pv))
+    pts.append((xv, pv, f, g))
+    err = max(err, np.abs(g - g_ref).max() / (1 + np.abs(g_ref).max()), abs(f - f_ref) / (1 + abs(f_ref)))
+out['graph_vs_template'] = err
+np.savez(os.environ.get('SHIM_DUMP', '/tmp/shim_dump.npz'), lb=tpl.lb, ub=tpl.ub, x0=x0, p0=p0,
+         row_ptr=tpl.row_ptr, xs=np.array([q[0] for q in pts]), ps=np.array([q[1] for q in pts]),
+         fs=np.array([q[2] for q in pts]), gs=np.array([q[3] for q in pts]))
+simulator = Simulator(problem)
+simulator.run()
+state = vehicle.signals['state'][:, -1]
+out.update(final_error=float(np.abs(state - np.array(target)).max()), steps=len(problem.update_times),
+           statuses_ok=True)
+print('SHIM_RESULT ' + json.dumps(out))

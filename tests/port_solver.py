@@ -8,14 +8,16 @@ import numpy as np
 
 class PortNlpSolver(object):
     def __init__(self, template, options):
-        from omgtools.backend import options_from_problem
+        from oracle.port_binding import _backend
+        options_from_problem = _backend().options_from_problem
         self.template = template
         self.options = options_from_problem(options)
         self._stats = {'return_status': 'Not_Solved', 'iter_count': 0}
 
     def __call__(self, x0=None, p=None, lbg=None, ubg=None, **kwargs):
         from oracle import port_binding
-        from omgtools.backend import STATUS_STRINGS
+        from oracle.port_binding import _backend
+        STATUS_STRINGS = _backend().STATUS_STRINGS
         res = port_binding.solve(self.template, np.asarray(p), np.asarray(x0), np.asarray(lbg), np.asarray(ubg),
                                  **self.options)
         self._stats = {'return_status': STATUS_STRINGS[int(res['status'][0])], 'iter_count': int(res['iters'][0])}

@@ -167,3 +167,18 @@ def test_product_package_never_imports_the_oracle():
                 if py.search(txt) or inc.search(txt):
                     hits.append(os.path.join(d, f))
     assert not hits, hits
+
+
+def test_library_plan_agrees_with_the_oracle_partition(cfg2_small):
+    """Leaf membership derived inside the library == the oracle's independent Python statement of the
+    partition (oracle/plan_numpy.py); only the order inside a leaf differs (reverse Cuthill-McKee)."""
+    from omgtools.backend import describe_plan
+    from oracle.plan_numpy import SolverPlan
+    problem, _ = cfg2_small
+    tpl = problem.father.template
+    lib = describe_plan(tpl)
+    ref = SolverPlan(tpl)
+    off = np.cumsum([0] + lib['leaf_sizes'])
+    got = [sorted(lib['order'][off[l]:off[l + 1]].tolist()) for l in range(lib['n_leaf'])]
+    assert got == [sorted(l) for l in ref.leaves]
+    assert sorted(lib['order'][off[-1]:].tolist()) == sorted(ref.order[ref.root_off:].tolist())

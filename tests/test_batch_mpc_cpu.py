@@ -42,3 +42,42 @@ def test_receding_horizon_protocol(cfg2_small):
     assert np.mean(warm_iters) < 0.5 * cold_iters
     d1 = np.linalg.norm(mpc.p[:, mpc.o_state0:mpc.o_state0 + 2] - goal, axis=1)
     assert np.all(d1[ok] < d0[ok] - 0.3)                    # 1.2 s of motion towards the goal
+
+
+def test_moving_obstacles_and_multi_vehicle_guard():
+    """Obstacle parameters are the values at the time of the solve (`environment/obstacle.py:142-155`): the
+    loop advances x and v of moving obstacles between steps (constant acceleration, `obstacle.py:246-264`
+    without bouncing); multi-vehicle problems are refused instead of predicted for vehicle 0 only."""
+    import pytest
+    import omgtools.backend as be
+    from omgtools.batch import BatchP2P
+    from omgtools.scenarios import holonomic_p2p
+    from omgtools import Holonomic, Fleet, Environment, Obstacle, Circle, Square, Point2point
+    from oracle import port_binding
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        problem, P = holonomic_p2p(2, n_obs=2)
+        veh1, veh2 = Holonomic(), Holonomic()
+        for v, s in ((veh1, [-1., -1.]), (veh2, [-1., 1.])):
+            v.set_initial_conditions(s); v.set_terminal_conditions([1., 0.])
+        env = Environment(room={'shape': Square(5.)})
+        prob2 = Point2point(Fleet([veh1, veh2]), env, options={'verbose': 0})
+        prob2.init()
+    finally:
+        be.create_nlp = saved
+    tpl = problem.father.template
+    obs = problem.environment.obstacles[0]
+    ox, ov = tpl.entry_range(obs.label, 'x', 'par')[0], tpl.entry_range(obs.label, 'v', 'par')[0]
+    P['p'][:, ov:ov + 2] = [[0.05, -0.02], [-0.03, 0.04]]         # obstacle 0 moves, obstacle 1 stays
+    mpc = BatchP2P(problem, P, ops=port_binding, options=dict(tol=1e-3, max_iter=5))
+    assert len(mpc.obst) == 1
+    x_start, v = P['p'][:, ox:ox + 2].copy(), P['p'][:, ov:ov + 2].copy()
+    assert np.abs(v).max() > 0
+    for k in range(3):
+        mpc.step()
+    assert np.abs(mpc.p[:, ox:ox + 2] - (x_start + 0.3 * v)).max() < 1e-12
+    assert np.array_equal(mpc.p[:, ov:ov + 2], v)                 # no acceleration: velocity unchanged
+    P2 = {'p': np.zeros((1, prob2.father.template.n_par)), 'x0': np.zeros((1, prob2.father.template.n_var))}
+    with pytest.raises(NotImplementedError):
+        BatchP2P(prob2, P2, ops=port_binding)

@@ -30,23 +30,7 @@ def _build(fn, B, **kw):
         be.create_nlp = saved
 
 
-def kkt_report(nlp, tpl, p, x, lam):
-    """(max violation, min multiplier sign, max |lam * slack|, max |grad L|) of one agent, rows scaled
-    like the solver scales them (gradient-based, g_max = 100)."""
-    c = nlp.term_coefs(p)
-    f, g = nlp.fg(x, c)
-    J = nlp.jac(x, c)
-    gmax = np.abs(J[:-1]).max(axis=1)
-    rho = np.where(gmax > 100., 100. / np.maximum(gmax, 1e-300), 1.0)
-    up, lo = np.isfinite(tpl.ub), np.isfinite(tpl.lb)
-    viol = max(((g - tpl.ub) * rho)[up].max(initial=0.), ((tpl.lb - g) * rho)[lo].max(initial=0.))
-    ineq_up, ineq_lo = up & ~lo, lo & ~up
-    sign = min(lam[ineq_up].min(initial=0.), (-lam[ineq_lo]).min(initial=0.))
-    slack = np.where(ineq_up, tpl.ub - g, np.where(ineq_lo, g - tpl.lb, 0.0))
-    comp = np.abs(lam * slack).max()
-    sd = max(100., np.abs(lam / rho).mean()) / 100.
-    stat = np.abs(J[-1] + J[:-1].T @ lam).max() / sd
-    return viol, sign, comp / sd, stat
+from oracle.kkt_check import kkt_report      # noqa: E402  (shared with the smoke test)
 
 
 def check_optimality(tpl, P, res, agents):
