@@ -1,3 +1,28 @@
+# This file is derived from OMG-tools (meco-group/omg-tools, `omgtools/problems/problem.py`, `point2point.py`).
+#
+# OMG-tools -- Optimal Motion Generation-tools
+# Copyright (C) 2016 Ruben Van Parys & Tim Mercy, KU Leuven.
+# All rights reserved.
+#
+# OMG-tools is free software; you can redistribute it and/or
+# modify it under the terms of the GNU Lesser General Public
+# License as published by the Free Software Foundation; either
+# version 3 of the License, or (at your option) any later version.
+# This software is distributed in the hope that it will be useful,
+# but WITHOUT ANY WARRANTY; without even the implied warranty of
+# MERCHANTABILITY or FITNESS FOR A PARTICULAR PURPOSE. See the GNU
+# Lesser General Public License for more details.
+#
+# You should have received a copy of the GNU Lesser General Public
+# License along with this program; if not, write to the Free Software
+# Foundation, Inc., 51 Franklin Street, Fifth Floor, Boston, MA 02110-1301 USA
+#
+# Modifications: the public classes, option names, method order and messages of the files named
+# above are kept so that scripts written for OMG-tools run unchanged where the original package is
+# not installed (benchmark and test tiers of this repository); the CasADi expression layer underneath
+# is replaced by explicit polynomials (symbolic.py) and the solver call by the HIP path (backend.py).
+# Where the original package IS installed, use omgx_shim instead: it runs the original classes themselves.
+
 """`Problem`, `Point2point` (fixed-T) -- the receding-horizon solve.
 
 Behavioural spec: reference `problems/problem.py` (options 54-74, init 85-91,
