@@ -211,7 +211,8 @@ class ShimSolver(object):
     def __call__(self, x0=None, p=None, lbg=None, ubg=None, **kwargs):
         x0, p, lbg, ubg = self._vec(x0), self._vec(p), self._vec(lbg), self._vec(ubg)
         if self._impl is None:
-            self.template = template_from_nlp(self.nlp, lbg, ubg)
+            import casadi
+            self.template = casadi.deep(template_from_nlp, self.nlp, lbg, ubg)
             options = {'solver': 'ipopt', 'solver_options': {'ipopt': {k: v for k, v in self.opts.items() if k.startswith('ipopt.')}},
                        'verbose': 0}
             if solver_factory is not None:

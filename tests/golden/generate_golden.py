@@ -76,11 +76,11 @@ def dump(problem, tag, rng, n_pts=4):
     father = problem.father
     nlp = problem.problem.nlp
     X, Pm = nlp['x'].cat, nlp['p'].cat
-    x_init = father._var_result.cat.copy()
+    x_init = father._var_result.cat.reshape(-1).copy()
     problem.reinitialize()
-    x_reinit = father._var_result.cat.copy()
-    p0 = father.set_parameters(0.).cat.copy()
-    lb, ub = father._lb.cat.copy(), father._ub.cat.copy()
+    x_reinit = father._var_result.cat.reshape(-1).copy()
+    p0 = father.set_parameters(0.).cat.reshape(-1).copy()
+    lb, ub = father._lb.cat.reshape(-1).copy(), father._ub.cat.reshape(-1).copy()
     n_var, n_par = x_init.size, p0.size
     t_idx = [off for (name, off, r, c) in layout_of(father._par_struct) if name.endswith('/t')][0]
     knot_time = getattr(problem, 'knot_time', None)       # FreeT: no knot time, t is always 0

@@ -10,7 +10,7 @@ tests/test_golden_solutions.py (CPU tier: host build of the kernel; GPU tier: th
                  the local minimum an interior point reaches, otherwise from inside that basin; the field
                  `method` says which (see `_solve_slsqp`).
   sol_cfg3.npz   8 agents of the Quadrotor class (K = 13, 5 moving circles),
-  sol_cfg5.npz   8 agents of the Holonomic3D class (K = 15, 10 spheres): oracle/ipm_numpy.py at tol 1e-8
+  sol_cfg5.npz   8 agents of the Holonomic3D class (K = 15, 10 spheres): oracle/ipm_numpy.py at tol 1e-6
                  (SLSQP needs hours at these sizes), each solution then handed to SLSQP as a starting
                  point for a bounded number of iterations: the objective must not improve (field `f_polish`).
 
@@ -59,16 +59,17 @@ def _solve_slsqp(b):
     tpl, P, nlp = _STATE['tpl'], _STATE['P'], _STATE['nlp']
     t0 = time.time()
     xa, fa, oka = solve_slsqp(nlp, tpl, P['x0'][b], P['p'][b], maxiter=600)
-    r = ipm_numpy.solve(nlp, P['x0'][b], P['p'][b], tpl.lb, tpl.ub, opts={'tol': 1e-8, 'max_iter': 400})
+    # (tol 1e-6: at 1e-8 the dense unpivoted LDL' of the numpy statement ends in rounding noise for half of the agents)
+    r = ipm_numpy.solve(nlp, P['x0'][b], P['p'][b], tpl.lb, tpl.ub, opts={'tol': 1e-6, 'max_iter': 400})
     okb, fb = r['status'] == 0, float(r['f'])
-    if oka and okb and abs(fa - fb) < 1e-6 * (1 + abs(fa)):
+    if oka and okb and abs(fa - fb) < 1e-5 * (1 + abs(fa)):
         return b, xa, fa, True, 0, time.time() - t0
     if okb:
         xc, fc, okc = solve_slsqp(nlp, tpl, r['x'], P['p'][b], maxiter=600)
-        if okc and abs(fc - fb) < 1e-6 * (1 + abs(fb)):
+        if okc and abs(fc - fb) < 1e-5 * (1 + abs(fb)):
             return b, xc, fc, True, 2, time.time() - t0
         return b, r['x'], fb, True, 1, time.time() - t0
-    return b, xa, fa, bool(oka), 0, time.time() - t0
+    return b, xa, fa, bool(oka), 3, time.time() - t0          # method 3: SLSQP only (the interior point did not converge)
 
 
 def _solve_ipm(b):
@@ -76,7 +77,7 @@ def _solve_ipm(b):
     from oracle import ipm_numpy
     tpl, P, nlp = _STATE['tpl'], _STATE['P'], _STATE['nlp']
     t0 = time.time()
-    opts = dict(P.get('solver_options', {}), tol=1e-8, max_iter=500)
+    opts = dict(P.get('solver_options', {}), tol=float(os.environ.get('ORACLE_TOL', '1e-6')), max_iter=500)
     r = ipm_numpy.solve(nlp, P['x0'][b], P['p'][b], tpl.lb, tpl.ub, opts=opts)
     f_polish = np.nan
     if r['status'] == 0:
