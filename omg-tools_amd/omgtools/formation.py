@@ -68,8 +68,12 @@ class ADMMUpdater(OptiChild):
         l_ji = np.atleast_1d(self.define_parameter('l_ji', n_nghb * ns))
         rho = self.define_parameter('rho')
 
-        def fwd(vec):                      # only the future piece of each spline is penalised
+        def fwd(vec):                      # only the future piece of the spline is penalised
             return shift_knot1_fwd(vec, basis, t0)
+        # As executed, the reference transforms x only: `self._transform_spline([x_i, z_i, l_i], tf, self.q_i)`
+        # (`admm.py:87-88`) changes the dict of x in place, but for the struct-valued z and l it builds and
+        # returns NEW structs (`dualmethod.py:154-157`) that the caller drops -- z and l enter the objective as
+        # stored.  Pinned by tests/test_golden_admm.py against the reference's own graphs.
         obj = Poly()
         for k in range(n_dim):
             x = fwd(np.asarray(center[k].coeffs, dtype=object))
@@ -78,7 +82,6 @@ class ADMMUpdater(OptiChild):
                 o = j * ns + k * L
                 pairs.append((z_ji[o:o + L], l_ji[o:o + L]))
             for z, l in pairs:
-                z, l = fwd(z), fwd(l)
                 for q in range(L):
                     diff = x[q] - z[q]
                     obj = obj + l[q] * diff + 0.5 * rho * diff * diff
@@ -133,9 +136,14 @@ def coupling_matrix(L, n_dim, degree, n_nghb, P_term):
 
 def zupdate_matrices(basis, n_dim, n_nghb, t0):
     """(M, F): z_all = M (x_all + l_all/rho) with
-    M = blkdiag(T_bwd) (I - A'(AA')^{-1}A) blkdiag(T_fwd)  and F = blkdiag(T_fwd)
+    M = blkdiag(T_bwd) (I - A'(AA')^{-1}A) blkdiag(T_fwd)
     (`admm.py:144-162`: f=-(l+rho x), G=-AA'/rho, mu=G^{-1}h, z=-(A'mu+f)/rho with
-    b = 0, then the backward knot transform)."""
+    b = 0, then the backward knot transform) and F the transform the residuals are measured in.
+    As executed the reference applies NO knot transform in the z-update and the residuals: the transformed
+    structs `_transform_spline` returns are dropped (`admm.py:143-146, 286-289`, `dualmethod.py:154-157`).
+    For M that makes no difference (the coupling rows are differences of whole splines and the terminal
+    rows touch the last coefficients only: T_bwd Pi T_fwd = Pi); for the residuals it does, so F = I.
+    Pinned by tests/test_golden_admm.py."""
     L, d = len(basis), basis.degree
     P_term = [basis.derivative(o)[1][-1, :] for o in range(1, d + 1)]
     A = coupling_matrix(L, n_dim, d, n_nghb, P_term)
@@ -144,7 +152,7 @@ def zupdate_matrices(basis, n_dim, n_nghb, t0):
     F = np.kron(np.eye(nb), Tf)
     Bk = np.kron(np.eye(nb), Tb)
     Pi = np.eye(A.shape[1]) - A.T @ np.linalg.solve(A @ A.T, A)
-    return Bk @ Pi @ F, F
+    return Bk @ Pi @ F, np.eye(F.shape[0])
 
 
 class FormationLayout(object):

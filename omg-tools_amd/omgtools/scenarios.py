@@ -170,7 +170,7 @@ def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0,
     (circular interconnection), shape of `examples/formation_holonomic.py:22-57`
     scaled to the fleet size.  Returns (problem, updater, father,
     layout, P) with P = {'p' [B,n_par], 'x0' [B,n_var], 'nbr' [B,2]}."""
-    from .shapes import Rectangle
+    from .shapes import Rectangle, Circle
     from .formation import build_updx_template, FormationLayout, circular_neighbors
     vehicle = Holonomic()
     vehicle.define_knots(knot_intervals=knot_intervals)
@@ -182,6 +182,9 @@ def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0,
         rect = Rectangle(width=3., height=0.2)
         environment.add_obstacle(Obstacle({'position': [-2.6, -1.0]}, shape=rect))
         environment.add_obstacle(Obstacle({'position': [2.6, -1.0]}, shape=rect))
+        # the moving circle of `examples/formation_holonomic.py:41-44` (there it is pushed at t = 3 s by a
+        # simulation trajectory; the synthetic workload gives it that velocity from the start)
+        environment.add_obstacle(Obstacle({'position': [1.5, 0.5], 'velocity': [-0.15, 0.0]}, shape=Circle(0.4)))
     problem, updater, father = build_updx_template(
         vehicle, environment, 2, {'horizon_time': horizon_time})
     tpl = father.template
@@ -195,6 +198,7 @@ def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0,
     for l, obs in enumerate(environment.obstacles):
         chk, rad = obs.shape.get_checkpoints()
         lo = tpl.entry_range(obs.label, 'x', 'par')[0]; p[:, lo:lo + 2] = obs.signals['position'][:, -1]
+        lo = tpl.entry_range(obs.label, 'v', 'par')[0]; p[:, lo:lo + 2] = obs.signals['velocity'][:, -1]
         lo = tpl.entry_range(obs.label, 'checkpoints', 'par')[0]; p[:, lo:lo + 2 * len(chk)] = np.reshape(chk, -1)
         lo = tpl.entry_range(obs.label, 'rad', 'par')[0]; p[:, lo:lo + len(rad)] = rad
     for b in range(n_agents):

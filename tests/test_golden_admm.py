@@ -1,0 +1,121 @@
+"""The formation-ADMM path pinned to the reference: tests/golden/admm_formation.npz holds values produced by
+EXECUTING the reference's own `problems/formation.py`, `distributedproblem.py`, `dualmethod.py` and
+`admm.py` (generator tests/golden/generate_golden_admm.py, casadi stand-in of omgx_shim evaluated on numbers)
+for `examples/formation_holonomic.py` (4 vehicles, two rectangles, the moving circle).  Compared here, at
+1e-9: the x-update NLP of this repository's front end (`formation.build_updx_template`: layout, bounds, f
+and g at seeded random points), the z-update (coupling matrix A as a projector, b = 0, outputs of the
+closed form), the multiplier update and the residuals (product formulas in `formation.py`, the numpy
+statement the GPU test compares the HIP kernels with: tests/admm_numpy_ops.py / oracle/admm_numpy.py)."""
+import os
+
+import numpy as np
+import pytest
+
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'admm_formation.npz')
+
+
+@pytest.fixture(scope='module')
+def fix():
+    return np.load(FIX)
+
+
+@pytest.fixture(scope='module')
+def updx():
+    import omgtools.backend as be
+    from omgtools import Holonomic, Environment, Obstacle, Rectangle, Circle, Square
+    from omgtools.formation import build_updx_template
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        vehicle = Holonomic()
+        vehicle.set_initial_conditions([-1.5, -1.7])
+        vehicle.set_terminal_conditions([2., 1.8])
+        environment = Environment(room={'shape': Square(5.)})
+        rectangle = Rectangle(width=3., height=0.2)
+        environment.add_obstacle(Obstacle({'position': [-2.1, -0.5]}, shape=rectangle))
+        environment.add_obstacle(Obstacle({'position': [1.7, -0.5]}, shape=rectangle))
+        environment.add_obstacle(Obstacle({'position': [1.5, 0.5]}, shape=Circle(0.4)))
+        return build_updx_template(vehicle, environment, 2, {'horizon_time': 10.})
+    finally:
+        be.create_nlp = saved
+
+
+def test_xupdate_nlp_equals_the_reference(fix, updx):
+    """`ADMM.construct_upd_x` (`problems/admm.py:63-115`): same variables, parameters, rows, bounds and the
+    same f, g as the reference's graphs."""
+    from oracle.nlp_numpy import NumpyNLP
+    problem, updater, father = updx
+    tpl = father.template
+    assert (tpl.n_var, tpl.n_con, tpl.n_par) == (fix['updx_x0'].size, fix['updx_lb'].size, fix['updx_p0'].size) == (151, 671, 212)
+    for which, tag in (('var', 'var'), ('par', 'par'), ('con', 'con')):
+        mine = [(name, off, r, c) for (_, name, off, r, c) in tpl.block_table(which)]
+        ref = [(str(n).split('/')[-1], int(o), int(r), int(c)) for n, (o, r, c) in zip(fix['updx_%s_names' % tag], fix['updx_%s_layout' % tag])]
+        assert [(o, r, c) for _, o, r, c in mine] == [(o, r, c) for _, o, r, c in ref], which
+        if which != 'con':                                       # (constraint names carry per-process counters)
+            assert [n for n, _, _, _ in mine] == [n for n, _, _, _ in ref], which
+    assert np.array_equal(tpl.lb, fix['updx_lb']) and np.array_equal(tpl.ub, fix['updx_ub'])
+    nlp = NumpyNLP(tpl)
+    for xv, pv, fr, gr in zip(fix['updx_xs'], fix['updx_ps'], fix['updx_fs'], fix['updx_gs']):
+        f, g = nlp.fg(xv, nlp.term_coefs(pv))
+        assert abs(f - fr) < 1e-9 * (1 + abs(fr))
+        assert np.abs(g - gr).max() < 1e-9 * (1 + np.abs(gr).max())
+
+
+def test_zupdate_coupling_equals_the_reference(fix, updx):
+    """`_check_for_lineq` (`admm.py:313-354`): A spans the same constraints (same projector on its null
+    space; scaling and order of the rows are immaterial), b = 0; neighbour order "next, previous"
+    (`distributedproblem.py:181-182`); the closed-form z-update (`admm.py:117-168`) gives the reference's
+    outputs, also for t > 0 (forward / backward knot transform)."""
+    from omgtools.formation import coupling_matrix, zupdate_matrices
+    problem, updater, father = updx
+    basis = problem.vehicles[0].basis
+    L, d = len(basis), basis.degree
+    assert int(fix['n_shared']) == 2 * L == 26
+    assert list(fix['nghb_index']) == [1, 3]
+    assert np.abs(fix['updz_b']).max() == 0.0
+    P_term = [basis.derivative(o)[1][-1, :] for o in range(1, d + 1)]
+    A = coupling_matrix(L, 2, d, 2, P_term)
+    Ar = fix['updz_A']
+    assert A.shape == Ar.shape == (58, 78)
+
+    def projector(M):
+        return np.eye(M.shape[1]) - M.T @ np.linalg.solve(M @ M.T, M)
+    assert np.abs(projector(A) - projector(Ar)).max() < 1e-9
+    ns, nij = 26, 52
+    for vin, vout in zip(fix['updz_in'], fix['updz_out']):
+        x_i, l_i, l_ij, x_j = vin[:ns], vin[ns:2 * ns], vin[2 * ns:2 * ns + nij], vin[2 * ns + nij:2 * ns + 2 * nij]
+        t, T, rho = vin[-3:]
+        M, F = zupdate_matrices(basis, 2, 2, t / T)
+        z_all = M @ (np.r_[x_i, x_j] + np.r_[l_i, l_ij] / rho)
+        assert np.abs(z_all - vout).max() < 1e-9 * (1 + np.abs(vout).max())
+
+
+def test_lambda_update_and_residuals_equal_the_reference(fix, updx):
+    """`construct_upd_l` (`admm.py:248-268`): l <- l + rho (x - z) on untransformed coefficients;
+    `construct_upd_res` (`admm.py:270-307`): pr, dr, cr on forward-shifted coefficients."""
+    from omgtools.formation import zupdate_matrices
+    problem, updater, father = updx
+    basis = problem.vehicles[0].basis
+    ns, nij = 26, 52
+    for vin, vout in zip(fix['updl_in'], fix['updl_out']):
+        x_i, z_i = vin[:ns], vin[ns:2 * ns]
+        z_ij = vin[2 * ns:2 * ns + nij]
+        l_i = vin[2 * ns + nij:3 * ns + nij]
+        l_ij = vin[3 * ns + nij:3 * ns + 2 * nij]
+        x_j = vin[3 * ns + 2 * nij:3 * ns + 3 * nij]
+        rho = vin[-1]
+        out = np.r_[l_i + rho * (x_i - z_i), l_ij + rho * (x_j - z_ij)]
+        assert np.abs(out - vout).max() < 1e-12 * (1 + np.abs(vout).max())
+    for vin, vout in zip(fix['res_in'], fix['res_out']):
+        o = 0
+        parts = []
+        for n in (ns, ns, ns, nij, nij, nij):
+            parts.append(vin[o:o + n]); o += n
+        x_i, z_i, z_i_p, z_ij, z_ij_p, x_j = parts
+        t, T, rho = vin[-3:]
+        _, F = zupdate_matrices(basis, 2, 2, t / T)
+        assert np.array_equal(F, np.eye(78))         # as executed, the reference measures them untransformed
+        fw = lambda a, b: F @ np.r_[a, b]
+        pr = np.sum((fw(x_i, x_j) - fw(z_i, z_ij)) ** 2)
+        dr = rho * np.sum((fw(z_i, z_ij) - fw(z_i_p, z_ij_p)) ** 2)
+        assert np.abs(np.array([pr, dr, rho * pr + dr]) - vout).max() < 1e-9 * (1 + np.abs(vout).max())
