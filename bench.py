@@ -86,18 +86,24 @@ def measured_traffic(n_agents):
 def cpu_baseline(problem, P, opts, steps, warmup, budget_s):
     """Oracle CPU port on the same workload, protocol and tolerance: cold solve, `warmup` untimed
     receding-horizon steps, then `steps` timed ones (exactly the GPU's timed region), repeated from
-    the cold start until about `budget_s` seconds of timed CPU work are collected -- on all host
-    cores (one agent per thread at a time) and, with a 64-agent sample, on one thread."""
+    the cold start until about `budget_s` seconds of timed CPU work are collected.  The host solver has
+    the life cycle of the HIP handle (oracle/port_binding.PortPool): structure plan built once, worker
+    threads created once and pinned to one logical cpu per physical core, the glue of a step (prediction,
+    obstacle motion, knot shift) executed per agent by the worker that then solves it -- no Python between
+    the agents of a step.  Second leg: one pinned thread on a 64-agent sample."""
     from omgtools.batch import BatchP2P
     from oracle import port_binding            # the checker, timed as the reported CPU baseline
-    cores = os.cpu_count() or 1
+    cpus = port_binding.granted_cpus()
+    quota = port_binding.cpu_quota()
+    tpl = problem.father.template
     out = {}
-    for label, threads, n_agents, budget in (('all', cores, P['p'].shape[0], budget_s), ('one', 1, min(64, P['p'].shape[0]), budget_s / 4.)):
+    for label, use, n_agents, budget in (('all', cpus, P['p'].shape[0], budget_s), ('one', cpus[:1], min(64, P['p'].shape[0]), budget_s / 4.)):
         sub = {'p': P['p'][:n_agents], 'x0': P['x0'][:n_agents]}
+        pool = port_binding.PortPool(tpl, cpus=use)
         ok, its, dt, reps = 0, 0, 0.0, 0
         while dt < budget and reps < 200:
             mpc = BatchP2P(problem, sub, ops=port_binding, options=opts)
-            mpc.n_threads = threads
+            mpc.pool = pool
             mpc.solve_cold()
             for _ in range(warmup):
                 mpc.step()
@@ -108,14 +114,91 @@ def cpu_baseline(problem, P, opts, steps, warmup, budget_s):
                 its += int(mpc.iters.sum())
             dt += time.perf_counter() - t0
             reps += 1
+        pool.close()
         out[label] = dict(rate=ok / dt, reps=reps, agents=n_agents, dt=dt, iters=its / float(reps * steps * n_agents))
     a, o = out['all'], out['one']
-    return {'value': a['rate'], 'unit': 'solves/s', 'cores': cores, 'kind': 'port',
+    return {'value': a['rate'], 'unit': 'solves/s', 'cores': len(cpus), 'kind': 'port',
             'sample': '%d repetitions of the bench protocol (cold solve, %d warm-up steps untimed; %d receding-horizon '
-                      'steps timed) on all %d agents with %d host threads, %.1f s timed; single thread: %d repetitions '
-                      'on the first %d agents, %.1f s timed'
-                      % (a['reps'], warmup, steps, a['agents'], cores, a['dt'], o['reps'], o['agents'], o['dt']),
-            'single_thread_value': o['rate'], 'mean_iters': a['iters']}
+                      'steps timed) on all %d agents with a persistent pool of %d threads pinned one per physical core '
+                      '(%d logical cpus visible, cgroup cpu quota %s: more threads than the quota only get throttled, '
+                      'profiles/r02_cpu_pool_sweep.txt), step glue in C inside the workers, %.1f s timed; single pinned '
+                      'thread: %d repetitions on the first %d agents, %.1f s timed'
+                      % (a['reps'], warmup, steps, a['agents'], len(cpus), os.cpu_count() or 1,
+                         'none' if quota is None else '%.0f cpus' % quota, a['dt'], o['reps'], o['agents'], o['dt']),
+            'single_thread_value': o['rate'], 'mean_iters': a['iters'],
+            'note': 'host build of the same interior-point statements (oracle/port), not IPOPT: CasADi/IPOPT is not '
+                    'installable here (BASELINE.md)'}
+
+
+def latency_episodes(mpc, x0_init, p_init, n_ep, n_steps, host):
+    """p50 over n_ep x n_steps timed receding-horizon steps (SURVEY 8d: median over >= 200 timed batch solves);
+    every episode restarts from the cold solve so that the agents are under way, not parked at the goal.
+    host=False: the span is the solve kernel (events on its stream), data resident.  host=True: the span is what
+    a caller with host buffers pays (8d's "device time incl. parameter upload and coefficient download"): p and
+    the warm start uploaded from pinned host memory, the step, then x, the multipliers' status and iteration
+    counts downloaded to pinned host memory."""
+    B = mpc.B
+    ms, ok = [], 0
+    if host:
+        p_h = torch.empty(mpc.p.shape, dtype=torch.float64).pin_memory()
+        x_h = torch.empty(mpc.x.shape, dtype=torch.float64).pin_memory()
+        st_h = torch.empty(B, dtype=torch.int32).pin_memory()
+        it_h = torch.empty(B, dtype=torch.int32).pin_memory()
+    evs = []
+    for e in range(n_ep):
+        mpc.x.copy_(x0_init)
+        mpc.p.copy_(p_init)
+        mpc.time = 0.0
+        mpc.solve_cold()
+        for k in range(n_steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if host:
+                p_h.copy_(mpc.p)
+                x_h.copy_(mpc.x)
+                torch.cuda.synchronize()
+                a.record()
+                mpc.p.copy_(p_h, non_blocking=True)
+                mpc.x.copy_(x_h, non_blocking=True)
+                mpc.step()
+                x_h.copy_(mpc.x, non_blocking=True)
+                st_h.copy_(mpc.status, non_blocking=True)
+                it_h.copy_(mpc.iters, non_blocking=True)
+                b.record()
+                torch.cuda.synchronize()
+                ok += int((st_h == 0).sum())
+            else:
+                mpc.step(events=(a, b))
+                ok += int((mpc.status == 0).sum().item())
+            evs.append((a, b))
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in evs]
+    return {'samples': len(ms), 'p50_ms': float(np.median(ms)), 'p90_ms': float(np.percentile(ms, 90)),
+            'max_ms': float(np.max(ms)), 'mean_ms': float(np.mean(ms)), 'solves_per_s': ok / (sum(ms) * 1e-3),
+            'solved_fraction': ok / float(len(ms) * B)}
+
+
+def unedited_rule(args, dev, seed):
+    """SURVEY 8d's obstacle rule as written (discs rejected only when they overlap; omgtools/scenarios.py adds
+    a passable-gap rule for the headline workload): solved fractions of the same protocol on that generator."""
+    from omgtools.scenarios import holonomic_p2p
+    from omgtools.batch import BatchP2P
+    import omgtools.backend as be
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        problem, P = holonomic_p2p(args.agents, seed=seed, gap=0.0)
+    finally:
+        be.create_nlp = saved
+    mpc = BatchP2P(problem, P, ops='hip', device=dev, options=dict(tol=args.tol, max_iter=300))
+    mpc.solve_cold()
+    cold_ok = int((mpc.status == 0).sum().item())
+    ok = 0
+    for _ in range(20):
+        mpc.step()
+        ok += int((mpc.status == 0).sum().item())
+    mpc.solver.close()
+    return {'rule': 'discs may touch (no passable-gap rejection)', 'cold_solved_fraction': cold_ok / float(args.agents),
+            'step_solved_fraction': ok / float(20 * args.agents), 'steps': 20}
 
 
 def bench_formation(args, rank, local_rank, world, dist, dev):
@@ -139,14 +222,15 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
             dist.barrier()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
-        admm.iterate(0.0)
+        admm.iterate(0.0, sync=False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        status, res = admm.iterate(0.0)
+        status, _ = admm.iterate(0.0, sync=False)           # nothing leaves the device inside the loop
     barrier()
     elapsed = time.perf_counter() - t0
     n_ok = int((status == 0).sum().item())
+    res = admm.residuals[-1]
     elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist if world > 1 else None)
     if rank != 0:
         return
@@ -158,7 +242,7 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
         'config': {'workload': 'configs[3]: FormationPoint2point ADMM, %d Holonomic agents, circular '
                                'interconnection, knot_intervals=10, 2 rectangular obstacles, rho=1, tol=%g'
                                % (N, args.tol), 'agents_total': N, 'n_var': tpl.n_var, 'n_con': tpl.n_con,
-                   'parallelism': 'agents sharded contiguously; halo all_gather + residual all_reduce per iteration'},
+                   'parallelism': 'agents sharded contiguously; two all_gathers per iteration (x_i rows; [z_ij | l_ij] rows + residual sums)'},
         'solved_fraction': n_ok_all / float(N), 'residuals': list(res)}))
 
 
@@ -231,6 +315,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='seconds of timed CPU work for the cpu_baseline leg (all host cores; a quarter of it on one)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the latency / host-boundary / 8d-rule legs (profiling runs)')
     ap.add_argument('--workload', choices=['p2p', 'formation', 'quadrotor', 'holonomic3d'], default='p2p',
                     help="p2p = BASELINE.json configs[1] (headline); formation = configs[3], 512-agent ADMM")
     args = ap.parse_args()
@@ -335,9 +420,15 @@ def main():
         'p50_batch_latency_ms': float(np.median(kernel_ms)), 'max_batch_latency_ms': float(np.max(kernel_ms)),
         'max_iters_in_a_step': int(it_log.max().item()),
         'solved_fraction': n_ok / float(B), 'mean_iters': it_sum / float(n_meas * B),
+        # co-headline: the cold solve of the whole batch from the reference's initial guess (SURVEY 8d target
+        # >= 1e4 solves/s), with its own roofline object
         'cold_solve': {'solves_per_s': cold_ok / (cold_k * 1e-3), 'kernel_ms': cold_k,
                        'solved_fraction': cold_ok / float(B), 'mean_iters': cold_iters / float(B),
-                       'achieved_tflops': cold_iters * flops_per_iter / (cold_k * 1e-3) / 1e12},
+                       'roofline': {'bound': 'mfma', 'kernel': 'ipm_solve_kernel',
+                                    'achieved': cold_iters * flops_per_iter / (cold_k * 1e-3) / 1e12,
+                                    'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                    'frac': cold_iters * flops_per_iter / (cold_k * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                                    'traffic': None, 'kernel_ms': cold_k}},
         'lds_bytes_per_agent': solver.lds_bytes,
         'roofline': {'bound': 'mfma', 'kernel': 'ipm_solve_kernel', 'achieved': achieved,
                      'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -350,6 +441,10 @@ def main():
                              'rocprofv3 --stats averages)'},
         'step_kernel_ms': [round(v, 3) for v in kernel_ms], 'step_max_iters': it_log[W:].max(dim=1).values.tolist(),
     }
+    if world == 1 and not args.no_extras:
+        out['latency_resident'] = latency_episodes(mpc, x0_init, p_init, 5, 40, host=False)
+        out['latency_host_boundary'] = latency_episodes(mpc, x0_init, p_init, 5, 40, host=True)
+        out['survey_8d_obstacle_rule'] = unedited_rule(args, dev, 20240807 + 2)
     if world == 1:
         # trajectory extraction (A11) against the HBM roofline, at the workload's batch and at 16x (the
         # 49 MB of one 1024-agent launch last ~10 us: launch-latency bound)

@@ -8,9 +8,11 @@ include/omgx.h) on the GPU, or the numpy oracle in the CPU distributed test.
 Sharding: agents are split contiguously over the ranks; a rank
 needs the consensus rows of the few remote agents its own agents are neighbours
 with (2 for the circular topology).  Every rank publishes the rows other ranks
-need, one `all_gather` per exchange, plus one `all_reduce` of the three residual
-sums per iteration (reference: plain attribute reads `admm.py:468-475` and a Python
-sum `admm.py:601-603`).
+need.  Two collectives per iteration: one `all_gather` of the published x_i rows after the
+x-update, and one `all_gather` of the published [z_ij | l_ij] rows in which every rank's three
+residual sums ride along as one more row (reference: plain attribute reads `admm.py:468-475` and
+a Python sum `admm.py:601-603`).  Nothing is copied to the host inside the loop: the residual
+history stays on the device until somebody asks for it.
 """
 import ctypes as C
 
@@ -44,6 +46,9 @@ class HaloPlan(object):
         publish = [sorted(set(g for q in range(world) if q != r for g in needed[q] if owner[g] == r))
                    for r in range(world)]
         self.max_pub = max([len(pp) for pp in publish] + [1])
+        # the same on every rank: either all ranks enter the collective of an exchange or none does (a rank
+        # whose own agents only have local neighbours must still take part when another rank needs rows)
+        self.any_halo = any(len(nd) > 0 for nd in needed)
         self.publish_local = np.array([g - self.lo for g in publish[rank]], dtype=np.int64)
         self.needed = needed[rank]
         # where each needed agent sits in the all_gather result [world, max_pub, width]
@@ -57,47 +62,79 @@ class HaloPlan(object):
 
 class BatchADMM(object):
 
-    def __init__(self, layout, nbr_global, ops, rank=0, world=1, dist=None, rho=1.0, horizon_time=10.):
+    def __init__(self, layout, nbr_global, ops, rank=0, world=1, dist=None, rho=1.0, horizon_time=10.,
+                 nesterov_acceleration=False, nesterov_reset=False, eta=0.999, AMA=False):
         self.lay, self.ops, self.dist = layout, ops, dist
         self.halo = HaloPlan(np.asarray(nbr_global), rank, world)
         self.slot = reverse_slots(np.asarray(nbr_global))[self.halo.lo:self.halo.hi].astype(np.int32)
         self.rho, self.T = float(rho), float(horizon_time)
+        # `problems/admm.py:568-571` (options of ADMMProblem)
+        self.nesterov, self.nesterov_reset, self.eta, self.AMA = bool(nesterov_acceleration), bool(nesterov_reset), float(eta), bool(AMA)
         self._mcache = {}
         self.iteration = 0
-        self.residuals = []
+        self._res = []                     # per iteration: backend array [3] = (pr^2 sum, dr^2 sum, cr sum)
+        if hasattr(ops, 'bind'):
+            ops.bind(self.halo, self.slot)
 
     # -- exchange ---------------------------------------------------------------------
-    def extend(self, local):
-        """[B_local, w] -> [B_local + halo, w] (backend array type in, same type out)."""
-        if self.halo.world == 1 or not self.halo.needed:
-            return local
-        return self.ops.exchange(local, self.halo, self.dist)
+    def exchanging(self):
+        return self.halo.world > 1 and self.halo.any_halo
+
+    def extend(self, local, extra=None):
+        """[B_local, w] -> [B_local + halo, w] (backend array type in, same type out).  `extra` ([k] values)
+        rides along and comes back summed over the ranks."""
+        if not self.exchanging():
+            return (local, extra) if extra is not None else local
+        out, summed = self.ops.exchange(local, self.halo, self.dist, extra)
+        return (out, summed) if extra is not None else out
 
     def matrices(self, t_rel):
         key = round(t_rel / self.T, 12)
         if key not in self._mcache:
-            self._mcache[key] = zupdate_matrices(self.lay.basis, self.lay.n_dim, self.lay.n_nghb, key)
+            M, F = zupdate_matrices(self.lay.basis, self.lay.n_dim, self.lay.n_nghb, key)
+            self._mcache[key] = self.ops.resident(M, F) if hasattr(self.ops, 'resident') else (M, F)
         return self._mcache[key]
 
     # -- iteration ----------------------------------------------------------------------
     def initialize(self):
         self.ops.init_consensus(self.lay)
 
-    def iterate(self, t_rel=0.0):
+    def iterate(self, t_rel=0.0, sync=True):
+        """One ADMM iteration (`admm.py:584-611`).  sync=False returns (status, None) and leaves the
+        residuals on the device (`residuals` fetches the whole history at once)."""
         ops, lay = self.ops, self.lay
         ops.set_time(lay, t_rel, self.rho)
         status = ops.solve()                                   # x-update
         x_i = ops.center(lay)
-        x_ext = self.extend(x_i)                               # communicate #1
+        x_ext = self.extend(x_i)                               # collective #1
         M, F = self.matrices(t_rel)
+        if self.nesterov:
+            ops.save_previous(lay)                             # z_p, l_p of `admm.py:409-410, 450-451`
         res = ops.update(lay, x_ext, self.halo.nbr_local, M, F, self.rho)
-        z_ext, l_ext = self.extend(ops.z_ij_flat()), self.extend(ops.l_ij_flat())
-        ops.communicate(lay, self.halo.nbr_local, self.slot, z_ext, l_ext)   # communicate #2
-        sums = ops.reduce_residuals(res, self.dist if self.halo.world > 1 else None)
-        pr, dr, cr = float(np.sqrt(sums[0])), float(np.sqrt(sums[1])), float(sums[2])
-        self.residuals.append((pr, dr, cr))
+        sums = ops.residual_sums(res)                          # [3], backend array, no host copy
+        # with acceleration the previous z_ij, l_ij travel too: the extrapolation is elementwise with fleet-wide
+        # scalars, so every rank applies it to the rows it received instead of waiting for a third collective
+        buf = ops.zl_flat(with_prev=self.nesterov)
+        if self.exchanging():
+            buf, sums = self.extend(buf, sums)                 # collective #2: [z_ij | l_ij] rows + the residual sums
+        elif self.dist is not None and self.halo.world > 1:
+            sums = ops.allreduce(sums, self.dist)              # (no halo anywhere: disjoint groups still share the sums)
+        zl_ext = ops.accelerate(lay, sums, buf, self.eta, self.nesterov_reset, self.AMA) if self.nesterov else buf
+        ops.communicate(lay, self.halo.nbr_local, self.slot, zl_ext)
+        self._res.append(sums)
         self.iteration += 1
-        return status, (pr, dr, cr)
+        if not sync:
+            return status, None
+        s3 = ops.to_host(sums)
+        return status, (float(np.sqrt(s3[0])), float(np.sqrt(s3[1])), float(s3[2]))
+
+    @property
+    def residuals(self):
+        """[(primal, dual, combined)] per iteration (`admm.py:601-605, 624-627`); one host copy."""
+        if not self._res:
+            return []
+        arr = self.ops.to_host_stack(self._res)
+        return [(float(np.sqrt(r[0])), float(np.sqrt(r[1])), float(r[2])) for r in arr]
 
 
 class HipAdmmOps(object):
@@ -134,6 +171,25 @@ class HipAdmmOps(object):
             [C.c_double] + [C.c_void_p] * 4
         lib.omgx_admm_communicate.argtypes = [C.c_void_p, C.POINTER(AdmmLayoutC)] + [C.c_void_p] * 5
         solver.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.zl = torch.zeros((B, 2 * self.nn * self.ns), **f64)      # [z_ij | l_ij] packed for the exchange
+        self._nbr = self._slot = None
+        # Nesterov state (`admm.py:510-554`), all on the device
+        self.alpha = torch.ones((), **f64)
+        self.c_res_p = None
+        self._prev = None
+
+    def bind(self, halo, slot):
+        """Index tensors that never change: uploaded once."""
+        t = self.torch
+        self._nbr = t.as_tensor(np.ascontiguousarray(halo.nbr_local), dtype=t.int32, device=self.dev)
+        self._slot = t.as_tensor(np.ascontiguousarray(slot), dtype=t.int32, device=self.dev)
+        self._pub = t.as_tensor(halo.publish_local, dtype=t.int64, device=self.dev)
+        self._src = t.as_tensor(halo.src, dtype=t.int64, device=self.dev)
+
+    def resident(self, M, F):
+        t = self.torch
+        return (t.as_tensor(np.ascontiguousarray(M), dtype=t.float64, device=self.dev),
+                t.as_tensor(np.ascontiguousarray(F), dtype=t.float64, device=self.dev))
 
     def _chk(self, rc, what):
         if rc != 0:
@@ -167,16 +223,31 @@ class HipAdmmOps(object):
 
     def update(self, lay, x_ext, nbr_local, M, F, rho):
         t = self.torch
-        nbr = t.as_tensor(np.ascontiguousarray(nbr_local), dtype=t.int32, device=self.dev)
-        Md = t.as_tensor(np.ascontiguousarray(M), dtype=t.float64, device=self.dev)
-        Fd = t.as_tensor(np.ascontiguousarray(F), dtype=t.float64, device=self.dev)
+        if self._nbr is None:                      # (used without BatchADMM.bind: upload now)
+            self._nbr = t.as_tensor(np.ascontiguousarray(nbr_local), dtype=t.int32, device=self.dev)
+        if not t.is_tensor(M):
+            M, F = self.resident(M, F)
         x_ext = x_ext.contiguous()
         self._chk(self.solver.lib.omgx_admm_update(
-            self.solver._h, C.byref(self.layc), x_ext.data_ptr(), nbr.data_ptr(), Md.data_ptr(),
-            Fd.data_ptr(), float(rho), self.p.data_ptr(), self.z_ij.data_ptr(), self.l_ij.data_ptr(),
+            self.solver._h, C.byref(self.layc), x_ext.data_ptr(), self._nbr.data_ptr(), M.data_ptr(),
+            F.data_ptr(), float(rho), self.p.data_ptr(), self.z_ij.data_ptr(), self.l_ij.data_ptr(),
             self.res.data_ptr()), 'omgx_admm_update')
-        self._keep = (nbr, Md, Fd, x_ext)
+        self._keep = (M, F, x_ext)
         return self.res
+
+    def residual_sums(self, res):
+        return res.sum(dim=0)
+
+    def zl_flat(self, with_prev=False):
+        B, w = self.B, self.nn * self.ns
+        if with_prev and self.zl.shape[1] != 4 * w:
+            self.zl = self.torch.zeros((B, 4 * w), dtype=self.torch.float64, device=self.dev)
+        self.zl[:, :w] = self.z_ij.view(B, -1)
+        self.zl[:, w:2 * w] = self.l_ij.view(B, -1)
+        if with_prev:
+            self.zl[:, 2 * w:3 * w] = self._prev[1].view(B, -1)
+            self.zl[:, 3 * w:] = self._prev[3].view(B, -1)
+        return self.zl
 
     def z_ij_flat(self):
         return self.z_ij.view(self.B, -1)
@@ -184,15 +255,57 @@ class HipAdmmOps(object):
     def l_ij_flat(self):
         return self.l_ij.view(self.B, -1)
 
-    def communicate(self, lay, nbr_local, slot, z_ext, l_ext):
+    def communicate(self, lay, nbr_local, slot, zl_ext):
         t = self.torch
-        nbr = t.as_tensor(np.ascontiguousarray(nbr_local), dtype=t.int32, device=self.dev)
-        sl = t.as_tensor(np.ascontiguousarray(slot), dtype=t.int32, device=self.dev)
-        z_ext, l_ext = z_ext.contiguous(), l_ext.contiguous()
+        if self._slot is None:
+            self._nbr = t.as_tensor(np.ascontiguousarray(nbr_local), dtype=t.int32, device=self.dev)
+            self._slot = t.as_tensor(np.ascontiguousarray(slot), dtype=t.int32, device=self.dev)
+        w = self.nn * self.ns
+        z_ext, l_ext = zl_ext[:, :w].contiguous(), zl_ext[:, w:].contiguous()
         self._chk(self.solver.lib.omgx_admm_communicate(
-            self.solver._h, C.byref(self.layc), nbr.data_ptr(), sl.data_ptr(), z_ext.data_ptr(),
+            self.solver._h, C.byref(self.layc), self._nbr.data_ptr(), self._slot.data_ptr(), z_ext.data_ptr(),
             l_ext.data_ptr(), self.p.data_ptr()), 'omgx_admm_communicate')
-        self._keep2 = (nbr, sl, z_ext, l_ext)
+        self._keep2 = (z_ext, l_ext)
+
+    # -- Nesterov acceleration (`admm.py:510-554`), branch-free on the device --------------------
+    def save_previous(self, lay):
+        ns = self.ns
+        self._prev = (self.p[:, lay.p_zi:lay.p_zi + ns].clone(), self.z_ij.clone(),
+                      self.p[:, lay.p_li:lay.p_li + ns].clone(), self.l_ij.clone())
+
+    def accelerate(self, lay, sums, ext, eta, reset, AMA):
+        """ext [B + halo, 4w] = [z_ij | l_ij | z_ij_p | l_ij_p] -> accelerated [z_ij | l_ij] of the same rows; the
+        local rows and z_i, l_i are updated in place."""
+        t, ns, B, w = self.torch, self.ns, self.B, self.nn * self.ns
+        c_res = sums[2]
+        if self.c_res_p is None:
+            self.c_res_p = c_res / eta
+        z_i, l_i = self.p[:, lay.p_zi:lay.p_zi + ns], self.p[:, lay.p_li:lay.p_li + ns]
+        z_i_p, l_i_p = self._prev[0], self._prev[2]
+        alpha_p = self.alpha
+        alpha_n = 0.5 * (1. + t.sqrt(1. + 4. * alpha_p ** 2))
+        wl = (alpha_p - 1.) / alpha_n
+        wz = t.zeros_like(wl) if AMA else wl
+        good = (c_res <= eta * self.c_res_p) if reset else t.ones((), dtype=t.bool, device=self.dev)
+        z_i.copy_(t.where(good, z_i + wz * (z_i - z_i_p), z_i_p))
+        l_i.copy_(t.where(good, l_i + wl * (l_i - l_i_p), l_i_p))
+        z, l, z_p, l_p = ext[:, :w], ext[:, w:2 * w], ext[:, 2 * w:3 * w], ext[:, 3 * w:]
+        out = t.cat([t.where(good, z + wz * (z - z_p), z_p), t.where(good, l + wl * (l - l_p), l_p)], dim=1)
+        self.z_ij.copy_(out[:B, :w].reshape(B, self.nn, ns))
+        self.l_ij.copy_(out[:B, w:].reshape(B, self.nn, ns))
+        self.alpha = t.where(good, alpha_n, t.ones_like(alpha_n))
+        self.c_res_p = t.where(good, c_res, self.c_res_p / eta)
+        return out
+
+    def to_host(self, a):
+        return a.cpu().numpy()
+
+    def to_host_stack(self, lst):
+        return self.torch.stack(lst).cpu().numpy()
+
+    def allreduce(self, sums, dist):
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        return sums
 
     # -- host bookkeeping of the drop-in problem class (formation.FormationPoint2point) -----------
     def upload_params(self, p_host, cols):
@@ -220,20 +333,19 @@ class HipAdmmOps(object):
             self._chk(lib.omgx_shift_rows(h, data.data_ptr(), int(stride), self.B, None, ents.ctypes.data,
                                           len(ents), mats.ctypes.data, mats.size), 'omgx_shift_rows')
 
-    def exchange(self, local, halo, dist):
+    def exchange(self, local, halo, dist, extra=None):
+        """One all_gather: every rank sends the rows other ranks need (+ one row carrying `extra`, whose sum
+        over the ranks is returned).  -> ([B_local + halo, w], summed extra or None)."""
         t = self.torch
         w = local.shape[1]
-        send = t.zeros((halo.max_pub, w), dtype=local.dtype, device=local.device)
+        rows = halo.max_pub + (1 if extra is not None else 0)
+        send = t.zeros((rows, w), dtype=local.dtype, device=local.device)
         if len(halo.publish_local):
-            send[:len(halo.publish_local)] = local[t.as_tensor(halo.publish_local, device=local.device)]
-        gathered = [t.empty_like(send) for _ in range(halo.world)]
-        dist.all_gather(gathered, send)
-        allp = t.stack(gathered)
-        src = t.as_tensor(halo.src, device=local.device)
-        return t.cat([local, allp[src[:, 0], src[:, 1]]], dim=0)
-
-    def reduce_residuals(self, res, dist):
-        sums = res.sum(dim=0)
-        if dist is not None:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        return sums.cpu().numpy()
+            send[:len(halo.publish_local)] = local[self._pub]
+        if extra is not None:
+            send[halo.max_pub, :extra.numel()] = extra
+        allp = t.empty((halo.world,) + tuple(send.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(allp, send)
+        summed = allp[:, halo.max_pub, :extra.numel()].sum(dim=0) if extra is not None else None
+        out = t.cat([local, allp[self._src[:, 0], self._src[:, 1]]], dim=0) if len(halo.needed) else local
+        return out, summed

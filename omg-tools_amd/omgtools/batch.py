@@ -132,14 +132,16 @@ class BatchP2P(object):
                 raise ValueError("ops must be 'hip' or an injected host solver object (tests / CPU baseline)")
             self.port = ops                          # injected by tests / bench.py's cpu_baseline leg
             self.n_threads = 1
+            self.pool = None                         # optional: a host solver with `solve(p, x, lam, status, iters, dw,
+            #                                          step=...)` that also runs the step glue per agent (bench.py)
             self.dw = np.zeros(self.B)            # inertia correction carried between warm solves
-            self.p, self.x = np.array(P['p'], float), np.array(P['x0'], float)
+            self.p, self.x = np.ascontiguousarray(P['p'], dtype=float).copy(), np.ascontiguousarray(P['x0'], dtype=float).copy()
             self.lam = np.zeros((self.B, tpl.n_con))
             self.status = np.zeros(self.B, dtype=np.int32)
             self.iters = np.zeros(self.B, dtype=np.int32)
 
     # -- solves ------------------------------------------------------------------------
-    def _solve(self, warm, events=None):
+    def _solve(self, warm, events=None, step_desc=None):
         if self.kind == 'hip':
             self.solver.set_options(warm_start=int(warm),
                                     max_iter=self.max_iter_step if warm else self.max_iter_cold)
@@ -155,6 +157,11 @@ class BatchP2P(object):
             if events is not None:
                 events[1].record()
             self.x, self.x_new = self.x_new, self.x
+        elif self.pool is not None:
+            if not warm:
+                self.lam[:] = 0.
+            self.pool.solve(self.p, self.x, self.lam, self.status, self.iters, self.dw, step=step_desc,
+                            **dict(self.opts, warm_start=int(warm), max_iter=self.max_iter_step if warm else self.max_iter_cold))
         else:
             r = self.port.solve(self.tpl, self.p, self.x, lam_g0=self.lam if warm else None,
                                 status0=self.status if warm else None, warm_start=int(warm),
@@ -175,6 +182,10 @@ class BatchP2P(object):
         tau = (rel_prev + self.update_time) / self.T
         crossed = int(np.round(t_prev / self.knot_time, 6)) < int(np.round(t_now / self.knot_time, 6))
         t_rel = float(np.round(t_now, 6) % self.knot_time)
+        if self.kind == 'host' and self.pool is not None:
+            self.time = t_now
+            self._solve(True, step_desc=self._pool_step(tau, t_rel, crossed))
+            return crossed
         if self.kind == 'hip':
             # one kernel: state0 / input0 from the plan at tau and the new t, all written into p
             self.solver.predict(self.x, self.p, self.o_spl, nd, self.basis.degree, self.basis.knots, tau,
@@ -199,6 +210,27 @@ class BatchP2P(object):
         # (3) warm-started solve
         self._solve(True, events)
         return crossed
+
+    def _pool_step(self, tau, t_rel, crossed):
+        """Constants of this step for a pool that runs the glue per agent in its workers (field names of the
+        `StepDesc` the pool defines)."""
+        desc = self.pool.step_desc()
+        E = np.ascontiguousarray(self.basis.eval_basis([tau])[0])
+        dbasis, P1 = self.basis.derivative(1)
+        Ed = np.ascontiguousarray(dbasis.eval_basis([tau])[0] @ P1 / self.T)
+        obst = np.ascontiguousarray(np.array(self.obst, dtype=np.int32).reshape(-1, 4))
+        perm = np.ascontiguousarray(self.perm, dtype=np.int64)
+        ents = np.ascontiguousarray(self.shift_entries, dtype=np.int32)
+        mats = np.ascontiguousarray(self.shift_mats, dtype=np.float64)
+        desc._keep = (E, Ed, obst, perm, ents, mats)
+        desc.o_spl, desc.n_dim, desc.L = self.o_spl, self.n_dim, self.L
+        desc.o_state0, desc.o_input0, desc.o_t = self.o_state0, self.o_input0, self.o_t
+        desc.t_rel, desc.dt = t_rel, self.update_time
+        desc.E, desc.Ed = E.ctypes.data, Ed.ctypes.data
+        desc.n_obst, desc.obst = len(self.obst), obst.ctypes.data
+        desc.crossed, desc.n_shift = int(crossed), len(ents)
+        desc.shift_entries, desc.shift_mats, desc.perm = ents.ctypes.data, mats.ctypes.data, perm.ctypes.data
+        return desc
 
     def _shift(self):
         if self.kind == 'hip':

@@ -212,6 +212,7 @@ class FormationPoint2point(object):
         self.environment = environment
         self.options = {'verbose': 2, 'horizon_time': 10., 'rho': 2., 'init_iter': 5,
                         'max_iter_per_update': 1, 'max_iter': None, 'solver': 'ipopt',
+                        'nesterov_acceleration': False, 'eta': 0.999, 'nesterov_reset': False, 'AMA': False,
                         'solver_options': {'ipopt': {'ipopt.tol': 1e-3}}}
         for key, value in (options or {}).items():
             if key == 'solver_options':
@@ -235,7 +236,8 @@ class FormationPoint2point(object):
             raise ValueError('every vehicle needs the same number of neighbours (one shared x-update template)')
         self.nbr = np.array(nbr, dtype=np.int32)
         sub_opts = {k: v for k, v in self.options.items()
-                    if k not in ('rho', 'init_iter', 'max_iter_per_update', 'max_iter')}
+                    if k not in ('rho', 'init_iter', 'max_iter_per_update', 'max_iter', 'nesterov_acceleration',
+                                 'eta', 'nesterov_reset', 'AMA')}
         sub_opts['verbose'] = 0
         self.subs = []
         for veh in self.vehicles:
@@ -285,7 +287,8 @@ class FormationPoint2point(object):
         else:
             self.ops = self._ops_kind(tpl, lay, p0, x0, self.xupdate_tol())
         self.admm = BatchADMM(lay, self.nbr, self.ops, rho=self.options['rho'],
-                              horizon_time=self.options['horizon_time'])
+                              horizon_time=self.options['horizon_time'],
+                              **{k: self.options[k] for k in ('nesterov_acceleration', 'eta', 'nesterov_reset', 'AMA')})
         return 0.
 
     def xupdate_tol(self):

@@ -37,7 +37,7 @@ def _place_obstacles(rng, n_obs, start, goal, r_lo, r_hi, box, clearance=0.3, ga
 
 
 def holonomic_p2p(n_agents, knot_intervals=11, n_obs=3, seed=20240807 + 2,
-                  safety_distance=0., horizon_time=10., options=None):
+                  safety_distance=0., horizon_time=10., options=None, gap=0.25):
     """Config 2: batch of independent Holonomic point-to-point problems with
     `n_obs` static circular obstacles each."""
     rng = np.random.default_rng(seed)
@@ -60,7 +60,7 @@ def holonomic_p2p(n_agents, knot_intervals=11, n_obs=3, seed=20240807 + 2,
     for b in range(n_agents):
         start = rng_pos.uniform(-2., -1., size=2)
         goal = rng_pos.uniform(1., 2., size=2)
-        centres, radii = _place_obstacles(rng_pos, n_obs, start, goal, 0.2, 0.4, 0.8)
+        centres, radii = _place_obstacles(rng_pos, n_obs, start, goal, 0.2, 0.4, 0.8, gap=gap)
         lo, hi = tpl.entry_range(vehicle.label, 'state0', 'par'); p[b, lo:hi] = start
         lo, hi = tpl.entry_range(vehicle.label, 'poseT', 'par'); p[b, lo:hi] = goal
         for l, obs in enumerate(environment.obstacles):

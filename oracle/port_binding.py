@@ -68,3 +68,97 @@ def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, status0=N
     if rc != 0:
         raise RuntimeError('omgx_port_solve failed: %d' % rc)
     return dict(x=x, lam_g=lam, status=status, iters=iters)
+
+
+# -- bench.py's cpu_baseline: persistent pinned pool, plan built once, step glue in C ---------------------
+class StepDesc(C.Structure):
+    _fields_ = [('o_spl', C.c_int32), ('n_dim', C.c_int32), ('L', C.c_int32), ('o_state0', C.c_int32),
+                ('o_input0', C.c_int32), ('o_t', C.c_int32), ('t_rel', C.c_double), ('dt', C.c_double),
+                ('E', C.c_void_p), ('Ed', C.c_void_p), ('n_obst', C.c_int32), ('obst', C.c_void_p),
+                ('crossed', C.c_int32), ('n_shift', C.c_int32), ('shift_entries', C.c_void_p),
+                ('shift_mats', C.c_void_p), ('perm', C.c_void_p)]
+
+
+def physical_cpus():
+    """One logical cpu per physical core (first sibling of every /sys topology group); all cpus the process
+    may run on when the topology files are missing."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, out = set(), []
+    for cpu in allowed:
+        path = '/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list' % cpu
+        try:
+            key = open(path).read().strip()
+        except OSError:
+            key = str(cpu)
+        if key not in seen:
+            seen.add(key)
+            out.append(cpu)
+    return out
+
+
+def cpu_quota():
+    """cpus the cgroup grants (cpu.max quota / period, cgroup v2; cfs_quota_us / cfs_period_us, v1); None = no limit."""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        return None if q == 'max' else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+def granted_cpus():
+    """The cpus a fair baseline runs on: one logical cpu per physical core, no more of them than the cgroup's
+    cpu quota pays for (threads beyond the quota only get throttled: tools/cpu_pool_sweep.py)."""
+    cpus = physical_cpus()
+    quota = cpu_quota()
+    if quota is not None:
+        cpus = cpus[:max(1, int(quota + 0.5))]
+    return cpus
+
+
+class PortPool(object):
+    """Host solver with the life cycle of the HIP handle: created once per template, reused by every step."""
+
+    def __init__(self, template, cpus=None, n_threads=None):
+        be = _backend()
+        self.lib = lib = load()
+        lib.omgx_port_pool_create.restype = C.c_void_p
+        lib.omgx_port_pool_create.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib.omgx_port_pool_destroy.argtypes = [C.c_void_p]
+        lib.omgx_port_pool_solve.restype = C.c_int
+        lib.omgx_port_pool_solve.argtypes = [C.c_void_p] * 2 + [C.c_int32] + [C.c_void_p] * 9
+        self.tpl, self._be = template, be
+        ct, self._keep = be.make_ctemplate(template)
+        if n_threads is None:
+            cpus = granted_cpus() if cpus is None else list(cpus)
+            n_threads = len(cpus)
+        self.n_threads = int(n_threads)
+        arr = np.ascontiguousarray(cpus, dtype=np.int32) if cpus is not None else None
+        self._h = lib.omgx_port_pool_create(C.addressof(ct), self.n_threads, arr.ctypes.data if arr is not None else None)
+        if not self._h:
+            raise RuntimeError('omgx_port_pool_create failed')
+        self.lb = np.ascontiguousarray(template.lb, dtype=float)
+        self.ub = np.ascontiguousarray(template.ub, dtype=float)
+
+    def solve(self, p, x, lam, status, iters, dw, step=None, **options):
+        """In place on the caller's arrays (p, x, lam, status, iters, dw: C-contiguous, float64 / int32)."""
+        opt = self._be.make_options(**options)
+        rc = self.lib.omgx_port_pool_solve(self._h, C.addressof(opt), p.shape[0], p.ctypes.data, x.ctypes.data,
+                                           self.lb.ctypes.data, self.ub.ctypes.data, lam.ctypes.data,
+                                           status.ctypes.data, iters.ctypes.data, dw.ctypes.data,
+                                           C.addressof(step) if step is not None else None)
+        if rc != 0:
+            raise RuntimeError('omgx_port_pool_solve failed: %d' % rc)
+
+    def step_desc(self):
+        return StepDesc()
+
+    def close(self):
+        if self._h:
+            self.lib.omgx_port_pool_destroy(self._h)
+            self._h = None

@@ -84,27 +84,80 @@ class NumpyAdmmOps(object):
     def l_ij_flat(self):
         return self.l_ij.reshape(self.B, -1)
 
-    def communicate(self, lay, nbr, slot, z_ext, l_ext):
+    def zl_flat(self, with_prev=False):
+        parts = [self.z_ij, self.l_ij] + ([self._prev[1], self._prev[3]] if with_prev else [])
+        return np.concatenate([a.reshape(self.B, -1) for a in parts], axis=1)
+
+    def residual_sums(self, res):
+        return res.sum(axis=0)
+
+    def communicate(self, lay, nbr, slot, zl_ext):
         ns, nn = self.ns, self.nn
-        z_ext, l_ext = z_ext.reshape(-1, nn, ns), l_ext.reshape(-1, nn, ns)
+        w = nn * ns
+        z_ext, l_ext = zl_ext[:, :w].reshape(-1, nn, ns), zl_ext[:, w:].reshape(-1, nn, ns)
         for k in range(nn):
             self.p[:, lay.p_zji + k * ns:lay.p_zji + (k + 1) * ns] = z_ext[nbr[:, k], slot[:, k]]
             self.p[:, lay.p_lji + k * ns:lay.p_lji + (k + 1) * ns] = l_ext[nbr[:, k], slot[:, k]]
 
-    def exchange(self, local, halo, dist):
+    def exchange(self, local, halo, dist, extra=None):
         import torch
         w = local.shape[1]
-        send = torch.zeros((halo.max_pub, w), dtype=torch.float64)
+        rows = halo.max_pub + (1 if extra is not None else 0)
+        send = torch.zeros((rows, w), dtype=torch.float64)
         if len(halo.publish_local):
             send[:len(halo.publish_local)] = torch.from_numpy(local[halo.publish_local])
+        if extra is not None:
+            send[halo.max_pub, :len(extra)] = torch.from_numpy(np.asarray(extra, float))
         gathered = [torch.empty_like(send) for _ in range(halo.world)]
         dist.all_gather(gathered, send)
         allp = torch.stack(gathered).numpy()
-        return np.concatenate([local, allp[halo.src[:, 0], halo.src[:, 1]]], axis=0)
+        summed = allp[:, halo.max_pub, :len(extra)].sum(axis=0) if extra is not None else None
+        out = np.concatenate([local, allp[halo.src[:, 0], halo.src[:, 1]]], axis=0) if len(halo.needed) else local
+        return out, summed
 
-    def reduce_residuals(self, res, dist):
+    def allreduce(self, sums, dist):
         import torch
-        sums = torch.from_numpy(res.sum(axis=0))
-        if dist is not None:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        return sums.numpy()
+        s = torch.from_numpy(np.asarray(sums, float).copy())
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        return s.numpy()
+
+    def to_host(self, a):
+        return np.asarray(a)
+
+    def to_host_stack(self, lst):
+        return np.stack([np.asarray(a) for a in lst])
+
+    # -- Nesterov acceleration: the reference's statements (`admm.py:510-554`) ---------------------
+    def save_previous(self, lay):
+        ns = self.ns
+        self._prev = (self.p[:, lay.p_zi:lay.p_zi + ns].copy(), self.z_ij.copy(),
+                      self.p[:, lay.p_li:lay.p_li + ns].copy(), self.l_ij.copy())
+
+    def accelerate(self, lay, sums, ext, eta, reset, AMA):
+        ns, nn, B = self.ns, self.nn, self.B
+        w = nn * ns
+        c_res = float(sums[2])
+        if not hasattr(self, 'c_res_p'):
+            self.c_res_p = (1. / eta) * c_res
+        if not hasattr(self, 'alpha'):
+            self.alpha = 1.
+        z_i, l_i = self.p[:, lay.p_zi:lay.p_zi + ns], self.p[:, lay.p_li:lay.p_li + ns]
+        z_i_p, l_i_p = self._prev[0], self._prev[2]
+        z_ij, l_ij, z_ij_p, l_ij_p = (ext[:, k * w:(k + 1) * w].copy() for k in range(4))
+        if (not reset) or c_res <= eta * self.c_res_p:
+            alpha_p = self.alpha
+            self.alpha = 0.5 * (1. + np.sqrt(1 + 4. * alpha_p ** 2))
+            if not AMA:
+                z_i[:] = z_i + ((alpha_p - 1) / self.alpha) * (z_i - z_i_p)
+                z_ij = z_ij + ((alpha_p - 1) / self.alpha) * (z_ij - z_ij_p)
+            l_i[:] = l_i + ((alpha_p - 1) / self.alpha) * (l_i - l_i_p)
+            l_ij = l_ij + ((alpha_p - 1) / self.alpha) * (l_ij - l_ij_p)
+            self.c_res_p = c_res
+        else:
+            self.alpha = 1.
+            z_i[:], l_i[:] = z_i_p, l_i_p
+            z_ij, l_ij = z_ij_p, l_ij_p
+            self.c_res_p = (1. / eta) * self.c_res_p
+        self.z_ij = z_ij[:B].reshape(B, nn, ns).copy()
+        self.l_ij = l_ij[:B].reshape(B, nn, ns).copy()
+        return np.concatenate([z_ij, l_ij], axis=1)

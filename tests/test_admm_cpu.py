@@ -76,7 +76,16 @@ def test_driver_matches_oracle_iteration():
     assert admm.residuals[-1][0] < admm.residuals[0][0]       # consensus is being reached
 
 
-def _worker(rank, world, port, q):
+def _ring_groups(sizes):
+    """Neighbour table of disjoint rings: agent i is coupled to its two ring neighbours."""
+    rows, off = [], 0
+    for m in sizes:
+        rows += [[off + (k + 1) % m, off + (k - 1) % m] for k in range(m)]
+        off += m
+    return np.array(rows, dtype=np.int32)
+
+
+def _worker(rank, world, port, q, n=6, sizes=None, kw=None):
     sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -86,40 +95,105 @@ def _worker(rank, world, port, q):
     from omgtools.admm import BatchADMM
     from omgtools.distributed import shard_range, gather_solutions
     from admm_numpy_ops import NumpyAdmmOps
-    tpl, lay, P = _scenario(6)
-    lo, hi = shard_range(6, rank, world)
+    tpl, lay, P = _scenario(n)
+    nbr = P['nbr'] if sizes is None else _ring_groups(sizes)
+    lo, hi = shard_range(n, rank, world)
     ops = NumpyAdmmOps(tpl, lay, P['p'][lo:hi], P['x0'][lo:hi])
-    admm = BatchADMM(lay, P['nbr'], ops, rank=rank, world=world, dist=dist, rho=1.0)
+    admm = BatchADMM(lay, nbr, ops, rank=rank, world=world, dist=dist, rho=1.0, **(kw or {}))
     admm.initialize()
-    for _ in range(3):
-        admm.iterate(0.0)
-    x_all = gather_solutions(ops.x, 6, dist=dist)
+    for _ in range(4 if kw else 3):
+        admm.iterate(0.0, sync=False)                         # nothing comes to the host inside the loop
+    x_all = gather_solutions(ops.x, n, dist=dist)
     if rank == 0:
         q.put((admm.residuals, x_all))
     dist.destroy_process_group()
 
 
-def test_two_rank_halo_exchange_matches_single_process():
+def _sharded_vs_single(world, n=6, sizes=None, kw=None, port_off=0):
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    from omgtools.admm import BatchADMM, HaloPlan
+    from omgtools.admm import BatchADMM
     from admm_numpy_ops import NumpyAdmmOps
-    tpl, lay, P = _scenario(6)
-    halo = HaloPlan(P['nbr'], 1, 2)
-    assert (halo.lo, halo.hi) == (3, 6) and halo.needed == [0, 2]
+    tpl, lay, P = _scenario(n)
+    nbr = P['nbr'] if sizes is None else _ring_groups(sizes)
     ops = NumpyAdmmOps(tpl, lay, P['p'], P['x0'])
-    ref = BatchADMM(lay, P['nbr'], ops, rho=1.0)
+    ref = BatchADMM(lay, nbr, ops, rho=1.0, **(kw or {}))
     ref.initialize()
-    for _ in range(3):
+    for _ in range(4 if kw else 3):
         ref.iterate(0.0)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 1000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + port_off + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n, sizes, kw)) for r in range(world)]
     for pr in procs:
         pr.start()
-    residuals, x_all = q.get(timeout=240)
-    for pr in procs:
-        pr.join(timeout=60)
-        assert pr.exitcode == 0
+    try:
+        residuals, x_all = q.get(timeout=240)
+    finally:
+        for pr in procs:
+            pr.join(timeout=60)
+            if pr.is_alive():
+                pr.terminate()
+    assert all(pr.exitcode == 0 for pr in procs)
     assert np.allclose(np.array(residuals), np.array(ref.residuals), rtol=1e-9, atol=1e-12)
     assert np.abs(x_all - ops.x).max() < 1e-9
+    return ref
+
+
+def test_two_rank_halo_exchange_matches_single_process():
+    from omgtools.admm import HaloPlan
+    nbr = _scenario(6)[2]['nbr']
+    halo = HaloPlan(nbr, 1, 2)
+    assert (halo.lo, halo.hi) == (3, 6) and halo.needed == [0, 2] and halo.any_halo
+    _sharded_vs_single(2)
+
+
+def test_rank_without_halo_needs_still_joins_the_collectives():
+    """Agents 0..5 form one ring over ranks 0 and 1, agents 6..8 a ring of their own on rank 2: rank 2 needs
+    nothing and publishes nothing, but the exchange is a collective of all three ranks (a rank that skips
+    it leaves the others waiting; its residual sums also travel in it)."""
+    from omgtools.admm import HaloPlan
+    nbr = _ring_groups([6, 3])
+    halos = [HaloPlan(nbr, r, 3) for r in range(3)]
+    assert halos[2].needed == [] and len(halos[2].publish_local) == 0
+    assert halos[0].needed and all(h.any_halo for h in halos)
+    _sharded_vs_single(3, n=9, sizes=[6, 3], port_off=1000)
+
+
+def test_nesterov_acceleration_sharded_matches_single_process():
+    """`problems/admm.py:510-554` with reset: the previous z_ij, l_ij ride in the second exchange and every rank
+    extrapolates the rows it received with the fleet-wide alpha / reset decision."""
+    kw = dict(nesterov_acceleration=True, nesterov_reset=True, eta=0.999)
+    ref = _sharded_vs_single(2, kw=kw, port_off=2000)
+    assert ref.ops.alpha >= 1.0
+
+
+def test_nesterov_statements_against_the_reference_formulas():
+    """One accelerate() of the ops against the reference's statements written out on plain arrays."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from omgtools.admm import BatchADMM
+    from admm_numpy_ops import NumpyAdmmOps
+    tpl, lay, P = _scenario(5)
+    ops = NumpyAdmmOps(tpl, lay, P['p'], P['x0'])
+    admm = BatchADMM(lay, P['nbr'], ops, rho=1.0, nesterov_acceleration=True, nesterov_reset=False)
+    admm.initialize()
+    admm.iterate(0.0)                                           # alpha 1 -> (1 + sqrt 5) / 2, weight 0
+    ns = lay.ns
+    z_p, l_p = ops.p[:, lay.p_zi:lay.p_zi + ns].copy(), ops.p[:, lay.p_li:lay.p_li + ns].copy()
+    zij_p, lij_p = ops.z_ij.copy(), ops.l_ij.copy()
+    a1 = ops.alpha
+    assert abs(a1 - 0.5 * (1 + np.sqrt(5.))) < 1e-15
+    # second iteration: redo the plain update on a copy, then extrapolate by hand
+    plain = NumpyAdmmOps(tpl, lay, ops.p.copy(), ops.x.copy())
+    plain.z_ij, plain.l_ij = zij_p.copy(), lij_p.copy()
+    plain.lam, plain.status, plain.dw = ops.lam.copy(), ops.status.copy(), ops.dw.copy()
+    ref = BatchADMM(lay, P['nbr'], plain, rho=1.0)
+    ref.iterate(0.0)
+    admm.iterate(0.0)
+    a2 = 0.5 * (1 + np.sqrt(1 + 4 * a1 ** 2))
+    w = (a1 - 1) / a2
+    z_new, l_new = plain.p[:, lay.p_zi:lay.p_zi + ns], plain.p[:, lay.p_li:lay.p_li + ns]
+    assert np.allclose(ops.p[:, lay.p_zi:lay.p_zi + ns], z_new + w * (z_new - z_p), atol=1e-13)
+    assert np.allclose(ops.p[:, lay.p_li:lay.p_li + ns], l_new + w * (l_new - l_p), atol=1e-13)
+    assert np.allclose(ops.z_ij, plain.z_ij + w * (plain.z_ij - zij_p), atol=1e-13)
+    assert np.allclose(ops.l_ij, plain.l_ij + w * (plain.l_ij - lij_p), atol=1e-13)
+    assert abs(ops.alpha - a2) < 1e-15

@@ -81,3 +81,34 @@ def test_moving_obstacles_and_multi_vehicle_guard():
     P2 = {'p': np.zeros((1, prob2.father.template.n_par)), 'x0': np.zeros((1, prob2.father.template.n_var))}
     with pytest.raises(NotImplementedError):
         BatchP2P(prob2, P2, ops=port_binding)
+
+
+def test_pool_step_glue_in_c_equals_the_numpy_glue():
+    """bench.py's CPU baseline runs the step glue per agent inside the pinned workers of oracle/port
+    (`omgx_port_pool_solve`): same iterates as the numpy statements of BatchP2P.step, knot crossing included."""
+    import omgtools.backend as be
+    from omgtools.scenarios import holonomic_p2p
+    from omgtools.batch import BatchP2P
+    from oracle import port_binding
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        problem, P = holonomic_p2p(6)
+    finally:
+        be.create_nlp = saved
+    opts = dict(tol=1e-3, max_iter=300)
+    a = BatchP2P(problem, P, ops=port_binding, options=opts)
+    b = BatchP2P(problem, P, ops=port_binding, options=opts)
+    b.pool = port_binding.PortPool(problem.father.template, n_threads=2)
+    a.solve_cold()
+    b.solve_cold()
+    assert np.array_equal(a.x, b.x)
+    crossings = 0
+    for _ in range(11):
+        ca, cb = a.step(), b.step()
+        assert ca == cb
+        crossings += int(ca)
+        assert np.array_equal(a.status, b.status) and np.array_equal(a.iters, b.iters)
+        assert np.abs(a.x - b.x).max() < 1e-8 and np.abs(a.p - b.p).max() < 1e-11
+    assert crossings >= 1
+    b.pool.close()

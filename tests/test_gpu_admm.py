@@ -40,6 +40,35 @@ def test_batch_admm_matches_numpy_backend():
     solver.close()
 
 
+def test_nesterov_acceleration_matches_numpy_backend():
+    """`problems/admm.py:510-554` on the device (branch-free, alpha and the reset decision never visit the host)
+    against the reference's statements in the numpy backend; no host copy inside the loop."""
+    import torch
+    from test_admm_cpu import _scenario
+    from admm_numpy_ops import NumpyAdmmOps
+    from omgtools.admm import BatchADMM, HipAdmmOps
+    from omgtools.backend import BatchSolver
+    tpl, lay, P = _scenario(8)
+    dev = torch.device('cuda', 0)
+    for kw in (dict(nesterov_acceleration=True), dict(nesterov_acceleration=True, nesterov_reset=True, eta=0.9),
+               dict(nesterov_acceleration=True, AMA=True)):
+        solver = BatchSolver(tpl, 8, options=dict(tol=1e-6, max_iter=200))
+        gpu = BatchADMM(lay, P['nbr'], HipAdmmOps(solver, tpl, lay, P['p'], P['x0'], dev), rho=1.0, **kw)
+        cpu_ops = NumpyAdmmOps(tpl, lay, P['p'], P['x0'])
+        cpu = BatchADMM(lay, P['nbr'], cpu_ops, rho=1.0, **kw)
+        gpu.initialize()
+        cpu.initialize()
+        for it in range(5):
+            gpu.iterate(0.0, sync=False)
+            cpu.iterate(0.0)
+        assert np.allclose(np.array(gpu.residuals), np.array(cpu.residuals), rtol=1e-5, atol=1e-8), kw
+        assert abs(float(gpu.ops.alpha) - cpu_ops.alpha) < 1e-12, kw
+        assert np.abs(gpu.ops.z_ij.cpu().numpy() - cpu_ops.z_ij).max() < 1e-6, kw
+        assert np.abs(gpu.ops.l_ij.cpu().numpy() - cpu_ops.l_ij).max() < 1e-6, kw
+        assert np.abs(gpu.ops.p.cpu().numpy() - cpu_ops.p).max() < 1e-6, kw
+        solver.close()
+
+
 def test_shift_rows_on_consensus_state():
     import ctypes as C
     import torch
