@@ -105,6 +105,15 @@ typedef struct omgx_options {
 
 typedef struct omgx_batch omgx_batch;
 
+/* Template files.  The Python front end (omgtools.backend.save_template, after the reference's own
+ * `problem.init()` built the problem) writes the template of a problem class once; a C/C++ caller reads it
+ * back -- the role of the generated nlp.so in the reference's export (`export/export.py:236-262`,
+ * `export/point2point/Point2Point.cpp:80-91` generateProblem).  `omgx_template_read` allocates; release with
+ * `omgx_template_free` (never free() a template you filled in yourself with it). */
+int  omgx_template_write(const omgx_template* tpl, const char* path);
+int  omgx_template_read(const char* path, omgx_template** out);
+void omgx_template_free(omgx_template* tpl);
+
 int  omgx_version(void);
 const char* omgx_last_error(void);
 const char* omgx_status_string(int32_t status);

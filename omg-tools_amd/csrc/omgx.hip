@@ -541,6 +541,88 @@ int omgx_plan_describe(const omgx_template* tpl, omgx_plan_info* info, int32_t* 
   return OMGX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Template files: the counts and arrays of omgx_template, written by the Python front end
+// (omgtools.backend.save_template) once per problem class and read by C/C++ callers -- the role the
+// generated nlp.so plays for the reference's C++ export (`export/export.py:236-262`, loaded in
+// `Point2Point.cpp:80-91`).  Layout: "OMGXTPL2", 13 int32 counts, then the arrays in struct order.
+namespace {
+struct TplField { int kind; size_t count; const void* const* src; void** dst; };     // kind 0 int32, 1 double
+
+size_t tpl_fields(const omgx_template& t, omgx_template* m, TplField* f) {
+  const omgx_template& s = t;
+  size_t k = 0;
+#define OMGX_F(KD, NAME, CNT) f[k].kind = KD; f[k].count = (size_t)(CNT); f[k].src = (const void* const*)&s.NAME; f[k].dst = m ? (void**)&m->NAME : nullptr; ++k;
+  OMGX_F(0, prog, 6 * (size_t)t.n_prog)      OMGX_F(1, knots, t.n_knots)       OMGX_F(0, pp_ptr, t.n_pp + 1)
+  OMGX_F(1, pm_coef, t.n_mono)               OMGX_F(0, pm_ptr, t.n_mono + 1)   OMGX_F(0, pm_atom, t.n_matom)
+  OMGX_F(0, slot_pp, t.n_slots)              OMGX_F(0, row_ptr, t.n_con + 2)   OMGX_F(1, t_coef, t.n_terms)
+  OMGX_F(0, t_slot, t.n_terms)               OMGX_F(0, t_var, 3 * (size_t)t.n_terms)
+  OMGX_F(0, eq_rows, t.n_eq)                 OMGX_F(0, root_vars, t.n_root_vars)
+#undef OMGX_F
+  return k;
+}
+}  // namespace
+
+int omgx_template_write(const omgx_template* tpl, const char* path) {
+  int rc = check_template(tpl);
+  if (rc != OMGX_OK) return rc;
+  if (!path) { g_err = "null path"; return OMGX_E_INVALID; }
+  FILE* fp = fopen(path, "wb");
+  if (!fp) { g_err = std::string("cannot write ") + path; return OMGX_E_INVALID; }
+  const int32_t counts[13] = {tpl->n_var, tpl->n_par, tpl->n_con, tpl->n_atoms, tpl->n_slots, tpl->n_terms, tpl->n_prog,
+                              tpl->n_knots, tpl->n_pp, tpl->n_mono, tpl->n_matom, tpl->n_eq, tpl->n_root_vars};
+  bool ok = fwrite("OMGXTPL2", 1, 8, fp) == 8 && fwrite(counts, sizeof(int32_t), 13, fp) == 13;
+  TplField f[16];
+  const size_t nf = tpl_fields(*tpl, nullptr, f);
+  for (size_t i = 0; i < nf && ok; ++i) {
+    const size_t sz = f[i].kind ? sizeof(double) : sizeof(int32_t);
+    if (f[i].count && fwrite(*f[i].src, sz, f[i].count, fp) != f[i].count) ok = false;
+  }
+  if (fclose(fp) != 0) ok = false;
+  if (!ok) { g_err = std::string("short write to ") + path; return OMGX_E_INVALID; }
+  return OMGX_OK;
+}
+
+void omgx_template_free(omgx_template* t) {
+  if (!t) return;
+  TplField f[16];
+  const size_t nf = tpl_fields(*t, t, f);
+  for (size_t i = 0; i < nf; ++i) free(*f[i].dst);
+  free(t);
+}
+
+int omgx_template_read(const char* path, omgx_template** out) {
+  if (!path || !out) { g_err = "null argument"; return OMGX_E_INVALID; }
+  *out = nullptr;
+  FILE* fp = fopen(path, "rb");
+  if (!fp) { g_err = std::string("cannot read ") + path; return OMGX_E_INVALID; }
+  char magic[8];
+  int32_t c[13];
+  if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, "OMGXTPL2", 8) != 0 || fread(c, sizeof(int32_t), 13, fp) != 13) {
+    fclose(fp); g_err = std::string(path) + " is not an omgx template file"; return OMGX_E_INVALID;
+  }
+  for (int i = 0; i < 13; ++i) if (c[i] < 0 || c[i] > (1 << 26)) { fclose(fp); g_err = "template file: bad counts"; return OMGX_E_INVALID; }
+  omgx_template* t = (omgx_template*)calloc(1, sizeof(omgx_template));
+  if (!t) { fclose(fp); g_err = "out of memory"; return OMGX_E_INVALID; }
+  t->n_var = c[0]; t->n_par = c[1]; t->n_con = c[2]; t->n_atoms = c[3]; t->n_slots = c[4]; t->n_terms = c[5]; t->n_prog = c[6];
+  t->n_knots = c[7]; t->n_pp = c[8]; t->n_mono = c[9]; t->n_matom = c[10]; t->n_eq = c[11]; t->n_root_vars = c[12];
+  TplField f[16];
+  const size_t nf = tpl_fields(*t, t, f);
+  bool ok = true;
+  for (size_t i = 0; i < nf; ++i) {
+    const size_t sz = f[i].kind ? sizeof(double) : sizeof(int32_t);
+    *f[i].dst = calloc(f[i].count + 1, sz);                  // (+1: an empty array still gets an address)
+    if (!*f[i].dst) { ok = false; continue; }
+    if (ok && f[i].count && fread(*f[i].dst, sz, f[i].count, fp) != f[i].count) ok = false;
+  }
+  fclose(fp);
+  if (!ok) { omgx_template_free(t); g_err = std::string("truncated template file ") + path; return OMGX_E_INVALID; }
+  const int rc = check_template(t);
+  if (rc != OMGX_OK) { omgx_template_free(t); return rc; }
+  *out = t;
+  return OMGX_OK;
+}
+
 void omgx_default_options(omgx_options* o) {
   o->tol = 1e-3; o->max_iter = 300; o->mu_init = 0.1; o->kappa_push = 1.0;
   o->nu_init = 100.0; o->scale_gmax = 100.0; o->warm_start = 0; o->kappa_warm = 1e-3;

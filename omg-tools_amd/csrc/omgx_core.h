@@ -33,6 +33,7 @@
 #ifdef OMGX_COUNT_FACT
 #include <atomic>
 static std::atomic<long> omgx_dbg_nfact(0);
+static std::atomic<long> omgx_dbg_cnt[8];      // 0 leaf failures, 1 root failures, 2 dw=0 attempts that failed, 3 decrease attempts that failed, 4 iterations
 #endif
 namespace omgx {
 
@@ -1314,6 +1315,9 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
     }
 #endif
 #endif
+#ifdef OMGX_COUNT_FACT
+    if (bad) ++omgx_dbg_cnt[0];
+#endif
     if (bad) return 1;
   }
   OMGX_TOC(PH_F_LEAF);
@@ -1380,6 +1384,9 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   // 43 k cycles standalone, but 1.5 % slower inside the fused kernel in an A/B of three bench runs each)
   ldl_blocked<2>(c, Ms + d.n_leaf, 1, w.kkt, w.dinv, w.col, stage, &bad);
   OMGX_TOC(PH_F_ROOT);
+#ifdef OMGX_COUNT_FACT
+  if (bad) ++omgx_dbg_cnt[1];
+#endif
   return bad;
 }
 
@@ -1952,6 +1959,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       const int bad = kkt_factor(c, d, K, w);
 #ifdef OMGX_COUNT_FACT
       ++omgx_dbg_nfact;
+      if (first_trial) ++omgx_dbg_cnt[4];
+      if (bad && dw == 0.0) ++omgx_dbg_cnt[2];
+      if (bad && decreasing) ++omgx_dbg_cnt[3];
 #endif
       OMGX_TOC(PH_FACTOR);
       first_trial = 0;

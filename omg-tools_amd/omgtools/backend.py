@@ -127,6 +127,16 @@ def make_ctemplate(tpl, plan=None):
     return ct, keep
 
 
+def save_template(tpl, path, lib=None):
+    """Write the template file C/C++ callers load with `omgx_template_read` (include/omgx.h): what the
+    reference's exporter does with the generated nlp.so (`export/export.py:236-262`)."""
+    lib = lib or load_library()
+    ct, keep = make_ctemplate(tpl)
+    lib.omgx_template_write.argtypes = [C.POINTER(CTemplate), C.c_char_p]
+    _check(lib, lib.omgx_template_write(C.byref(ct), os.fsencode(path)), 'omgx_template_write')
+    return path
+
+
 def describe_plan(tpl, lib=None):
     """What the library derives from the template (host only, no device needed): dict with the leaf
     sizes / bandwidths / coupling counts, the root size and `order` (position -> variable)."""

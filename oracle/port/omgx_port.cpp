@@ -223,5 +223,6 @@ extern "C" int omgx_port_pool_solve(void* h, const omgx_options* opt, int32_t n_
 }
 
 #ifdef OMGX_COUNT_FACT
+extern "C" long omgx_port_cnt(int k, int reset) { long v = omgx_dbg_cnt[k].load(); if (reset) omgx_dbg_cnt[k] = 0; return v; }
 extern "C" long omgx_port_nfact(int reset) { long v = omgx_dbg_nfact.load(); if (reset) omgx_dbg_nfact = 0; return v; }
 #endif
