@@ -286,6 +286,27 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
     n_ok = int((status == 0).sum().item())
     it_sum = int(iters.sum().item())
     elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist if world > 1 else None)
+    # receding-horizon steps of the same batch (the protocol of the headline: cold solve, warm-up, timed steps)
+    from omgtools.batch import BatchP2P
+    solver.close()
+    mpc = BatchP2P(problem, P, ops='hip', device=dev, options=dict(P.get('solver_options', {}), tol=args.tol, max_iter=300))
+    mpc.solve_cold()
+    rh_steps = max(args.steps, 10)
+    for _ in range(args.warmup):
+        mpc.step()
+    barrier()
+    t0 = time.perf_counter()
+    rh_ok, rh_it = 0, 0
+    st_log = torch.zeros((rh_steps, B), dtype=torch.int32, device=dev)
+    it_log = torch.zeros((rh_steps, B), dtype=torch.int32, device=dev)
+    for k in range(rh_steps):
+        mpc.step()
+        st_log[k].copy_(mpc.status)
+        it_log[k].copy_(mpc.iters)
+    barrier()
+    rh_elapsed = time.perf_counter() - t0
+    rh_ok, rh_it = int((st_log == 0).sum().item()), int(it_log.sum().item())
+    rh_elapsed, rh_ok_all = reduce_report(rh_elapsed, rh_ok, device=dev, dist=dist if world > 1 else None)
     if rank != 0:
         return
     n = tpl.n_var
@@ -298,7 +319,13 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': '%s: %d agents per GPU, cold solve from the reference initial guess, tol=%g'
                                % (args.workload, B, args.tol), 'n_var': tpl.n_var, 'n_con': tpl.n_con},
-        'solved_fraction': n_ok / float(B), 'mean_iters': it_sum / float(B), 'workspace': solver.workspace(),
+        'solved_fraction': n_ok / float(B), 'mean_iters': it_sum / float(B), 'workspace': mpc.solver.workspace(),
+        'receding_horizon': {'solves_per_s': rh_ok_all / rh_elapsed, 'ms_per_step': rh_elapsed / rh_steps * 1e3,
+                             'steps': rh_steps, 'warmup': args.warmup, 'solved_fraction': rh_ok / float(rh_steps * B),
+                             'mean_iters': rh_it / float(rh_steps * B), 'max_iters': int(it_log.max().item()),
+                             'protocol': 'cold solve, warm-up steps, then timed steps (update_time 0.1 s, ideal '
+                                         'prediction incl. the second derivative for the Quadrotor, moving obstacles '
+                                         'advanced, primal-dual warm start)'},
         'roofline': {'bound': 'mfma', 'kernel': 'ipm_solve_kernel', 'achieved': flops / (k_ms * 1e-3) / 1e12,
                      'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': flops / (k_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,

@@ -189,6 +189,41 @@ int  omgx_batch_predict(omgx_batch* b, const double* x, double* p, int32_t coeff
                         int32_t degree, const double* knots, int32_t n_knots, double tau, double inv_T,
                         int32_t p_state0, int32_t p_input0, int32_t p_t, double t_value);
 
+/* General form (device-resident x, p): for o < n_out (<= 4, <= degree + 1) and p_off[o] >= 0,
+ *   p[p_off[o] + k] <- d^o/dt^o spline_k at tau = spline_k^(o)(tau) * inv_T^o
+ * -- the Quadrotor's initial conditions are spl0, dspl0, ddspl0 (`vehicles/quadrotor.py:76-85`).
+ * mode OMGX_PREDICT_RK4 (integrator models, `ode` = input: Holonomic, Holonomic3D): p[p_off[0] + k] is the
+ * caller's current state state_in[b, k] integrated over the n_sub sample intervals of length dtau (spline
+ * domain; sample time dtau / inv_T) that end at tau, with the inputs the plan holds there, by the statements
+ * of `Vehicle::integrate` (`export/vehicles/Vehicle.cpp:82-110`); the derivatives o >= 1 are those at tau. */
+#define OMGX_PREDICT_IDEAL 0
+#define OMGX_PREDICT_RK4   1
+int  omgx_batch_predict_ex(omgx_batch* b, const double* x, double* p, int32_t coeff_off, int32_t n_spl,
+                           int32_t degree, const double* knots, int32_t n_knots, double tau, double inv_T,
+                           int32_t n_out, const int32_t* p_off, int32_t p_t, double t_value, int32_t mode,
+                           const double* state_in, int32_t n_sub, double dtau);
+
+/* `Vehicle.store` (reference `vehicles/vehicle.py:250-300` -> `splines2signals`, e.g.
+ * `vehicles/holonomic.py:116-124`) for the whole batch, device pointers only:
+ *   out[b, o, k, i] = d^o/dt^o spline_k(t0[b] + i*dt)   (o < n_der: state, input, dinput ...; time
+ *                     derivatives, i.e. spline-domain derivatives * inv_T^o),
+ *   v_tot[b, i]     = |first time derivative|           (optional, needs n_der >= 2).
+ * knots: host pointer.  A fixed-T plan is one segment: `concat_splines` (`spline_extra.py:308-404`) is the
+ * identity on it.  omgx_batch_store samples a given x; omgx_batch_set_store makes every following
+ * omgx_batch_solve write the same outputs for the solution it just found, inside the solve kernel (the
+ * solution is still in LDS there; sp == NULL switches it off again).  The arrays a spec points at must stay
+ * valid while it is set. */
+typedef struct omgx_store_spec {
+  double* out;            /* [B, n_der, n_spl, n_samp] device */
+  double* v_tot;          /* [B, n_samp] device, or NULL */
+  const double* t0;       /* [B] device: first sample, spline domain */
+  const double* knots;    /* [n_knots] host, n_knots <= 40 */
+  int32_t coeff_off, n_spl, degree, n_knots, n_der, n_samp;
+  double  dt, inv_T;
+} omgx_store_spec;
+int  omgx_batch_store(omgx_batch* b, const double* x, const omgx_store_spec* sp);
+int  omgx_batch_set_store(omgx_batch* b, const omgx_store_spec* sp);
+
 /* Same shift on any device-resident row-major array (stride doubles per row, n_rows rows):
  * used for the ADMM consensus state on a knot crossing (`problems/admm.py:477-491`). */
 int  omgx_shift_rows(omgx_batch* b, double* data, int32_t stride, int32_t n_rows, const uint8_t* mask,

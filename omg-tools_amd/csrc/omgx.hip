@@ -37,6 +37,123 @@ constexpr int kLdsLimit = 160 * 1024;
 
 }  // namespace
 
+// out[b, o, k, i] = d^o/dt^o spline_k(t0[b] + i*dt); one block = (agent, 1024-sample chunk).
+//
+// Bound: HBM writes (8 n_der n_spl bytes per sample).  The de Boor recursion per sample (about 20
+// fp64 divisions for 3 derivative orders of 2 cubic splines) kept the first version at 20 % of the HBM
+// roofline, so the recursion is run once per knot span instead of once per sample: every block turns
+// its agent's splines into local power series  p_{o,k,j}(h) = sum_m S_k^{(o+m)}(k_j+) / m!  h^m  around
+// the left knot of each span j (a few dozen small de Boor evaluations, spread over the block) and a
+// sample is a span look-up plus one Horner evaluation per output value.
+struct KnotArg { double k[40]; };
+#define OMGX_SAMPLE_CHUNK 1024      // samples per block: the per-block set-up is amortised over 4 samples per thread
+
+// What `Vehicle.store` extracts from a solution (reference `vehicles/vehicle.py:250-300` ->
+// `splines2signals`, e.g. `vehicles/holonomic.py:116-124`): derivative orders 0 .. n_der-1 of the n_spl
+// splines on a time grid, order o scaled by inv_T^o (time derivatives), and optionally the speed
+// v_tot = |first derivative|.  Passed by value to the kernels; out == nullptr: nothing to do.
+struct StoreArgs {
+  double* out;            // [B, n_der, n_spl, n_samp]
+  double* v_tot;          // [B, n_samp] or nullptr (needs n_der >= 2)
+  const double* t0;       // [B] first sample, spline domain
+  int coeff_off, n_spl, degree, n_knots, n_der, n_samp;
+  double dt, inv_T;
+  KnotArg knots;
+};
+
+__host__ __device__ inline size_t sample_scratch_doubles(int n_spl, int degree, int n_knots, int n_der) {
+  const int L = n_knots - degree - 1, n_span = n_knots - 2 * degree - 1, D1 = degree + 1;
+  return (size_t)n_knots + (size_t)D1 * n_spl * L + (size_t)D1 * n_spl * n_span + (size_t)n_der * n_spl * n_span * D1;
+}
+
+// value at u of the spline with coefficients c on the knot vector kk (degree dg <= 5), inside span jo.
+// Fully unrolled triangle with compile-time indices: a dynamically indexed local array would live in
+// scratch (global) memory.
+__device__ __forceinline__ double deboor_at(const double* c, const double* kk, int dg, int jo, double u) {
+  double dbo[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) dbo[r] = (r <= dg) ? c[jo - dg + r] : 0.0;
+#pragma unroll
+  for (int lev = 1; lev <= 5; ++lev) {
+#pragma unroll
+    for (int r = 5; r >= 1; --r) {
+      if (lev <= dg && r >= lev && r <= dg) {
+        const int idx = jo - dg + r;
+        const double den = kk[idx + dg - lev + 1] - kk[idx];
+        const double a = den != 0.0 ? (u - kk[idx]) / den : 0.0;
+        dbo[r] = (1.0 - a) * dbo[r - 1] + a * dbo[r];
+      }
+    }
+  }
+  return dg == 0 ? dbo[0] : (dg == 1 ? dbo[1] : (dg == 2 ? dbo[2] : (dg == 3 ? dbo[3] : (dg == 4 ? dbo[4] : dbo[5]))));
+}
+
+// Samples [i_begin, i_end) of one agent by the whole workgroup.  coeffs: [n_spl][L] (global memory or
+// LDS), scratch: sample_scratch_doubles() doubles the workgroup may overwrite.  Used by sample_kernel and
+// by the epilogue of the solve kernel (the solution is still in LDS there).
+template <typename OutT>
+__device__ void sample_agent(const double* coeffs, double* scratch, int n_spl, int degree, const KnotArg& knots,
+                             int n_knots, int n_der, double tb, double dt, double inv_T, int n_samp, int i_begin,
+                             int i_end, OutT* out_b, OutT* vtot_b) {
+  const int L = n_knots - degree - 1;
+  const int n_span = n_knots - 2 * degree - 1;    // spans j = degree .. degree + n_span - 1
+  const int D1 = degree + 1;
+  double* kn = scratch;                           // [n_knots]
+  double* cf = kn + n_knots;                      // [D1][n_spl][L]      coefficients of every derivative order
+  double* val = cf + D1 * n_spl * L;              // [D1][n_spl][n_span] S^{(q)}(k_j+)
+  double* pw = val + D1 * n_spl * n_span;         // [n_der][n_spl][n_span][D1] local power series
+  for (int i = threadIdx.x; i < n_knots; i += blockDim.x) kn[i] = knots.k[i];
+  for (int i = threadIdx.x; i < n_spl * L; i += blockDim.x) cf[i] = coeffs[i];
+  __syncthreads();
+  for (int o = 1; o <= degree; ++o) {             // c^(o)_i = (d-o+1) (c^(o-1)_{i+1}-c^(o-1)_i)/(k_{i+d+1}-k_{i+o})
+    const int Lo = L - o, dd = degree - o + 1;
+    for (int e = threadIdx.x; e < n_spl * Lo; e += blockDim.x) {
+      const int k = e / Lo, i = e - k * Lo;
+      const double* src = cf + ((o - 1) * n_spl + k) * L;
+      const double den = kn[i + degree + 1] - kn[i + o];
+      cf[(o * n_spl + k) * L + i] = den != 0.0 ? dd * (src[i + 1] - src[i]) / den : 0.0;
+    }
+    __syncthreads();
+  }
+  // right-hand limits of every derivative order at the left knot of every span
+  for (int e = threadIdx.x; e < D1 * n_spl * n_span; e += blockDim.x) {
+    const int q = e / (n_spl * n_span), r = e - q * n_spl * n_span, k = r / n_span, sp = r - k * n_span;
+    const int j = degree + sp;
+    // the q-th derivative lives on the knot vector kn[q .. n_knots-q), its span index there is j - q
+    val[e] = deboor_at(cf + (q * n_spl + k) * L, kn + q, degree - q, j - q, kn[j]);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n_der * n_spl * n_span * D1; e += blockDim.x) {
+    const int m = e % D1, r = e / D1;             // r = (o, k, sp)
+    const int o = r / (n_spl * n_span), ks = r - o * n_spl * n_span;
+    double f = 1.0;
+    for (int q = 2; q <= m; ++q) f *= q;
+    for (int q = 0; q < o; ++q) f /= inv_T;       // time derivative of order o: spline-domain derivative * inv_T^o
+    pw[e] = (o + m <= degree) ? val[(o + m) * n_spl * n_span + ks] / f : 0.0;
+  }
+  __syncthreads();
+  for (int i = i_begin + threadIdx.x; i < i_end; i += blockDim.x) {
+    const double u = tb + i * dt;
+    // span j: k_j < u <= k_{j+1} (reference convention, `basics/spline.py:131-136`)
+    int j = degree;
+    for (int q = degree + 1; q < n_knots - degree - 1; ++q) if (kn[q] < u) j = q;
+    const double h = u - kn[j];
+    const int sp = j - degree;
+    double v2 = 0.0;
+    for (int o = 0; o < n_der; ++o) {
+      const int dg = degree - o;
+      for (int k = 0; k < n_spl; ++k) {
+        const double* c = pw + (((o * n_spl + k) * n_span) + sp) * D1;
+        double v = c[dg];
+        for (int m = dg - 1; m >= 0; --m) v = fma(v, h, c[m]);
+        out_b[((size_t)o * n_spl + k) * n_samp + i] = (OutT)v;
+        if (o == 1) v2 = fma(v, v, v2);
+      }
+    }
+    if (vtot_b) vtot_b[i] = (OutT)sqrt(v2);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
@@ -48,7 +165,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  double* __restrict__ x, double* __restrict__ lam, int32_t* __restrict__ status,
                  int32_t* __restrict__ iters, int n_agents, long long* __restrict__ prof,
                  double* __restrict__ slabs, size_t slab_doubles, double* __restrict__ dw_state,
-                 const int32_t* __restrict__ order) {
+                 const int32_t* __restrict__ order, StoreArgs st) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
@@ -82,6 +199,14 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
       lam[(size_t)b * d.n_con + q] =
           (r.status == 3 || w.rtype[q] == omgx::ROW_FREE) ? 0.0 : w.rho[q] * w.z[q];
     if (threadIdx.x == 0) { status[b] = r.status; iters[b] = r.iters; dw_state[b] = r.dw; }
+    if (st.out) {
+      // `Vehicle.store` fused behind the solve (reference `vehicles/vehicle.py:250-300`): the trajectories of
+      // this agent straight from the solution in LDS; the KKT store is free now and serves as scratch
+      __syncthreads();
+      sample_agent<double>(w.x + st.coeff_off, w.kkt, st.n_spl, st.degree, st.knots, st.n_knots, st.n_der, st.t0[b],
+                           st.dt, st.inv_T, st.n_samp, 0, st.n_samp, st.out + (size_t)b * st.n_der * st.n_spl * st.n_samp,
+                           st.v_tot ? st.v_tot + (size_t)b * st.n_samp : nullptr);
+    }
 #ifdef OMGX_PROFILE
     __syncthreads();
     if (threadIdx.x == 0) prof_lds[omgx::PH_TOTAL] = clock64() - t_begin;
@@ -94,7 +219,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
-                             const int32_t*);
+                             const int32_t*, StoreArgs);
 static ipm_kernel_t ipm_kernel_for(int mode) {
   switch (mode) {
     case omgx::WS_LDS: return ipm_solve_kernel<omgx::WS_LDS>;
@@ -104,163 +229,107 @@ static ipm_kernel_t ipm_kernel_for(int mode) {
   }
 }
 
-// out[b, o, k, i] = d^o/dt^o spline_k(t0[b] + i*dt); one block = (agent, 1024-sample chunk).
-//
-// Bound: HBM writes (8 n_der n_spl bytes per sample).  The de Boor recursion per sample (about 20
-// fp64 divisions for 3 derivative orders of 2 cubic splines) kept the first version at 20 % of the HBM
-// roofline, so the recursion is run once per knot span instead of once per sample: every block turns
-// its agent's splines into local power series  p_{o,k,j}(h) = sum_m S_k^{(o+m)}(k_j+) / m!  h^m  around
-// the left knot of each span j (a few dozen small de Boor evaluations, spread over the block) and a
-// sample is a span look-up plus one Horner evaluation per output value.
-struct KnotArg { double k[40]; };
-#define OMGX_SAMPLE_CHUNK 1024      // samples per block: the per-block set-up is amortised over 4 samples per thread
-
-// value at u of the spline with coefficients c on the knot vector kk (degree dg <= 5), inside span jo.
-// Fully unrolled triangle with compile-time indices: a dynamically indexed local array would live in
-// scratch (global) memory.
-__device__ __forceinline__ double deboor_at(const double* c, const double* kk, int dg, int jo, double u) {
-  double dbo[6];
-#pragma unroll
-  for (int r = 0; r < 6; ++r) dbo[r] = (r <= dg) ? c[jo - dg + r] : 0.0;
-#pragma unroll
-  for (int lev = 1; lev <= 5; ++lev) {
-#pragma unroll
-    for (int r = 5; r >= 1; --r) {
-      if (lev <= dg && r >= lev && r <= dg) {
-        const int idx = jo - dg + r;
-        const double den = kk[idx + dg - lev + 1] - kk[idx];
-        const double a = den != 0.0 ? (u - kk[idx]) / den : 0.0;
-        dbo[r] = (1.0 - a) * dbo[r - 1] + a * dbo[r];
-      }
-    }
-  }
-  return dg == 0 ? dbo[0] : (dg == 1 ? dbo[1] : (dg == 2 ? dbo[2] : (dg == 3 ? dbo[3] : (dg == 4 ? dbo[4] : dbo[5]))));
-}
-
 template <typename OutT>
 __global__ void __launch_bounds__(256)
 sample_kernel(const double* __restrict__ x, int x_stride, int coeff_off, int n_spl, int degree,
               KnotArg knots, int n_knots, int n_der,
-              const double* __restrict__ t0, double dt, int n_samp, OutT* __restrict__ out) {
+              const double* __restrict__ t0, double dt, double inv_T, int n_samp, OutT* __restrict__ out,
+              OutT* __restrict__ v_tot) {
   extern __shared__ __align__(16) double lds[];
-  const int L = n_knots - degree - 1;
-  const int n_span = n_knots - 2 * degree - 1;    // spans j = degree .. degree + n_span - 1
-  const int D1 = degree + 1;
-  double* kn = lds;                               // [n_knots]
-  double* cf = kn + n_knots;                      // [D1][n_spl][L]      coefficients of every derivative order
-  double* val = cf + D1 * n_spl * L;              // [D1][n_spl][n_span] S^{(q)}(k_j+)
-  double* pw = val + D1 * n_spl * n_span;         // [n_der][n_spl][n_span][D1] local power series
   const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < n_knots; i += blockDim.x) kn[i] = knots.k[i];
-  for (int i = threadIdx.x; i < n_spl * L; i += blockDim.x)
-    cf[i] = x[(size_t)b * x_stride + coeff_off + i];
-  __syncthreads();
-  for (int o = 1; o <= degree; ++o) {             // c^(o)_i = (d-o+1) (c^(o-1)_{i+1}-c^(o-1)_i)/(k_{i+d+1}-k_{i+o})
-    const int Lo = L - o, dd = degree - o + 1;
-    for (int e = threadIdx.x; e < n_spl * Lo; e += blockDim.x) {
-      const int k = e / Lo, i = e - k * Lo;
-      const double* src = cf + ((o - 1) * n_spl + k) * L;
-      const double den = kn[i + degree + 1] - kn[i + o];
-      cf[(o * n_spl + k) * L + i] = den != 0.0 ? dd * (src[i + 1] - src[i]) / den : 0.0;
-    }
-    __syncthreads();
-  }
-  // right-hand limits of every derivative order at the left knot of every span
-  for (int e = threadIdx.x; e < D1 * n_spl * n_span; e += blockDim.x) {
-    const int q = e / (n_spl * n_span), r = e - q * n_spl * n_span, k = r / n_span, sp = r - k * n_span;
-    const int j = degree + sp;
-    // the q-th derivative lives on the knot vector kn[q .. n_knots-q), its span index there is j - q
-    val[e] = deboor_at(cf + (q * n_spl + k) * L, kn + q, degree - q, j - q, kn[j]);
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < n_der * n_spl * n_span * D1; e += blockDim.x) {
-    const int m = e % D1, r = e / D1;             // r = (o, k, sp)
-    const int o = r / (n_spl * n_span), ks = r - o * n_spl * n_span;
-    double f = 1.0;
-    for (int q = 2; q <= m; ++q) f *= q;
-    pw[e] = (o + m <= degree) ? val[(o + m) * n_spl * n_span + ks] / f : 0.0;
-  }
-  __syncthreads();
-  const double tb = t0[b];
   const int i_end = min(n_samp, (int)(blockIdx.x + 1) * OMGX_SAMPLE_CHUNK);
-  for (int i = blockIdx.x * OMGX_SAMPLE_CHUNK + threadIdx.x; i < i_end; i += blockDim.x) {
-    const double u = tb + i * dt;
-    // span j: k_j < u <= k_{j+1} (reference convention, `basics/spline.py:131-136`)
-    int j = degree;
-    for (int q = degree + 1; q < n_knots - degree - 1; ++q) if (kn[q] < u) j = q;
-    const double h = u - kn[j];
-    const int sp = j - degree;
-    for (int o = 0; o < n_der; ++o) {
-      const int dg = degree - o;
-      for (int k = 0; k < n_spl; ++k) {
-        const double* c = pw + (((o * n_spl + k) * n_span) + sp) * D1;
-        double v = c[dg];
-        for (int m = dg - 1; m >= 0; --m) v = fma(v, h, c[m]);
-        out[(((size_t)b * n_der + o) * n_spl + k) * n_samp + i] = (OutT)v;
+  sample_agent<OutT>(x + (size_t)b * x_stride + coeff_off, lds, n_spl, degree, knots, n_knots, n_der, t0[b], dt, inv_T,
+                     n_samp, blockIdx.x * OMGX_SAMPLE_CHUNK, i_end, out + (size_t)b * n_der * n_spl * n_samp,
+                     v_tot ? v_tot + (size_t)b * n_samp : nullptr);
+}
+
+// Prediction of one receding-horizon step: thread (agent b, spline k) evaluates the plan and its time
+// derivatives at tau by de Boor on the active span and writes them into the parameter vector (state0 /
+// input0 / ...), thread k == 0 also the time since the last knot crossing.  RK4 mode: the state is the
+// caller's current state integrated over the n_sub sample intervals before tau with the inputs the plan
+// holds there, by the statements of the reference's `Vehicle::integrate` (export/vehicles/Vehicle.cpp:82-110)
+// for the integrator models (`ode` = input: Holonomic, Holonomic3D).
+struct PredictArgs {
+  KnotArg kn;
+  int coeff_off, n_spl, degree, n_knots, n_out, p_off[4], p_t, mode, n_sub;
+  double tau, inv_T, t_value, dtau;
+  const double* state_in;
+};
+
+// d-th derivative (spline-domain units) at u of the spline whose coefficients on span j are c[j-degree .. j]
+__device__ __forceinline__ double spline_der_at(const double* c, const double* kk, int degree, int j, double u, int dord) {
+  double v[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) v[r] = (r <= degree) ? c[j - degree + r] : 0.0;
+  // after o differences v[r] (r = o .. degree) holds c^(o)_{j-degree+r}
+#pragma unroll
+  for (int o = 1; o <= 3; ++o) {
+    if (o <= dord) {
+#pragma unroll
+      for (int r = 5; r >= 1; --r) {
+        if (r >= o && r <= degree) {
+          const int i = j - degree + r;                       // c^(o)_i = (degree-o+1) (c^(o-1)_i - c^(o-1)_{i-1}) / (k_{i+degree-o+1} - k_i)
+          const double den = kk[i + degree - o + 1] - kk[i];
+          v[r] = den != 0.0 ? (degree - o + 1) * (v[r] - v[r - 1]) / den : 0.0;
+        }
       }
     }
   }
-}
-
-// Ideal prediction of one receding-horizon step: thread (agent b, spline k) evaluates the plan and
-// its first derivative at tau by de Boor on the active span and writes them into the parameter
-// vector (state0 / input0), thread k == 0 also the time since the last knot crossing.
-__global__ void __launch_bounds__(256)
-predict_kernel(const double* __restrict__ x, int n_var, double* __restrict__ p, int n_par, int B,
-               int coeff_off, int n_spl, int degree, KnotArg kn, int n_knots, double tau, double inv_T,
-               int p_state0, int p_input0, int p_t, double t_value) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= B * n_spl) return;
-  const int b = id / n_spl, k = id - b * n_spl;
-  const int L = n_knots - degree - 1;
-  const double* c = x + (size_t)b * n_var + coeff_off + k * L;
-  int j = degree;                                  // span: k_j < tau <= k_{j+1} (`basics/spline.py:131-136`)
-  for (int q = degree + 1; q < n_knots - degree - 1; ++q) if (kn.k[q] < tau) j = q;
-  double v[6], dv[6];
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    const int i = j - degree + r;
-    v[r] = (r <= degree) ? c[i] : 0.0;
-  }
-#pragma unroll
-  for (int r = 0; r < 5; ++r) {                     // derivative coefficients c'_i, i = j-degree+1+r .. j
-    const int i = j - degree + 1 + r;
-    double den = (r < degree) ? kn.k[i + degree] - kn.k[i] : 0.0;
-    dv[r] = (r < degree && den != 0.0) ? degree * (v[r + 1] - v[r]) / den : 0.0;
-  }
-  dv[5] = 0.0;
+  const int dg = degree - dord;
 #pragma unroll
   for (int lev = 1; lev <= 5; ++lev) {
 #pragma unroll
     for (int r = 5; r >= 1; --r) {
-      if (lev <= degree && r >= lev && r <= degree) {
+      if (lev <= dg && r >= dord + lev && r <= degree) {
         const int i = j - degree + r;
-        const double den = kn.k[i + degree - lev + 1] - kn.k[i];
-        const double a = den != 0.0 ? (tau - kn.k[i]) / den : 0.0;
+        const double den = kk[i + dg - lev + 1] - kk[i];
+        const double a = den != 0.0 ? (u - kk[i]) / den : 0.0;
         v[r] = (1.0 - a) * v[r - 1] + a * v[r];
       }
     }
   }
-  const int dg = degree - 1;                        // derivative spline: degree-1 on knots k[1 .. n_knots-1)
+  double out = 0.0;
 #pragma unroll
-  for (int lev = 1; lev <= 4; ++lev) {
-#pragma unroll
-    for (int r = 4; r >= 1; --r) {
-      if (lev <= dg && r >= lev && r <= dg) {
-        const int i = j - degree + 1 + r;           // original index of c'_i
-        const double den = kn.k[i + dg - lev + 1] - kn.k[i];
-        const double a = den != 0.0 ? (tau - kn.k[i]) / den : 0.0;
-        dv[r] = (1.0 - a) * dv[r - 1] + a * dv[r];
-      }
-    }
-  }
-  double val = 0.0, der = 0.0;
-#pragma unroll
-  for (int r = 0; r < 6; ++r) { if (r == degree) val = v[r]; if (r == dg) der = dv[r]; }
+  for (int r = 0; r < 6; ++r) if (r == degree) out = v[r];
+  return out;
+}
+
+__device__ __forceinline__ int span_of(const double* kk, int degree, int n_knots, double u) {
+  int j = degree;                                  // span: k_j < u <= k_{j+1} (`basics/spline.py:131-136`)
+  for (int q = degree + 1; q < n_knots - degree - 1; ++q) if (kk[q] < u) j = q;
+  return j;
+}
+
+__global__ void __launch_bounds__(256)
+predict_kernel(const double* __restrict__ x, int n_var, double* __restrict__ p, int n_par, int B, PredictArgs a) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * a.n_spl) return;
+  const int b = id / a.n_spl, k = id - b * a.n_spl;
+  const int L = a.n_knots - a.degree - 1;
+  const double* c = x + (size_t)b * n_var + a.coeff_off + k * L;
   double* pb = p + (size_t)b * n_par;
-  pb[p_state0 + k] = val;
-  pb[p_input0 + k] = der * inv_T;
-  if (k == 0 && p_t >= 0) pb[p_t] = t_value;
+  const int j = span_of(a.kn.k, a.degree, a.n_knots, a.tau);
+  double sc = 1.0;
+  for (int o = 0; o < a.n_out; ++o) {
+    if (a.p_off[o] >= 0 && !(o == 0 && a.mode == OMGX_PREDICT_RK4))
+      pb[a.p_off[o] + k] = spline_der_at(c, a.kn.k, a.degree, j, a.tau, o) * sc;
+    sc *= a.inv_T;
+  }
+  if (a.mode == OMGX_PREDICT_RK4 && a.p_off[0] >= 0) {
+    // k1 = k2 = k3 = u_i, k4 = u_{i+1} for an integrator; h = sample time
+    const double h = a.dtau / a.inv_T;
+    double st = a.state_in[(size_t)b * a.n_spl + k];
+    double u0 = a.tau - a.n_sub * a.dtau;
+    double ui = spline_der_at(c, a.kn.k, a.degree, span_of(a.kn.k, a.degree, a.n_knots, u0), u0, 1) * a.inv_T;
+    for (int i = 0; i < a.n_sub; ++i) {
+      const double u1 = a.tau - (a.n_sub - 1 - i) * a.dtau;
+      const double un = spline_der_at(c, a.kn.k, a.degree, span_of(a.kn.k, a.degree, a.n_knots, u1), u1, 1) * a.inv_T;
+      st += (h / 6.0) * (ui + 2.0 * ui + 2.0 * ui + un);
+      ui = un;
+    }
+    pb[a.p_off[0] + k] = st;
+  }
+  if (k == 0 && a.p_t >= 0) pb[a.p_t] = a.t_value;
 }
 
 // Launch order for the next solve: agents bucketed by the iteration count of their previous solve,
@@ -401,6 +470,7 @@ struct omgx_batch {
   double* d_slabs = nullptr;
   double* d_dw = nullptr;          // per-agent inertia correction carried between warm-started solves
   const int32_t* d_order = nullptr; // optional launch order (device pointer owned by the caller)
+  StoreArgs store = {};             // trajectories written by the solve kernel (omgx_batch_set_store); out == nullptr: off
   std::vector<void*> allocs;
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -752,7 +822,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   HIPCHK(hipEventRecord(b->ev0, b->stream));
   hipLaunchKernelGGL(ipm_kernel_for(b->ws_mode), dim3(b->n_slabs), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev,
                      b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
-                     b->d_slabs, b->slab_doubles, b->d_dw, b->d_order);
+                     b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, b->store);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   b->timed = true;
@@ -852,14 +922,14 @@ int omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off, int32_t
   }
   const dim3 grid((n_samp + OMGX_SAMPLE_CHUNK - 1) / OMGX_SAMPLE_CHUNK, B), block(256);
   const int n_span = n_knots - 2 * degree - 1, D1 = degree + 1;
-  const size_t lds = ((size_t)n_knots + (size_t)D1 * n_spl * L + (size_t)D1 * n_spl * n_span +
-                      (size_t)n_der * n_spl * n_span * D1) * sizeof(double);
+  const size_t lds = sample_scratch_doubles(n_spl, degree, n_knots, n_der) * sizeof(double);
+  (void)L; (void)n_span; (void)D1;
   if (as_f32)
     hipLaunchKernelGGL(sample_kernel<float>, grid, block, lds, b->stream, d_xx, d.n_var, coeff_off, n_spl, degree,
-                       kn, n_knots, n_der, d_t0, dt, n_samp, (float*)d_out);
+                       kn, n_knots, n_der, d_t0, dt, 1.0, n_samp, (float*)d_out, (float*)nullptr);
   else
     hipLaunchKernelGGL(sample_kernel<double>, grid, block, lds, b->stream, d_xx, d.n_var, coeff_off, n_spl, degree,
-                       kn, n_knots, n_der, d_t0, dt, n_samp, (double*)d_out);
+                       kn, n_knots, n_der, d_t0, dt, 1.0, n_samp, (double*)d_out, (double*)nullptr);
   HIPCHK(hipGetLastError());
   if (!dev) {
     HIPCHK(hipMemcpyAsync(out, d_out, out_elems * esz, hipMemcpyDeviceToHost, b->stream));
@@ -869,21 +939,83 @@ int omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off, int32_t
   return OMGX_OK;      // device pointers: stream-ordered, the caller synchronises (omgx_batch_sync)
 }
 
+namespace {
+int fill_store(omgx_batch* b, const omgx_store_spec* sp, StoreArgs* st) {
+  if (!sp->out || !sp->t0 || !sp->knots || sp->degree < 1 || sp->degree > 5 || sp->n_der < 1 || sp->n_der > sp->degree + 1 ||
+      sp->n_samp <= 0 || sp->n_spl <= 0 || sp->n_knots > 40 || sp->n_knots < 2 * sp->degree + 2 || !(sp->inv_T > 0.0) ||
+      (sp->v_tot && sp->n_der < 2)) {
+    g_err = "bad store specification"; return OMGX_E_INVALID;
+  }
+  const int L = sp->n_knots - sp->degree - 1;
+  if (sp->coeff_off < 0 || sp->coeff_off + sp->n_spl * L > b->dims.n_var) { g_err = "store: coefficients outside x"; return OMGX_E_INVALID; }
+  st->out = sp->out; st->v_tot = sp->v_tot; st->t0 = sp->t0;
+  st->coeff_off = sp->coeff_off; st->n_spl = sp->n_spl; st->degree = sp->degree; st->n_knots = sp->n_knots;
+  st->n_der = sp->n_der; st->n_samp = sp->n_samp; st->dt = sp->dt; st->inv_T = sp->inv_T;
+  for (int i = 0; i < 40; ++i) st->knots.k[i] = i < sp->n_knots ? sp->knots[i] : 0.0;
+  return OMGX_OK;
+}
+}  // namespace
+
+int omgx_batch_store(omgx_batch* b, const double* x, const omgx_store_spec* sp) {
+  if (!b || !x || !sp) { g_err = "null argument"; return OMGX_E_INVALID; }
+  StoreArgs st;
+  int rc = fill_store(b, sp, &st);
+  if (rc != OMGX_OK) return rc;
+  HIPCHK(hipSetDevice(b->device));
+  const dim3 grid((st.n_samp + OMGX_SAMPLE_CHUNK - 1) / OMGX_SAMPLE_CHUNK, b->n_agents), block(256);
+  const size_t lds = sample_scratch_doubles(st.n_spl, st.degree, st.n_knots, st.n_der) * sizeof(double);
+  hipLaunchKernelGGL(sample_kernel<double>, grid, block, lds, b->stream, x, b->dims.n_var, st.coeff_off, st.n_spl,
+                     st.degree, st.knots, st.n_knots, st.n_der, st.t0, st.dt, st.inv_T, st.n_samp, st.out, st.v_tot);
+  HIPCHK(hipGetLastError());
+  return OMGX_OK;
+}
+
+int omgx_batch_set_store(omgx_batch* b, const omgx_store_spec* sp) {
+  if (!b) { g_err = "null handle"; return OMGX_E_INVALID; }
+  if (!sp) { b->store = StoreArgs{}; return OMGX_OK; }
+  StoreArgs st;
+  int rc = fill_store(b, sp, &st);
+  if (rc != OMGX_OK) return rc;
+  if (sample_scratch_doubles(st.n_spl, st.degree, st.n_knots, st.n_der) > (size_t)b->kkt_doubles) {
+    g_err = "store: the per-agent scratch does not fit the KKT store"; return OMGX_E_TOOLARGE;
+  }
+  b->store = st;
+  return OMGX_OK;
+}
+
+int omgx_batch_predict_ex(omgx_batch* b, const double* x, double* p, int32_t coeff_off, int32_t n_spl, int32_t degree,
+                          const double* knots, int32_t n_knots, double tau, double inv_T, int32_t n_out,
+                          const int32_t* p_off, int32_t p_t, double t_value, int32_t mode, const double* state_in,
+                          int32_t n_sub, double dtau) {
+  if (!b || !x || !p || !knots || !p_off || n_knots > 40 || degree > 5 || degree < 1 || n_spl <= 0 || n_out < 1 || n_out > 4 ||
+      n_out > degree + 1 || (mode != OMGX_PREDICT_IDEAL && mode != OMGX_PREDICT_RK4) ||
+      (mode == OMGX_PREDICT_RK4 && (!state_in || n_sub < 1 || !(dtau > 0.0) || n_out < 2))) {
+    g_err = "bad argument"; return OMGX_E_INVALID;
+  }
+  const omgx::Dims& d = b->dims;
+  const int L = n_knots - degree - 1;
+  if (coeff_off < 0 || coeff_off + n_spl * L > d.n_var || p_t >= d.n_par) { g_err = "predict: offsets outside x / p"; return OMGX_E_INVALID; }
+  PredictArgs a;
+  for (int o = 0; o < 4; ++o) {
+    a.p_off[o] = o < n_out ? p_off[o] : -1;
+    if (a.p_off[o] >= 0 && a.p_off[o] + n_spl > d.n_par) { g_err = "predict: offsets outside p"; return OMGX_E_INVALID; }
+  }
+  HIPCHK(hipSetDevice(b->device));
+  for (int i = 0; i < 40; ++i) a.kn.k[i] = i < n_knots ? knots[i] : 0.0;
+  a.coeff_off = coeff_off; a.n_spl = n_spl; a.degree = degree; a.n_knots = n_knots; a.n_out = n_out;
+  a.tau = tau; a.inv_T = inv_T; a.p_t = p_t; a.t_value = t_value; a.mode = mode; a.state_in = state_in; a.n_sub = n_sub; a.dtau = dtau;
+  const int n = b->n_agents * n_spl;
+  hipLaunchKernelGGL(predict_kernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, x, d.n_var, p, d.n_par, b->n_agents, a);
+  HIPCHK(hipGetLastError());
+  return OMGX_OK;
+}
+
 int omgx_batch_predict(omgx_batch* b, const double* x, double* p, int32_t coeff_off, int32_t n_spl, int32_t degree,
                        const double* knots, int32_t n_knots, double tau, double inv_T, int32_t p_state0,
                        int32_t p_input0, int32_t p_t, double t_value) {
-  if (!b || !x || !p || !knots || degree < 1 || degree > 5 || n_knots > 40 || n_knots < 2 * (degree + 1) || n_spl <= 0) {
-    g_err = "bad argument"; return OMGX_E_INVALID;
-  }
-  HIPCHK(hipSetDevice(b->device));
-  const omgx::Dims& d = b->dims;
-  KnotArg kn;
-  for (int i = 0; i < 40; ++i) kn.k[i] = i < n_knots ? knots[i] : 0.0;
-  const int n = b->n_agents * n_spl;
-  hipLaunchKernelGGL(predict_kernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, x, d.n_var, p, d.n_par,
-                     b->n_agents, coeff_off, n_spl, degree, kn, n_knots, tau, inv_T, p_state0, p_input0, p_t, t_value);
-  HIPCHK(hipGetLastError());
-  return OMGX_OK;
+  const int32_t off[2] = {p_state0, p_input0};
+  return omgx_batch_predict_ex(b, x, p, coeff_off, n_spl, degree, knots, n_knots, tau, inv_T, 2, off, p_t, t_value,
+                               OMGX_PREDICT_IDEAL, nullptr, 0, 0.0);
 }
 
 int omgx_admm_center(omgx_batch* b, const omgx_admm_layout* lay, const double* x, const double* p, double* x_i) {

@@ -1960,6 +1960,8 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 #ifdef OMGX_COUNT_FACT
       ++omgx_dbg_nfact;
       if (first_trial) ++omgx_dbg_cnt[4];
+      if (first_trial && dw == 0.0) ++omgx_dbg_cnt[5];
+      if (!bad && dw == 0.0) ++omgx_dbg_cnt[6];
       if (bad && dw == 0.0) ++omgx_dbg_cnt[2];
       if (bad && decreasing) ++omgx_dbg_cnt[3];
 #endif

@@ -127,6 +127,16 @@ def make_ctemplate(tpl, plan=None):
     return ct, keep
 
 
+class CStoreSpec(C.Structure):
+    """include/omgx.h omgx_store_spec"""
+    _fields_ = [('out', C.c_void_p), ('v_tot', C.c_void_p), ('t0', C.c_void_p), ('knots', C.c_void_p),
+                ('coeff_off', C.c_int32), ('n_spl', C.c_int32), ('degree', C.c_int32), ('n_knots', C.c_int32),
+                ('n_der', C.c_int32), ('n_samp', C.c_int32), ('dt', C.c_double), ('inv_T', C.c_double)]
+
+
+PREDICT_IDEAL, PREDICT_RK4 = 0, 1
+
+
 def save_template(tpl, path, lib=None):
     """Write the template file C/C++ callers load with `omgx_template_read` (include/omgx.h): what the
     reference's exporter does with the generated nlp.so (`export/export.py:236-262`)."""
@@ -203,6 +213,11 @@ def load_library(path=None):
     lib.omgx_batch_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_double,
                                       C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
+    lib.omgx_batch_predict_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_void_p,
+                                          C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_int32, C.c_double]
+    lib.omgx_batch_store.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CStoreSpec)]
+    lib.omgx_batch_set_store.argtypes = [C.c_void_p, C.POINTER(CStoreSpec)]
     if path == LIB_PATH:
         _lib = lib
     return lib
@@ -342,6 +357,45 @@ class BatchSolver(object):
             self._h, ptr(x), ptr(p), int(coeff_off), int(n_spl), int(degree), knots.ctypes.data, len(knots),
             float(tau), float(inv_T), int(p_state0), int(p_input0), int(p_t), float(t_value)),
             'omgx_batch_predict')
+
+    def predict_ex(self, x, p, coeff_off, n_spl, degree, knots, tau, inv_T, p_off, p_t, t_value,
+                   mode=PREDICT_IDEAL, state_in=None, n_sub=0, dtau=0.0):
+        """p[p_off[o] + k] <- o-th time derivative of spline k at tau (o < len(p_off), -1 skips); mode
+        PREDICT_RK4: p[p_off[0] + k] <- state_in integrated over the n_sub sample intervals that end at tau
+        (include/omgx.h omgx_batch_predict_ex).  Device-resident tensors / pointers."""
+        knots = np.ascontiguousarray(knots, dtype=np.float64)
+        off = np.ascontiguousarray(p_off, dtype=np.int32)
+
+        def ptr(a):
+            return None if a is None else (a.data_ptr() if hasattr(a, 'data_ptr') else int(a))
+        _check(self.lib, self.lib.omgx_batch_predict_ex(
+            self._h, ptr(x), ptr(p), int(coeff_off), int(n_spl), int(degree), knots.ctypes.data, len(knots),
+            float(tau), float(inv_T), len(off), off.ctypes.data, int(p_t), float(t_value), int(mode), ptr(state_in),
+            int(n_sub), float(dtau)), 'omgx_batch_predict_ex')
+
+    def _store_spec(self, out, v_tot, t0, coeff_off, n_spl, degree, knots, n_der, n_samp, dt, inv_T):
+        knots = np.ascontiguousarray(knots, dtype=np.float64)
+        sp = CStoreSpec(out.data_ptr(), v_tot.data_ptr() if v_tot is not None else None, t0.data_ptr(),
+                        knots.ctypes.data, int(coeff_off), int(n_spl), int(degree), len(knots), int(n_der),
+                        int(n_samp), float(dt), float(inv_T))
+        sp._keep = (knots, out, v_tot, t0)
+        return sp
+
+    def store(self, x, out, v_tot, t0, coeff_off, n_spl, degree, knots, n_der, n_samp, dt, inv_T):
+        """`Vehicle.store` of the batch on device tensors: out [B, n_der, n_spl, n_samp] time derivatives on the
+        grid t0[b] + i dt (spline domain), v_tot [B, n_samp] or None."""
+        sp = self._store_spec(out, v_tot, t0, coeff_off, n_spl, degree, knots, n_der, n_samp, dt, inv_T)
+        _check(self.lib, self.lib.omgx_batch_store(self._h, x.data_ptr(), C.byref(sp)), 'omgx_batch_store')
+
+    def set_store(self, out=None, v_tot=None, t0=None, coeff_off=0, n_spl=0, degree=0, knots=None, n_der=0, n_samp=0,
+                  dt=0.0, inv_T=1.0):
+        """Every following solve writes the trajectories of its solutions inside the solve kernel (out=None: off)."""
+        if out is None:
+            self._store = None
+            _check(self.lib, self.lib.omgx_batch_set_store(self._h, None), 'omgx_batch_set_store')
+            return
+        self._store = self._store_spec(out, v_tot, t0, coeff_off, n_spl, degree, knots, n_der, n_samp, dt, inv_T)
+        _check(self.lib, self.lib.omgx_batch_set_store(self._h, C.byref(self._store)), 'omgx_batch_set_store')
 
     def sample(self, x, coeff_off, n_spl, degree, knots, n_der, t0, dt, n_samp,
                out=None, as_f32=False, device=False):

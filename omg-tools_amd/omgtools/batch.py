@@ -76,8 +76,13 @@ class BatchP2P(object):
         self.update_time = float(update_time)
         self.B = P['p'].shape[0]
         self.o_spl = tpl.entry_range(veh.label, 'splines_seg0', 'var')[0]
-        self.o_state0 = tpl.entry_range(veh.label, 'state0', 'par')[0]
-        self.o_input0 = tpl.entry_range(veh.label, 'input0', 'par')[0]
+        # initial conditions the prediction writes: time derivatives 0, 1, (2) of the plan at the time of the
+        # next solve (`vehicles/holonomic.py:88-89,153-159`: state0, input0; `vehicles/quadrotor.py:76-85,110-114`:
+        # spl0, dspl0, ddspl0)
+        names = ('spl0', 'dspl0', 'ddspl0') if (veh.label, 'spl0') in tpl.par_layout else ('state0', 'input0')
+        self.p_offs = [tpl.entry_range(veh.label, nm, 'par')[0] for nm in names]
+        self.n_spl = veh.n_spl
+        self.o_state0, self.o_input0 = self.p_offs[0], self.p_offs[1]
         self.o_t = tpl.entry_range(problem.label, 't', 'par')[0]
         # obstacle motion model between two solves (`environment/obstacle.py:246-264` without bouncing):
         # the parameters x, v, a of every obstacle are the values AT the time of the solve
@@ -187,16 +192,13 @@ class BatchP2P(object):
             self._solve(True, step_desc=self._pool_step(tau, t_rel, crossed))
             return crossed
         if self.kind == 'hip':
-            # one kernel: state0 / input0 from the plan at tau and the new t, all written into p
-            self.solver.predict(self.x, self.p, self.o_spl, nd, self.basis.degree, self.basis.knots, tau,
-                                1.0 / self.T, self.o_state0, self.o_input0, self.o_t, t_rel)
+            # one kernel: the initial conditions from the plan at tau and the new t, all written into p
+            self.solver.predict_ex(self.x, self.p, self.o_spl, self.n_spl, self.basis.degree, self.basis.knots, tau,
+                                   1.0 / self.T, self.p_offs, self.o_t, t_rel)
         else:
-            E = self.basis.eval_basis([tau])[0]
-            dbasis, P1 = self.basis.derivative(1)
-            Ed = dbasis.eval_basis([tau])[0] @ P1 / self.T
-            c = self.x[:, self.o_spl:self.o_spl + nd * L].reshape(B, nd, L)
-            self.p[:, self.o_state0:self.o_state0 + nd] = c @ E
-            self.p[:, self.o_input0:self.o_input0 + nd] = c @ Ed
+            c = self.x[:, self.o_spl:self.o_spl + self.n_spl * L].reshape(B, self.n_spl, L)
+            for o, E in enumerate(self._eval_rows(tau)):
+                self.p[:, self.p_offs[o]:self.p_offs[o] + self.n_spl] = c @ E
             self.p[:, self.o_t] = t_rel
         # obstacles move on: x <- x + v dt + a dt^2 / 2, v <- v + a dt (a no-op for static obstacles)
         dt = self.update_time
@@ -211,13 +213,22 @@ class BatchP2P(object):
         self._solve(True, events)
         return crossed
 
+    def _eval_rows(self, tau):
+        """[E_0, E_1, ...]: c @ E_o = o-th time derivative of the plan at tau."""
+        rows = [self.basis.eval_basis([tau])[0]]
+        for o in range(1, len(self.p_offs)):
+            dbasis, Po = self.basis.derivative(o)
+            rows.append(dbasis.eval_basis([tau])[0] @ Po / self.T ** o)
+        return rows
+
     def _pool_step(self, tau, t_rel, crossed):
         """Constants of this step for a pool that runs the glue per agent in its workers (field names of the
         `StepDesc` the pool defines)."""
         desc = self.pool.step_desc()
-        E = np.ascontiguousarray(self.basis.eval_basis([tau])[0])
-        dbasis, P1 = self.basis.derivative(1)
-        Ed = np.ascontiguousarray(dbasis.eval_basis([tau])[0] @ P1 / self.T)
+        rows = [np.ascontiguousarray(r) for r in self._eval_rows(tau)]
+        if len(rows) != 2 or self.n_spl != self.n_dim:
+            raise NotImplementedError('the pool step glue carries state0 / input0 only')
+        E, Ed = rows
         obst = np.ascontiguousarray(np.array(self.obst, dtype=np.int32).reshape(-1, 4))
         perm = np.ascontiguousarray(self.perm, dtype=np.int64)
         ents = np.ascontiguousarray(self.shift_entries, dtype=np.int32)

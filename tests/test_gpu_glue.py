@@ -1,0 +1,154 @@
+"""The receding-horizon glue either side of the solve on the device: prediction with
+higher derivatives and with the reference's RK4 statements, `Vehicle.store` as a kernel and fused behind the
+solve -- each against the host front end's own functions (omgtools.vehicles / omgtools.splines, which
+tests/test_front_end_* pin to the reference)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup(n, scen='holonomic_p2p'):
+    import omgtools.backend as be
+    from omgtools import scenarios
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        problem, P = getattr(scenarios, scen)(n)
+    finally:
+        be.create_nlp = saved
+    return problem, P
+
+
+def _random_plan(problem, P, rng):
+    """x with random spline coefficients (smooth enough to be a plan)."""
+    tpl, veh = problem.father.template, problem.vehicles[0]
+    lo, hi = tpl.entry_range(veh.label, 'splines_seg0', 'var')
+    x = np.array(P['x0'])
+    x[:, lo:hi] += rng.normal(scale=0.3, size=(x.shape[0], hi - lo))
+    return x, lo
+
+
+def test_predict_with_second_derivative_matches_the_spline_algebra():
+    """Quadrotor: spl0, dspl0, ddspl0 (`vehicles/quadrotor.py:76-85`) from the plan at tau."""
+    import torch
+    from omgtools.backend import BatchSolver
+    from omgtools.splines import BSpline
+    problem, P = _setup(6, 'quadrotor_p2p')
+    tpl, veh = problem.father.template, problem.vehicles[0]
+    T = float(problem.options['horizon_time'])
+    x, lo = _random_plan(problem, P, np.random.default_rng(3))
+    L, nd = len(veh.basis), veh.n_spl
+    solver = BatchSolver(tpl, 6)
+    xd = torch.as_tensor(x, device='cuda:0')
+    pd = torch.zeros((6, tpl.n_par), dtype=torch.float64, device='cuda:0')
+    offs = [tpl.entry_range(veh.label, nm, 'par')[0] for nm in ('spl0', 'dspl0', 'ddspl0')]
+    o_t = tpl.entry_range(problem.label, 't', 'par')[0]
+    for tau in (0.0, 0.013, 1.0 / 13, 0.37, 1.0):
+        solver.predict_ex(xd, pd, lo, nd, veh.degree, veh.basis.knots, tau, 1.0 / T, offs, o_t, 0.25)
+        got = pd.cpu().numpy()
+        for b in range(6):
+            for k in range(nd):
+                s = BSpline(veh.basis, x[b, lo + k * L:lo + (k + 1) * L])
+                for o in range(3):
+                    want = (s.derivative(o) if o else s)(tau) / T ** o
+                    assert abs(got[b, offs[o] + k] - want) < 1e-10 * max(1.0, abs(want)), (tau, b, k, o)
+        assert np.all(got[:, o_t] == 0.25)
+    solver.close()
+
+
+def test_rk4_prediction_follows_the_reference_statements():
+    """`Vehicle::integrate` (`export/vehicles/Vehicle.cpp:82-110`) with `ode` = input (holonomic.py:126-127)."""
+    import torch
+    from omgtools.backend import BatchSolver, PREDICT_RK4
+    from omgtools.splines import BSpline
+    problem, P = _setup(5)
+    tpl, veh = problem.father.template, problem.vehicles[0]
+    T = float(problem.options['horizon_time'])
+    x, lo = _random_plan(problem, P, np.random.default_rng(4))
+    L, nd = len(veh.basis), veh.n_dim
+    solver = BatchSolver(tpl, 5)
+    xd = torch.as_tensor(x, device='cuda:0')
+    pd = torch.zeros((5, tpl.n_par), dtype=torch.float64, device='cuda:0')
+    state = np.random.default_rng(5).normal(size=(5, nd))
+    sd = torch.as_tensor(state, device='cuda:0')
+    o_s = tpl.entry_range(veh.label, 'state0', 'par')[0]
+    o_i = tpl.entry_range(veh.label, 'input0', 'par')[0]
+    sample_time, steps = 0.01, 10                                  # update_time 0.1 s at 100 Hz
+    tau = 0.3 + steps * sample_time / T
+    solver.predict_ex(xd, pd, lo, nd, veh.degree, veh.basis.knots, tau, 1.0 / T, [o_s, o_i], -1, 0.,
+                      mode=PREDICT_RK4, state_in=sd, n_sub=steps, dtau=sample_time / T)
+    got = pd.cpu().numpy()
+    for b in range(5):
+        spl = [BSpline(veh.basis, x[b, lo + k * L:lo + (k + 1) * L]) for k in range(nd)]
+        inp = np.array([[s.derivative(1)(0.3 + i * sample_time / T) / T for s in spl] for i in range(steps + 1)])
+        state0 = state[b].copy()
+        stateT = state0.copy()
+        for i in range(steps):                                     # the C++ loop, line by line
+            k1 = inp[i]
+            k2 = inp[i]
+            k3 = inp[i]
+            k4 = inp[i + 1]
+            stateT += (sample_time / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
+        assert np.abs(got[b, o_s:o_s + nd] - stateT).max() < 1e-12
+        assert np.abs(got[b, o_i:o_i + nd] - inp[steps]).max() < 1e-12
+    solver.close()
+
+
+def test_store_kernel_and_fused_store_match_splines2signals():
+    """`Vehicle.store` -> `splines2signals` (state, input, dinput, v_tot on the sample grid): the stand-alone
+    kernel on a given x, and the same arrays written by the solve kernel for the solution it found."""
+    import torch
+    from omgtools.backend import BatchSolver
+    from omgtools.splines import BSpline
+    B = 8
+    problem, P = _setup(B)
+    tpl, veh = problem.father.template, problem.vehicles[0]
+    T = float(problem.options['horizon_time'])
+    lo = tpl.entry_range(veh.label, 'splines_seg0', 'var')[0]
+    L, nd, n_samp, sample_time = len(veh.basis), veh.n_dim, 1001, 0.01
+    dev = torch.device('cuda', 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    solver = BatchSolver(tpl, B, options=dict(tol=1e-6, max_iter=300))
+    out = torch.zeros((B, 3, nd, n_samp), **f64)
+    vt = torch.zeros((B, n_samp), **f64)
+    t0 = torch.zeros(B, **f64)
+    knots = veh.basis.knots
+    # fused: the solve writes the trajectories of its own solution
+    solver.set_store(out, vt, t0, lo, nd, veh.degree, knots, 3, n_samp, sample_time / T, 1.0 / T)
+    xd, pd = torch.as_tensor(P['x0'], **f64), torch.as_tensor(P['p'], **f64)
+    lb, ub = torch.as_tensor(tpl.lb, **f64), torch.as_tensor(tpl.ub, **f64)
+    xs, lam = torch.empty_like(xd), torch.zeros((B, tpl.n_con), **f64)
+    st, it = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+    solver.solve_device(pd, xd, lb, ub, xs, lam, st, it, bounds_shared=True)
+    torch.cuda.synchronize()
+    assert (st == 0).all()
+    fused, fused_v = out.cpu().numpy().copy(), vt.cpu().numpy().copy()
+    x = xs.cpu().numpy()
+    time = np.linspace(0., (n_samp - 1) * sample_time, n_samp)
+    for b in range(B):
+        spl = [BSpline(veh.basis, x[b, lo + k * L:lo + (k + 1) * L]) for k in range(nd)]
+        # reference units: the stored splines live on [0, T]; derivative order o scales with 1 / T^o
+        sig = {'state': np.array([s(time / T) for s in spl]),
+               'input': np.array([s.derivative(1)(time / T) / T for s in spl]),
+               'dinput': np.array([s.derivative(2)(time / T) / T ** 2 for s in spl])}
+        for o, key in enumerate(('state', 'input', 'dinput')):
+            scale = max(1.0, np.abs(sig[key]).max())
+            assert np.abs(fused[b, o] - sig[key]).max() < 1e-10 * scale, (b, key)
+        assert np.abs(fused_v[b] - np.sqrt((sig['input'] ** 2).sum(axis=0))).max() < 1e-10
+    # stand-alone kernel on the same x: the same bits
+    solver.set_store(None)
+    out2, vt2 = torch.zeros_like(out), torch.zeros_like(vt)
+    solver.store(xs, out2, vt2, t0, lo, nd, veh.degree, knots, 3, n_samp, sample_time / T, 1.0 / T)
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), fused) and np.array_equal(vt2.cpu().numpy(), fused_v)
+    # and a solve after set_store(None) leaves the arrays alone
+    out.zero_()
+    solver.solve_device(pd, xd, lb, ub, xs, lam, st, it, bounds_shared=True)
+    torch.cuda.synchronize()
+    assert float(out.abs().max()) == 0.0
+    solver.close()

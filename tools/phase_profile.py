@@ -18,6 +18,35 @@ PHASES = ['jac', 'resid', 'assemble', 'factor', 'solve', 'step', 'linesearch', '
           'f_park', 'f_sweep', 'f_scale', 'a_tcol', 'a_hess', 's_p_load', 's_p_div', 's_p_bspl', 's_p_slots']
 
 
+def mpc_mode(problem, P, B, steps=20, warmup=3):
+    """The headline protocol (bench.py): cold solve, `warmup` receding-horizon steps, then the phase counters
+    of `steps` steps summed -- cycles per solve and per iteration of the warm-started steps."""
+    import torch
+    from omgtools.batch import BatchP2P
+    mpc = BatchP2P(problem, P, ops='hip', device=torch.device('cuda', 0), options=dict(tol=1e-3, max_iter=300))
+    solver = mpc.solver
+    solver.lib.omgx_batch_phase_cycles.argtypes = [C.c_void_p, C.c_void_p]
+    mpc.solve_cold()
+    for _ in range(warmup):
+        mpc.step()
+    tot = np.zeros(len(PHASES))
+    its, ms = 0, []
+    prof = np.zeros((B, len(PHASES)), dtype=np.int64)
+    for _ in range(steps):
+        mpc.step()
+        torch.cuda.synchronize()
+        ms.append(solver.last_kernel_ms())
+        solver.lib.omgx_batch_phase_cycles(solver._h, prof.ctypes.data)
+        tot += prof.sum(axis=0)
+        its += int(mpc.iters.sum().item())
+    n_solves = B * steps
+    out = {'mode': 'mpc', 'agents': B, 'steps': steps, 'kernel_ms_mean': float(np.mean(ms)), 'kernel_ms_p50': float(np.median(ms)),
+           'iters_per_solve': its / n_solves,
+           'cycles_per_solve': {p: float(tot[k] / n_solves) for k, p in enumerate(PHASES)},
+           'cycles_per_iter': {p: float(tot[k] / max(1, its)) for k, p in enumerate(PHASES)}}
+    print(json.dumps(out, indent=1))
+
+
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     be.LIB_PATH = os.environ.get('OMGX_PROF_LIB', os.path.join(ROOT, 'omg-tools_amd', 'csrc', 'libomgx_prof.so'))
@@ -27,6 +56,8 @@ def main():
     problem, P = holonomic_p2p(B)
     be.create_nlp = saved
     tpl = problem.father.template
+    if len(sys.argv) > 2 and sys.argv[2] == 'mpc':
+        return mpc_mode(problem, P, B)
     solver = be.BatchSolver(tpl, B, options=dict(tol=1e-3, max_iter=300))
     warm = len(sys.argv) > 2 and sys.argv[2] == 'warm'
     for _ in range(2):
