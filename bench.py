@@ -261,36 +261,33 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
     problem, P = fn(B, seed=20240807 + (3 if args.workload == 'quadrotor' else 5) + 1000 * rank)
     be.create_nlp = saved
     tpl = problem.father.template
-    solver = BatchSolver(tpl, B, device=local_rank, options=dict(P.get('solver_options', {}), tol=args.tol, max_iter=300))
-    solver.set_stream(torch.cuda.current_stream().cuda_stream)
-    f64 = dict(dtype=torch.float64, device=dev)
-    p, x0 = torch.as_tensor(P['p'], **f64), torch.as_tensor(P['x0'], **f64)
-    lb, ub = torch.as_tensor(tpl.lb, **f64), torch.as_tensor(tpl.ub, **f64)
-    x, lam = torch.empty_like(x0), torch.zeros((B, tpl.n_con), **f64)
-    status = torch.zeros(B, dtype=torch.int32, device=dev)
-    iters = torch.zeros(B, dtype=torch.int32, device=dev)
+    from omgtools.batch import BatchP2P
+    mpc = BatchP2P(problem, P, ops='hip', device=dev, options=dict(P.get('solver_options', {}), tol=args.tol, max_iter=300))
+    x0_init, p_init = mpc.x.clone(), mpc.p.clone()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    kernel_ms = []
+    # one step = the cold solve of the whole batch from the reference's initial guess, restart passes for the
+    # agents whose phase I stalls included (BatchP2P.solve_cold)
+    passes = 0
     for k in range(args.warmup + args.steps):
         if k == args.warmup:
             barrier()
             t0 = time.perf_counter()
-        solver.solve_device(p, x0, lb, ub, x, lam, status, iters, bounds_shared=True)
+        mpc.x.copy_(x0_init)
+        mpc.p.copy_(p_init)
+        mpc.time = 0.0
+        passes = mpc.solve_cold()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms.append(solver.last_kernel_ms())
+    kernel_ms = [elapsed / args.steps * 1e3]
+    status, iters = mpc.status, mpc.iters
     n_ok = int((status == 0).sum().item())
     it_sum = int(iters.sum().item())
     elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist if world > 1 else None)
     # receding-horizon steps of the same batch (the protocol of the headline: cold solve, warm-up, timed steps)
-    from omgtools.batch import BatchP2P
-    solver.close()
-    mpc = BatchP2P(problem, P, ops='hip', device=dev, options=dict(P.get('solver_options', {}), tol=args.tol, max_iter=300))
-    mpc.solve_cold()
     rh_steps = max(args.steps, 10)
     for _ in range(args.warmup):
         mpc.step()
@@ -317,8 +314,9 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
         'unit': 'solves/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': '%s: %d agents per GPU, cold solve from the reference initial guess, tol=%g'
-                               % (args.workload, B, args.tol), 'n_var': tpl.n_var, 'n_con': tpl.n_con},
+        'config': {'workload': '%s: %d agents per GPU, cold solve from the reference initial guess (agents that do not '
+                               'converge from it are solved again from the guess bent sideways: %d restart passes), tol=%g'
+                               % (args.workload, B, passes, args.tol), 'n_var': tpl.n_var, 'n_con': tpl.n_con},
         'solved_fraction': n_ok / float(B), 'mean_iters': it_sum / float(B), 'workspace': mpc.solver.workspace(),
         'receding_horizon': {'solves_per_s': rh_ok_all / rh_elapsed, 'ms_per_step': rh_elapsed / rh_steps * 1e3,
                              'steps': rh_steps, 'warmup': args.warmup, 'solved_fraction': rh_ok / float(rh_steps * B),
@@ -329,7 +327,7 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
         'roofline': {'bound': 'mfma', 'kernel': 'ipm_solve_kernel', 'achieved': flops / (k_ms * 1e-3) / 1e12,
                      'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': flops / (k_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
-                     'kernel_ms': k_ms}}))
+                     'kernel_ms': k_ms, 'note': 'iterations of the final pass of every agent; time = the whole cold step'}}))
 
 
 def main():

@@ -45,6 +45,10 @@ extern "C" {
 #define OMGX_PTR_DEVICE     1   /* p/x0/x/lam_g/status/iters are device pointers */
 #define OMGX_BOUNDS_SHARED  2   /* lbg/ubg hold n_con values shared by all agents */
 #define OMGX_BOUNDS_DEVICE  4   /* lbg/ubg are device pointers */
+#define OMGX_ONLY_FAILED    8   /* restart pass: agents whose status entry is Solve_Succeeded on entry are skipped
+                                   (their x, lam_g, status, iters are left as they are); the others are solved from
+                                   x0 -- e.g. another initial guess after a phase-I stall (needs OMGX_PTR_DEVICE, or
+                                   host buffers that hold the results of the previous call) */
 
 /* Flat NLP description (host pointers, copied by create): what the reference hands to
  * `nlpsol('solver', 'ipopt', {x, p, f, g}, ...)` (`basics/optilayer.py:54-60`) as CasADi graphs, here as

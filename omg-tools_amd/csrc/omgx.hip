@@ -12,6 +12,7 @@
 //   shift_kernel       warm-start shift T*coeffs (`spline_extra.py:165-191`).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -165,7 +166,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  double* __restrict__ x, double* __restrict__ lam, int32_t* __restrict__ status,
                  int32_t* __restrict__ iters, int n_agents, long long* __restrict__ prof,
                  double* __restrict__ slabs, size_t slab_doubles, double* __restrict__ dw_state,
-                 const int32_t* __restrict__ order, StoreArgs st) {
+                 const int32_t* __restrict__ order, StoreArgs st, int only_failed) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
@@ -183,6 +184,8 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   // that their long solves overlap the rest of the batch instead of trailing it
   for (int slot = blockIdx.x; slot < n_agents; slot += gridDim.x) {
     const int b = order ? order[slot] : slot;
+    // restart pass (OMGX_ONLY_FAILED): agents that are solved already keep x, lam_g, status, iters
+    if (only_failed && status[b] == 0) continue;
 #ifdef OMGX_PROFILE
     if (threadIdx.x < omgx::PH_COUNT) prof_lds[threadIdx.x] = 0;
     __syncthreads();
@@ -219,7 +222,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
-                             const int32_t*, StoreArgs);
+                             const int32_t*, StoreArgs, int);
 static ipm_kernel_t ipm_kernel_for(int mode) {
   switch (mode) {
     case omgx::WS_LDS: return ipm_solve_kernel<omgx::WS_LDS>;
@@ -539,6 +542,9 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   }
   b->ws_mode = mode; b->lds_bytes = nl * sizeof(double); b->slab_doubles = ng;
   if (mode != omgx::WS_LDS) b->dims.wave_ok = 0;      // the wave-level routines address the KKT store as LDS
+  // developer knobs (A/B measurements of the register-resident routines against the blocked ones)
+  if (const char* e = getenv("OMGX_WAVE_LEAF")) b->dims.wave_leaf = b->dims.wave_leaf && atoi(e);
+  if (const char* e = getenv("OMGX_WAVE_ROOT")) b->dims.wave_root = b->dims.wave_root && atoi(e);
   const omgx::Tables& H = plan.tables;
   const omgx::Dims& d = plan.dims;
   UP(prog, 6 * d.n_prog); UP(knots, t->n_knots); UP(pp_ptr, t->n_pp + 1); UP(pm_coef, t->n_mono);
@@ -812,6 +818,12 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
       HIPCHK(hipMemcpyAsync(b->d_lam, lam_g, (size_t)B * d.n_con * sizeof(double), hipMemcpyHostToDevice, b->stream));
       HIPCHK(hipMemcpyAsync(b->d_status, status, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
     }
+    if (flags & OMGX_ONLY_FAILED) {       // the skipped agents keep what the caller's buffers hold
+      HIPCHK(hipMemcpyAsync(b->d_x, x, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream));
+      HIPCHK(hipMemcpyAsync(b->d_lam, lam_g, (size_t)B * d.n_con * sizeof(double), hipMemcpyHostToDevice, b->stream));
+      HIPCHK(hipMemcpyAsync(b->d_status, status, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+      HIPCHK(hipMemcpyAsync(b->d_iters, iters, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+    }
     kp = b->d_p; kx0 = b->d_x0; kx = b->d_x; klam = b->d_lam; kst = b->d_status; kit = b->d_iters;
   }
   if (!bdev) {
@@ -822,7 +834,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   HIPCHK(hipEventRecord(b->ev0, b->stream));
   hipLaunchKernelGGL(ipm_kernel_for(b->ws_mode), dim3(b->n_slabs), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev,
                      b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
-                     b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, b->store);
+                     b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, b->store, (flags & OMGX_ONLY_FAILED) ? 1 : 0);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   b->timed = true;

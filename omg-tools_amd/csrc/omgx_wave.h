@@ -35,7 +35,7 @@ __device__ __forceinline__ void wave_fence() {
 // rows [n, nreg): carried rows held one per lane; rows [nreg, nreg + nvec): carried rows held as lane
 // vectors.  Row r starts at base + r * ld + packed * r (r + 1) / 2 (row-major leaf panels: packed = 0;
 // packed lower root: ld = 0, packed = 1).  Pivots j < npos must be positive, the others negative.
-struct WPanel { int base, ld, packed, n, nreg, nvec, npos, bw; };    // bw: half bandwidth of the symmetric block (n - 1: dense)
+struct WPanel { int base, ld, packed, n, nreg, nvec, npos, bw, vrow; };    // bw: half bandwidth of the symmetric block (n - 1: dense); vrow: index of the first vector row (>= nreg: the rows between are carried by wave_carry)
 
 // The descriptor fields are the same in every lane but come from LDS (per-lane loads): without this the
 // compiler has to treat every loop bound of the routines below as divergent (exec-masked regions
@@ -46,6 +46,7 @@ __device__ __forceinline__ WPanel wpanel_uniform(const WPanel& Q) {
   P.packed = __builtin_amdgcn_readfirstlane(Q.packed); P.n = __builtin_amdgcn_readfirstlane(Q.n);
   P.nreg = __builtin_amdgcn_readfirstlane(Q.nreg); P.nvec = __builtin_amdgcn_readfirstlane(Q.nvec);
   P.npos = __builtin_amdgcn_readfirstlane(Q.npos); P.bw = __builtin_amdgcn_readfirstlane(Q.bw);
+  P.vrow = __builtin_amdgcn_readfirstlane(Q.vrow);
   return P;
 }
 
@@ -55,6 +56,23 @@ __device__ __forceinline__ int wrow(const WPanel& P, int r) { return P.base + r 
 // out-of-line routines below take offsets into it, so that their accesses stay ds_* instructions (a
 // pointer argument would be a generic pointer: flat_* instructions).
 extern __shared__ double omgx_lds[];
+
+// Where a panel lives: LDS (offset into the workgroup's dynamic LDS) or global memory (spill modes).  Explicit
+// address spaces: a generic pointer would turn every access into a flat_* instruction.
+typedef __attribute__((address_space(1))) double wgdouble;
+template <bool G> struct WStore;
+template <> struct WStore<false> {
+  int off;
+  __device__ __forceinline__ WStore(int o, double*) : off(o) {}
+  __device__ __forceinline__ double ld(int i) const { return omgx_lds[off + i]; }
+  __device__ __forceinline__ void st(int i, double v) const { omgx_lds[off + i] = v; }
+};
+template <> struct WStore<true> {
+  wgdouble* g;
+  __device__ __forceinline__ WStore(int, double* p) : g((wgdouble*)p) {}
+  __device__ __forceinline__ double ld(int i) const { return g[i]; }
+  __device__ __forceinline__ void st(int i, double v) const { g[i] = v; }
+};
 
 // In-place LDL' of a panel by one wave, the matrix in registers: lane i holds row i, a[k] = A[i][k].
 // Straight-line code: all NC columns are processed whatever the order n is (the columns >= n work on
@@ -75,9 +93,10 @@ extern __shared__ double omgx_lds[];
 // On return the panel holds U = L D (rows < n, lower part and diagonal) / W = B L^{-T} (carried rows), the
 // vector rows are stored forward-substituted.  Returns 1 if a pivot had the wrong sign.  `off`: offset of
 // the KKT store in the dynamic LDS (doubles).
-template <int NC, int BW>
-__device__ __forceinline__ int wave_ldl(int off, const WPanel Pin) {
-  double* A = omgx_lds + off;
+// G: the store lives in global memory (`g`: its address; spill modes) instead of LDS (`off`).
+template <int NC, int BW, bool G = false>
+__device__ __forceinline__ int wave_ldl(int off, const WPanel Pin, double* g = nullptr) {
+  const WStore<G> A(off, g);
   const WPanel P = wpanel_uniform(Pin);
   const int lane = threadIdx.x & 63;
   const int n = P.n;
@@ -87,13 +106,13 @@ __device__ __forceinline__ int wave_ldl(int off, const WPanel Pin) {
   double a[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) {                       // unconditional loads (all in flight), masked afterwards
-    const double v = A[ra + (k < n ? k : n - 1)];
+    const double v = A.ld(ra + (k < n ? k : n - 1));
     a[k] = (has_row && k < n) ? v : 0.0;
   }
   double yv0, yv1;
   {
     const int c = sym_row ? lane : 0;
-    const double v0 = A[wrow(P, P.nreg) + c], v1 = A[wrow(P, P.nreg + (P.nvec > 1 ? 1 : 0)) + c];
+    const double v0 = A.ld(wrow(P, P.vrow) + c), v1 = A.ld(wrow(P, P.vrow + (P.nvec > 1 ? 1 : 0)) + c);
     yv0 = (P.nvec > 0 && sym_row) ? v0 : 0.0;
     yv1 = (P.nvec > 1 && sym_row) ? v1 : 0.0;
   }
@@ -135,12 +154,12 @@ __device__ __forceinline__ int wave_ldl(int off, const WPanel Pin) {
       for (int k = 0; k < NC; ++k) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        if (k < n && (!sym_row || k <= ln)) A[ra + k] = a[k];
+        if (k < n && (!sym_row || k <= ln)) A.st(ra + k, a[k]);
       }
     }
     if (sym_row) {
-      if (P.nvec > 0) A[wrow(P, P.nreg) + lane] = yv0;
-      if (P.nvec > 1) A[wrow(P, P.nreg + 1) + lane] = yv1;
+      if (P.nvec > 0) A.st(wrow(P, P.vrow) + lane, yv0);
+      if (P.nvec > 1) A.st(wrow(P, P.vrow + 1) + lane, yv1);
     }
   }
   return bad;
@@ -152,6 +171,45 @@ __device__ __forceinline__ double wave_dinv(const double* A, const WPanel P) {
   const int c = lane < P.n ? lane : 0;
   const double d = A[wrow(P, c) + c];
   return lane < P.n ? rcp_pivot(d) : 0.0;
+}
+
+// Carried rows that did not fit the lanes of wave_ldl (leaf order + coupling rows > 64: the Quadrotor and 3-D
+// classes): rows [r0, r0 + nrows) of the panel, one per lane, W = B L^{-T} by forward substitution along the row,
+//   w_k -= (w_j / d_j) u_kj   for the columns k in (j, j + BW]  (u_kj = 0 outside the band),
+// with u_kj read from the stored factor (the same address in every lane: a broadcast read) and the inverse
+// pivots from `dinv` (LDS).  Same straight-line form as wave_ldl; call after wave_ldl + wave_fence.
+template <int NC, int BW, bool G>
+__device__ __forceinline__ void wave_carry(int off, const WPanel Pin, double* g, const double* dinv, int r0, int nrows) {
+  const WStore<G> A(off, g);
+  const WPanel P = wpanel_uniform(Pin);
+  const int lane = threadIdx.x & 63;
+  const int n = P.n;
+  nrows = __builtin_amdgcn_readfirstlane(nrows); r0 = __builtin_amdgcn_readfirstlane(r0);
+  const bool has = lane < nrows;
+  const int ra = wrow(P, r0 + (has ? lane : 0));
+  double a[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const double v = A.ld(ra + (k < n ? k : n - 1));
+    a[k] = (has && k < n) ? v : 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const double dj = dinv[j < n ? j : 0];
+    const double lw = (j < n) ? a[j] * dj : 0.0;
+#pragma unroll
+    for (int q = 1; q <= BW; ++q) {
+      const int k = j + q;
+      if (k < NC) {
+        const double u = A.ld(wrow(P, k < n ? k : n - 1) + (j < n ? j : 0));
+        a[k] = fma(-lw, (k < n) ? u : 0.0, a[k]);
+      }
+    }
+  }
+  if (has) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k) if (k < n) A.st(ra + k, a[k]);
+  }
 }
 
 // x <- L^{-T} z for the factor stored in the panel (U = L D in LDS, left by wave_ldl): lane j reads

@@ -135,6 +135,7 @@ class CStoreSpec(C.Structure):
 
 
 PREDICT_IDEAL, PREDICT_RK4 = 0, 1
+ONLY_FAILED = 8
 
 
 def save_template(tpl, path, lib=None):
@@ -330,10 +331,12 @@ class BatchSolver(object):
         return dict(x=x, lam_g=lam, status=status, iters=iters)
 
     # -- device pointers (torch tensors / raw ints) -------------------------------------
-    def solve_device(self, p, x0, lbg, ubg, x, lam_g, status, iters, bounds_shared=True):
+    def solve_device(self, p, x0, lbg, ubg, x, lam_g, status, iters, bounds_shared=True, only_failed=False):
+        """only_failed: restart pass -- agents whose `status` is 0 keep x / lam_g / status / iters, the others are
+        solved from x0 (OMGX_ONLY_FAILED)."""
         def ptr(a):
             return a.data_ptr() if hasattr(a, 'data_ptr') else int(a)
-        flags = PTR_DEVICE | BOUNDS_DEVICE | (BOUNDS_SHARED if bounds_shared else 0)
+        flags = PTR_DEVICE | BOUNDS_DEVICE | (BOUNDS_SHARED if bounds_shared else 0) | (ONLY_FAILED if only_failed else 0)
         _check(self.lib, self.lib.omgx_batch_solve(
             self._h, ptr(p), ptr(x0), ptr(lbg), ptr(ubg), ptr(x), ptr(lam_g), ptr(status),
             ptr(iters), flags), 'omgx_batch_solve')

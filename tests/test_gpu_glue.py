@@ -152,3 +152,33 @@ def test_store_kernel_and_fused_store_match_splines2signals():
     torch.cuda.synchronize()
     assert float(out.abs().max()) == 0.0
     solver.close()
+
+
+def test_restart_pass_solves_only_the_failed_agents():
+    """OMGX_ONLY_FAILED: a second call with other initial guesses touches only the agents that failed; BatchP2P's
+    cold solve uses it with the straight-line guess bent sideways (Quadrotor class: phase-I stalls)."""
+    import torch
+    from omgtools.batch import BatchP2P
+    problem, P = _setup(64, 'quadrotor_p2p')
+    opts = dict(P.get('solver_options', {}), tol=1e-3, max_iter=300)
+    plain = BatchP2P(problem, P, ops='hip', options=opts)
+    assert plain.solve_cold(bends=()) == 0
+    st0, x0 = plain.status.cpu().numpy().copy(), plain.x.cpu().numpy().copy()
+    failed = np.nonzero(st0 != 0)[0]
+    assert 0 < len(failed) < 16                                     # the class has its stragglers ...
+    mpc = BatchP2P(problem, P, ops='hip', options=opts)
+    passes = mpc.solve_cold()
+    st1, x1 = mpc.status.cpu().numpy(), mpc.x.cpu().numpy()
+    assert passes >= 1 and (st1 == 0).all()                         # ... and the bent guesses get all of them through
+    ok = st0 == 0
+    assert np.array_equal(x1[ok], x0[ok])                           # untouched: the same bits as without restarts
+    assert np.abs(x1[failed] - x0[failed]).max() > 1e-3
+    # the restarted solutions satisfy the optimality conditions of the reference's NLP
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    nlp = NumpyNLP(problem.father.template)
+    lam = mpc.lam.cpu().numpy()
+    for b in failed[:4]:
+        assert_kkt(nlp, problem.father.template, P['p'][b], x1[b], lam[b], 1e-2, ('restart', b))
+    plain.solver.close()
+    mpc.solver.close()

@@ -50,15 +50,15 @@ def mpc_mode(problem, P, B, steps=20, warmup=3):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     be.LIB_PATH = os.environ.get('OMGX_PROF_LIB', os.path.join(ROOT, 'omg-tools_amd', 'csrc', 'libomgx_prof.so'))
-    from omgtools.scenarios import holonomic_p2p
+    from omgtools import scenarios
     saved = be.create_nlp
     be.create_nlp = lambda tpl, opt, name='': (None, 0.)
-    problem, P = holonomic_p2p(B)
+    problem, P = getattr(scenarios, os.environ.get('OMGX_SCENARIO', 'holonomic_p2p'))(B)
     be.create_nlp = saved
     tpl = problem.father.template
     if len(sys.argv) > 2 and sys.argv[2] == 'mpc':
         return mpc_mode(problem, P, B)
-    solver = be.BatchSolver(tpl, B, options=dict(tol=1e-3, max_iter=300))
+    solver = be.BatchSolver(tpl, B, options=dict(P.get('solver_options', {}), tol=1e-3, max_iter=300))
     warm = len(sys.argv) > 2 and sys.argv[2] == 'warm'
     for _ in range(2):
         res = solver.solve(P['p'], P['x0'])
