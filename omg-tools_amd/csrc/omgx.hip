@@ -158,7 +158,7 @@ __device__ void sample_agent(const double* coeffs, double* scratch, int n_spl, i
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool WAVE_ONLY>
 __global__ void __launch_bounds__(512)
 ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  const double* __restrict__ p, const double* __restrict__ x0,
@@ -171,7 +171,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
                                d, kkt_doubles);
-  omgx::CtxT<(MODE != omgx::WS_LDS)> c; c.red = w.red;
+  omgx::CtxT<(MODE != omgx::WS_LDS), WAVE_ONLY> c; c.red = w.red;
 #ifdef OMGX_PROFILE
   __shared__ long long prof_lds[omgx::PH_COUNT];
   c.prof = prof_lds;
@@ -223,12 +223,12 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
                              const int32_t*, StoreArgs, int);
-static ipm_kernel_t ipm_kernel_for(int mode) {
+static ipm_kernel_t ipm_kernel_for(int mode, int wave_ok) {
   switch (mode) {
-    case omgx::WS_LDS: return ipm_solve_kernel<omgx::WS_LDS>;
-    case omgx::WS_KKT_HBM: return ipm_solve_kernel<omgx::WS_KKT_HBM>;
-    case omgx::WS_JAC_HBM: return ipm_solve_kernel<omgx::WS_JAC_HBM>;
-    default: return ipm_solve_kernel<omgx::WS_ROWS_HBM>;
+    case omgx::WS_LDS: return wave_ok ? ipm_solve_kernel<omgx::WS_LDS, true> : ipm_solve_kernel<omgx::WS_LDS, false>;
+    case omgx::WS_KKT_HBM: return ipm_solve_kernel<omgx::WS_KKT_HBM, false>;
+    case omgx::WS_JAC_HBM: return ipm_solve_kernel<omgx::WS_JAC_HBM, false>;
+    default: return ipm_solve_kernel<omgx::WS_ROWS_HBM, false>;
   }
 }
 
@@ -482,6 +482,11 @@ struct omgx_batch {
   double *d_p = nullptr, *d_x0 = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_x = nullptr, *d_lam = nullptr;
   int32_t *d_status = nullptr, *d_iters = nullptr;
   long long* d_prof = nullptr;
+  // shift tables (entries + T matrices) live in the handle: uploaded when they change (a receding-horizon loop
+  // passes the same ones at every knot crossing), so that a shift is one stream-ordered launch
+  std::vector<int32_t> shift_ent_host; std::vector<double> shift_T_host;
+  int32_t* d_shift_ent = nullptr; double* d_shift_T = nullptr; size_t shift_ent_cap = 0, shift_T_cap = 0;
+  uint8_t* d_mask = nullptr;
 };
 
 namespace {
@@ -732,8 +737,12 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
       hipEventCreate(&b->ev1) != hipSuccess) { g_err = "stream/event creation failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
   b->stream = b->own_stream;
   if (hipMemset(b->d_dw, 0, (size_t)n_agents * sizeof(double)) != hipSuccess) { g_err = "hipMemset failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
-  if (hipFuncSetAttribute((const void*)ipm_kernel_for(b->ws_mode), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)b->lds_bytes) != hipSuccess) {
+  // (the attribute belongs to the kernel, not to the handle: keep the largest request of the process)
+  static int lds_reserved[2 * omgx::WS_MODES] = {0};
+  int& reserved = lds_reserved[2 * b->ws_mode + (b->dims.wave_ok ? 1 : 0)];
+  if ((int)b->lds_bytes > reserved) reserved = (int)b->lds_bytes;
+  if (hipFuncSetAttribute((const void*)ipm_kernel_for(b->ws_mode, b->dims.wave_ok), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          reserved) != hipSuccess) {
     g_err = "cannot reserve dynamic LDS for ipm_solve_kernel"; omgx_batch_destroy(b); return OMGX_E_HIP;
   }
   if (b->ws_mode != omgx::WS_LDS) {
@@ -755,6 +764,9 @@ void omgx_batch_destroy(omgx_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
+  if (b->d_shift_ent) (void)hipFree(b->d_shift_ent);
+  if (b->d_shift_T) (void)hipFree(b->d_shift_T);
+  if (b->d_mask) (void)hipFree(b->d_mask);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
@@ -832,7 +844,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
     klb = b->d_lb; kub = b->d_ub;
   }
   HIPCHK(hipEventRecord(b->ev0, b->stream));
-  hipLaunchKernelGGL(ipm_kernel_for(b->ws_mode), dim3(b->n_slabs), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev,
+  hipLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok), dim3(b->n_slabs), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev,
                      b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
                      b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, b->store, (flags & OMGX_ONLY_FAILED) ? 1 : 0);
   HIPCHK(hipGetLastError());
@@ -871,47 +883,80 @@ int omgx_batch_last_kernel_ms(omgx_batch* b, double* ms) {
   return OMGX_OK;
 }
 
+namespace {
+// entries / T matrices of a shift into the handle's device buffers (no-op when unchanged); max_elems: LDS doubles
+int stage_shift_tables(omgx_batch* b, const int32_t* entries, int32_t n_ent, const double* Tmats, int32_t n_tmat,
+                       int limit, int* max_elems) {
+  *max_elems = 0;
+  for (int e = 0; e < n_ent; ++e) {
+    const int32_t* q = entries + 4 * e;
+    if (q[0] < 0 || q[1] <= 0 || q[2] <= 0 || q[3] < 0 || q[0] + q[1] * q[2] > limit || q[3] + q[1] * q[1] > n_tmat) {
+      g_err = "shift entry outside the array / the matrices"; return OMGX_E_INVALID;
+    }
+    if (q[1] * q[2] > *max_elems) *max_elems = q[1] * q[2];
+  }
+  const size_t ne = 4 * (size_t)n_ent, nt = (size_t)n_tmat;
+  const bool same = b->shift_ent_host.size() == ne && b->shift_T_host.size() == nt &&
+                    memcmp(b->shift_ent_host.data(), entries, ne * sizeof(int32_t)) == 0 &&
+                    memcmp(b->shift_T_host.data(), Tmats, nt * sizeof(double)) == 0;
+  if (same) return OMGX_OK;
+  // (stream order: kernels of earlier shifts read the old tables; they are done before these copies start)
+  if (ne > b->shift_ent_cap) {
+    if (b->d_shift_ent) (void)hipFree(b->d_shift_ent);
+    b->d_shift_ent = nullptr; b->shift_ent_cap = 0;
+    HIPCHK(hipMalloc((void**)&b->d_shift_ent, ne * sizeof(int32_t)));
+    b->shift_ent_cap = ne;
+  }
+  if (nt > b->shift_T_cap) {
+    if (b->d_shift_T) (void)hipFree(b->d_shift_T);
+    b->d_shift_T = nullptr; b->shift_T_cap = 0;
+    HIPCHK(hipMalloc((void**)&b->d_shift_T, nt * sizeof(double)));
+    b->shift_T_cap = nt;
+  }
+  b->shift_ent_host.assign(entries, entries + ne);
+  b->shift_T_host.assign(Tmats, Tmats + nt);
+  HIPCHK(hipMemcpyAsync(b->d_shift_ent, b->shift_ent_host.data(), ne * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_shift_T, b->shift_T_host.data(), nt * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  return OMGX_OK;
+}
+}  // namespace
+
 int omgx_batch_shift(omgx_batch* b, double* x, const uint8_t* mask, const int32_t* entries, int32_t n_ent,
                      const double* Tmats, int32_t n_tmat, int32_t flags) {
-  if (!b || !x || !entries || !Tmats || n_ent <= 0) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  if (!b || !x || !entries || !Tmats || n_ent <= 0 || n_tmat <= 0) { g_err = "bad argument"; return OMGX_E_INVALID; }
   HIPCHK(hipSetDevice(b->device));
   const omgx::Dims& d = b->dims;
   const int B = b->n_agents;
   const bool dev = flags & OMGX_PTR_DEVICE;
-  int32_t* d_ent = nullptr; double* d_T = nullptr; uint8_t* d_mask = nullptr; double* d_xx = x;
   int max_elems = 0;
-  for (int e = 0; e < n_ent; ++e) {
-    const int sz = entries[4 * e + 1] * entries[4 * e + 2];
-    if (sz > max_elems) max_elems = sz;
-  }
-  HIPCHK(hipMalloc((void**)&d_ent, 4 * n_ent * sizeof(int32_t)));
-  HIPCHK(hipMalloc((void**)&d_T, n_tmat * sizeof(double)));
-  HIPCHK(hipMemcpyAsync(d_ent, entries, 4 * n_ent * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(d_T, Tmats, n_tmat * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  int rc = stage_shift_tables(b, entries, n_ent, Tmats, n_tmat, d.n_var, &max_elems);
+  if (rc != OMGX_OK) return rc;
+  const uint8_t* d_mask = mask; double* d_xx = x;
   if (!dev) {
     HIPCHK(hipMemcpyAsync(b->d_x, x, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream));
     d_xx = b->d_x;
     if (mask) {
-      HIPCHK(hipMalloc((void**)&d_mask, B));
-      HIPCHK(hipMemcpyAsync(d_mask, mask, B, hipMemcpyHostToDevice, b->stream));
+      if (!b->d_mask) HIPCHK(hipMalloc((void**)&b->d_mask, B));
+      HIPCHK(hipMemcpyAsync(b->d_mask, mask, B, hipMemcpyHostToDevice, b->stream));
+      d_mask = b->d_mask;
     }
-  } else {
-    d_mask = (uint8_t*)mask;
   }
   hipLaunchKernelGGL(shift_kernel, dim3(B), dim3(64), max_elems * sizeof(double), b->stream, d_xx, d.n_var,
-                     d_mask, d_ent, n_ent, d_T);
+                     d_mask, b->d_shift_ent, n_ent, b->d_shift_T);
   HIPCHK(hipGetLastError());
-  if (!dev) HIPCHK(hipMemcpyAsync(x, b->d_x, (size_t)B * d.n_var * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));
-  (void)hipFree(d_ent); (void)hipFree(d_T);
-  if (!dev && d_mask) (void)hipFree(d_mask);
-  return OMGX_OK;
+  if (!dev) {
+    HIPCHK(hipMemcpyAsync(x, b->d_x, (size_t)B * d.n_var * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+  }
+  return OMGX_OK;      // device pointers: stream-ordered, no host synchronisation
 }
 
 int omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off, int32_t n_spl, int32_t degree,
                       const double* knots, int32_t n_knots, int32_t n_der, const double* t0, double dt,
                       int32_t n_samp, void* out, int32_t as_f32, int32_t flags) {
-  if (!b || !x || !knots || !t0 || !out || degree > 5 || n_der > degree + 1 || n_samp <= 0) {
+  if (!b || !x || !knots || !t0 || !out || degree < 0 || degree > 5 || n_der < 1 || n_der > degree + 1 || n_samp <= 0 ||
+      n_spl <= 0 || n_knots < 2 * (degree + 1) || n_knots > 40 || coeff_off < 0 ||
+      coeff_off + n_spl * (n_knots - degree - 1) > b->dims.n_var) {
     g_err = "bad argument"; return OMGX_E_INVALID;
   }
   HIPCHK(hipSetDevice(b->device));
@@ -923,12 +968,18 @@ int omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off, int32_t
   KnotArg kn;
   for (int i = 0; i < 40; ++i) kn.k[i] = i < n_knots ? knots[i] : 0.0;
   double* d_t0 = nullptr; void* d_out = out; const double* d_xx = x;
+  struct DevTmp {                                   // temporaries of the host-pointer path: freed on every way out
+    void* p[2] = {nullptr, nullptr};
+    ~DevTmp() { for (void* q : p) if (q) (void)hipFree(q); }
+  } tmp;
   if (!dev) {
     HIPCHK(hipMemcpyAsync(b->d_x, x, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream));
     d_xx = b->d_x;
     HIPCHK(hipMalloc((void**)&d_t0, B * sizeof(double)));
+    tmp.p[0] = d_t0;
     HIPCHK(hipMemcpyAsync(d_t0, t0, B * sizeof(double), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMalloc(&d_out, out_elems * esz));
+    tmp.p[1] = d_out;
   } else {
     d_t0 = (double*)t0;
   }
@@ -946,7 +997,6 @@ int omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off, int32_t
   if (!dev) {
     HIPCHK(hipMemcpyAsync(out, d_out, out_elems * esz, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
-    (void)hipFree(d_out); (void)hipFree(d_t0);
   }
   return OMGX_OK;      // device pointers: stream-ordered, the caller synchronises (omgx_batch_sync)
 }
@@ -1068,24 +1118,15 @@ int omgx_admm_communicate(omgx_batch* b, const omgx_admm_layout* lay, const int3
 
 int omgx_shift_rows(omgx_batch* b, double* data, int32_t stride, int32_t n_rows, const uint8_t* mask,
                     const int32_t* entries, int32_t n_ent, const double* Tmats, int32_t n_tmat) {
-  // device-pointer variant of omgx_batch_shift for arbitrary row-major arrays (p, z_ij, l_ij ...)
-  if (!b || !data || !entries || !Tmats || n_ent <= 0 || n_rows <= 0) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  // device-pointer variant of omgx_batch_shift for arbitrary row-major arrays (p, z_ij, l_ij ...); stream-ordered
+  if (!b || !data || !entries || !Tmats || n_ent <= 0 || n_rows <= 0 || n_tmat <= 0 || stride <= 0) { g_err = "bad argument"; return OMGX_E_INVALID; }
   HIPCHK(hipSetDevice(b->device));
-  int32_t* d_ent = nullptr; double* d_T = nullptr;
   int max_elems = 0;
-  for (int e = 0; e < n_ent; ++e) {
-    const int sz = entries[4 * e + 1] * entries[4 * e + 2];
-    if (sz > max_elems) max_elems = sz;
-  }
-  HIPCHK(hipMalloc((void**)&d_ent, 4 * n_ent * sizeof(int32_t)));
-  HIPCHK(hipMalloc((void**)&d_T, n_tmat * sizeof(double)));
-  HIPCHK(hipMemcpyAsync(d_ent, entries, 4 * n_ent * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(d_T, Tmats, n_tmat * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  int rc = stage_shift_tables(b, entries, n_ent, Tmats, n_tmat, stride, &max_elems);
+  if (rc != OMGX_OK) return rc;
   hipLaunchKernelGGL(shift_kernel, dim3(n_rows), dim3(64), max_elems * sizeof(double), b->stream, data, stride,
-                     mask, d_ent, n_ent, d_T);
+                     mask, b->d_shift_ent, n_ent, b->d_shift_T);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(b->stream));
-  (void)hipFree(d_ent); (void)hipFree(d_T);
   return OMGX_OK;
 }
 

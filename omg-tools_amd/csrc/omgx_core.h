@@ -265,6 +265,7 @@ OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
 // ---------------------------------------------------------------------------
 #ifdef OMGX_HOST_PORT
 struct Ctx {
+  static constexpr bool wave_only = false;
   double* red;
   int tid() const { return 0; }
   int nthr() const { return 1; }
@@ -281,9 +282,12 @@ struct Ctx {
   void wave_sync() const {}
 };
 #else
-template <bool kHbm>
+// kWaveOnly: the kernel instance for templates whose panels all fit one wave (Dims::wave_ok): the blocked LDS
+// routines are not compiled into it
+template <bool kHbm, bool kWaveOnly = false>
 struct CtxT {
   static constexpr bool hbm = kHbm;
+  static constexpr bool wave_only = kWaveOnly;
   double* red;
   long long* prof;
   __device__ int tid() const { return threadIdx.x; }
@@ -1420,11 +1424,12 @@ OMGX_FN void kkt_solve_wave(const C& c, const Dims& d, const Kkt& K, Work& w, do
 template <class C>
 OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
 #ifndef OMGX_HOST_PORT
-  if (d.wave_ok) return kkt_factor_wave(c, d, K, w);
+  if (C::wave_only || d.wave_ok) return kkt_factor_wave(c, d, K, w);
 #ifdef OMGX_WAVE_GENERAL
   if (d.wave_leaf) return kkt_factor_wave_general(c, d, K, w);
 #endif
 #endif
+  if constexpr (C::wave_only) return 1; else {
   int bad = 0;
   OMGX_TIC();
   BMat* Ms = (BMat*)w.col;
@@ -1522,6 +1527,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   if (bad) ++omgx_dbg_cnt[1];
 #endif
   return bad;
+  }
 }
 
 // Unit-lower triangular solves in blocks of 4 columns, executed by ONE wave (lanes = rows): every
@@ -1595,8 +1601,9 @@ OMGX_FN void trsv_bwd4(const C& c, const double* A, Addr L, int n, double* y, co
 template <class C>
 OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double* sol) {
 #ifndef OMGX_HOST_PORT
-  if (d.wave_ok) { kkt_solve_wave(c, d, K, w, sol); return; }
+  if (C::wave_only || d.wave_ok) { kkt_solve_wave(c, d, K, w, sol); return; }
 #endif
+  if constexpr (!C::wave_only) {
   double* yr = sol + d.root_off;
   // leaf dimensions from the matrix descriptors kkt_factor left in LDS (not from the global plan
   // tables: every look-up there is a dependent global load)
@@ -1647,6 +1654,7 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
   }
   c.sync();
   OMGX_TOC(PH_K_BWD);
+  }
 }
 
 // Right-hand side of the Newton system into the carried rows of the block-arrow store (after the
