@@ -30,6 +30,10 @@
 #define OMGX_HD __host__ __device__ inline
 #endif
 
+#ifdef OMGX_HOST_PORT
+#include <vector>
+static thread_local std::vector<double> omgx_rbak;      // root block before its factorisation (host twin of the wave path)
+#endif
 #ifdef OMGX_COUNT_FACT
 #include <atomic>
 static std::atomic<long> omgx_dbg_nfact(0);
@@ -1247,7 +1251,22 @@ OMGX_FN int kkt_factor_wave(const C& c, const Dims& d, const Kkt& K, Work& w) {
     if (c.tid() == 0) c.prof[PH_F_SWEEP] += clock64() - tr0_;      // raw root time
 #endif
   }
-  const int bad = c.rmax(badr ? 1.0 : 0.0) > 0.0 ? 1 : 0;
+  const int bad = c.rmax(badr ? 1.0 : 0.0) > 0.0 ? 2 : 0;       // 2: the leaves are fine, the root has the wrong inertia
+  OMGX_TOC(PH_F_ROOT);
+  return bad;
+}
+
+// Root block alone once more (its diagonal was changed in place): wave_ldl stores nothing when a pivot has the
+// wrong sign, so after a failed attempt the store still holds the root as the Schur complements left it and
+// the leaf factors stay valid.
+template <class C>
+OMGX_FN int kkt_refactor_root_wave(const C& c, const Dims& d, const Kkt& K, Work& w) {
+  const BMat* Ms = (const BMat*)w.col;
+  const int koff = (int)(w.kkt - omgx_lds);
+  OMGX_TIC();
+  int badr = 0;
+  if (c.wave() == 0) badr = wave_ldl<OMGX_WAVE_COLS, OMGX_WAVE_COLS>(koff, wpanel_root(Ms[d.n_leaf], d.n_root));
+  const int bad = c.rmax(badr ? 1.0 : 0.0) > 0.0 ? 2 : 0;
   OMGX_TOC(PH_F_ROOT);
   return bad;
 }
@@ -1521,13 +1540,42 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   // with the one-barrier left-looking sweep
   // (the cooperative routine was tried for the root as well -- one row wave + one block wave: 31 k against
   // 43 k cycles standalone, but 1.5 % slower inside the fused kernel in an A/B of three bench runs each)
+#ifdef OMGX_HOST_PORT
+  // the host twin of "a failed root factorisation leaves the store untouched" (kkt_refactor_root): keep a copy
+  if (d.wave_ok) omgx_rbak.assign(R, R + ((size_t)(d.nr + 1) * (d.nr + 2)) / 2);
+#endif
   ldl_blocked<2>(c, Ms + d.n_leaf, 1, w.kkt, w.dinv, w.col, stage, &bad);
   OMGX_TOC(PH_F_ROOT);
 #ifdef OMGX_COUNT_FACT
   if (bad) ++omgx_dbg_cnt[1];
 #endif
-  return bad;
+  return bad ? 2 : 0;
   }
+}
+
+// The root block once more after its diagonal was changed (inertia correction of the root variables only: the
+// leaf factors and the Schur complements stay).  Device: wave path only.  Host: from the copy taken before the
+// failed attempt.
+template <class C>
+OMGX_FN void kkt_root_before_retry(const C& c, const Dims& d, const Kkt& K, Work& w) {
+#ifdef OMGX_HOST_PORT
+  double* R = K.R();
+  for (size_t i = 0; i < omgx_rbak.size(); ++i) R[i] = omgx_rbak[i];
+#endif
+}
+template <class C>
+OMGX_FN int kkt_refactor_root(const C& c, const Dims& d, const Kkt& K, Work& w) {
+#ifndef OMGX_HOST_PORT
+  return kkt_refactor_root_wave(c, d, K, w);
+#else
+  int bad = 0;
+  BMat* Ms = (BMat*)w.col;
+  double* stage = w.col + OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1);
+  double* R = K.R();
+  omgx_rbak.assign(R, R + ((size_t)(d.nr + 1) * (d.nr + 2)) / 2);
+  ldl_blocked<2>(c, Ms + d.n_leaf, 1, w.kkt, w.dinv, w.col, stage, &bad);
+  return bad ? 2 : 0;
+#endif
 }
 
 // Unit-lower triangular solves in blocks of 4 columns, executed by ONE wave (lanes = rows): every
@@ -2102,7 +2150,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
       if (c.tid() == 0) c.prof[PH_ASSEMBLE] = c.prof[PH_A_ZERO] + c.prof[PH_A_PAIRS] + c.prof[PH_A_TCOL] + c.prof[PH_A_HESS] + c.prof[PH_A_REST] + c.prof[PH_A_DIAG];
 #endif
-      const int bad = kkt_factor(c, d, K, w);
+      int bad = kkt_factor(c, d, K, w);
 #ifdef OMGX_COUNT_FACT
       ++omgx_dbg_nfact;
       if (first_trial) ++omgx_dbg_cnt[4];
@@ -2114,6 +2162,53 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       OMGX_TOC(PH_FACTOR);
       first_trial = 0;
       if (!bad) { if (decreasing) dw_backoff = 1; break; }
+      if (bad == 2 && d.wave_ok && warm) {
+        // The leaves are positive definite at this dw and their Schur complements are in the root, which alone
+        // has the wrong inertia: raise the inertia correction of the root variables only (with positive definite
+        // leaves a large enough one always works) and factorise the root again -- no reassembly, no leaf
+        // factorisation (the failed attempt left the store untouched).  The leaves keep the smaller value for
+        // this iteration; the next one starts from the root's value on both.  (Tried and dropped: separate
+        // tracking of a leaf and a root value -- the leaf value then decays to zero, fails there and pays full
+        // retries: 1.14 instead of 1.00 full factorisations per cold iteration, and four instead of two of
+        // 1024 cold solves fail.)  Warm starts only: on cold solves the same rule saves 13 % of the cycles per
+        // iteration but sends 2 of 1024 agents of config 2 into a phase-I stall that the plain rule avoids, and
+        // their restart costs more than was saved (cold solve of the batch 69 ms instead of 15.7 ms).
+        double dwr = dw;
+        for (;;) {
+          const double dw_prev_try = dwr;
+          if (decreasing) {          // back to the last value that worked, try less often
+            decreasing = 0; dwr = dw_last;
+            dw_backoff = dw_backoff < OMGX_DW_BACKOFF_MAX ? 2 * dw_backoff : OMGX_DW_BACKOFF_MAX;
+            dw_hold = dw_backoff;
+          } else {
+            dwr = (dwr == 0.0) ? OMGX_DW_FIRST : dwr * OMGX_DW_INC;
+          }
+          if (dwr > OMGX_DW_MAX) { failed = 1; break; }
+          c.sync();
+          kkt_root_before_retry(c, d, K, w);
+          OMGX_PFOR(k, d.n_root) {
+            const int q = d.root_off + k;
+            const double wq = T.reg_w[q];
+            const double f = (wq == 1.0 ? reg_root : (wq == -1.0 ? reg_leaf : wq));
+            double a_new = dwr * f, a_old = dw_prev_try * f;
+            if (wq == 1.0 || wq == -1.0) {
+              a_new = fmin(a_new, w.xt[q] + OMGX_DW_CAP_FLOOR * dwr);
+              a_old = fmin(a_old, w.xt[q] + OMGX_DW_CAP_FLOOR * dw_prev_try);
+            }
+            w.kkt[T.diag_addr[q]] += a_new - a_old;
+          }
+          c.sync();
+          bad = kkt_refactor_root(c, d, K, w);
+#ifdef OMGX_COUNT_FACT
+          ++omgx_dbg_cnt[7];
+#endif
+          OMGX_TOC(PH_FACTOR);
+          if (!bad) break;
+        }
+        if (failed) break;
+        dw = dwr;                    // what the next iteration starts from
+        break;
+      }
       if (decreasing) {            // back to the last value that worked, try less often
         decreasing = 0; dw = dw_last;
         dw_backoff = dw_backoff < OMGX_DW_BACKOFF_MAX ? 2 * dw_backoff : OMGX_DW_BACKOFF_MAX;

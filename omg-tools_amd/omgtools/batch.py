@@ -182,6 +182,10 @@ class BatchP2P(object):
         at mid-course -- a different side of the obstacles; the reference has no such retry (its user would
         re-initialise by hand), `bends=()` switches it off.  Returns the number of restart passes."""
         self._solve(False)
+        return self.restart_failed(bends)
+
+    def restart_failed(self, bends=(1.0, -1.0, 2.5, -2.5)):
+        """Restart passes of a cold solve (see solve_cold); returns how many were needed."""
         passes = 0
         if self.kind != 'hip' or not bends:
             return passes

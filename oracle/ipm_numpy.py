@@ -417,17 +417,59 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             dw = dw_last * o['dw_dec']
             decreasing = True
         tries = 0
-        while True:
+        lv = np.asarray(getattr(nlp, 'leaf_vars', []), dtype=np.int64)
+        # (warm starts only, like the kernel)
+        root_retry = o.get('root_retry', bool(getattr(nlp, 'wave_ok', False)) and z0 is not None) and len(lv) > 0
+        is_root = np.ones(N, bool)
+        is_root[lv] = False
+
+        def shift(dw_vec):
+            return np.where(nl, np.minimum(dw_vec * reg, gersh + o['dw_cap_floor'] * dw_vec), dw_vec * reg)
+
+        def factor(dw_vec):
             K = np.zeros((N + mE, N + mE))
-            K[:N, :N] = M + np.diag(np.where(nl, np.minimum(dw * reg, gersh + o['dw_cap_floor'] * dw), dw * reg))
+            K[:N, :N] = M + np.diag(shift(dw_vec))
             K[N:, :N] = Je
             K[:N, N:] = Je.T
             K[N:, N:] = -o['delta_c'] * np.eye(mE)
             L, d = ldl_nopivot(K)
+            return K, L, d, bool(np.all(d[:N] > 0) and np.all(d[N:] < 0))
+        while True:
+            K, L, d, ok = factor(np.full(N, dw))
             nfact += 1
-            if np.all(d[:N] > 0) and np.all(d[N:] < 0):
+            if ok:
                 if decreasing:
                     dw_backoff = 1
+                break
+            leaves_pd = False
+            if root_retry:
+                try:
+                    np.linalg.cholesky(K[np.ix_(lv, lv)])
+                    leaves_pd = True
+                except np.linalg.LinAlgError:
+                    leaves_pd = False
+            if leaves_pd:
+                # (omgx_core.h: the leaf blocks are positive definite at this dw, the root alone has the wrong
+                # inertia: raise the inertia correction of the root variables only)
+                dwr = dw
+                while True:
+                    if decreasing:
+                        decreasing = False
+                        dwr = dw_last
+                        dw_backoff = min(2 * dw_backoff, o.get('dw_backoff_max', 8))
+                        dw_hold = dw_backoff
+                    else:
+                        dwr = o['dw_first'] if dwr == 0.0 else dwr * o['dw_inc']
+                    if dwr > o['dw_max']:
+                        status = 4
+                        break
+                    K, L, d, ok = factor(np.where(is_root, dwr, dw))
+                    nfact += 1
+                    if ok:
+                        break
+                if status == 4:
+                    break
+                dw = dwr
                 break
             if decreasing:
                 decreasing = False

@@ -147,6 +147,11 @@ class SolverPlan(object):
         self.cpl_ptr = np.cumsum([0] + [len(c) for c in cpl]).astype(np.int32)
         self.cpl_idx = np.array([i for c in cpl for i in c], dtype=np.int32)
         # root-local index -> row in B_l (or -1), flattened [n_leaf, n_root]
+        # csrc/omgx_plan.h `wave_ok`: every panel fits one wave -- the solver then answers a root block of the wrong
+        # inertia by raising the inertia correction of the root variables only
+        nr = self.n_root + self.n_eq
+        self.wave_ok = nr <= 40 and all(len(leaf) <= 40 and len(leaf) + len(c) - 1 <= 64 and len(c) + 1 <= 32
+                                        for leaf, c in zip(self.leaves, cpl))
         self.cpl_map = -np.ones((max(self.n_leaf, 1), self.n_root), dtype=np.int32)
         for l, c in enumerate(cpl):
             self.cpl_map[l, c] = np.arange(len(c))
