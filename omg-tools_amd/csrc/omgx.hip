@@ -166,7 +166,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  double* __restrict__ x, double* __restrict__ lam, int32_t* __restrict__ status,
                  int32_t* __restrict__ iters, int n_agents, long long* __restrict__ prof,
                  double* __restrict__ slabs, size_t slab_doubles, double* __restrict__ dw_state,
-                 const int32_t* __restrict__ order, StoreArgs st, int only_failed) {
+                 const int32_t* __restrict__ order, const StoreArgs* __restrict__ stp, int only_failed) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
@@ -202,9 +202,12 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
       lam[(size_t)b * d.n_con + q] =
           (r.status == 3 || w.rtype[q] == omgx::ROW_FREE) ? 0.0 : w.rho[q] * w.z[q];
     if (threadIdx.x == 0) { status[b] = r.status; iters[b] = r.iters; dw_state[b] = r.dw; }
-    if (st.out) {
+    if (stp) {
       // `Vehicle.store` fused behind the solve (reference `vehicles/vehicle.py:250-300`): the trajectories of
       // this agent straight from the solution in LDS; the KKT store is free now and serves as scratch
+      // (the specification sits in device memory: as a by-value kernel argument its 90 dwords would be kept in
+      // scalar registers across the whole solve)
+      const StoreArgs st = *stp;
       __syncthreads();
       sample_agent<double>(w.x + st.coeff_off, w.kkt, st.n_spl, st.degree, st.knots, st.n_knots, st.n_der, st.t0[b],
                            st.dt, st.inv_T, st.n_samp, 0, st.n_samp, st.out + (size_t)b * st.n_der * st.n_spl * st.n_samp,
@@ -222,7 +225,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
-                             const int32_t*, StoreArgs, int);
+                             const int32_t*, const StoreArgs*, int);
 static ipm_kernel_t ipm_kernel_for(int mode, int wave_ok) {
   switch (mode) {
     case omgx::WS_LDS: return wave_ok ? ipm_solve_kernel<omgx::WS_LDS, true> : ipm_solve_kernel<omgx::WS_LDS, false>;
@@ -474,6 +477,7 @@ struct omgx_batch {
   double* d_dw = nullptr;          // per-agent inertia correction carried between warm-started solves
   const int32_t* d_order = nullptr; // optional launch order (device pointer owned by the caller)
   StoreArgs store = {};             // trajectories written by the solve kernel (omgx_batch_set_store); out == nullptr: off
+  StoreArgs* d_store = nullptr;     // its copy in device memory (what the kernel reads)
   std::vector<void*> allocs;
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -764,6 +768,7 @@ void omgx_batch_destroy(omgx_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
+  if (b->d_store) (void)hipFree(b->d_store);
   if (b->d_shift_ent) (void)hipFree(b->d_shift_ent);
   if (b->d_shift_T) (void)hipFree(b->d_shift_T);
   if (b->d_mask) (void)hipFree(b->d_mask);
@@ -846,7 +851,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   HIPCHK(hipEventRecord(b->ev0, b->stream));
   hipLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok), dim3(b->n_slabs), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev,
                      b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
-                     b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, b->store, (flags & OMGX_ONLY_FAILED) ? 1 : 0);
+                     b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, b->store.out ? b->d_store : nullptr, (flags & OMGX_ONLY_FAILED) ? 1 : 0);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   b->timed = true;
@@ -902,7 +907,8 @@ int stage_shift_tables(omgx_batch* b, const int32_t* entries, int32_t n_ent, con
   if (same) return OMGX_OK;
   // (stream order: kernels of earlier shifts read the old tables; they are done before these copies start)
   if (ne > b->shift_ent_cap) {
-    if (b->d_shift_ent) (void)hipFree(b->d_shift_ent);
+    if (b->d_store) (void)hipFree(b->d_store);
+  if (b->d_shift_ent) (void)hipFree(b->d_shift_ent);
     b->d_shift_ent = nullptr; b->shift_ent_cap = 0;
     HIPCHK(hipMalloc((void**)&b->d_shift_ent, ne * sizeof(int32_t)));
     b->shift_ent_cap = ne;
@@ -1035,13 +1041,16 @@ int omgx_batch_store(omgx_batch* b, const double* x, const omgx_store_spec* sp) 
 int omgx_batch_set_store(omgx_batch* b, const omgx_store_spec* sp) {
   if (!b) { g_err = "null handle"; return OMGX_E_INVALID; }
   if (!sp) { b->store = StoreArgs{}; return OMGX_OK; }
+  HIPCHK(hipSetDevice(b->device));
   StoreArgs st;
   int rc = fill_store(b, sp, &st);
   if (rc != OMGX_OK) return rc;
   if (sample_scratch_doubles(st.n_spl, st.degree, st.n_knots, st.n_der) > (size_t)b->kkt_doubles) {
     g_err = "store: the per-agent scratch does not fit the KKT store"; return OMGX_E_TOOLARGE;
   }
+  if (!b->d_store) HIPCHK(hipMalloc((void**)&b->d_store, sizeof(StoreArgs)));
   b->store = st;
+  HIPCHK(hipMemcpyAsync(b->d_store, &b->store, sizeof(StoreArgs), hipMemcpyHostToDevice, b->stream));
   return OMGX_OK;
 }
 

@@ -294,7 +294,10 @@ struct CtxT {
   static constexpr bool wave_only = kWaveOnly;
   double* red;
   long long* prof;
-  __device__ int tid() const { return threadIdx.x; }
+  // (opaque to the optimiser: otherwise every per-thread table address `base + tid * size` of every phase is
+  // computed once at kernel entry, kept alive across the whole solve and -- at the 256-register cap -- spilled to
+  // scratch memory and reloaded from there in every iteration)
+  __device__ int tid() const { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
   __device__ int nthr() const { return blockDim.x; }
   __device__ void sync() const { __syncthreads(); }
   template <int OP> __device__ double reduce(double v) const {
@@ -665,23 +668,33 @@ OMGX_FN void row_jac(const Tables& T, Work& w, int r, const double* xv) {
 OMGX_FN int tri(int i, int k) { return i * (i + 1) / 2 + k; }   // packed lower, row-major, i >= k
 
 struct Kkt {
-  const Dims* d; const Tables* T; double* a;
+  // (copies of the few table pointers / dimensions it needs, not pointers to the structs: a struct whose address
+  // escapes into a helper object cannot be kept in scalar registers -- the compiler copied all of Dims and
+  // Tables into every lane's scratch memory at kernel entry)
+  const int32_t *d_off, *b_off, *leaf_off, *leaf_bw, *cpl_ptr, *cpl_idx, *blk, *cpl_map;
+  int n_leaf, n_root, root_off;
+  double* a;
+  OMGX_FN void bind(const Dims& dd, const Tables& TT, double* store) {
+    d_off = TT.d_off; b_off = TT.b_off; leaf_off = TT.leaf_off; leaf_bw = TT.leaf_bw; cpl_ptr = TT.cpl_ptr;
+    cpl_idx = TT.cpl_idx; blk = TT.blk; cpl_map = TT.cpl_map;
+    n_leaf = dd.n_leaf; n_root = dd.n_root; root_off = dd.root_off; a = store;
+  }
   // leaf l: panel of (n_l + nc_l + 1) rows with odd leading dimension ld_l; rows [0,n_l) hold the
   // leaf block D_l (lower part), rows [n_l, n_l+nc_l) the coupling rows B_l (one per coupled
   // root position), row n_l+nc_l the right-hand side of the leaf.  Root block R: packed lower,
   // row-major, nr rows + one more for its right-hand side.  The right-hand sides are carried through
   // the factorisation like coupling rows, so the forward substitutions L^{-1} r come out of it.
-  OMGX_FN double* P(int l) const { return a + T->d_off[l]; }
-  OMGX_FN int ld(int l) const { return T->b_off[l]; }
-  OMGX_FN double* R() const { return a + T->d_off[d->n_leaf]; }
-  OMGX_FN int nl(int l) const { return T->leaf_off[l + 1] - T->leaf_off[l]; }
-  OMGX_FN int nc(int l) const { return T->cpl_ptr[l + 1] - T->cpl_ptr[l]; }
+  OMGX_FN double* P(int l) const { return a + d_off[l]; }
+  OMGX_FN int ld(int l) const { return b_off[l]; }
+  OMGX_FN double* R() const { return a + d_off[n_leaf]; }
+  OMGX_FN int nl(int l) const { return leaf_off[l + 1] - leaf_off[l]; }
+  OMGX_FN int nc(int l) const { return cpl_ptr[l + 1] - cpl_ptr[l]; }
   // address of entry (p, q), positions with p >= q, p,q < N
   OMGX_FN double* at(int p, int q) const {
-    const int ro = d->root_off;
-    if (p < ro) { const int l = T->blk[p], o = T->leaf_off[l]; return P(l) + (p - o) * ld(l) + (q - o); }
-    if (q < ro) { const int l = T->blk[q]; const int arow = T->cpl_map[l * d->n_root + (p - ro)];
-                  return P(l) + (nl(l) + arow) * ld(l) + (q - T->leaf_off[l]); }
+    const int ro = root_off;
+    if (p < ro) { const int l = blk[p], o = leaf_off[l]; return P(l) + (p - o) * ld(l) + (q - o); }
+    if (q < ro) { const int l = blk[q]; const int arow = cpl_map[l * n_root + (p - ro)];
+                  return P(l) + (nl(l) + arow) * ld(l) + (q - leaf_off[l]); }
     return R() + tri(p - ro, q - ro);
   }
 };
@@ -1135,11 +1148,11 @@ OMGX_FN void kkt_describe(const C& c, const Dims& d, const Kkt& K, Work& w) {
     int pan = pan0;
     for (int l = 0; l < d.n_leaf; ++l) {
       BMat& M = Ms[l];
-      M.a = K.T->d_off[l]; M.ld = K.ld(l); M.nfact = K.nl(l); M.rows = K.nl(l) + K.nc(l) + 1; M.npos = M.nfact;   // + the rhs row
-      M.dinv = K.T->leaf_off[l]; M.pan = pan; pan += OMGX_PAN_LD * M.rows; M.cpl = K.T->cpl_ptr[l]; M.bw = K.T->leaf_bw[l];
+      M.a = K.d_off[l]; M.ld = K.ld(l); M.nfact = K.nl(l); M.rows = K.nl(l) + K.nc(l) + 1; M.npos = M.nfact;   // + the rhs row
+      M.dinv = K.leaf_off[l]; M.pan = pan; pan += OMGX_PAN_LD * M.rows; M.cpl = K.cpl_ptr[l]; M.bw = K.leaf_bw[l];
     }
     BMat& Mr = Ms[d.n_leaf];
-    Mr.a = K.T->d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr + 1; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0; Mr.cpl = 0; Mr.bw = d.nr;
+    Mr.a = K.d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr + 1; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0; Mr.cpl = 0; Mr.bw = d.nr;
   }
   c.sync();
 }
@@ -1200,7 +1213,7 @@ OMGX_FN int kkt_factor_wave(const C& c, const Dims& d, const Kkt& K, Work& w) {
       nc1 = __builtin_amdgcn_readfirstlane(M.rows) - n;            // coupling rows + the right-hand-side row (last)
       const double* Wt = w.kkt + __builtin_amdgcn_readfirstlane(M.a) + n * ld;
       const double* di = w.dinv + __builtin_amdgcn_readfirstlane(M.dinv);
-      const int32_t* ci = K.T->cpl_idx + __builtin_amdgcn_readfirstlane(M.cpl);
+      const int32_t* ci = K.cpl_idx + __builtin_amdgcn_readfirstlane(M.cpl);
       // root positions of this lane's rows / columns (global table: requested before the MFMA loop)
       const int cb0 = lane & 15, cb1 = 16 + (lane & 15);
       ci_b0 = ci[cb0 < nc1 - 1 ? cb0 : 0]; ci_b1 = ci[cb1 < nc1 - 1 ? cb1 : 0];
@@ -1326,7 +1339,7 @@ OMGX_FN int kkt_factor_wave_general(const C& c, const Dims& d, const Kkt& K, Wor
 #pragma unroll
     for (int i = 0; i < 10; ++i) acc[i] = v4d{0.0, 0.0, 0.0, 0.0};
     int nc1 = 0;
-    const int32_t* ci = K.T->cpl_idx;
+    const int32_t* ci = K.cpl_idx;
     if (l < d.n_leaf) {
       const BMat M = Ms[l];
       const int n = __builtin_amdgcn_readfirstlane(M.nfact), ld = __builtin_amdgcn_readfirstlane(M.ld);
@@ -1419,7 +1432,7 @@ OMGX_FN void kkt_solve_wave(const C& c, const Dims& d, const Kkt& K, Work& w, do
     const BMat M = Ms[l];
     const WPanel P = wpanel_uniform(wpanel_leaf(M));
     const int n = P.n, nc = P.nreg + 1 - P.n, ld = P.ld;          // (wave-uniform values: scalar loop bounds)
-    const int32_t* ci = K.T->cpl_idx + __builtin_amdgcn_readfirstlane(M.cpl);
+    const int32_t* ci = K.cpl_idx + __builtin_amdgcn_readfirstlane(M.cpl);
     if (lane < nc) xg[lane] = sol[d.root_off + ci[lane]];
     wave_fence();
     const int j = lane < n ? lane : 0;
@@ -1485,8 +1498,8 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   for (int l = 0; l < d.n_leaf; ++l) {
     const int n = K.nl(l), nc = K.nc(l), ld = K.ld(l);
     const double* Wt = K.P(l) + n * ld;
-    const double* di = w.dinv + K.T->leaf_off[l];
-    const int32_t* ci = K.T->cpl_idx + K.T->cpl_ptr[l];
+    const double* di = w.dinv + K.leaf_off[l];
+    const int32_t* ci = K.cpl_idx + K.cpl_ptr[l];
     // carried rows 0..nc-1 are coupling rows (root position ci[a]), row nc the leaf's right-hand side,
     // which lands in the root's right-hand-side row (index nr):  r_r -= Wt D^{-1} (L^{-1} r_l)
     for (int ai = 0; ai <= nc; ++ai) for (int ak = 0; ak <= ai && ak < nc; ++ak) {
@@ -1507,7 +1520,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
       const int n = M.nfact, nc = M.rows - M.nfact, ld = M.ld;
       const double* Wt = w.kkt + M.a + n * ld;
       const double* di = w.dinv + M.dinv;
-      const int32_t* ci = K.T->cpl_idx + M.cpl;
+      const int32_t* ci = K.cpl_idx + M.cpl;
       const int tn = (nc + 15) >> 4, nwm = c.nwaves() - 1;
       int tile = 0;
       for (int ti = 0; ti < tn; ++ti) for (int tj = 0; tj <= ti; ++tj, ++tile) {
@@ -1686,7 +1699,7 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
     const BMat M = Ms[l];
     const int n = M.nfact, nc = M.rows - 1 - M.nfact, ld = M.ld, j = q - M.dinv;
     const double* Pn = w.kkt + M.a + n * ld + j;
-    const int32_t* ci = K.T->cpl_idx + M.cpl;
+    const int32_t* ci = K.cpl_idx + M.cpl;
     double acc = 0.0;
 #pragma unroll 4
     for (int a = 0; a < nc; ++a) acc += Pn[a * ld] * yr[ci[a]];
@@ -1737,7 +1750,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
                          const double* lam0, int prev_status, int kkt_doubles, double dw_prev = 0.0) {
   const int n = d.n_var, m = d.n_con, N = d.N;
   Result res; res.status = 1; res.iters = 0; res.f = 0; res.mu = o.mu_init; res.t = 0; res.dw = 0;
-  Kkt K; K.d = &d; K.T = &T; K.a = w.kkt;
+  Kkt K; K.bind(d, T, w.kkt);
   OMGX_TIC();
   kkt_describe(c, d, K, w);
   OMGX_TOC(PH_S_DESC);

@@ -42,11 +42,37 @@ def main():
     hbm = (fetch['mean_kb_per_launch'] + write['mean_kb_per_launch']) * 1024.0
     json.dump({'FETCH_SIZE': fetch, 'WRITE_SIZE': write, 'hbm_bytes_per_launch': hbm,
                'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes '
-                       '(python bench.py --steps 5 --warmup 1 --no-cpu: 3 cold solves + 6 receding-horizon '
-                       'steps), kernel ipm_solve_kernel<0>, 1024 agents; counter unit KB; mean over those launches.'},
+                       '(python bench.py --no-cpu --no-extras --steps 5 --warmup 1: 4 cold solves + 6 receding-horizon '
+                       'steps), kernel ipm_solve_kernel<0, true>, 1024 agents; counter unit KB; mean over those launches.'},
               open(os.path.join(out, '%s_pmc_hbm.json' % tag), 'w'), indent=1)
+    # further counter passes: mean per launch of every counter, cold launches (the first 4) and warm ones apart
+    def multi(sub, names):
+        path = newest(os.path.join(PROF, sub, '*', '*_counter_collection.csv'))
+        per = {n: [] for n in names}
+        for row in csv.DictReader(open(path)):
+            if 'ipm_solve_kernel' in row['Kernel_Name'] and row['Counter_Name'] in per:
+                per[row['Counter_Name']].append(float(row['Counter_Value']))
+        return {n: {'launches': len(v), 'mean_cold': sum(v[:4]) / max(1, len(v[:4])),
+                    'mean_warm': sum(v[4:]) / max(1, len(v[4:]))} for n, v in per.items()}
+    mf = multi('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CU_CYCLES', 'SQ_INSTS_VALU_MFMA_MOPS_F64'])
+    for k in ('mean_cold', 'mean_warm'):
+        mf['mfma_busy_over_cu_busy_' + k[5:]] = mf['SQ_VALU_MFMA_BUSY_CYCLES'][k] / max(1.0, mf['SQ_BUSY_CU_CYCLES'][k])
+    mf['note'] = ('rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 -- python bench.py '
+                  '--no-cpu --no-extras --steps 5 --warmup 1; launches 0-3 are the cold solves of the batch, the rest '
+                  'receding-horizon steps; 1024 agents')
+    json.dump(mf, open(os.path.join(out, '%s_pmc_mfma.json' % tag), 'w'), indent=1)
+    lw = multi('lds', ['SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_INSTS_LDS'])
+    lw.update(multi('wait', ['SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_WAVE_CYCLES']))
+    for k in ('mean_cold', 'mean_warm'):
+        lw['wait_any_over_wave_cycles_' + k[5:]] = lw['SQ_WAIT_ANY'][k] / max(1.0, lw['SQ_WAVE_CYCLES'][k])
+        lw['active_inst_over_wave_cycles_' + k[5:]] = lw['SQ_ACTIVE_INST_ANY'][k] / max(1.0, lw['SQ_WAVE_CYCLES'][k])
+        lw['bank_conflict_over_lds_active_' + k[5:]] = lw['SQ_LDS_BANK_CONFLICT'][k] / max(1.0, lw['SQ_LDS_IDX_ACTIVE'][k])
+    lw['note'] = 'two separate rocprofv3 --pmc passes (LDS counters; wave wait / issue split), same command as the MFMA pass'
+    json.dump(lw, open(os.path.join(out, '%s_pmc_lds_wait.json' % tag), 'w'), indent=1)
     print('kernel stats:', rows[1][0][:40], rows[1][1:4])
     print('HBM bytes / launch:', hbm)
+    print('MFMA busy / CU busy: cold %.3f warm %.3f' % (mf['mfma_busy_over_cu_busy_cold'], mf['mfma_busy_over_cu_busy_warm']))
+    print('wait / wave cycles: cold %.3f warm %.3f' % (lw['wait_any_over_wave_cycles_cold'], lw['wait_any_over_wave_cycles_warm']))
 
 
 if __name__ == '__main__':
