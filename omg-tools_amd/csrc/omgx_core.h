@@ -164,6 +164,7 @@ struct Opts {
 #define OMGX_TAU_MIN     0.99
 #define OMGX_DELTA_C     1e-8
 #define OMGX_ETA         1e-4
+#define OMGX_PHI_NOISE   1e-10   // predicted merit decrease (relative) below which the Armijo test is skipped
 #define OMGX_DW_FIRST    1e-4
 #define OMGX_DW_INC      10.0
 #define OMGX_DW_DEC      (1.0 / 3.0)
@@ -172,6 +173,8 @@ struct Opts {
 #define OMGX_DW_HEAVY    10.0
 #define OMGX_KAPPA_EPS_HEAVY 100.0
 #define OMGX_DW_BACKOFF_MAX 8
+#define OMGX_LS_RETRY    3       // line-search failures in a row that are answered by a heavier inertia correction
+#define OMGX_LS_RETRY_DW 100.0
 #define OMGX_DW_CAP_FLOOR 0.03  // share of dw every nonlinear variable keeps under the Gershgorin cap
 #define OMGX_DW_LINEAR   1e-8   // relative inertia correction of variables that only appear linearly
 #define OMGX_S_MAX       100.0
@@ -300,28 +303,46 @@ struct CtxT {
   __device__ int tid() const { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
   __device__ int nthr() const { return blockDim.x; }
   __device__ void sync() const { __syncthreads(); }
-  template <int OP> __device__ double reduce(double v) const {
-    for (int off = 32; off > 0; off >>= 1) {
-      double o = __shfl_down(v, off, 64);
-      v = OP == 0 ? v + o : (OP == 1 ? fmax(v, o) : fmin(v, o));
-    }
-    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    if ((threadIdx.x & 63) == 0) red[wave] = v;
-    __syncthreads();
-    double r = red[0];
-    for (int i = 1; i < nw; ++i) r = OP == 0 ? r + red[i] : (OP == 1 ? fmax(r, red[i]) : fmin(r, red[i]));
-    __syncthreads();
-    return r;
-  }
   // N values at once (op: 0 sum, 1 max, 2 min) for the price of one: two barriers in total.
   // Ops are template arguments so that everything unrolls into registers (no scratch).
   template <int OP> static __device__ __forceinline__ double comb(double a, double b) {
     return OP == 0 ? a + b : (OP == 1 ? fmax(a, b) : fmin(a, b));
   }
+  // Reduction over the 64 lanes of a wave on the cross-lane data path (DPP), not through the LDS crossbar:
+  // four rotations inside each row of 16 lanes (row_ror 8, 4, 2, 1: afterwards every lane holds the result of its
+  // row), then the four rows are read out by v_readlane and combined.  The __shfl_down ladder it replaces is six
+  // dependent ds_bpermute pairs per value, ~360 cycles; an interior-point iteration reduces ~25 values.
+  // All lanes must be active.  The result is the same in every lane; fixed order: deterministic.
+  template <int OP, int CTRL> static __device__ __forceinline__ double dpp_comb(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return comb<OP>(v, __hiloint2double(hi2, lo2));
+  }
+  template <int OP> static __device__ __forceinline__ double wave_reduce(double v) {
+    v = dpp_comb<OP, 0x128>(v);      // row_ror:8
+    v = dpp_comb<OP, 0x124>(v);      // row_ror:4
+    v = dpp_comb<OP, 0x122>(v);      // row_ror:2
+    v = dpp_comb<OP, 0x121>(v);      // row_ror:1
+    const double r0 = rl(v, 0), r1 = rl(v, 16), r2 = rl(v, 32), r3 = rl(v, 48);
+    return comb<OP>(comb<OP>(r0, r1), comb<OP>(r2, r3));
+  }
+  static __device__ __forceinline__ double rl(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+  }
+  template <int OP> __device__ double reduce(double v) const {
+    v = wave_reduce<OP>(v);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int i = 1; i < nw; ++i) r = comb<OP>(r, red[i]);
+    __syncthreads();
+    return r;
+  }
   template <int I, int N, int OP0, int... OPS>
   __device__ __forceinline__ void red_wave(double (&v)[N]) const {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[I] = comb<OP0>(v[I], __shfl_down(v[I], off, 64));
+    v[I] = wave_reduce<OP0>(v[I]);
     if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * N + I] = v[I];
     if constexpr (sizeof...(OPS) > 0) red_wave<I + 1, N, OPS...>(v);
   }
@@ -1853,7 +1874,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // cold starts may damp the leaf (hyperplane) variables less and the root (trajectory) variables more
   // than dw (same product: the same bilinear negative curvature is covered); warm starts use dw on both
     const double reg_leaf = warm ? 1.0 : o.dw_leaf_ratio_cold, reg_root = warm ? 1.0 : 1.0 / o.dw_leaf_ratio_cold;
-  int it = 0, status = 1;
+  int it = 0, status = 1, ls_fail = 0;
 #ifdef OMGX_EXP_COLD_NU
   const double nu_stall_max = OMGX_EXP_COLD_NU;
 #else
@@ -1864,6 +1885,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   if (c.tid() == 0) c.prof[PH_SETUP] += c.prof[PH_S_DESC] + c.prof[PH_S_PARAMS] + c.prof[PH_S_JAC0] + c.prof[PH_S_CLASS] + c.prof[PH_S_INIT];
 #endif
 
+#if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
+  long long resid_seen_ = 0;
+#endif
   for (it = 0; it <= o.max_iter; ++it) {
     OMGX_TIC();
     // ---- Jacobian (scaled): one thread per entry; only the entries that depend on x ------------
@@ -1922,6 +1946,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       if (c.tid() == 0) { w.gbar[N - 1] = 0.0; w.xt[N - 1] = 0.0; }
     }
     c.sync();
+    OMGX_TOC(PH_LA);                                      // (profiling build: column sums of the residual phase)
     double rd_max = 0.0;
     OMGX_PFOR(q, n) rd_max = fmax(rd_max, fabs(w.dinv[q]));
     double viol = 0.0, zh = 0.0, rE_max = 0.0, rE_sum = 0.0, vz = 0.0, lam_sum = 0.0, cnt = 0.0;
@@ -1942,6 +1967,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       c.template reduce_ops<1, 0, 0, 0, 1, 1, 1, 0>(rv);
       rd_max = rv[0]; lam_sum = rv[1]; vz = rv[2]; cnt = rv[3]; viol = rv[4]; zh = rv[5]; rE_max = rv[6]; rE_sum = rv[7];
     }
+    OMGX_TOC(PH_LS);                                      // (error measures and their reduction)
     const double sd = fmax(OMGX_S_MAX, lam_sum / fmax(1.0, cnt)) / OMGX_S_MAX;
     const double err0 = fmax(rd_max / sd, fmax(viol, zh / sd));
     res.f = f; res.mu = mu; res.t = t; res.iters = it;
@@ -1997,7 +2023,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     if (c.tid() == 0) w.gbar[N - 1] = gbar_t;
     c.sync();
 
-    OMGX_TOC(PH_RESID);
+    OMGX_TOC(PH_LB);                                      // (barrier update loop, barrier gradient)
+#if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
+    if (c.tid() == 0) { c.prof[PH_RESID] += c.prof[PH_LA] + c.prof[PH_LS] + c.prof[PH_LB] - resid_seen_; resid_seen_ = c.prof[PH_LA] + c.prof[PH_LS] + c.prof[PH_LB]; }
+#endif
     // ---- assemble + factorise with inertia correction --------------------------------
     // Tracking of the inertia correction dw.  When the previous iteration needed dw > 0 the
     // (doomed) dw = 0 attempt is skipped.  A decrease dw_last/3 is attempted only every
@@ -2241,7 +2270,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     if (!use_t && c.tid() == 0) w.sol[N - 1] = 0.0;
     c.sync();
     const double dt = w.sol[N - 1];
-    double ap_l = 1.0, ad_l = 1.0, ymax = 0.0, gdx = 0.0;
+    double ap_l = 1.0, ad_l = 1.0, ymax = 0.0, gdx = 0.0, ysum = 0.0;
     const double tau = fmax(OMGX_TAU_MIN, 1.0 - mu);
     OMGX_PFOR(ir, m) {
       const int r = T.row_perm[ir];
@@ -2268,6 +2297,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         if (dzr < 0.0) ad_l = fmin(ad_l, -tau * w.z[r] / dzr);
       } else if (ty == ROW_EQ) {
         ymax = fmax(ymax, fabs(w.sol[N + T.eq_index[r]]));
+        ysum += fabs(w.sol[N + T.eq_index[r]]);
       }
     }
     OMGX_PFOR(q, N) gdx += w.gbar[q] * w.sol[q];
@@ -2275,9 +2305,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     OMGX_PFOR(r, m) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) lns += log(w.s[r]);
     double a_p, a_d;
     {
-      double rv[5] = {ap_l, ad_l, ymax, gdx, lns};
-      c.template reduce_ops<2, 2, 1, 0, 0>(rv);
-      a_p = rv[0]; a_d = rv[1]; ymax = rv[2]; gdx = rv[3]; lns = rv[4];
+      double rv[6] = {ap_l, ad_l, ymax, gdx, lns, ysum};
+      c.template reduce_ops<2, 2, 1, 0, 0, 0>(rv);
+      a_p = rv[0]; a_d = rv[1]; ymax = rv[2]; gdx = rv[3]; lns = rv[4]; ysum = rv[5];
     }
     double dzt = 0.0;
     if (use_t) {
@@ -2287,11 +2317,16 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     }
     const double nuE = 2.0 * fmax(1.0, ymax);
     const double phi0 = f + nu * t - mu * lns - (use_t ? mu * log(t) : 0.0) + nuE * rE_sum;
-    const double dphi = gdx - nuE * rE_sum;
+    // The equality block carries -delta_c I (quasi-definite system): the linearised equality residual after the full
+    // step is delta_c * y_new, not zero -- the penalty term can only promise the difference.  (Without this the
+    // Armijo test asks, at the end of a tight solve, for a decrease of nuE * 2e-8 that no step can deliver, the
+    // step length collapses and the solve stalls a factor 1.2 above a tolerance of 1e-6.)
+    const double dphi = gdx - nuE * fmax(0.0, rE_sum - OMGX_DELTA_C * ysum);
 
     OMGX_TOC(PH_STEP);
     // ---- Armijo backtracking on the barrier function, iterate stays strictly feasible ----
     double alpha = a_p, ft = f, tt = t; int ok = 0;
+    const bool phi_noise = fabs(a_p * dphi) <= OMGX_PHI_NOISE * (1.0 + fabs(phi0));
     for (int bt = 0; bt < OMGX_MAX_BACKTRACK; ++bt) {
       OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + alpha * w.sol[q]; }
       c.sync();
@@ -2316,7 +2351,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       }
       if (smin > 0.0) {
         const double phit = ft + nu * tt - mu * lnst - (use_t ? mu * log(tt) : 0.0) + nuE * rEt;
-        if (phit <= phi0 + OMGX_ETA * alpha * dphi || phit - phi0 <= 10.0 * 2.220446049250313e-16 * fabs(phi0)) { ok = 1; break; }
+        // (near the solution the decrease a Newton step predicts, ~ error^2, drops below what the merit function can
+        // resolve -- its value is a sum of ~n_con terms of size 1 -- and the Armijo test then compares rounding
+        // noise: such a step is taken as it is, like IPOPT's tiny-step rule; the error test decides about the rest)
+        if (phi_noise || phit <= phi0 + OMGX_ETA * alpha * dphi || phit - phi0 <= 10.0 * 2.220446049250313e-16 * fabs(phi0)) { ok = 1; break; }
       }
       alpha *= 0.5;
       c.sync();
@@ -2325,10 +2363,28 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
     if (c.tid() == 0) c.prof[PH_LINESEARCH] = c.prof[PH_L_TERMS] + c.prof[PH_L_ROWS];
 #endif
+#if !defined(OMGX_HOST_PORT) && defined(OMGX_TRACE_DEV)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      printf("it %3d mu %.2e t %.3e nu %.1e zt %.2e err %.3e rd %.2e viol %.2e zh %.2e sd %.2e dw %.2e alpha %.2e ok %d f %.10e dphi %.3e phi0 %.6e a_p %.2e gdx %.3e\n", it, mu, t, nu, zt, err0, rd_max, viol, zh, sd, dw_last, alpha, ok, f, dphi, phi0, a_p, gdx);
+#endif
 #if defined(OMGX_HOST_PORT) && defined(OMGX_TRACE)
     fprintf(stderr, "it %3d mu %.2e t %.3e nu %.1e zt %.2e err %.2e dw %.2e alpha %.2e rE %.2e f %.4e\n", it, mu, t, nu, zt, err0, dw_last, alpha, rE_sum, f);
 #endif
-    if (!ok) { status = 4; break; }
+    if (!ok) {
+      // No acceptable step along this direction: at tight tolerances the decrease the Armijo test asks for sinks
+      // into the rounding noise of the merit function (which lanes add what first decides which agent it hits).
+      // Before giving up, take the iteration again with a heavier inertia correction -- a direction closer to
+      // steepest descent of the barrier function -- up to OMGX_LS_RETRY times in a row.
+      if (ls_fail < OMGX_LS_RETRY) {
+        ++ls_fail;
+        dw_last = fmax(dw_last, OMGX_DW_FIRST) * OMGX_LS_RETRY_DW;
+        dw_hold = 2; dw_backoff = OMGX_DW_BACKOFF_MAX;
+        c.sync();
+        continue;
+      }
+      status = 4; break;
+    }
+    ls_fail = 0;
     // ---- accept --------------------------------------------------------------------
     c.sync();
     OMGX_PFOR(q, N) w.x[q] = w.xt[q];

@@ -310,6 +310,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
     dw_last = 0.0
     dw_hold, dw_backoff = 0, 1
     status, it, nfact = 1, 0, 0
+    ls_fail = 0
     N = n + 1                      # (x, t)
     t_check = t
     # inertia correction acts on the variables that appear in a nonlinear term only: the rows
@@ -513,8 +514,10 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         thE = np.abs(rE).sum()
         nuE = 2.0 * max(1.0, np.abs(y_new).max() if mE else 0.0)
         phi0 = f + nu * t - mu * np.log(s).sum() - (mu * np.log(t) if use_t else 0.0) + nuE * thE
-        dphi = g_bar @ dxt - nuE * thE
+        # (quasi-definite system: the linearised equality residual after the full step is delta_c * y_new)
+        dphi = g_bar @ dxt - nuE * max(0.0, thE - o['delta_c'] * (np.abs(y_new).sum() if mE else 0.0))
         alpha, ok = a_p, False
+        phi_noise = abs(a_p * dphi) <= o.get('phi_noise', 1e-10) * (1.0 + abs(phi0))      # (omgx_core.h OMGX_PHI_NOISE)
         for bt in range(o['max_backtrack']):
             xt = x + alpha * dxt[:n]
             tt = t + alpha * dt
@@ -523,15 +526,22 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             if st.min() > 0 and st.min() >= (1 - tau) * 0.0:
                 phit = ft + nu * tt - mu * np.log(st).sum() - (mu * np.log(tt) if use_t else 0.0) \
                     + nuE * np.abs(cEt - tt * cE0).sum()
-                if phit <= phi0 + o['eta'] * alpha * dphi or phit - phi0 <= 10 * np.finfo(float).eps * abs(phi0):
+                if phi_noise or phit <= phi0 + o['eta'] * alpha * dphi or phit - phi0 <= 10 * np.finfo(float).eps * abs(phi0):
                     ok = True
                     break
             alpha *= 0.5
         if trace is not None:
             trace[-1].update(alpha=alpha, a_p=a_p, a_d=a_d, ok=ok, tries=tries, bt=bt, dphi=dphi)
         if not ok:
+            # (omgx_core.h: the iteration again with a heavier inertia correction, up to 3 times in a row)
+            if ls_fail < o.get('ls_retry', 3):
+                ls_fail += 1
+                dw_last = max(dw_last, o['dw_first']) * o.get('ls_retry_dw', 100.0)
+                dw_hold, dw_backoff = 2, o.get('dw_backoff_max', 8)
+                continue
             status = 4
             break
+        ls_fail = 0
         x, t, s, f, h, cE = xt, tt, st, ft, ht, cEt
         if z0 is not None:
             # component-wise dual step: every multiplier takes its full Newton step, clipped at the
