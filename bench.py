@@ -72,14 +72,14 @@ def sample_roofline(torch, tpl, veh, dev, n_agents, horizon_time, reps=20):
 
 def measured_traffic(n_agents):
     """HBM bytes per launch of ipm_solve_kernel over receding-horizon steps, from the committed PMC
-    passes (profiles/r01_pmc_hbm.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
-    this bench at 1024 agents; launches 0-2 are the cold solves, the rest warm steps); None for
+    passes (profiles/r02_pmc_hbm.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    this bench at 1024 agents; launches 0-3 are the cold solves, the rest warm steps); None for
     other batch sizes."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm.json')
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm.json')
     if n_agents != 1024 or not os.path.exists(path):
         return None
     d = json.load(open(path))
-    warm = lambda name: float(np.mean(d[name]['per_launch_kb'][3:])) * 1024.0
+    warm = lambda name: float(np.mean(d[name]['per_launch_kb'][4:])) * 1024.0
     return warm('FETCH_SIZE') + warm('WRITE_SIZE')
 
 
