@@ -161,7 +161,10 @@ int  omgx_batch_solve(omgx_batch* b, const double* p, const double* x0,
                       double* x, double* lam_g, int32_t* status, int32_t* iters,
                       int32_t flags);
 int  omgx_batch_sync(omgx_batch* b);
-/* Device time (ms, HIP events on the handle's stream) of the last solve kernel. */
+/* Device time (ms, HIP events on the handle's stream) of the last solve kernel.  The two event records per solve
+ * cost ~10 us of stream time each; a resident loop that does its own timing switches them off
+ * (omgx_batch_set_timing(b, 0): omgx_batch_last_kernel_ms then fails until a timed solve has run again). */
+int  omgx_batch_set_timing(omgx_batch* b, int32_t on);
 int  omgx_batch_last_kernel_ms(omgx_batch* b, double* ms);
 
 /* Warm-start shift  coeffs <- T * coeffs  for the masked agents

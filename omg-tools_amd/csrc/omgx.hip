@@ -482,6 +482,7 @@ struct omgx_batch {
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  bool timing = true;              // bracket every solve kernel with events (omgx_batch_set_timing)
   // staging buffers for host-pointer calls
   double *d_p = nullptr, *d_x0 = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_x = nullptr, *d_lam = nullptr;
   int32_t *d_status = nullptr, *d_iters = nullptr;
@@ -848,13 +849,13 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
     HIPCHK(hipMemcpyAsync(b->d_ub, ubg, nb * sizeof(double), hipMemcpyHostToDevice, b->stream));
     klb = b->d_lb; kub = b->d_ub;
   }
-  HIPCHK(hipEventRecord(b->ev0, b->stream));
+  if (b->timing) HIPCHK(hipEventRecord(b->ev0, b->stream));
   hipLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok), dim3(b->n_slabs), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev,
                      b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
                      b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, b->store.out ? b->d_store : nullptr, (flags & OMGX_ONLY_FAILED) ? 1 : 0);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(b->ev1, b->stream));
-  b->timed = true;
+  if (b->timing) HIPCHK(hipEventRecord(b->ev1, b->stream));
+  b->timed = b->timing;
   if (!dev) {
     HIPCHK(hipMemcpyAsync(x, b->d_x, (size_t)B * d.n_var * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipMemcpyAsync(lam_g, b->d_lam, (size_t)B * d.n_con * sizeof(double), hipMemcpyDeviceToHost, b->stream));
@@ -876,6 +877,13 @@ int omgx_batch_phase_cycles(omgx_batch* b, long long* out) {   // profiling buil
 int omgx_batch_sync(omgx_batch* b) {
   if (!b) return OMGX_E_INVALID;
   HIPCHK(hipStreamSynchronize(b->stream));
+  return OMGX_OK;
+}
+
+int omgx_batch_set_timing(omgx_batch* b, int32_t on) {
+  if (!b) { g_err = "null handle"; return OMGX_E_INVALID; }
+  b->timing = on != 0;
+  if (!b->timing) b->timed = false;
   return OMGX_OK;
 }
 

@@ -2368,7 +2368,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       printf("it %3d mu %.2e t %.3e nu %.1e zt %.2e err %.3e rd %.2e viol %.2e zh %.2e sd %.2e dw %.2e alpha %.2e ok %d f %.10e dphi %.3e phi0 %.6e a_p %.2e gdx %.3e\n", it, mu, t, nu, zt, err0, rd_max, viol, zh, sd, dw_last, alpha, ok, f, dphi, phi0, a_p, gdx);
 #endif
 #if defined(OMGX_HOST_PORT) && defined(OMGX_TRACE)
-    fprintf(stderr, "it %3d mu %.2e t %.3e nu %.1e zt %.2e err %.2e dw %.2e alpha %.2e rE %.2e f %.4e\n", it, mu, t, nu, zt, err0, dw_last, alpha, rE_sum, f);
+    fprintf(stderr, "it %3d mu %.2e t %.3e nu %.1e zt %.2e err %.2e (rd %.2e viol %.2e zh %.2e sd %.1e) dw %.2e alpha %.2e rE %.2e f %.4e\n", it, mu, t, nu, zt, err0, rd_max, viol, zh, sd, dw_last, alpha, rE_sum, f);
 #endif
     if (!ok) {
       // No acceptable step along this direction: at tight tolerances the decrease the Armijo test asks for sinks

@@ -344,6 +344,11 @@ class BatchSolver(object):
     def sync(self):
         _check(self.lib, self.lib.omgx_batch_sync(self._h), 'omgx_batch_sync')
 
+    def set_timing(self, on):
+        """Event records around every solve kernel (needed by last_kernel_ms; ~20 us of stream time per solve)."""
+        self.lib.omgx_batch_set_timing.argtypes = [C.c_void_p, C.c_int32]
+        _check(self.lib, self.lib.omgx_batch_set_timing(self._h, int(bool(on))), 'omgx_batch_set_timing')
+
     def last_kernel_ms(self):
         ms = C.c_double()
         _check(self.lib, self.lib.omgx_batch_last_kernel_ms(self._h, C.byref(ms)),

@@ -26,6 +26,7 @@ def mpc_mode(problem, P, B, steps=20, warmup=3):
     mpc = BatchP2P(problem, P, ops='hip', device=torch.device('cuda', 0), options=dict(tol=1e-3, max_iter=300))
     solver = mpc.solver
     solver.lib.omgx_batch_phase_cycles.argtypes = [C.c_void_p, C.c_void_p]
+    solver.set_timing(True)
     mpc.solve_cold()
     for _ in range(warmup):
         mpc.step()
