@@ -438,39 +438,6 @@ OMGX_FN double pp_eval_packed(const Tables& T, int pp, const double* a) {
   return tot;
 }
 
-// B_{i,deg}(u) by its own Cox-de Boor triangle (deg <= 5): every basis function is independent, so a
-// row of them is evaluated by as many threads; no dynamically indexed local array (scratch memory).
-OMGX_FN double bspl_entry(const double* k, int deg, double u, int i) {
-  double b[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int idx = i + j;
-    double v = 0.0;
-    if (j <= deg) {
-      const bool left_closed = (idx < deg + 1) && (k[0] == k[idx]);
-      const bool lo = left_closed ? (u >= k[idx]) : (u > k[idx]);
-      v = (lo && u <= k[idx + 1]) ? 1.0 : 0.0;
-    }
-    b[j] = v;
-  }
-#pragma unroll
-  for (int r = 1; r <= 5; ++r) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      if (r <= deg && j <= deg - r) {
-        const int idx = i + j;
-        double v = 0.0;
-        double den = k[idx + r] - k[idx];
-        if (den != 0.0) v = (u - k[idx]) * b[j] / den;
-        den = k[idx + r + 1] - k[idx + 1];
-        if (den != 0.0) v += (k[idx + r + 1] - u) * b[j + 1] / den;
-        b[j] = v;
-      }
-    }
-  }
-  return b[0];
-}
-
 // All basis functions of one basis row at u by the span algorithm (The NURBS Book A2.2, O(deg^2) with
 // deg (deg + 1) / 2 divisions) instead of one Cox-de Boor triangle per function: the deg + 1 functions of
 // the active span are computed together, the others are zero.  Span convention of the reference
@@ -573,19 +540,6 @@ OMGX_FN double term_coef(const Tables& T, const Work& w, int t) {
 
 OMGX_FN double rec_coef(const Work& w, double coef, int slot) { return slot < 0 ? coef : coef * w.slots[slot]; }
 
-// unscaled value of Jacobian entry e at xv: the sum of its items in table order (owner-computes: one
-// thread per entry, no atomics, the same rounding in every run)
-OMGX_FN double jac_entry(const Tables& T, const Work& w, int e, const double* xv) {
-  double s = 0.0;
-  for (int i = T.je_ptr[e]; i < T.je_ptr[e + 1]; ++i) {
-    const JItem q = T.je_item[i];
-    // (selects on clamped indices instead of branches: the loads of the items stay in flight together)
-    const double xs = w.slots[q.slot < 0 ? 0 : q.slot], xa = xv[q.va < 0 ? 0 : q.va], xb = xv[q.vb < 0 ? 0 : q.vb];
-    s += q.coef * (q.slot < 0 ? 1.0 : xs) * (q.va < 0 ? 1.0 : xa) * (q.vb < 0 ? 1.0 : xb);
-  }
-  return s;
-}
-
 // sum of the items of the entry in slot i of an ELL item table (four at a time, all loads in flight)
 OMGX_FN double jac_entry_ell(const JItem* ell, const int32_t* glen, int n_owner, const Work& w, int i, const double* xv) {
   const int L = glen[i >> 6];
@@ -629,31 +583,6 @@ OMGX_FN double row_value_ell(const Tables& T, const Work& w, int i, int m, const
   return g;
 }
 
-// unscaled value of row r (r < m) at xv from the packed term records, term order
-OMGX_FN double row_value_rec(const Tables& T, const Work& w, int r, const double* xv) {
-  double g = 0.0;
-#pragma unroll 4
-  for (int t = T.row_ptr[r]; t < T.row_ptr[r + 1]; ++t) {
-    const TermRec q = T.trec[t];
-    const double xs = w.slots[q.slot < 0 ? 0 : q.slot];
-    const double x0 = xv[q.v0 < 0 ? 0 : q.v0], x1 = xv[q.v1 < 0 ? 0 : q.v1], x2 = xv[q.v2 < 0 ? 0 : q.v2];
-    g += q.coef * (q.slot < 0 ? 1.0 : xs) * (q.v0 < 0 ? 1.0 : x0) * (q.v1 < 0 ? 1.0 : x1) * (q.v2 < 0 ? 1.0 : x2);
-  }
-  return g;
-}
-
-// value of row r (unscaled) at the variable-order point xv
-OMGX_FN double row_value(const Tables& T, const Work& w, int r, const double* xv) {
-  double g = 0.0;
-  for (int t = T.row_ptr[r]; t < T.row_ptr[r + 1]; ++t) {
-    double v = term_coef(T, w, t);
-    const int32_t* tv = T.t_var + 3 * t;
-    if (tv[0] >= 0) { v *= xv[tv[0]]; if (tv[1] >= 0) { v *= xv[tv[1]]; if (tv[2] >= 0) v *= xv[tv[2]]; } }
-    g += v;
-  }
-  return g;
-}
-
 // this thread's share of row r (terms strided over the workgroup); the caller sums the shares
 template <class C>
 OMGX_FN double row_value_share(const C& c, const Tables& T, const Work& w, int r, const double* xv) {
@@ -665,22 +594,6 @@ OMGX_FN double row_value_share(const C& c, const Tables& T, const Work& w, int r
     g += v;
   }
   return g;
-}
-
-// unscaled Jacobian entries of row r into jval[jr_ptr[r]..)
-OMGX_FN void row_jac(const Tables& T, Work& w, int r, const double* xv) {
-  for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) w.jval[e] = 0.0;
-  for (int t = T.row_ptr[r]; t < T.row_ptr[r + 1]; ++t) {
-    const double cf = term_coef(T, w, t);
-    const int32_t* tv = T.t_var + 3 * t;
-    const int32_t* je = T.t_jidx + 3 * t;
-    if (tv[0] < 0) continue;
-    if (tv[1] < 0) { w.jval[je[0]] += cf; continue; }
-    const double x0 = xv[tv[0]], x1 = xv[tv[1]];
-    if (tv[2] < 0) { w.jval[je[0]] += cf * x1; w.jval[je[1]] += cf * x0; continue; }
-    const double x2 = xv[tv[2]];
-    w.jval[je[0]] += cf * x1 * x2; w.jval[je[1]] += cf * x0 * x2; w.jval[je[2]] += cf * x0 * x1;
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1488,9 +1401,6 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   BMat* Ms = (BMat*)w.col;
   double* stage = w.col + OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1);
   if (d.n_leaf > 0) {
-#ifdef OMGX_LDL_MFMA
-    ldl_blocked<1>(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, stage, &bad);
-#else
 #ifdef OMGX_HOST_PORT
     ldl_left4(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad);
 #else
@@ -1505,7 +1415,6 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
       if (coop) ldl_left4_coop<1>(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad, total_rows, nmax);
       else ldl_left4(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad);
     }
-#endif
 #endif
 #ifdef OMGX_COUNT_FACT
     if (bad) ++omgx_dbg_cnt[0];
@@ -1610,37 +1519,6 @@ OMGX_FN int kkt_refactor_root(const C& c, const Dims& d, const Kkt& K, Work& w) 
   ldl_blocked<2>(c, Ms + d.n_leaf, 1, w.kkt, w.dinv, w.col, stage, &bad);
   return bad ? 2 : 0;
 #endif
-}
-
-// Unit-lower triangular solves in blocks of 4 columns, executed by ONE wave (lanes = rows): every
-// lane reads the 4 right-hand-side entries and the 6 sub-diagonal entries of the block, finishes
-// the block redundantly in registers, then updates its own row with 4 multiply-adds -- n/4
-// wave-synchronised steps instead of n.  `L(i, j)` returns the offset of entry (i, j), i > j.
-template <class C, class Addr>
-OMGX_FN void trsv_fwd4(const C& c, const double* A, Addr L, int n, double* y) {
-  const int lane = c.lane(), nln = c.nlanes();
-  for (int jb = 0; jb < n; jb += 4) {
-    const int nb = (n - jb) < 4 ? (n - jb) : 4;
-    const int q1 = nb > 1 ? 1 : 0, q2 = nb > 2 ? 2 : 0, q3 = nb > 3 ? 3 : 0;
-    const double m1 = nb > 1 ? 1.0 : 0.0, m2 = nb > 2 ? 1.0 : 0.0, m3 = nb > 3 ? 1.0 : 0.0;
-    const double r0 = y[jb], r1 = y[jb + q1], r2 = y[jb + q2], r3 = y[jb + q3];
-    // (masked entries of a partial last block read the diagonal entry (jb, jb): finite, times 0)
-    const double l10 = m1 * A[L(jb + q1, jb)];
-    const double l20 = m2 * A[L(jb + q2, jb)], l21 = m2 * A[L(jb + q2, jb + (q2 ? 1 : 0))];
-    const double l30 = m3 * A[L(jb + q3, jb)], l31 = m3 * A[L(jb + q3, jb + (q3 ? 1 : 0))],
-                 l32 = m3 * A[L(jb + q3, jb + (q3 ? 2 : 0))];
-    const double y0 = r0, y1 = r1 - l10 * y0, y2 = r2 - l20 * y0 - l21 * y1, y3 = r3 - l30 * y0 - l31 * y1 - l32 * y2;
-    for (int i = jb + lane; i < n; i += nln) {
-      if (i >= jb + nb) {
-        const int o = L(i, jb);
-        y[i] -= A[o] * y0 + m1 * A[o + q1] * y1 + m2 * A[o + q2] * y2 + m3 * A[o + q3] * y3;
-      } else {
-        const int q = i - jb;
-        y[i] = q == 0 ? y0 : (q == 1 ? y1 : (q == 2 ? y2 : y3));
-      }
-    }
-    c.wave_sync();
-  }
 }
 
 // x <- L^{-T} y for the same storage (entry (i, j) of L, i > j, multiplies x_i into row j).  With
