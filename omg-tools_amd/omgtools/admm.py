@@ -344,8 +344,10 @@ class HipAdmmOps(object):
             send[:len(halo.publish_local)] = local[self._pub]
         if extra is not None:
             send[halo.max_pub, :extra.numel()] = extra
-        allp = t.empty((halo.world,) + tuple(send.shape), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(allp, send)
+        # (concatenated form [world * rows, w]: accepted by every backend; viewed as [world, rows, w] afterwards)
+        flat = t.empty((halo.world * rows, w), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(flat, send)
+        allp = flat.view(halo.world, rows, w)
         summed = allp[:, halo.max_pub, :extra.numel()].sum(dim=0) if extra is not None else None
         out = t.cat([local, allp[self._src[:, 0], self._src[:, 1]]], dim=0) if len(halo.needed) else local
         return out, summed

@@ -197,3 +197,45 @@ def test_nesterov_statements_against_the_reference_formulas():
     assert np.allclose(ops.z_ij, plain.z_ij + w * (plain.z_ij - zij_p), atol=1e-13)
     assert np.allclose(ops.l_ij, plain.l_ij + w * (plain.l_ij - lij_p), atol=1e-13)
     assert abs(ops.alpha - a2) < 1e-15
+
+
+def _exchange_worker(rank, world, port, q):
+    """The device path's exchange (HipAdmmOps.exchange / bind: torch tensors, all_gather_into_tensor) on CPU
+    tensors over gloo -- the index logic of the multi-GPU path without a GPU."""
+    sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from omgtools.admm import HaloPlan, HipAdmmOps
+    nbr = _ring_groups([7, 3])                     # 10 agents over 3 ranks: uneven shards, one self-contained group
+    halo = HaloPlan(nbr, rank, world)
+    ops = HipAdmmOps.__new__(HipAdmmOps)           # only the exchange plumbing: no solver, no device
+    ops.torch, ops.dev = torch, torch.device('cpu')
+    ops.bind(halo, np.zeros_like(halo.nbr_local))
+    Bl, w = halo.hi - halo.lo, 5
+    rows = torch.arange(halo.lo, halo.hi, dtype=torch.float64)[:, None] * 100. + torch.arange(w, dtype=torch.float64)[None, :]
+    extra = torch.tensor([1.0 + rank, 10.0 * (rank + 1), 0.5], dtype=torch.float64)
+    out, summed = ops.exchange(rows, halo, dist, extra)
+    # every row this rank's agents refer to is the row of that global agent
+    want = torch.tensor([[g * 100. + k for k in range(w)] for g in list(range(halo.lo, halo.hi)) + halo.needed], dtype=torch.float64)
+    ok = bool(torch.equal(out, want)) and bool(torch.allclose(summed, torch.tensor([6., 60., 1.5], dtype=torch.float64)))
+    idx = torch.as_tensor(halo.nbr_local, dtype=torch.int64)
+    ok = ok and bool(torch.equal(out[idx][:, :, 0] / 100., torch.as_tensor(nbr[halo.lo:halo.hi], dtype=torch.float64)))
+    out2, none = ops.exchange(rows, halo, dist, None)
+    ok = ok and none is None and bool(torch.equal(out2, want))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_device_path_exchange_indexing_over_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29600 + 3000 + os.getpid() % 1000
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 3, port, q)) for r in range(3)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=120) for _ in range(3))
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(pr.exitcode == 0 for pr in procs) and got == {0: True, 1: True, 2: True}
