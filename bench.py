@@ -204,17 +204,18 @@ def unedited_rule(args, dev, seed):
 def bench_formation(args, rank, local_rank, world, dist, dev):
     """configs[3]: FormationPoint2point ADMM, 512 Holonomic agents (fixed total: strong
     scaling), one step = one full ADMM iteration (x-update + exchanges + z/l/residuals)."""
-    from omgtools.scenarios import formation_holonomic
+    from omgtools.scenarios import formation_holonomic, rendezvous_holonomic
     from omgtools.backend import BatchSolver
     from omgtools.admm import BatchADMM, HipAdmmOps
     from omgtools.distributed import shard_range, reduce_report
     N = 512 if args.agents == 1024 else args.agents
-    problem, updater, father, lay, P = formation_holonomic(N)
+    rendezvous = args.workload == 'rendezvous'
+    problem, updater, father, lay, P = (rendezvous_holonomic if rendezvous else formation_holonomic)(N)
     tpl = father.template
     lo, hi = shard_range(N, rank, world)
     solver = BatchSolver(tpl, hi - lo, device=local_rank, options=dict(tol=args.tol, max_iter=300))
     ops = HipAdmmOps(solver, tpl, lay, P['p'][lo:hi], P['x0'][lo:hi], dev)
-    admm = BatchADMM(lay, P['nbr'], ops, rank=rank, world=world, dist=dist if world > 1 else None, rho=1.0)
+    admm = BatchADMM(lay, P['nbr'], ops, rank=rank, world=world, dist=dist if world > 1 else None, rho=2.0 if rendezvous else 1.0)
     admm.initialize()
 
     def barrier():
@@ -235,12 +236,15 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
     if rank != 0:
         return
     print(json.dumps({
-        'metric': 'ADMM agent-updates/sec, 512-agent Holonomic FormationPoint2point', 'value': n_ok_all * args.steps / elapsed,
+        'metric': 'ADMM agent-updates/sec, %d-agent Holonomic %s' % (N, 'RendezVous' if rendezvous else 'FormationPoint2point'),
+        'value': n_ok_all * args.steps / elapsed,
         'unit': 'agent-updates/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': 'configs[3]: FormationPoint2point ADMM, %d Holonomic agents, circular '
-                               'interconnection, knot_intervals=10, 2 rectangular obstacles, rho=1, tol=%g'
+        'config': {'workload': ('RendezVous ADMM (free end points, `problems/rendezvous.py`), %d Holonomic agents, circular '
+                                'interconnection, knot_intervals=10, 1 rectangular obstacle, rho=2, tol=%g' if rendezvous else
+                                'configs[3]: FormationPoint2point ADMM, %d Holonomic agents, circular '
+                                'interconnection, knot_intervals=10, 2 rectangular obstacles + 1 moving circle, rho=1, tol=%g')
                                % (N, args.tol), 'agents_total': N, 'n_var': tpl.n_var, 'n_con': tpl.n_con,
                    'parallelism': 'agents sharded contiguously; two all_gathers per iteration (x_i rows; [z_ij | l_ij] rows + residual sums)'},
         'solved_fraction': n_ok_all / float(N), 'residuals': list(res)}))
@@ -341,7 +345,7 @@ def main():
                     help='seconds of timed CPU work for the cpu_baseline leg (all host cores; a quarter of it on one)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the latency / host-boundary / 8d-rule legs (profiling runs)')
-    ap.add_argument('--workload', choices=['p2p', 'formation', 'quadrotor', 'holonomic3d'], default='p2p',
+    ap.add_argument('--workload', choices=['p2p', 'formation', 'rendezvous', 'quadrotor', 'holonomic3d'], default='p2p',
                     help="p2p = BASELINE.json configs[1] (headline); formation = configs[3], 512-agent ADMM")
     args = ap.parse_args()
 
@@ -355,7 +359,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    if args.workload == 'formation':
+    if args.workload in ('formation', 'rendezvous'):
         return bench_formation(args, rank, local_rank, world, dist, dev)
     if args.workload in ('quadrotor', 'holonomic3d'):
         return bench_cold(args, rank, local_rank, world, dist, dev)

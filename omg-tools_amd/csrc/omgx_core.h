@@ -2246,6 +2246,11 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       printf("it %3d mu %.2e t %.3e nu %.1e zt %.2e err %.3e rd %.2e viol %.2e zh %.2e sd %.2e dw %.2e alpha %.2e ok %d f %.10e dphi %.3e phi0 %.6e a_p %.2e gdx %.3e\n", it, mu, t, nu, zt, err0, rd_max, viol, zh, sd, dw_last, alpha, ok, f, dphi, phi0, a_p, gdx);
 #endif
 #if defined(OMGX_HOST_PORT) && defined(OMGX_TRACE)
+    {
+      int rb = -1; double best = 1e300;
+      for (int r = 0; r < m; ++r) if ((w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) && w.ds[r] < 0.0) { const double q_ = -w.s[r] / w.ds[r]; if (q_ < best) { best = q_; rb = r; } }
+      if (rb >= 0) fprintf(stderr, "      blocking row %d ratio %.3e s %.3e ds %.3e z %.3e vv %.3e | dt %.3e t %.3e\n", rb, best, w.s[rb], w.ds[rb], w.z[rb], w.vv[rb], dt, t);
+    }
     fprintf(stderr, "it %3d mu %.2e t %.3e nu %.1e zt %.2e err %.2e (rd %.2e viol %.2e zh %.2e sd %.1e) dw %.2e alpha %.2e rE %.2e f %.4e\n", it, mu, t, nu, zt, err0, rd_max, viol, zh, sd, dw_last, alpha, rE_sum, f);
 #endif
     if (!ok) {

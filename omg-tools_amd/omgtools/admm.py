@@ -91,7 +91,10 @@ class BatchADMM(object):
     def matrices(self, t_rel):
         key = round(t_rel / self.T, 12)
         if key not in self._mcache:
-            M, F = zupdate_matrices(self.lay.basis, self.lay.n_dim, self.lay.n_nghb, key)
+            if hasattr(self.lay, 'zupdate'):          # (rendezvous.RendezVousLayout: a plain consensus projector)
+                M, F = self.lay.zupdate(key)
+            else:
+                M, F = zupdate_matrices(self.lay.basis, self.lay.n_dim, self.lay.n_nghb, key)
             self._mcache[key] = self.ops.resident(M, F) if hasattr(self.ops, 'resident') else (M, F)
         return self._mcache[key]
 

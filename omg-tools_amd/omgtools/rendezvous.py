@@ -1,0 +1,127 @@
+# This file is derived from OMG-tools (meco-group/omg-tools, `omgtools/problems/rendezvous.py`, `admm.py` (API surface)).
+#
+# OMG-tools -- Optimal Motion Generation-tools
+# Copyright (C) 2016 Ruben Van Parys & Tim Mercy, KU Leuven.
+# All rights reserved.
+#
+# OMG-tools is free software; you can redistribute it and/or
+# modify it under the terms of the GNU Lesser General Public
+# License as published by the Free Software Foundation; either
+# version 3 of the License, or (at your option) any later version.
+# This software is distributed in the hope that it will be useful,
+# but WITHOUT ANY WARRANTY; without even the implied warranty of
+# MERCHANTABILITY or FITNESS FOR A PARTICULAR PURPOSE. See the GNU
+# Lesser General Public License for more details.
+#
+# You should have received a copy of the GNU Lesser General Public
+# License along with this program; if not, write to the Free Software
+# Foundation, Inc., 51 Franklin Street, Fifth Floor, Boston, MA 02110-1301 USA
+#
+# Modifications: explicit polynomials instead of CasADi graphs, one shared x-update template for the whole
+# fleet, the ADMM iteration as batched device kernels (admm.py).
+
+"""RendezVous ADMM: every vehicle plans to a FREE end point and the fleet agrees on where to meet.
+
+Behavioural spec: reference `problems/rendezvous.py:26-67` (FreeEndPoint2point sub-problems,
+`problems/point2point.py:376-418`; coupling constraints `centre_i - centre_j = 0` between neighbours on the
+fleet centre `conT + rel_pos_c` of the free end points) on top of `problems/admm.py` (x-update 63-115, z-update
+117-168, multiplier update 248-268, residuals 270-307).  The shared quantity is a plain vector of n_dim numbers
+(no spline, hence no knot transform anywhere); the z-update projects onto z_i = z_ij for every neighbour.
+
+Same device machinery as the formation problem (formation.py / admm.py): one x-update template for the fleet,
+consensus state inside p [B, n_par], `BatchADMM.iterate`.  The kernels see the shared vector as n_dim "splines"
+with one coefficient each (layout L = 1).  Pinned against the reference's own graphs by
+tests/golden/admm_rendezvous.npz (generator tests/golden/generate_golden_admm.py).
+"""
+import numpy as np
+
+from .opti import OptiChild, OptiFather
+from .problems import FreeEndPoint2point
+from .symbolic import Poly
+
+
+class RendezVousUpdater(OptiChild):
+    """Owner of the ADMM parameters of one agent's x-update (`admm.py:63-72`)."""
+
+    def __init__(self):
+        OptiChild.__init__(self, 'admm')
+
+    def construct(self, center, n_nghb):
+        ns = len(center)
+        z_i = np.atleast_1d(self.define_parameter('z_i', ns))
+        z_ji = np.atleast_1d(self.define_parameter('z_ji', n_nghb * ns))
+        l_i = np.atleast_1d(self.define_parameter('l_i', ns))
+        l_ji = np.atleast_1d(self.define_parameter('l_ji', n_nghb * ns))
+        rho = self.define_parameter('rho')
+        obj = Poly()
+        for k in range(ns):
+            pairs = [(z_i[k], l_i[k])] + [(z_ji[j * ns + k], l_ji[j * ns + k]) for j in range(n_nghb)]
+            for z, l in pairs:
+                diff = center[k] - z
+                obj = obj + l * diff + 0.5 * rho * diff * diff
+        self.define_objective(obj)
+
+
+def build_rendezvous_template(vehicle, environment, n_nghb, options=None):
+    """The x-update NLP of one rendez-vous agent as an `NLPTemplate` (children in the reference's order
+    `[vehicle, problem, environment, admm] + obstacles`, `problems/dualmethod.py:52-53`)."""
+    import omgtools.backend as be
+    opts = {'verbose': 0}
+    opts.update(options or {})
+    problem = FreeEndPoint2point(vehicle, environment, opts, {vehicle: list(range(vehicle.n_dim))})
+    updater = RendezVousUpdater()
+    father = OptiFather([vehicle, problem, environment, updater] + environment.obstacles)
+    problem.father = father
+    with father.table:
+        rel_pos_c = np.atleast_1d(vehicle.define_parameter('rel_pos_c', vehicle.n_dim))
+        problem.construct()
+        # the free end point, requested like the reference does (`rendezvous.py:44`: define_symbol('conT0', ...))
+        conT = np.asarray(vehicle.define_symbol('conT0', vehicle.n_dim), dtype=object).reshape(-1)
+        center = vehicle.get_fleet_center(list(conT), list(np.asarray(rel_pos_c, dtype=object).reshape(-1)), substitute=True)
+        updater.construct(center, n_nghb)
+        saved = be.create_nlp
+        be.create_nlp = lambda tpl, opt, name='': (None, 0.)   # the batch solver is created by the caller
+        try:
+            father.construct_problem(opts)
+        finally:
+            be.create_nlp = saved
+    father.init_transformations(problem.init_primal_transform, problem.init_dual_transform)
+    return problem, updater, father
+
+
+def consensus_matrix(ns, n_nghb):
+    """A of the z-update's equality constraints (`rendezvous.py:47-58` seen through `admm.py:313-354`):
+    z_i - z_ij = 0 for every neighbour; unknown vector [z_i | z_ij (neighbour by neighbour)]."""
+    A = np.zeros((n_nghb * ns, (1 + n_nghb) * ns))
+    for j in range(n_nghb):
+        A[j * ns:(j + 1) * ns, :ns] = np.eye(ns)
+        A[j * ns:(j + 1) * ns, (1 + j) * ns:(2 + j) * ns] = -np.eye(ns)
+    return A
+
+
+class RendezVousLayout(object):
+    """Offsets of everything the ADMM kernels touch inside x and p (same fields as FormationLayout; the shared
+    vector is n_dim blocks of L = 1 coefficient)."""
+
+    def __init__(self, template, vehicle, problem, updater, n_nghb):
+        t = template
+        self.n_dim, self.L, self.degree = vehicle.n_dim, 1, 0
+        self.ns, self.n_nghb = self.n_dim, n_nghb
+        self.x_spl = t.entry_range(problem.label, 'conT0', 'var')[0]           # what omgx_admm_center reads
+        self.x_traj = t.entry_range(vehicle.label, 'splines_seg0', 'var')[0]
+        par = lambda child, name: t.entry_range(child.label, name, 'par')[0]
+        self.p_rel = par(vehicle, 'rel_pos_c')
+        self.p_state0, self.p_input0 = par(vehicle, 'state0'), par(vehicle, 'input0')
+        self.p_poseT = par(vehicle, 'poseT')
+        self.p_T, self.p_t = par(problem, 'T'), par(problem, 't')
+        self.p_zi, self.p_zji = par(updater, 'z_i'), par(updater, 'z_ji')
+        self.p_li, self.p_lji = par(updater, 'l_i'), par(updater, 'l_ji')
+        self.p_rho = par(updater, 'rho')
+        self.basis = vehicle.basis
+        A = consensus_matrix(self.ns, n_nghb)
+        self._M = np.eye(A.shape[1]) - A.T @ np.linalg.solve(A @ A.T, A)
+
+    def zupdate(self, t0):
+        """(M, F) of the closed-form z-update z_all = M (x_all + l_all / rho) (`admm.py:144-162`); nothing depends
+        on the time: the shared vector is not a spline."""
+        return self._M, np.eye(self._M.shape[0])

@@ -211,3 +211,47 @@ def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0,
         x0[b, lay.x_spl:lay.x_spl + 2 * L] = np.c_[np.linspace(start[0], goal[0], L),
                                                    np.linspace(start[1], goal[1], L)].reshape(-1, order='F')
     return problem, updater, father, lay, {'p': p, 'x0': x0, 'nbr': circular_neighbors(n_agents)}
+
+
+def rendezvous_holonomic(n_agents, knot_intervals=10, seed=20240807 + 6, rho=2.0, horizon_time=10.):
+    """RendezVous ADMM workload in the shape of `examples/rendezvous_holonomic_export.py:31-53` scaled to the fleet
+    size: `n_agents` Holonomic vehicles start on a large circle and agree on a meeting point in a regular-polygon
+    configuration (circular interconnection), one rectangular obstacle.  Returns (problem, updater, father,
+    layout, P) like `formation_holonomic`."""
+    from .shapes import Rectangle
+    from .rendezvous import build_rendezvous_template, RendezVousLayout
+    from .formation import circular_neighbors
+    rng = np.random.default_rng(seed)
+    vehicle = Holonomic(shapes=Circle(0.1), options={'room_constraints': None})
+    vehicle.define_knots(knot_intervals=knot_intervals)
+    vehicle.set_initial_conditions([0., 0.])
+    vehicle.set_terminal_conditions([0., 0.])
+    radius = max(0.2, 0.2 * n_agents / (2 * np.pi))
+    span = 3. + 2. * radius
+    environment = Environment(room={'shape': Square(2. * span + 4.)})
+    environment.add_obstacle(Obstacle({'position': [0.3 * span, -0.2 * span]}, shape=Rectangle(width=1.5, height=0.2)))
+    problem, updater, father = build_rendezvous_template(vehicle, environment, 2, {'horizon_time': horizon_time})
+    tpl = father.template
+    lay = RendezVousLayout(tpl, vehicle, problem, updater, 2)
+    ang = 2 * np.pi * np.arange(n_agents) / n_agents
+    config = radius * np.c_[np.cos(ang), np.sin(ang)]
+    starts = span * np.c_[np.cos(ang + 0.4), np.sin(ang + 0.4)] * (0.7 + 0.3 * rng.random((n_agents, 1)))
+    L = len(vehicle.basis)
+    p = np.zeros((n_agents, tpl.n_par))
+    x0 = np.zeros((n_agents, tpl.n_var))
+    for obs in environment.obstacles:
+        chk, rad = obs.shape.get_checkpoints()
+        lo = tpl.entry_range(obs.label, 'x', 'par')[0]; p[:, lo:lo + 2] = obs.signals['position'][:, -1]
+        lo = tpl.entry_range(obs.label, 'checkpoints', 'par')[0]; p[:, lo:lo + 2 * len(chk)] = np.reshape(chk, -1)
+        lo = tpl.entry_range(obs.label, 'rad', 'par')[0]; p[:, lo:lo + len(rad)] = rad
+    for b in range(n_agents):
+        goal = config[b]                                                # first guess: meet at the origin
+        p[b, lay.p_rel:lay.p_rel + 2] = -config[b]                      # rel_pos_c = -configuration (fleet.py:93-98)
+        p[b, lay.p_state0:lay.p_state0 + 2] = starts[b]
+        p[b, lay.p_poseT:lay.p_poseT + 2] = goal
+        p[b, lay.p_T] = horizon_time
+        p[b, lay.p_rho] = rho
+        x0[b, lay.x_traj:lay.x_traj + 2 * L] = np.c_[np.linspace(starts[b, 0], goal[0], L),
+                                                     np.linspace(starts[b, 1], goal[1], L)].reshape(-1, order='F')
+        x0[b, lay.x_spl:lay.x_spl + 2] = goal                           # conT0 (`point2point.py:391-399`)
+    return problem, updater, father, lay, {'p': p, 'x0': x0, 'nbr': circular_neighbors(n_agents)}

@@ -20,6 +20,7 @@ python tools/phase_profile.py 1024 mpc > gpurun_out/${TAG}_phase_cycles_mpc.json
 ./tools/micro/bcast > gpurun_out/${TAG}_micro_bcast.txt 2>&1
 ./tools/micro/icache > gpurun_out/${TAG}_micro_icache.txt 2>&1
 python bench.py --workload formation --steps 50 --warmup 5 > gpurun_out/${TAG}_bench_formation_n1.json 2> gpurun_out/bench_formation.err
+python bench.py --workload rendezvous --steps 50 --warmup 5 > gpurun_out/${TAG}_bench_rendezvous.json 2> gpurun_out/bench_rendezvous.err
 python bench.py --workload quadrotor --steps 5 --warmup 2 > gpurun_out/${TAG}_bench_quadrotor.json 2> gpurun_out/bench_quadrotor.err
 python bench.py --workload holonomic3d --steps 3 --warmup 1 > gpurun_out/${TAG}_bench_holonomic3d.json 2> gpurun_out/bench_holonomic3d.err
 python tools/cpu_pool_sweep.py > gpurun_out/${TAG}_cpu_pool_sweep.txt 2>&1
