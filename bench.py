@@ -74,13 +74,15 @@ def measured_traffic(n_agents):
     """HBM bytes per launch of ipm_solve_kernel over receding-horizon steps, from the committed PMC
     passes (profiles/r02_pmc_hbm.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
     this bench at 1024 agents; launches 0-3 are the cold solves, the rest warm steps); None for
-    other batch sizes."""
+    other batch sizes.  Counter unit KB; FETCH_SIZE doubled: on gfx950 rocprofv3 reports half the bytes of wide
+    coalesced reads (MI355X_MICROARCH.md, HBM section) -- the table records are 16-byte-per-lane loads -- so this is
+    an upper bound for the mixed access widths of this kernel; WRITE_SIZE as reported."""
     path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm.json')
     if n_agents != 1024 or not os.path.exists(path):
         return None
     d = json.load(open(path))
     warm = lambda name: float(np.mean(d[name]['per_launch_kb'][4:])) * 1024.0
-    return warm('FETCH_SIZE') + warm('WRITE_SIZE')
+    return 2.0 * warm('FETCH_SIZE') + warm('WRITE_SIZE')
 
 
 def cpu_baseline(problem, P, opts, steps, warmup, budget_s):
