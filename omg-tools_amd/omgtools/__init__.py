@@ -14,8 +14,9 @@ from .environment import Environment, Obstacle
 from .problems import Problem, Point2point, FixedTPoint2point, FreeTPoint2point, FreeEndPoint2point
 from .execution import Simulator, Deployer
 from .formation import FormationPoint2point
+from .rendezvous import RendezVous
 
 __all__ = ['np', 'RegularPrisma', 'Circle', 'Polyhedron', 'RegularPolyhedron', 'Rectangle', 'Square', 'Sphere', 'Polyhedron3D',
            'Cuboid', 'Cube', 'Plate', 'BSplineBasis', 'BSpline', 'Vehicle', 'Holonomic',
            'Holonomic3D', 'Quadrotor', 'Fleet', 'Environment', 'Obstacle', 'Problem',
-           'Point2point', 'FixedTPoint2point', 'FreeTPoint2point', 'FreeEndPoint2point', 'FormationPoint2point', 'Simulator', 'Deployer']
+           'Point2point', 'FixedTPoint2point', 'FreeTPoint2point', 'FreeEndPoint2point', 'FormationPoint2point', 'RendezVous', 'Simulator', 'Deployer']

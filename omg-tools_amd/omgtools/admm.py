@@ -333,6 +333,8 @@ class HipAdmmOps(object):
                                            (self.l_ij, self.nn * self.ns, shift_side)):
             ents = np.ascontiguousarray(ents, dtype=np.int32)
             mats = np.ascontiguousarray(mats, dtype=np.float64)
+            if len(ents) == 0:
+                continue
             self._chk(lib.omgx_shift_rows(h, data.data_ptr(), int(stride), self.B, None, ents.ctypes.data,
                                           len(ents), mats.ctypes.data, mats.size), 'omgx_shift_rows')
 

@@ -241,7 +241,7 @@ class FormationPoint2point(object):
         sub_opts['verbose'] = 0
         self.subs = []
         for veh in self.vehicles:
-            problem, updater, father = build_updx_template(veh, self.environment.copy(), n_nghb, sub_opts)
+            problem, updater, father = self._build_template(veh, self.environment.copy(), n_nghb, sub_opts)
             veh._values['rel_pos_c'] = np.asarray(veh.rel_pos_c, dtype=float).reshape(-1, 1)
             self.subs.append((problem, updater, father))
         tpl = self.subs[0][2].template
@@ -250,7 +250,7 @@ class FormationPoint2point(object):
             if (t.n_var, t.n_con, t.n_par, t.n_terms) != (tpl.n_var, tpl.n_con, tpl.n_par, tpl.n_terms):
                 raise ValueError('vehicles of one formation must share the x-update structure')
         self.tpl = tpl
-        self.lay = lay = FormationLayout(tpl, self.vehicles[0], self.subs[0][0], self.subs[0][1], n_nghb)
+        self.lay = lay = self._make_layout(tpl, self.vehicles[0], self.subs[0][0], self.subs[0][1], n_nghb)
         self.knot_time = self.subs[0][0].knot_time
         # parameter columns owned by the device-side consensus state (never overwritten from the host)
         keep = np.ones(tpl.n_par, dtype=bool)
@@ -268,12 +268,16 @@ class FormationPoint2point(object):
             ents.append([lo, rows, cols, off]); mats.append(Ts.reshape(-1)); off += Ts.size
         self._shift_x = (np.array(ents, dtype=np.int32), np.concatenate(mats))
         L, nd = lay.L, lay.n_dim
-        p_ents = [[lay.p_zi, L, nd, 0], [lay.p_li, L, nd, 0]]
-        for j in range(n_nghb):
-            p_ents += [[lay.p_zji + j * lay.ns, L, nd, 0], [lay.p_lji + j * lay.ns, L, nd, 0]]
-        self._shift_p = (np.array(p_ents, dtype=np.int32), Tm.reshape(-1).copy())
-        self._shift_side = (np.array([[j * lay.ns, L, nd, 0] for j in range(n_nghb)], dtype=np.int32),
-                            Tm.reshape(-1).copy())
+        if self._consensus_is_spline:
+            p_ents = [[lay.p_zi, L, nd, 0], [lay.p_li, L, nd, 0]]
+            for j in range(n_nghb):
+                p_ents += [[lay.p_zji + j * lay.ns, L, nd, 0], [lay.p_lji + j * lay.ns, L, nd, 0]]
+            self._shift_p = (np.array(p_ents, dtype=np.int32), Tm.reshape(-1).copy())
+            self._shift_side = (np.array([[j * lay.ns, L, nd, 0] for j in range(n_nghb)], dtype=np.int32),
+                                Tm.reshape(-1).copy())
+        else:                  # (the shared quantity is a plain vector: nothing of the consensus state is shifted)
+            self._shift_p = (np.zeros((0, 4), dtype=np.int32), np.zeros(0))
+            self._shift_side = (np.zeros((0, 4), dtype=np.int32), np.zeros(0))
         # device state
         p0, x0 = self._host_parameters(0.), self._host_variables()
         if self._ops_kind == 'hip':
@@ -290,6 +294,15 @@ class FormationPoint2point(object):
                               horizon_time=self.options['horizon_time'],
                               **{k: self.options[k] for k in ('nesterov_acceleration', 'eta', 'nesterov_reset', 'AMA')})
         return 0.
+
+    # -- what a derived problem class (rendezvous.RendezVous) replaces ------------------------------------
+    _consensus_is_spline = True
+
+    def _build_template(self, vehicle, environment, n_nghb, options):
+        return build_updx_template(vehicle, environment, n_nghb, options)
+
+    def _make_layout(self, tpl, vehicle, problem, updater, n_nghb):
+        return FormationLayout(tpl, vehicle, problem, updater, n_nghb)
 
     def xupdate_tol(self):
         """Tolerance of the x-update solves: `ipopt.tol` x 1e-3.  IPOPT's last (superlinear) step

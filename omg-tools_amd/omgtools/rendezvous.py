@@ -35,6 +35,7 @@ tests/golden/admm_rendezvous.npz (generator tests/golden/generate_golden_admm.py
 """
 import numpy as np
 
+from .formation import FormationPoint2point
 from .opti import OptiChild, OptiFather
 from .problems import FreeEndPoint2point
 from .symbolic import Poly
@@ -125,3 +126,42 @@ class RendezVousLayout(object):
         """(M, F) of the closed-form z-update z_all = M (x_all + l_all / rho) (`admm.py:144-162`); nothing depends
         on the time: the shared vector is not a spline."""
         return self._M, np.eye(self._M.shape[0])
+
+
+class RendezVous(FormationPoint2point):
+    """Drop-in for the reference's `RendezVous` (`problems/rendezvous.py:26-89` on top of `ADMMProblem`): same
+    constructor and options, the methods `Simulator` / `Deployer` call.  Host bookkeeping per vehicle as in
+    `FormationPoint2point` (sub-problems are `FreeEndPoint2point`), one shared x-update template, a dual update
+    = one `BatchADMM.iterate` over the fleet."""
+
+    _consensus_is_spline = False
+
+    def __init__(self, fleet, environment, options=None, ops='hip'):
+        opts = {'rho': 2.}
+        opts.update(options or {})
+        FormationPoint2point.__init__(self, fleet, environment, opts, ops=ops)
+
+    def _build_template(self, vehicle, environment, n_nghb, options):
+        return build_rendezvous_template(vehicle, environment, n_nghb, options)
+
+    def _make_layout(self, tpl, vehicle, problem, updater, n_nghb):
+        return RendezVousLayout(tpl, vehicle, problem, updater, n_nghb)
+
+    def stop_criterium(self, current_time, update_time):
+        """`rendezvous.py:69-85`: the vehicles have met when their positions differ by the configured offsets
+        (summed squared deviation over all neighbour pairs below (5e-2)^2)."""
+        if self.options['max_iter'] and self.iteration > self.options['max_iter']:
+            return True
+        res = 0.
+        config = self.fleet.configuration
+        for veh in self.vehicles:
+            ind_veh = sorted(config[veh].keys())
+            rel_conT = self.fleet.get_rel_config(veh)
+            for nghb in self.fleet.get_neighbors(veh):
+                ind_nghb = sorted(config[nghb].keys())
+                for k, (ind_v, ind_n) in enumerate(zip(ind_veh, ind_nghb)):
+                    rcT = rel_conT[nghb]
+                    rcT = rcT if isinstance(rcT, float) else rcT[k]
+                    res += np.linalg.norm(veh.trajectories['splines'][ind_v, 0] -
+                                          nghb.trajectories['splines'][ind_n, 0] - rcT) ** 2
+        return bool(np.sqrt(res) <= 5.e-2)

@@ -151,3 +151,47 @@ def test_rendezvous_hip_matches_numpy_backend():
         assert np.abs(gpu.ops.x.cpu().numpy()[:, lay.x_spl:lay.x_spl + 2] - cpu_ops.x[:, lay.x_spl:lay.x_spl + 2]).max() < 1e-6
         assert np.abs(gpu.ops.z_ij.cpu().numpy() - cpu_ops.z_ij).max() < 1e-6
     solver.close()
+
+
+def rendezvous_example(ops, n=4, verbose=0):
+    """The script of `examples/rendezvous_holonomic_export.py:31-53` (without the export) through `Simulator`."""
+    from omgtools import (Holonomic, Fleet, Environment, Obstacle, RegularPolyhedron, Rectangle, Circle, Square,
+                          RendezVous, Simulator)
+    vehicles = [Holonomic(shapes=Circle(0.1), options={'room_constraints': None}) for _ in range(n)]
+    fleet = Fleet(vehicles)
+    configuration = RegularPolyhedron(0.2, n, np.pi / 4.).vertices.T
+    fleet.set_configuration(configuration.tolist())
+    fleet.set_initial_conditions([[0., 3.], [3., 3.], [3., 0.], [0., 0.]])
+    fleet.set_terminal_conditions(np.zeros((n, 2)).tolist())
+    environment = Environment(room={'shape': Square(5.), 'position': [1.5, 1.5]})
+    environment.add_obstacle(Obstacle({'position': [3.2, 1.0]}, shape=Rectangle(width=3., height=0.2)))
+    problem = RendezVous(fleet, environment, options={'rho': 2., 'horizon_time': 10, 'init_iter': 5, 'verbose': verbose},
+                         ops=ops)
+    problem.init()
+    simulator = Simulator(problem)
+    simulator.run()
+    return problem, vehicles, configuration
+
+
+def check_rendezvous_run(problem, vehicles, configuration):
+    """The vehicles end at rest, in the configured formation around a common point they were not told."""
+    ends = np.array([veh.signals['state'][:, -1] for veh in vehicles])
+    centre = (ends - configuration).mean(axis=0)
+    assert np.abs(ends - configuration - centre).max() < 5e-2
+    assert 0.5 < centre[0] < 2.5 and 0.5 < centre[1] < 2.5              # somewhere between the four corners
+    for veh in vehicles:
+        assert np.linalg.norm(veh.signals["input"][:, -1]) < 0.15          # (the stop criterium looks at positions only)
+        assert np.abs(veh.signals['input']).max() <= 0.5 + 3e-2
+    assert problem.iteration > 30
+
+
+def test_rendezvous_example_through_the_simulator_cpu():
+    from admm_numpy_ops import NumpyAdmmOps
+    out = rendezvous_example(lambda tpl, lay, p, x0, tol: NumpyAdmmOps(tpl, lay, p, x0, tol=tol))
+    check_rendezvous_run(*out)
+
+
+@pytest.mark.gpu
+def test_rendezvous_example_through_the_simulator_hip():
+    out = rendezvous_example('hip')
+    check_rendezvous_run(*out)
