@@ -18,7 +18,7 @@ import numpy as np
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libomgx.so')
+LIB_PATH = os.environ.get('OMGX_LIB') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libomgx.so')      # (OMGX_LIB: developer override, e.g. an experimental build)
 
 PTR_DEVICE, BOUNDS_SHARED, BOUNDS_DEVICE = 1, 2, 4
 
