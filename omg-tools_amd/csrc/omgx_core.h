@@ -1924,6 +1924,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     // practically undamped even while dw covers the active hyperplane rows elsewhere.
     int first_trial = 1;
     OMGX_PFOR(q, N) w.xt[q] = 0.0;
+    // weight of every row in the Lagrangian Hessian (multiplier x signed scale): one read per Hessian item instead of
+    // three (w.ht -- 1/s during the residual phase -- is free until the line search)
+    OMGX_PFOR(r, m) w.ht[r] = (w.rtype[r] != ROW_FREE) ? w.z[r] * w.rho[r] : 0.0;
     for (;;) {
       OMGX_PFOR(i, kkt_doubles) w.kkt[i] = 0.0;
       c.sync();
@@ -1996,7 +1999,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 #pragma unroll
             for (int i = 0; i < OMGX_REC_BATCH; ++i) {
               const int r = q[i].row < m ? q[i].row : 0;
-              const double lam = (q[i].row < m) ? ((w.rtype[r] != ROW_FREE) ? w.z[r] * w.rho[r] : 0.0) : 1.0;
+              const double lam = (q[i].row < m) ? w.ht[r] : 1.0;          // (row multiplier x signed scale, set below the residuals)
               const double xs = w.slots[q[i].slot < 0 ? 0 : q[i].slot], x3 = w.x[q[i].vthird < 0 ? 0 : q[i].vthird];
               h[i] = (q[i].kind ? 2.0 : 1.0) * lam * q[i].coef * (q[i].slot < 0 ? 1.0 : xs) * (q[i].vthird < 0 ? 1.0 : x3);
             }
@@ -2024,7 +2027,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 #pragma unroll
             for (int i = 0; i < OMGX_REC_BATCH; ++i) {
               const int r = q[i].row < m ? q[i].row : 0;
-              const double lam = (q[i].row < m) ? ((w.rtype[r] != ROW_FREE) ? w.z[r] * w.rho[r] : 0.0) : 1.0;
+              const double lam = (q[i].row < m) ? w.ht[r] : 1.0;
               const double xs = w.slots[q[i].slot < 0 ? 0 : q[i].slot], x3 = w.x[q[i].vthird < 0 ? 0 : q[i].vthird];
               const double h = lam * q[i].coef * (q[i].slot < 0 ? 1.0 : xs) * (q[i].vthird < 0 ? 1.0 : x3);
               g[i] = q[i].kind ? (h < 0.0 ? -2.0 * h : 0.0) : fabs(h);
