@@ -295,6 +295,8 @@ template <bool kHbm, bool kWaveOnly = false>
 struct CtxT {
   static constexpr bool hbm = kHbm;
   static constexpr bool wave_only = kWaveOnly;
+  // the wave-level routines address the KKT store as LDS: the spill-mode instances do not carry them
+  static constexpr bool no_wave = kHbm;
   double* red;
   long long* prof;
   // (opaque to the optimiser: otherwise every per-thread table address `base + tid * size` of every phase is
@@ -1390,7 +1392,7 @@ OMGX_FN void kkt_solve_wave(const C& c, const Dims& d, const Kkt& K, Work& w, do
 template <class C>
 OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
 #ifndef OMGX_HOST_PORT
-  if (C::wave_only || d.wave_ok) return kkt_factor_wave(c, d, K, w);
+  if constexpr (!C::no_wave) { if (C::wave_only || d.wave_ok) return kkt_factor_wave(c, d, K, w); }
 #ifdef OMGX_WAVE_GENERAL
   if (d.wave_leaf) return kkt_factor_wave_general(c, d, K, w);
 #endif
@@ -1509,7 +1511,8 @@ OMGX_FN void kkt_root_before_retry(const C& c, const Dims& d, const Kkt& K, Work
 template <class C>
 OMGX_FN int kkt_refactor_root(const C& c, const Dims& d, const Kkt& K, Work& w) {
 #ifndef OMGX_HOST_PORT
-  return kkt_refactor_root_wave(c, d, K, w);
+  if constexpr (C::no_wave) return 1;      // (never reached: Dims::wave_ok is 0 in the spill modes)
+  else return kkt_refactor_root_wave(c, d, K, w);
 #else
   int bad = 0;
   BMat* Ms = (BMat*)w.col;
@@ -1561,7 +1564,7 @@ OMGX_FN void trsv_bwd4(const C& c, const double* A, Addr L, int n, double* y, co
 template <class C>
 OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double* sol) {
 #ifndef OMGX_HOST_PORT
-  if (C::wave_only || d.wave_ok) { kkt_solve_wave(c, d, K, w, sol); return; }
+  if constexpr (!C::no_wave) { if (C::wave_only || d.wave_ok) { kkt_solve_wave(c, d, K, w, sol); return; } }
 #endif
   if constexpr (!C::wave_only) {
   double* yr = sol + d.root_off;
