@@ -770,8 +770,11 @@ OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* di
              g30 = db[6], g31 = db[7], g32 = db[8], g33 = db[9];
       double v0 = A[br + jb], v1 = A[br + jb + q1], v2 = A[br + jb + q2], v3 = A[br + jb + q3];
       const double m1 = nb > 1 ? 1.0 : 0.0, m2 = nb > 2 ? 1.0 : 0.0, m3 = nb > 3 ? 1.0 : 0.0;
+      // banded block (leaf in its Cuthill-McKee order, no fill outside the band): the block rows jb .. jb + 3 are
+      // zero left of column jb - bw, those columns contribute exact zeros
+      const int k0 = jb > M.bw ? jb - M.bw : 0;
 #pragma unroll 4
-      for (int k = 0; k < jb; ++k) {
+      for (int k = k0; k < jb; ++k) {
         const double tk = iv[k];
         const double u0 = A[b0 + k], u1 = m1 * A[b1 + k], u2 = m2 * A[b2 + k], u3 = m3 * A[b3 + k], ur = A[br + k];
         const double t0 = u0 * tk, t1 = u1 * tk, t2 = u2 * tk, t3 = u3 * tk;
