@@ -53,6 +53,7 @@ struct Dims {
   int n_eqe;    // Jacobian entries of the equality rows
   int max_leaf, max_cpl;
   int col_doubles;   // scratch for the blocked LDL' (staging + panel buffers)
+  int col_small;     // the same for the spill modes (left-looking leaf sweep only: inverse pivots + parked diagonal blocks per leaf): kept in LDS there
   int mono_packed;   // 1: every parameter monomial has <= 4 atoms, Tables::pm_rec is valid
   int n_hess;        // number of HessRec records
   int rp_packed;     // 1: rows and positions fit 16 bits each, Tables::je_rp is valid
@@ -213,7 +214,7 @@ struct Work {
 // Workspace placement.  Mode 0 keeps every array in LDS (the fast path: cfg 1/2/4).  Problems
 // whose arrays exceed the 160 KiB of one CU spill the largest ones to a per-workgroup slab in
 // HBM (L2/MALL-cached), largest first:
-//   mode 1  kkt + col            mode 2  + jval
+//   mode 1  kkt                  mode 2  + jval
 //   mode 3  + the eight [n_con] row arrays and rtype (only the O(n_var) vectors stay in LDS)
 enum { WS_LDS = 0, WS_KKT_HBM = 1, WS_JAC_HBM = 2, WS_ROWS_HBM = 3, WS_MODES = 4 };
 
@@ -227,7 +228,9 @@ OMGX_HD void work_split(const Dims& d, int kkt_doubles, int mode, size_t* lds, s
   const size_t rows = 8 * (size_t)d.n_con + (d.n_con + 1) / 2;
   (mode >= WS_ROWS_HBM ? ng : nl) += rows;
   (mode >= WS_JAC_HBM ? ng : nl) += d.nnz_j + 1;      // + one slot that stays 0.0 (padding records point at it)
-  (mode >= WS_KKT_HBM ? ng : nl) += (size_t)kkt_doubles + d.col_doubles;
+  // (the spill modes keep the matrix descriptors and the small panel scratch of the leaf sweep in LDS: every row of
+  // every block column reads them)
+  if (mode >= WS_KKT_HBM) { ng += (size_t)kkt_doubles; nl += d.col_small; } else nl += (size_t)kkt_doubles + d.col_doubles;
   *lds = nl; *hbm = ng;
 }
 
@@ -259,7 +262,7 @@ OMGX_HD void work_carve_split(Work& w, double* lds, double* hbm, const Dims& d, 
     w.rtype = (int32_t*)p; p += (d.n_con + 1) / 2;
   }
   if (MODE >= WS_JAC_HBM) { w.jval = g; g += d.nnz_j + 1; } else { w.jval = p; p += d.nnz_j + 1; }
-  if (MODE >= WS_KKT_HBM) { w.kkt = g; g += kkt_doubles; w.col = g; g += d.col_doubles; }
+  if (MODE >= WS_KKT_HBM) { w.kkt = g; g += kkt_doubles; w.col = p; p += d.col_small; }
   else { w.kkt = p; p += kkt_doubles; w.col = p; p += d.col_doubles; }
 }
 
@@ -272,7 +275,7 @@ OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
 // ---------------------------------------------------------------------------
 #ifdef OMGX_HOST_PORT
 struct Ctx {
-  static constexpr bool wave_only = false;
+  static constexpr bool wave_only = false, hbm = false, no_wave = false;
   double* red;
   int tid() const { return 0; }
   int nthr() const { return 1; }
@@ -654,6 +657,7 @@ struct Kkt {
 struct BMat { int a, ld, nfact, rows, npos, dinv, pan, cpl, bw, pad_; };   // cpl: offset of the leaf's coupling index list (cpl_ptr[l])   // a: offset in kkt; dinv: offset in w.dinv (-1: none); pan: offset in w.col
 static_assert(sizeof(BMat) <= OMGX_BMAT_DOUBLES * sizeof(double), "BMat larger than its LDS slot");
 #define OMGX_NB 4
+#define OMGX_PAN_SMALL(n) (4 * (n) + 16)      // per leaf in the spill modes: ldl_left4 keeps n inverse pivots + 10 doubles per 4 columns there
 #define OMGX_PAN_LD 5      // panel buffer row stride: U[4] + pad (odd: conflict-free row-per-lane access)
 #define OMGX_STAGE_LD 20   // per matrix: 4x4 block rows [16] + inverse pivots of the block [4]
 
@@ -1088,7 +1092,7 @@ OMGX_FN void kkt_describe(const C& c, const Dims& d, const Kkt& K, Work& w) {
     for (int l = 0; l < d.n_leaf; ++l) {
       BMat& M = Ms[l];
       M.a = K.d_off[l]; M.ld = K.ld(l); M.nfact = K.nl(l); M.rows = K.nl(l) + K.nc(l) + 1; M.npos = M.nfact;   // + the rhs row
-      M.dinv = K.leaf_off[l]; M.pan = pan; pan += OMGX_PAN_LD * M.rows; M.cpl = K.cpl_ptr[l]; M.bw = K.leaf_bw[l];
+      M.dinv = K.leaf_off[l]; M.pan = pan; pan += C::hbm ? OMGX_PAN_SMALL(M.nfact) : OMGX_PAN_LD * M.rows; M.cpl = K.cpl_ptr[l]; M.bw = K.leaf_bw[l];
     }
     BMat& Mr = Ms[d.n_leaf];
     Mr.a = K.d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr + 1; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0; Mr.cpl = 0; Mr.bw = d.nr;
@@ -1417,7 +1421,8 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
       }
       // a spare wave per leaf next to the row waves
       const bool coop = room && ((total_rows + 63) >> 6) + d.n_leaf <= c.nwaves();       // (leaf panels are row-major: baddr_k<1>)
-      if (coop) ldl_left4_coop<1>(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad, total_rows, nmax);
+      if constexpr (C::hbm) ldl_left4(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad);     // (the small panel scratch of the spill modes has no room for the cooperative form)
+      else if (coop) ldl_left4_coop<1>(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad, total_rows, nmax);
       else ldl_left4(c, Ms, d.n_leaf, w.kkt, w.dinv, w.col, &bad);
     }
 #endif
@@ -1463,13 +1468,26 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
         typedef double v4d __attribute__((ext_vector_type(4)));
         v4d acc = {0.0, 0.0, 0.0, 0.0};
         const int ra = 16 * ti + (lane & 15), rb = 16 * tj + (lane & 15), q = lane >> 4;
-        for (int j0 = 0; j0 < n; j0 += 4) {
-          const int j = j0 + q;
-          const int jc = j < n ? j : n - 1, rac = ra < nc ? ra : nc - 1, rbc = rb < nc ? rb : nc - 1;
-          const double wa = Wt[rac * ld + jc], wd = di[jc], wb = Wt[rbc * ld + jc];     // unconditional loads
-          const double av = (ra < nc && j < n) ? wa * wd : 0.0;
-          const double bv = (rb < nc && j < n) ? wb : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        const int rac = ra < nc ? ra : nc - 1, rbc = rb < nc ? rb : nc - 1;
+        const double* Wa = Wt + rac * ld;
+        const double* Wb = Wt + rbc * ld;
+        // eight K steps per round: their 24 loads are in flight together (in the spill modes every one of them is
+        // an L2 round trip; one step at a time the sweep over a 64-column leaf was 16 of them in a row)
+        for (int j0 = 0; j0 < n; j0 += 32) {
+          double wa[8], wb[8], wd[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + 4 * u + q;
+            const int jc = j < n ? j : n - 1;
+            wa[u] = Wa[jc]; wd[u] = di[jc]; wb[u] = Wb[jc];     // unconditional loads
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + 4 * u + q;
+            const double av = (ra < nc && j < n) ? wa[u] * wd[u] : 0.0;
+            const double bv = (rb < nc && j < n) ? wb[u] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          }
         }
         const int cb = 16 * tj + (lane & 15);
         for (int i = 0; i < 4; ++i) {

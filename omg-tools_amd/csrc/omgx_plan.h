@@ -237,6 +237,10 @@ struct HostPlan {
       d.col_doubles = (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + OMGX_PAN_LD * pr;
       const int wave_scratch = OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1) + 16 * 64;      // kkt_solve_wave: 64 doubles per wave
       if (d.col_doubles < wave_scratch) d.col_doubles = wave_scratch;
+      int small = 0;
+      for (int l = 0; l < d.n_leaf; ++l) small += OMGX_PAN_SMALL(leaf_off[l + 1] - leaf_off[l]);
+      if (small < OMGX_PAN_LD * (d.nr + 1)) small = OMGX_PAN_LD * (d.nr + 1);      // the root's panel buffer starts at the same offset
+      d.col_small = (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + small;
     }
     kkt_doubles = off;                           // (side and dump slots of the assembly are appended below)
     // the wave-level register routines apply when every panel fits one wave
