@@ -166,12 +166,13 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  double* __restrict__ x, double* __restrict__ lam, int32_t* __restrict__ status,
                  int32_t* __restrict__ iters, int n_agents, long long* __restrict__ prof,
                  double* __restrict__ slabs, size_t slab_doubles, double* __restrict__ dw_state,
-                 const int32_t* __restrict__ order, const StoreArgs* __restrict__ stp, int only_failed) {
+                 const int32_t* __restrict__ order, const StoreArgs* __restrict__ stp, int only_failed,
+                 int* __restrict__ next_slot) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
                                d, kkt_doubles);
-  omgx::CtxT<(MODE != omgx::WS_LDS), WAVE_ONLY> c; c.red = w.red;
+  omgx::CtxT<(MODE != omgx::WS_LDS), WAVE_ONLY, (MODE >= omgx::WS_ROWS_HBM)> c; c.red = w.red;
 #ifdef OMGX_PROFILE
   __shared__ long long prof_lds[omgx::PH_COUNT];
   c.prof = prof_lds;
@@ -182,8 +183,19 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   // slabs and every workgroup walks over its agents.
   // `order` (optional) maps launch slots to agents: the host can put expected stragglers first so
   // that their long solves overlap the rest of the batch instead of trailing it
-  for (int slot = blockIdx.x; slot < n_agents; slot += gridDim.x) {
+  // Spill modes hand the launch slots out dynamically (next_slot: a counter the host zeroes before the launch):
+  // solves differ by a factor of several in their iteration counts, and a fixed share of agents per workgroup would
+  // leave most of the chip waiting for the unluckiest one.  Which workgroup solves an agent does not change its result.
+  __shared__ int slot_lds;
+  for (int slot = blockIdx.x; slot < n_agents;) {
     const int b = order ? order[slot] : slot;
+    if (MODE == omgx::WS_LDS || !next_slot) slot += gridDim.x;
+    else {
+      if (threadIdx.x == 0) slot_lds = gridDim.x + atomicAdd(next_slot, 1);
+      __syncthreads();
+      slot = slot_lds;
+      __syncthreads();
+    }
     // restart pass (OMGX_ONLY_FAILED): agents that are solved already keep x, lam_g, status, iters
     if (only_failed && status[b] == 0) continue;
 #ifdef OMGX_PROFILE
@@ -225,7 +237,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
-                             const int32_t*, const StoreArgs*, int);
+                             const int32_t*, const StoreArgs*, int, int*);
 static ipm_kernel_t ipm_kernel_for(int mode, int wave_ok) {
   switch (mode) {
     case omgx::WS_LDS: return wave_ok ? ipm_solve_kernel<omgx::WS_LDS, true> : ipm_solve_kernel<omgx::WS_LDS, false>;
@@ -476,6 +488,7 @@ struct omgx_batch {
   double* d_slabs = nullptr;
   double* d_dw = nullptr;          // per-agent inertia correction carried between warm-started solves
   const int32_t* d_order = nullptr; // optional launch order (device pointer owned by the caller)
+  int* d_next = nullptr;            // spill modes: counter of the dynamic slot hand-out
   StoreArgs store = {};             // trajectories written by the solve kernel (omgx_batch_set_store); out == nullptr: off
   StoreArgs* d_store = nullptr;     // its copy in device memory (what the kernel reads)
   std::vector<void*> allocs;
@@ -758,6 +771,7 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
     if (slabs > n_agents) slabs = n_agents;
     b->n_slabs = slabs;
     if ((rc = dalloc(b, (size_t)slabs * b->slab_doubles, &b->d_slabs))) { omgx_batch_destroy(b); return rc; }
+    if ((rc = dalloc(b, (size_t)1, &b->d_next))) { omgx_batch_destroy(b); return rc; }
   } else {
     b->n_slabs = n_agents;
   }
@@ -849,10 +863,12 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
     HIPCHK(hipMemcpyAsync(b->d_ub, ubg, nb * sizeof(double), hipMemcpyHostToDevice, b->stream));
     klb = b->d_lb; kub = b->d_ub;
   }
+  if (b->d_next) HIPCHK(hipMemsetAsync(b->d_next, 0, sizeof(int), b->stream));
   if (b->timing) HIPCHK(hipEventRecord(b->ev0, b->stream));
   hipLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok), dim3(b->n_slabs), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev,
                      b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
-                     b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, b->store.out ? b->d_store : nullptr, (flags & OMGX_ONLY_FAILED) ? 1 : 0);
+                     b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, b->store.out ? b->d_store : nullptr, (flags & OMGX_ONLY_FAILED) ? 1 : 0,
+                     b->d_next);
   HIPCHK(hipGetLastError());
   if (b->timing) HIPCHK(hipEventRecord(b->ev1, b->stream));
   b->timed = b->timing;

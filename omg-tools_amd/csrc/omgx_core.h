@@ -206,6 +206,7 @@ struct Work {
   double *gbar, *sol;             // [N], [N + n_eq]   position order
   double *kkt;                    // D_l (packed) | B_l | R (packed)
   double *col;                    // [col_doubles] blocked-LDL' staging + panel buffers
+  double *root;                   // mode 3 only: LDS copy of the packed root block (+ its right-hand-side row) from the Schur step on
   double *dinv;                   // [N] inverse leaf pivots
   int32_t *rtype;                 // [n_con]
   double *red;                    // reduction scratch [64]
@@ -218,6 +219,8 @@ struct Work {
 //   mode 3  + the eight [n_con] row arrays and rtype (only the O(n_var) vectors stay in LDS)
 enum { WS_LDS = 0, WS_KKT_HBM = 1, WS_JAC_HBM = 2, WS_ROWS_HBM = 3, WS_MODES = 4 };
 
+OMGX_HD size_t root_doubles(const Dims& d) { return ((size_t)(d.nr + 1) * (d.nr + 2)) / 2; }
+
 OMGX_HD void work_split(const Dims& d, int kkt_doubles, int mode, size_t* lds, size_t* hbm) {
   size_t nl = 0, ng = 0;
   nl += d.n_atoms + d.n_slots + d.n_knots;
@@ -227,6 +230,7 @@ OMGX_HD void work_split(const Dims& d, int kkt_doubles, int mode, size_t* lds, s
   nl += 64;                       // red
   const size_t rows = 8 * (size_t)d.n_con + (d.n_con + 1) / 2;
   (mode >= WS_ROWS_HBM ? ng : nl) += rows;
+  if (mode >= WS_ROWS_HBM) nl += root_doubles(d);      // (with the row arrays out of LDS there is room for the root block)
   (mode >= WS_JAC_HBM ? ng : nl) += d.nnz_j + 1;      // + one slot that stays 0.0 (padding records point at it)
   // (the spill modes keep the matrix descriptors and the small panel scratch of the leaf sweep in LDS: every row of
   // every block column reads them)
@@ -264,6 +268,7 @@ OMGX_HD void work_carve_split(Work& w, double* lds, double* hbm, const Dims& d, 
   if (MODE >= WS_JAC_HBM) { w.jval = g; g += d.nnz_j + 1; } else { w.jval = p; p += d.nnz_j + 1; }
   if (MODE >= WS_KKT_HBM) { w.kkt = g; g += kkt_doubles; w.col = p; p += d.col_small; }
   else { w.kkt = p; p += kkt_doubles; w.col = p; p += d.col_doubles; }
+  if (MODE >= WS_ROWS_HBM) { w.root = p; p += root_doubles(d); } else w.root = nullptr;
 }
 
 OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
@@ -275,7 +280,7 @@ OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
 // ---------------------------------------------------------------------------
 #ifdef OMGX_HOST_PORT
 struct Ctx {
-  static constexpr bool wave_only = false, hbm = false, no_wave = false;
+  static constexpr bool wave_only = false, hbm = false, no_wave = false, root_lds = false;
   double* red;
   int tid() const { return 0; }
   int nthr() const { return 1; }
@@ -294,9 +299,10 @@ struct Ctx {
 #else
 // kWaveOnly: the kernel instance for templates whose panels all fit one wave (Dims::wave_ok): the blocked LDS
 // routines are not compiled into it
-template <bool kHbm, bool kWaveOnly = false>
+template <bool kHbm, bool kWaveOnly = false, bool kRootLds = false>
 struct CtxT {
   static constexpr bool hbm = kHbm;
+  static constexpr bool root_lds = kRootLds;      // Work::root holds the root block from the Schur step on (mode 3)
   static constexpr bool wave_only = kWaveOnly;
   // the wave-level routines address the KKT store as LDS: the spill-mode instances do not carry them
   static constexpr bool no_wave = kHbm;
@@ -1095,7 +1101,8 @@ OMGX_FN void kkt_describe(const C& c, const Dims& d, const Kkt& K, Work& w) {
       M.dinv = K.leaf_off[l]; M.pan = pan; pan += C::hbm ? OMGX_PAN_SMALL(M.nfact) : OMGX_PAN_LD * M.rows; M.cpl = K.cpl_ptr[l]; M.bw = K.leaf_bw[l];
     }
     BMat& Mr = Ms[d.n_leaf];
-    Mr.a = K.d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr + 1; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0; Mr.cpl = 0; Mr.bw = d.nr;
+    Mr.a = C::root_lds ? 0 : K.d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr + 1; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0; Mr.cpl = 0; Mr.bw = d.nr;
+    Mr.pad_ = K.d_off[d.n_leaf];      // where the assembly writes the root block (Mr.a: where the factorisation reads it)
   }
   c.sync();
 }
@@ -1433,7 +1440,15 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   }
   OMGX_TOC(PH_F_LEAF);
   // Schur complement onto the root:  R[ci[a]][ci[b]] -= sum_j Wt[a][j] Wt[b][j] / d_j
-  double* R = K.R();
+  // (mode 3: from here on the root block lives in LDS -- the Schur updates, its factorisation and its substitutions
+  // are read-modify-write chains on a few thousand doubles; nothing reads the store's copy again)
+  if constexpr (C::root_lds) {
+    const double* Rg = K.R();
+    const int nrd = ((d.nr + 1) * (d.nr + 2)) / 2;
+    OMGX_PFOR(i, nrd) w.root[i] = Rg[i];
+    c.sync();
+  }
+  double* R = C::root_lds ? w.root : K.R();
 #ifdef OMGX_HOST_PORT
   for (int l = 0; l < d.n_leaf; ++l) {
     const int n = K.nl(l), nc = K.nc(l), ld = K.ld(l);
@@ -1510,7 +1525,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   // the host twin of "a failed root factorisation leaves the store untouched" (kkt_refactor_root): keep a copy
   if (d.wave_ok) omgx_rbak.assign(R, R + ((size_t)(d.nr + 1) * (d.nr + 2)) / 2);
 #endif
-  ldl_blocked<2>(c, Ms + d.n_leaf, 1, w.kkt, w.dinv, w.col, stage, &bad);
+  ldl_blocked<2>(c, Ms + d.n_leaf, 1, C::root_lds ? w.root : w.kkt, w.dinv, w.col, stage, &bad);
   OMGX_TOC(PH_F_ROOT);
 #ifdef OMGX_COUNT_FACT
   if (bad) ++omgx_dbg_cnt[1];
@@ -1602,7 +1617,8 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
   }
   {
     const int rbase = Ms[d.n_leaf].a, nr = d.nr;
-    OMGX_PFOR(k, nr) yr[k] = w.kkt[rbase + tri(nr, k)] / w.kkt[rbase + tri(k, k)];
+    const double* rootp = C::root_lds ? w.root : w.kkt;
+    OMGX_PFOR(k, nr) yr[k] = rootp[rbase + tri(nr, k)] / rootp[rbase + tri(k, k)];
   }
   c.sync();
   OMGX_TOC(PH_K_FWD);
@@ -1610,7 +1626,7 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
   if (c.wave() == 0) {
     const int n = d.nr, rbase = Ms[d.n_leaf].a;
     auto Lr = [=](int i, int j) { return rbase + tri(i, j); };
-    trsv_bwd4(c, w.kkt, Lr, n, yr);
+    trsv_bwd4(c, C::root_lds ? w.root : w.kkt, Lr, n, yr);
   }
   c.sync();
   OMGX_TOC(PH_K_ROOT);
@@ -1653,7 +1669,7 @@ OMGX_FN void kkt_rhs(const C& c, const Dims& d, const Tables& T, Work& w, double
     const BMat M = Ms[l];
     w.kkt[M.a + (M.rows - 1) * M.ld + (q - M.dinv)] = -w.gbar[q];
   }
-  const int rbase = Ms[d.n_leaf].a, nr = d.nr;
+  const int rbase = Ms[d.n_leaf].pad_, nr = d.nr;
   OMGX_PFOR(k, nr) {
     double v;
     if (k < d.n_root) v = -w.gbar[d.root_off + k];
