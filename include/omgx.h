@@ -143,6 +143,14 @@ int  omgx_batch_set_order(omgx_batch* b, const int32_t* order_device);
  * written by omgx_batch_solve), largest first, on the handle's stream, and install it as the
  * launch order (the receding-horizon loop calls this before every warm-started solve). */
 int  omgx_batch_order_by_iters(omgx_batch* b, const int32_t* iters_device, int32_t* order_device);
+/* Restart guesses for the following COLD solves (device-pointer solves; warm-started solves ignore them):
+ * x0_alt_device [n_alt][n_agents][n_var] (device pointer, owned by the caller; n_alt = 0 / NULL switches it off).
+ * An agent that does not reach Solve_Succeeded from x0 is solved again from x0_alt[0], then x0_alt[1], ... inside the
+ * same launch, by the workgroup that holds it; x, lam_g, status and iters are those of its last attempt.
+ * attempts_device (optional, [n_agents] int32 on the device) receives the number of restarts each agent used.
+ * The reference has no such retry (`problems/problem.py:113`: its user re-initialises by hand); the results
+ * equal separate OMGX_ONLY_FAILED passes from the same guesses. */
+int  omgx_batch_set_restarts(omgx_batch* b, const double* x0_alt_device, int32_t n_alt, int32_t* attempts_device);
 /* LDS bytes the solve kernel needs per agent (for diagnostics / DESIGN.md). */
 int  omgx_batch_lds_bytes(const omgx_batch* b);
 /* Workspace placement chosen at create: mode 0 = every per-agent array in LDS; 1 = KKT store and

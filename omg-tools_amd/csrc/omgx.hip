@@ -167,7 +167,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  int32_t* __restrict__ iters, int n_agents, long long* __restrict__ prof,
                  double* __restrict__ slabs, size_t slab_doubles, double* __restrict__ dw_state,
                  const int32_t* __restrict__ order, const StoreArgs* __restrict__ stp, int only_failed,
-                 int* __restrict__ next_slot) {
+                 int* __restrict__ next_slot, const double* __restrict__ x0_alt, int n_alt, int32_t* __restrict__ attempts) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
@@ -205,10 +205,21 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 #endif
     const double* lbb = lb + (bounds_shared ? 0 : (size_t)b * d.n_con);
     const double* ubb = ub + (bounds_shared ? 0 : (size_t)b * d.n_con);
-    omgx::Result r = omgx::ipm_solve(c, d, T, o, w, p + (size_t)b * d.n_par, x0 + (size_t)b * d.n_var,
-                                     lbb, ubb, o.warm_start ? lam + (size_t)b * d.n_con : nullptr,
-                                     o.warm_start ? status[b] : 0, kkt_doubles, o.warm_start ? dw_state[b] : 0.0);
-    __syncthreads();
+    // Restart guesses (omgx_batch_set_restarts; cold solves only): an agent that does not converge from x0 is solved
+    // again from x0_alt[0], x0_alt[1], ... by the same workgroup right away -- a separate pass over the failed agents
+    // would leave the chip to a handful of them for as long as their slowest solve takes.
+    omgx::Result r;
+    int attempt = 0;
+    for (;;) {
+      const double* xs = attempt == 0 ? x0 + (size_t)b * d.n_var : x0_alt + ((size_t)(attempt - 1) * n_agents + b) * d.n_var;
+      r = omgx::ipm_solve(c, d, T, o, w, p + (size_t)b * d.n_par, xs,
+                          lbb, ubb, o.warm_start ? lam + (size_t)b * d.n_con : nullptr,
+                          o.warm_start ? status[b] : 0, kkt_doubles, o.warm_start ? dw_state[b] : 0.0);
+      __syncthreads();
+      if (r.status == 0 || o.warm_start || attempt >= n_alt) break;
+      ++attempt;
+    }
+    if (attempts && threadIdx.x == 0) attempts[b] = attempt;
     for (int i = threadIdx.x; i < d.n_var; i += blockDim.x) x[(size_t)b * d.n_var + i] = w.x[i];
     for (int q = threadIdx.x; q < d.n_con; q += blockDim.x)
       lam[(size_t)b * d.n_con + q] =
@@ -237,7 +248,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
-                             const int32_t*, const StoreArgs*, int, int*);
+                             const int32_t*, const StoreArgs*, int, int*, const double*, int, int32_t*);
 static ipm_kernel_t ipm_kernel_for(int mode, int wave_ok) {
   switch (mode) {
     case omgx::WS_LDS: return wave_ok ? ipm_solve_kernel<omgx::WS_LDS, true> : ipm_solve_kernel<omgx::WS_LDS, false>;
@@ -489,6 +500,9 @@ struct omgx_batch {
   double* d_dw = nullptr;          // per-agent inertia correction carried between warm-started solves
   const int32_t* d_order = nullptr; // optional launch order (device pointer owned by the caller)
   int* d_next = nullptr;            // spill modes: counter of the dynamic slot hand-out
+  const double* d_x0_alt = nullptr; // restart guesses [n_alt][n_agents][n_var] (device, owned by the caller)
+  int n_alt = 0;
+  int32_t* d_attempts = nullptr;    // optional [n_agents] (device, owned by the caller): restarts each agent used
   StoreArgs store = {};             // trajectories written by the solve kernel (omgx_batch_set_store); out == nullptr: off
   StoreArgs* d_store = nullptr;     // its copy in device memory (what the kernel reads)
   std::vector<void*> allocs;
@@ -812,6 +826,14 @@ int omgx_batch_set_order(omgx_batch* b, const int32_t* order_device) {
   return OMGX_OK;
 }
 
+int omgx_batch_set_restarts(omgx_batch* b, const double* x0_alt_device, int32_t n_alt, int32_t* attempts_device) {
+  if (!b || n_alt < 0 || (n_alt > 0 && !x0_alt_device)) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  b->d_x0_alt = n_alt > 0 ? x0_alt_device : nullptr;
+  b->n_alt = n_alt;
+  b->d_attempts = attempts_device;
+  return OMGX_OK;
+}
+
 int omgx_batch_order_by_iters(omgx_batch* b, const int32_t* iters_device, int32_t* order_device) {
   if (!b || !iters_device || !order_device) { g_err = "null argument"; return OMGX_E_INVALID; }
   HIPCHK(hipSetDevice(b->device));
@@ -868,7 +890,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   hipLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok), dim3(b->n_slabs), dim3(kThreads), b->lds_bytes, b->stream, d, b->dev,
                      b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
                      b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, b->store.out ? b->d_store : nullptr, (flags & OMGX_ONLY_FAILED) ? 1 : 0,
-                     b->d_next);
+                     b->d_next, b->d_x0_alt, b->d_x0_alt ? b->n_alt : 0, b->d_attempts);
   HIPCHK(hipGetLastError());
   if (b->timing) HIPCHK(hipEventRecord(b->ev1, b->stream));
   b->timed = b->timing;

@@ -341,6 +341,19 @@ class BatchSolver(object):
             self._h, ptr(p), ptr(x0), ptr(lbg), ptr(ubg), ptr(x), ptr(lam_g), ptr(status),
             ptr(iters), flags), 'omgx_batch_solve')
 
+    def set_restarts(self, x0_alt=None, attempts=None):
+        """Restart guesses of the following cold device solves (include/omgx.h omgx_batch_set_restarts): x0_alt
+        [n_alt, B, n_var] device tensor or None, attempts [B] int32 device tensor or None.  The caller keeps both
+        alive until the solves are done."""
+        self.lib.omgx_batch_set_restarts.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        n_alt = 0 if x0_alt is None else int(x0_alt.shape[0])
+        if n_alt and (tuple(x0_alt.shape[1:]) != (self.n_agents, self.template.n_var) or not x0_alt.is_contiguous()):
+            raise ValueError("x0_alt must be a contiguous [n_alt, %d, %d] tensor" % (self.n_agents, self.template.n_var))
+        _check(self.lib, self.lib.omgx_batch_set_restarts(
+            self._h, x0_alt.data_ptr() if n_alt else None, n_alt,
+            attempts.data_ptr() if attempts is not None else None), 'omgx_batch_set_restarts')
+        self._restart_keep = (x0_alt, attempts)
+
     def sync(self):
         _check(self.lib, self.lib.omgx_batch_sync(self._h), 'omgx_batch_sync')
 

@@ -175,37 +175,55 @@ class BatchP2P(object):
                                 **dict(self.opts, max_iter=self.max_iter_step if warm else self.max_iter_cold))
             self.x, self.lam, self.status, self.iters = r['x'], r['lam_g'], r['status'], r['iters']
 
-    def solve_cold(self, bends=(1.0, -1.0, 2.5, -2.5)):
+    def solve_cold(self, bends=(1.0, -1.0, 2.5, -2.5), fused=True):
         """Cold solve from the reference's initial guess (`get_init_spline_value`: coefficients on the straight
         line).  Agents that do not converge from it (phase I stalls: e.g. 5 % of the Quadrotor class with its five
         moving obstacles) are solved again from the same guess bent sideways by `bends[0]`, then `bends[1]` ... metres
         at mid-course -- a different side of the obstacles; the reference has no such retry (its user would
-        re-initialise by hand), `bends=()` switches it off.  Returns the number of restart passes."""
-        self._solve(False)
-        return self.restart_failed(bends)
+        re-initialise by hand), `bends=()` switches it off.  fused: the restarts run inside the launch of the first
+        attempt (`omgx_batch_set_restarts`), else as separate passes over the failed agents (`restart_failed`) --
+        same guesses, same results.  Returns the largest number of restarts an agent needed."""
+        if self.kind != 'hip' or not bends:
+            self._solve(False)
+            return 0
+        if not fused:
+            self._solve(False)
+            return self.restart_failed(bends)
+        t = self.torch
+        alts = t.stack([self._bent(self.x, s) for s in bends]).contiguous()
+        attempts = t.zeros(self.B, dtype=t.int32, device=self.dev)
+        self.solver.set_restarts(alts, attempts)
+        try:
+            self._solve(False)
+        finally:
+            self.solver.set_restarts(None)
+        return int(attempts.max().item())
+
+    def _bent(self, x_first, s):
+        """The initial guess x_first with its spline coefficients moved sideways (perpendicular to start -> goal in
+        the x-y plane) by s * sin^2(pi * k / (L - 1)) metres."""
+        t = self.torch
+        L, ns = self.L, self.n_spl
+        c = x_first[:, self.o_spl:self.o_spl + ns * L].reshape(self.B, ns, L)
+        d = c[:, :, -1] - c[:, :, 0]
+        d = d / d.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        nrm = t.zeros_like(d)
+        nrm[:, 0], nrm[:, 1] = -d[:, 1], d[:, 0]
+        nrm = nrm / nrm.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        bump = t.sin(t.linspace(0., 1., L, dtype=t.float64, device=self.dev) * np.pi) ** 2
+        alt = x_first.clone()
+        alt[:, self.o_spl:self.o_spl + ns * L] += (float(s) * nrm[:, :, None] * bump[None, None, :]).reshape(self.B, -1)
+        return alt
 
     def restart_failed(self, bends=(1.0, -1.0, 2.5, -2.5)):
         """Restart passes of a cold solve (see solve_cold); returns how many were needed."""
         passes = 0
         if self.kind != 'hip' or not bends:
             return passes
-        t = self.torch
-        x_first = None
         for s in bends:
             if bool((self.status == 0).all()):
                 break
-            if x_first is None:
-                x_first = self._x_init            # the guess the first pass started from
-                L, ns = self.L, self.n_spl
-                c = x_first[:, self.o_spl:self.o_spl + ns * L].reshape(self.B, ns, L)
-                d = c[:, :, -1] - c[:, :, 0]
-                d = d / d.norm(dim=1, keepdim=True).clamp_min(1e-12)
-                nrm = t.zeros_like(d)             # a unit vector perpendicular to start -> goal (in the x-y plane)
-                nrm[:, 0], nrm[:, 1] = -d[:, 1], d[:, 0]
-                nrm = nrm / nrm.norm(dim=1, keepdim=True).clamp_min(1e-12)
-                bump = t.sin(t.linspace(0., 1., L, dtype=t.float64, device=self.dev) * np.pi) ** 2
-            alt = x_first.clone()
-            alt[:, self.o_spl:self.o_spl + ns * L] += (float(s) * nrm[:, :, None] * bump[None, None, :]).reshape(self.B, -1)
+            alt = self._bent(self._x_init, s)      # (_x_init: the guess the first pass started from)
             # the solved agents sit in self.x (the output of the last pass): they are skipped and keep it
             self.solver.set_options(warm_start=0, max_iter=self.max_iter_cold)
             self.solver.solve_device(self.p, alt, self.lb, self.ub, self.x, self.lam, self.status, self.iters,

@@ -180,5 +180,13 @@ def test_restart_pass_solves_only_the_failed_agents():
     lam = mpc.lam.cpu().numpy()
     for b in failed[:4]:
         assert_kkt(nlp, problem.father.template, P['p'][b], x1[b], lam[b], 1e-2, ('restart', b))
+    # the same restarts as separate OMGX_ONLY_FAILED passes: same guesses, same bits
+    sep = BatchP2P(problem, P, ops='hip', options=opts)
+    passes_sep = sep.solve_cold(fused=False)
+    assert passes_sep == passes
+    assert np.array_equal(sep.x.cpu().numpy(), x1) and np.array_equal(sep.status.cpu().numpy(), st1)
+    assert np.array_equal(sep.iters.cpu().numpy(), mpc.iters.cpu().numpy())
+    assert np.array_equal(sep.lam.cpu().numpy(), lam)
     plain.solver.close()
     mpc.solver.close()
+    sep.solver.close()
