@@ -4,7 +4,7 @@ Each builder returns (problem, P) where `problem` is an initialised single-agent
 `Point2point` (its template is shared by the whole batch) and P is a dict of
 per-agent arrays: 'p' [B, n_par] parameter vectors in the template's layout,
 'x0' [B, n_var] initial guesses (`get_init_spline_value`, hyperplanes zero), and for
-the Quadrotor / 3-D classes 'solver_options' (settings of the HIP solver that suit the
+the Quadrotor class 'solver_options' (settings of the HIP solver that suit the
 class, like the per-problem `solver_options` of the reference's examples).
 """
 import numpy as np
@@ -122,8 +122,8 @@ def quadrotor_p2p(n_agents, knot_intervals=13, n_obs=5, seed=20240807 + 3, horiz
         _set(tpl, p, b, problem.label, 'T', horizon_time)
         _straight_line(tpl, x0, b, vehicle, start, goal, clamp=vehicle.degree)
     # cold starts of this class: barrier parameter from 1 instead of 0.1 (82 -> 57 iterations on average, the
-    # same agents converge); asymmetric inertia weights as for the 3-D class
-    return problem, {'p': p, 'x0': x0, 'solver_options': {'dw_leaf_ratio_cold': 0.3, 'mu_init': 1.0}}
+    # same agents converge)
+    return problem, {'p': p, 'x0': x0, 'solver_options': {'mu_init': 1.0}}
 
 
 def holonomic3d_p2p(n_agents, knot_intervals=15, n_obs=10, seed=20240807 + 5, horizon_time=12.,
@@ -161,7 +161,7 @@ def holonomic3d_p2p(n_agents, knot_intervals=15, n_obs=10, seed=20240807 + 5, ho
             _set(tpl, p, b, obs.label, 'rad', radii[l])
         _set(tpl, p, b, problem.label, 'T', horizon_time)
         _straight_line(tpl, x0, b, vehicle, start, goal)
-    return problem, {'p': p, 'x0': x0, 'solver_options': {'dw_leaf_ratio_cold': 0.3}}
+    return problem, {'p': p, 'x0': x0, 'solver_options': {}}
 
 
 def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0, horizon_time=10.,
