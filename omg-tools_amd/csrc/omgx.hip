@@ -557,6 +557,19 @@ int pick_mode(const omgx::Dims& d, int kkt_doubles, size_t* lds_doubles, size_t*
   return mode;
 }
 
+// The plan of a template for the workspace mode it gets: the spill modes store the leaf panels by columns
+// (omgx_plan.h `col_major`), so their plan is built a second time once the mode is known.
+bool plan_for_mode(omgx::HostPlan& plan, const omgx_template& t, int* mode, size_t* lds_doubles, size_t* hbm_doubles) {
+  if (!plan.build(t)) return false;
+  *mode = pick_mode(plan.dims, plan.kkt_doubles, lds_doubles, hbm_doubles);
+  if (*mode != omgx::WS_LDS && *mode != omgx::WS_MODES) {
+    plan = omgx::HostPlan();
+    if (!plan.build(t, true)) return false;
+    omgx::work_split(plan.dims, plan.kkt_doubles, *mode, lds_doubles, hbm_doubles);
+  }
+  return true;
+}
+
 int check_template(const omgx_template* t) {
   if (!t || t->n_var <= 0 || t->n_par < 0 || t->n_con < 0 || t->n_terms < 0 || t->n_eq < 0 || t->n_root_vars < 0 ||
       !t->row_ptr || (t->n_terms > 0 && (!t->t_coef || !t->t_slot || !t->t_var)) || (t->n_eq > 0 && !t->eq_rows) ||
@@ -566,11 +579,11 @@ int check_template(const omgx_template* t) {
 
 int build_batch(omgx_batch* b, const omgx_template* t) {
   omgx::HostPlan plan;
-  if (!plan.build(*t)) { g_err = "inconsistent template: " + plan.error; return OMGX_E_INVALID; }
+  size_t nl = 0, ng = 0;
+  int mode = 0;
+  if (!plan_for_mode(plan, *t, &mode, &nl, &ng)) { g_err = "inconsistent template: " + plan.error; return OMGX_E_INVALID; }
   b->dims = plan.dims;
   b->kkt_doubles = plan.kkt_doubles;
-  size_t nl = 0, ng = 0;
-  const int mode = pick_mode(plan.dims, plan.kkt_doubles, &nl, &ng);
   if (mode == omgx::WS_MODES) {
     char buf[160];
     snprintf(buf, sizeof buf, "per-agent O(n_var) vectors (%zu B) exceed the %d B LDS of one CU", nl * sizeof(double), kLdsLimit);
@@ -636,13 +649,14 @@ int omgx_plan_describe(const omgx_template* tpl, omgx_plan_info* info, int32_t* 
   int rc = check_template(tpl);
   if (rc != OMGX_OK) return rc;
   omgx::HostPlan plan;
-  if (!plan.build(*tpl)) { g_err = "inconsistent template: " + plan.error; return OMGX_E_INVALID; }
+  size_t nl = 0, ng = 0;
+  int mode = 0;
+  if (!plan_for_mode(plan, *tpl, &mode, &nl, &ng)) { g_err = "inconsistent template: " + plan.error; return OMGX_E_INVALID; }
   const omgx::Dims& d = plan.dims;
   memset(info, 0, sizeof *info);
   info->n_leaf = d.n_leaf; info->n_root = d.n_root; info->n_eq = d.n_eq; info->nnz_j = d.nnz_j;
   info->kkt_doubles = plan.kkt_doubles; info->wave_path = d.wave_ok;
-  size_t nl = 0, ng = 0;
-  info->ws_mode = pick_mode(d, plan.kkt_doubles, &nl, &ng);
+  info->ws_mode = mode;
   info->lds_bytes = (int64_t)(nl * sizeof(double));
   for (int l = 0; l < d.n_leaf && l < OMGX_PLAN_MAX_LEAF; ++l) {
     info->leaf_size[l] = plan.leaf_off[l + 1] - plan.leaf_off[l];

@@ -634,14 +634,6 @@ struct Kkt {
   OMGX_FN double* R() const { return a + d_off[n_leaf]; }
   OMGX_FN int nl(int l) const { return leaf_off[l + 1] - leaf_off[l]; }
   OMGX_FN int nc(int l) const { return cpl_ptr[l + 1] - cpl_ptr[l]; }
-  // address of entry (p, q), positions with p >= q, p,q < N
-  OMGX_FN double* at(int p, int q) const {
-    const int ro = root_off;
-    if (p < ro) { const int l = blk[p], o = leaf_off[l]; return P(l) + (p - o) * ld(l) + (q - o); }
-    if (q < ro) { const int l = blk[q]; const int arow = cpl_map[l * n_root + (p - ro)];
-                  return P(l) + (nl(l) + arow) * ld(l) + (q - leaf_off[l]); }
-    return R() + tri(p - ro, q - ro);
-  }
 };
 
 // ---------------------------------------------------------------------------
@@ -670,6 +662,10 @@ static_assert(sizeof(BMat) <= OMGX_BMAT_DOUBLES * sizeof(double), "BMat larger t
 // (branch-free on purpose: with `ld ? row-major : packed` as a conditional the compiler sinks the
 // LDS load that uses the address into the two branches, and a sequence of such loads -- the ten
 // entries of a diagonal block -- becomes ten serialised round trips)
+// Leaf panels are stored by rows in the LDS modes (odd leading dimension: one thread per row is conflict-free) and
+// by columns in the spill modes (one thread per row then reads consecutive addresses of the HBM slab; the plan
+// writes its precomputed addresses the same way, omgx_plan.h `col_major`): entry (r, k) = a + r * sr + k * sc.
+#define OMGX_PANEL_STRIDES(C, M, sr, sc) const int sr = C::hbm ? 1 : (M).ld, sc = C::hbm ? (M).ld : 1
 OMGX_FN int baddr(const BMat& M, int r, int k) { return M.a + r * M.ld + (M.ld == 0 ? 1 : 0) * ((r * (r + 1)) >> 1) + k; }
 // storage kind known at compile time (one multiply instead of two and a select per address):
 // KIND 0 generic, 1 row-major (leaf panels), 2 packed lower (root)
@@ -757,7 +753,8 @@ OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* di
     const BMat M = Ms[mi];
     const int a = e < 1 ? 0 : (e < 3 ? 1 : (e < 6 ? 2 : 3)), k = e - ((a * (a + 1)) >> 1);
     const int ra = 4 * blk + a, ck = 4 * blk + k;
-    colb[M.pan + M.nfact + 10 * blk + e] = (ra < M.nfact) ? A[baddr(M, ra, ck)] : (a == k ? 1.0 : 0.0);
+    OMGX_PANEL_STRIDES(C, M, sr, sc);
+    colb[M.pan + M.nfact + 10 * blk + e] = (ra < M.nfact) ? A[M.a + ra * sr + ck * sc] : (a == k ? 1.0 : 0.0);
   }
   c.sync();
   OMGX_TOC(PH_F_PARK);
@@ -774,11 +771,12 @@ OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* di
       const bool diag_row = r < jb + nb;
       // block rows (clamped for a partial last block: their products are masked below)
       const int q1 = nb > 1 ? 1 : 0, q2 = nb > 2 ? 2 : 0, q3 = nb > 3 ? 3 : 0;
-      const int b0 = baddr(M, jb, 0), b1 = baddr(M, jb + q1, 0), b2 = baddr(M, jb + q2, 0), b3 = baddr(M, jb + q3, 0);
-      const int br = baddr(M, r, 0);
+      OMGX_PANEL_STRIDES(C, M, sr, sc);
+      const int b0 = M.a + jb * sr, b1 = M.a + (jb + q1) * sr, b2 = M.a + (jb + q2) * sr, b3 = M.a + (jb + q3) * sr;
+      const int br = M.a + r * sr;
       double g00 = db[0], g10 = db[1], g11 = db[2], g20 = db[3], g21 = db[4], g22 = db[5],
              g30 = db[6], g31 = db[7], g32 = db[8], g33 = db[9];
-      double v0 = A[br + jb], v1 = A[br + jb + q1], v2 = A[br + jb + q2], v3 = A[br + jb + q3];
+      double v0 = A[br + jb * sc], v1 = A[br + (jb + q1) * sc], v2 = A[br + (jb + q2) * sc], v3 = A[br + (jb + q3) * sc];
       const double m1 = nb > 1 ? 1.0 : 0.0, m2 = nb > 2 ? 1.0 : 0.0, m3 = nb > 3 ? 1.0 : 0.0;
       // banded block (leaf in its Cuthill-McKee order, no fill outside the band): the block rows jb .. jb + 3 are
       // zero left of column jb - bw, those columns contribute exact zeros
@@ -786,7 +784,7 @@ OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* di
 #pragma unroll 4
       for (int k = k0; k < jb; ++k) {
         const double tk = iv[k];
-        const double u0 = A[b0 + k], u1 = m1 * A[b1 + k], u2 = m2 * A[b2 + k], u3 = m3 * A[b3 + k], ur = A[br + k];
+        const double u0 = A[b0 + k * sc], u1 = m1 * A[b1 + k * sc], u2 = m2 * A[b2 + k * sc], u3 = m3 * A[b3 + k * sc], ur = A[br + k * sc];
         const double t0 = u0 * tk, t1 = u1 * tk, t2 = u2 * tk, t3 = u3 * tk;
         g00 -= u0 * t0;
         g10 -= u1 * t0; g11 -= u1 * t1;
@@ -803,19 +801,19 @@ OMGX_FN void ldl_left4(const C& c, const BMat* Ms, int nm, double* A, double* di
         if (!pos_ok) badl = 1;
         iv[jb + q] = iq;
         // U = L D inside the block, the pivot itself on the diagonal
-        if (q == 1) { A[br + jb] = B.l10 * B.d0; }
-        else if (q == 2) { A[br + jb] = B.l20 * B.d0; A[br + jb + 1] = B.l21 * B.d1; }
-        else if (q == 3) { A[br + jb] = B.l30 * B.d0; A[br + jb + 1] = B.l31 * B.d1; A[br + jb + 2] = B.l32 * B.d2; }
-        A[br + jb + q] = dq;
+        if (q == 1) { A[br + jb * sc] = B.l10 * B.d0; }
+        else if (q == 2) { A[br + jb * sc] = B.l20 * B.d0; A[br + (jb + 1) * sc] = B.l21 * B.d1; }
+        else if (q == 3) { A[br + jb * sc] = B.l30 * B.d0; A[br + (jb + 1) * sc] = B.l31 * B.d1; A[br + (jb + 2) * sc] = B.l32 * B.d2; }
+        A[br + (jb + q) * sc] = dq;
       } else {
         const double u0 = v0;
         const double u1 = v1 - u0 * B.l10;
         const double u2 = v2 - u0 * B.l20 - u1 * B.l21;
         const double u3 = v3 - u0 * B.l30 - u1 * B.l31 - u2 * B.l32;
-        A[br + jb] = u0;
-        if (nb > 1) A[br + jb + 1] = u1;
-        if (nb > 2) A[br + jb + 2] = u2;
-        if (nb > 3) A[br + jb + 3] = u3;
+        A[br + jb * sc] = u0;
+        if (nb > 1) A[br + (jb + 1) * sc] = u1;
+        if (nb > 2) A[br + (jb + 2) * sc] = u2;
+        if (nb > 3) A[br + (jb + 3) * sc] = u3;
       }
     }
     c.sync();
@@ -1472,8 +1470,9 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
     for (int l = 0; l < d.n_leaf; ++l) {
       const BMat M = Ms[l];                       // dimensions from LDS, not from the global plan tables
       // carried rows: nc - 1 coupling rows + the right-hand-side row (last), which maps to row nr of the root
-      const int n = M.nfact, nc = M.rows - M.nfact, ld = M.ld;
-      const double* Wt = w.kkt + M.a + n * ld;
+      const int n = M.nfact, nc = M.rows - M.nfact;
+      OMGX_PANEL_STRIDES(C, M, sr, sc);
+      const double* Wt = w.kkt + M.a + n * sr;
       const double* di = w.dinv + M.dinv;
       const int32_t* ci = K.cpl_idx + M.cpl;
       const int tn = (nc + 15) >> 4, nwm = c.nwaves() - 1;
@@ -1484,8 +1483,8 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
         v4d acc = {0.0, 0.0, 0.0, 0.0};
         const int ra = 16 * ti + (lane & 15), rb = 16 * tj + (lane & 15), q = lane >> 4;
         const int rac = ra < nc ? ra : nc - 1, rbc = rb < nc ? rb : nc - 1;
-        const double* Wa = Wt + rac * ld;
-        const double* Wb = Wt + rbc * ld;
+        const double* Wa = Wt + rac * sr;
+        const double* Wb = Wt + rbc * sr;
         // eight K steps per round: their 24 loads are in flight together (in the spill modes every one of them is
         // an L2 round trip; one step at a time the sweep over a 64-column leaf was 16 of them in a row)
         for (int j0 = 0; j0 < n; j0 += 32) {
@@ -1494,7 +1493,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
           for (int u = 0; u < 8; ++u) {
             const int j = j0 + 4 * u + q;
             const int jc = j < n ? j : n - 1;
-            wa[u] = Wa[jc]; wd[u] = di[jc]; wb[u] = Wb[jc];     // unconditional loads
+            wa[u] = Wa[jc * sc]; wd[u] = di[jc]; wb[u] = Wb[jc * sc];     // unconditional loads
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
@@ -1613,7 +1612,8 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
     int l = 0;
     while (q >= Ms[l].dinv + Ms[l].nfact) ++l;
     const BMat M = Ms[l];
-    sol[q] = w.kkt[M.a + (M.rows - 1) * M.ld + (q - M.dinv)] * w.dinv[q];
+    OMGX_PANEL_STRIDES(C, M, sr, sc);
+    sol[q] = w.kkt[M.a + (M.rows - 1) * sr + (q - M.dinv) * sc] * w.dinv[q];
   }
   {
     const int rbase = Ms[d.n_leaf].a, nr = d.nr;
@@ -1636,21 +1636,23 @@ OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double*
     int l = 0;
     while (q >= Ms[l].dinv + Ms[l].nfact) ++l;
     const BMat M = Ms[l];
-    const int n = M.nfact, nc = M.rows - 1 - M.nfact, ld = M.ld, j = q - M.dinv;
-    const double* Pn = w.kkt + M.a + n * ld + j;
+    const int n = M.nfact, nc = M.rows - 1 - M.nfact, j = q - M.dinv;
+    OMGX_PANEL_STRIDES(C, M, sr, sc);
+    const double* Pn = w.kkt + M.a + n * sr + j * sc;
     const int32_t* ci = K.cpl_idx + M.cpl;
     double acc = 0.0;
 #pragma unroll 4
-    for (int a = 0; a < nc; ++a) acc += Pn[a * ld] * yr[ci[a]];
+    for (int a = 0; a < nc; ++a) acc += Pn[a * sr] * yr[ci[a]];
     sol[q] -= acc * w.dinv[q];
   }
   c.sync();
   OMGX_TOC(PH_K_LEAFRHS);
   for (int l = c.wave(); l < d.n_leaf; l += c.nwaves()) {
     const BMat M = Ms[l];
-    const int n = M.nfact, ld = M.ld, base = M.a;
+    const int n = M.nfact, base = M.a;
+    OMGX_PANEL_STRIDES(C, M, sr, sc);
     double* yl = sol + M.dinv;
-    trsv_bwd4(c, w.kkt, [=](int i, int j) { return base + i * ld + j; }, n, yl, w.dinv + M.dinv);   // panels hold U = L D
+    trsv_bwd4(c, w.kkt, [=](int i, int j) { return base + i * sr + j * sc; }, n, yl, w.dinv + M.dinv);   // panels hold U = L D
   }
   c.sync();
   OMGX_TOC(PH_K_BWD);
@@ -1667,7 +1669,8 @@ OMGX_FN void kkt_rhs(const C& c, const Dims& d, const Tables& T, Work& w, double
     int l = 0;
     while (q >= Ms[l].dinv + Ms[l].nfact) ++l;
     const BMat M = Ms[l];
-    w.kkt[M.a + (M.rows - 1) * M.ld + (q - M.dinv)] = -w.gbar[q];
+    OMGX_PANEL_STRIDES(C, M, sr, sc);
+    w.kkt[M.a + (M.rows - 1) * sr + (q - M.dinv) * sc] = -w.gbar[q];
   }
   const int rbase = Ms[d.n_leaf].pad_, nr = d.nr;
   OMGX_PFOR(k, nr) {

@@ -203,7 +203,11 @@ struct HostPlan {
     return bin;
   }
 
-  bool build(const omgx_template& t) {
+  // col_major: leaf panels column by column (the spill modes: one thread per panel row then reads consecutive
+  // addresses of the HBM slab; the LDS modes keep rows with an odd leading dimension, conflict-free there)
+  bool col_major = false;
+  bool build(const omgx_template& t, bool col_major_panels = false) {
+    col_major = col_major_panels;
     Dims& d = dims;
     d = Dims();
     d.n_var = t.n_var; d.n_par = t.n_par; d.n_con = t.n_con; d.n_atoms = t.n_atoms;
@@ -227,7 +231,8 @@ struct HostPlan {
       const int ld = n | 1;                        // odd leading dimension: conflict-free row-per-lane access
       // rows [0,n): D_l, rows [n,n+nc): coupling rows B_l, row n+nc: the right-hand side of the leaf
       // (carried through the factorisation like a coupling row: it comes out as L^{-1} r)
-      d_off[l] = off; b_off[l] = ld; off += (n + nc + 1) * ld;
+      if (col_major) { const int ldc = (n + nc + 2) & ~1; d_off[l] = off; b_off[l] = ldc; off += n * ldc; }      // (even: columns start 16-byte aligned)
+      else { d_off[l] = off; b_off[l] = ld; off += (n + nc + 1) * ld; }
     }
     d_off[d.n_leaf] = off; off += (d.nr + 1) * (d.nr + 2) / 2;      // packed root + its right-hand-side row
     {
@@ -292,12 +297,13 @@ struct HostPlan {
     auto tri = [](int i, int k) { return i * (i + 1) / 2 + k; };
     auto addr = [&](int p, int q) -> int32_t {               // p >= q, positions
       const int ro = d.root_off;
-      if (p < ro) { const int l = blk[p], o = leaf_off[l]; if (blk[q] != l) return -1; return d_off[l] + (p - o) * b_off[l] + (q - o); }
+      if (p < ro) { const int l = blk[p], o = leaf_off[l]; if (blk[q] != l) return -1;
+                    return col_major ? d_off[l] + (q - o) * b_off[l] + (p - o) : d_off[l] + (p - o) * b_off[l] + (q - o); }
       if (q < ro) {
         const int l = blk[q], n = leaf_off[l + 1] - leaf_off[l];
         const int arow = cpl_map[(size_t)l * d.n_root + (p - ro)];
         if (arow < 0) return -1;
-        return d_off[l] + (n + arow) * b_off[l] + (q - leaf_off[l]);
+        return col_major ? d_off[l] + (q - leaf_off[l]) * b_off[l] + (n + arow) : d_off[l] + (n + arow) * b_off[l] + (q - leaf_off[l]);
       }
       return d_off[d.n_leaf] + tri(p - ro, q - ro);
     };

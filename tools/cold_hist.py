@@ -1,5 +1,6 @@
 import sys, os, time
-sys.path.insert(0, 'omg-tools_amd')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
 import numpy as np, torch
 import omgtools.backend as be
 from omgtools import scenarios
