@@ -153,9 +153,10 @@ int  omgx_batch_order_by_iters(omgx_batch* b, const int32_t* iters_device, int32
 int  omgx_batch_set_restarts(omgx_batch* b, const double* x0_alt_device, int32_t n_alt, int32_t* attempts_device);
 /* LDS bytes the solve kernel needs per agent (for diagnostics / DESIGN.md). */
 int  omgx_batch_lds_bytes(const omgx_batch* b);
-/* Workspace placement chosen at create: mode 0 = every per-agent array in LDS; 1 = KKT store and
- * factorisation panels in an HBM slab; 2 = + Jacobian values; 3 = + the per-row arrays (only the
- * O(n_var) vectors stay in LDS).  Spill modes run min(n_agents, n_slabs) persistent workgroups. */
+/* Workspace placement chosen at create: mode 0 = every per-agent array in LDS; 1 = KKT store in an
+ * HBM slab (leaf panels by columns); 2 = + Jacobian values; 3 = + the per-row arrays (the O(n_var)
+ * vectors, the matrix descriptors and a copy of the root block stay in LDS).  Spill modes run
+ * min(n_agents, n_slabs) persistent workgroups that take their agents from an atomic counter. */
 int  omgx_batch_workspace(const omgx_batch* b, int32_t* mode, int64_t* lds_bytes,
                           int64_t* hbm_bytes_per_slab, int32_t* n_slabs);
 
