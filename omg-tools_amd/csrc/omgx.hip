@@ -172,7 +172,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
                                d, kkt_doubles);
-  omgx::CtxT<(MODE != omgx::WS_LDS), WAVE_ONLY, (MODE >= omgx::WS_ROWS_HBM)> c; c.red = w.red;
+  omgx::CtxT<(MODE != omgx::WS_LDS), WAVE_ONLY, (MODE != omgx::WS_LDS)> c; c.red = w.red;
 #ifdef OMGX_PROFILE
   __shared__ long long prof_lds[omgx::PH_COUNT];
   c.prof = prof_lds;

@@ -188,6 +188,8 @@ struct Opts {
 #define OMGX_WARM_ZMIN   1e-8
 #define OMGX_MAX_LEAF    16
 #define OMGX_BMAT_DOUBLES 5      // sizeof(BMat) / 8
+#define OMGX_PAN_LD 5      // panel buffer row stride: U[4] + pad (odd: conflict-free row-per-lane access)
+#define OMGX_STAGE_LD 20   // per matrix: 4x4 block rows [16] + inverse pivots of the block [4]
 #define OMGX_MIN_LEAF    8       // smaller components are gathered into one leaf
 #define OMGX_NBIN        512     // owner bins of the assembly passes (= threads of the solve workgroup)
 #define OMGX_REC_BATCH   8       // records an owner loads at a time (all in flight together)
@@ -206,7 +208,7 @@ struct Work {
   double *gbar, *sol;             // [N], [N + n_eq]   position order
   double *kkt;                    // D_l (packed) | B_l | R (packed)
   double *col;                    // [col_doubles] blocked-LDL' staging + panel buffers
-  double *root;                   // mode 3 only: LDS copy of the packed root block (+ its right-hand-side row) from the Schur step on
+  double *root;                   // spill modes: LDS copy of the packed root block (+ its right-hand-side row) from the Schur step on (inside col)
   double *dinv;                   // [N] inverse leaf pivots
   int32_t *rtype;                 // [n_con]
   double *red;                    // reduction scratch [64]
@@ -230,7 +232,6 @@ OMGX_HD void work_split(const Dims& d, int kkt_doubles, int mode, size_t* lds, s
   nl += 64;                       // red
   const size_t rows = 8 * (size_t)d.n_con + (d.n_con + 1) / 2;
   (mode >= WS_ROWS_HBM ? ng : nl) += rows;
-  if (mode >= WS_ROWS_HBM) nl += root_doubles(d);      // (with the row arrays out of LDS there is room for the root block)
   (mode >= WS_JAC_HBM ? ng : nl) += d.nnz_j + 1;      // + one slot that stays 0.0 (padding records point at it)
   // (the spill modes keep the matrix descriptors and the small panel scratch of the leaf sweep in LDS: every row of
   // every block column reads them)
@@ -268,7 +269,9 @@ OMGX_HD void work_carve_split(Work& w, double* lds, double* hbm, const Dims& d, 
   if (MODE >= WS_JAC_HBM) { w.jval = g; g += d.nnz_j + 1; } else { w.jval = p; p += d.nnz_j + 1; }
   if (MODE >= WS_KKT_HBM) { w.kkt = g; g += kkt_doubles; w.col = p; p += d.col_small; }
   else { w.kkt = p; p += kkt_doubles; w.col = p; p += d.col_doubles; }
-  if (MODE >= WS_ROWS_HBM) { w.root = p; p += root_doubles(d); } else w.root = nullptr;
+  // spill modes: the root block is copied behind the root's panel buffer before the Schur updates -- over the leaf
+  // sweep's scratch, which is dead by then (Dims::col_small covers both)
+  w.root = MODE >= WS_KKT_HBM ? w.col + (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + OMGX_PAN_LD * (d.nr + 1) : nullptr;
 }
 
 OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
@@ -302,7 +305,7 @@ struct Ctx {
 template <bool kHbm, bool kWaveOnly = false, bool kRootLds = false>
 struct CtxT {
   static constexpr bool hbm = kHbm;
-  static constexpr bool root_lds = kRootLds;      // Work::root holds the root block from the Schur step on (mode 3)
+  static constexpr bool root_lds = kRootLds;      // Work::root holds the root block from the Schur step on (spill modes)
   static constexpr bool wave_only = kWaveOnly;
   // the wave-level routines address the KKT store as LDS: the spill-mode instances do not carry them
   static constexpr bool no_wave = kHbm;
@@ -656,8 +659,6 @@ struct BMat { int a, ld, nfact, rows, npos, dinv, pan, cpl, bw, pad_; };   // cp
 static_assert(sizeof(BMat) <= OMGX_BMAT_DOUBLES * sizeof(double), "BMat larger than its LDS slot");
 #define OMGX_NB 4
 #define OMGX_PAN_SMALL(n) (4 * (n) + 16)      // per leaf in the spill modes: ldl_left4 keeps n inverse pivots + 10 doubles per 4 columns there
-#define OMGX_PAN_LD 5      // panel buffer row stride: U[4] + pad (odd: conflict-free row-per-lane access)
-#define OMGX_STAGE_LD 20   // per matrix: 4x4 block rows [16] + inverse pivots of the block [4]
 
 // (branch-free on purpose: with `ld ? row-major : packed` as a conditional the compiler sinks the
 // LDS load that uses the address into the two branches, and a sequence of such loads -- the ten
@@ -1438,7 +1439,7 @@ OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
   }
   OMGX_TOC(PH_F_LEAF);
   // Schur complement onto the root:  R[ci[a]][ci[b]] -= sum_j Wt[a][j] Wt[b][j] / d_j
-  // (mode 3: from here on the root block lives in LDS -- the Schur updates, its factorisation and its substitutions
+  // (spill modes: from here on the root block lives in LDS -- the Schur updates, its factorisation and its substitutions
   // are read-modify-write chains on a few thousand doubles; nothing reads the store's copy again)
   if constexpr (C::root_lds) {
     const double* Rg = K.R();

@@ -244,7 +244,8 @@ struct HostPlan {
       if (d.col_doubles < wave_scratch) d.col_doubles = wave_scratch;
       int small = 0;
       for (int l = 0; l < d.n_leaf; ++l) small += OMGX_PAN_SMALL(leaf_off[l + 1] - leaf_off[l]);
-      if (small < OMGX_PAN_LD * (d.nr + 1)) small = OMGX_PAN_LD * (d.nr + 1);      // the root's panel buffer starts at the same offset
+      // the root's panel buffer starts at the same offset, followed by the LDS copy of the root block (Work::root)
+      { const int rootpart = OMGX_PAN_LD * (d.nr + 1) + (int)root_doubles(d); if (small < rootpart) small = rootpart; }
       d.col_small = (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + small;
     }
     kkt_doubles = off;                           // (side and dump slots of the assembly are appended below)
