@@ -169,6 +169,8 @@ def latency_episodes(mpc, x0_init, p_init, n_ep, n_steps, host):
                 torch.cuda.synchronize()
                 ok += int((st_h == 0).sum())
             else:
+                a.record()                  # (creates the handles; the library re-stamps both on the solve kernel's dispatch)
+                b.record()
                 mpc.step(events=(a, b))
                 ok += int((mpc.status == 0).sum().item())
             evs.append((a, b))
@@ -418,7 +420,7 @@ def main():
     torch.cuda.synchronize()
     # ---- receding-horizon steps: SURVEY.md 8d protocol (cold solve, then warm-started steps) ----
     # per-step statistics are logged on the device (no host sync inside the timed region): the
-    # solve kernel is bracketed by events on the stream it is launched on (torch's current stream,
+    # solve kernel carries two events on its own dispatch packet (stream = torch's current stream,
     # handed to the library with set_stream), status / iteration counts are copied into [K, B] logs
     K, W = args.steps, args.warmup
     # (status and iteration counts live in one [2, B] array, so that logging a step is a single copy)
@@ -426,6 +428,10 @@ def main():
     mpc.status, mpc.iters = si[0], si[1]
     si_log = torch.zeros((W + K, 2, B), dtype=torch.int32, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(W + K)]
+    for a, b in ev:                         # (torch creates the HIP event on the first record: their handles go to the
+        a.record()                          # library, which attaches them to the solve kernel's dispatch packet --
+        b.record()                          # begin / end stamps of the kernel itself, nothing extra on the stream)
+    torch.cuda.synchronize()
     for k in range(W + K):
         if k == W:
             barrier()

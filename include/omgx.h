@@ -170,9 +170,13 @@ int  omgx_batch_solve(omgx_batch* b, const double* p, const double* x0,
                       double* x, double* lam_g, int32_t* status, int32_t* iters,
                       int32_t flags);
 int  omgx_batch_sync(omgx_batch* b);
-/* Device time (ms, HIP events on the handle's stream) of the last solve kernel.  The two event records per solve
- * cost ~10 us of stream time each; a resident loop that does its own timing switches them off
- * (omgx_batch_set_timing(b, 0): omgx_batch_last_kernel_ms then fails until a timed solve has run again). */
+/* Attach two hipEvent_t (as void*, created by the caller with timing enabled) to the NEXT solve launch only: they
+ * receive the begin and end stamps of the solve kernel itself (carried by its dispatch packet, no extra packets on
+ * the stream).  hipEventElapsedTime(start, stop) after the launch completed = the kernel's duration. */
+int  omgx_batch_set_launch_events(omgx_batch* b, void* start_event, void* stop_event);
+/* Device time (ms) of the last solve kernel from the handle's own event pair (attached to the dispatch like the
+ * caller's pair above).  omgx_batch_set_timing(b, 0) switches it off: omgx_batch_last_kernel_ms then fails until
+ * a timed solve has run again; a launch that carried the caller's pair is not timed by the handle's. */
 int  omgx_batch_set_timing(omgx_batch* b, int32_t on);
 int  omgx_batch_last_kernel_ms(omgx_batch* b, double* ms);
 

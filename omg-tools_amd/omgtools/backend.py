@@ -354,6 +354,19 @@ class BatchSolver(object):
             attempts.data_ptr() if attempts is not None else None), 'omgx_batch_set_restarts')
         self._restart_keep = (x0_alt, attempts)
 
+    def set_launch_events(self, start, stop):
+        """Attach two timing events to the next solve launch (include/omgx.h omgx_batch_set_launch_events): torch.cuda
+        events (already recorded once, so that their handles exist) or raw hipEvent_t handles.  They get the begin /
+        end stamps of the solve kernel itself; nothing else is put on the stream."""
+        def handle(e):
+            h = e.cuda_event if hasattr(e, 'cuda_event') else int(e)
+            if not h:
+                raise ValueError('the event has no handle yet: record it once before handing it over')
+            return h
+        self.lib.omgx_batch_set_launch_events.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(self.lib, self.lib.omgx_batch_set_launch_events(self._h, handle(start), handle(stop)),
+               'omgx_batch_set_launch_events')
+
     def sync(self):
         _check(self.lib, self.lib.omgx_batch_sync(self._h), 'omgx_batch_sync')
 

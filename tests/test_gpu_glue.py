@@ -190,3 +190,34 @@ def test_restart_pass_solves_only_the_failed_agents():
     plain.solver.close()
     mpc.solver.close()
     sep.solver.close()
+
+
+def test_launch_events_time_the_solve_kernel_itself():
+    """omgx_batch_set_launch_events: the caller's events ride on the dispatch packet of the next solve kernel (one
+    launch only); the handle's own timing (last_kernel_ms) uses the same mechanism and agrees."""
+    import time
+    import torch
+    from omgtools.batch import BatchP2P
+    problem, P = _setup(64)
+    mpc = BatchP2P(problem, P, ops='hip', options=dict(tol=1e-3, max_iter=300))
+    mpc.solver.set_timing(True)
+    mpc.solve_cold(bends=())
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with pytest.raises(ValueError):
+        mpc.solver.set_launch_events(a, b)                 # no handle before the first record
+    a.record()
+    b.record()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mpc.step(events=(a, b))
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    ms = a.elapsed_time(b)
+    assert 0.01 < ms < wall_ms
+    assert (mpc.status == 0).all()
+    # one shot: the next launch is timed by the handle's own pair again
+    mpc.step()
+    torch.cuda.synchronize()
+    own = mpc.solver.last_kernel_ms()
+    assert 0.01 < own < 50.0 and a.elapsed_time(b) == ms
+    mpc.solver.close()
