@@ -421,34 +421,34 @@ def main():
     # ---- receding-horizon steps: SURVEY.md 8d protocol (cold solve, then warm-started steps) ----
     # per-step statistics are logged on the device (no host sync inside the timed region): the
     # solve kernel carries two events on its own dispatch packet (stream = torch's current stream,
-    # handed to the library with set_stream), status / iteration counts are copied into [K, B] logs
+    # handed to the library with set_stream), the per-step counts (solved agents, sum and maximum of the iteration
+    # counts) are added up by the solve kernel itself in a [W + K, 4] device array (omgx_batch_set_stats)
     K, W = args.steps, args.warmup
-    # (status and iteration counts live in one [2, B] array, so that logging a step is a single copy)
-    si = torch.stack([mpc.status, mpc.iters])
-    mpc.status, mpc.iters = si[0], si[1]
-    si_log = torch.zeros((W + K, 2, B), dtype=torch.int32, device=dev)
+    stats = torch.zeros((W + K, 4), dtype=torch.int64, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(W + K)]
     for a, b in ev:                         # (torch creates the HIP event on the first record: their handles go to the
         a.record()                          # library, which attaches them to the solve kernel's dispatch packet --
         b.record()                          # begin / end stamps of the kernel itself, nothing extra on the stream)
     torch.cuda.synchronize()
+    solver.set_stats(stats)
     for k in range(W + K):
         if k == W:
             barrier()
             t0 = time.perf_counter()
         mpc.step(events=ev[k])
-        si_log[k].copy_(si)
     barrier()
     elapsed = time.perf_counter() - t0
-    st_log, it_log = si_log[:, 0], si_log[:, 1]
+    solver.set_stats(None)
+    stats = stats.cpu().numpy()             # rows: {solved, sum of iterations, largest iteration count, agents}
+    assert (stats[:, 3] == B).all()
     all_ms = [a.elapsed_time(b) for a, b in ev]
     kernel_ms = all_ms[W:]
-    n_ok = float((st_log[W:] == 0).sum().item()) / K           # solved agents per step (mean)
-    it_sum = int(it_log[W:].sum().item())
+    n_ok = float(stats[W:, 0].sum()) / K                       # solved agents per step (mean)
+    it_sum = int(stats[W:, 1].sum())
     n_meas = K
     # every launch of the solve kernel in this process (what `rocprofv3 --stats` averages over)
     launches_ms = cold_kernel_all + all_ms            # (restart passes, if any, are further launches: not in this list)
-    launches_iters = len(cold_kernel_all) * cold_iters + int(it_log.sum().item())
+    launches_iters = len(cold_kernel_all) * cold_iters + int(stats[:, 1].sum())
     elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist if world > 1 else None)
     if rank != 0:
         return
@@ -471,7 +471,7 @@ def main():
                    'agents_per_gpu': B, 'n_var': tpl.n_var, 'n_con': tpl.n_con,
                    'parallelism': 'agents sharded across ranks, no collective on the solve path'},
         'p50_batch_latency_ms': float(np.median(kernel_ms)), 'max_batch_latency_ms': float(np.max(kernel_ms)),
-        'max_iters_in_a_step': int(it_log.max().item()),
+        'max_iters_in_a_step': int(stats[:, 2].max()),
         'solved_fraction': n_ok / float(B), 'mean_iters': it_sum / float(n_meas * B),
         # co-headline: the cold solve of the whole batch from the reference's initial guess (SURVEY 8d target
         # >= 1e4 solves/s), with its own roofline object
@@ -494,7 +494,7 @@ def main():
                      'note': 'algorithmic flops = sum(iters) x (n^3/3+2n^2), n=n_var (SURVEY 8d); achieved/kernel_ms '
                              'over the timed steps, all_launches = cold solves + warm-up + timed steps (the set '
                              'rocprofv3 --stats averages)'},
-        'step_kernel_ms': [round(v, 3) for v in kernel_ms], 'step_max_iters': it_log[W:].max(dim=1).values.tolist(),
+        'step_kernel_ms': [round(v, 3) for v in kernel_ms], 'step_max_iters': [int(v) for v in stats[W:, 2]],
     }
     if world == 1 and not args.no_extras:
         out['latency_resident'] = latency_episodes(mpc, x0_init, p_init, 5, 40, host=False)

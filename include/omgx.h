@@ -170,6 +170,12 @@ int  omgx_batch_solve(omgx_batch* b, const double* p, const double* x0,
                       double* x, double* lam_g, int32_t* status, int32_t* iters,
                       int32_t flags);
 int  omgx_batch_sync(omgx_batch* b);
+/* Launch statistics without a host round trip: stats_device [n_slots][4] int64 on the device, zeroed and owned
+ * by the caller (n_slots = 0 / NULL switches it off).  The k-th solve launch after this call adds into row
+ * k % n_slots: {agents that ended with Solve_Succeeded, sum of their iteration counts over all agents it solved,
+ * largest iteration count, agents it solved} -- integer atomics from inside the solve kernel.  A monitoring hook for
+ * resident receding-horizon loops (the reference prints these per solve, `problems/problem.py:113-127`). */
+int  omgx_batch_set_stats(omgx_batch* b, int64_t* stats_device, int32_t n_slots);
 /* Attach two hipEvent_t (as void*, created by the caller with timing enabled) to the NEXT solve launch only: they
  * receive the begin and end stamps of the solve kernel itself (carried by its dispatch packet, no extra packets on
  * the stream).  hipEventElapsedTime(start, stop) after the launch completed = the kernel's duration. */

@@ -168,7 +168,8 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  int32_t* __restrict__ iters, int n_agents, long long* __restrict__ prof,
                  double* __restrict__ slabs, size_t slab_doubles, double* __restrict__ dw_state,
                  const int32_t* __restrict__ order, const StoreArgs* __restrict__ stp, int only_failed,
-                 int* __restrict__ next_slot, const double* __restrict__ x0_alt, int n_alt, int32_t* __restrict__ attempts) {
+                 int* __restrict__ next_slot, const double* __restrict__ x0_alt, int n_alt, int32_t* __restrict__ attempts,
+                 unsigned long long* __restrict__ stats) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
@@ -225,7 +226,15 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
     for (int q = threadIdx.x; q < d.n_con; q += blockDim.x)
       lam[(size_t)b * d.n_con + q] =
           (r.status == 3 || w.rtype[q] == omgx::ROW_FREE) ? 0.0 : w.rho[q] * w.z[q];
-    if (threadIdx.x == 0) { status[b] = r.status; iters[b] = r.iters; dw_state[b] = r.dw; }
+    if (threadIdx.x == 0) {
+      status[b] = r.status; iters[b] = r.iters; dw_state[b] = r.dw;
+      if (stats) {      // launch statistics (omgx_batch_set_stats): integer atomics, the same totals in any order
+        atomicAdd(stats + 0, r.status == 0 ? 1ull : 0ull);
+        atomicAdd(stats + 1, (unsigned long long)r.iters);
+        atomicMax(stats + 2, (unsigned long long)r.iters);
+        atomicAdd(stats + 3, 1ull);
+      }
+    }
     if (stp) {
       // `Vehicle.store` fused behind the solve (reference `vehicles/vehicle.py:250-300`): the trajectories of
       // this agent straight from the solution in LDS; the KKT store is free now and serves as scratch
@@ -249,7 +258,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
-                             const int32_t*, const StoreArgs*, int, int*, const double*, int, int32_t*);
+                             const int32_t*, const StoreArgs*, int, int*, const double*, int, int32_t*, unsigned long long*);
 static ipm_kernel_t ipm_kernel_for(int mode, int wave_ok) {
   switch (mode) {
     case omgx::WS_LDS: return wave_ok ? ipm_solve_kernel<omgx::WS_LDS, true> : ipm_solve_kernel<omgx::WS_LDS, false>;
@@ -504,6 +513,8 @@ struct omgx_batch {
   const double* d_x0_alt = nullptr; // restart guesses [n_alt][n_agents][n_var] (device, owned by the caller)
   int n_alt = 0;
   int32_t* d_attempts = nullptr;    // optional [n_agents] (device, owned by the caller): restarts each agent used
+  int64_t* d_stats = nullptr;       // optional [stats_slots][4] launch statistics (device, owned by the caller)
+  int stats_slots = 0; long long stats_launch = 0;
   StoreArgs store = {};             // trajectories written by the solve kernel (omgx_batch_set_store); out == nullptr: off
   StoreArgs* d_store = nullptr;     // its copy in device memory (what the kernel reads)
   std::vector<void*> allocs;
@@ -913,7 +924,8 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
                         e0, e1, 0u, d, b->dev,
                         b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
                         b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, (const StoreArgs*)(b->store.out ? b->d_store : nullptr), (flags & OMGX_ONLY_FAILED) ? 1 : 0,
-                        b->d_next, b->d_x0_alt, b->d_x0_alt ? b->n_alt : 0, b->d_attempts);
+                        b->d_next, b->d_x0_alt, b->d_x0_alt ? b->n_alt : 0, b->d_attempts,
+                        (unsigned long long*)(b->d_stats ? b->d_stats + 4 * (size_t)(b->stats_launch++ % b->stats_slots) : nullptr));
   HIPCHK(hipGetLastError());
   if (!dev) {
     HIPCHK(hipMemcpyAsync(x, b->d_x, (size_t)B * d.n_var * sizeof(double), hipMemcpyDeviceToHost, b->stream));
@@ -936,6 +948,13 @@ int omgx_batch_phase_cycles(omgx_batch* b, long long* out) {   // profiling buil
 int omgx_batch_sync(omgx_batch* b) {
   if (!b) return OMGX_E_INVALID;
   HIPCHK(hipStreamSynchronize(b->stream));
+  return OMGX_OK;
+}
+
+int omgx_batch_set_stats(omgx_batch* b, int64_t* stats_device, int32_t n_slots) {
+  if (!b || n_slots < 0 || (n_slots > 0 && !stats_device)) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  b->d_stats = n_slots > 0 ? stats_device : nullptr;
+  b->stats_slots = n_slots; b->stats_launch = 0;
   return OMGX_OK;
 }
 

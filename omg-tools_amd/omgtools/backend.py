@@ -354,6 +354,17 @@ class BatchSolver(object):
             attempts.data_ptr() if attempts is not None else None), 'omgx_batch_set_restarts')
         self._restart_keep = (x0_alt, attempts)
 
+    def set_stats(self, stats=None):
+        """Launch statistics on the device (include/omgx.h omgx_batch_set_stats): stats [n_slots, 4] int64 device
+        tensor (zeroed by the caller, kept alive by it) or None; row k % n_slots of the k-th following solve gets
+        {solved agents, sum of iterations, largest iteration count, agents solved}."""
+        self.lib.omgx_batch_set_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        if stats is not None and (stats.dim() != 2 or stats.shape[1] != 4 or not stats.is_contiguous() or stats.element_size() != 8):
+            raise ValueError('stats must be a contiguous [n_slots, 4] int64 tensor')
+        _check(self.lib, self.lib.omgx_batch_set_stats(self._h, stats.data_ptr() if stats is not None else None,
+                                                        int(stats.shape[0]) if stats is not None else 0), 'omgx_batch_set_stats')
+        self._stats_keep = stats
+
     def set_launch_events(self, start, stop):
         """Attach two timing events to the next solve launch (include/omgx.h omgx_batch_set_launch_events): torch.cuda
         events (already recorded once, so that their handles exist) or raw hipEvent_t handles.  They get the begin /

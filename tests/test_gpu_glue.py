@@ -221,3 +221,26 @@ def test_launch_events_time_the_solve_kernel_itself():
     own = mpc.solver.last_kernel_ms()
     assert 0.01 < own < 50.0 and a.elapsed_time(b) == ms
     mpc.solver.close()
+
+
+def test_launch_statistics_match_the_per_agent_outputs():
+    """omgx_batch_set_stats: the counts the solve kernel adds up per launch equal those of the status / iters arrays."""
+    import torch
+    from omgtools.batch import BatchP2P
+    problem, P = _setup(96)
+    mpc = BatchP2P(problem, P, ops='hip', options=dict(tol=1e-3, max_iter=300))
+    stats = torch.zeros((3, 4), dtype=torch.int64, device='cuda')
+    mpc.solver.set_stats(stats)
+    mpc.solve_cold(bends=())
+    ref = [(int((mpc.status == 0).sum()), int(mpc.iters.sum()), int(mpc.iters.max()), 96)]
+    for _ in range(3):                                   # the fourth launch wraps around into row 0
+        mpc.step()
+        ref.append((int((mpc.status == 0).sum()), int(mpc.iters.sum()), int(mpc.iters.max()), 96))
+    got = stats.cpu().numpy()
+    assert tuple(got[1]) == ref[1] and tuple(got[2]) == ref[2]
+    assert got[0, 0] == ref[0][0] + ref[3][0] and got[0, 1] == ref[0][1] + ref[3][1]
+    assert got[0, 2] == max(ref[0][2], ref[3][2]) and got[0, 3] == 192
+    mpc.solver.set_stats(None)
+    mpc.step()
+    assert np.array_equal(stats.cpu().numpy(), got)
+    mpc.solver.close()
