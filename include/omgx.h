@@ -141,7 +141,9 @@ int  omgx_batch_set_stream(omgx_batch* b, void* hip_stream);
 int  omgx_batch_set_order(omgx_batch* b, const int32_t* order_device);
 /* Fill order_device [n_agents] from the iteration counts of the previous solve (iters_device, as
  * written by omgx_batch_solve), largest first, on the handle's stream, and install it as the
- * launch order (the receding-horizon loop calls this before every warm-started solve). */
+ * launch order (the receding-horizon loop calls this before every warm-started solve).  The work is
+ * deferred to the next launch of the handle: an omgx_batch_predict(_ex) launch carries it as one more
+ * workgroup, otherwise the next omgx_batch_solve runs it first -- iters_device must stay as it is until then. */
 int  omgx_batch_order_by_iters(omgx_batch* b, const int32_t* iters_device, int32_t* order_device);
 /* Restart guesses for the following COLD solves (device-pointer solves; warm-started solves ignore them):
  * x0_alt_device [n_alt][n_agents][n_var] (device pointer, owned by the caller; n_alt = 0 / NULL switches it off).

@@ -339,8 +339,32 @@ __device__ __forceinline__ int span_of(const double* kk, int degree, int n_knots
   return j;
 }
 
+// Launch order for the next solve: agents bucketed by the iteration count of their previous solve,
+// largest first (64 buckets, counting sort in LDS by one workgroup; the order inside a bucket is
+// arbitrary).  Replaces a device-wide sort: this is ~10 us.
+__device__ __forceinline__ void order_block(const int32_t* __restrict__ iters, int32_t* __restrict__ order, int B) {
+  __shared__ int cnt[64], off[64];
+  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int it = iters[b];
+    atomicAdd(&cnt[63 - (it < 0 ? 0 : (it > 63 ? 63 : it))], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { int a = 0; for (int k = 0; k < 64; ++k) { off[k] = a; a += cnt[k]; } }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int it = iters[b];
+    order[atomicAdd(&off[63 - (it < 0 ? 0 : (it > 63 ? 63 : it))], 1)] = b;
+  }
+}
+
+// (ord_iters != nullptr: the launch carries one more workgroup, which computes the launch order of the next solve --
+// the receding-horizon step then has one launch less in front of its solve kernel)
 __global__ void __launch_bounds__(256)
-predict_kernel(const double* __restrict__ x, int n_var, double* __restrict__ p, int n_par, int B, PredictArgs a) {
+predict_kernel(const double* __restrict__ x, int n_var, double* __restrict__ p, int n_par, int B, PredictArgs a,
+               const int32_t* __restrict__ ord_iters, int32_t* __restrict__ ord_out) {
+  if (ord_iters && blockIdx.x == gridDim.x - 1) { order_block(ord_iters, ord_out, B); return; }
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= B * a.n_spl) return;
   const int b = id / a.n_spl, k = id - b * a.n_spl;
@@ -371,26 +395,8 @@ predict_kernel(const double* __restrict__ x, int n_var, double* __restrict__ p, 
   if (k == 0 && a.p_t >= 0) pb[a.p_t] = a.t_value;
 }
 
-// Launch order for the next solve: agents bucketed by the iteration count of their previous solve,
-// largest first (64 buckets, counting sort in LDS by one workgroup; the order inside a bucket is
-// arbitrary).  Replaces a device-wide sort: this is ~10 us.
 __global__ void __launch_bounds__(1024)
-order_kernel(const int32_t* __restrict__ iters, int32_t* __restrict__ order, int B) {
-  __shared__ int cnt[64], off[64];
-  if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
-  __syncthreads();
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    const int it = iters[b];
-    atomicAdd(&cnt[63 - (it < 0 ? 0 : (it > 63 ? 63 : it))], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) { int a = 0; for (int k = 0; k < 64; ++k) { off[k] = a; a += cnt[k]; } }
-  __syncthreads();
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    const int it = iters[b];
-    order[atomicAdd(&off[63 - (it < 0 ? 0 : (it > 63 ? 63 : it))], 1)] = b;
-  }
-}
+order_kernel(const int32_t* __restrict__ iters, int32_t* __restrict__ order, int B) { order_block(iters, order, B); }
 
 __global__ void __launch_bounds__(64)
 shift_kernel(double* __restrict__ x, int x_stride, const uint8_t* __restrict__ mask,
@@ -509,6 +515,7 @@ struct omgx_batch {
   double* d_slabs = nullptr;
   double* d_dw = nullptr;          // per-agent inertia correction carried between warm-started solves
   const int32_t* d_order = nullptr; // optional launch order (device pointer owned by the caller)
+  const int32_t* pend_iters = nullptr; int32_t* pend_order = nullptr;   // omgx_batch_order_by_iters not launched yet
   int* d_next = nullptr;            // spill modes: counter of the dynamic slot hand-out
   const double* d_x0_alt = nullptr; // restart guesses [n_alt][n_agents][n_var] (device, owned by the caller)
   int n_alt = 0;
@@ -847,9 +854,18 @@ int omgx_batch_set_stream(omgx_batch* b, void* s) {
   return OMGX_OK;
 }
 
+static int flush_order(omgx_batch* b) {
+  if (!b->pend_iters) return OMGX_OK;
+  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, b->stream, b->pend_iters, b->pend_order, b->n_agents);
+  b->pend_iters = nullptr; b->pend_order = nullptr;
+  HIPCHK(hipGetLastError());
+  return OMGX_OK;
+}
+
 int omgx_batch_set_order(omgx_batch* b, const int32_t* order_device) {
   if (!b) return OMGX_E_INVALID;
   b->d_order = order_device;
+  b->pend_iters = nullptr; b->pend_order = nullptr;
   return OMGX_OK;
 }
 
@@ -863,9 +879,9 @@ int omgx_batch_set_restarts(omgx_batch* b, const double* x0_alt_device, int32_t 
 
 int omgx_batch_order_by_iters(omgx_batch* b, const int32_t* iters_device, int32_t* order_device) {
   if (!b || !iters_device || !order_device) { g_err = "null argument"; return OMGX_E_INVALID; }
-  HIPCHK(hipSetDevice(b->device));
-  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, b->stream, iters_device, order_device, b->n_agents);
-  HIPCHK(hipGetLastError());
+  // deferred: the next omgx_batch_predict(_ex) launch carries the ordering as one more workgroup; a solve that comes
+  // first launches order_kernel itself (flush_order)
+  b->pend_iters = iters_device; b->pend_order = order_device;
   b->d_order = order_device;
   return OMGX_OK;
 }
@@ -912,6 +928,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
     HIPCHK(hipMemcpyAsync(b->d_ub, ubg, nb * sizeof(double), hipMemcpyHostToDevice, b->stream));
     klb = b->d_lb; kub = b->d_ub;
   }
+  { const int rc_o = flush_order(b); if (rc_o != OMGX_OK) return rc_o; }
   if (b->d_next) HIPCHK(hipMemsetAsync(b->d_next, 0, sizeof(int), b->stream));
   // Timing events ride on the dispatch packet of the solve kernel (hipExtLaunchKernelGGL: the packet's own begin / end
   // stamps) -- separate hipEventRecord calls around it cost two more packets, ~25 us of stream time per solve.
@@ -1168,7 +1185,9 @@ int omgx_batch_predict_ex(omgx_batch* b, const double* x, double* p, int32_t coe
   a.coeff_off = coeff_off; a.n_spl = n_spl; a.degree = degree; a.n_knots = n_knots; a.n_out = n_out;
   a.tau = tau; a.inv_T = inv_T; a.p_t = p_t; a.t_value = t_value; a.mode = mode; a.state_in = state_in; a.n_sub = n_sub; a.dtau = dtau;
   const int n = b->n_agents * n_spl;
-  hipLaunchKernelGGL(predict_kernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, x, d.n_var, p, d.n_par, b->n_agents, a);
+  const int32_t* oi = b->pend_iters; int32_t* oo = b->pend_order;
+  b->pend_iters = nullptr; b->pend_order = nullptr;
+  hipLaunchKernelGGL(predict_kernel, dim3((n + 255) / 256 + (oi ? 1 : 0)), dim3(256), 0, b->stream, x, d.n_var, p, d.n_par, b->n_agents, a, oi, oo);
   HIPCHK(hipGetLastError());
   return OMGX_OK;
 }

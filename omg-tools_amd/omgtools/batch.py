@@ -146,14 +146,14 @@ class BatchP2P(object):
             self.iters = np.zeros(self.B, dtype=np.int32)
 
     # -- solves ------------------------------------------------------------------------
-    def _solve(self, warm, events=None, step_desc=None):
+    def _solve(self, warm, events=None, step_desc=None, ordered=False):
         if self.kind == 'hip':
             self.solver.set_options(warm_start=int(warm),
                                     max_iter=self.max_iter_step if warm else self.max_iter_cold)
             if not warm:
                 self.lam.zero_()
                 self._x_init = self.x.clone()
-            if warm and self.straggler_first:
+            if warm and self.straggler_first and not ordered:
                 # agents that needed most iterations last time are launched first
                 self.solver.order_by_iters(self.iters, self._order)
             if events is not None:                 # timing events of the caller (bench.py): on the solve kernel's own dispatch
@@ -244,6 +244,9 @@ class BatchP2P(object):
             self._solve(True, step_desc=self._pool_step(tau, t_rel, crossed))
             return crossed
         if self.kind == 'hip':
+            # (asked for before the prediction: its launch then carries the ordering as one more workgroup)
+            if self.straggler_first:
+                self.solver.order_by_iters(self.iters, self._order)
             # one kernel: the initial conditions from the plan at tau and the new t, all written into p
             self.solver.predict_ex(self.x, self.p, self.o_spl, self.n_spl, self.basis.degree, self.basis.knots, tau,
                                    1.0 / self.T, self.p_offs, self.o_t, t_rel)
@@ -262,7 +265,7 @@ class BatchP2P(object):
             self._shift()
         self.time = t_now
         # (3) warm-started solve
-        self._solve(True, events)
+        self._solve(True, events, ordered=self.kind == 'hip' and self.straggler_first)
         return crossed
 
     def _eval_rows(self, tau):
