@@ -185,7 +185,8 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   // slabs and every workgroup walks over its agents.
   // `order` (optional) maps launch slots to agents: the host can put expected stragglers first so
   // that their long solves overlap the rest of the batch instead of trailing it
-  // Spill modes hand the launch slots out dynamically (next_slot: a counter the host zeroes before the launch):
+  // Spill modes hand the launch slots out dynamically (next_slot[0]: a counter that is zero at every launch -- the
+  // workgroup that finishes last resets it, next_slot[1] counts the finished ones):
   // solves differ by a factor of several in their iteration counts, and a fixed share of agents per workgroup would
   // leave most of the chip waiting for the unluckiest one.  Which workgroup solves an agent does not change its result.
   __shared__ int slot_lds;
@@ -253,6 +254,10 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
     if (prof && threadIdx.x < omgx::PH_COUNT) prof[(size_t)b * omgx::PH_COUNT + threadIdx.x] = prof_lds[threadIdx.x];
 #endif
     __syncthreads();
+  }
+  if (MODE != omgx::WS_LDS && next_slot && threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(next_slot + 1, 1) == (int)gridDim.x - 1) { next_slot[0] = 0; next_slot[1] = 0; __threadfence(); }
   }
 }
 
@@ -819,7 +824,8 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
     if (slabs > n_agents) slabs = n_agents;
     b->n_slabs = slabs;
     if ((rc = dalloc(b, (size_t)slabs * b->slab_doubles, &b->d_slabs))) { omgx_batch_destroy(b); return rc; }
-    if ((rc = dalloc(b, (size_t)1, &b->d_next))) { omgx_batch_destroy(b); return rc; }
+    if ((rc = dalloc(b, (size_t)2, &b->d_next))) { omgx_batch_destroy(b); return rc; }
+    if (hipMemset(b->d_next, 0, 2 * sizeof(int)) != hipSuccess) { g_err = "hipMemset failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
   } else {
     b->n_slabs = n_agents;
   }
@@ -929,7 +935,6 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
     klb = b->d_lb; kub = b->d_ub;
   }
   { const int rc_o = flush_order(b); if (rc_o != OMGX_OK) return rc_o; }
-  if (b->d_next) HIPCHK(hipMemsetAsync(b->d_next, 0, sizeof(int), b->stream));
   // Timing events ride on the dispatch packet of the solve kernel (hipExtLaunchKernelGGL: the packet's own begin / end
   // stamps) -- separate hipEventRecord calls around it cost two more packets, ~25 us of stream time per solve.
   // The caller's pair (omgx_batch_set_launch_events, one launch) goes first, else the handle's own when timing is on.
