@@ -117,6 +117,17 @@ class BatchADMM(object):
         sums = ops.residual_sums(res)                          # [3], backend array, no host copy
         # with acceleration the previous z_ij, l_ij travel too: the extrapolation is elementwise with fleet-wide
         # scalars, so every rank applies it to the rows it received instead of waiting for a third collective
+        if not self.nesterov and not self.exchanging() and getattr(ops, '_slot', None) is not None:
+            # nothing travels and nothing is extrapolated: the neighbours' rows are read where update left them
+            if self.dist is not None and self.halo.world > 1:
+                sums = ops.allreduce(sums, self.dist)
+            ops.communicate_local(lay)
+            self._res.append(sums)
+            self.iteration += 1
+            if not sync:
+                return status, None
+            s3 = ops.to_host(sums)
+            return status, (float(np.sqrt(s3[0])), float(np.sqrt(s3[1])), float(s3[2]))
         buf = ops.zl_flat(with_prev=self.nesterov)
         if self.exchanging():
             buf, sums = self.extend(buf, sums)                 # collective #2: [z_ij | l_ij] rows + the residual sums
@@ -210,8 +221,11 @@ class HipAdmmOps(object):
         self.l_ij.zero_()
 
     def set_time(self, lay, t_rel, rho):
-        self.p[:, lay.p_t] = t_rel
-        self.p[:, lay.p_rho] = rho
+        # (both stay the same over the iterations of one update: written only when they change)
+        if getattr(self, '_t_rho', None) != (float(t_rel), float(rho)):
+            self.p[:, lay.p_t] = t_rel
+            self.p[:, lay.p_rho] = rho
+            self._t_rho = (float(t_rel), float(rho))
 
     def solve(self):
         self.solver.solve_device(self.p, self.x, self.lb, self.ub, self.x_new, self.lam,
@@ -270,6 +284,12 @@ class HipAdmmOps(object):
             l_ext.data_ptr(), self.p.data_ptr()), 'omgx_admm_communicate')
         self._keep2 = (z_ext, l_ext)
 
+    def communicate_local(self, lay):
+        """communicate when every neighbour is a local agent and nothing is extrapolated: z_ij, l_ij as they are."""
+        self._chk(self.solver.lib.omgx_admm_communicate(
+            self.solver._h, C.byref(self.layc), self._nbr.data_ptr(), self._slot.data_ptr(), self.z_ij.data_ptr(),
+            self.l_ij.data_ptr(), self.p.data_ptr()), 'omgx_admm_communicate')
+
     # -- Nesterov acceleration (`admm.py:510-554`), branch-free on the device --------------------
     def save_previous(self, lay):
         ns = self.ns
@@ -314,6 +334,7 @@ class HipAdmmOps(object):
     def upload_params(self, p_host, cols):
         t = self.torch
         idx = t.as_tensor(np.asarray(cols), dtype=t.int64, device=self.dev)
+        self._t_rho = None
         self.p[:, idx] = t.as_tensor(np.ascontiguousarray(p_host[:, cols]), dtype=t.float64, device=self.dev)
 
     def upload_x(self, x_host):
