@@ -143,7 +143,8 @@ int  omgx_batch_set_order(omgx_batch* b, const int32_t* order_device);
  * written by omgx_batch_solve), largest first, on the handle's stream, and install it as the
  * launch order (the receding-horizon loop calls this before every warm-started solve).  The work is
  * deferred to the next launch of the handle: an omgx_batch_predict(_ex) launch carries it as one more
- * workgroup, otherwise the next omgx_batch_solve runs it first -- iters_device must stay as it is until then. */
+ * workgroup, otherwise the next omgx_batch_solve or omgx_batch_sync runs it first -- iters_device must stay as it
+ * is until then. */
 int  omgx_batch_order_by_iters(omgx_batch* b, const int32_t* iters_device, int32_t* order_device);
 /* Restart guesses for the following COLD solves (device-pointer solves; warm-started solves ignore them):
  * x0_alt_device [n_alt][n_agents][n_var] (device pointer, owned by the caller; n_alt = 0 / NULL switches it off).

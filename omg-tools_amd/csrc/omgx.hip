@@ -969,6 +969,7 @@ int omgx_batch_phase_cycles(omgx_batch* b, long long* out) {   // profiling buil
 
 int omgx_batch_sync(omgx_batch* b) {
   if (!b) return OMGX_E_INVALID;
+  { const int rc_o = flush_order(b); if (rc_o != OMGX_OK) return rc_o; }      // (a deferred omgx_batch_order_by_iters)
   HIPCHK(hipStreamSynchronize(b->stream));
   return OMGX_OK;
 }
