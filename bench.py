@@ -277,8 +277,8 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    # one step = the cold solve of the whole batch from the reference's initial guess, restart passes for the
-    # agents whose phase I stalls included (BatchP2P.solve_cold)
+    # one step = the cold solve of the whole batch from the reference's initial guess, restarts of the agents whose
+    # phase I stalls included (BatchP2P.solve_cold: restart guesses handed to the launch)
     passes = 0
     for k in range(args.warmup + args.steps):
         if k == args.warmup:
@@ -323,7 +323,8 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': '%s: %d agents per GPU, cold solve from the reference initial guess (agents that do not '
-                               'converge from it are solved again from the guess bent sideways: %d restart passes), tol=%g'
+                               'converge from it are solved again, inside the same launch, from the guess bent sideways: '
+                               'at most %d restarts per agent), tol=%g'
                                % (args.workload, B, passes, args.tol), 'n_var': tpl.n_var, 'n_con': tpl.n_con},
         'solved_fraction': n_ok / float(B), 'mean_iters': it_sum / float(B), 'workspace': mpc.solver.workspace(),
         'receding_horizon': {'solves_per_s': rh_ok_all / rh_elapsed, 'ms_per_step': rh_elapsed / rh_steps * 1e3,
