@@ -229,11 +229,23 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
     for _ in range(args.warmup):
         admm.iterate(0.0, sync=False)
     barrier()
+    stats = torch.zeros((args.steps, 4), dtype=torch.int64, device=dev)     # per x-update: solved, sum / max of iterations, agents
+    solver.set_stats(stats)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         status, _ = admm.iterate(0.0, sync=False)           # nothing leaves the device inside the loop
     barrier()
     elapsed = time.perf_counter() - t0
+    solver.set_stats(None)
+    stats = stats.cpu().numpy()
+    if os.environ.get('OMGX_PHASES'):                      # developer: per-phase cycles of the last x-update (profiling build)
+        import ctypes
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+        from phase_profile import PHASES as _PH
+        prof = np.zeros((hi - lo, len(_PH)), dtype=np.int64)
+        solver.lib.omgx_batch_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        solver.lib.omgx_batch_phase_cycles(solver._h, prof.ctypes.data)
+        print({p_: round(float(prof[:, k].mean()) / 1e3, 1) for k, p_ in enumerate(_PH) if prof[:, k].mean() > 500}, file=sys.stderr)
     n_ok = int((status == 0).sum().item())
     res = admm.residuals[-1]
     elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist if world > 1 else None)
@@ -251,7 +263,8 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
                                 'interconnection, knot_intervals=10, 2 rectangular obstacles + 1 moving circle, rho=1, tol=%g')
                                % (N, args.tol), 'agents_total': N, 'n_var': tpl.n_var, 'n_con': tpl.n_con,
                    'parallelism': 'agents sharded contiguously; two all_gathers per iteration (x_i rows; [z_ij | l_ij] rows + residual sums)'},
-        'solved_fraction': n_ok_all / float(N), 'residuals': list(res)}))
+        'solved_fraction': n_ok_all / float(N), 'residuals': list(res),
+        'x_update_mean_iters': float(stats[:, 1].sum()) / max(1, int(stats[:, 3].sum())), 'x_update_max_iters': int(stats[:, 2].max())}))
 
 
 def bench_cold(args, rank, local_rank, world, dist, dev):

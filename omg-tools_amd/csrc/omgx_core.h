@@ -55,6 +55,7 @@ struct Dims {
   int col_doubles;   // scratch for the blocked LDL' (staging + panel buffers)
   int col_small;     // the same for the spill modes (left-looking leaf sweep only: inverse pivots + parked diagonal blocks per leaf): kept in LDS there
   int mono_packed;   // 1: every parameter monomial has <= 4 atoms, Tables::pm_rec is valid
+  int n_long;        // slots with more than OMGX_SLOT_CAP monomials (the first n_long entries of Tables::sl_list)
   int n_hess;        // number of HessRec records
   int rp_packed;     // 1: rows and positions fit 16 bits each, Tables::je_rp is valid
   int n_knots;       // total length of the knot vectors of the atoms program (copied to LDS per solve)
@@ -192,6 +193,7 @@ struct Opts {
 #define OMGX_STAGE_LD 20   // per matrix: 4x4 block rows [16] + inverse pivots of the block [4]
 #define OMGX_MIN_LEAF    8       // smaller components are gathered into one leaf
 #define OMGX_NBIN        512     // owner bins of the assembly passes (= threads of the solve workgroup)
+#define OMGX_SLOT_CAP    16      // monomials of a parameter slot one thread sums (setup); the rest of a longer slot: one wave
 #define OMGX_REC_BATCH   8       // records an owner loads at a time (all in flight together)
 #define OMGX_RUN_CAP     16      // longest run of records summed by one owner (longer runs are cut, see omgx_plan.h)
 #define OMGX_WAVE_ROWS   64      // register rows of a panel the wave-level routines take (lanes)
@@ -289,6 +291,7 @@ struct Ctx {
   int nthr() const { return 1; }
   void sync() const {}
   double rsum(double v) const { return v; }
+  double wave_sum(double v) const { return v; }
   double rmax(double v) const { return v; }
   double rmin(double v) const { return v; }
   template <int... OPS> void reduce_ops(double (&)[sizeof...(OPS)]) const {}
@@ -376,6 +379,7 @@ struct CtxT {
     __syncthreads();
   }
   __device__ double rsum(double v) const { return reduce<0>(v); }
+  __device__ double wave_sum(double v) const { return wave_reduce<0>(v); }      // all lanes of the wave must be active
   __device__ double rmax(double v) const { return reduce<1>(v); }
   __device__ double rmin(double v) const { return reduce<2>(v); }
   __device__ void add(double* p, double v) const { atomicAdd(p, v); }   // ds_add_f64 on LDS
@@ -417,6 +421,17 @@ enum { PH_JAC = 0, PH_RESID, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_STEP, PH_LINES
 OMGX_FN double pp_eval(const Tables& T, int pp, const double* a) {
   double tot = 0.0;
   for (int m = T.pp_ptr[pp]; m < T.pp_ptr[pp + 1]; ++m) {
+    double v = T.pm_coef[m];
+    for (int q = T.pm_ptr[m]; q < T.pm_ptr[m + 1]; ++q) v *= a[T.pm_atom[q]];
+    tot += v;
+  }
+  return tot;
+}
+
+// monomials [m0, m1) of the CSR tables
+OMGX_FN double csr_range_eval(const Tables& T, int m0, int m1, const double* a) {
+  double tot = 0.0;
+  for (int m = m0; m < m1; ++m) {
     double v = T.pm_coef[m];
     for (int q = T.pm_ptr[m]; q < T.pm_ptr[m + 1]; ++q) v *= a[T.pm_atom[q]];
     tot += v;
@@ -542,7 +557,44 @@ OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, co
       }
       w.slots[T.sl_list[i]] = tot;
     }
-  } else { OMGX_PFOR(s, d.n_slots) w.slots[s] = pp_eval(T, T.slot_pp[s], w.atoms); }
+    if (d.n_long > 0) {
+      // the tail of the long slots, one wave per slot: lanes stride over the monomials, fixed-order wave sum (a single
+      // thread walking the 314 monomials of the constant term of the formation objective was 302 k of the 379 k
+      // cycles of a converged ADMM x-update)
+      c.sync();
+      for (int q = c.wave(); q < d.n_long; q += c.nwaves()) {
+        const int sl = T.sl_list[q];
+        const int m0 = T.slot_rng[2 * sl] + OMGX_SLOT_CAP, m1 = T.slot_rng[2 * sl + 1];
+        double part = 0.0;
+        for (int m = m0 + c.lane(); m < m1; m += c.nlanes()) {
+          const MonoRec r = T.pm_rec[m];
+          const double a0 = w.atoms[r.a0 < 0 ? 0 : r.a0], a1 = w.atoms[r.a1 < 0 ? 0 : r.a1];
+          const double a2 = w.atoms[r.a2 < 0 ? 0 : r.a2], a3 = w.atoms[r.a3 < 0 ? 0 : r.a3];
+          part += r.coef * (r.a0 < 0 ? 1.0 : a0) * (r.a1 < 0 ? 1.0 : a1) * (r.a2 < 0 ? 1.0 : a2) * (r.a3 < 0 ? 1.0 : a3);
+        }
+        const double rest = c.wave_sum(part);
+        if (c.lane() == 0) w.slots[sl] += rest;
+      }
+    }
+  } else {
+    // (monomials with more than four atoms: the CSR tables, three chained loads per monomial -- the same split:
+    // a thread sums the first OMGX_SLOT_CAP monomials of its slot, a wave the rest of a long one)
+    OMGX_PFOR(s, d.n_slots) {
+      const int m0 = T.slot_rng[2 * s], m1 = T.slot_rng[2 * s + 1];
+      w.slots[s] = csr_range_eval(T, m0, m1 < m0 + OMGX_SLOT_CAP ? m1 : m0 + OMGX_SLOT_CAP, w.atoms);
+    }
+    if (d.n_long > 0) {
+      c.sync();
+      for (int q = c.wave(); q < d.n_long; q += c.nwaves()) {
+        const int sl = T.sl_list[q];
+        const int m0 = T.slot_rng[2 * sl] + OMGX_SLOT_CAP, m1 = T.slot_rng[2 * sl + 1];
+        double part = 0.0;
+        for (int m = m0 + c.lane(); m < m1; m += c.nlanes()) part += csr_range_eval(T, m, m + 1, w.atoms);
+        const double rest = c.wave_sum(part);
+        if (c.lane() == 0) w.slots[sl] += rest;
+      }
+    }
+  }
   c.sync();
   OMGX_TOC(PH_P_SLOTS);
 }

@@ -373,10 +373,21 @@ struct HostPlan {
       std::stable_sort(sl_list.begin(), sl_list.begin() + no, [&](int x, int y) { return cnt(x) > cnt(y); });
       sl_glen.assign((no + 63) / 64 + 1, 0);
       int steps = 0;
-      for (int i = 0; i < no; ++i) { const int len = (cnt(sl_list[i]) + 3) / 4 * 4; sl_glen[i >> 6] = std::max(sl_glen[i >> 6], len); steps = std::max(steps, len); }
+      // (the table holds the first OMGX_SLOT_CAP monomials of a slot; the rest of a longer slot -- the constant term of
+      // an ADMM objective has hundreds -- is summed by a whole wave, eval_params: the long slots are the first n_long
+      // entries of sl_list)
+      d.n_long = 0;
+      for (int i = 0; i < no; ++i) {
+        const int c_ = std::min(cnt(sl_list[i]), OMGX_SLOT_CAP);
+        if (cnt(sl_list[i]) > OMGX_SLOT_CAP) ++d.n_long;
+        const int len = (c_ + 3) / 4 * 4; sl_glen[i >> 6] = std::max(sl_glen[i >> 6], len); steps = std::max(steps, len);
+      }
       sl_ell.assign((size_t)std::max(1, steps) * std::max(1, no), MonoRec{0.0, -1, -1, -1, -1});
       if (d.mono_packed)
-        for (int i = 0; i < no; ++i) for (int k = slot_rng[2 * sl_list[i]]; k < slot_rng[2 * sl_list[i] + 1]; ++k) sl_ell[(size_t)(k - slot_rng[2 * sl_list[i]]) * no + i] = pm_rec[k];
+        for (int i = 0; i < no; ++i) {
+          const int k0 = slot_rng[2 * sl_list[i]], k1 = std::min(slot_rng[2 * sl_list[i] + 1], k0 + OMGX_SLOT_CAP);
+          for (int k = k0; k < k1; ++k) sl_ell[(size_t)(k - k0) * no + i] = pm_rec[k];
+        }
       T.sl_list = sl_list.data(); T.sl_ell = sl_ell.data(); T.sl_glen = sl_glen.data();
     }
     // packed (row, position) of the Jacobian entries
