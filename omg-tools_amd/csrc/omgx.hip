@@ -623,7 +623,15 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   const omgx::Tables& H = plan.tables;
   const omgx::Dims& d = plan.dims;
   UP(prog, 6 * d.n_prog); UP(knots, t->n_knots); UP(pp_ptr, t->n_pp + 1); UP(pm_coef, t->n_mono);
-  UP(pm_ptr, t->n_mono + 1); UP(pm_atom, t->n_matom); UP(slot_pp, d.n_slots); UP(pm_rec, plan.pm_rec.size());
+  UP(pm_ptr, t->n_mono + 1); UP(pm_atom, t->n_matom); UP(slot_pp, d.n_slots);
+  // (packed monomial records: 16-byte MonoRec or, with 5..8 atoms per monomial, 24-byte MonoRec8 behind the same pointers)
+  if (d.mono_packed == 2) {
+    const omgx::MonoRec8* dev8 = nullptr;
+    int rc8 = upload(b, plan.pm_rec8.data(), plan.pm_rec8.size(), &dev8); if (rc8 != OMGX_OK) return rc8;
+    b->dev.pm_rec = (const omgx::MonoRec*)dev8;
+    rc8 = upload(b, plan.sl_ell8.data(), plan.sl_ell8.size(), &dev8); if (rc8 != OMGX_OK) return rc8;
+    b->dev.sl_ell = (const omgx::MonoRec*)dev8;
+  } else { UP(pm_rec, plan.pm_rec.size()); UP(sl_ell, plan.sl_ell.size()); }
   UP(row_ptr, d.n_con + 2); UP(t_coef, d.n_terms); UP(t_slot, d.n_terms); UP(t_var, 3 * d.n_terms);
   UP(order, d.N); UP(pos, d.N); UP(leaf_off, d.n_leaf + 1); UP(leaf_bw, plan.leaf_bw.size()); UP(blk, d.N);
   UP(eq_rows, d.n_eq); UP(eq_index, d.n_con);
@@ -644,7 +652,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   UP(cs_ell, plan.cs_ell.size()); UP(cs_glen, plan.cs_glen.size()); UP(cs_col, plan.cs_col.size());
   UP(jv_ell, plan.jv_ell.size()); UP(jv_glen, plan.jv_glen.size());
   UP(ja_list, plan.ja_list.size()); UP(ja_ell, plan.ja_ell.size()); UP(ja_glen, plan.ja_glen.size());
-  UP(sl_list, plan.sl_list.size()); UP(sl_ell, plan.sl_ell.size()); UP(sl_glen, plan.sl_glen.size());
+  UP(sl_list, plan.sl_list.size()); UP(sl_glen, plan.sl_glen.size());
   return OMGX_OK;
 }
 

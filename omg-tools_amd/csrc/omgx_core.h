@@ -54,7 +54,7 @@ struct Dims {
   int max_leaf, max_cpl;
   int col_doubles;   // scratch for the blocked LDL' (staging + panel buffers)
   int col_small;     // the same for the spill modes (left-looking leaf sweep only: inverse pivots + parked diagonal blocks per leaf): kept in LDS there
-  int mono_packed;   // 1: every parameter monomial has <= 4 atoms, Tables::pm_rec is valid
+  int mono_packed;   // 1: every parameter monomial has <= 4 atoms, Tables::pm_rec / sl_ell hold MonoRec; 2: <= 8 atoms, MonoRec8; 0: CSR tables only
   int n_long;        // slots with more than OMGX_SLOT_CAP monomials (the first n_long entries of Tables::sl_list)
   int n_hess;        // number of HessRec records
   int rp_packed;     // 1: rows and positions fit 16 bits each, Tables::je_rp is valid
@@ -73,6 +73,8 @@ struct Dims {
 // one parameter monomial coef * prod atoms[a_k] as a single 16-byte record (a_k = -1: unused): one
 // load per monomial instead of the pointer chase pm_ptr -> pm_atom -> atoms of the CSR form
 struct MonoRec { double coef; int16_t a0, a1, a2, a3; };
+// the same with up to eight atoms (Dims::mono_packed == 2: ADMM objectives multiply rho, multipliers and basis values)
+struct MonoRec8 { double coef; int16_t a0, a1, a2, a3, a4, a5, a6, a7; };
 
 // One polynomial term coef * slot * x_v0 x_v1 x_v2 as a single 40-byte record (v_k = -1: unused) with
 // its row and the Jacobian entries it feeds: one sequence of wide loads per term instead of nine
@@ -504,6 +506,57 @@ OMGX_FN void bspl_row(const double* k, int n_knots, int deg, double u, double* o
   for (int r = 0; r < 6; ++r) if (r <= deg && inside) out[j - deg + r] = N[r];
 }
 
+// value of one packed monomial (branch-free: an unused atom reads atom 0 and multiplies by one)
+OMGX_FN double mono_value(const MonoRec& r, const double* at) {
+  const double a0 = at[r.a0 < 0 ? 0 : r.a0], a1 = at[r.a1 < 0 ? 0 : r.a1];
+  const double a2 = at[r.a2 < 0 ? 0 : r.a2], a3 = at[r.a3 < 0 ? 0 : r.a3];
+  return r.coef * (r.a0 < 0 ? 1.0 : a0) * (r.a1 < 0 ? 1.0 : a1) * (r.a2 < 0 ? 1.0 : a2) * (r.a3 < 0 ? 1.0 : a3);
+}
+OMGX_FN double mono_value(const MonoRec8& r, const double* at) {
+  const double a0 = at[r.a0 < 0 ? 0 : r.a0], a1 = at[r.a1 < 0 ? 0 : r.a1];
+  const double a2 = at[r.a2 < 0 ? 0 : r.a2], a3 = at[r.a3 < 0 ? 0 : r.a3];
+  const double a4 = at[r.a4 < 0 ? 0 : r.a4], a5 = at[r.a5 < 0 ? 0 : r.a5];
+  const double a6 = at[r.a6 < 0 ? 0 : r.a6], a7 = at[r.a7 < 0 ? 0 : r.a7];
+  return r.coef * (r.a0 < 0 ? 1.0 : a0) * (r.a1 < 0 ? 1.0 : a1) * (r.a2 < 0 ? 1.0 : a2) * (r.a3 < 0 ? 1.0 : a3)
+                * (r.a4 < 0 ? 1.0 : a4) * (r.a5 < 0 ? 1.0 : a5) * (r.a6 < 0 ? 1.0 : a6) * (r.a7 < 0 ? 1.0 : a7);
+}
+
+// Slot values from the packed tables: the first OMGX_SLOT_CAP monomials of every slot from the ELL table, one thread
+// per slot, four records at a time (all loads in flight), summed in table order; the tail of a long slot by one
+// wave: lanes stride over the monomials, fixed-order wave sum (a single thread walking the 314 monomials of the
+// constant term of the formation objective was 302 k of the 379 k cycles of a converged ADMM x-update).
+template <class Rec, class C>
+OMGX_FN void slots_packed(const C& c, const Dims& d, const Tables& T, Work& w) {
+  const Rec* ell = (const Rec*)T.sl_ell;
+  const Rec* rec = (const Rec*)T.pm_rec;
+  OMGX_PFOR(i, d.n_slots) {
+    const int L = T.sl_glen[i >> 6];
+    double tot = 0.0;
+    for (int s0 = 0; s0 < L; s0 += 4) {
+      Rec q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = ell[(s0 + k) * d.n_slots + i];
+      double v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = mono_value(q[k], w.atoms);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tot += v[k];
+    }
+    w.slots[T.sl_list[i]] = tot;
+  }
+  if (d.n_long > 0) {
+    c.sync();
+    for (int q = c.wave(); q < d.n_long; q += c.nwaves()) {
+      const int sl = T.sl_list[q];
+      const int m0 = T.slot_rng[2 * sl] + OMGX_SLOT_CAP, m1 = T.slot_rng[2 * sl + 1];
+      double part = 0.0;
+      for (int m = m0 + c.lane(); m < m1; m += c.nlanes()) part += mono_value(rec[m], w.atoms);
+      const double rest = c.wave_sum(part);
+      if (c.lane() == 0) w.slots[sl] += rest;
+    }
+  }
+}
+
 template <class C>
 OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, const double* p) {
   OMGX_PFOR(i, d.n_par) w.atoms[i] = p[i];
@@ -515,7 +568,7 @@ OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, co
     const int32_t* op = T.prog + 6 * k;
     if (op[0] == OP_DIV) {
       if (c.tid() == 0)
-        w.atoms[op[3]] = d.mono_packed ? pp_eval_packed(T, op[1], w.atoms) / pp_eval_packed(T, op[2], w.atoms)
+        w.atoms[op[3]] = d.mono_packed == 1 ? pp_eval_packed(T, op[1], w.atoms) / pp_eval_packed(T, op[2], w.atoms)
                                        : pp_eval(T, op[1], w.atoms) / pp_eval(T, op[2], w.atoms);
       ++k;
       c.sync();
@@ -536,48 +589,10 @@ OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, co
     c.sync();
     OMGX_TOC(PH_P_BSPL);
   }
-  if (d.mono_packed) {
-    // monomials of every slot from the ELL table, four at a time (all loads in flight), summed in table order
-    OMGX_PFOR(i, d.n_slots) {
-      const int L = T.sl_glen[i >> 6];
-      double tot = 0.0;
-      for (int s0 = 0; s0 < L; s0 += 4) {
-        MonoRec q[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) q[k] = T.sl_ell[(s0 + k) * d.n_slots + i];
-        double v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const double a0 = w.atoms[q[k].a0 < 0 ? 0 : q[k].a0], a1 = w.atoms[q[k].a1 < 0 ? 0 : q[k].a1];
-          const double a2 = w.atoms[q[k].a2 < 0 ? 0 : q[k].a2], a3 = w.atoms[q[k].a3 < 0 ? 0 : q[k].a3];
-          v[k] = q[k].coef * (q[k].a0 < 0 ? 1.0 : a0) * (q[k].a1 < 0 ? 1.0 : a1) * (q[k].a2 < 0 ? 1.0 : a2) * (q[k].a3 < 0 ? 1.0 : a3);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) tot += v[k];
-      }
-      w.slots[T.sl_list[i]] = tot;
-    }
-    if (d.n_long > 0) {
-      // the tail of the long slots, one wave per slot: lanes stride over the monomials, fixed-order wave sum (a single
-      // thread walking the 314 monomials of the constant term of the formation objective was 302 k of the 379 k
-      // cycles of a converged ADMM x-update)
-      c.sync();
-      for (int q = c.wave(); q < d.n_long; q += c.nwaves()) {
-        const int sl = T.sl_list[q];
-        const int m0 = T.slot_rng[2 * sl] + OMGX_SLOT_CAP, m1 = T.slot_rng[2 * sl + 1];
-        double part = 0.0;
-        for (int m = m0 + c.lane(); m < m1; m += c.nlanes()) {
-          const MonoRec r = T.pm_rec[m];
-          const double a0 = w.atoms[r.a0 < 0 ? 0 : r.a0], a1 = w.atoms[r.a1 < 0 ? 0 : r.a1];
-          const double a2 = w.atoms[r.a2 < 0 ? 0 : r.a2], a3 = w.atoms[r.a3 < 0 ? 0 : r.a3];
-          part += r.coef * (r.a0 < 0 ? 1.0 : a0) * (r.a1 < 0 ? 1.0 : a1) * (r.a2 < 0 ? 1.0 : a2) * (r.a3 < 0 ? 1.0 : a3);
-        }
-        const double rest = c.wave_sum(part);
-        if (c.lane() == 0) w.slots[sl] += rest;
-      }
-    }
-  } else {
-    // (monomials with more than four atoms: the CSR tables, three chained loads per monomial -- the same split:
+  if (d.mono_packed == 1) slots_packed<MonoRec>(c, d, T, w);
+  else if (d.mono_packed == 2) slots_packed<MonoRec8>(c, d, T, w);
+  else {
+    // (monomials with more than eight atoms: the CSR tables, three chained loads per monomial -- the same split:
     // a thread sums the first OMGX_SLOT_CAP monomials of its slot, a wave the rest of a long one)
     OMGX_PFOR(s, d.n_slots) {
       const int m0 = T.slot_rng[2 * s], m1 = T.slot_rng[2 * s + 1];

@@ -32,6 +32,7 @@ struct HostPlan {
   std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, h_addr, t_row, t_pos, tq_addr;
   std::vector<double> reg_w;
   std::vector<MonoRec> pm_rec;
+  std::vector<MonoRec8> pm_rec8, sl_ell8;      // (Dims::mono_packed == 2: Tables::pm_rec / sl_ell point at these)
   std::vector<int32_t> je_rp, slot_rng;
   std::vector<TermRec> trec;
   std::vector<HessRec> hrec;
@@ -272,17 +273,19 @@ struct HostPlan {
     // blocked routine stays in charge of it
     d.wave_root = 0;
     // packed parameter monomials
-    d.mono_packed = (d.n_atoms < 32768) ? 1 : 0;
+    {
+      int maxq = 0;
+      for (int mm = 0; mm < t.n_mono; ++mm) maxq = std::max(maxq, t.pm_ptr[mm + 1] - t.pm_ptr[mm]);
+      d.mono_packed = (d.n_atoms >= 32768 || maxq > 8) ? 0 : (maxq > 4 ? 2 : 1);
+    }
     pm_rec.assign(t.n_mono > 0 ? t.n_mono : 1, MonoRec{0.0, -1, -1, -1, -1});
-    for (int mm = 0; mm < t.n_mono; ++mm) {
+    pm_rec8.assign(d.mono_packed == 2 ? std::max(1, t.n_mono) : 1, MonoRec8{0.0, -1, -1, -1, -1, -1, -1, -1, -1});
+    for (int mm = 0; mm < t.n_mono && d.mono_packed; ++mm) {
       const int q0 = t.pm_ptr[mm], nq = t.pm_ptr[mm + 1] - q0;
-      if (nq > 4) { d.mono_packed = 0; break; }
-      MonoRec& r = pm_rec[mm];
-      r.coef = t.pm_coef[mm];
-      if (nq > 0) r.a0 = (int16_t)t.pm_atom[q0];
-      if (nq > 1) r.a1 = (int16_t)t.pm_atom[q0 + 1];
-      if (nq > 2) r.a2 = (int16_t)t.pm_atom[q0 + 2];
-      if (nq > 3) r.a3 = (int16_t)t.pm_atom[q0 + 3];
+      int16_t a[8];
+      for (int k = 0; k < 8; ++k) a[k] = k < nq ? (int16_t)t.pm_atom[q0 + k] : (int16_t)-1;
+      if (d.mono_packed == 1) pm_rec[mm] = MonoRec{t.pm_coef[mm], a[0], a[1], a[2], a[3]};
+      else pm_rec8[mm] = MonoRec8{t.pm_coef[mm], a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]};
     }
     Tables& T = tables;
     T = Tables();
@@ -382,13 +385,19 @@ struct HostPlan {
         if (cnt(sl_list[i]) > OMGX_SLOT_CAP) ++d.n_long;
         const int len = (c_ + 3) / 4 * 4; sl_glen[i >> 6] = std::max(sl_glen[i >> 6], len); steps = std::max(steps, len);
       }
-      sl_ell.assign((size_t)std::max(1, steps) * std::max(1, no), MonoRec{0.0, -1, -1, -1, -1});
+      const size_t ell_n = (size_t)std::max(1, steps) * std::max(1, no);
+      sl_ell.assign(d.mono_packed == 1 ? ell_n : 1, MonoRec{0.0, -1, -1, -1, -1});
+      sl_ell8.assign(d.mono_packed == 2 ? ell_n : 1, MonoRec8{0.0, -1, -1, -1, -1, -1, -1, -1, -1});
       if (d.mono_packed)
         for (int i = 0; i < no; ++i) {
           const int k0 = slot_rng[2 * sl_list[i]], k1 = std::min(slot_rng[2 * sl_list[i] + 1], k0 + OMGX_SLOT_CAP);
-          for (int k = k0; k < k1; ++k) sl_ell[(size_t)(k - k0) * no + i] = pm_rec[k];
+          for (int k = k0; k < k1; ++k) {
+            if (d.mono_packed == 1) sl_ell[(size_t)(k - k0) * no + i] = pm_rec[k];
+            else sl_ell8[(size_t)(k - k0) * no + i] = pm_rec8[k];
+          }
         }
-      T.sl_list = sl_list.data(); T.sl_ell = sl_ell.data(); T.sl_glen = sl_glen.data();
+      T.sl_list = sl_list.data(); T.sl_glen = sl_glen.data();
+      T.sl_ell = d.mono_packed == 2 ? (const MonoRec*)sl_ell8.data() : sl_ell.data();
     }
     // packed (row, position) of the Jacobian entries
     d.rp_packed = (m < 65535 && d.N < 65536) ? 1 : 0;
@@ -420,7 +429,7 @@ struct HostPlan {
     T.trec = trec.data(); T.hrec = hrec.data();
     T.eqe3 = eqe3.data();
     T.je_row = je_row.data(); T.jt_addr = jt_addr.data(); T.diag_addr = diag_addr.data(); T.tq_addr = tq_addr.data();
-    T.h_addr = h_addr.data(); T.t_row = t_row.data(); T.t_pos = t_pos.data(); T.pm_rec = pm_rec.data();
+    T.h_addr = h_addr.data(); T.t_row = t_row.data(); T.t_pos = t_pos.data(); T.pm_rec = dims.mono_packed == 2 ? (const MonoRec*)pm_rec8.data() : pm_rec.data();
     reg_w.assign(d.N, OMGX_DW_LINEAR);
     for (int tt = 0; tt < t.row_ptr[m + 1]; ++tt) {
       const int32_t* tv = t.t_var + 3 * tt;
