@@ -279,6 +279,11 @@ int  omgx_admm_center(omgx_batch* b, const omgx_admm_layout* lay, const double* 
 int  omgx_admm_update(omgx_batch* b, const omgx_admm_layout* lay, const double* x_ext,
                       const int32_t* nbr, const double* M, const double* F, double rho,
                       double* p, double* z_ij, double* l_ij, double* res);
+/* The same, and sums [3] (device) receives the fleet sums of the three residual columns of this rank's agents
+ * (`admm.py:601-605`), added up in a fixed order by the workgroup that finishes last -- no second launch. */
+int  omgx_admm_update_sums(omgx_batch* b, const omgx_admm_layout* lay, const double* x_ext,
+                           const int32_t* nbr, const double* M, const double* F, double rho,
+                           double* p, double* z_ij, double* l_ij, double* res, double* sums);
 /* neighbour exchange (`admm.py:468-475`): z_ji[b,k] = z_ij_ext[nbr[b,k], slot[b,k]] (same for l),
  * written into p.  z_ij_ext / l_ij_ext [B+halo, n_nghb, ns]. */
 int  omgx_admm_communicate(omgx_batch* b, const omgx_admm_layout* lay, const int32_t* nbr,

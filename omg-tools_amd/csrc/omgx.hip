@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(256)
 admm_update_kernel(omgx_admm_layout lay, const double* __restrict__ x_ext, const int32_t* __restrict__ nbr,
                    const double* __restrict__ M, const double* __restrict__ F, double rho,
                    double* __restrict__ p, int n_par, double* __restrict__ z_ij, double* __restrict__ l_ij,
-                   double* __restrict__ res) {
+                   double* __restrict__ res, double* __restrict__ sums, int* __restrict__ done) {
   extern __shared__ __align__(16) double lds[];
   const int ns = lay.n_dim * lay.L, nn = lay.n_nghb, na = (1 + nn) * ns;
   double* xa = lds; double* la = lds + na; double* zp = lds + 2 * na; double* va = lds + 3 * na;
@@ -491,6 +491,30 @@ admm_update_kernel(omgx_admm_layout lay, const double* __restrict__ x_ext, const
     D *= rho;
     res[3 * b] = P; res[3 * b + 1] = D; res[3 * b + 2] = rho * P + D;
   }
+  if (!sums) return;
+  // Fleet sums of the three residuals by the workgroup that finishes last (no second launch): thread t adds the
+  // agents t, t + 256, ... in that order, then a fixed tree over the 256 partial sums -- the same bits whichever
+  // workgroup happens to be the last one.
+  __shared__ int last;
+  if (threadIdx.x == 0) { __threadfence(); last = atomicAdd(done, 1) == (int)gridDim.x - 1 ? 1 : 0; }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const int B = gridDim.x;
+  const volatile double* rv = res;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int a = threadIdx.x; a < B; a += blockDim.x) { s0 += rv[3 * a]; s1 += rv[3 * a + 1]; s2 += rv[3 * a + 2]; }
+  double* t3 = lds;                       // (6 na + 16 doubles are there; 3 x 256 are needed: see the launch)
+  t3[threadIdx.x] = s0; t3[256 + threadIdx.x] = s1; t3[512 + threadIdx.x] = s2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      t3[threadIdx.x] += t3[threadIdx.x + off]; t3[256 + threadIdx.x] += t3[256 + threadIdx.x + off];
+      t3[512 + threadIdx.x] += t3[512 + threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { sums[0] = t3[0]; sums[1] = t3[256]; sums[2] = t3[512]; *done = 0; }
 }
 
 __global__ void admm_comm_kernel(omgx_admm_layout lay, const int32_t* __restrict__ nbr,
@@ -522,6 +546,7 @@ struct omgx_batch {
   const int32_t* d_order = nullptr; // optional launch order (device pointer owned by the caller)
   const int32_t* pend_iters = nullptr; int32_t* pend_order = nullptr;   // omgx_batch_order_by_iters not launched yet
   int* d_next = nullptr;            // spill modes: counter of the dynamic slot hand-out
+  int* d_admm_done = nullptr;       // admm_update_kernel: finished workgroups (fleet sums by the last one)
   const double* d_x0_alt = nullptr; // restart guesses [n_alt][n_agents][n_var] (device, owned by the caller)
   int n_alt = 0;
   int32_t* d_attempts = nullptr;    // optional [n_agents] (device, owned by the caller): restarts each agent used
@@ -1227,14 +1252,25 @@ int omgx_admm_center(omgx_batch* b, const omgx_admm_layout* lay, const double* x
 int omgx_admm_update(omgx_batch* b, const omgx_admm_layout* lay, const double* x_ext, const int32_t* nbr,
                      const double* M, const double* F, double rho, double* p, double* z_ij, double* l_ij,
                      double* res) {
+  return omgx_admm_update_sums(b, lay, x_ext, nbr, M, F, rho, p, z_ij, l_ij, res, nullptr);
+}
+
+int omgx_admm_update_sums(omgx_batch* b, const omgx_admm_layout* lay, const double* x_ext, const int32_t* nbr,
+                          const double* M, const double* F, double rho, double* p, double* z_ij, double* l_ij,
+                          double* res, double* sums) {
   if (!b || !lay || !x_ext || !nbr || !M || !F || !p || !z_ij || !l_ij || !res || !(rho > 0)) {
     g_err = "bad argument"; return OMGX_E_INVALID;
   }
   const int na = (1 + lay->n_nghb) * lay->n_dim * lay->L;
   if (na > 256) { g_err = "stacked consensus vector longer than 256"; return OMGX_E_TOOLARGE; }
   HIPCHK(hipSetDevice(b->device));
-  hipLaunchKernelGGL(admm_update_kernel, dim3(b->n_agents), dim3(256), (6 * na + 16) * sizeof(double), b->stream,
-                     *lay, x_ext, nbr, M, F, rho, p, b->dims.n_par, z_ij, l_ij, res);
+  if (sums && !b->d_admm_done) {
+    int rc = dalloc(b, (size_t)1, &b->d_admm_done); if (rc != OMGX_OK) return rc;
+    HIPCHK(hipMemset(b->d_admm_done, 0, sizeof(int)));
+  }
+  const size_t lds_doubles = (size_t)std::max(6 * na + 16, sums ? 3 * 256 : 0);
+  hipLaunchKernelGGL(admm_update_kernel, dim3(b->n_agents), dim3(256), lds_doubles * sizeof(double), b->stream,
+                     *lay, x_ext, nbr, M, F, rho, p, b->dims.n_par, z_ij, l_ij, res, sums, b->d_admm_done);
   HIPCHK(hipGetLastError());
   return OMGX_OK;
 }

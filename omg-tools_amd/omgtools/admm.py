@@ -183,7 +183,10 @@ class HipAdmmOps(object):
         lib.omgx_admm_center.argtypes = [C.c_void_p, C.POINTER(AdmmLayoutC)] + [C.c_void_p] * 3
         lib.omgx_admm_update.argtypes = [C.c_void_p, C.POINTER(AdmmLayoutC)] + [C.c_void_p] * 4 + \
             [C.c_double] + [C.c_void_p] * 4
+        lib.omgx_admm_update_sums.argtypes = [C.c_void_p, C.POINTER(AdmmLayoutC)] + [C.c_void_p] * 4 + \
+            [C.c_double] + [C.c_void_p] * 5
         lib.omgx_admm_communicate.argtypes = [C.c_void_p, C.POINTER(AdmmLayoutC)] + [C.c_void_p] * 5
+        self._sum_blocks, self._sum_k, self._sums = [], 0, None     # fleet residual sums, one row per update (history)
         solver.set_stream(torch.cuda.current_stream().cuda_stream)
         self.zl = torch.zeros((B, 2 * self.nn * self.ns), **f64)      # [z_ij | l_ij] packed for the exchange
         self._nbr = self._slot = None
@@ -245,15 +248,21 @@ class HipAdmmOps(object):
         if not t.is_tensor(M):
             M, F = self.resident(M, F)
         x_ext = x_ext.contiguous()
-        self._chk(self.solver.lib.omgx_admm_update(
+        # the fleet sums of the residuals come out of the same launch (the workgroup that finishes last adds them up
+        # in a fixed order); every update gets its own row, BatchADMM keeps them as the residual history
+        if self._sum_k % 1024 == 0:
+            self._sum_blocks.append(t.zeros((1024, 3), dtype=t.float64, device=self.dev))
+        self._sums = self._sum_blocks[-1][self._sum_k % 1024]
+        self._sum_k += 1
+        self._chk(self.solver.lib.omgx_admm_update_sums(
             self.solver._h, C.byref(self.layc), x_ext.data_ptr(), self._nbr.data_ptr(), M.data_ptr(),
             F.data_ptr(), float(rho), self.p.data_ptr(), self.z_ij.data_ptr(), self.l_ij.data_ptr(),
-            self.res.data_ptr()), 'omgx_admm_update')
+            self.res.data_ptr(), self._sums.data_ptr()), 'omgx_admm_update_sums')
         self._keep = (M, F, x_ext)
         return self.res
 
     def residual_sums(self, res):
-        return res.sum(dim=0)
+        return self._sums if res is self.res and self._sums is not None else res.sum(dim=0)
 
     def zl_flat(self, with_prev=False):
         B, w = self.B, self.nn * self.ns
