@@ -67,6 +67,30 @@ def test_solver_plan_is_block_arrow(cfg2_small):
     assert plan['wave_path'] == 1 and plan['ws_mode'] == 0
 
 
+def test_workspace_modes_of_the_benchmark_classes():
+    """Which workspace placement the library picks for BASELINE.json's classes (host only): config 2 all in LDS on the
+    register-resident path, config 3 with the KKT store in an HBM slab, config 5 with the row arrays there as well;
+    the LDS part always fits one CU; the formation template (monomials with up to seven atoms) is accepted."""
+    import omgtools.backend as be
+    from omgtools import scenarios
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        want = {'holonomic_p2p': (0, 1), 'quadrotor_p2p': (1, 0), 'holonomic3d_p2p': (3, 0)}
+        for name, (mode, wave) in want.items():
+            problem, _ = getattr(scenarios, name)(2)
+            plan = be.describe_plan(problem.father.template)
+            if mode == 0:
+                assert plan['wave_path'] == wave, name
+            assert plan['ws_mode'] == mode and 0 < plan['lds_bytes'] <= 160 * 1024, (name, plan['ws_mode'], plan['lds_bytes'])
+            assert all(bw <= 8 for bw in plan['leaf_bw']), name              # banded leaves (Cuthill-McKee order)
+        father = scenarios.formation_holonomic(4)[2]
+        plan = be.describe_plan(father.template)
+        assert plan['ws_mode'] in (0, 1) and plan['lds_bytes'] <= 160 * 1024
+    finally:
+        be.create_nlp = saved
+
+
 def test_plan_without_root_hint_finds_a_separator(cfg2_small):
     """No structure hint from the caller: the library picks the root itself (highest-degree variables
     first) and still gets leaves that fit one wave."""
