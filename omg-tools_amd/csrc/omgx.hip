@@ -496,13 +496,16 @@ admm_update_kernel(omgx_admm_layout lay, const double* __restrict__ x_ext, const
   // agents t, t + 256, ... in that order, then a fixed tree over the 256 partial sums -- the same bits whichever
   // workgroup happens to be the last one.
   __shared__ int last;
-  if (threadIdx.x == 0) { __threadfence(); last = atomicAdd(done, 1) == (int)gridDim.x - 1 ? 1 : 0; }
+  if (threadIdx.x == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); last = atomicAdd(done, 1) == (int)gridDim.x - 1 ? 1 : 0; }
   __syncthreads();
   if (!last) return;
-  __threadfence();
+  // (acquire at device scope: the other workgroups' res rows -- written before their release + counter increment --
+  // are visible to plain loads from here on, which the compiler can keep in flight together)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   const int B = gridDim.x;
-  const volatile double* rv = res;
+  const double* rv = res;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
   for (int a = threadIdx.x; a < B; a += blockDim.x) { s0 += rv[3 * a]; s1 += rv[3 * a + 1]; s2 += rv[3 * a + 2]; }
   double* t3 = lds;                       // (6 na + 16 doubles are there; 3 x 256 are needed: see the launch)
   t3[threadIdx.x] = s0; t3[256 + threadIdx.x] = s1; t3[512 + threadIdx.x] = s2;
