@@ -645,9 +645,6 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   }
   b->ws_mode = mode; b->lds_bytes = nl * sizeof(double); b->slab_doubles = ng;
   if (mode != omgx::WS_LDS) b->dims.wave_ok = 0;      // the wave-level routines address the KKT store as LDS
-  // developer knobs (A/B measurements of the register-resident routines against the blocked ones)
-  if (const char* e = getenv("OMGX_WAVE_LEAF")) b->dims.wave_leaf = b->dims.wave_leaf && atoi(e);
-  if (const char* e = getenv("OMGX_WAVE_ROOT")) b->dims.wave_root = b->dims.wave_root && atoi(e);
   const omgx::Tables& H = plan.tables;
   const omgx::Dims& d = plan.dims;
   UP(prog, 6 * d.n_prog); UP(knots, t->n_knots); UP(pp_ptr, t->n_pp + 1); UP(pm_coef, t->n_mono);
@@ -1058,8 +1055,7 @@ int stage_shift_tables(omgx_batch* b, const int32_t* entries, int32_t n_ent, con
   if (same) return OMGX_OK;
   // (stream order: kernels of earlier shifts read the old tables; they are done before these copies start)
   if (ne > b->shift_ent_cap) {
-    if (b->d_store) (void)hipFree(b->d_store);
-  if (b->d_shift_ent) (void)hipFree(b->d_shift_ent);
+    if (b->d_shift_ent) (void)hipFree(b->d_shift_ent);
     b->d_shift_ent = nullptr; b->shift_ent_cap = 0;
     HIPCHK(hipMalloc((void**)&b->d_shift_ent, ne * sizeof(int32_t)));
     b->shift_ent_cap = ne;

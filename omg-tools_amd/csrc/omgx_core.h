@@ -60,9 +60,6 @@ struct Dims {
   int rp_packed;     // 1: rows and positions fit 16 bits each, Tables::je_rp is valid
   int n_knots;       // total length of the knot vectors of the atoms program (copied to LDS per solve)
   int wave_ok;       // 1: every panel of the KKT store fits one wave (register-resident factorisation, omgx_wave.h)
-  int wave_leaf;     // 1 (and wave_ok == 0): leaves of <= 64 columns, band <= 8: register-resident leaf factorisation with a second pass
-                     //    for the coupling rows (wave_carry), the store in LDS or in global memory (kkt_factor_wave_general)
-  int wave_root;     // with wave_leaf: the root (nr <= 64) is factorised by one wave as well
   int n_jv;          // Jacobian entries whose value depends on x (the others are constant over a solve)
   int ka_len, kh_len, kg_len;   // records per owner bin (longest bin) of the pair / Hessian / Gershgorin passes
   int n_kafix, n_kgfix;         // targets whose run was cut (fix-up records)
@@ -297,7 +294,6 @@ struct Ctx {
   double rmax(double v) const { return v; }
   double rmin(double v) const { return v; }
   template <int... OPS> void reduce_ops(double (&)[sizeof...(OPS)]) const {}
-  void add(double* p, double v) const { *p += v; }
   int lane() const { return 0; }
   int nlanes() const { return 1; }
   int wave() const { return 0; }
@@ -384,7 +380,6 @@ struct CtxT {
   __device__ double wave_sum(double v) const { return wave_reduce<0>(v); }      // all lanes of the wave must be active
   __device__ double rmax(double v) const { return reduce<1>(v); }
   __device__ double rmin(double v) const { return reduce<2>(v); }
-  __device__ void add(double* p, double v) const { atomicAdd(p, v); }   // ds_add_f64 on LDS
   __device__ int lane() const { return threadIdx.x & 63; }
   __device__ int nlanes() const { return 64; }
   __device__ int wave() const { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }     // (provably wave-uniform: scalar branches)
@@ -1300,130 +1295,6 @@ OMGX_FN int kkt_refactor_root_wave(const C& c, const Dims& d, const Kkt& K, Work
   return bad;
 }
 
-#ifdef OMGX_WAVE_GENERAL
-// EXPERIMENT (off by default; -DOMGX_WAVE_GENERAL): measured on MI355X, round 2 (profiles/r02_spill_wave_ab.txt) --
-// the Quadrotor class gains 12 % per cold solve (47.6 against 54.0 ms, 64 agents) with the leaves done this way and
-// the root left to the blocked routine; the root by one wave from a store in global memory gives a wrong inertia
-// (not understood yet); for the 3-D class the second pass (512 dependent broadcast loads from L2 per leaf) costs
-// more than the first pass saves; and merely compiling these routines into the kernel slows the blocked path of
-// the 3-D class down by 40 % (755 against 538 ms per 1024 cold solves: register allocation of the surrounding
-// code).  What it needs next: the band of the factor staged in LDS for the second pass, the Schur loads batched.
-// (out of line: inlined into one function, the three 64-column routines push the register allocator into scratch
-// memory -- and this compiler then emits an illegal instruction for the private-aperture test)
-template <bool G> __device__ __attribute__((noinline)) int wave_ldl_leaf64(int off, WPanel P, double* g) { return wave_ldl<64, 8, G>(off, P, g); }
-template <bool G> __device__ __attribute__((noinline)) int wave_ldl_root64(int off, WPanel P, double* g) { return wave_ldl<64, 64, G>(off, P, g); }
-template <bool G> __device__ __attribute__((noinline)) void wave_carry64(int off, WPanel P, double* g, const double* dinv, int r0, int nrows) {
-  wave_carry<64, 8, G>(off, P, g, dinv, r0, nrows);
-}
-
-// General form for the classes whose panels do not fit one wave (Quadrotor: leaves of 42 + 35 coupling rows, root
-// 49; Holonomic3D: leaves of 64 + 55, root 73) and whose store lives in global memory (spill modes): the leaf
-// block and the two vector rows by wave_ldl<64, 8>, the coupling rows by a second pass (wave_carry), the Schur
-// complement as up to 4 x 4 MFMA tiles per leaf, the root by wave_ldl<64, 64> when it has <= 64 rows, else by the
-// blocked routine.  Same storage conventions as everything else: kkt_solve (the general one) finishes the job.
-template <class C>
-OMGX_FN int kkt_factor_wave_general(const C& c, const Dims& d, const Kkt& K, Work& w) {
-  typedef double v4d __attribute__((ext_vector_type(4)));
-  constexpr bool G = C::hbm;
-  const BMat* Ms = (const BMat*)w.col;
-  const int lane = c.lane(), wave = c.wave(), nw = c.nwaves();
-  const int koff = G ? 0 : (int)(w.kkt - omgx_lds);
-  OMGX_TIC();
-  int badl = 0;
-  for (int l = wave; l < d.n_leaf; l += nw) {
-    const BMat M = Ms[l];
-    WPanel P = wpanel_leaf(M);
-    P.nreg = P.n;                                       // the lanes hold the leaf block only; coupling rows: second pass
-    const int bl = wave_ldl_leaf64<G>(koff, P, w.kkt);
-    badl |= bl;
-    wave_fence();
-    const double dl = wave_dinv(w.kkt, P);
-    const int dv = __builtin_amdgcn_readfirstlane(M.dinv);
-    if (lane < P.n) w.dinv[dv + lane] = dl;
-    wave_fence();
-    if (!bl) {
-      const int ncr = __builtin_amdgcn_readfirstlane(M.rows) - 2 - __builtin_amdgcn_readfirstlane(M.nfact);     // coupling rows but the last (a vector row)
-      wave_carry64<G>(koff, P, w.kkt, w.dinv + dv, P.n, ncr);
-    }
-  }
-  if (c.rmax(badl ? 1.0 : 0.0) > 0.0) return 1;
-  OMGX_TOC(PH_F_LEAF);
-  double* R = K.R();
-  for (int base = 0; base < d.n_leaf; base += nw) {
-    const int l = base + wave;
-    v4d acc[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) acc[i] = v4d{0.0, 0.0, 0.0, 0.0};
-    int nc1 = 0;
-    const int32_t* ci = K.cpl_idx;
-    if (l < d.n_leaf) {
-      const BMat M = Ms[l];
-      const int n = __builtin_amdgcn_readfirstlane(M.nfact), ld = __builtin_amdgcn_readfirstlane(M.ld);
-      nc1 = __builtin_amdgcn_readfirstlane(M.rows) - n;            // coupling rows + the right-hand-side row (last)
-      const double* Wt = w.kkt + __builtin_amdgcn_readfirstlane(M.a) + n * ld;
-      const double* di = w.dinv + __builtin_amdgcn_readfirstlane(M.dinv);
-      ci += __builtin_amdgcn_readfirstlane(M.cpl);
-      const int nt = (nc1 + 15) >> 4, q = lane >> 4;
-      for (int j0 = 0; j0 < n; j0 += 4) {
-        const int j = j0 + q, jc = j < n ? j : n - 1;
-        const double dj = di[jc];
-        double bv[4];
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          const int r = 16 * ti + (lane & 15), rc = r < nc1 ? r : nc1 - 1;
-          const double v = Wt[rc * ld + jc];
-          bv[ti] = (r < nc1 && j < n) ? v : 0.0;
-        }
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          if (ti < nt) {
-#pragma unroll
-            for (int tj = 0; tj <= ti; ++tj) acc[(ti * (ti + 1)) / 2 + tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[ti] * dj, bv[tj], acc[(ti * (ti + 1)) / 2 + tj], 0, 0, 0);
-          }
-        }
-      }
-    }
-    // subtract from the root, one leaf per round (fixed order of the sums)
-    const int lend = base + nw < d.n_leaf ? base + nw : d.n_leaf;
-    for (int lr = base; lr < lend; ++lr) {
-      if (l == lr) {
-        const int nt = (nc1 + 15) >> 4;
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          if (ti < nt) {
-#pragma unroll
-            for (int tj = 0; tj <= ti; ++tj) {
-              const int cb = 16 * tj + (lane & 15);
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const int ca = 16 * ti + (lane >> 4) + 4 * i;
-                if (ca < nc1 && cb < nc1 - 1 && cb <= ca) {
-                  const int ra = ca < nc1 - 1 ? ci[ca] : d.nr;
-                  R[tri(ra, ci[cb])] -= acc[(ti * (ti + 1)) / 2 + tj][i];
-                }
-              }
-            }
-          }
-        }
-      }
-      c.sync();
-    }
-  }
-  OMGX_TOC(PH_F_SCHUR);
-  int bad = 0;
-  if (d.wave_root) {
-    int badr = 0;
-    if (wave == 0) badr = wave_ldl_root64<G>(koff, wpanel_root(Ms[d.n_leaf], d.n_root), w.kkt);
-    bad = c.rmax(badr ? 1.0 : 0.0) > 0.0 ? 1 : 0;
-  } else {
-    double* stage = w.col + OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1);
-    ldl_blocked<2>(c, (BMat*)w.col + d.n_leaf, 1, w.kkt, w.dinv, w.col, stage, &bad);
-  }
-  OMGX_TOC(PH_F_ROOT);
-  return bad;
-}
-
-#endif  // OMGX_WAVE_GENERAL
 
 // the solve that goes with kkt_factor_wave: root backward substitution by wave 0, then every leaf wave
 // corrects its right-hand side by the root solution and substitutes backwards -- no workgroup barrier
@@ -1473,9 +1344,6 @@ template <class C>
 OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
 #ifndef OMGX_HOST_PORT
   if constexpr (!C::no_wave) { if (C::wave_only || d.wave_ok) return kkt_factor_wave(c, d, K, w); }
-#ifdef OMGX_WAVE_GENERAL
-  if (d.wave_leaf) return kkt_factor_wave_general(c, d, K, w);
-#endif
 #endif
   if constexpr (C::wave_only) return 1; else {
   int bad = 0;

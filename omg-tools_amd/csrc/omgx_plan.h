@@ -256,22 +256,6 @@ struct HostPlan {
       const int n = leaf_off[l + 1] - leaf_off[l], nc = cpl_ptr[l + 1] - cpl_ptr[l];
       if (n > OMGX_WAVE_COLS || n + nc - 1 > OMGX_WAVE_ROWS || nc + 1 > 32) d.wave_ok = 0;
     }
-    // general form (kkt_factor_wave_general): leaves of <= 64 columns and <= 64 carried rows, band <= 8
-#ifdef OMGX_WAVE_GENERAL
-    d.wave_leaf = (d.wave_ok || d.n_leaf == 0) ? 0 : 1;
-#else
-    d.wave_leaf = 0;
-#endif
-    for (int l = 0; l < d.n_leaf; ++l) {
-      const int n = leaf_off[l + 1] - leaf_off[l], nc = cpl_ptr[l + 1] - cpl_ptr[l];
-      if (n > 64 || nc + 1 > 64 || leaf_bw[l] > 8) d.wave_leaf = 0;
-      // measured (profiles/r02_spill_wave_ab.txt): with the store in global memory the second pass (512 broadcast
-      // loads from L2 for a 64-column leaf) costs more than it saves; the Quadrotor class (42 columns) gains 12 %
-      if (n > 48) d.wave_leaf = 0;
-    }
-    // the root by one wave from a store in global memory: wrong inertia on the device (cause not found yet), the
-    // blocked routine stays in charge of it
-    d.wave_root = 0;
     // packed parameter monomials
     {
       int maxq = 0;

@@ -35,7 +35,7 @@ __device__ __forceinline__ void wave_fence() {
 // rows [n, nreg): carried rows held one per lane; rows [nreg, nreg + nvec): carried rows held as lane
 // vectors.  Row r starts at base + r * ld + packed * r (r + 1) / 2 (row-major leaf panels: packed = 0;
 // packed lower root: ld = 0, packed = 1).  Pivots j < npos must be positive, the others negative.
-struct WPanel { int base, ld, packed, n, nreg, nvec, npos, bw, vrow; };    // bw: half bandwidth of the symmetric block (n - 1: dense); vrow: index of the first vector row (>= nreg: the rows between are carried by wave_carry)
+struct WPanel { int base, ld, packed, n, nreg, nvec, npos, bw, vrow; };    // bw: half bandwidth of the symmetric block (n - 1: dense); vrow: index of the first vector row
 
 // The descriptor fields are the same in every lane but come from LDS (per-lane loads): without this the
 // compiler has to treat every loop bound of the routines below as divergent (exec-masked regions
@@ -171,45 +171,6 @@ __device__ __forceinline__ double wave_dinv(const double* A, const WPanel P) {
   const int c = lane < P.n ? lane : 0;
   const double d = A[wrow(P, c) + c];
   return lane < P.n ? rcp_pivot(d) : 0.0;
-}
-
-// Carried rows that did not fit the lanes of wave_ldl (leaf order + coupling rows > 64: the Quadrotor and 3-D
-// classes): rows [r0, r0 + nrows) of the panel, one per lane, W = B L^{-T} by forward substitution along the row,
-//   w_k -= (w_j / d_j) u_kj   for the columns k in (j, j + BW]  (u_kj = 0 outside the band),
-// with u_kj read from the stored factor (the same address in every lane: a broadcast read) and the inverse
-// pivots from `dinv` (LDS).  Same straight-line form as wave_ldl; call after wave_ldl + wave_fence.
-template <int NC, int BW, bool G>
-__device__ __forceinline__ void wave_carry(int off, const WPanel Pin, double* g, const double* dinv, int r0, int nrows) {
-  const WStore<G> A(off, g);
-  const WPanel P = wpanel_uniform(Pin);
-  const int lane = threadIdx.x & 63;
-  const int n = P.n;
-  nrows = __builtin_amdgcn_readfirstlane(nrows); r0 = __builtin_amdgcn_readfirstlane(r0);
-  const bool has = lane < nrows;
-  const int ra = wrow(P, r0 + (has ? lane : 0));
-  double a[NC];
-#pragma unroll
-  for (int k = 0; k < NC; ++k) {
-    const double v = A.ld(ra + (k < n ? k : n - 1));
-    a[k] = (has && k < n) ? v : 0.0;
-  }
-#pragma unroll
-  for (int j = 0; j < NC; ++j) {
-    const double dj = dinv[j < n ? j : 0];
-    const double lw = (j < n) ? a[j] * dj : 0.0;
-#pragma unroll
-    for (int q = 1; q <= BW; ++q) {
-      const int k = j + q;
-      if (k < NC) {
-        const double u = A.ld(wrow(P, k < n ? k : n - 1) + (j < n ? j : 0));
-        a[k] = fma(-lw, (k < n) ? u : 0.0, a[k]);
-      }
-    }
-  }
-  if (has) {
-#pragma unroll
-    for (int k = 0; k < NC; ++k) if (k < n) A.st(ra + k, a[k]);
-  }
 }
 
 // x <- L^{-T} z for the factor stored in the panel (U = L D in LDS, left by wave_ldl): lane j reads

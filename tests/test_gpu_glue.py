@@ -154,6 +154,63 @@ def test_store_kernel_and_fused_store_match_splines2signals():
     solver.close()
 
 
+def test_fused_store_survives_a_knot_crossing_shift():
+    """set_store -> shift (first use of the handle's shift tables) -> solve -> the trajectories the solve wrote equal
+    the stand-alone kernel's on the same solution -> destroy.  (Round-2 advice: the first shift on a handle used to
+    free the device copy of the store specification; the receding-horizon loop of INTEGRATION.md 4 is this
+    sequence.)"""
+    import torch
+    from omgtools.backend import BatchSolver
+    from omgtools.splines import shiftoverknot_T
+    B = 8
+    problem, P = _setup(B)
+    tpl, veh = problem.father.template, problem.vehicles[0]
+    T = float(problem.options['horizon_time'])
+    lo = tpl.entry_range(veh.label, 'splines_seg0', 'var')[0]
+    L, nd, n_samp, sample_time = len(veh.basis), veh.n_dim, 501, 0.01
+    dev = torch.device('cuda', 0)
+    f64 = dict(dtype=torch.float64, device=dev)
+    solver = BatchSolver(tpl, B, options=dict(tol=1e-6, max_iter=300))
+    out, vt, t0 = torch.zeros((B, 3, nd, n_samp), **f64), torch.zeros((B, n_samp), **f64), torch.zeros(B, **f64)
+    knots = veh.basis.knots
+    solver.set_store(out, vt, t0, lo, nd, veh.degree, knots, 3, n_samp, sample_time / T, 1.0 / T)
+    xd, pd = torch.as_tensor(P['x0'], **f64), torch.as_tensor(P['p'], **f64)
+    lb, ub = torch.as_tensor(tpl.lb, **f64), torch.as_tensor(tpl.ub, **f64)
+    xs, lam = torch.empty_like(xd), torch.zeros((B, tpl.n_con), **f64)
+    st, it = torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+    solver.solve_device(pd, xd, lb, ub, xs, lam, st, it, bounds_shared=True)
+    torch.cuda.synchronize()
+    assert (st == 0).all()
+    # knot crossing: the plan of every agent is shifted on the device (allocates the handle's shift tables)
+    Tm = shiftoverknot_T(veh.basis)
+    ents = np.array([[lo, L, nd, 0]], dtype=np.int32)
+    mask = torch.ones(B, dtype=torch.uint8, device=dev)
+    want = np.concatenate([Tm @ xs.cpu().numpy()[:, lo + k * L:lo + (k + 1) * L].T for k in range(nd)]).T
+    solver.shift(xs, mask, ents, np.asarray(Tm, dtype=np.float64).reshape(-1), device=True)
+    torch.cuda.synchronize()
+    assert np.abs(xs.cpu().numpy()[:, lo:lo + nd * L] - want).max() < 1e-12
+    # the next solve (from the shifted plan) still writes its trajectories where set_store said
+    out.zero_(); vt.zero_()
+    x2 = torch.empty_like(xd)
+    solver.solve_device(pd, xs, lb, ub, x2, lam, st, it, bounds_shared=True)
+    torch.cuda.synchronize()
+    assert (st == 0).all()
+    fused, fused_v = out.cpu().numpy().copy(), vt.cpu().numpy().copy()
+    assert np.abs(fused).max() > 0.1
+    # a second set_store (copies into the same device block) and the stand-alone kernel: the same bits
+    out2, vt2 = torch.zeros_like(out), torch.zeros_like(vt)
+    solver.set_store(out2, vt2, t0, lo, nd, veh.degree, knots, 3, n_samp, sample_time / T, 1.0 / T)
+    solver.solve_device(pd, xs, lb, ub, x2, lam, st, it, bounds_shared=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), fused) and np.array_equal(vt2.cpu().numpy(), fused_v)
+    solver.set_store(None)
+    out3, vt3 = torch.zeros_like(out), torch.zeros_like(vt)
+    solver.store(x2, out3, vt3, t0, lo, nd, veh.degree, knots, 3, n_samp, sample_time / T, 1.0 / T)
+    torch.cuda.synchronize()
+    assert np.array_equal(out3.cpu().numpy(), fused) and np.array_equal(vt3.cpu().numpy(), fused_v)
+    solver.close()
+
+
 def test_restart_pass_solves_only_the_failed_agents():
     """OMGX_ONLY_FAILED: a second call with other initial guesses touches only the agents that failed; BatchP2P's
     cold solve uses it with the straight-line guess bent sideways (Quadrotor class: phase-I stalls)."""
