@@ -359,6 +359,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--agents', type=int, default=1024, help='agents per GPU')
     ap.add_argument('--tol', type=float, default=1e-3)
+    ap.add_argument('--knot-intervals', type=int, default=11, help='(p2p workload; BASELINE configs[1]: 11)')
+    ap.add_argument('--obstacles', type=int, default=3, help='(p2p workload; BASELINE configs[1]: 3)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='seconds of timed CPU work for the cpu_baseline leg (all host cores; a quarter of it on one)')
     ap.add_argument('--no-cpu', action='store_true')
@@ -388,7 +390,7 @@ def main():
     B = args.agents
     saved = be.create_nlp
     be.create_nlp = lambda tpl, opt, name='': (None, 0.)      # BatchP2P below owns the product-path solver
-    problem, P = holonomic_p2p(B, seed=20240807 + 2 + 1000 * rank)
+    problem, P = holonomic_p2p(B, knot_intervals=args.knot_intervals, n_obs=args.obstacles, seed=20240807 + 2 + 1000 * rank)
     be.create_nlp = saved
     tpl = problem.father.template
     opts = dict(tol=args.tol, max_iter=300)
@@ -479,9 +481,9 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'configs[1]: %d-agent Holonomic Point2point per GPU, degree 3, '
-                               'knot_intervals=11, 3 circular obstacles; one step = one receding-horizon '
+                               'knot_intervals=%d, %d circular obstacles; one step = one receding-horizon '
                                'MPC step of every agent (update_time 0.1 s, ideal prediction, primal-dual '
-                               'warm start) after a cold solve; tol=%g' % (B, args.tol),
+                               'warm start) after a cold solve; tol=%g' % (B, args.knot_intervals, args.obstacles, args.tol),
                    'agents_per_gpu': B, 'n_var': tpl.n_var, 'n_con': tpl.n_con,
                    'parallelism': 'agents sharded across ranks, no collective on the solve path'},
         'p50_batch_latency_ms': float(np.median(kernel_ms)), 'max_batch_latency_ms': float(np.max(kernel_ms)),

@@ -36,6 +36,7 @@ thread_local std::string g_err;
 
 constexpr int kThreads = 512;
 constexpr int kLdsLimit = 160 * 1024;
+constexpr int kLdsHalf = kLdsLimit / 2 - 512;      // two workgroups per CU (their static LDS and the allocation granule taken off)
 
 }  // namespace
 
@@ -172,9 +173,9 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  unsigned long long* __restrict__ stats) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
-  omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
+    omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
                                d, kkt_doubles);
-  omgx::CtxT<(MODE != omgx::WS_LDS), WAVE_ONLY, (MODE != omgx::WS_LDS)> c; c.red = w.red;
+  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_kkt_hbm(MODE)> c; c.red = w.red;
 #ifdef OMGX_PROFILE
   __shared__ long long prof_lds[omgx::PH_COUNT];
   c.prof = prof_lds;
@@ -192,7 +193,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   __shared__ int slot_lds;
   for (int slot = blockIdx.x; slot < n_agents;) {
     const int b = order ? order[slot] : slot;
-    if (MODE == omgx::WS_LDS || !next_slot) slot += gridDim.x;
+    if (!next_slot) slot += gridDim.x;
     else {
       if (threadIdx.x == 0) slot_lds = gridDim.x + atomicAdd(next_slot, 1);
       __syncthreads();
@@ -255,7 +256,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 #endif
     __syncthreads();
   }
-  if (MODE != omgx::WS_LDS && next_slot && threadIdx.x == 0) {
+  if (next_slot && threadIdx.x == 0) {
     __threadfence();
     if (atomicAdd(next_slot + 1, 1) == (int)gridDim.x - 1) { next_slot[0] = 0; next_slot[1] = 0; __threadfence(); }
   }
@@ -269,6 +270,7 @@ static ipm_kernel_t ipm_kernel_for(int mode, int wave_ok) {
     case omgx::WS_LDS: return wave_ok ? ipm_solve_kernel<omgx::WS_LDS, true> : ipm_solve_kernel<omgx::WS_LDS, false>;
     case omgx::WS_KKT_HBM: return ipm_solve_kernel<omgx::WS_KKT_HBM, false>;
     case omgx::WS_JAC_HBM: return ipm_solve_kernel<omgx::WS_JAC_HBM, false>;
+    case omgx::WS_JAC_ONLY: return ipm_solve_kernel<omgx::WS_JAC_ONLY, true>;
     default: return ipm_solve_kernel<omgx::WS_ROWS_HBM, false>;
   }
 }
@@ -543,6 +545,8 @@ struct omgx_batch {
   int kkt_doubles = 0;
   size_t lds_bytes = 0;
   int ws_mode = 0, n_slabs = 0;        // workspace placement (omgx::WS_*), HBM slabs (= grid cap)
+  int threads = kThreads;              // workgroup size of the solve kernel
+  int per_cu = 1;                      // workgroups (agents in flight) per CU the workspace allows
   size_t slab_doubles = 0;
   double* d_slabs = nullptr;
   double* d_dw = nullptr;          // per-agent inertia correction carried between warm-started solves
@@ -603,17 +607,36 @@ int dalloc(omgx_batch* b, size_t n, T** dst) {
 // smallest spill mode whose LDS part fits one CU (WS_MODES: none does)
 int pick_mode(const omgx::Dims& d, int kkt_doubles, size_t* lds_doubles, size_t* hbm_doubles) {
   int mode = 0;
-  for (; mode < omgx::WS_MODES; ++mode) {
+  for (; mode <= omgx::WS_ROWS_HBM; ++mode) {
     omgx::work_split(d, kkt_doubles, mode, lds_doubles, hbm_doubles);
     if (*lds_doubles * sizeof(double) <= (size_t)kLdsLimit) break;
   }
-  return mode;
+  return mode <= omgx::WS_ROWS_HBM ? mode : omgx::WS_MODES;
 }
 
 // The plan of a template for the workspace mode it gets: the spill modes store the leaf panels by columns
 // (omgx_plan.h `col_major`), so their plan is built a second time once the mode is known.
-bool plan_for_mode(omgx::HostPlan& plan, const omgx_template& t, int* mode, size_t* lds_doubles, size_t* hbm_doubles) {
+// Templates on the register-resident wave path get the compact store; when their workspace then fits half a CU -- all
+// of it, or with the Jacobian values and hv in a slab (WS_JAC_ONLY) -- two agents share a CU: *per_cu = 2, workgroups
+// of 256 threads (a solve is latency bound: four waves are as fast as eight, and the second agent fills the gaps).
+bool plan_for_mode(omgx::HostPlan& plan, const omgx_template& t, int* mode, size_t* lds_doubles, size_t* hbm_doubles, int* per_cu) {
+  *per_cu = 1;
   if (!plan.build(t)) return false;
+  if (plan.dims.wave_ok && !getenv("OMGX_NO_COMPACT")) {
+    // (built in place: HostPlan::tables points into the plan's own vectors)
+    plan = omgx::HostPlan();
+    if (!plan.build(t, false, true)) return false;
+    const int cand[2] = {omgx::WS_LDS, omgx::WS_JAC_ONLY};
+    for (int k = 0; k < 2; ++k) {
+      omgx::work_split(plan.dims, plan.kkt_doubles, cand[k], lds_doubles, hbm_doubles);
+      if (*lds_doubles * sizeof(double) <= (size_t)kLdsHalf && !getenv("OMGX_ONE_PER_CU")) { *mode = cand[k]; *per_cu = 2; return true; }
+    }
+    omgx::work_split(plan.dims, plan.kkt_doubles, omgx::WS_LDS, lds_doubles, hbm_doubles);
+    if (*lds_doubles * sizeof(double) <= (size_t)kLdsLimit) { *mode = omgx::WS_LDS; return true; }
+    plan = omgx::HostPlan();
+    if (!plan.build(t)) return false;
+  }
+  plan.dims.wave_ok = 0;      // the blocked routines (dense panels)
   *mode = pick_mode(plan.dims, plan.kkt_doubles, lds_doubles, hbm_doubles);
   if (*mode != omgx::WS_LDS && *mode != omgx::WS_MODES) {
     plan = omgx::HostPlan();
@@ -634,7 +657,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   omgx::HostPlan plan;
   size_t nl = 0, ng = 0;
   int mode = 0;
-  if (!plan_for_mode(plan, *t, &mode, &nl, &ng)) { g_err = "inconsistent template: " + plan.error; return OMGX_E_INVALID; }
+  if (!plan_for_mode(plan, *t, &mode, &nl, &ng, &b->per_cu)) { g_err = "inconsistent template: " + plan.error; return OMGX_E_INVALID; }
   b->dims = plan.dims;
   b->kkt_doubles = plan.kkt_doubles;
   if (mode == omgx::WS_MODES) {
@@ -644,7 +667,8 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
     return OMGX_E_TOOLARGE;
   }
   b->ws_mode = mode; b->lds_bytes = nl * sizeof(double); b->slab_doubles = ng;
-  if (mode != omgx::WS_LDS) b->dims.wave_ok = 0;      // the wave-level routines address the KKT store as LDS
+  if (const char* e = getenv("OMGX_THREADS")) { const int t2 = atoi(e); if (t2 == 256 || t2 == 512) b->threads = t2; }      // (developer knob)
+  b->threads = b->per_cu >= 2 ? 256 : kThreads;
   const omgx::Tables& H = plan.tables;
   const omgx::Dims& d = plan.dims;
   UP(prog, 6 * d.n_prog); UP(knots, t->n_knots); UP(pp_ptr, t->n_pp + 1); UP(pm_coef, t->n_mono);
@@ -663,6 +687,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   UP(jr_ptr, d.n_con + 2); UP(jr_pos, d.nnz_j); UP(t_jidx, plan.t_jidx.size()); UP(row_leaf, d.n_con + 1);
   UP(cpl_ptr, d.n_leaf + 1); UP(cpl_idx, plan.cpl_idx.size()); UP(cpl_map, plan.cpl_map.size());
   UP(d_off, d.n_leaf + 1); UP(b_off, plan.b_off.size());
+  UP(lf_w, plan.lf_w.size()); UP(lf_ldb, plan.lf_ldb.size()); UP(lf_band, plan.lf_band.size()); UP(lf_kind, plan.lf_kind.size()); UP(dl_pos, plan.dl_pos.size());
   UP(pair4, plan.pair4.size()); UP(eqe3, plan.eqe3.size());
   UP(je_row, plan.je_row.size()); UP(jt_addr, plan.jt_addr.size()); UP(diag_addr, d.N); UP(tq_addr, plan.tq_addr.size());
   UP(h_addr, plan.h_addr.size()); UP(t_row, plan.t_row.size()); UP(t_pos, plan.t_pos.size()); UP(reg_w, d.N);
@@ -708,8 +733,8 @@ int omgx_plan_describe(const omgx_template* tpl, omgx_plan_info* info, int32_t* 
   if (rc != OMGX_OK) return rc;
   omgx::HostPlan plan;
   size_t nl = 0, ng = 0;
-  int mode = 0;
-  if (!plan_for_mode(plan, *tpl, &mode, &nl, &ng)) { g_err = "inconsistent template: " + plan.error; return OMGX_E_INVALID; }
+  int mode = 0, per_cu = 1;
+  if (!plan_for_mode(plan, *tpl, &mode, &nl, &ng, &per_cu)) { g_err = "inconsistent template: " + plan.error; return OMGX_E_INVALID; }
   const omgx::Dims& d = plan.dims;
   memset(info, 0, sizeof *info);
   info->n_leaf = d.n_leaf; info->n_root = d.n_root; info->n_eq = d.n_eq; info->nnz_j = d.nnz_j;
@@ -849,18 +874,21 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
                           reserved) != hipSuccess) {
     g_err = "cannot reserve dynamic LDS for ipm_solve_kernel"; omgx_batch_destroy(b); return OMGX_E_HIP;
   }
-  if (b->ws_mode != omgx::WS_LDS) {
+  {
+    // Persistent workgroups, as many as fit the chip at once (one or two per CU), that take their agents from an atomic
+    // counter -- in every mode: solves differ by a factor of several in their iteration counts.  The workgroups of the
+    // spill modes own a slab each.
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_err = "hipGetDeviceProperties failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
-    const int per_cu = (int)((size_t)kLdsLimit / (b->lds_bytes > 0 ? b->lds_bytes : 1));
-    int slabs = prop.multiProcessorCount * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+    int per_cu = (int)((size_t)kLdsLimit / (b->lds_bytes > 0 ? b->lds_bytes : 1));
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    if (b->ws_mode == omgx::WS_LDS || b->ws_mode == omgx::WS_JAC_ONLY) per_cu = b->per_cu;      // (bound by the registers of 512-thread workgroups otherwise)
+    int slabs = prop.multiProcessorCount * per_cu;
     if (slabs > n_agents) slabs = n_agents;
     b->n_slabs = slabs;
-    if ((rc = dalloc(b, (size_t)slabs * b->slab_doubles, &b->d_slabs))) { omgx_batch_destroy(b); return rc; }
+    if (b->slab_doubles > 0 && (rc = dalloc(b, (size_t)slabs * b->slab_doubles, &b->d_slabs))) { omgx_batch_destroy(b); return rc; }
     if ((rc = dalloc(b, (size_t)2, &b->d_next))) { omgx_batch_destroy(b); return rc; }
     if (hipMemset(b->d_next, 0, 2 * sizeof(int)) != hipSuccess) { g_err = "hipMemset failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
-  } else {
-    b->n_slabs = n_agents;
   }
   *out = b;
   return OMGX_OK;
@@ -975,7 +1003,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   hipEvent_t e1 = b->ext_ev0 ? b->ext_ev1 : (b->timing ? b->ev1 : nullptr);
   b->timed = b->timing && !b->ext_ev0;
   b->ext_ev0 = b->ext_ev1 = nullptr;
-  hipExtLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok), dim3(b->n_slabs), dim3(kThreads), (uint32_t)b->lds_bytes, b->stream,
+  hipExtLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok), dim3(b->n_slabs), dim3(b->threads), (uint32_t)b->lds_bytes, b->stream,
                         e0, e1, 0u, d, b->dev,
                         b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
                         b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, (const StoreArgs*)(b->store.out ? b->d_store : nullptr), (flags & OMGX_ONLY_FAILED) ? 1 : 0,

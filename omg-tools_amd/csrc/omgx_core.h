@@ -101,6 +101,10 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* jr_ptr; const int32_t* jr_pos; const int32_t* t_jidx; const int32_t* row_leaf;
   const int32_t* cpl_ptr; const int32_t* cpl_idx; const int32_t* cpl_map;
   const int32_t* d_off; const int32_t* b_off;   // panel offsets / leading dimensions inside the KKT store
+  // compact store of the wave path (omgx_plan.h `compact`): per leaf the offset of its carried rows (sparse diagonal
+  // leaf: the number of coupling slots S), the row stride and width of its band, its kind (0 banded panel, 1 sparse
+  // diagonal leaf); dl_pos[4 * leaf_off[l] + s * n_l + j]: root position coupled through slot s of variable j (-1: none)
+  const int32_t* lf_w; const int32_t* lf_ldb; const int32_t* lf_band; const int32_t* lf_kind; const int32_t* dl_pos;
   // precomputed KKT addresses (HostPlan): Jacobian pairs, t-column, diagonal, Hessian terms
   const int32_t* eqe3;      // [n_eqe][3] = {Jacobian entry, KKT address, row} of the equality-row entries
   const int32_t* pair4;     // [n_pairs][4] = {Jacobian entry a, entry b, KKT address, row}: one 16-byte record per pair
@@ -203,15 +207,17 @@ struct Work {
   double *atoms, *slots, *knots;
   double *x, *xt;                 // [N] variable order, x[n_var] = t
   double *hv, *ht;                // [n_con] scaled row values (h for inequality, c for equality)
-  double *bnd, *rho, *vv;         // [n_con] scaled bound, row scale (signed), phase-I weights
-  double *s, *z, *ds;             // [n_con] slack, multiplier (y for equality rows), slack step
+  double *rho, *vv;               // [n_con] row scale (signed), phase-I weights
+  double *z, *ds;                 // [n_con] multiplier (y for equality rows), slack step
+  // (the slack of an inequality row is not stored: every iterate keeps s = t v - h exactly -- `row_slack`; the bound of a
+  // row is read from the caller's lbg / ubg where the line search needs it)
   double *jval;                   // [nnz_j] scaled Jacobian entries (objective row unscaled)
   double *gbar, *sol;             // [N], [N + n_eq]   position order
   double *kkt;                    // D_l (packed) | B_l | R (packed)
   double *col;                    // [col_doubles] blocked-LDL' staging + panel buffers
   double *root;                   // spill modes: LDS copy of the packed root block (+ its right-hand-side row) from the Schur step on (inside col)
   double *dinv;                   // [N] inverse leaf pivots
-  int32_t *rtype;                 // [n_con]
+  int8_t *rtype;                  // [n_con]
   double *red;                    // reduction scratch [64]
 };
 
@@ -219,8 +225,15 @@ struct Work {
 // whose arrays exceed the 160 KiB of one CU spill the largest ones to a per-workgroup slab in
 // HBM (L2/MALL-cached), largest first:
 //   mode 1  kkt                  mode 2  + jval
-//   mode 3  + the eight [n_con] row arrays and rtype (only the O(n_var) vectors stay in LDS)
-enum { WS_LDS = 0, WS_KKT_HBM = 1, WS_JAC_HBM = 2, WS_ROWS_HBM = 3, WS_MODES = 4 };
+//   mode 3  + the six [n_con] row arrays and rtype (only the O(n_var) vectors stay in LDS)
+// Mode 4 is the other direction: templates on the register-resident wave path whose workspace then fits HALF a CU --
+// two workgroups (agents) per CU -- put the Jacobian values and the row values hv into the slab and keep the
+// (compact) KKT store and every array the owner passes gather from in LDS.
+enum { WS_LDS = 0, WS_KKT_HBM = 1, WS_JAC_HBM = 2, WS_ROWS_HBM = 3, WS_JAC_ONLY = 4, WS_MODES = 5 };
+OMGX_HD constexpr bool ws_kkt_hbm(int mode) { return mode >= WS_KKT_HBM && mode <= WS_ROWS_HBM; }
+OMGX_HD constexpr bool ws_jac_hbm(int mode) { return mode >= WS_JAC_HBM; }
+OMGX_HD constexpr bool ws_rows_hbm(int mode) { return mode == WS_ROWS_HBM; }
+OMGX_HD constexpr bool ws_hv_hbm(int mode) { return mode == WS_ROWS_HBM || mode == WS_JAC_ONLY; }
 
 OMGX_HD size_t root_doubles(const Dims& d) { return ((size_t)(d.nr + 1) * (d.nr + 2)) / 2; }
 
@@ -231,12 +244,13 @@ OMGX_HD void work_split(const Dims& d, int kkt_doubles, int mode, size_t* lds, s
   nl += d.N + (d.N + d.n_eq);
   nl += d.N;                      // dinv
   nl += 64;                       // red
-  const size_t rows = 8 * (size_t)d.n_con + (d.n_con + 1) / 2;
-  (mode >= WS_ROWS_HBM ? ng : nl) += rows;
-  (mode >= WS_JAC_HBM ? ng : nl) += d.nnz_j + 1;      // + one slot that stays 0.0 (padding records point at it)
+  const size_t rows = 5 * (size_t)d.n_con + (d.n_con + 7) / 8;
+  (ws_rows_hbm(mode) ? ng : nl) += rows;
+  (ws_hv_hbm(mode) ? ng : nl) += d.n_con;             // hv: only ever read by the thread that owns the row
+  (ws_jac_hbm(mode) ? ng : nl) += d.nnz_j + 1;        // + one slot that stays 0.0 (padding records point at it)
   // (the spill modes keep the matrix descriptors and the small panel scratch of the leaf sweep in LDS: every row of
   // every block column reads them)
-  if (mode >= WS_KKT_HBM) { ng += (size_t)kkt_doubles; nl += d.col_small; } else nl += (size_t)kkt_doubles + d.col_doubles;
+  if (ws_kkt_hbm(mode)) { ng += (size_t)kkt_doubles; nl += d.col_small; } else nl += (size_t)kkt_doubles + d.col_doubles;
   *lds = nl; *hbm = ng;
 }
 
@@ -256,23 +270,22 @@ OMGX_HD void work_carve_split(Work& w, double* lds, double* hbm, const Dims& d, 
   w.gbar = p; p += d.N;          w.sol = p; p += d.N + d.n_eq;
   w.dinv = p; p += d.N;
   w.red = p; p += 64;
-  if (MODE >= WS_ROWS_HBM) {
-    w.hv = g; g += d.n_con;        w.ht = g; g += d.n_con;
-    w.bnd = g; g += d.n_con;       w.rho = g; g += d.n_con;     w.vv = g; g += d.n_con;
-    w.s = g; g += d.n_con;         w.z = g; g += d.n_con;       w.ds = g; g += d.n_con;
-    w.rtype = (int32_t*)g; g += (d.n_con + 1) / 2;
+  if (ws_rows_hbm(MODE)) {
+    w.ht = g; g += d.n_con;        w.rho = g; g += d.n_con;     w.vv = g; g += d.n_con;
+    w.z = g; g += d.n_con;         w.ds = g; g += d.n_con;
+    w.rtype = (int8_t*)g; g += (d.n_con + 7) / 8;
   } else {
-    w.hv = p; p += d.n_con;        w.ht = p; p += d.n_con;
-    w.bnd = p; p += d.n_con;       w.rho = p; p += d.n_con;     w.vv = p; p += d.n_con;
-    w.s = p; p += d.n_con;         w.z = p; p += d.n_con;       w.ds = p; p += d.n_con;
-    w.rtype = (int32_t*)p; p += (d.n_con + 1) / 2;
+    w.ht = p; p += d.n_con;        w.rho = p; p += d.n_con;     w.vv = p; p += d.n_con;
+    w.z = p; p += d.n_con;         w.ds = p; p += d.n_con;
+    w.rtype = (int8_t*)p; p += (d.n_con + 7) / 8;
   }
-  if (MODE >= WS_JAC_HBM) { w.jval = g; g += d.nnz_j + 1; } else { w.jval = p; p += d.nnz_j + 1; }
-  if (MODE >= WS_KKT_HBM) { w.kkt = g; g += kkt_doubles; w.col = p; p += d.col_small; }
+  if (ws_hv_hbm(MODE)) { w.hv = g; g += d.n_con; } else { w.hv = p; p += d.n_con; }
+  if (ws_jac_hbm(MODE)) { w.jval = g; g += d.nnz_j + 1; } else { w.jval = p; p += d.nnz_j + 1; }
+  if (ws_kkt_hbm(MODE)) { w.kkt = g; g += kkt_doubles; w.col = p; p += d.col_small; }
   else { w.kkt = p; p += kkt_doubles; w.col = p; p += d.col_doubles; }
   // spill modes: the root block is copied behind the root's panel buffer before the Schur updates -- over the leaf
   // sweep's scratch, which is dead by then (Dims::col_small covers both)
-  w.root = MODE >= WS_KKT_HBM ? w.col + (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + OMGX_PAN_LD * (d.nr + 1) : nullptr;
+  w.root = ws_kkt_hbm(MODE) ? w.col + (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + OMGX_PAN_LD * (d.nr + 1) : nullptr;
 }
 
 OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
@@ -616,6 +629,10 @@ OMGX_FN double term_coef(const Tables& T, const Work& w, int t) {
 
 OMGX_FN double rec_coef(const Work& w, double coef, int slot) { return slot < 0 ? coef : coef * w.slots[slot]; }
 
+// slack of inequality row r at phase-I variable t: every iterate keeps s = t v - h exactly (the slack reset of the
+// accept step), so it is recomputed where it is needed instead of being stored
+OMGX_FN double row_slack(const Work& w, int r, double t) { return t * w.vv[r] - w.hv[r]; }
+
 // sum of the items of the entry in slot i of an ELL item table (four at a time, all loads in flight)
 OMGX_FN double jac_entry_ell(const JItem* ell, const int32_t* glen, int n_owner, const Work& w, int i, const double* xv) {
   const int L = glen[i >> 6];
@@ -681,12 +698,13 @@ struct Kkt {
   // (copies of the few table pointers / dimensions it needs, not pointers to the structs: a struct whose address
   // escapes into a helper object cannot be kept in scalar registers -- the compiler copied all of Dims and
   // Tables into every lane's scratch memory at kernel entry)
-  const int32_t *d_off, *b_off, *leaf_off, *leaf_bw, *cpl_ptr, *cpl_idx, *blk, *cpl_map;
+  const int32_t *d_off, *b_off, *leaf_off, *leaf_bw, *cpl_ptr, *cpl_idx, *blk, *cpl_map, *lf_w, *lf_ldb, *lf_band, *lf_kind, *dl_pos;
   int n_leaf, n_root, root_off;
   double* a;
   OMGX_FN void bind(const Dims& dd, const Tables& TT, double* store) {
     d_off = TT.d_off; b_off = TT.b_off; leaf_off = TT.leaf_off; leaf_bw = TT.leaf_bw; cpl_ptr = TT.cpl_ptr;
     cpl_idx = TT.cpl_idx; blk = TT.blk; cpl_map = TT.cpl_map;
+    lf_w = TT.lf_w; lf_ldb = TT.lf_ldb; lf_band = TT.lf_band; lf_kind = TT.lf_kind; dl_pos = TT.dl_pos;
     n_leaf = dd.n_leaf; n_root = dd.n_root; root_off = dd.root_off; a = store;
   }
   // leaf l: panel of (n_l + nc_l + 1) rows with odd leading dimension ld_l; rows [0,n_l) hold the
@@ -1158,6 +1176,13 @@ OMGX_FN void kkt_describe(const C& c, const Dims& d, const Kkt& K, Work& w) {
     int pan = pan0;
     for (int l = 0; l < d.n_leaf; ++l) {
       BMat& M = Ms[l];
+      if constexpr (C::wave_only) {
+        // compact store: a = band of the leaf block (sparse diagonal leaf: its arrays), pan = its carried rows
+        // (sparse: number of coupling slots), pad_ = row stride of the band, bw = stored band (-1: sparse leaf)
+        M.a = K.d_off[l]; M.ld = K.ld(l); M.nfact = K.nl(l); M.rows = K.nl(l) + K.nc(l) + 1; M.npos = M.nfact;
+        M.dinv = K.leaf_off[l]; M.pan = K.lf_w[l]; M.cpl = K.cpl_ptr[l]; M.bw = K.lf_kind[l] ? -1 : K.lf_band[l]; M.pad_ = K.lf_ldb[l];
+        continue;
+      }
       M.a = K.d_off[l]; M.ld = K.ld(l); M.nfact = K.nl(l); M.rows = K.nl(l) + K.nc(l) + 1; M.npos = M.nfact;   // + the rhs row
       M.dinv = K.leaf_off[l]; M.pan = pan; pan += C::hbm ? OMGX_PAN_SMALL(M.nfact) : OMGX_PAN_LD * M.rows; M.cpl = K.cpl_ptr[l]; M.bw = K.leaf_bw[l];
     }
@@ -1177,14 +1202,26 @@ OMGX_FN void kkt_describe(const C& c, const Dims& d, const Kkt& K, Work& w) {
 // round: fixed order of the sums); the root is factorised by wave 0.
 // ---------------------------------------------------------------------------
 OMGX_FN WPanel wpanel_leaf(const BMat& M) {
-  WPanel P; P.base = M.a; P.ld = M.ld; P.packed = 0; P.n = M.nfact; P.nreg = M.rows - 2; P.nvec = 2; P.npos = M.nfact; P.bw = M.bw;
-  P.vrow = M.rows - 2;
+  WPanel P; P.base = M.a; P.ld = M.ld; P.n = M.nfact; P.nreg = M.rows - 2; P.nvec = 2; P.npos = M.nfact; P.bw = M.bw;
+  P.vrow = M.rows - 2; P.band = M.bw; P.ldb = M.pad_; P.wbase = M.pan;
   return P;
 }
 OMGX_FN WPanel wpanel_root(const BMat& M, int n_root) {
-  WPanel P; P.base = M.a; P.ld = 0; P.packed = 1; P.n = M.nfact; P.nreg = M.nfact; P.nvec = 1; P.npos = n_root; P.bw = M.nfact;
-  P.vrow = M.nfact;
+  WPanel P; P.base = M.a; P.ld = 0; P.n = M.nfact; P.nreg = M.nfact; P.nvec = 1; P.npos = n_root; P.bw = M.nfact;
+  P.vrow = M.nfact; P.band = -1; P.ldb = 0; P.wbase = 0;
   return P;
+}
+
+// Sparse diagonal leaf (the terminal slacks g*: every variable alone on its diagonal, coupled to one trajectory
+// coefficient and to t): arrays of n entries each -- diagonal | S coupling slots | t coupling | right-hand side.
+// Nothing to factorise; its Schur complement has one owner per target (the plan checked that no root position is
+// coupled to two of its variables), the two entries every variable shares -- (t, t) and (rhs, t) -- are wave sums.
+struct DiagLeaf { int base, n, S, dinv, dl; };
+OMGX_FN DiagLeaf diag_leaf(const BMat& M) {
+  DiagLeaf L;
+  L.base = __builtin_amdgcn_readfirstlane(M.a); L.n = __builtin_amdgcn_readfirstlane(M.nfact);
+  L.S = __builtin_amdgcn_readfirstlane(M.pan); L.dinv = __builtin_amdgcn_readfirstlane(M.dinv); L.dl = 4 * L.dinv;
+  return L;
 }
 
 template <class C>
@@ -1199,11 +1236,18 @@ OMGX_FN int kkt_factor_wave(const C& c, const Dims& d, const Kkt& K, Work& w) {
   const long long tw0_ = clock64();
 #endif
   for (int l = wave; l < d.n_leaf; l += nw) {
+    const int kind_bw = __builtin_amdgcn_readfirstlane(Ms[l].bw);
+    if (kind_bw < 0) {
+      const DiagLeaf L = diag_leaf(Ms[l]);
+      const double dj = w.kkt[L.base + (lane < L.n ? lane : 0)];
+      if (lane < L.n) { w.dinv[L.dinv + lane] = rcp_pivot(dj); if (!(dj > 0.0)) badl = 1; }
+      continue;
+    }
     const WPanel P = wpanel_leaf(Ms[l]);
     // hyperplane leaves are banded (half bandwidth 5 in reverse Cuthill-McKee order): compile-time band of 8
-    badl |= (P.bw <= 8) ? wave_ldl<OMGX_WAVE_COLS, 8>(koff, P) : wave_ldl<OMGX_WAVE_COLS, OMGX_WAVE_COLS>(koff, P);
+    badl |= (kind_bw <= 8) ? wave_ldl<OMGX_WAVE_COLS, 8, true>(koff, P) : wave_ldl<OMGX_WAVE_COLS, OMGX_WAVE_COLS, true>(koff, P);
     wave_fence();
-    const double dl = wave_dinv(w.kkt, P);
+    const double dl = wave_dinv<true>(w.kkt, P);
     if (lane < P.n) w.dinv[Ms[l].dinv + lane] = dl;
   }
 #ifdef OMGX_PROFILE
@@ -1216,13 +1260,16 @@ OMGX_FN int kkt_factor_wave(const C& c, const Dims& d, const Kkt& K, Work& w) {
     const int l = base + wave;
     v4d acc00 = {0.0, 0.0, 0.0, 0.0}, acc10 = acc00, acc11 = acc00;
     int nc1 = 0, ci_b0 = 0, ci_b1 = 0, ci_a[8];
+    bool sparse = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ci_a[i] = 0;
     if (l < d.n_leaf) {
       const BMat M = Ms[l];
+      sparse = __builtin_amdgcn_readfirstlane(M.bw) < 0;
+      if (!sparse) {
       const int n = __builtin_amdgcn_readfirstlane(M.nfact), ld = __builtin_amdgcn_readfirstlane(M.ld);
       nc1 = __builtin_amdgcn_readfirstlane(M.rows) - n;            // coupling rows + the right-hand-side row (last)
-      const double* Wt = w.kkt + __builtin_amdgcn_readfirstlane(M.a) + n * ld;
+      const double* Wt = w.kkt + __builtin_amdgcn_readfirstlane(M.pan);
       const double* di = w.dinv + __builtin_amdgcn_readfirstlane(M.dinv);
       const int32_t* ci = K.cpl_idx + __builtin_amdgcn_readfirstlane(M.cpl);
       // root positions of this lane's rows / columns (global table: requested before the MFMA loop)
@@ -1246,11 +1293,12 @@ OMGX_FN int kkt_factor_wave(const C& c, const Dims& d, const Kkt& K, Work& w) {
           acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1 * dj, b1, acc11, 0, 0, 0);
         }
       }
+      }
     }
     // subtract from the root, one leaf per round
     const int lend = base + nw < d.n_leaf ? base + nw : d.n_leaf;
     for (int lr = base; lr < lend; ++lr) {
-      if (l == lr) {
+      if (l == lr && !sparse) {
         const int cb0 = lane & 15, cb1 = 16 + (lane & 15);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1259,6 +1307,42 @@ OMGX_FN int kkt_factor_wave(const C& c, const Dims& d, const Kkt& K, Work& w) {
           if (ca1 < nc1 && cb0 < nc1 - 1) R[tri(ci_a[4 + i], ci_b0)] -= acc10[i];
           if (ca1 < nc1 && cb1 < nc1 - 1 && cb1 <= ca1) R[tri(ci_a[4 + i], ci_b1)] -= acc11[i];
         }
+      } else if (l == lr) {
+        // sparse diagonal leaf: lane j owns variable j.  v_0 .. v_{S-1} at root positions p_0 .. p_{S-1}, v_t at
+        // the position of t (n_root - 1), the right-hand side r_j at row nr of the root
+        const DiagLeaf L = diag_leaf(Ms[l]);
+        const int j = lane < L.n ? lane : 0;
+        const bool on = lane < L.n;
+        const double* A = w.kkt + L.base + j;
+        const double di = w.dinv[L.dinv + j];
+        const double vt = A[(1 + L.S) * L.n], rj = A[(2 + L.S) * L.n];
+        const int pt = d.n_root - 1;
+        double vs[4]; int ps[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const bool has = s < L.S;
+          ps[s] = has ? K.dl_pos[L.dl + s * L.n + j] : -1;
+          const double v = A[(1 + (has ? s : 0)) * L.n];
+          vs[s] = (has && on && ps[s] >= 0) ? v : 0.0;
+        }
+        if (on) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            if (ps[s] < 0 || s >= L.S) continue;
+            const double u = vs[s] * di;
+#pragma unroll
+            for (int s2 = 0; s2 <= s; ++s2) {
+              if (ps[s2] < 0) continue;
+              const int pa = ps[s] > ps[s2] ? ps[s] : ps[s2], pb = ps[s] > ps[s2] ? ps[s2] : ps[s];
+              R[tri(pa, pb)] -= u * vs[s2];
+            }
+            R[tri(pt, ps[s])] -= u * vt;                  // (t is the last root variable: pt > every p_s)
+            R[tri(d.nr, ps[s])] -= u * rj;
+          }
+        }
+        // shared targets: fixed-order wave sums
+        const double stt = c.wave_sum(on ? vt * di * vt : 0.0), srt = c.wave_sum(on ? rj * di * vt : 0.0);
+        if (lane == 0) { R[tri(pt, pt)] -= stt; R[tri(d.nr, pt)] -= srt; }
       }
       c.sync();
     }
@@ -1270,7 +1354,7 @@ OMGX_FN int kkt_factor_wave(const C& c, const Dims& d, const Kkt& K, Work& w) {
 #ifdef OMGX_PROFILE
     const long long tr0_ = clock64();
 #endif
-    badr = wave_ldl<OMGX_WAVE_COLS, OMGX_WAVE_COLS>(koff, P);
+    badr = wave_ldl<OMGX_WAVE_COLS, OMGX_WAVE_COLS, false>(koff, P);
 #ifdef OMGX_PROFILE
     if (c.tid() == 0) c.prof[PH_F_SWEEP] += clock64() - tr0_;      // raw root time
 #endif
@@ -1289,12 +1373,11 @@ OMGX_FN int kkt_refactor_root_wave(const C& c, const Dims& d, const Kkt& K, Work
   const int koff = (int)(w.kkt - omgx_lds);
   OMGX_TIC();
   int badr = 0;
-  if (c.wave() == 0) badr = wave_ldl<OMGX_WAVE_COLS, OMGX_WAVE_COLS>(koff, wpanel_root(Ms[d.n_leaf], d.n_root));
+  if (c.wave() == 0) badr = wave_ldl<OMGX_WAVE_COLS, OMGX_WAVE_COLS, false>(koff, wpanel_root(Ms[d.n_leaf], d.n_root));
   const int bad = c.rmax(badr ? 1.0 : 0.0) > 0.0 ? 2 : 0;
   OMGX_TOC(PH_F_ROOT);
   return bad;
 }
-
 
 // the solve that goes with kkt_factor_wave: root backward substitution by wave 0, then every leaf wave
 // corrects its right-hand side by the root solution and substitutes backwards -- no workgroup barrier
@@ -1307,9 +1390,9 @@ OMGX_FN void kkt_solve_wave(const C& c, const Dims& d, const Kkt& K, Work& w, do
   OMGX_TIC();
   if (wave == 0) {
     const WPanel P = wpanel_root(Ms[d.n_leaf], d.n_root);
-    const double dl = wave_dinv(w.kkt, P);
-    const double y = w.kkt[wrow(P, P.n) + (lane < P.n ? lane : 0)];           // L^{-1} r: the carried vector row
-    const double x = wave_bwd<OMGX_WAVE_COLS>(koff, P, dl, y * dl);
+    const double dl = wave_dinv<false>(w.kkt, P);
+    const double y = w.kkt[wcarried<false>(P, P.n) + (lane < P.n ? lane : 0)];           // L^{-1} r: the carried vector row
+    const double x = wave_bwd<OMGX_WAVE_COLS, false>(koff, P, dl, y * dl);
     if (lane < P.n) sol[d.root_off + lane] = x;
   }
   c.sync();
@@ -1317,19 +1400,32 @@ OMGX_FN void kkt_solve_wave(const C& c, const Dims& d, const Kkt& K, Work& w, do
   double* xg = w.col + OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1) + wave * 64;      // gathered root solution of this wave's leaf
   for (int l = wave; l < d.n_leaf; l += nw) {
     const BMat M = Ms[l];
+    if (__builtin_amdgcn_readfirstlane(M.bw) < 0) {
+      // sparse diagonal leaf: x_j = (r_j - sum_s v_s x_r[p_s] - v_t x_t) / d_j
+      const DiagLeaf L = diag_leaf(M);
+      const int j = lane < L.n ? lane : 0;
+      const double* A = w.kkt + L.base + j;
+      double acc = A[(2 + L.S) * L.n] - A[(1 + L.S) * L.n] * sol[d.root_off + d.n_root - 1];
+      for (int s = 0; s < L.S; ++s) {
+        const int ps = K.dl_pos[L.dl + s * L.n + j];
+        acc = fma(-A[(1 + s) * L.n], sol[d.root_off + (ps < 0 ? 0 : ps)] * (ps < 0 ? 0.0 : 1.0), acc);
+      }
+      if (lane < L.n) sol[L.dinv + lane] = acc * w.dinv[L.dinv + j];
+      continue;
+    }
     const WPanel P = wpanel_uniform(wpanel_leaf(M));
     const int n = P.n, nc = P.nreg + 1 - P.n, ld = P.ld;          // (wave-uniform values: scalar loop bounds)
     const int32_t* ci = K.cpl_idx + __builtin_amdgcn_readfirstlane(M.cpl);
     if (lane < nc) xg[lane] = sol[d.root_off + ci[lane]];
     wave_fence();
     const int j = lane < n ? lane : 0;
-    const double* Wt = w.kkt + P.base + n * ld + j;
+    const double* Wt = w.kkt + P.wbase + j;
     double acc = Wt[nc * ld];                          // L^{-1} r_l
 #pragma unroll 4
     for (int a = 0; a < nc; ++a) acc = fma(-Wt[a * ld], xg[a], acc);
     const int dv = __builtin_amdgcn_readfirstlane(M.dinv);
     const double dl = w.dinv[dv + j];
-    const double x = wave_bwd<OMGX_WAVE_COLS>(koff, P, dl, acc * dl);
+    const double x = wave_bwd<OMGX_WAVE_COLS, true>(koff, P, dl, acc * dl);
     if (lane < n) sol[dv + lane] = x;
     wave_fence();
   }
@@ -1343,7 +1439,7 @@ OMGX_FN void kkt_solve_wave(const C& c, const Dims& d, const Kkt& K, Work& w, do
 template <class C>
 OMGX_FN int kkt_factor(const C& c, const Dims& d, const Kkt& K, Work& w) {
 #ifndef OMGX_HOST_PORT
-  if constexpr (!C::no_wave) { if (C::wave_only || d.wave_ok) return kkt_factor_wave(c, d, K, w); }
+  if constexpr (C::wave_only) return kkt_factor_wave(c, d, K, w);      // (compact store, omgx_plan.h)
 #endif
   if constexpr (C::wave_only) return 1; else {
   int bad = 0;
@@ -1482,7 +1578,7 @@ OMGX_FN void kkt_root_before_retry(const C& c, const Dims& d, const Kkt& K, Work
 template <class C>
 OMGX_FN int kkt_refactor_root(const C& c, const Dims& d, const Kkt& K, Work& w) {
 #ifndef OMGX_HOST_PORT
-  if constexpr (C::no_wave) return 1;      // (never reached: Dims::wave_ok is 0 in the spill modes)
+  if constexpr (!C::wave_only) return 1;      // (never reached: the blocked instances run with Dims::wave_ok = 0)
   else return kkt_refactor_root_wave(c, d, K, w);
 #else
   int bad = 0;
@@ -1535,7 +1631,7 @@ OMGX_FN void trsv_bwd4(const C& c, const double* A, Addr L, int n, double* y, co
 template <class C>
 OMGX_FN void kkt_solve(const C& c, const Dims& d, const Kkt& K, Work& w, double* sol) {
 #ifndef OMGX_HOST_PORT
-  if constexpr (!C::no_wave) { if (C::wave_only || d.wave_ok) { kkt_solve_wave(c, d, K, w, sol); return; } }
+  if constexpr (C::wave_only) { kkt_solve_wave(c, d, K, w, sol); return; }
 #endif
   if constexpr (!C::wave_only) {
   double* yr = sol + d.root_off;
@@ -1605,8 +1701,13 @@ OMGX_FN void kkt_rhs(const C& c, const Dims& d, const Tables& T, Work& w, double
     int l = 0;
     while (q >= Ms[l].dinv + Ms[l].nfact) ++l;
     const BMat M = Ms[l];
-    OMGX_PANEL_STRIDES(C, M, sr, sc);
-    w.kkt[M.a + (M.rows - 1) * sr + (q - M.dinv) * sc] = -w.gbar[q];
+    if constexpr (C::wave_only) {       // compact store: the right-hand side is the last carried row / the last array of a sparse leaf
+      const int ad = M.bw < 0 ? M.a + (2 + M.pan) * M.nfact + (q - M.dinv) : M.pan + (M.rows - 1 - M.nfact) * M.ld + (q - M.dinv);
+      w.kkt[ad] = -w.gbar[q];
+    } else {
+      OMGX_PANEL_STRIDES(C, M, sr, sc);
+      w.kkt[M.a + (M.rows - 1) * sr + (q - M.dinv) * sc] = -w.gbar[q];
+    }
   }
   const int rbase = Ms[d.n_leaf].pad_, nr = d.nr;
   OMGX_PFOR(k, nr) {
@@ -1671,9 +1772,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     double rho = (o.scale_gmax > 0.0 && gm > o.scale_gmax) ? o.scale_gmax / gm : 1.0;
     const double sg = (ty == ROW_LOWER) ? -1.0 : 1.0;
     w.rho[r] = sg * rho;                                  // signed scale: h = rho*(g - bound)
-    w.bnd[r] = (ty == ROW_LOWER || ty == ROW_EQ) ? l : (ty == ROW_UPPER ? u : 0.0);
+    const double bnd = (ty == ROW_LOWER || ty == ROW_EQ) ? l : (ty == ROW_UPPER ? u : 0.0);
     const double g = w.hv[r];
-    const double h = (ty == ROW_FREE) ? 0.0 : w.rho[r] * (g - w.bnd[r]);
+    const double h = (ty == ROW_FREE) ? 0.0 : w.rho[r] * (g - bnd);
     w.hv[r] = h;
     double v = 0.0;
     if (ty == ROW_UPPER || ty == ROW_LOWER) v = fmax(h + kpush, 0.0);
@@ -1694,8 +1795,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   if (c.tid() == 0) w.x[n] = t;
   OMGX_PFOR(r, m) {
     const int ty = w.rtype[r];
-    if (ty == ROW_UPPER || ty == ROW_LOWER) { w.s[r] = t * w.vv[r] - w.hv[r]; w.z[r] = mu / w.s[r]; }
-    else { w.s[r] = 1.0; w.z[r] = 0.0; }
+    w.z[r] = (ty == ROW_UPPER || ty == ROW_LOWER) ? mu / row_slack(w, r, t) : 0.0;
   }
   c.sync();
   if (warm) {
@@ -1706,7 +1806,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       const int ty = w.rtype[r];
       if (ty == ROW_UPPER || ty == ROW_LOWER) {
         w.z[r] = fmax(w.ds[r] / w.rho[r], OMGX_WARM_ZMIN);
-        sz += w.s[r] * w.z[r]; cnt0 += 1.0;
+        sz += row_slack(w, r, t) * w.z[r]; cnt0 += 1.0;
       } else if (ty == ROW_EQ) {
         w.z[r] = w.ds[r] / w.rho[r];
       }
@@ -1761,7 +1861,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     OMGX_PFOR(r, m) {
       const int ty = w.rtype[r];
       const bool ineq = (ty == ROW_UPPER || ty == ROW_LOWER);
-      const double is = ineq ? 1.0 / w.s[r] : 0.0;
+      const double is = ineq ? 1.0 / row_slack(w, r, t) : 0.0;
       w.ht[r] = is; w.ds[r] = ineq ? w.z[r] * is : 0.0;
     }
     c.sync();
@@ -1839,7 +1939,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       double comp = 0.0;
       OMGX_PFOR(r, m) {
         const int ty = w.rtype[r];
-        if (ty == ROW_UPPER || ty == ROW_LOWER) comp = fmax(comp, fabs(w.s[r] * w.z[r] - mu));
+        if (ty == ROW_UPPER || ty == ROW_LOWER) comp = fmax(comp, fabs(row_slack(w, r, t) * w.z[r] - mu));
       }
       comp = c.rmax(comp);
       if (use_t) comp = fmax(comp, fabs(t * zt - mu));
@@ -1874,7 +1974,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     // barrier gradient with the current mu
     OMGX_PFOR(q, n) w.gbar[q] += mu * w.xt[q];
     double vms = 0.0;
-    OMGX_PFOR(r, m) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) vms += w.vv[r] * (mu / w.s[r]);
+    OMGX_PFOR(r, m) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) vms += w.vv[r] * (mu / row_slack(w, r, t));
     vms = c.rsum(vms);
     const double gbar_t = use_t ? (nu - vms - mu / t) : 0.0;
     if (c.tid() == 0) w.gbar[N - 1] = gbar_t;
@@ -2152,8 +2252,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         }
         const double dsr = -(jd - w.vv[r] * dt);
         w.ds[r] = dsr;
-        const double dzr = mu / w.s[r] - w.z[r] - (w.z[r] / w.s[r]) * dsr;
-        if (dsr < 0.0) ap_l = fmin(ap_l, -tau * w.s[r] / dsr);
+        const double sr = row_slack(w, r, t);
+        const double dzr = mu / sr - w.z[r] - (w.z[r] / sr) * dsr;
+        if (dsr < 0.0) ap_l = fmin(ap_l, -tau * sr / dsr);
         if (dzr < 0.0) ad_l = fmin(ad_l, -tau * w.z[r] / dzr);
       } else if (ty == ROW_EQ) {
         ymax = fmax(ymax, fabs(w.sol[N + T.eq_index[r]]));
@@ -2162,7 +2263,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     }
     OMGX_PFOR(q, N) gdx += w.gbar[q] * w.sol[q];
     double lns = 0.0;
-    OMGX_PFOR(r, m) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) lns += log(w.s[r]);
+    OMGX_PFOR(r, m) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) lns += log(row_slack(w, r, t));
     double a_p, a_d;
     {
       double rv[6] = {ap_l, ad_l, ymax, gdx, lns, ysum};
@@ -2198,7 +2299,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         const int ty = w.rtype[r];
         const double gv = row_value_ell(T, w, i, m, w.xt);      // (also for free rows: the loop bound is per wave)
         if (ty == ROW_FREE) { w.ht[r] = 0.0; continue; }
-        const double h = w.rho[r] * (gv - w.bnd[r]);
+        const double h = w.rho[r] * (gv - ((ty == ROW_LOWER || ty == ROW_EQ) ? lb[r] : ub[r]));
         w.ht[r] = h;
         if (ty == ROW_EQ) rEt += fabs(h - tt * w.vv[r]);
         else { const double st = tt * w.vv[r] - h; smin = fmin(smin, st); if (st > 0.0) lnst += log(st); }
@@ -2230,8 +2331,8 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 #if defined(OMGX_HOST_PORT) && defined(OMGX_TRACE)
     {
       int rb = -1; double best = 1e300;
-      for (int r = 0; r < m; ++r) if ((w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) && w.ds[r] < 0.0) { const double q_ = -w.s[r] / w.ds[r]; if (q_ < best) { best = q_; rb = r; } }
-      if (rb >= 0) fprintf(stderr, "      blocking row %d ratio %.3e s %.3e ds %.3e z %.3e vv %.3e | dt %.3e t %.3e\n", rb, best, w.s[rb], w.ds[rb], w.z[rb], w.vv[rb], dt, t);
+      for (int r = 0; r < m; ++r) if ((w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) && w.ds[r] < 0.0) { const double q_ = -row_slack(w, r, t) / w.ds[r]; if (q_ < best) { best = q_; rb = r; } }
+      if (rb >= 0) fprintf(stderr, "      blocking row %d ratio %.3e s %.3e ds %.3e z %.3e vv %.3e | dt %.3e t %.3e\n", rb, best, row_slack(w, rb, t), w.ds[rb], w.z[rb], w.vv[rb], dt, t);
     }
     fprintf(stderr, "it %3d mu %.2e t %.3e nu %.1e zt %.2e err %.2e (rd %.2e viol %.2e zh %.2e sd %.1e) dw %.2e alpha %.2e rE %.2e f %.4e\n", it, mu, t, nu, zt, err0, rd_max, viol, zh, sd, dw_last, alpha, rE_sum, f);
 #endif
@@ -2253,12 +2354,13 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     // ---- accept --------------------------------------------------------------------
     c.sync();
     OMGX_PFOR(q, N) w.x[q] = w.xt[q];
+    const double t_old = t;
     t = tt; f = ft;
     OMGX_PFOR(r, m) {
       const int ty = w.rtype[r];
+      const double s_old = row_slack(w, r, t_old);
       w.hv[r] = w.ht[r];
       if (ty == ROW_UPPER || ty == ROW_LOWER) {
-        const double s_old = w.s[r];
         const double dzr = mu / s_old - w.z[r] - (w.z[r] / s_old) * w.ds[r];
         const double sn = t * w.vv[r] - w.ht[r];
         // warm starts take the dual step component-wise (full Newton step, each multiplier clipped by
@@ -2266,7 +2368,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         // horizon releases -- does not scale down the step of all the others
         double zn = warm ? fmax(w.z[r] + dzr, (1.0 - tau) * w.z[r]) : w.z[r] + a_d * dzr;
         zn = fmin(fmax(zn, mu / (OMGX_KAPPA_SIGMA * sn)), OMGX_KAPPA_SIGMA * mu / sn);
-        w.s[r] = sn; w.z[r] = zn;
+        w.z[r] = zn;
       } else if (ty == ROW_EQ) {
         const double yn = w.sol[N + T.eq_index[r]];
         w.z[r] = w.z[r] + alpha * (yn - w.z[r]);

@@ -8,6 +8,7 @@
 // Lagrangian Hessian / constraint Jacobian (`basics/optilayer.py:49-60`, `expand=True`) and MUMPS does its
 // own symbolic analysis; this is the symbolic phase of the hand-written solver.
 #pragma once
+#include <stdlib.h>
 #include <algorithm>
 #include <functional>
 #include <numeric>
@@ -28,6 +29,8 @@ struct HostPlan {
   std::vector<int32_t> order, pos, blk, leaf_off, leaf_bw, eq_rows, eq_index;
   std::vector<int32_t> jr_ptr, jr_pos, t_jidx, row_leaf, cpl_ptr, cpl_idx, cpl_map;
   std::vector<int32_t> d_off, b_off;
+  std::vector<int32_t> lf_w, lf_ldb, lf_band, lf_kind, dl_pos;      // compact store of the wave path (Tables)
+  std::vector<std::vector<std::vector<int>>> var_cpl;                // [leaf][variable]: root positions (but t) its entries of B_l can touch
   // ---- addresses and packed records ---------------------------------------------------------------
   std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, h_addr, t_row, t_pos, tq_addr;
   std::vector<double> reg_w;
@@ -189,6 +192,18 @@ struct HostPlan {
       for (int i : s) { cpl_map[(size_t)l * d.n_root + i] = k++; cpl_idx.push_back(i); }
       cpl_ptr.push_back((int)cpl_idx.size());
     }
+    // which root positions every leaf variable meets in a row (or a nonlinear objective term): the entries of B_l that
+    // can be non-zero (the phase-I variable t apart: it meets every variable)
+    var_cpl.assign(d.n_leaf, {});
+    for (int l = 0; l < d.n_leaf; ++l) var_cpl[l].assign(leaf_off[l + 1] - leaf_off[l], {});
+    auto meet = [&](const std::vector<int>& vs) {
+      for (int a : vs) { if (leaf_of[a] < 0) continue;
+        std::vector<int>& dst = var_cpl[leaf_of[a]][pos[a] - leaf_off[leaf_of[a]]];
+        for (int b : vs) if (leaf_of[b] < 0 && std::find(dst.begin(), dst.end(), pos[b] - d.root_off) == dst.end()) dst.push_back(pos[b] - d.root_off); }
+    };
+    for (int r = 0; r < m; ++r) meet(rows_vars[r]);
+    for (auto& vs : obj_cpl) meet(vs);
+    for (auto& lv : var_cpl) for (auto& v : lv) std::sort(v.begin(), v.end());
     return true;
   }
 
@@ -207,8 +222,12 @@ struct HostPlan {
   // col_major: leaf panels column by column (the spill modes: one thread per panel row then reads consecutive
   // addresses of the HBM slab; the LDS modes keep rows with an odd leading dimension, conflict-free there)
   bool col_major = false;
-  bool build(const omgx_template& t, bool col_major_panels = false) {
-    col_major = col_major_panels;
+  // compact: the store of the register-resident wave path (device, LDS): leaf blocks by their band, the carried rows
+  // dense behind it, a diagonal leaf whose variables meet the root through a few entries each (the terminal slacks)
+  // as plain arrays -- config 2: 80 KB -> 42 KB, which is what lets two agents share a CU
+  bool compact = false;
+  bool build(const omgx_template& t, bool col_major_panels = false, bool compact_store = false) {
+    col_major = col_major_panels; compact = compact_store;
     Dims& d = dims;
     d = Dims();
     d.n_var = t.n_var; d.n_par = t.n_par; d.n_con = t.n_con; d.n_atoms = t.n_atoms;
@@ -223,6 +242,8 @@ struct HostPlan {
     blk.assign(d.N, -1);
     d.max_leaf = 0; d.max_cpl = 0;
     d_off.assign(d.n_leaf + 1, 0); b_off.assign(d.n_leaf > 0 ? d.n_leaf : 1, 0);
+    lf_w.assign(b_off.size(), 0); lf_ldb.assign(b_off.size(), 0); lf_band.assign(b_off.size(), 0); lf_kind.assign(b_off.size(), 0);
+    dl_pos.assign(4 * (size_t)std::max(1, d.root_off), -1);
     int off = 0;
     for (int l = 0; l < d.n_leaf; ++l) {
       const int n = leaf_off[l + 1] - leaf_off[l], nc = cpl_ptr[l + 1] - cpl_ptr[l];
@@ -230,6 +251,31 @@ struct HostPlan {
       if (n > d.max_leaf) d.max_leaf = n;
       if (nc > d.max_cpl) d.max_cpl = nc;
       const int ld = n | 1;                        // odd leading dimension: conflict-free row-per-lane access
+      if (compact) {
+        int S = 0; bool sparse = leaf_bw[l] == 0;
+        if (sparse) {
+          std::vector<int> seen(d.n_root, 0);
+          for (auto& v : var_cpl[l]) { S = std::max(S, (int)v.size()); for (int q : v) if (seen[q]++) sparse = false; }     // a root position met by two variables: shared targets
+          if (S > 4 || n > OMGX_WAVE_ROWS) sparse = false;
+          if (getenv("OMGX_NO_SPARSE")) sparse = false;      // (developer knob)
+        }
+        lf_kind[l] = sparse ? 1 : 0;
+        d_off[l] = off;
+        if (sparse) {
+          // arrays of n: diagonal | S coupling slots | coupling with t | right-hand side
+          b_off[l] = n; lf_w[l] = S; lf_ldb[l] = 0; lf_band[l] = 0;
+          for (int j = 0; j < n; ++j) for (size_t s2 = 0; s2 < var_cpl[l][j].size(); ++s2) dl_pos[4 * (size_t)leaf_off[l] + s2 * n + j] = var_cpl[l][j][s2];
+          off += n * (S + 3);
+        } else {
+          const int band = leaf_bw[l] <= 8 ? leaf_bw[l] : n - 1;      // (wider than the compile-time band of the wave routine: dense)
+          const int ldb = (band + 1) | 1;
+          lf_band[l] = band; lf_ldb[l] = ldb; b_off[l] = ld;
+          off += n * ldb;
+          lf_w[l] = off;
+          off += (nc + 1) * ld;
+        }
+        continue;
+      }
       // rows [0,n): D_l, rows [n,n+nc): coupling rows B_l, row n+nc: the right-hand side of the leaf
       // (carried through the factorisation like a coupling row: it comes out as L^{-1} r)
       if (col_major) { const int ldc = (n + nc + 2) & ~1; d_off[l] = off; b_off[l] = ldc; off += n * ldc; }      // (even: columns start 16-byte aligned)
@@ -241,8 +287,9 @@ struct HostPlan {
       for (int l = 0; l < d.n_leaf; ++l) leaf_rows += (leaf_off[l + 1] - leaf_off[l]) + (cpl_ptr[l + 1] - cpl_ptr[l]) + 1;
       const int pr = leaf_rows > d.nr + 1 ? leaf_rows : d.nr + 1;
       d.col_doubles = (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + OMGX_PAN_LD * pr;
-      const int wave_scratch = OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1) + 16 * 64;      // kkt_solve_wave: 64 doubles per wave
+      const int wave_scratch = OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1) + 8 * 64;      // kkt_solve_wave: 64 doubles per wave
       if (d.col_doubles < wave_scratch) d.col_doubles = wave_scratch;
+      if (compact) d.col_doubles = wave_scratch;      // (the wave path needs no panel buffers: descriptors + the gathered root solutions)
       int small = 0;
       for (int l = 0; l < d.n_leaf; ++l) small += OMGX_PAN_SMALL(leaf_off[l + 1] - leaf_off[l]);
       // the root's panel buffer starts at the same offset, followed by the LDS copy of the root block (Work::root)
@@ -281,10 +328,25 @@ struct HostPlan {
     T.row_leaf = row_leaf.data();
     T.cpl_ptr = cpl_ptr.data(); T.cpl_idx = cpl_idx.data(); T.cpl_map = cpl_map.data();
     T.d_off = d_off.data(); T.b_off = b_off.data();
+    T.lf_w = lf_w.data(); T.lf_ldb = lf_ldb.data(); T.lf_band = lf_band.data(); T.lf_kind = lf_kind.data(); T.dl_pos = dl_pos.data();
     // ---- precomputed addresses -------------------------------------------------------
     auto tri = [](int i, int k) { return i * (i + 1) / 2 + k; };
     auto addr = [&](int p, int q) -> int32_t {               // p >= q, positions
       const int ro = d.root_off;
+      if (compact && q < ro) {
+        const int l = blk[q], o = leaf_off[l], nl = leaf_off[l + 1] - o;
+        if (p < ro) {
+          if (blk[p] != l) return -1;
+          if (lf_kind[l]) return p == q ? d_off[l] + (p - o) : -1;
+          return (p - q) <= lf_band[l] ? d_off[l] + (p - o) * lf_ldb[l] + (q - p + lf_band[l]) : -1;
+        }
+        const int arow = cpl_map[(size_t)l * d.n_root + (p - ro)];
+        if (arow < 0) return -1;
+        if (!lf_kind[l]) return lf_w[l] + arow * b_off[l] + (q - o);
+        if (p - ro == d.n_root - 1) return d_off[l] + (1 + lf_w[l]) * nl + (q - o);       // coupling with t
+        for (int s2 = 0; s2 < lf_w[l]; ++s2) if (dl_pos[4 * (size_t)o + s2 * nl + (q - o)] == p - ro) return d_off[l] + (1 + s2) * nl + (q - o);
+        return -1;
+      }
       if (p < ro) { const int l = blk[p], o = leaf_off[l]; if (blk[q] != l) return -1;
                     return col_major ? d_off[l] + (q - o) * b_off[l] + (p - o) : d_off[l] + (p - o) * b_off[l] + (q - o); }
       if (q < ro) {

@@ -33,9 +33,12 @@ __device__ __forceinline__ void wave_fence() {
 
 // A panel of the KKT store as one wave sees it.  Rows [0, n): the symmetric block (lower part stored);
 // rows [n, nreg): carried rows held one per lane; rows [nreg, nreg + nvec): carried rows held as lane
-// vectors.  Row r starts at base + r * ld + packed * r (r + 1) / 2 (row-major leaf panels: packed = 0;
-// packed lower root: ld = 0, packed = 1).  Pivots j < npos must be positive, the others negative.
-struct WPanel { int base, ld, packed, n, nreg, nvec, npos, bw, vrow; };    // bw: half bandwidth of the symmetric block (n - 1: dense); vrow: index of the first vector row
+// vectors.  Pivots j < npos must be positive, the others negative.  Two storage forms:
+//   packed (root block, band < 0): row r starts at base + r (r + 1) / 2;
+//   banded (leaf panels, band >= 0): row i of the symmetric block keeps its entries (i, i - band) .. (i, i) at
+//     base + i * ldb (a leaf in reverse Cuthill-McKee order has no fill outside its band), the carried rows are
+//     dense rows of n entries at wbase + (r - n) * ld.
+struct WPanel { int base, ld, n, nreg, nvec, npos, bw, vrow, band, ldb, wbase; };    // bw: half bandwidth the factorisation works with (n - 1: dense); vrow: index of the first vector row
 
 // The descriptor fields are the same in every lane but come from LDS (per-lane loads): without this the
 // compiler has to treat every loop bound of the routines below as divergent (exec-masked regions
@@ -43,36 +46,29 @@ struct WPanel { int base, ld, packed, n, nreg, nvec, npos, bw, vrow; };    // bw
 __device__ __forceinline__ WPanel wpanel_uniform(const WPanel& Q) {
   WPanel P;
   P.base = __builtin_amdgcn_readfirstlane(Q.base); P.ld = __builtin_amdgcn_readfirstlane(Q.ld);
-  P.packed = __builtin_amdgcn_readfirstlane(Q.packed); P.n = __builtin_amdgcn_readfirstlane(Q.n);
+  P.n = __builtin_amdgcn_readfirstlane(Q.n);
   P.nreg = __builtin_amdgcn_readfirstlane(Q.nreg); P.nvec = __builtin_amdgcn_readfirstlane(Q.nvec);
   P.npos = __builtin_amdgcn_readfirstlane(Q.npos); P.bw = __builtin_amdgcn_readfirstlane(Q.bw);
-  P.vrow = __builtin_amdgcn_readfirstlane(Q.vrow);
+  P.vrow = __builtin_amdgcn_readfirstlane(Q.vrow); P.band = __builtin_amdgcn_readfirstlane(Q.band);
+  P.ldb = __builtin_amdgcn_readfirstlane(Q.ldb); P.wbase = __builtin_amdgcn_readfirstlane(Q.wbase);
   return P;
 }
 
-__device__ __forceinline__ int wrow(const WPanel& P, int r) { return P.base + r * P.ld + P.packed * ((r * (r + 1)) >> 1); }
+// start of carried row r >= n (a dense row of n entries)
+template <bool BANDED>
+__device__ __forceinline__ int wcarried(const WPanel& P, int r) {
+  return BANDED ? P.wbase + (r - P.n) * P.ld : P.base + ((r * (r + 1)) >> 1);
+}
+// offset such that entry (i, k) of the symmetric block sits at wsym(P, i) + k (banded: only i - band <= k <= i exist)
+template <bool BANDED>
+__device__ __forceinline__ int wsym(const WPanel& P, int i) {
+  return BANDED ? P.base + i * P.ldb + P.band - i : P.base + ((i * (i + 1)) >> 1);
+}
 
 // All dynamic LDS of the workgroup (HIP: every `extern __shared__` array starts at the same address): the
 // out-of-line routines below take offsets into it, so that their accesses stay ds_* instructions (a
 // pointer argument would be a generic pointer: flat_* instructions).
 extern __shared__ double omgx_lds[];
-
-// Where a panel lives: LDS (offset into the workgroup's dynamic LDS) or global memory (spill modes).  Explicit
-// address spaces: a generic pointer would turn every access into a flat_* instruction.
-typedef __attribute__((address_space(1))) double wgdouble;
-template <bool G> struct WStore;
-template <> struct WStore<false> {
-  int off;
-  __device__ __forceinline__ WStore(int o, double*) : off(o) {}
-  __device__ __forceinline__ double ld(int i) const { return omgx_lds[off + i]; }
-  __device__ __forceinline__ void st(int i, double v) const { omgx_lds[off + i] = v; }
-};
-template <> struct WStore<true> {
-  wgdouble* g;
-  __device__ __forceinline__ WStore(int, double* p) : g((wgdouble*)p) {}
-  __device__ __forceinline__ double ld(int i) const { return g[i]; }
-  __device__ __forceinline__ void st(int i, double v) const { g[i] = v; }
-};
 
 // In-place LDL' of a panel by one wave, the matrix in registers: lane i holds row i, a[k] = A[i][k].
 // Straight-line code: all NC columns are processed whatever the order n is (the columns >= n work on
@@ -92,27 +88,33 @@ template <> struct WStore<true> {
 //     garbage then, but nothing traps).
 // On return the panel holds U = L D (rows < n, lower part and diagonal) / W = B L^{-T} (carried rows), the
 // vector rows are stored forward-substituted.  Returns 1 if a pivot had the wrong sign.  `off`: offset of
-// the KKT store in the dynamic LDS (doubles).
-// G: the store lives in global memory (`g`: its address; spill modes) instead of LDS (`off`).
-template <int NC, int BW, bool G = false>
-__device__ __forceinline__ int wave_ldl(int off, const WPanel Pin, double* g = nullptr) {
-  const WStore<G> A(off, g);
+// the KKT store in the dynamic LDS (doubles).  BANDED: storage form of the panel (WPanel).
+template <int NC, int BW, bool BANDED>
+__device__ __forceinline__ int wave_ldl(int off, const WPanel Pin) {
+  const double* A = omgx_lds + off;
+  double* Aw = omgx_lds + off;
   const WPanel P = wpanel_uniform(Pin);
   const int lane = threadIdx.x & 63;
   const int n = P.n;
   const bool has_row = lane < P.nreg;
   const bool sym_row = lane < n;                       // a row of the symmetric block: only its lower part is stored
-  const int ra = wrow(P, has_row ? lane : 0);
+  const int rl = has_row ? lane : 0;
+  const int ra = rl < n ? wsym<BANDED>(P, rl) : wcarried<BANDED>(P, rl);
+  // stored columns of this lane's row: [klo, khi]
+  const int klo = (BANDED && rl < n && rl > P.band) ? rl - P.band : 0;
+  const int khi = rl < n ? rl : n - 1;
   double a[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) {                       // unconditional loads (all in flight), masked afterwards
-    const double v = A.ld(ra + (k < n ? k : n - 1));
-    a[k] = (has_row && k < n) ? v : 0.0;
+    const int kk = k < klo ? klo : (k > khi ? khi : k);
+    const double v = A[ra + kk];
+    a[k] = (has_row && k >= klo && k <= khi) ? v : 0.0;
   }
+  const int v0a = wcarried<BANDED>(P, P.vrow), v1a = wcarried<BANDED>(P, P.vrow + (P.nvec > 1 ? 1 : 0));
   double yv0, yv1;
   {
     const int c = sym_row ? lane : 0;
-    const double v0 = A.ld(wrow(P, P.vrow) + c), v1 = A.ld(wrow(P, P.vrow + (P.nvec > 1 ? 1 : 0)) + c);
+    const double v0 = A[v0a + c], v1 = A[v1a + c];
     yv0 = (P.nvec > 0 && sym_row) ? v0 : 0.0;
     yv1 = (P.nvec > 1 && sym_row) ? v1 : 0.0;
   }
@@ -154,29 +156,31 @@ __device__ __forceinline__ int wave_ldl(int off, const WPanel Pin, double* g = n
       for (int k = 0; k < NC; ++k) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        if (k < n && (!sym_row || k <= ln)) A.st(ra + k, a[k]);
+        // (a row of the symmetric block: its stored part [klo, lane]; a carried row: all n columns)
+        if (k < n && (sym_row ? (k <= ln && k >= klo) : true)) Aw[ra + k] = a[k];
       }
     }
     if (sym_row) {
-      if (P.nvec > 0) A.st(wrow(P, P.vrow) + lane, yv0);
-      if (P.nvec > 1) A.st(wrow(P, P.vrow + 1) + lane, yv1);
+      if (P.nvec > 0) Aw[v0a + lane] = yv0;
+      if (P.nvec > 1) Aw[v1a + lane] = yv1;
     }
   }
   return bad;
 }
 
 // inverse pivot of column `lane`, read back from the stored diagonal (after wave_ldl + wave_fence)
+template <bool BANDED>
 __device__ __forceinline__ double wave_dinv(const double* A, const WPanel P) {
   const int lane = threadIdx.x & 63;
   const int c = lane < P.n ? lane : 0;
-  const double d = A[wrow(P, c) + c];
+  const double d = A[wsym<BANDED>(P, c) + c];
   return lane < P.n ? rcp_pivot(d) : 0.0;
 }
 
 // x <- L^{-T} z for the factor stored in the panel (U = L D in LDS, left by wave_ldl): lane j reads
 // column j (u_ij, i > j), scales it by its own inverse pivot and the wave substitutes backwards with one
 // broadcast per row.  z: component `lane` (lanes >= n ignored); returns x_lane.
-template <int NC>
+template <int NC, bool BANDED>
 __device__ __forceinline__ double wave_bwd(int off, const WPanel Pin, double dinvl, double z) {
   const double* A = omgx_lds + off;
   const WPanel P = wpanel_uniform(Pin);
@@ -186,8 +190,12 @@ __device__ __forceinline__ double wave_bwd(int off, const WPanel Pin, double din
   const int c = lane < n ? lane : 0;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
-    const double v = A[wrow(P, i < n ? i : n - 1) + c];
-    lt[i] = (i < n && lane < i) ? v * dinvl : 0.0;
+    const int ic = i < n ? i : n - 1;
+    // (banded: entry (i, c) exists for i - c <= band; outside the band the factor is zero)
+    const bool in = !BANDED || ic - c <= P.band;
+    const int cc = in ? c : ic - P.band;
+    const double v = A[wsym<BANDED>(P, ic) + cc];
+    lt[i] = (i < n && lane < i && in) ? v * dinvl : 0.0;
   }
   double x = lane < n ? z : 0.0;
 #pragma unroll
