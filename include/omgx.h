@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define OMGX_VERSION 2
+#define OMGX_VERSION 3
 
 /* error codes */
 #define OMGX_OK            0
@@ -105,6 +105,10 @@ typedef struct omgx_options {
   double  dw_leaf_ratio_cold;  /* cold starts weight the inertia correction of nonlinear leaf (hyperplane)
                            variables by this ratio and of root (trajectory) variables by its inverse;
                            1 = symmetric (default); 0.3 suits the Quadrotor / 3-D classes */
+  double  warm_mu_factor;      /* warm starts begin at the barrier parameter clamp(warm_mu_factor * mean(s z), tol / 10,
+                           mu_init).  0 (default): at tol / 10, where the previous solve of the agent ended -- a receding-
+                           horizon step then needs no barrier update of its own; 1: the average complementarity of the
+                           shifted point (knot-crossing steps, where the problem changed more) */
 } omgx_options;
 
 typedef struct omgx_batch omgx_batch;

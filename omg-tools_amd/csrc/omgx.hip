@@ -170,7 +170,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  double* __restrict__ slabs, size_t slab_doubles, double* __restrict__ dw_state,
                  const int32_t* __restrict__ order, const StoreArgs* __restrict__ stp, int only_failed,
                  int* __restrict__ next_slot, const double* __restrict__ x0_alt, int n_alt, int32_t* __restrict__ attempts,
-                 unsigned long long* __restrict__ stats) {
+                 unsigned long long* __restrict__ stats, int stagger) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
     omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
@@ -191,6 +191,10 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   // solves differ by a factor of several in their iteration counts, and a fixed share of agents per workgroup would
   // leave most of the chip waiting for the unluckiest one.  Which workgroup solves an agent does not change its result.
   __shared__ int slot_lds;
+  // Two workgroups per CU start together and would run their (equally long) solves in lockstep -- both in a one-wave
+  // phase, then both in an all-waves phase.  The workgroup in the second wave slot starts `stagger` x 8 k cycles late.
+  if (stagger > 0 && (__builtin_amdgcn_s_getreg(6148) & 1))      // HW_ID[3:0] = wave slot within the SIMD
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
   for (int slot = blockIdx.x; slot < n_agents;) {
     const int b = order ? order[slot] : slot;
     if (!next_slot) slot += gridDim.x;
@@ -219,6 +223,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
       r = omgx::ipm_solve(c, d, T, o, w, p + (size_t)b * d.n_par, xs,
                           lbb, ubb, o.warm_start ? lam + (size_t)b * d.n_con : nullptr,
                           o.warm_start ? status[b] : 0, kkt_doubles, o.warm_start ? dw_state[b] : 0.0);
+      __builtin_amdgcn_s_setprio(0);
       __syncthreads();
       if (r.status == 0 || o.warm_start || attempt >= n_alt) break;
       ++attempt;
@@ -264,7 +269,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
-                             const int32_t*, const StoreArgs*, int, int*, const double*, int, int32_t*, unsigned long long*);
+                             const int32_t*, const StoreArgs*, int, int*, const double*, int, int32_t*, unsigned long long*, int);
 static ipm_kernel_t ipm_kernel_for(int mode, int wave_ok) {
   switch (mode) {
     case omgx::WS_LDS: return wave_ok ? ipm_solve_kernel<omgx::WS_LDS, true> : ipm_solve_kernel<omgx::WS_LDS, false>;
@@ -547,6 +552,7 @@ struct omgx_batch {
   int ws_mode = 0, n_slabs = 0;        // workspace placement (omgx::WS_*), HBM slabs (= grid cap)
   int threads = kThreads;              // workgroup size of the solve kernel
   int per_cu = 1;                      // workgroups (agents in flight) per CU the workspace allows
+  int prio_iter = 0, stagger = 0; // straggler priority / start offset of the second workgroup of a CU (two per CU only)
   size_t slab_doubles = 0;
   double* d_slabs = nullptr;
   double* d_dw = nullptr;          // per-agent inertia correction carried between warm-started solves
@@ -669,6 +675,9 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   b->ws_mode = mode; b->lds_bytes = nl * sizeof(double); b->slab_doubles = ng;
   if (const char* e = getenv("OMGX_THREADS")) { const int t2 = atoi(e); if (t2 == 256 || t2 == 512) b->threads = t2; }      // (developer knob)
   b->threads = b->per_cu >= 2 ? 256 : kThreads;
+  if (b->per_cu >= 2) { b->prio_iter = 2; b->stagger = 0; }
+  if (const char* e = getenv("OMGX_PRIO_ITER")) b->prio_iter = atoi(e);      // (developer knobs)
+  if (const char* e = getenv("OMGX_STAGGER")) b->stagger = atoi(e);
   const omgx::Tables& H = plan.tables;
   const omgx::Dims& d = plan.dims;
   UP(prog, 6 * d.n_prog); UP(knots, t->n_knots); UP(pp_ptr, t->n_pp + 1); UP(pm_coef, t->n_mono);
@@ -836,7 +845,7 @@ int omgx_template_read(const char* path, omgx_template** out) {
 void omgx_default_options(omgx_options* o) {
   o->tol = 1e-3; o->max_iter = 300; o->mu_init = 0.1; o->kappa_push = 1.0;
   o->nu_init = 100.0; o->scale_gmax = 100.0; o->warm_start = 0; o->kappa_warm = 1e-3;
-  o->dw_leaf_ratio_cold = 1.0;
+  o->dw_leaf_ratio_cold = 1.0; o->warm_mu_factor = 0.0;
 }
 
 int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device, omgx_batch** out) {
@@ -851,7 +860,7 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
   omgx_batch* b = new omgx_batch();
   b->device = device; b->n_agents = n_agents;
   omgx_options o; omgx_default_options(&o);
-  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm, o.dw_leaf_ratio_cold};
+  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm, o.dw_leaf_ratio_cold, 0, o.warm_mu_factor};
   int rc = build_batch(b, tpl);
   if (rc != OMGX_OK) { omgx_batch_destroy(b); return rc; }
   const omgx::Dims& d = b->dims;
@@ -911,7 +920,7 @@ void omgx_batch_destroy(omgx_batch* b) {
 int omgx_batch_set_options(omgx_batch* b, const omgx_options* o) {
   if (!b || !o || !(o->tol > 0) || o->max_iter < 0) { g_err = "bad options"; return OMGX_E_INVALID; }
   b->opts = {o->tol, o->max_iter, o->mu_init, o->kappa_push, o->nu_init, o->scale_gmax, o->warm_start, o->kappa_warm,
-             o->dw_leaf_ratio_cold > 0 ? o->dw_leaf_ratio_cold : 1.0};
+             o->dw_leaf_ratio_cold > 0 ? o->dw_leaf_ratio_cold : 1.0, 0, o->warm_mu_factor >= 0 ? o->warm_mu_factor : 0.0};
   return OMGX_OK;
 }
 
@@ -1003,12 +1012,14 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   hipEvent_t e1 = b->ext_ev0 ? b->ext_ev1 : (b->timing ? b->ev1 : nullptr);
   b->timed = b->timing && !b->ext_ev0;
   b->ext_ev0 = b->ext_ev1 = nullptr;
+  b->opts.prio_iter = b->prio_iter;
   hipExtLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok), dim3(b->n_slabs), dim3(b->threads), (uint32_t)b->lds_bytes, b->stream,
                         e0, e1, 0u, d, b->dev,
                         b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
                         b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, (const StoreArgs*)(b->store.out ? b->d_store : nullptr), (flags & OMGX_ONLY_FAILED) ? 1 : 0,
                         b->d_next, b->d_x0_alt, b->d_x0_alt ? b->n_alt : 0, b->d_attempts,
-                        (unsigned long long*)(b->d_stats ? b->d_stats + 4 * (size_t)(b->stats_launch++ % b->stats_slots) : nullptr));
+                        (unsigned long long*)(b->d_stats ? b->d_stats + 4 * (size_t)(b->stats_launch++ % b->stats_slots) : nullptr),
+                        b->stagger);
   HIPCHK(hipGetLastError());
   if (!dev) {
     HIPCHK(hipMemcpyAsync(x, b->d_x, (size_t)B * d.n_var * sizeof(double), hipMemcpyDeviceToHost, b->stream));

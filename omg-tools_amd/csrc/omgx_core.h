@@ -158,6 +158,8 @@ struct Opts {
   int warm_start;      // 1: lam0 holds the multipliers of the previous solve (primal-dual warm start)
   double kappa_warm;   // kappa_push used for warm starts
   double dw_leaf_ratio_cold;   // cold starts: inertia-correction weight of nonlinear leaf variables (root: its inverse)
+  int prio_iter;               // device: iteration from which a solve runs at raised wave priority (0: never)
+  double warm_mu_factor;       // warm starts: mu_0 = clamp(warm_mu_factor * mean(s z), tol / 10, mu_init)
 };
 
 // fixed constants of the iteration (same values in oracle/ipm_numpy.py DEFAULTS)
@@ -171,13 +173,19 @@ struct Opts {
 #define OMGX_ETA         1e-4
 #define OMGX_PHI_NOISE   1e-10   // predicted merit decrease (relative) below which the Armijo test is skipped
 #define OMGX_DW_FIRST    1e-4
+#ifndef OMGX_DW_INC
 #define OMGX_DW_INC      10.0
+#endif
+#ifndef OMGX_DW_DEC
 #define OMGX_DW_DEC      (1.0 / 3.0)
+#endif
 #define OMGX_DW_MAX      1e10
 #define OMGX_DW_ZERO     1e-9
 #define OMGX_DW_HEAVY    10.0
 #define OMGX_KAPPA_EPS_HEAVY 100.0
+#ifndef OMGX_DW_BACKOFF_MAX
 #define OMGX_DW_BACKOFF_MAX 8
+#endif
 #define OMGX_LS_RETRY    3       // line-search failures in a row that are answered by a heavier inertia correction
 #define OMGX_LS_RETRY_DW 100.0
 #define OMGX_DW_CAP_FLOOR 0.03  // share of dw every nonlinear variable keeps under the Gershgorin cap
@@ -1812,7 +1820,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       }
     }
     { double rv[2] = {sz, cnt0}; c.template reduce_ops<0, 0>(rv); sz = rv[0]; cnt0 = rv[1]; }
-    mu = fmin(o.mu_init, fmax(o.tol / 10.0, sz / fmax(1.0, cnt0)));
+    mu = fmin(o.mu_init, fmax(o.tol / 10.0, o.warm_mu_factor * sz / fmax(1.0, cnt0)));
     // multiplier of t >= 0: dual feasible in t (nu - v'z - zt = 0) rather than on the central path,
     // so that the first Newton step in t is O(t) instead of O(nu t^2 / mu)
   }
@@ -1846,6 +1854,11 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   long long resid_seen_ = 0;
 #endif
   for (it = 0; it <= o.max_iter; ++it) {
+#ifndef OMGX_HOST_PORT
+    // a solve that is still running after this many iterations is one the rest of the batch will wait for: its waves win
+    // the issue arbitration against the agent that shares the CU from here on (reset by the kernel after the solve)
+    if (it == o.prio_iter) __builtin_amdgcn_s_setprio(2);
+#endif
     OMGX_TIC();
     // ---- Jacobian (scaled): one thread per entry; only the entries that depend on x ------------
     if (it > 0) {        // (iteration 0: left by the setup)

@@ -22,6 +22,10 @@ import numpy as np
 from .splines import shiftoverknot_T
 
 
+# solver options of a knot-crossing step (BatchP2P `cross_options`)
+CROSS_OPTIONS = {}
+
+
 def dual_shift_perm(father, extrapolate=True):
     """perm[r] = row whose multiplier warm-starts row r after the horizon moved by
     one knot interval (-1: none).  Spline-valued constraint entries are indexed by
@@ -54,13 +58,17 @@ def dual_shift_perm(father, extrapolate=True):
 class BatchP2P(object):
 
     def __init__(self, problem, P, ops='hip', device=None, options=None, update_time=0.1,
-                 max_iter_step=None, shift_every_spline=True, straggler_first=True):
+                 max_iter_step=None, shift_every_spline=True, straggler_first=True, cross_options=None):
         # max_iter_step: iteration cap of a receding-horizon step (default: the cold-solve cap; an
         # agent that hits it keeps its last strictly feasible iterate and restarts cold next step).
         # shift_every_spline: on a knot crossing shift every spline variable like the generated
         # C++ does (`export/export.py:414-439`); False = the Python rule, names containing 'seg'
         # only (`optilayer.py:482`), which leaves the stale leading coefficient of g* / eps_* (it
         # carries no cost just before the crossing, so the barrier parks it far from its bound).
+        # cross_options: solver options of the step right after a knot crossing (the shifted plan sits on the boundary of
+        # the rows that enter the horizon and its multipliers are index-shifted: a wider push into the interior and the
+        # barrier parameter of the shifted point itself)
+        self.cross_options = dict(cross_options) if cross_options is not None else dict(CROSS_OPTIONS)
         self.problem = problem
         father = problem.father
         self.tpl = tpl = father.template
@@ -109,6 +117,8 @@ class BatchP2P(object):
         self.opts = dict(tol=1e-3, max_iter=300)
         self.opts.update(options or {})
         self.max_iter_cold = self.opts['max_iter']
+        from .backend import DEFAULT_OPTIONS
+        self._base_extra = dict((k, self.opts.get(k, DEFAULT_OPTIONS[k])) for k in self.cross_options)   # (what a non-crossing step resets them to)
         self.max_iter_step = int(max_iter_step) if max_iter_step else self.max_iter_cold
         self.kind = 'hip' if ops == 'hip' else 'host'
         self.straggler_first = bool(straggler_first)
@@ -146,10 +156,11 @@ class BatchP2P(object):
             self.iters = np.zeros(self.B, dtype=np.int32)
 
     # -- solves ------------------------------------------------------------------------
-    def _solve(self, warm, events=None, step_desc=None, ordered=False):
+    def _solve(self, warm, events=None, step_desc=None, ordered=False, extra=None):
+        extra = extra or {}
         if self.kind == 'hip':
             self.solver.set_options(warm_start=int(warm),
-                                    max_iter=self.max_iter_step if warm else self.max_iter_cold)
+                                    max_iter=self.max_iter_step if warm else self.max_iter_cold, **dict(self._base_extra, **extra))
             if not warm:
                 self.lam.zero_()
                 self._x_init = self.x.clone()
@@ -165,12 +176,12 @@ class BatchP2P(object):
             if not warm:
                 self.lam[:] = 0.
             self.pool.solve(self.p, self.x, self.lam, self.status, self.iters, self.dw, step=step_desc,
-                            **dict(self.opts, warm_start=int(warm), max_iter=self.max_iter_step if warm else self.max_iter_cold))
+                            **dict(self.opts, warm_start=int(warm), max_iter=self.max_iter_step if warm else self.max_iter_cold, **extra))
         else:
             r = self.port.solve(self.tpl, self.p, self.x, lam_g0=self.lam if warm else None,
                                 status0=self.status if warm else None, warm_start=int(warm),
                                 n_threads=self.n_threads, dw_state=self.dw,
-                                **dict(self.opts, max_iter=self.max_iter_step if warm else self.max_iter_cold))
+                                **dict(self.opts, max_iter=self.max_iter_step if warm else self.max_iter_cold, **extra))
             self.x, self.lam, self.status, self.iters = r['x'], r['lam_g'], r['status'], r['iters']
 
     def solve_cold(self, bends=(1.0, -1.0, 2.5, -2.5), fused=True):
@@ -241,7 +252,7 @@ class BatchP2P(object):
         t_rel = float(np.round(t_now, 6) % self.knot_time)
         if self.kind == 'host' and self.pool is not None:
             self.time = t_now
-            self._solve(True, step_desc=self._pool_step(tau, t_rel, crossed))
+            self._solve(True, step_desc=self._pool_step(tau, t_rel, crossed), extra=self.cross_options if crossed else None)
             return crossed
         if self.kind == 'hip':
             # (asked for before the prediction: its launch then carries the ordering as one more workgroup)
@@ -265,7 +276,7 @@ class BatchP2P(object):
             self._shift()
         self.time = t_now
         # (3) warm-started solve
-        self._solve(True, events, ordered=self.kind == 'hip' and self.straggler_first)
+        self._solve(True, events, ordered=self.kind == 'hip' and self.straggler_first, extra=self.cross_options if crossed else None)
         return crossed
 
     def _eval_rows(self, tau):

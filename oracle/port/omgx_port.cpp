@@ -38,6 +38,7 @@ extern "C" int omgx_port_solve_mt(const omgx_template* tpl, const omgx_options* 
   o.kappa_push = opt->kappa_push; o.nu_init = opt->nu_init; o.scale_gmax = opt->scale_gmax;
   o.warm_start = opt->warm_start; o.kappa_warm = opt->kappa_warm;
   o.dw_leaf_ratio_cold = opt->dw_leaf_ratio_cold > 0 ? opt->dw_leaf_ratio_cold : 1.0;
+  o.prio_iter = 0; o.warm_mu_factor = opt->warm_mu_factor >= 0 ? opt->warm_mu_factor : 0.0;
   const omgx::Dims& d = plan.dims;
   std::atomic<int> next(0);
   auto worker = [&]() {
@@ -163,6 +164,7 @@ extern "C" int omgx_port_pool_solve(void* h, const omgx_options* opt, int32_t n_
   o.kappa_push = opt->kappa_push; o.nu_init = opt->nu_init; o.scale_gmax = opt->scale_gmax;
   o.warm_start = opt->warm_start; o.kappa_warm = opt->kappa_warm;
   o.dw_leaf_ratio_cold = opt->dw_leaf_ratio_cold > 0 ? opt->dw_leaf_ratio_cold : 1.0;
+  o.prio_iter = 0; o.warm_mu_factor = opt->warm_mu_factor >= 0 ? opt->warm_mu_factor : 0.0;
   std::atomic<int> next(0);
   pp->run([&](int tid) {
     double* buf = pp->bufs[tid].data();

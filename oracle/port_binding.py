@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-PORT_PATH = os.path.join(_DIR, '_build', 'libomgx_port.so')
+PORT_PATH = os.environ.get('OMGX_PORT_LIB') or os.path.join(_DIR, '_build', 'libomgx_port.so')      # (OMGX_PORT_LIB: developer override, e.g. a build with other constants)
 
 
 def build():
