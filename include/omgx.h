@@ -106,9 +106,10 @@ typedef struct omgx_options {
                            variables by this ratio and of root (trajectory) variables by its inverse;
                            1 = symmetric (default); 0.3 suits the Quadrotor / 3-D classes */
   double  warm_mu_factor;      /* warm starts begin at the barrier parameter clamp(warm_mu_factor * mean(s z), tol / 10,
-                           mu_init).  0 (default): at tol / 10, where the previous solve of the agent ended -- a receding-
-                           horizon step then needs no barrier update of its own; 1: the average complementarity of the
-                           shifted point (knot-crossing steps, where the problem changed more) */
+                           mu_init).  1 (default): the average complementarity of the point handed in (safe when the
+                           problem changed between the solves: ADMM x-updates); 0: at tol / 10, where the previous solve
+                           of the agent ended -- receding-horizon steps of one agent then need no barrier update of
+                           their own (BatchP2P sets it: fewer stragglers between knot crossings) */
 } omgx_options;
 
 typedef struct omgx_batch omgx_batch;
@@ -177,6 +178,16 @@ int  omgx_batch_solve(omgx_batch* b, const double* p, const double* x0,
                       double* x, double* lam_g, int32_t* status, int32_t* iters,
                       int32_t flags);
 int  omgx_batch_sync(omgx_batch* b);
+
+/* Verification entry (host pointers, not a hot path): what the solve kernel's own tables evaluate at
+ * the caller's point x [B, n_var] with parameters p [B, n_par] and multipliers lam_g [B, n_con] -- by the device code
+ * of the solve (parameter stage, Jacobian items, row terms, the Hessian items of the assembly pass), unscaled:
+ *   g [B, n_con] constraint values, f [B] objective, jac [B, n_con + 1, n_var] dense Jacobian of (g, f) (last row: the
+ *   objective gradient), hess [B, n_var, n_var] dense symmetric Hessian of f + lam_g' g.
+ * What CasADi's AD derives inside nlpsol (`basics/optilayer.py:49-60`, `expand=True`); compared with the oracle's
+ * numpy restatement in tests/test_gpu_eval.py.  Any output pointer may be NULL. */
+int  omgx_batch_eval(omgx_batch* b, const double* p, const double* x, const double* lam_g, double* g, double* f,
+                     double* jac, double* hess);
 /* Launch statistics without a host round trip: stats_device [n_slots][4] int64 on the device, zeroed and owned
  * by the caller (n_slots = 0 / NULL switches it off).  The k-th solve launch after this call adds into row
  * k % n_slots: {agents that ended with Solve_Succeeded, sum of their iteration counts over all agents it solved,

@@ -267,6 +267,43 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   }
 }
 
+// Verification entry (omgx_batch_eval): one workgroup evaluates the tables of the solve at a caller's point and dumps the
+// raw arrays -- row values, objective, Jacobian entries, the KKT store holding the Lagrangian Hessian -- to `out`
+// [agent][n_con + 1 + nnz_j + kkt_doubles]; the host scatters them into dense matrices.
+template <int MODE, bool WAVE_ONLY>
+__global__ void __launch_bounds__(512)
+ipm_eval_kernel(omgx::Dims d, omgx::Tables T, int kkt_doubles, const double* __restrict__ p, const double* __restrict__ x,
+                const double* __restrict__ lam, int n_agents, double* __restrict__ slabs, size_t slab_doubles,
+                double* __restrict__ out) {
+  extern __shared__ __align__(16) double lds[];
+  omgx::Work w;
+  omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
+                               d, kkt_doubles);
+  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_kkt_hbm(MODE)> c; c.red = w.red; c.prof = nullptr;
+  const size_t stride = (size_t)d.n_con + 1 + d.nnz_j + kkt_doubles;
+  for (int b = blockIdx.x; b < n_agents; b += gridDim.x) {
+    double* o = out + (size_t)b * stride;
+    omgx::ipm_eval(c, d, T, w, p + (size_t)b * d.n_par, x + (size_t)b * d.n_var, lam + (size_t)b * d.n_con, kkt_doubles,
+                   o + d.n_con);
+    for (int i = threadIdx.x; i < d.n_con; i += blockDim.x) o[i] = w.hv[i];
+    for (int i = threadIdx.x; i < d.nnz_j; i += blockDim.x) o[d.n_con + 1 + i] = w.jval[i];
+    for (int i = threadIdx.x; i < kkt_doubles; i += blockDim.x) o[d.n_con + 1 + d.nnz_j + i] = w.kkt[i];
+    __syncthreads();
+  }
+}
+
+typedef void (*ipm_eval_kernel_t)(omgx::Dims, omgx::Tables, int, const double*, const double*, const double*, int, double*,
+                                  size_t, double*);
+static ipm_eval_kernel_t ipm_eval_kernel_for(int mode, int wave_ok) {
+  switch (mode) {
+    case omgx::WS_LDS: return wave_ok ? ipm_eval_kernel<omgx::WS_LDS, true> : ipm_eval_kernel<omgx::WS_LDS, false>;
+    case omgx::WS_KKT_HBM: return ipm_eval_kernel<omgx::WS_KKT_HBM, false>;
+    case omgx::WS_JAC_HBM: return ipm_eval_kernel<omgx::WS_JAC_HBM, false>;
+    case omgx::WS_JAC_ONLY: return ipm_eval_kernel<omgx::WS_JAC_ONLY, true>;
+    default: return ipm_eval_kernel<omgx::WS_ROWS_HBM, false>;
+  }
+}
+
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
                              const int32_t*, const StoreArgs*, int, int*, const double*, int, int32_t*, unsigned long long*, int);
@@ -582,6 +619,8 @@ struct omgx_batch {
   std::vector<int32_t> shift_ent_host; std::vector<double> shift_T_host;
   int32_t* d_shift_ent = nullptr; double* d_shift_T = nullptr; size_t shift_ent_cap = 0, shift_T_cap = 0;
   uint8_t* d_mask = nullptr;
+  // omgx_batch_eval: Jacobian entry -> (row, variable), stored Hessian entry -> (address, variable a, variable b)
+  std::vector<int32_t> ev_jrow, ev_jvar, ev_hess;
 };
 
 namespace {
@@ -680,6 +719,16 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   if (const char* e = getenv("OMGX_STAGGER")) b->stagger = atoi(e);
   const omgx::Tables& H = plan.tables;
   const omgx::Dims& d = plan.dims;
+  {
+    b->ev_jrow.assign(plan.je_row.begin(), plan.je_row.begin() + d.nnz_j);
+    b->ev_jvar.resize(d.nnz_j);
+    for (int e = 0; e < d.nnz_j; ++e) b->ev_jvar[e] = plan.order[plan.jr_pos[e]];
+    for (int q1 = 0; q1 + 1 < d.N; ++q1)          // (positions but the phase-I variable t, the last one)
+      for (int q2 = 0; q2 <= q1; ++q2) {
+        const int32_t ad = plan.kkt_addr(q1, q2);
+        if (ad >= 0) { b->ev_hess.push_back(ad); b->ev_hess.push_back(plan.order[q1]); b->ev_hess.push_back(plan.order[q2]); }
+      }
+  }
   UP(prog, 6 * d.n_prog); UP(knots, t->n_knots); UP(pp_ptr, t->n_pp + 1); UP(pm_coef, t->n_mono);
   UP(pm_ptr, t->n_mono + 1); UP(pm_atom, t->n_matom); UP(slot_pp, d.n_slots);
   // (packed monomial records: 16-byte MonoRec or, with 5..8 atoms per monomial, 24-byte MonoRec8 behind the same pointers)
@@ -845,7 +894,7 @@ int omgx_template_read(const char* path, omgx_template** out) {
 void omgx_default_options(omgx_options* o) {
   o->tol = 1e-3; o->max_iter = 300; o->mu_init = 0.1; o->kappa_push = 1.0;
   o->nu_init = 100.0; o->scale_gmax = 100.0; o->warm_start = 0; o->kappa_warm = 1e-3;
-  o->dw_leaf_ratio_cold = 1.0; o->warm_mu_factor = 0.0;
+  o->dw_leaf_ratio_cold = 1.0; o->warm_mu_factor = 1.0;
 }
 
 int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device, omgx_batch** out) {
@@ -1043,6 +1092,53 @@ int omgx_batch_sync(omgx_batch* b) {
   if (!b) return OMGX_E_INVALID;
   { const int rc_o = flush_order(b); if (rc_o != OMGX_OK) return rc_o; }      // (a deferred omgx_batch_order_by_iters)
   HIPCHK(hipStreamSynchronize(b->stream));
+  return OMGX_OK;
+}
+
+int omgx_batch_eval(omgx_batch* b, const double* p, const double* x, const double* lam_g, double* g, double* f,
+                    double* jac, double* hess) {
+  if (!b || !p || !x || !lam_g) { g_err = "null argument"; return OMGX_E_INVALID; }
+  HIPCHK(hipSetDevice(b->device));
+  const omgx::Dims& d = b->dims;
+  const int B = b->n_agents;
+  const size_t stride = (size_t)d.n_con + 1 + d.nnz_j + b->kkt_doubles;
+  double *d_out = nullptr, *d_lam = nullptr;
+  HIPCHK(hipMalloc((void**)&d_out, (size_t)B * stride * sizeof(double)));
+  if (hipMalloc((void**)&d_lam, (size_t)B * d.n_con * sizeof(double)) != hipSuccess) { (void)hipFree(d_out); g_err = "hipMalloc failed"; return OMGX_E_HIP; }
+  std::vector<double> out((size_t)B * stride);
+  hipError_t e = hipMemcpyAsync(b->d_p, p, (size_t)B * d.n_par * sizeof(double), hipMemcpyHostToDevice, b->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(b->d_x0, x, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_lam, lam_g, (size_t)B * d.n_con * sizeof(double), hipMemcpyHostToDevice, b->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(ipm_eval_kernel_for(b->ws_mode, b->dims.wave_ok), dim3(b->n_slabs), dim3(b->threads), (uint32_t)b->lds_bytes,
+                       b->stream, d, b->dev, b->kkt_doubles, (const double*)b->d_p, (const double*)b->d_x0, (const double*)d_lam, B,
+                       b->d_slabs, b->slab_doubles, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, out.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  (void)hipFree(d_out); (void)hipFree(d_lam);
+  if (e != hipSuccess) { g_err = std::string("omgx_batch_eval: ") + hipGetErrorString(e); return OMGX_E_HIP; }
+  const size_t nv = d.n_var, nc = d.n_con;
+  for (int a = 0; a < B; ++a) {
+    const double* o = out.data() + (size_t)a * stride;
+    if (g) for (size_t r = 0; r < nc; ++r) g[a * nc + r] = o[r];
+    if (f) f[a] = o[nc];
+    if (jac) {
+      double* J = jac + (size_t)a * (nc + 1) * nv;
+      for (size_t i = 0; i < (nc + 1) * nv; ++i) J[i] = 0.0;
+      for (int en = 0; en < d.nnz_j; ++en) J[(size_t)b->ev_jrow[en] * nv + b->ev_jvar[en]] = o[nc + 1 + en];
+    }
+    if (hess) {
+      double* Hm = hess + (size_t)a * nv * nv;
+      for (size_t i = 0; i < nv * nv; ++i) Hm[i] = 0.0;
+      const double* kk = o + nc + 1 + d.nnz_j;
+      for (size_t i = 0; i + 2 < b->ev_hess.size(); i += 3) {
+        const int va = b->ev_hess[i + 1], vb = b->ev_hess[i + 2];
+        Hm[(size_t)va * nv + vb] = kk[b->ev_hess[i]]; Hm[(size_t)vb * nv + va] = kk[b->ev_hess[i]];
+      }
+    }
+  }
   return OMGX_OK;
 }
 

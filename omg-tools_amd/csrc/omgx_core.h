@@ -1726,6 +1726,38 @@ OMGX_FN void kkt_rhs(const C& c, const Dims& d, const Tables& T, Work& w, double
   }
 }
 
+// Lagrangian Hessian, the share of owner bin `bin`: the items of the terms with >= 2 variables, weight w.ht[row] =
+// multiplier x signed scale (row m = objective: 1), summed per KKT address in table order and added to the store
+// (omgx_plan.h (4): ELL records, the target in the last record of its run, everything else to the dump slot).
+// Used by the assembly of the solve and by the verification entry (ipm_eval).
+OMGX_FN void hess_bin(const Dims& d, const Tables& T, Work& w, int m, int bin, int dump) {
+  double acc = 0.0;
+  for (int e0 = 0; e0 < d.kh_len; e0 += OMGX_REC_BATCH) {
+    HItem q[OMGX_REC_BATCH];
+#pragma unroll
+    for (int i = 0; i < OMGX_REC_BATCH; ++i) q[i] = T.kh_rec[(e0 + i) * OMGX_NBIN + bin];
+    double h[OMGX_REC_BATCH];
+#pragma unroll
+    for (int i = 0; i < OMGX_REC_BATCH; ++i) {
+      const int r = q[i].row < m ? q[i].row : 0;
+      const double lam = (q[i].row < m) ? w.ht[r] : 1.0;          // (row multiplier x signed scale, set below the residuals)
+      const double xs = w.slots[q[i].slot < 0 ? 0 : q[i].slot], x3 = w.x[q[i].vthird < 0 ? 0 : q[i].vthird];
+      h[i] = (q[i].kind ? 2.0 : 1.0) * lam * q[i].coef * (q[i].slot < 0 ? 1.0 : xs) * (q[i].vthird < 0 ? 1.0 : x3);
+    }
+    // (the old values are read first, together: a thread's targets are distinct, only the dump
+    // slot repeats, and what ends up there does not matter)
+    double old[OMGX_REC_BATCH];
+#pragma unroll
+    for (int i = 0; i < OMGX_REC_BATCH; ++i) old[i] = w.kkt[q[i].target >= 0 ? q[i].target : dump];
+#pragma unroll
+    for (int i = 0; i < OMGX_REC_BATCH; ++i) {
+      acc += h[i];
+      w.kkt[q[i].target >= 0 ? q[i].target : dump] = old[i] + acc;
+      acc = q[i].target >= 0 ? 0.0 : acc;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // the solve
 // ---------------------------------------------------------------------------
@@ -2080,34 +2112,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       OMGX_TOC(PH_A_TCOL);
       for (int bin = c.tid(); bin < OMGX_NBIN; bin += c.nthr()) {
         const int dump = d.dump_off + (bin & 63);
-        {
-          // Lagrangian Hessian: terms with >= 2 variables, weight = multiplier * signed scale (row m = objective: 1)
-          double acc = 0.0;
-          for (int e0 = 0; e0 < d.kh_len; e0 += OMGX_REC_BATCH) {
-            HItem q[OMGX_REC_BATCH];
-#pragma unroll
-            for (int i = 0; i < OMGX_REC_BATCH; ++i) q[i] = T.kh_rec[(e0 + i) * OMGX_NBIN + bin];
-            double h[OMGX_REC_BATCH];
-#pragma unroll
-            for (int i = 0; i < OMGX_REC_BATCH; ++i) {
-              const int r = q[i].row < m ? q[i].row : 0;
-              const double lam = (q[i].row < m) ? w.ht[r] : 1.0;          // (row multiplier x signed scale, set below the residuals)
-              const double xs = w.slots[q[i].slot < 0 ? 0 : q[i].slot], x3 = w.x[q[i].vthird < 0 ? 0 : q[i].vthird];
-              h[i] = (q[i].kind ? 2.0 : 1.0) * lam * q[i].coef * (q[i].slot < 0 ? 1.0 : xs) * (q[i].vthird < 0 ? 1.0 : x3);
-            }
-            // (the old values are read first, together: a thread's targets are distinct, only the dump
-            // slot repeats, and what ends up there does not matter)
-            double old[OMGX_REC_BATCH];
-#pragma unroll
-            for (int i = 0; i < OMGX_REC_BATCH; ++i) old[i] = w.kkt[q[i].target >= 0 ? q[i].target : dump];
-#pragma unroll
-            for (int i = 0; i < OMGX_REC_BATCH; ++i) {
-              acc += h[i];
-              w.kkt[q[i].target >= 0 ? q[i].target : dump] = old[i] + acc;
-              acc = q[i].target >= 0 ? 0.0 : acc;
-            }
-          }
-        }
+        hess_bin(d, T, w, m, bin, dump);
         if (first_trial) {
           // Gershgorin row sums of the Hessian, term by term (no cancellation), owner = position
           double acc = 0.0;
@@ -2397,6 +2402,30 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   res.status = status; res.iters = it > o.max_iter ? o.max_iter : it; res.f = f; res.mu = mu; res.t = t;
   res.dw = dw_last * reg_root;      // handed to the next (warm, symmetric) solve: the damping the root block had
   return res;
+}
+
+// Verification entry: what the tables of the solve evaluate at a given point, by the device code of
+// the solve itself -- parameter stage, Jacobian items, row terms, the Hessian items of the assembly pass -- without any
+// scaling: w.hv <- g(x, p) (unscaled row values), *f <- objective, w.jval <- every Jacobian entry (objective row
+// included), the KKT store <- the Hessian of f + lam' g at its addresses (nothing else in it).
+template <class C>
+OMGX_FN void ipm_eval(const C& c, const Dims& d, const Tables& T, Work& w, const double* p, const double* x,
+                      const double* lam, int kkt_doubles, double* f_out) {
+  const int n = d.n_var, m = d.n_con;
+  Kkt K; K.bind(d, T, w.kkt);
+  kkt_describe(c, d, K, w);
+  OMGX_PFOR(i, n) w.x[i] = x[i];
+  if (c.tid() == 0) w.x[n] = 0.0;
+  eval_params(c, d, T, w, p);
+  OMGX_PFOR(i, d.nnz_j) w.jval[T.ja_list[i]] = jac_entry_ell(T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
+  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell(T, w, i, m, w.x); }
+  OMGX_PFOR(r, m) w.ht[r] = lam[r];
+  OMGX_PFOR(i, kkt_doubles) w.kkt[i] = 0.0;
+  const double f = c.rsum(row_value_share(c, T, w, m, w.x));
+  if (c.tid() == 0) *f_out = f;
+  c.sync();
+  for (int bin = c.tid(); bin < OMGX_NBIN; bin += c.nthr()) hess_bin(d, T, w, m, bin, d.dump_off + (bin & 63));
+  c.sync();
 }
 
 }  // namespace omgx

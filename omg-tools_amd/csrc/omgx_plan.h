@@ -219,6 +219,36 @@ struct HostPlan {
     return bin;
   }
 
+  // address of entry (p, q), p >= q (positions), inside the KKT store; -1: the structure has no such entry
+  int32_t kkt_addr(int p, int q) const {
+  const Dims& d = dims;
+  auto tri = [](int i, int k) { return i * (i + 1) / 2 + k; };
+    const int ro = d.root_off;
+    if (compact && q < ro) {
+      const int l = blk[q], o = leaf_off[l], nl = leaf_off[l + 1] - o;
+      if (p < ro) {
+        if (blk[p] != l) return -1;
+        if (lf_kind[l]) return p == q ? d_off[l] + (p - o) : -1;
+        return (p - q) <= lf_band[l] ? d_off[l] + (p - o) * lf_ldb[l] + (q - p + lf_band[l]) : -1;
+      }
+      const int arow = cpl_map[(size_t)l * d.n_root + (p - ro)];
+      if (arow < 0) return -1;
+      if (!lf_kind[l]) return lf_w[l] + arow * b_off[l] + (q - o);
+      if (p - ro == d.n_root - 1) return d_off[l] + (1 + lf_w[l]) * nl + (q - o);       // coupling with t
+      for (int s2 = 0; s2 < lf_w[l]; ++s2) if (dl_pos[4 * (size_t)o + s2 * nl + (q - o)] == p - ro) return d_off[l] + (1 + s2) * nl + (q - o);
+      return -1;
+    }
+    if (p < ro) { const int l = blk[p], o = leaf_off[l]; if (blk[q] != l) return -1;
+                  return col_major ? d_off[l] + (q - o) * b_off[l] + (p - o) : d_off[l] + (p - o) * b_off[l] + (q - o); }
+    if (q < ro) {
+      const int l = blk[q], n = leaf_off[l + 1] - leaf_off[l];
+      const int arow = cpl_map[(size_t)l * d.n_root + (p - ro)];
+      if (arow < 0) return -1;
+      return col_major ? d_off[l] + (q - leaf_off[l]) * b_off[l] + (n + arow) : d_off[l] + (n + arow) * b_off[l] + (q - leaf_off[l]);
+    }
+    return d_off[d.n_leaf] + tri(p - ro, q - ro);
+  }
+
   // col_major: leaf panels column by column (the spill modes: one thread per panel row then reads consecutive
   // addresses of the HBM slab; the LDS modes keep rows with an odd leading dimension, conflict-free there)
   bool col_major = false;
@@ -331,32 +361,7 @@ struct HostPlan {
     T.lf_w = lf_w.data(); T.lf_ldb = lf_ldb.data(); T.lf_band = lf_band.data(); T.lf_kind = lf_kind.data(); T.dl_pos = dl_pos.data();
     // ---- precomputed addresses -------------------------------------------------------
     auto tri = [](int i, int k) { return i * (i + 1) / 2 + k; };
-    auto addr = [&](int p, int q) -> int32_t {               // p >= q, positions
-      const int ro = d.root_off;
-      if (compact && q < ro) {
-        const int l = blk[q], o = leaf_off[l], nl = leaf_off[l + 1] - o;
-        if (p < ro) {
-          if (blk[p] != l) return -1;
-          if (lf_kind[l]) return p == q ? d_off[l] + (p - o) : -1;
-          return (p - q) <= lf_band[l] ? d_off[l] + (p - o) * lf_ldb[l] + (q - p + lf_band[l]) : -1;
-        }
-        const int arow = cpl_map[(size_t)l * d.n_root + (p - ro)];
-        if (arow < 0) return -1;
-        if (!lf_kind[l]) return lf_w[l] + arow * b_off[l] + (q - o);
-        if (p - ro == d.n_root - 1) return d_off[l] + (1 + lf_w[l]) * nl + (q - o);       // coupling with t
-        for (int s2 = 0; s2 < lf_w[l]; ++s2) if (dl_pos[4 * (size_t)o + s2 * nl + (q - o)] == p - ro) return d_off[l] + (1 + s2) * nl + (q - o);
-        return -1;
-      }
-      if (p < ro) { const int l = blk[p], o = leaf_off[l]; if (blk[q] != l) return -1;
-                    return col_major ? d_off[l] + (q - o) * b_off[l] + (p - o) : d_off[l] + (p - o) * b_off[l] + (q - o); }
-      if (q < ro) {
-        const int l = blk[q], n = leaf_off[l + 1] - leaf_off[l];
-        const int arow = cpl_map[(size_t)l * d.n_root + (p - ro)];
-        if (arow < 0) return -1;
-        return col_major ? d_off[l] + (q - leaf_off[l]) * b_off[l] + (n + arow) : d_off[l] + (n + arow) * b_off[l] + (q - leaf_off[l]);
-      }
-      return d_off[d.n_leaf] + tri(p - ro, q - ro);
-    };
+    auto addr = [&](int p, int q) -> int32_t { return kkt_addr(p, q); };
     const int m = d.n_con, n = d.n_var;
     je_row.assign(d.nnz_j > 0 ? d.nnz_j : 1, 0);
     jt_addr.assign(d.nnz_j > 0 ? d.nnz_j : 1, 0);

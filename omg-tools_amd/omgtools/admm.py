@@ -151,6 +151,56 @@ class BatchADMM(object):
         return [(float(np.sqrt(r[0])), float(np.sqrt(r[1])), float(r[2])) for r in arr]
 
 
+class FormationMPC(object):
+    """The receding-horizon protocol of the reference's ADMM problems with nothing leaving the device
+    (`problems/dualmethod.py:200-224`: `init_iter` iterations at the start time, afterwards `max_iter_per_update`
+    iteration(s) per update, the time advanced by `update_time`; `problems/admm.py:477-491`: on a knot crossing the
+    warm start of x and the whole consensus state are shifted; ideal prediction `vehicles/vehicle.py:323-326`: the
+    initial conditions of the next x-update are the current plan at the new time).  One `step()` =
+      prediction launch (state0, input0, t into p) -> moving obstacles advanced -> shift on a crossing -> ADMM iteration(s).
+    ops: `HipAdmmOps`; obstacles: [(p_x, p_v, p_a, n_dim)] of the obstacles that move."""
+
+    def __init__(self, admm, father, tpl, lay, vehicle, obstacles=(), update_time=0.1, init_iter=5, iters_per_update=1,
+                 knot_time=None, consensus_is_spline=True):
+        from .formation import shift_tables
+        self.admm, self.ops, self.lay, self.tpl = admm, admm.ops, lay, tpl
+        self.T, self.update_time = admm.T, float(update_time)
+        # the plan the prediction reads: the vehicle's own splines (the consensus quantity may be something else: RendezVous)
+        self.basis, self.n_spl = vehicle.basis, vehicle.n_spl
+        self.o_spl = tpl.entry_range(vehicle.label, 'splines_seg0', 'var')[0]
+        self.knot_time = float(knot_time) if knot_time is not None else self.T / (len(self.basis.knots) - 2 * self.basis.degree - 1)
+        self.init_iter, self.iters_per_update = int(init_iter), int(iters_per_update)
+        self.shift = shift_tables(father, tpl, lay, self.basis, consensus_is_spline)
+        self.obst = list(obstacles)
+        self.time = 0.0
+
+    def initialize(self):
+        self.admm.initialize()
+        for _ in range(self.init_iter):
+            self.admm.iterate(0.0, sync=False)
+
+    def step(self):
+        lay, ops = self.lay, self.ops
+        t_prev, t_now = self.time, self.time + self.update_time
+        rel_prev = np.round(t_prev, 6) % self.knot_time
+        tau = (rel_prev + self.update_time) / self.T
+        crossed = int(np.round(t_prev / self.knot_time, 6)) < int(np.round(t_now / self.knot_time, 6))
+        t_rel = float(np.round(t_now, 6) % self.knot_time)
+        ops.predict(self.o_spl, self.n_spl, self.basis, tau, 1.0 / self.T, [lay.p_state0, lay.p_input0], lay.p_t, t_rel)
+        dt = self.update_time
+        for ox, ov, oa, nd in self.obst:        # x <- x + v dt + a dt^2 / 2, v <- v + a dt (`environment/obstacle.py:246-264`)
+            px, pv, pa = ops.p[:, ox:ox + nd], ops.p[:, ov:ov + nd], ops.p[:, oa:oa + nd]
+            px += dt * pv + (0.5 * dt * dt) * pa
+            pv += dt * pa
+        if crossed:
+            ops.shift(*self.shift)
+        self.time = t_now
+        status = None
+        for _ in range(self.iters_per_update):
+            status, _ = self.admm.iterate(t_rel, sync=False)
+        return status, crossed
+
+
 class HipAdmmOps(object):
     """Device-resident state + the HIP kernels of include/omgx.h (torch tensors
     only as the allocator / collective carrier)."""
@@ -229,6 +279,13 @@ class HipAdmmOps(object):
             self.p[:, lay.p_t] = t_rel
             self.p[:, lay.p_rho] = rho
             self._t_rho = (float(t_rel), float(rho))
+
+    def predict(self, o_spl, n_spl, basis, tau, inv_T, p_offs, p_t, t_rel):
+        """Ideal prediction (`vehicles/vehicle.py:323-326`): p[p_offs[o] + k] <- o-th time derivative of spline k of the
+        current plan at tau, p[p_t] <- t_rel; one launch (`omgx_batch_predict_ex`)."""
+        self.solver.predict_ex(self.x, self.p, o_spl, n_spl, basis.degree, basis.knots, tau, inv_T, p_offs, p_t, t_rel)
+        if getattr(self, '_t_rho', None) is not None:       # (the launch wrote t: set_time has nothing left to do)
+            self._t_rho = (float(t_rel), self._t_rho[1])
 
     def solve(self):
         self.solver.solve_device(self.p, self.x, self.lb, self.ub, self.x_new, self.lam,

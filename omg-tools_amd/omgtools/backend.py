@@ -58,7 +58,7 @@ class COptions(C.Structure):
 
 DEFAULT_OPTIONS = dict(tol=1e-3, max_iter=300, mu_init=0.1, kappa_push=1.0,
                        nu_init=100.0, scale_gmax=100.0, warm_start=0, kappa_warm=1e-3,
-                       dw_leaf_ratio_cold=1.0, warm_mu_factor=0.0)
+                       dw_leaf_ratio_cold=1.0, warm_mu_factor=1.0)
 
 
 def make_options(**kw):
@@ -377,6 +377,20 @@ class BatchSolver(object):
         self.lib.omgx_batch_set_launch_events.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _check(self.lib, self.lib.omgx_batch_set_launch_events(self._h, handle(start), handle(stop)),
                'omgx_batch_set_launch_events')
+
+    def eval(self, p, x, lam_g):
+        """Verification entry (`omgx_batch_eval`): g, f, dense Jacobian of (g, f) and dense Hessian of f + lam_g' g at
+        x, evaluated by the device code of the solve from its own tables."""
+        t, B = self.template, self.n_agents
+        p = np.ascontiguousarray(np.asarray(p, float).reshape(B, t.n_par))
+        x = np.ascontiguousarray(np.asarray(x, float).reshape(B, t.n_var))
+        lam = np.ascontiguousarray(np.asarray(lam_g, float).reshape(B, t.n_con))
+        g, f = np.empty((B, t.n_con)), np.empty(B)
+        jac, hess = np.empty((B, t.n_con + 1, t.n_var)), np.empty((B, t.n_var, t.n_var))
+        self.lib.omgx_batch_eval.argtypes = [C.c_void_p] * 8
+        _check(self.lib, self.lib.omgx_batch_eval(self._h, p.ctypes.data, x.ctypes.data, lam.ctypes.data, g.ctypes.data,
+                                                  f.ctypes.data, jac.ctypes.data, hess.ctypes.data), 'omgx_batch_eval')
+        return dict(g=g, f=f, jac=jac, hess=hess)
 
     def sync(self):
         _check(self.lib, self.lib.omgx_batch_sync(self._h), 'omgx_batch_sync')

@@ -114,7 +114,8 @@ class BatchP2P(object):
         self.shift_mats = np.concatenate(mats)
         self._shift_dense = [(e, m.reshape(e[1], e[1])) for e, m in zip(ents, mats)]
         self.time = 0.0
-        self.opts = dict(tol=1e-3, max_iter=300)
+        # (warm_mu_factor 0: a step starts at the barrier parameter the previous solve of the agent ended with)
+        self.opts = dict(tol=1e-3, max_iter=300, warm_mu_factor=0.0)
         self.opts.update(options or {})
         self.max_iter_cold = self.opts['max_iter']
         from .backend import DEFAULT_OPTIONS

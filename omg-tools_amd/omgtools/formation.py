@@ -192,6 +192,30 @@ def reverse_slots(nbr):
     return slot
 
 
+def shift_tables(father, tpl, lay, basis, consensus_is_spline=True):
+    """Knot-crossing shift of an ADMM fleet (`problems/admm.py:477-491`): (entries, T matrices) for every spline
+    variable of x, for the consensus blocks z_i, l_i, z_ji, l_ji inside p and for the side arrays z_ij / l_ij --
+    the three arguments of `HipAdmmOps.shift`."""
+    Tm = shiftoverknot_T(basis)
+    ents, mats, off = [], [], 0
+    for label, name, spl in father.shifted_entries(every_spline=True):
+        lo, rows, cols = tpl.var_layout[(label, name)]
+        Ts = shiftoverknot_T(spl['basis'])
+        ents.append([lo, rows, cols, off]); mats.append(Ts.reshape(-1)); off += Ts.size
+    shift_x = (np.array(ents, dtype=np.int32), np.concatenate(mats))
+    L, nd, n_nghb = lay.L, lay.n_dim, lay.n_nghb
+    if consensus_is_spline:
+        p_ents = [[lay.p_zi, L, nd, 0], [lay.p_li, L, nd, 0]]
+        for j in range(n_nghb):
+            p_ents += [[lay.p_zji + j * lay.ns, L, nd, 0], [lay.p_lji + j * lay.ns, L, nd, 0]]
+        shift_p = (np.array(p_ents, dtype=np.int32), Tm.reshape(-1).copy())
+        shift_side = (np.array([[j * lay.ns, L, nd, 0] for j in range(n_nghb)], dtype=np.int32), Tm.reshape(-1).copy())
+    else:                  # (the shared quantity is a plain vector: nothing of the consensus state is shifted)
+        shift_p = (np.zeros((0, 4), dtype=np.int32), np.zeros(0))
+        shift_side = (np.zeros((0, 4), dtype=np.int32), np.zeros(0))
+    return shift_x, shift_p, shift_side
+
+
 class FormationPoint2point(object):
     """Drop-in for the reference's `FormationPoint2point` (`problems/formation.py:26-72` on top of
     `ADMMProblem` `problems/admm.py:556-628`, `DualProblem` `problems/dualmethod.py:190-244`,
@@ -258,26 +282,8 @@ class FormationPoint2point(object):
                           (lay.p_lji, n_nghb * lay.ns)):
             keep[off:off + size] = False
         self.host_cols = np.nonzero(keep)[0]
-        # shift tables: every spline variable of x; consensus blocks inside p; side arrays z_ij / l_ij
-        veh0, father0 = self.vehicles[0], self.subs[0][2]
-        Tm = shiftoverknot_T(veh0.basis)
-        ents, mats, off = [], [], 0
-        for label, name, spl in father0.shifted_entries(every_spline=True):
-            lo, rows, cols = tpl.var_layout[(label, name)]
-            Ts = shiftoverknot_T(spl['basis'])
-            ents.append([lo, rows, cols, off]); mats.append(Ts.reshape(-1)); off += Ts.size
-        self._shift_x = (np.array(ents, dtype=np.int32), np.concatenate(mats))
-        L, nd = lay.L, lay.n_dim
-        if self._consensus_is_spline:
-            p_ents = [[lay.p_zi, L, nd, 0], [lay.p_li, L, nd, 0]]
-            for j in range(n_nghb):
-                p_ents += [[lay.p_zji + j * lay.ns, L, nd, 0], [lay.p_lji + j * lay.ns, L, nd, 0]]
-            self._shift_p = (np.array(p_ents, dtype=np.int32), Tm.reshape(-1).copy())
-            self._shift_side = (np.array([[j * lay.ns, L, nd, 0] for j in range(n_nghb)], dtype=np.int32),
-                                Tm.reshape(-1).copy())
-        else:                  # (the shared quantity is a plain vector: nothing of the consensus state is shifted)
-            self._shift_p = (np.zeros((0, 4), dtype=np.int32), np.zeros(0))
-            self._shift_side = (np.zeros((0, 4), dtype=np.int32), np.zeros(0))
+        self._shift_x, self._shift_p, self._shift_side = shift_tables(self.subs[0][2], tpl, lay, self.vehicles[0].basis,
+                                                                       self._consensus_is_spline)
         # device state
         p0, x0 = self._host_parameters(0.), self._host_variables()
         if self._ops_kind == 'hip':

@@ -25,6 +25,19 @@ class NumpyAdmmOps(object):
         self.p[:, lay.p_t] = t_rel
         self.p[:, lay.p_rho] = rho
 
+    def predict(self, o_spl, n_spl, basis, tau, inv_T, p_offs, p_t, t_rel):
+        """Ideal prediction (`vehicles/vehicle.py:323-326`) with the front end's own spline algebra."""
+        L = len(basis)
+        c = self.x[:, o_spl:o_spl + n_spl * L].reshape(self.B, n_spl, L)
+        for o, off in enumerate(p_offs):
+            if o == 0:
+                E = basis.eval_basis([tau])[0]
+            else:
+                dbasis, Po = basis.derivative(o)
+                E = dbasis.eval_basis([tau])[0] @ Po * inv_T ** o
+            self.p[:, off:off + n_spl] = c @ np.asarray(E).reshape(-1)
+        self.p[:, p_t] = t_rel
+
     def solve(self):
         # consecutive x-updates are neighbouring problems: primal-dual warm start from the previous
         # one (first call: status 1 everywhere = cold), like HipAdmmOps

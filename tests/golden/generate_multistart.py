@@ -1,0 +1,187 @@
+"""Generates tests/golden/sol_cfg2_ms.npz and tests/golden/sol_mpc_cfg2.npz: parity fixtures whose every number
+comes from scipy SLSQP (dense SQP with its own QP solver and line search) on the restated NLP
+(oracle/nlp_numpy.py, pinned to the reference's construct code by tests/golden/nlp_*.npz).  Neither the product
+kernel nor its numpy mirror (oracle/ipm_numpy.py) chooses a basin or a starting point here.
+
+  sol_cfg2_ms.npz   64 seeded agents of config 2 (Holonomic, K = 11, 3 circles), multi-start: SLSQP from the
+                    reference's initial guess (`get_init_spline_value`, hyperplanes zero), from that guess bent
+                    sideways by +-0.5, +-1, +-1.5 and +-2.5 m at mid-course (the other sides of the obstacles) and from twelve
+                    seeded perturbations of the guess (hyperplane normals drawn at random instead of zero: from the
+                    degenerate all-zero normals the first step of any method decides the side).  Every converged
+                    start is stored (`x_all`, `f_all`, `ok_all`): the product, started from the reference's guess,
+                    must land in one of these minima.
+  sol_mpc_cfg2.npz  the warm-started path: 8 agents, 12 receding-horizon steps (one knot crossing) of the protocol of
+                    bench.py run on the host (oracle port as the solver object); the inputs of every step -- p_k, the
+                    shifted plan x0_k, the shifted multipliers lam_k -- are dumped, and the NLP of every step is
+                    solved by SLSQP from x0_k.  A warm-started product solve from the dumped inputs must return
+                    SLSQP's solution.
+
+Run from the repository root:  python tests/golden/generate_multistart.py [cfg2] [mpc]   (about 25 minutes on 8 cores)"""
+import os
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+HERE = os.path.dirname(os.path.abspath(__file__))
+BENDS = (1.0, -1.0, 2.5, -2.5, 0.5, -0.5, 1.5, -1.5)
+N_RANDOM = 12
+_STATE = {}
+
+
+def _scenario(n):
+    import omgtools.backend as be
+    from omgtools import scenarios
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    return scenarios.holonomic_p2p(n)
+
+
+def _init(n):
+    from oracle.nlp_numpy import NumpyNLP
+    problem, P = _scenario(n)
+    tpl = problem.father.template
+    _STATE.update(tpl=tpl, P=P, nlp=NumpyNLP(tpl), problem=problem)
+
+
+def bent(tpl, problem, x0, s):
+    """BatchP2P._bent on one agent: the straight-line guess moved sideways by s sin^2(pi k / (L - 1)) metres."""
+    veh = problem.vehicles[0]
+    L, ns = len(veh.basis), veh.n_spl
+    lo = tpl.entry_range(veh.label, 'splines_seg0', 'var')[0]
+    c = x0[lo:lo + ns * L].reshape(ns, L)
+    d = c[:, -1] - c[:, 0]
+    d = d / max(np.linalg.norm(d), 1e-12)
+    nrm = np.array([-d[1], d[0]])
+    out = x0.copy()
+    out[lo:lo + ns * L] += (s * nrm[:, None] * (np.sin(np.linspace(0., 1., L) * np.pi) ** 2)[None, :]).reshape(-1)
+    return out
+
+
+def starts_of(b):
+    tpl, P, problem = _STATE['tpl'], _STATE['P'], _STATE['problem']
+    x0 = P['x0'][b]
+    out = [x0] + [bent(tpl, problem, x0, s) for s in BENDS]
+    rng = np.random.default_rng(9000 + b)
+    hyp = [k for k in tpl.var_layout if k[1].startswith('a_')]
+    for _ in range(N_RANDOM):
+        x = x0.copy()
+        for key in hyp:
+            lo, rows, cols = tpl.var_layout[key]
+            nrm = rng.normal(size=cols)
+            nrm /= np.linalg.norm(nrm)
+            x[lo:lo + rows * cols] = 0.5 * np.repeat(nrm, rows)         # a constant unit direction, half length
+        out.append(x)
+    return out
+
+
+def _solve_start(job):
+    from slsqp_reference import solve_slsqp
+    b, k = job
+    tpl, P, nlp = _STATE['tpl'], _STATE['P'], _STATE['nlp']
+    t0 = time.time()
+    x, f, ok = solve_slsqp(nlp, tpl, starts_of(b)[k], P['p'][b], maxiter=800)
+    return b, k, x, f, ok, time.time() - t0
+
+
+def distinct_minima(x_all, f_all, ok_all, lo, hi):
+    """The converged starts of every agent with duplicates removed (same objective to 1e-6 relative and the same
+    trajectory coefficients to 1e-3): x_min [n, K, n_var] (NaN padded), f_min [n, K], n_min [n], and the index of the
+    start that found each one first."""
+    n, ns, nv = x_all.shape
+    keep = []
+    for b in range(n):
+        mine = []
+        for k in range(ns):
+            if not ok_all[b, k]:
+                continue
+            if any(abs(f_all[b, k] - f_all[b, j]) < 1e-6 * (1 + abs(f_all[b, j])) and
+                   np.abs(x_all[b, k, lo:hi] - x_all[b, j, lo:hi]).max() < 1e-3 for j in mine):
+                continue
+            mine.append(k)
+        keep.append(mine)
+    K = max(len(m) for m in keep)
+    x_min = np.full((n, K, nv), np.nan); f_min = np.full((n, K), np.nan); first = np.full((n, K), -1, dtype=np.int32)
+    for b, mine in enumerate(keep):
+        for i, k in enumerate(mine):
+            x_min[b, i], f_min[b, i], first[b, i] = x_all[b, k], f_all[b, k], k
+    return x_min, f_min, np.array([len(m) for m in keep], dtype=np.int32), first
+
+
+def run_cfg2(n, workers):
+    t0 = time.time()
+    n_start = 1 + len(BENDS) + N_RANDOM
+    jobs = [(b, k) for b in range(n) for k in range(n_start)]
+    with ProcessPoolExecutor(workers, initializer=_init, initargs=(n,)) as ex:
+        res = list(ex.map(_solve_start, jobs, chunksize=1))
+    _init(n)
+    tpl, P, problem = _STATE['tpl'], _STATE['P'], _STATE['problem']
+    lo, hi = tpl.entry_range(problem.vehicles[0].label, 'splines_seg0', 'var')
+    x_all = np.zeros((n, n_start, tpl.n_var)); f_all = np.full((n, n_start), np.nan); ok_all = np.zeros((n, n_start), dtype=bool)
+    secs = np.zeros((n, n_start))
+    for b, k, x, f, ok, s in res:
+        x_all[b, k], f_all[b, k], ok_all[b, k], secs[b, k] = x, f, ok, s
+    x_min, f_min, n_min, first = distinct_minima(x_all, f_all, ok_all, lo, hi)
+    np.savez_compressed(os.path.join(HERE, 'sol_cfg2_ms.npz'), p=P['p'][:n], x0=P['x0'][:n], x_min=x_min, f_min=f_min,
+                        n_min=n_min, first_start=first, f_all=f_all, ok_all=ok_all, spl=np.array([lo, hi]), n_var=tpl.n_var,
+                        n_con=tpl.n_con, n_par=tpl.n_par, seconds=secs, bends=np.array(BENDS), n_random=N_RANDOM)
+    print('sol_cfg2_ms.npz: %d agents x %d starts, %d converged, %d..%d distinct minima per agent, %.0f s'
+          % (n, n_start, int(ok_all.sum()), n_min.min(), n_min.max(), time.time() - t0))
+
+
+# ---- warm-started path ------------------------------------------------------------------------------------------
+def _solve_step(job):
+    from slsqp_reference import solve_slsqp
+    tpl, nlp = _STATE['tpl'], _STATE['nlp']
+    k, b, x0, p = job
+    t0 = time.time()
+    x, f, ok = solve_slsqp(nlp, tpl, x0, p, maxiter=800)
+    return k, b, x, f, ok, time.time() - t0
+
+
+def run_mpc(n, steps, workers):
+    from omgtools.batch import BatchP2P
+    from oracle import port_binding
+    t0 = time.time()
+    _init(n)
+    tpl, P, problem = _STATE['tpl'], _STATE['P'], _STATE['problem']
+    mpc = BatchP2P(problem, P, ops=port_binding, options=dict(tol=1e-6, max_iter=500))
+    mpc.pool = None                                   # the step glue in numpy (so that the inputs of the solve can be taken)
+    mpc.solve_cold(bends=())
+    assert (np.asarray(mpc.status) == 0).all()
+    dump = dict(p=[], x0=[], lam=[], crossed=[], x_port=[])
+    solve = mpc._solve
+
+    def tap(warm, *a, **kw):
+        dump['p'].append(np.array(mpc.p)); dump['x0'].append(np.array(mpc.x)); dump['lam'].append(np.array(mpc.lam))
+        solve(warm, *a, **kw)
+        dump['x_port'].append(np.array(mpc.x))
+    mpc._solve = tap
+    for k in range(steps):
+        dump['crossed'].append(bool(mpc.step()))
+        assert (np.asarray(mpc.status) == 0).all(), k
+    jobs = [(k, b, dump['x0'][k][b], dump['p'][k][b]) for k in range(steps) for b in range(n)]
+    with ProcessPoolExecutor(workers, initializer=_init, initargs=(n,)) as ex:
+        res = list(ex.map(_solve_step, jobs, chunksize=1))
+    x = np.zeros((steps, n, tpl.n_var)); f = np.zeros((steps, n)); ok = np.zeros((steps, n), dtype=bool)
+    for k, b, xs, fs, oks, s in res:
+        x[k, b], f[k, b], ok[k, b] = xs, fs, oks
+    lo, hi = tpl.entry_range(problem.vehicles[0].label, 'splines_seg0', 'var')
+    np.savez_compressed(os.path.join(HERE, 'sol_mpc_cfg2.npz'), p=np.array(dump['p']), x0=np.array(dump['x0']),
+                        lam=np.array(dump['lam']), crossed=np.array(dump['crossed']), x=x, f=f, ok=ok, x_port=np.array(dump['x_port']),
+                        spl=np.array([lo, hi]), n_var=tpl.n_var, n_con=tpl.n_con, n_par=tpl.n_par)
+    print('sol_mpc_cfg2.npz: %d steps x %d agents, %d converged, crossings at %s, %.0f s'
+          % (steps, n, int(ok.sum()), np.nonzero(dump['crossed'])[0].tolist(), time.time() - t0))
+
+
+if __name__ == '__main__':
+    workers = int(os.environ.get('WORKERS', '8'))
+    which = sys.argv[1:] or ['cfg2', 'mpc']
+    if 'mpc' in which:
+        run_mpc(8, 12, workers)
+    if 'cfg2' in which:
+        run_cfg2(64, workers)

@@ -239,3 +239,47 @@ def test_device_path_exchange_indexing_over_gloo():
     for pr in procs:
         pr.join(timeout=60)
     assert all(pr.exitcode == 0 for pr in procs) and got == {0: True, 1: True, 2: True}
+
+
+def test_formation_mpc_protocol_on_the_host():
+    """The receding-horizon protocol of the formation loop (`problems/dualmethod.py:200-224`, `admm.py:477-491`) as
+    `FormationMPC` drives it -- prediction, moving obstacle, knot-crossing shift of x and of the consensus state, one ADMM
+    iteration per update -- on the numpy backend: the x-updates do real work (the consensus moves with the fleet),
+    every one converges, the fleet advances in formation and the primal residual stays small across a crossing."""
+    import omgtools.backend as be
+    from omgtools import scenarios
+    from omgtools.admm import BatchADMM, FormationMPC
+    from admm_numpy_ops import NumpyAdmmOps
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        problem, updater, father, lay, P = scenarios.formation_holonomic(6)
+    finally:
+        be.create_nlp = saved
+    tpl = father.template
+    ops = NumpyAdmmOps(tpl, lay, P['p'], P['x0'], tol=1e-6)
+    admm = BatchADMM(lay, P['nbr'], ops, rho=1.0)
+    moving = []
+    for obs in problem.environment.obstacles:
+        ox, ov, oa = (tpl.entry_range(obs.label, nm, 'par') for nm in ('x', 'v', 'a'))
+        if np.any(P['p'][:, ov[0]:ov[1]] != 0.):
+            moving.append((ox[0], ov[0], oa[0], ox[1] - ox[0]))
+    assert len(moving) == 1
+    mpc = FormationMPC(admm, father, tpl, lay, problem.vehicles[0], obstacles=moving, update_time=0.1, init_iter=5,
+                       knot_time=problem.knot_time)
+    mpc.initialize()
+    x_obst0 = ops.p[0, moving[0][0]]
+    start = ops.p[:, lay.p_state0:lay.p_state0 + 2].copy()
+    crossings = 0
+    for k in range(12):
+        status, crossed = mpc.step()
+        crossings += crossed
+        assert np.all(np.asarray(status) == 0), k
+    assert crossings == 1
+    assert abs(ops.p[0, moving[0][0]] - (x_obst0 - 0.15 * 1.2)) < 1e-12          # the circle moved on
+    moved = ops.p[:, lay.p_state0:lay.p_state0 + 2] - start
+    assert np.all(moved[:, 1] > 0.2)                                            # 1.2 s towards the goal (+y)
+    assert np.abs(moved - moved.mean(axis=0)).max() < 0.05                        # ... in formation
+    res = admm.residuals
+    # one iteration per update keeps the consensus converging while the fleet moves (and through the crossing)
+    assert len(res) == 5 + 12 and res[-1][0] < res[4][0] and max(r[0] for r in res[5:]) < 2.5 * res[4][0], [r[0] for r in res]

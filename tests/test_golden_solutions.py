@@ -1,14 +1,20 @@
-"""Parity against solutions computed by solvers that share no code with the product kernel
-(tests/golden/sol_*.npz, generator tests/golden/generate_solutions.py): scipy SLSQP on 64 seeded agents
-of config 2, the dense numpy interior point (+ SLSQP polish) on 8 agents each of the Quadrotor and
-Holonomic3D classes.  CasADi/IPOPT outputs are unobtainable here; from the reference's
-initial guess the product must reach the same local minimum: objective to 1e-5 relative, trajectory
-coefficients (the output the reference consumes, `problems/point2point.py:213-229`) to 1e-4 for at least 85 %
-of the agents (the reference's own C++-vs-Python acceptance, `export/tests/point2point/test.cpp:131,138`)
-and to 2e-3 for all (the optimal faces of the linear objective are flat).  Where the two
-end in different local minima of this non-convex problem the product's objective must not be worse
-than the fixture's by more than the tolerance, and every returned point must satisfy the optimality
-conditions of the reference's NLP.
+"""Parity against solutions computed by solvers that share no code with the product kernel.  CasADi/IPOPT outputs
+are unobtainable here; the stand-ins:
+
+  config 2 (tests/golden/sol_cfg2_ms.npz, generator tests/golden/generate_multistart.py): 64 seeded agents, scipy SLSQP
+  from 21 starting points each -- the reference's initial guess, that guess bent to the other sides of the obstacles,
+  seeded random hyperplane normals -- every distinct minimum stored (2 to 5 per agent).  Neither the product nor its
+  numpy mirror chose a basin or a starting point of that fixture.  From the reference's initial guess the product must
+  land IN ONE OF THE STORED MINIMA: objective to 1e-5 relative, trajectory coefficients (the output the reference
+  consumes, `problems/point2point.py:213-229`) to 1e-4 for at least 85 % of the agents (the reference's own
+  C++-vs-Python acceptance, `export/tests/point2point/test.cpp:131,138`) and to 2e-3 for all (the optimal faces of the
+  linear objective are flat); at least 95 % of the agents must do so, a point outside the stored set may not be worse
+  than the best stored minimum by more than 1e-3 (1 + |f|), and every returned point must satisfy the optimality
+  conditions of the reference's NLP.
+
+  Quadrotor and Holonomic3D classes (sol_cfg3.npz, sol_cfg5.npz, generator generate_solutions.py): 8 agents each, the
+  dense numpy interior point + SLSQP polish (SLSQP from scratch needs hours at these sizes): same criteria against the
+  one stored solution per agent, another local minimum accepted if it is not worse by more than 0.25 (1 + |f|).
 
 CPU tier: host build of the kernel source (same-source check of the host logic); GPU tier: the HIP path
 through the C ABI."""
@@ -18,7 +24,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = [('sol_cfg2.npz', 'holonomic_p2p', 64, 0.9), ('sol_cfg3.npz', 'quadrotor_p2p', 8, 0.6),
+CASES = [('sol_cfg2_ms.npz', 'holonomic_p2p', 64, 0.95), ('sol_cfg3.npz', 'quadrotor_p2p', 8, 0.6),
          ('sol_cfg5.npz', 'holonomic3d_p2p', 8, 0.7)]
 TOL = 1e-6
 
@@ -47,6 +53,23 @@ def check_case(fixture, scenario, n, min_match, solve):
     nlp = NumpyNLP(tpl)
     lo, hi = d['spl']
     matched, compared, tight = 0, 0, 0
+    if 'x_min' in d:                       # multi-start fixture: the product must land in one of the stored minima
+        assert (res['status'] == 0).all(), res['status']
+        for b in range(n):
+            assert_kkt(nlp, tpl, P['p'][b], res['x'][b], res['lam_g'][b], 10 * TOL, (fixture, b))
+            f = nlp.fg(res['x'][b], nlp.term_coefs(P['p'][b]))[0]
+            hits = [k for k in range(int(d['n_min'][b])) if abs(f - d['f_min'][b, k]) < 1e-5 * (1 + abs(f))]
+            if hits:
+                dx = min(np.abs(res['x'][b, lo:hi] - d['x_min'][b, k, lo:hi]).max() for k in hits)
+                assert dx < 2e-3, (fixture, b, dx)
+                tight += dx < 1e-4
+                matched += 1
+            else:
+                best = np.nanmin(d['f_min'][b])
+                assert f < best + 1e-3 * (1 + abs(best)), (fixture, b, f, best)
+        assert matched >= min_match * n, (fixture, matched, n)
+        assert tight >= 0.85 * matched, (fixture, tight, matched)
+        return matched, n
     for b in range(n):
         if res['status'][b] != 0:
             continue
