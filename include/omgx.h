@@ -77,7 +77,24 @@ typedef struct omgx_template {
    * vehicle's spline coefficients, `vehicles/vehicle.py:105-120`); n_root_vars = 0: chosen automatically */
   int32_t n_root_vars;
   const int32_t* root_vars; /* [n_root_vars] */
+  /* Block table (optional, n_blocks = 0: none): where every named entry of x, p and g sits -- the offsets the
+   * reference's exporter hard-codes into the generated C++ (`export/export.py:302-353`, consumed by
+   * `Point2Point::fillParameterDict / extractData`, `export/point2point/Point2Point.cpp:263-294`), in the order of
+   * `OptiFather._var_struct / _par_struct / _con_struct` (`basics/optilayer.py:225-272`).  Entry i: name
+   * "<child label>.<entry name>" (block_names: the n_blocks NUL-terminated strings one after the other), kind
+   * (OMGX_BLOCK_VAR / _PAR / _CON), offset into the flat vector and shape rows x cols (column-major inside the
+   * entry: spline k of a (len(basis) x n_spl) entry occupies [off + k * rows, off + (k + 1) * rows)). */
+  int32_t n_blocks, block_names_len;
+  const char* block_names;          /* [block_names_len] */
+  const int32_t* block_kind;        /* [n_blocks] */
+  const int32_t* block_off;         /* [n_blocks] */
+  const int32_t* block_rows;        /* [n_blocks] */
+  const int32_t* block_cols;        /* [n_blocks] */
 } omgx_template;
+
+#define OMGX_BLOCK_VAR 0
+#define OMGX_BLOCK_PAR 1
+#define OMGX_BLOCK_CON 2
 
 /* What the library derived from a template (host only, needs no device). */
 #define OMGX_PLAN_MAX_LEAF 16
@@ -130,6 +147,15 @@ void omgx_default_options(omgx_options* o);
 
 /* Derive the solver plan of a template without creating a batch (host only).  order [n_var+1]
  * (position -> variable, n_var = the phase-I variable) may be NULL. */
+/* Block table look-up (host only): number of entries of a kind, entry i of a kind in table order, an entry by
+ * name.  Return OMGX_OK, or OMGX_E_INVALID (omgx_last_error) when the template carries no such entry.  The name
+ * pointer stays valid as long as the template does. */
+int  omgx_template_n_blocks(const omgx_template* tpl, int32_t kind);
+int  omgx_template_block_at(const omgx_template* tpl, int32_t kind, int32_t i, const char** name, int32_t* off,
+                            int32_t* rows, int32_t* cols);
+int  omgx_template_block(const omgx_template* tpl, int32_t kind, const char* name, int32_t* off, int32_t* rows,
+                         int32_t* cols);
+
 int  omgx_plan_describe(const omgx_template* tpl, omgx_plan_info* info, int32_t* order);
 
 /* Create a batch of n_agents independent problems sharing one template. */

@@ -813,9 +813,10 @@ int omgx_plan_describe(const omgx_template* tpl, omgx_plan_info* info, int32_t* 
 // Template files: the counts and arrays of omgx_template, written by the Python front end
 // (omgtools.backend.save_template) once per problem class and read by C/C++ callers -- the role the
 // generated nlp.so plays for the reference's C++ export (`export/export.py:236-262`, loaded in
-// `Point2Point.cpp:80-91`).  Layout: "OMGXTPL2", 13 int32 counts, then the arrays in struct order.
+// `Point2Point.cpp:80-91`).  Layout: "OMGXTPL3", 15 int32 counts (the last two: block-table entries and the length of
+// their names), then the arrays in struct order, the block table last ("OMGXTPL2" files -- 13 counts, no table -- are still read).
 namespace {
-struct TplField { int kind; size_t count; const void* const* src; void** dst; };     // kind 0 int32, 1 double
+struct TplField { int kind; size_t count; const void* const* src; void** dst; };     // kind 0 int32, 1 double, 2 char
 
 size_t tpl_fields(const omgx_template& t, omgx_template* m, TplField* f) {
   const omgx_template& s = t;
@@ -826,6 +827,8 @@ size_t tpl_fields(const omgx_template& t, omgx_template* m, TplField* f) {
   OMGX_F(0, slot_pp, t.n_slots)              OMGX_F(0, row_ptr, t.n_con + 2)   OMGX_F(1, t_coef, t.n_terms)
   OMGX_F(0, t_slot, t.n_terms)               OMGX_F(0, t_var, 3 * (size_t)t.n_terms)
   OMGX_F(0, eq_rows, t.n_eq)                 OMGX_F(0, root_vars, t.n_root_vars)
+  OMGX_F(2, block_names, t.block_names_len)  OMGX_F(0, block_kind, t.n_blocks)        OMGX_F(0, block_off, t.n_blocks)
+  OMGX_F(0, block_rows, t.n_blocks)          OMGX_F(0, block_cols, t.n_blocks)
 #undef OMGX_F
   return k;
 }
@@ -837,13 +840,14 @@ int omgx_template_write(const omgx_template* tpl, const char* path) {
   if (!path) { g_err = "null path"; return OMGX_E_INVALID; }
   FILE* fp = fopen(path, "wb");
   if (!fp) { g_err = std::string("cannot write ") + path; return OMGX_E_INVALID; }
-  const int32_t counts[13] = {tpl->n_var, tpl->n_par, tpl->n_con, tpl->n_atoms, tpl->n_slots, tpl->n_terms, tpl->n_prog,
-                              tpl->n_knots, tpl->n_pp, tpl->n_mono, tpl->n_matom, tpl->n_eq, tpl->n_root_vars};
-  bool ok = fwrite("OMGXTPL2", 1, 8, fp) == 8 && fwrite(counts, sizeof(int32_t), 13, fp) == 13;
-  TplField f[16];
+  const int32_t counts[15] = {tpl->n_var, tpl->n_par, tpl->n_con, tpl->n_atoms, tpl->n_slots, tpl->n_terms, tpl->n_prog,
+                              tpl->n_knots, tpl->n_pp, tpl->n_mono, tpl->n_matom, tpl->n_eq, tpl->n_root_vars,
+                              tpl->n_blocks, tpl->block_names_len};
+  bool ok = fwrite("OMGXTPL3", 1, 8, fp) == 8 && fwrite(counts, sizeof(int32_t), 15, fp) == 15;
+  TplField f[24];
   const size_t nf = tpl_fields(*tpl, nullptr, f);
   for (size_t i = 0; i < nf && ok; ++i) {
-    const size_t sz = f[i].kind ? sizeof(double) : sizeof(int32_t);
+    const size_t sz = f[i].kind == 1 ? sizeof(double) : (f[i].kind == 2 ? 1 : sizeof(int32_t));
     if (f[i].count && fwrite(*f[i].src, sz, f[i].count, fp) != f[i].count) ok = false;
   }
   if (fclose(fp) != 0) ok = false;
@@ -853,7 +857,7 @@ int omgx_template_write(const omgx_template* tpl, const char* path) {
 
 void omgx_template_free(omgx_template* t) {
   if (!t) return;
-  TplField f[16];
+  TplField f[24];
   const size_t nf = tpl_fields(*t, t, f);
   for (size_t i = 0; i < nf; ++i) free(*f[i].dst);
   free(t);
@@ -865,20 +869,23 @@ int omgx_template_read(const char* path, omgx_template** out) {
   FILE* fp = fopen(path, "rb");
   if (!fp) { g_err = std::string("cannot read ") + path; return OMGX_E_INVALID; }
   char magic[8];
-  int32_t c[13];
-  if (fread(magic, 1, 8, fp) != 8 || memcmp(magic, "OMGXTPL2", 8) != 0 || fread(c, sizeof(int32_t), 13, fp) != 13) {
+  int32_t c[15] = {0};
+  const bool head = fread(magic, 1, 8, fp) == 8;
+  const int n_counts = head && memcmp(magic, "OMGXTPL3", 8) == 0 ? 15 : (head && memcmp(magic, "OMGXTPL2", 8) == 0 ? 13 : 0);
+  if (n_counts == 0 || fread(c, sizeof(int32_t), n_counts, fp) != (size_t)n_counts) {
     fclose(fp); g_err = std::string(path) + " is not an omgx template file"; return OMGX_E_INVALID;
   }
-  for (int i = 0; i < 13; ++i) if (c[i] < 0 || c[i] > (1 << 26)) { fclose(fp); g_err = "template file: bad counts"; return OMGX_E_INVALID; }
+  for (int i = 0; i < 15; ++i) if (c[i] < 0 || c[i] > (1 << 26)) { fclose(fp); g_err = "template file: bad counts"; return OMGX_E_INVALID; }
   omgx_template* t = (omgx_template*)calloc(1, sizeof(omgx_template));
   if (!t) { fclose(fp); g_err = "out of memory"; return OMGX_E_INVALID; }
   t->n_var = c[0]; t->n_par = c[1]; t->n_con = c[2]; t->n_atoms = c[3]; t->n_slots = c[4]; t->n_terms = c[5]; t->n_prog = c[6];
   t->n_knots = c[7]; t->n_pp = c[8]; t->n_mono = c[9]; t->n_matom = c[10]; t->n_eq = c[11]; t->n_root_vars = c[12];
-  TplField f[16];
+  t->n_blocks = c[13]; t->block_names_len = c[14];
+  TplField f[24];
   const size_t nf = tpl_fields(*t, t, f);
   bool ok = true;
   for (size_t i = 0; i < nf; ++i) {
-    const size_t sz = f[i].kind ? sizeof(double) : sizeof(int32_t);
+    const size_t sz = f[i].kind == 1 ? sizeof(double) : (f[i].kind == 2 ? 1 : sizeof(int32_t));
     *f[i].dst = calloc(f[i].count + 1, sz);                  // (+1: an empty array still gets an address)
     if (!*f[i].dst) { ok = false; continue; }
     if (ok && f[i].count && fread(*f[i].dst, sz, f[i].count, fp) != f[i].count) ok = false;
@@ -889,6 +896,59 @@ int omgx_template_read(const char* path, omgx_template** out) {
   if (rc != OMGX_OK) { omgx_template_free(t); return rc; }
   *out = t;
   return OMGX_OK;
+}
+
+// ---- block table -----------------------------------------------------------------------------------------
+namespace {
+// name of block i (its offset inside block_names), or nullptr when the table is malformed
+const char* block_name(const omgx_template* t, int i) {
+  if (!t->block_names || t->block_names_len <= 0 || t->block_names[t->block_names_len - 1] != 0) return nullptr;
+  const char* p = t->block_names;
+  const char* end = t->block_names + t->block_names_len;
+  for (int k = 0; k < i; ++k) { p += strlen(p) + 1; if (p >= end) return nullptr; }
+  return p < end ? p : nullptr;
+}
+}  // namespace
+
+int omgx_template_n_blocks(const omgx_template* tpl, int32_t kind) {
+  if (!tpl) { g_err = "null template"; return OMGX_E_INVALID; }
+  int n = 0;
+  for (int i = 0; i < tpl->n_blocks; ++i) if (tpl->block_kind[i] == kind) ++n;
+  return n;
+}
+
+int omgx_template_block_at(const omgx_template* tpl, int32_t kind, int32_t i, const char** name, int32_t* off,
+                           int32_t* rows, int32_t* cols) {
+  if (!tpl || i < 0) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  int n = 0;
+  for (int k = 0; k < tpl->n_blocks; ++k) {
+    if (tpl->block_kind[k] != kind) continue;
+    if (n++ == i) {
+      const char* nm = block_name(tpl, k);
+      if (!nm) { g_err = "malformed block table"; return OMGX_E_INVALID; }
+      if (name) *name = nm;
+      if (off) *off = tpl->block_off[k];
+      if (rows) *rows = tpl->block_rows[k];
+      if (cols) *cols = tpl->block_cols[k];
+      return OMGX_OK;
+    }
+  }
+  g_err = "block index out of range"; return OMGX_E_INVALID;
+}
+
+int omgx_template_block(const omgx_template* tpl, int32_t kind, const char* name, int32_t* off, int32_t* rows,
+                        int32_t* cols) {
+  if (!tpl || !name) { g_err = "null argument"; return OMGX_E_INVALID; }
+  for (int k = 0; k < tpl->n_blocks; ++k) {
+    const char* nm = tpl->block_kind[k] == kind ? block_name(tpl, k) : nullptr;
+    if (nm && strcmp(nm, name) == 0) {
+      if (off) *off = tpl->block_off[k];
+      if (rows) *rows = tpl->block_rows[k];
+      if (cols) *cols = tpl->block_cols[k];
+      return OMGX_OK;
+    }
+  }
+  g_err = std::string("the template has no entry named ") + name; return OMGX_E_INVALID;
 }
 
 void omgx_default_options(omgx_options* o) {

@@ -37,7 +37,9 @@ class CTemplate(C.Structure):
                [('prog', _I32P), ('knots', _F64P), ('pp_ptr', _I32P), ('pm_coef', _F64P),
                 ('pm_ptr', _I32P), ('pm_atom', _I32P), ('slot_pp', _I32P),
                 ('row_ptr', _I32P), ('t_coef', _F64P), ('t_slot', _I32P), ('t_var', _I32P)] + \
-               [('n_eq', C.c_int32), ('eq_rows', _I32P), ('n_root_vars', C.c_int32), ('root_vars', _I32P)]
+               [('n_eq', C.c_int32), ('eq_rows', _I32P), ('n_root_vars', C.c_int32), ('root_vars', _I32P)] + \
+               [('n_blocks', C.c_int32), ('block_names_len', C.c_int32), ('block_names', C.c_char_p),
+                ('block_kind', _I32P), ('block_off', _I32P), ('block_rows', _I32P), ('block_cols', _I32P)]
 
 
 class CPlanInfo(C.Structure):
@@ -124,6 +126,17 @@ def make_ctemplate(tpl, plan=None):
     ct.n_eq, ct.eq_rows = len(eq_rows), i32(np.r_[eq_rows, 0])
     root = root_hint_vars(tpl)
     ct.n_root_vars, ct.root_vars = len(root), i32(np.r_[root, 0])
+    # block table: name, kind, offset, shape of every entry of x / p / g, in the reference's struct order
+    # (`basics/optilayer.py:225-272`; the offsets `export/export.py:302-353` hard-codes into the generated C++)
+    names, kinds, offs, rows, cols = [], [], [], [], []
+    for kind, which in enumerate(('var', 'par', 'con')):
+        for label, name, off, r, c in tpl.block_table(which):
+            names.append('%s.%s' % (label, name)); kinds.append(kind); offs.append(off); rows.append(r); cols.append(c)
+    blob = b''.join(n.encode() + b'\0' for n in names)
+    keep.append(blob)
+    ct.n_blocks, ct.block_names_len, ct.block_names = len(names), len(blob), blob
+    ct.block_kind, ct.block_off = i32(np.r_[kinds, 0]), i32(np.r_[offs, 0])
+    ct.block_rows, ct.block_cols = i32(np.r_[rows, 0]), i32(np.r_[cols, 0])
     return ct, keep
 
 

@@ -34,16 +34,17 @@ N_RANDOM = 12
 _STATE = {}
 
 
-def _scenario(n):
+def _scenario(n, name='holonomic_p2p'):
     import omgtools.backend as be
     from omgtools import scenarios
     be.create_nlp = lambda tpl, opt, name='': (None, 0.)
-    return scenarios.holonomic_p2p(n)
+    return getattr(scenarios, name)(n)
 
 
-def _init(n):
+def _init(n, name='holonomic_p2p', bends=None, n_random=None):
     from oracle.nlp_numpy import NumpyNLP
-    problem, P = _scenario(n)
+    problem, P = _scenario(n, name)
+    _STATE.update(bends=BENDS if bends is None else bends, n_random=N_RANDOM if n_random is None else n_random, name=name)
     tpl = problem.father.template
     _STATE.update(tpl=tpl, P=P, nlp=NumpyNLP(tpl), problem=problem)
 
@@ -65,10 +66,10 @@ def bent(tpl, problem, x0, s):
 def starts_of(b):
     tpl, P, problem = _STATE['tpl'], _STATE['P'], _STATE['problem']
     x0 = P['x0'][b]
-    out = [x0] + [bent(tpl, problem, x0, s) for s in BENDS]
+    out = [x0] + [bent(tpl, problem, x0, s) for s in _STATE['bends']]
     rng = np.random.default_rng(9000 + b)
     hyp = [k for k in tpl.var_layout if k[1].startswith('a_')]
-    for _ in range(N_RANDOM):
+    for _ in range(_STATE['n_random']):
         x = x0.copy()
         for key in hyp:
             lo, rows, cols = tpl.var_layout[key]
@@ -84,7 +85,9 @@ def _solve_start(job):
     b, k = job
     tpl, P, nlp = _STATE['tpl'], _STATE['P'], _STATE['nlp']
     t0 = time.time()
-    x, f, ok = solve_slsqp(nlp, tpl, starts_of(b)[k], P['p'][b], maxiter=800)
+    big = _STATE['name'] != 'holonomic_p2p'      # (the larger classes: SLSQP ends with 'positive directional derivative')
+    x, f, ok = solve_slsqp(nlp, tpl, starts_of(b)[k], P['p'][b], maxiter=1500 if big else 800,
+                           accept=(0, 8) if big else (0,), viol_tol=1e-7 if big else 1e-8)
     return b, k, x, f, ok, time.time() - t0
 
 
@@ -112,13 +115,13 @@ def distinct_minima(x_all, f_all, ok_all, lo, hi):
     return x_min, f_min, np.array([len(m) for m in keep], dtype=np.int32), first
 
 
-def run_cfg2(n, workers):
+def run_cfg2(n, workers, name='holonomic_p2p', out='sol_cfg2_ms.npz', bends=BENDS, n_random=N_RANDOM):
     t0 = time.time()
-    n_start = 1 + len(BENDS) + N_RANDOM
+    n_start = 1 + len(bends) + n_random
     jobs = [(b, k) for b in range(n) for k in range(n_start)]
-    with ProcessPoolExecutor(workers, initializer=_init, initargs=(n,)) as ex:
+    with ProcessPoolExecutor(workers, initializer=_init, initargs=(n, name, bends, n_random)) as ex:
         res = list(ex.map(_solve_start, jobs, chunksize=1))
-    _init(n)
+    _init(n, name, bends, n_random)
     tpl, P, problem = _STATE['tpl'], _STATE['P'], _STATE['problem']
     lo, hi = tpl.entry_range(problem.vehicles[0].label, 'splines_seg0', 'var')
     x_all = np.zeros((n, n_start, tpl.n_var)); f_all = np.full((n, n_start), np.nan); ok_all = np.zeros((n, n_start), dtype=bool)
@@ -126,11 +129,11 @@ def run_cfg2(n, workers):
     for b, k, x, f, ok, s in res:
         x_all[b, k], f_all[b, k], ok_all[b, k], secs[b, k] = x, f, ok, s
     x_min, f_min, n_min, first = distinct_minima(x_all, f_all, ok_all, lo, hi)
-    np.savez_compressed(os.path.join(HERE, 'sol_cfg2_ms.npz'), p=P['p'][:n], x0=P['x0'][:n], x_min=x_min, f_min=f_min,
+    np.savez_compressed(os.path.join(HERE, out), p=P['p'][:n], x0=P['x0'][:n], x_min=x_min, f_min=f_min,
                         n_min=n_min, first_start=first, f_all=f_all, ok_all=ok_all, spl=np.array([lo, hi]), n_var=tpl.n_var,
-                        n_con=tpl.n_con, n_par=tpl.n_par, seconds=secs, bends=np.array(BENDS), n_random=N_RANDOM)
-    print('sol_cfg2_ms.npz: %d agents x %d starts, %d converged, %d..%d distinct minima per agent, %.0f s'
-          % (n, n_start, int(ok_all.sum()), n_min.min(), n_min.max(), time.time() - t0))
+                        n_con=tpl.n_con, n_par=tpl.n_par, seconds=secs, bends=np.array(bends), n_random=n_random)
+    print('%s: %d agents x %d starts, %d converged, %d..%d distinct minima per agent, %.0f s'
+          % (out, n, n_start, int(ok_all.sum()), n_min.min(), n_min.max(), time.time() - t0))
 
 
 # ---- warm-started path ------------------------------------------------------------------------------------------
@@ -185,3 +188,7 @@ if __name__ == '__main__':
         run_mpc(8, 12, workers)
     if 'cfg2' in which:
         run_cfg2(64, workers)
+    if 'cfg3' in which:
+        run_cfg2(8, workers, 'quadrotor_p2p', 'sol_cfg3_ms.npz', bends=(1.0, -1.0, 2.5, -2.5), n_random=4)
+    if 'cfg5' in which:
+        run_cfg2(8, workers, 'holonomic3d_p2p', 'sol_cfg5_ms.npz', bends=(1.0, -1.0, 2.5, -2.5), n_random=4)

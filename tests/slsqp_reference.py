@@ -6,7 +6,9 @@ import numpy as np
 from scipy.optimize import minimize
 
 
-def solve_slsqp(nlp, tpl, x0, p, maxiter=400):
+def solve_slsqp(nlp, tpl, x0, p, maxiter=400, accept=(0,), viol_tol=1e-8):
+    """accept: SLSQP exit codes taken as converged (8 = 'positive directional derivative for linesearch' is where it
+    stops on the larger classes once no step improves the objective any more; the feasibility bound still applies)."""
     c = nlp.term_coefs(p)
     eq = tpl.lb == tpl.ub
     ineq = np.isfinite(tpl.ub) & ~eq
@@ -18,4 +20,4 @@ def solve_slsqp(nlp, tpl, x0, p, maxiter=400):
                    method='SLSQP', options={'maxiter': maxiter, 'ftol': 1e-12})
     g = nlp.fg(out.x, c)[1]
     viol = max((g - tpl.ub)[ineq].max(), np.abs(g[eq] - tpl.lb[eq]).max())
-    return out.x, float(out.fun), bool(out.status == 0 and viol < 1e-8)
+    return out.x, float(out.fun), bool(out.status in accept and viol < viol_tol)

@@ -49,6 +49,41 @@ def test_c_program_links_and_reads_the_template(exe, case):
     assert int(got['lds_bytes']) == plan['lds_bytes']
 
 
+def test_block_table_travels_through_the_abi_and_fills_p_by_name(exe, case):
+    """the table (name, offset, rows, cols) of x / p / g -- what the reference's exporter hard-codes into the
+    generated C++ (`export/export.py:302-353`) -- is part of the template and of the template file; the C program lists it
+    and fills p (conditions, obstacles) and the initial guess by entry name like `Point2Point::fillParameterDict`
+    (`Point2Point.cpp:263-294`): the same arrays as the Python scenario builder's."""
+    tpl, P, path, d = case
+    lines = subprocess.check_output([exe, path, 'blocks']).decode().strip().split('\n')
+    got = [(k, n, int(o), int(r), int(c)) for k, n, o, r, c in (ln.split() for ln in lines)]
+    want = [(which, '%s.%s' % (label, name), off, r, c) for which in ('var', 'par', 'con')
+            for label, name, off, r, c in tpl.block_table(which)]
+    assert got == want and len(got) > 20
+    # the documented order of x (`problem.py:45-48`): vehicle splines first, then the problem's g0, g1, then a / b per obstacle
+    xs = [n.split('.')[1] for k, n, o, r, c in got if k == 'var']
+    assert xs[0] == 'splines_seg0' and xs[1:3] == ['g0', 'g1'] and xs[3].startswith('a_') and xs[4].startswith('b_')
+    B = P['p'].shape[0]
+    veh_state = tpl.entry_range([n for k, n, *_ in got if n.endswith('.state0')][0].split('.')[0], 'state0', 'par')[0]
+    cond = str(d / 'cond.bin')
+    obs = [(n.split('.')[0]) for k, n, *_ in got if k == 'par' and n.endswith('.rad')]
+    with open(cond, 'wb') as fp:
+        fp.write(np.array([B, len(obs)], dtype=np.int32).tobytes())
+        for b in range(B):
+            pose = tpl.entry_range([n for k, n, *_ in got if n.endswith('.poseT')][0].split('.')[0], 'poseT', 'par')[0]
+            o_T = [o for k, n, o, r, c in got if k == 'par' and n.endswith('.T')][0]
+            fp.write(np.r_[P['p'][b, veh_state:veh_state + 2], P['p'][b, pose:pose + 2], P['p'][b, o_T]].tobytes())
+            for lab in obs:
+                ox, orad = tpl.entry_range(lab, 'x', 'par')[0], tpl.entry_range(lab, 'rad', 'par')[0]
+                fp.write(np.r_[P['p'][b, ox:ox + 2], P['p'][b, orad]].tobytes())
+    out = str(d / 'filled.bin')
+    subprocess.check_call([exe, path, 'fill', cond, out])
+    raw = np.frombuffer(open(out, 'rb').read())
+    p_c, x_c = raw[:B * tpl.n_par].reshape(B, tpl.n_par), raw[B * tpl.n_par:].reshape(B, tpl.n_var)
+    assert np.array_equal(p_c, P['p'])
+    assert np.abs(x_c - P['x0']).max() < 1e-14
+
+
 def test_template_file_round_trip_and_rejects_garbage(case, tmp_path):
     import ctypes as C
     import omgtools.backend as be
