@@ -165,7 +165,7 @@ def holonomic3d_p2p(n_agents, knot_intervals=15, n_obs=10, seed=20240807 + 5, ho
 
 
 def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0, horizon_time=10.,
-                        with_obstacles=True):
+                        with_obstacles=True, obstacles=None):
     """Config 4: `n_agents` Holonomic vehicles keeping a regular-polygon formation
     (circular interconnection), shape of `examples/formation_holonomic.py:22-57`
     scaled to the fleet size.  Returns (problem, updater, father,
@@ -178,7 +178,10 @@ def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0,
     vehicle.set_terminal_conditions([1., 1.])
     radius = max(0.2, 0.2 * n_agents / (2 * np.pi))
     environment = Environment(room={'shape': Square(2. * radius + 12.)})
-    if with_obstacles:
+    if obstacles is not None:            # [(position, velocity, shape)]: a caller's own environment
+        for pos, vel, shape in obstacles:
+            environment.add_obstacle(Obstacle({'position': list(pos), 'velocity': list(vel)}, shape=shape))
+    elif with_obstacles:
         rect = Rectangle(width=3., height=0.2)
         environment.add_obstacle(Obstacle({'position': [-2.6, -1.0]}, shape=rect))
         environment.add_obstacle(Obstacle({'position': [2.6, -1.0]}, shape=rect))

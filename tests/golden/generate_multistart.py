@@ -57,7 +57,9 @@ def bent(tpl, problem, x0, s):
     c = x0[lo:lo + ns * L].reshape(ns, L)
     d = c[:, -1] - c[:, 0]
     d = d / max(np.linalg.norm(d), 1e-12)
-    nrm = np.array([-d[1], d[0]])
+    nrm = np.zeros(ns)
+    nrm[0], nrm[1] = -d[1], d[0]                     # perpendicular to start -> goal in the x-y plane
+    nrm /= max(np.linalg.norm(nrm), 1e-12)
     out = x0.copy()
     out[lo:lo + ns * L] += (s * nrm[:, None] * (np.sin(np.linspace(0., 1., L) * np.pi) ** 2)[None, :]).reshape(-1)
     return out

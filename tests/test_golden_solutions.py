@@ -24,7 +24,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = [('sol_cfg2_ms.npz', 'holonomic_p2p', 64, 0.95), ('sol_cfg3.npz', 'quadrotor_p2p', 8, 0.6),
+CASES = [('sol_cfg2_ms.npz', 'holonomic_p2p', 64, 0.95), ('sol_cfg3_ms.npz', 'quadrotor_p2p', 8, 0.9),
          ('sol_cfg5.npz', 'holonomic3d_p2p', 8, 0.7)]
 TOL = 1e-6
 
