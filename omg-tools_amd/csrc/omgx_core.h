@@ -1789,14 +1789,21 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   const bool warm = o.warm_start && prev_status == 0;     // callers pass lam0 whenever warm_start is set
   const double kpush = warm ? o.kappa_warm : o.kappa_push;
   // unscaled Jacobian entries (one thread per entry) and row values (one thread per row) at x0 ...
-  OMGX_PFOR(i, d.nnz_j) w.jval[T.ja_list[i]] = jac_entry_ell(T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
+  // (the unscaled entries go to the KKT store, which is idle during the setup, when that is LDS: the row classification
+  // below reads every entry of its row, and with two agents per CU the Jacobian values themselves live in a slab)
+  double* jtmp = (C::hbm || kkt_doubles < d.nnz_j + 1) ? w.jval : w.kkt;
+  OMGX_PFOR(i, d.nnz_j) jtmp[T.ja_list[i]] = jac_entry_ell(T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
   OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell(T, w, i, m, w.x); }
-  if (c.tid() == 0) w.jval[d.nnz_j] = 0.0;               // the slot padding records point at
+  if (c.tid() == 0) { jtmp[d.nnz_j] = 0.0; w.jval[d.nnz_j] = 0.0; }      // the slot padding records point at
   c.sync();
   OMGX_TOC(PH_S_JAC0);
   // ... then one thread per row: classification, gradient-based scale, phase-I weight
+  // (rows in the order of the ELL table of their Jacobian entries, eight entries in flight at a time: with the Jacobian
+  // values in a slab -- two agents per CU -- a row that walks its entries one by one pays a memory round trip each)
   double bad_local = 0.0;
-  OMGX_PFOR(r, m) {
+  OMGX_PFOR(ir, m) {
+    const int r = T.row_perm[ir];
+    const int Lr = T.jp_glen[ir >> 6];
     const double l = lb[r], u = ub[r];
     const bool fl = isfinite(l), fu = isfinite(u);
     int ty = ROW_FREE;
@@ -1808,7 +1815,16 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     if (ty == ROW_BAD) bad_local = 1.0;
     w.rtype[r] = ty;
     double gm = 0.0;
-    for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) gm = fmax(gm, fabs(w.jval[e]));
+    for (int s0 = 0; s0 < Lr; s0 += 8) {
+      int32_t e[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = T.jp_ell[2 * ((s0 + k) * m + ir)];
+      double jv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) jv[k] = jtmp[e[k]];            // (padding: the slot that holds 0.0)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) gm = fmax(gm, fabs(jv[k]));
+    }
     double rho = (o.scale_gmax > 0.0 && gm > o.scale_gmax) ? o.scale_gmax / gm : 1.0;
     const double sg = (ty == ROW_LOWER) ? -1.0 : 1.0;
     w.rho[r] = sg * rho;                                  // signed scale: h = rho*(g - bound)
@@ -1820,12 +1836,15 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     if (ty == ROW_UPPER || ty == ROW_LOWER) v = fmax(h + kpush, 0.0);
     else if (ty == ROW_EQ) v = h;
     w.vv[r] = v;
-    // the Jacobian the first iteration needs is this one with the rows scaled (plus the objective row,
-    // below): no second pass over the constraint terms at x0; the row's entries are in flight anyway
-    const double sc = (ty == ROW_FREE) ? 0.0 : w.rho[r];
-    for (int e = T.jr_ptr[r]; e < T.jr_ptr[r + 1]; ++e) w.jval[e] *= sc;
   }
   if (c.rmax(bad_local) > 0.0) { res.status = 3; return res; }
+  // the Jacobian the first iteration needs is this one with the rows scaled (the objective row as it is): one thread per
+  // entry, no second pass over the constraint terms at x0
+  OMGX_PFOR_U4(e, d.nnz_j) {
+    const int r = d.rp_packed ? (int)((uint32_t)T.je_rp[e] >> 16) : T.je_row[e];
+    const double sc = (r < m) ? ((w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r]) : 1.0;
+    w.jval[e] = jtmp[e] * sc;
+  }
   OMGX_TOC(PH_S_CLASS);
   double any_local = 0.0;
   OMGX_PFOR(r, m) if (w.vv[r] != 0.0) any_local = 1.0;

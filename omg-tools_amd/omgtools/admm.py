@@ -72,7 +72,8 @@ class BatchADMM(object):
         self.nesterov, self.nesterov_reset, self.eta, self.AMA = bool(nesterov_acceleration), bool(nesterov_reset), float(eta), bool(AMA)
         self._mcache = {}
         self.iteration = 0
-        self._res = []                     # per iteration: backend array [3] = (pr^2 sum, dr^2 sum, cr sum)
+        self._res = []                     # per iteration: backend array [3] = (pr^2 sum, dr^2 sum, cr sum), not fetched yet
+        self._res_host, self.history_cap = [], 100000      # fetched rows (the newest `history_cap` are kept)
         if hasattr(ops, 'bind'):
             ops.bind(self.halo, self.slot)
 
@@ -146,9 +147,14 @@ class BatchADMM(object):
     def residuals(self):
         """[(primal, dual, combined)] per iteration (`admm.py:601-605, 624-627`); one host copy."""
         if not self._res:
-            return []
+            return list(self._res_host)
+        # only the rows that were not fetched yet travel to the host; the device-side handles are dropped afterwards
         arr = self.ops.to_host_stack(self._res)
-        return [(float(np.sqrt(r[0])), float(np.sqrt(r[1])), float(r[2])) for r in arr]
+        self._res_host += [(float(np.sqrt(r[0])), float(np.sqrt(r[1])), float(r[2])) for r in arr]
+        self._res = []
+        if len(self._res_host) > self.history_cap:
+            del self._res_host[:len(self._res_host) - self.history_cap]
+        return list(self._res_host)
 
 
 class FormationMPC(object):
@@ -309,6 +315,7 @@ class HipAdmmOps(object):
         # in a fixed order); every update gets its own row, BatchADMM keeps them as the residual history
         if self._sum_k % 1024 == 0:
             self._sum_blocks.append(t.zeros((1024, 3), dtype=t.float64, device=self.dev))
+            self._sum_blocks = self._sum_blocks[-1:]      # (rows of older blocks stay alive through the views BatchADMM holds until they are fetched)
         self._sums = self._sum_blocks[-1][self._sum_k % 1024]
         self._sum_k += 1
         self._chk(self.solver.lib.omgx_admm_update_sums(
@@ -429,11 +436,14 @@ class HipAdmmOps(object):
         """One all_gather: every rank sends the rows other ranks need (+ one row carrying `extra`, whose sum
         over the ranks is returned).  -> ([B_local + halo, w], summed extra or None)."""
         t = self.torch
-        w = local.shape[1]
+        wl = local.shape[1]
+        # (the row that carries `extra` needs extra.numel() columns: a RendezVous fleet with one shared number and one
+        # neighbour exchanges rows of two)
+        w = max(wl, extra.numel()) if extra is not None else wl
         rows = halo.max_pub + (1 if extra is not None else 0)
         send = t.zeros((rows, w), dtype=local.dtype, device=local.device)
         if len(halo.publish_local):
-            send[:len(halo.publish_local)] = local[self._pub]
+            send[:len(halo.publish_local), :wl] = local[self._pub]
         if extra is not None:
             send[halo.max_pub, :extra.numel()] = extra
         # (concatenated form [world * rows, w]: accepted by every backend; viewed as [world, rows, w] afterwards)
@@ -441,5 +451,5 @@ class HipAdmmOps(object):
         dist.all_gather_into_tensor(flat, send)
         allp = flat.view(halo.world, rows, w)
         summed = allp[:, halo.max_pub, :extra.numel()].sum(dim=0) if extra is not None else None
-        out = t.cat([local, allp[self._src[:, 0], self._src[:, 1]]], dim=0) if len(halo.needed) else local
+        out = t.cat([local, allp[self._src[:, 0], self._src[:, 1], :wl]], dim=0) if len(halo.needed) else local
         return out, summed

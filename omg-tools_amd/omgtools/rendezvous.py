@@ -142,6 +142,13 @@ class RendezVous(FormationPoint2point):
         FormationPoint2point.__init__(self, fleet, environment, opts, ops=ops)
 
     def _build_template(self, vehicle, environment, n_nghb, options):
+        # the reference frees the end point in the dimensions the fleet configuration names
+        # (`rendezvous.py:30-47`: free_ind = configuration[veh].keys()); this path shares one x-update template and one
+        # consensus layout of n_dim numbers: a configuration on a subset of the dimensions is refused, not widened
+        keys = sorted(self.fleet.configuration[vehicle].keys())
+        if keys != list(range(vehicle.n_dim)):
+            raise NotImplementedError('RendezVous: the fleet configuration must cover all %d dimensions of the vehicle '
+                                      '(got %s)' % (vehicle.n_dim, keys))
         return build_rendezvous_template(vehicle, environment, n_nghb, options)
 
     def _make_layout(self, tpl, vehicle, problem, updater, n_nghb):
@@ -150,8 +157,6 @@ class RendezVous(FormationPoint2point):
     def stop_criterium(self, current_time, update_time):
         """`rendezvous.py:69-85`: the vehicles have met when their positions differ by the configured offsets
         (summed squared deviation over all neighbour pairs below (5e-2)^2)."""
-        if self.options['max_iter'] and self.iteration > self.options['max_iter']:
-            return True
         res = 0.
         config = self.fleet.configuration
         for veh in self.vehicles:

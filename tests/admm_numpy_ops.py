@@ -114,18 +114,19 @@ class NumpyAdmmOps(object):
 
     def exchange(self, local, halo, dist, extra=None):
         import torch
-        w = local.shape[1]
+        wl = local.shape[1]
+        w = max(wl, len(extra)) if extra is not None else wl
         rows = halo.max_pub + (1 if extra is not None else 0)
         send = torch.zeros((rows, w), dtype=torch.float64)
         if len(halo.publish_local):
-            send[:len(halo.publish_local)] = torch.from_numpy(local[halo.publish_local])
+            send[:len(halo.publish_local), :wl] = torch.from_numpy(local[halo.publish_local])
         if extra is not None:
             send[halo.max_pub, :len(extra)] = torch.from_numpy(np.asarray(extra, float))
         gathered = [torch.empty_like(send) for _ in range(halo.world)]
         dist.all_gather(gathered, send)
         allp = torch.stack(gathered).numpy()
         summed = allp[:, halo.max_pub, :len(extra)].sum(axis=0) if extra is not None else None
-        out = np.concatenate([local, allp[halo.src[:, 0], halo.src[:, 1]]], axis=0) if len(halo.needed) else local
+        out = np.concatenate([local, allp[halo.src[:, 0], halo.src[:, 1], :wl]], axis=0) if len(halo.needed) else local
         return out, summed
 
     def allreduce(self, sums, dist):

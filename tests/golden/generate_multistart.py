@@ -193,4 +193,4 @@ if __name__ == '__main__':
     if 'cfg3' in which:
         run_cfg2(8, workers, 'quadrotor_p2p', 'sol_cfg3_ms.npz', bends=(1.0, -1.0, 2.5, -2.5), n_random=4)
     if 'cfg5' in which:
-        run_cfg2(8, workers, 'holonomic3d_p2p', 'sol_cfg5_ms.npz', bends=(1.0, -1.0, 2.5, -2.5), n_random=4)
+        run_cfg2(8, workers, 'holonomic3d_p2p', 'sol_cfg5_ms.npz', bends=(1.0, -1.0, 2.5, -2.5), n_random=20)
