@@ -31,6 +31,28 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X datasheet FP64 matrix (MFMA f64) pea
 HBM_PEAK_GBPS = 8000.0             # MI355X HBM3E (MI355X_MICROARCH.md)
 
 
+def executed_flops_per_iter(tpl):
+    """Flops one interior-point iteration of the structured solver actually executes on the linear algebra (SURVEY.md 8d
+    asks for them next to the dense-n figure): per hyperplane leaf the banded LDL' (n B (B + 1)), the forward substitution of
+    its carried rows (coupling rows + right-hand side, n (2 B + 1) each), its Schur complement W D^-1 W' (symmetric, 2 n per
+    entry); the root block nr^3 / 3; the substitutions; three flops per Jacobian pair of J' Sigma J.  One factorisation
+    attempt per iteration (the inertia correction adds about 0.3 on cold solves).  From `omgx_plan_describe`."""
+    from omgtools.backend import describe_plan
+    pl = describe_plan(tpl)
+    nr = pl['n_root'] + pl['n_eq']
+    fl = nr ** 3 / 3.0 + 2.0 * nr ** 2
+    for n, bw, nc in zip(pl['leaf_sizes'], pl['leaf_bw'], pl['leaf_cpl']):
+        B = min(bw, n - 1)
+        if B == 0:                                      # diagonal leaf: a division and a few products per coupling entry
+            fl += n * (4 + 2 * 3)
+            continue
+        rows = nc + 1
+        fl += n * B * (B + 1) + rows * n * (2 * B + 1) + (rows * (rows + 1) // 2) * 2 * n + rows * n
+        fl += 2 * nc * n + 2 * n * B                    # leaf substitutions
+    fl += 3.0 * pl['n_pairs']
+    return fl
+
+
 def sample_roofline(torch, tpl, veh, dev, n_agents, horizon_time, reps=20):
     """Second roofline of SURVEY 8d: post-solve trajectory sampling (A11, `sample_kernel`) against HBM
     bandwidth.  Algorithmic bytes per agent = 8 n_spl L (coefficients in) + 8 n_der n_spl n_samp (samples
@@ -77,7 +99,7 @@ def measured_traffic(n_agents):
     other batch sizes.  Counter unit KB; FETCH_SIZE doubled: on gfx950 rocprofv3 reports half the bytes of wide
     coalesced reads (MI355X_MICROARCH.md, HBM section) -- the table records are 16-byte-per-lane loads -- so this is
     an upper bound for the mixed access widths of this kernel; WRITE_SIZE as reported."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm.json')
+    path = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm.json')          # (collected by tools/run_profiles.sh with this round's kernel)
     if n_agents != 1024 or not os.path.exists(path):
         return None
     d = json.load(open(path))
@@ -179,6 +201,38 @@ def latency_episodes(mpc, x0_init, p_init, n_ep, n_steps, host):
     return {'samples': len(ms), 'p50_ms': float(np.median(ms)), 'p90_ms': float(np.percentile(ms, 90)),
             'max_ms': float(np.max(ms)), 'mean_ms': float(np.mean(ms)), 'solves_per_s': ok / (sum(ms) * 1e-3),
             'solved_fraction': ok / float(len(ms) * B)}
+
+
+def store_leg(mpc, problem, tpl, x0_init, p_init, n_steps, dev):
+    """The same receding-horizon steps with `Vehicle.store` fused behind the solve (`omgx_batch_set_store`, A11:
+    state, input, dinput and v_tot of every agent on its 1001-point sample grid, written by the solve kernel straight
+    from the solution): wall time per step between barriers, against the same steps without it."""
+    veh = problem.vehicles[0]
+    T = float(problem.options['horizon_time'])
+    B, nd, n_samp, sample_time = mpc.B, veh.n_dim, 1001, 0.01
+    lo = tpl.entry_range(veh.label, 'splines_seg0', 'var')[0]
+    f64 = dict(dtype=torch.float64, device=dev)
+    out, vt, t0 = torch.zeros((B, 3, nd, n_samp), **f64), torch.zeros((B, n_samp), **f64), torch.zeros(B, **f64)
+    res = {}
+    for name in ('plain', 'with_store'):
+        mpc.x.copy_(x0_init); mpc.p.copy_(p_init); mpc.time = 0.0
+        mpc.solve_cold()
+        if name == 'with_store':
+            mpc.solver.set_store(out, vt, t0, lo, nd, veh.degree, veh.basis.knots, 3, n_samp, sample_time / T, 1.0 / T)
+        for _ in range(3):
+            mpc.step()
+        torch.cuda.synchronize()
+        t_0 = time.perf_counter()
+        for _ in range(n_steps):
+            mpc.step()
+        torch.cuda.synchronize()
+        res[name] = (time.perf_counter() - t_0) / n_steps * 1e3
+        ok = int((mpc.status == 0).sum().item())
+        mpc.solver.set_store(None)
+    bytes_out = out.numel() * 8 + vt.numel() * 8
+    return {'ms_per_step_plain': res['plain'], 'ms_per_step_with_store': res['with_store'],
+            'store_MB_per_step': bytes_out / 1e6, 'solves_per_s_with_store': ok / (res['with_store'] * 1e-3),
+            'note': 'state / input / dinput / v_tot of every agent on 1001 samples, written by the solve kernel (A11 fused)'}
 
 
 def unedited_rule(args, dev, seed):
@@ -362,7 +416,9 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
         'roofline': {'bound': 'mfma', 'kernel': 'ipm_solve_kernel', 'achieved': flops / (k_ms * 1e-3) / 1e12,
                      'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': flops / (k_ms * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 'traffic': None,
-                     'kernel_ms': k_ms, 'note': 'iterations of the final pass of every agent; time = the whole cold step'}}))
+                     'kernel_ms': k_ms, 'note': 'iterations of the final pass of every agent; time = the whole cold step',
+                     'executed_flops_per_iter': executed_flops_per_iter(tpl), 'dense_n_flops_per_iter': tpl.n_var ** 3 / 3.0 + 2.0 * tpl.n_var ** 2,
+                     'executed_TFLOPs': it_sum * executed_flops_per_iter(tpl) / (k_ms * 1e-3) / 1e12}}))
 
 
 def main():
@@ -486,6 +542,7 @@ def main():
     n = tpl.n_var
     flops_per_iter = n ** 3 / 3.0 + 2.0 * n ** 2          # dense-n LDL' + 2 solves
     achieved = (it_sum / n_meas) * flops_per_iter / (k_ms * 1e-3) / 1e12
+    exec_flops = executed_flops_per_iter(tpl)
     cold_k = float(np.mean(cold_ms))
     out = {
         'metric': 'MPC solves/sec, 1024-agent Holonomic Point2point batch per GPU',
@@ -518,6 +575,8 @@ def main():
                      'peak': FP64_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / FP64_MATRIX_PEAK_TFLOPS, 'traffic': measured_traffic(B),
                      'kernel_ms': k_ms,
+                     'executed_flops_per_iter': exec_flops, 'dense_n_flops_per_iter': flops_per_iter,
+                     'executed_TFLOPs': (it_sum / n_meas) * exec_flops / (k_ms * 1e-3) / 1e12,
                      'all_launches': {'n': len(launches_ms), 'mean_ms': float(np.mean(launches_ms)),
                                       'achieved': launches_iters * flops_per_iter / (sum(launches_ms) * 1e-3) / 1e12},
                      'note': 'algorithmic flops = sum(iters) x (n^3/3+2n^2), n=n_var (SURVEY 8d); achieved/kernel_ms '
@@ -529,6 +588,7 @@ def main():
         out['latency_resident'] = latency_episodes(mpc, x0_init, p_init, 5, 40, host=False)
         out['latency_host_boundary'] = latency_episodes(mpc, x0_init, p_init, 5, 40, host=True)
         out['survey_8d_obstacle_rule'] = unedited_rule(args, dev, 20240807 + 2)
+        out['trajectory_store_fused'] = store_leg(mpc, problem, tpl, x0_init, p_init, 20, dev)
     if world == 1:
         # trajectory extraction (A11) against the HBM roofline, at the workload's batch and at 16x (the
         # 49 MB of one 1024-agent launch last ~10 us: launch-latency bound)

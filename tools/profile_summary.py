@@ -43,7 +43,7 @@ def main():
     json.dump({'FETCH_SIZE': fetch, 'WRITE_SIZE': write, 'hbm_bytes_per_launch': hbm,
                'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes '
                        '(python bench.py --no-cpu --no-extras --steps 5 --warmup 1: 4 cold solves + 6 receding-horizon '
-                       'steps), kernel ipm_solve_kernel<0, true>, 1024 agents; counter unit KB; mean over those launches.'},
+                       'steps), kernel ipm_solve_kernel (the instance of the workspace mode, see VGPR / LDS / workgroup columns), 1024 agents; counter unit KB; mean over those launches.'},
               open(os.path.join(out, '%s_pmc_hbm.json' % tag), 'w'), indent=1)
     # further counter passes: mean per launch of every counter, cold launches (the first 4) and warm ones apart
     def multi(sub, names):
@@ -69,6 +69,14 @@ def main():
         lw['bank_conflict_over_lds_active_' + k[5:]] = lw['SQ_LDS_BANK_CONFLICT'][k] / max(1.0, lw['SQ_LDS_IDX_ACTIVE'][k])
     lw['note'] = 'two separate rocprofv3 --pmc passes (LDS counters; wave wait / issue split), same command as the MFMA pass'
     json.dump(lw, open(os.path.join(out, '%s_pmc_lds_wait.json' % tag), 'w'), indent=1)
+    try:
+        oc = multi('occ', ['GRBM_GUI_ACTIVE', 'SQ_WAVES', 'SQ_BUSY_CYCLES'])
+        oc['note'] = ('rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES, same command: SQ_WAVES = waves launched per kernel '
+                      '(persistent workgroups: grid x waves per workgroup); the launch geometry (workgroup size, LDS, VGPR) is in '
+                      'the pmc_hbm file')
+        json.dump(oc, open(os.path.join(out, '%s_pmc_occupancy.json' % tag), 'w'), indent=1)
+    except SystemExit:
+        pass
     print('kernel stats:', rows[1][0][:40], rows[1][1:4])
     print('HBM bytes / launch:', hbm)
     print('MFMA busy / CU busy: cold %.3f warm %.3f' % (mf['mfma_busy_over_cu_busy_cold'], mf['mfma_busy_over_cu_busy_warm']))
