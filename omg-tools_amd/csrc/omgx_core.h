@@ -186,6 +186,15 @@ struct Opts {
 #ifndef OMGX_DW_BACKOFF_MAX
 #define OMGX_DW_BACKOFF_MAX 8
 #endif
+#ifndef OMGX_EXPAND_MAX
+#define OMGX_EXPAND_MAX   16.0    // longest multiple of a regularised Newton step the line search offers
+#endif
+#ifndef OMGX_EXPAND_DW
+#define OMGX_EXPAND_DW    1e-2    // ... when the inertia correction is at least this heavy
+#endif
+#ifndef OMGX_EXPAND_FROM
+#define OMGX_EXPAND_FROM  2       // ... after this many iterations in a row that accepted their full step at the first trial
+#endif
 #define OMGX_LS_RETRY    3       // line-search failures in a row that are answered by a heavier inertia correction
 #define OMGX_LS_RETRY_DW 100.0
 #define OMGX_DW_CAP_FLOOR 0.03  // share of dw every nonlinear variable keeps under the Gershgorin cap
@@ -198,6 +207,9 @@ struct Opts {
 #define OMGX_STALL_ITERS 20
 #endif
 #define OMGX_WARM_ZMIN   1e-8
+#ifndef OMGX_WARM_ZREL
+#define OMGX_WARM_ZREL   0.1     // multipliers handed to a warm start are lifted to OMGX_WARM_ZREL * tol (IPOPT: warm_start_mult_bound_push)
+#endif
 #define OMGX_MAX_LEAF    16
 #define OMGX_BMAT_DOUBLES 5      // sizeof(BMat) / 8
 #define OMGX_PAN_LD 5      // panel buffer row stride: U[4] + pad (odd: conflict-free row-per-lane access)
@@ -1864,7 +1876,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     OMGX_PFOR(r, m) {
       const int ty = w.rtype[r];
       if (ty == ROW_UPPER || ty == ROW_LOWER) {
-        w.z[r] = fmax(w.ds[r] / w.rho[r], OMGX_WARM_ZMIN);
+        // (a row with a small slack AND a vanishing multiplier is invisible to the Newton system -- Sigma = z / s -- until the
+        // step runs into it: hundreds of iterations with step lengths of 1e-2 on a knot-crossing x-update; the floor keeps
+        // such rows in the picture)
+        w.z[r] = fmax(w.ds[r] / w.rho[r], fmax(OMGX_WARM_ZMIN, OMGX_WARM_ZREL * o.tol));
         sz += row_slack(w, r, t) * w.z[r]; cnt0 += 1.0;
       } else if (ty == ROW_EQ) {
         w.z[r] = w.ds[r] / w.rho[r];
@@ -1890,7 +1905,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // cold starts may damp the leaf (hyperplane) variables less and the root (trajectory) variables more
   // than dw (same product: the same bilinear negative curvature is covered); warm starts use dw on both
     const double reg_leaf = warm ? 1.0 : o.dw_leaf_ratio_cold, reg_root = warm ? 1.0 : 1.0 / o.dw_leaf_ratio_cold;
-  int it = 0, status = 1, ls_fail = 0;
+  int it = 0, status = 1, ls_fail = 0, full_steps = 0;
 #ifdef OMGX_EXP_COLD_NU
   const double nu_stall_max = OMGX_EXP_COLD_NU;
 #else
@@ -2267,7 +2282,8 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     if (!use_t && c.tid() == 0) w.sol[N - 1] = 0.0;
     c.sync();
     const double dt = w.sol[N - 1];
-    double ap_l = 1.0, ad_l = 1.0, ymax = 0.0, gdx = 0.0, ysum = 0.0;
+    // (the primal boundary step is collected up to OMGX_EXPAND_MAX: a heavily regularised step may be lengthened, below)
+    double ap_l = OMGX_EXPAND_MAX, ad_l = 1.0, ymax = 0.0, gdx = 0.0, ysum = 0.0;
     const double tau = fmax(OMGX_TAU_MIN, 1.0 - mu);
     OMGX_PFOR(ir, m) {
       const int r = T.row_perm[ir];
@@ -2323,8 +2339,22 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 
     OMGX_TOC(PH_STEP);
     // ---- Armijo backtracking on the barrier function, iterate stays strictly feasible ----
-    double alpha = a_p, ft = f, tt = t; int ok = 0;
+    // A step of the regularised system (inertia correction dw > 0) is a proximal step: in the directions the Lagrangian
+    // Hessian leaves flat -- hyperplanes that may slide along an inactive face, the released leading coefficient -- it
+    // moves by (gradient / dw) only, and a solve near its solution crawls towards the tolerance at 1 % per iteration (observed:
+    // 112 iterations at dw = 29 on a knot-crossing step, err 3e-3 -> 1e-3).  Such a step is offered LONGER first: the
+    // largest power of two times the Newton step that the boundary allows, up to OMGX_EXPAND_MAX, then the usual halving;
+    // the Armijo test on the barrier function decides.  Only in that regime: after OMGX_EXPAND_FROM iterations in a row
+    // whose full step was accepted at once; undamped Newton steps (dw = 0) are never lengthened.
+    const double a_bnd = a_p;
+    a_p = fmin(a_bnd, 1.0);
     const bool phi_noise = fabs(a_p * dphi) <= OMGX_PHI_NOISE * (1.0 + fabs(phi0));
+    if (!phi_noise && dw_last > OMGX_EXPAND_DW && full_steps >= OMGX_EXPAND_FROM) {
+      double ex = 1.0;
+      while (2.0 * ex <= a_bnd && 2.0 * ex <= OMGX_EXPAND_MAX) ex *= 2.0;
+      a_p = fmin(a_bnd, ex);
+    }
+    double alpha = a_p, ft = f, tt = t; int ok = 0;
     for (int bt = 0; bt < OMGX_MAX_BACKTRACK; ++bt) {
       OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + alpha * w.sol[q]; }
       c.sync();
@@ -2388,6 +2418,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       status = 4; break;
     }
     ls_fail = 0;
+    full_steps = (alpha >= 1.0 && alpha == a_p) ? full_steps + 1 : 0;      // (accepted at the first trial, not cut by the boundary)
     // ---- accept --------------------------------------------------------------------
     c.sync();
     OMGX_PFOR(q, N) w.x[q] = w.xt[q];
@@ -2408,7 +2439,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         w.z[r] = zn;
       } else if (ty == ROW_EQ) {
         const double yn = w.sol[N + T.eq_index[r]];
-        w.z[r] = w.z[r] + alpha * (yn - w.z[r]);
+        w.z[r] = w.z[r] + fmin(alpha, 1.0) * (yn - w.z[r]);      // (a lengthened primal step: the multipliers take the Newton step)
       }
     }
     if (use_t) {

@@ -25,8 +25,9 @@ DEFAULTS = dict(dw_cap_floor=0.03, tol=1e-8, max_iter=200, mu_init=0.1, kappa_ep
                 theta_mu=1.5, tau_min=0.99, s_push=1.0, delta_c=1e-8, eta=1e-4,
                 rho=0.1, dw_first=1e-4, dw_inc=10.0, dw_dec=1. / 3., dw_max=1e10, dw_zero=1e-9, dw_heavy=10.0, kappa_eps_heavy=100.0,
                 s_max=100.0, kappa_sigma=1e10, max_backtrack=25, max_soc=2,
-                slack_reset=True, kappa_push=1.0, stall_iters=20, warm_zmin=1e-8, nu_init=100.0, nu_max=1e8, e_push=1.0, scale_gmax=100.0, s_phi=2.3, s_theta=1.1, delta_sw=1.0,
-                gamma_theta=1e-5, gamma_phi=1e-5, filter_size=8, warm_mu_factor=1.0)
+                slack_reset=True, kappa_push=1.0, stall_iters=20, warm_zmin=1e-8, warm_zrel=0.1, nu_init=100.0, nu_max=1e8, e_push=1.0, scale_gmax=100.0, s_phi=2.3, s_theta=1.1, delta_sw=1.0,
+                gamma_theta=1e-5, gamma_phi=1e-5, filter_size=8, warm_mu_factor=1.0,
+                expand_max=16.0, expand_dw=1e-2, expand_from=2)
 
 STATUS = {0: 'Solve_Succeeded', 1: 'Maximum_Iterations_Exceeded',
           2: 'Infeasible_Problem_Detected', 3: 'Unsupported_Bounds',
@@ -301,7 +302,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         # primal-dual warm start: multipliers of the previous solve (unscaled lam_g),
         # barrier parameter from the average complementarity
         lam0 = np.asarray(z0, float) / rho
-        z = np.maximum(sig * lam0[iH], o['warm_zmin'])
+        z = np.maximum(sig * lam0[iH], max(o['warm_zmin'], o['warm_zrel'] * o['tol']))
         y = lam0[iE].copy()
         mu = float(min(o['mu_init'], max(o['tol'] / 10., o['warm_mu_factor'] * (s * z).mean())))
     # multiplier of t >= 0: dual feasible in t (nu - v'z - c0'y - zt = 0) rather than on the central
@@ -310,7 +311,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
     dw_last = 0.0
     dw_hold, dw_backoff = 0, 1
     status, it, nfact = 1, 0, 0
-    ls_fail = 0
+    ls_fail, full_steps = 0, 0
     N = n + 1                      # (x, t)
     t_check = t
     # inertia correction acts on the variables that appear in a nonlinear term only: the rows
@@ -330,9 +331,9 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         is_leaf[np.asarray(getattr(nlp, 'leaf_vars', []), dtype=np.int64)] = True
         reg = np.where(nl, np.where(is_leaf, ratio, 1.0 / ratio), reg)
 
-    def ftb(vv, dv, tau_):
+    def ftb(vv, dv, tau_, cap=1.0):
         neg = dv < 0
-        return min(1.0, (-tau_ * vv[neg] / dv[neg]).min()) if neg.any() else 1.0
+        return min(cap, (-tau_ * vv[neg] / dv[neg]).min()) if neg.any() else cap
 
     for it in range(o['max_iter'] + 1):
         J = nlp.jac(x, c)
@@ -504,7 +505,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         dt = dxt[n]
         dzt = (mu / t - zt - (zt / t) * dt) if use_t else 0.0
         tau = max(o['tau_min'], 1.0 - mu)
-        a_p = ftb(s, ds, tau)
+        a_p = ftb(s, ds, tau, o['expand_max'])            # (the boundary step up to expand_max: omgx_core.h OMGX_EXPAND_MAX)
         a_d = ftb(z, dz, tau)
         if use_t:
             if dt < 0:
@@ -516,8 +517,16 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         phi0 = f + nu * t - mu * np.log(s).sum() - (mu * np.log(t) if use_t else 0.0) + nuE * thE
         # (quasi-definite system: the linearised equality residual after the full step is delta_c * y_new)
         dphi = g_bar @ dxt - nuE * max(0.0, thE - o['delta_c'] * (np.abs(y_new).sum() if mE else 0.0))
-        alpha, ok = a_p, False
+        # a step of the regularised system may be offered longer (omgx_core.h: the crawl of the proximal iteration)
+        a_bnd = a_p
+        a_p = min(a_bnd, 1.0)
         phi_noise = abs(a_p * dphi) <= o.get('phi_noise', 1e-10) * (1.0 + abs(phi0))      # (omgx_core.h OMGX_PHI_NOISE)
+        if not phi_noise and dw_last > o['expand_dw'] and full_steps >= o['expand_from']:
+            ex = 1.0
+            while 2.0 * ex <= a_bnd and 2.0 * ex <= o['expand_max']:
+                ex *= 2.0
+            a_p = min(a_bnd, ex)
+        alpha, ok = a_p, False
         for bt in range(o['max_backtrack']):
             xt = x + alpha * dxt[:n]
             tt = t + alpha * dt
@@ -542,6 +551,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             status = 4
             break
         ls_fail = 0
+        full_steps = full_steps + 1 if (alpha >= 1.0 and alpha == a_p) else 0
         x, t, s, f, h, cE = xt, tt, st, ft, ht, cEt
         if z0 is not None:
             # component-wise dual step: every multiplier takes its full Newton step, clipped at the
@@ -552,7 +562,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         else:
             z = z + a_d * dz
             zt = zt + a_d * dzt
-        y = y + alpha * (y_new - y)
+        y = y + min(alpha, 1.0) * (y_new - y)
         z = np.minimum(np.maximum(z, mu / (o['kappa_sigma'] * s)), o['kappa_sigma'] * mu / s)
         if use_t:
             zt = min(max(zt, mu / (o['kappa_sigma'] * t)), o['kappa_sigma'] * mu / t)
