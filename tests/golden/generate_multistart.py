@@ -10,13 +10,17 @@ kernel nor its numpy mirror (oracle/ipm_numpy.py) chooses a basin or a starting 
                     degenerate all-zero normals the first step of any method decides the side).  Every converged
                     start is stored (`x_all`, `f_all`, `ok_all`): the product, started from the reference's guess,
                     must land in one of these minima.
+  sol_cfg3_ms.npz   8 agents of the Quadrotor class (K = 13, 5 moving circles), 9 starts each (guess, four bends, four
+                    random hyperplane directions); SLSQP stops on these sizes with exit code 8 ('positive directional
+                    derivative': no step improves the objective any more), accepted with the feasibility bound 1e-7.
+  sol_cfg5_ms.npz   8 agents of the Holonomic3D class (K = 15, 10 spheres), 25 starts each.
   sol_mpc_cfg2.npz  the warm-started path: 8 agents, 12 receding-horizon steps (one knot crossing) of the protocol of
                     bench.py run on the host (oracle port as the solver object); the inputs of every step -- p_k, the
                     shifted plan x0_k, the shifted multipliers lam_k -- are dumped, and the NLP of every step is
                     solved by SLSQP from x0_k.  A warm-started product solve from the dumped inputs must return
                     SLSQP's solution.
 
-Run from the repository root:  python tests/golden/generate_multistart.py [cfg2] [mpc]   (about 25 minutes on 8 cores)"""
+Run from the repository root:  python tests/golden/generate_multistart.py [cfg2] [cfg3] [cfg5] [mpc]   (cfg2 5 min, cfg3 7 min, cfg5 30 min on 7 cores)"""
 import os
 import sys
 import time

@@ -12,9 +12,15 @@ are unobtainable here; the stand-ins:
   than the best stored minimum by more than 1e-3 (1 + |f|), and every returned point must satisfy the optimality
   conditions of the reference's NLP.
 
-  Quadrotor and Holonomic3D classes (sol_cfg3.npz, sol_cfg5.npz, generator generate_solutions.py): 8 agents each, the
-  dense numpy interior point + SLSQP polish (SLSQP from scratch needs hours at these sizes): same criteria against the
-  one stored solution per agent, another local minimum accepted if it is not worse by more than 0.25 (1 + |f|).
+  Quadrotor class (sol_cfg3_ms.npz, same generator): 8 agents, 9 starting points each, 2-4 distinct minima per agent;
+  same criteria -- 8 of 8 agents land in a stored minimum, coefficients to 1e-4.
+
+  Holonomic3D class (sol_cfg5_ms.npz): 8 agents, 25 starting points each (ten spheres in 3-D: many ways round), 1-4
+  distinct minima per agent.  6 of 8 agents land in a stored minimum (coefficients to 3e-5); the other two end in
+  local minima that none of the 25 SLSQP starts visits -- one 0.9 % above the best stored minimum, one 19 % above it (a
+  longer way round an obstacle; every SLSQP start finds the shorter one): KKT points of the reference's NLP, not the best
+  ones.  For this class a point outside the stored set is accepted when it is not worse than the best stored minimum
+  by more than 0.25 (1 + |f|), and at least 70 % of the agents must be inside.
 
 CPU tier: host build of the kernel source (same-source check of the host logic); GPU tier: the HIP path
 through the C ABI."""
@@ -25,7 +31,8 @@ import pytest
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CASES = [('sol_cfg2_ms.npz', 'holonomic_p2p', 64, 0.95), ('sol_cfg3_ms.npz', 'quadrotor_p2p', 8, 0.9),
-         ('sol_cfg5.npz', 'holonomic3d_p2p', 8, 0.7)]
+         ('sol_cfg5_ms.npz', 'holonomic3d_p2p', 8, 0.7)]
+ESCAPE = {'sol_cfg5_ms.npz': 0.25}          # how much worse than the best stored minimum a point outside the set may be
 TOL = 1e-6
 
 
@@ -66,7 +73,7 @@ def check_case(fixture, scenario, n, min_match, solve):
                 matched += 1
             else:
                 best = np.nanmin(d['f_min'][b])
-                assert f < best + 1e-3 * (1 + abs(best)), (fixture, b, f, best)
+                assert f < best + ESCAPE.get(fixture, 1e-3) * (1 + abs(best)), (fixture, b, f, best)
         assert matched >= min_match * n, (fixture, matched, n)
         assert tight >= 0.85 * matched, (fixture, tight, matched)
         return matched, n
