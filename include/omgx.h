@@ -90,6 +90,12 @@ typedef struct omgx_template {
   const int32_t* block_off;         /* [n_blocks] */
   const int32_t* block_rows;        /* [n_blocks] */
   const int32_t* block_cols;        /* [n_blocks] */
+  /* Default bounds of g (optional, has_bounds = 0: none): the LBG_DEF / UBG_DEF constants of the reference's generated
+   * C++ (`export/export.py:236-262`, `Point2Point.cpp:32`), +-inf allowed; a caller without the Python front end
+   * (compat/Point2Point) passes them to omgx_batch_solve. */
+  int32_t has_bounds;
+  const double* lbg_def;            /* [n_con] */
+  const double* ubg_def;            /* [n_con] */
 } omgx_template;
 
 #define OMGX_BLOCK_VAR 0

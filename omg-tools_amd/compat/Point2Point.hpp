@@ -1,0 +1,105 @@
+// omg::Point2Point -- header-compatible with the reference's exported C++ class
+// (`export/point2point/Point2Point.hpp:34-107`: obstacle_t, the three constructors, reset / resetTime / recover,
+// update(condition0, conditionT, state_trajectory, input_trajectory, obstacles[, predict_shift]), getCoefficients,
+// getLenBasis, n_dim, n_obs), backed by libomgx.so instead of CasADi + IPOPT.  Where the reference's exporter bakes
+// the problem into generated code -- N_VAR / N_PAR / N_CON, LBG_DEF / UBG_DEF, the labels, the offsets of every entry,
+// the spline transformations (`export/export.py:236-444`) -- this class reads a template file written once by the
+// Python front end (`omgtools.backend.save_template`): sizes, default bounds and the block table come from there,
+// the shift matrices are computed from the bases.  Template path: environment variable OMG_TEMPLATE, else the macro
+// OMG_TEMPLATE_FILE, else "p2p.omgx"; solver tolerance: OMG_TOL (default 1e-3 = the exporter's TOL).
+#ifndef OMG_COMPAT_POINT2POINT
+#define OMG_COMPAT_POINT2POINT
+
+#include <limits>
+#include <map>
+#include <string>
+#include <vector>
+#include "Vehicle.hpp"
+
+struct omgx_template;
+struct omgx_batch;
+
+namespace omg {
+
+const double inf = std::numeric_limits<double>::infinity();
+
+typedef struct obstacle {
+    std::vector<double> position;
+    std::vector<double> velocity;
+    std::vector<double> acceleration;
+    std::vector<double> checkpoints;
+    std::vector<double> radii;
+    std::vector<double> traj_coeffs;     // (kept for datatype compatibility; not used by fixed-T problems)
+    bool avoid;
+} obstacle_t;
+
+class Point2Point {
+  private:
+    omgx_template* tpl;
+    omgx_batch* problem;
+    bool solve(double, std::vector<obstacle_t>&);
+    bool _recover;
+    struct Block { std::string label, name; int kind, off, rows, cols; };
+    std::vector<Block> blocks;
+    std::string vehicle_lbl, p2p_lbl;
+    std::vector<std::string> obstacle_lbl;
+    std::map<int, std::vector<double>> shift_T;          // spline degree -> shift matrix of its basis
+    const Block* find(int kind, const std::string& label, const std::string& name) const;
+    void readBlockTable();
+
+  protected:
+    Vehicle* vehicle;
+    std::vector<double> spline_coeffs_vec;
+    double current_time = 0.0;
+    double current_time_prev = 0.0;
+    double horizon_time;
+    double update_time;
+    double sample_time;
+    int trajectory_length;
+    std::vector<double> parameters;
+    std::vector<double> variables;
+    std::vector<double> multipliers;
+    std::vector<double> lbg;
+    std::vector<double> ubg;
+    std::vector<double> time;
+    std::vector<std::vector<double>> state_trajectory;
+    std::vector<std::vector<double>> input_trajectory;
+    std::string solver_output;
+    int n_var, n_par, n_con;
+    const int freeT = 0;
+
+    void setParameters(std::vector<obstacle_t>&);
+    void initVariables();
+    void updateBounds(double, std::vector<obstacle_t>&);
+    void retrieveTrajectories(std::vector<std::vector<double>>&);
+    void getParameterVector(std::vector<double>&, std::map<std::string, std::map<std::string, std::vector<double>>>&);
+    void getVariableVector(std::vector<double>&, std::map<std::string, std::map<std::string, std::vector<double>>>&);
+    void getVariableDict(std::vector<double>&, std::map<std::string, std::map<std::string, std::vector<double>>>&);
+    void transformSplines(double, double);
+
+    virtual void generateProblem();
+    virtual void fillParameterDict(std::vector<obstacle_t>&, std::map<std::string, std::map<std::string, std::vector<double>>>&);
+    virtual void extractData();
+    virtual void initialize();
+
+  public:
+    int n_dim;
+    int n_obs;
+    Point2Point(Vehicle* vehicle, double update_time, double sample_time, double horizon_time);
+    Point2Point(Vehicle* vehicle, double update_time, double sample_time, double horizon_time, int trajectory_length);
+    Point2Point(Vehicle* vehicle, double update_time, double sample_time, double horizon_time, int trajectory_length, bool initialize);
+    virtual ~Point2Point();
+    virtual void reset();
+    virtual void resetTime();
+    virtual void recover();
+    bool update(std::vector<double>&, std::vector<double>&, std::vector<std::vector<double>>&, std::vector<std::vector<double>>&, std::vector<obstacle_t>&);
+    bool update(std::vector<double>&, std::vector<double>&, std::vector<std::vector<double>>&, std::vector<std::vector<double>>&, std::vector<obstacle_t>&, int);
+    void getCoefficients(std::vector<double>& coeffs);
+    int getLenBasis();
+    int getIterations() const { return last_iters; }        // (extension: interior-point iterations of the last update)
+  private:
+    int last_iters = 0;
+};
+
+}  // namespace omg
+#endif

@@ -813,8 +813,8 @@ int omgx_plan_describe(const omgx_template* tpl, omgx_plan_info* info, int32_t* 
 // Template files: the counts and arrays of omgx_template, written by the Python front end
 // (omgtools.backend.save_template) once per problem class and read by C/C++ callers -- the role the
 // generated nlp.so plays for the reference's C++ export (`export/export.py:236-262`, loaded in
-// `Point2Point.cpp:80-91`).  Layout: "OMGXTPL3", 15 int32 counts (the last two: block-table entries and the length of
-// their names), then the arrays in struct order, the block table last ("OMGXTPL2" files -- 13 counts, no table -- are still read).
+// `Point2Point.cpp:80-91`).  Layout: "OMGXTPL3", 16 int32 counts (the last three: block-table entries, the length of
+// their names, whether default bounds follow), then the arrays in struct order, the block table last ("OMGXTPL2" files -- 13 counts, no table -- are still read).
 namespace {
 struct TplField { int kind; size_t count; const void* const* src; void** dst; };     // kind 0 int32, 1 double, 2 char
 
@@ -829,6 +829,7 @@ size_t tpl_fields(const omgx_template& t, omgx_template* m, TplField* f) {
   OMGX_F(0, eq_rows, t.n_eq)                 OMGX_F(0, root_vars, t.n_root_vars)
   OMGX_F(2, block_names, t.block_names_len)  OMGX_F(0, block_kind, t.n_blocks)        OMGX_F(0, block_off, t.n_blocks)
   OMGX_F(0, block_rows, t.n_blocks)          OMGX_F(0, block_cols, t.n_blocks)
+  OMGX_F(1, lbg_def, t.has_bounds ? t.n_con : 0)  OMGX_F(1, ubg_def, t.has_bounds ? t.n_con : 0)
 #undef OMGX_F
   return k;
 }
@@ -840,10 +841,10 @@ int omgx_template_write(const omgx_template* tpl, const char* path) {
   if (!path) { g_err = "null path"; return OMGX_E_INVALID; }
   FILE* fp = fopen(path, "wb");
   if (!fp) { g_err = std::string("cannot write ") + path; return OMGX_E_INVALID; }
-  const int32_t counts[15] = {tpl->n_var, tpl->n_par, tpl->n_con, tpl->n_atoms, tpl->n_slots, tpl->n_terms, tpl->n_prog,
+  const int32_t counts[16] = {tpl->n_var, tpl->n_par, tpl->n_con, tpl->n_atoms, tpl->n_slots, tpl->n_terms, tpl->n_prog,
                               tpl->n_knots, tpl->n_pp, tpl->n_mono, tpl->n_matom, tpl->n_eq, tpl->n_root_vars,
-                              tpl->n_blocks, tpl->block_names_len};
-  bool ok = fwrite("OMGXTPL3", 1, 8, fp) == 8 && fwrite(counts, sizeof(int32_t), 15, fp) == 15;
+                              tpl->n_blocks, tpl->block_names_len, tpl->has_bounds ? 1 : 0};
+  bool ok = fwrite("OMGXTPL3", 1, 8, fp) == 8 && fwrite(counts, sizeof(int32_t), 16, fp) == 16;
   TplField f[24];
   const size_t nf = tpl_fields(*tpl, nullptr, f);
   for (size_t i = 0; i < nf && ok; ++i) {
@@ -869,18 +870,18 @@ int omgx_template_read(const char* path, omgx_template** out) {
   FILE* fp = fopen(path, "rb");
   if (!fp) { g_err = std::string("cannot read ") + path; return OMGX_E_INVALID; }
   char magic[8];
-  int32_t c[15] = {0};
+  int32_t c[16] = {0};
   const bool head = fread(magic, 1, 8, fp) == 8;
-  const int n_counts = head && memcmp(magic, "OMGXTPL3", 8) == 0 ? 15 : (head && memcmp(magic, "OMGXTPL2", 8) == 0 ? 13 : 0);
+  const int n_counts = head && memcmp(magic, "OMGXTPL3", 8) == 0 ? 16 : (head && memcmp(magic, "OMGXTPL2", 8) == 0 ? 13 : 0);
   if (n_counts == 0 || fread(c, sizeof(int32_t), n_counts, fp) != (size_t)n_counts) {
     fclose(fp); g_err = std::string(path) + " is not an omgx template file"; return OMGX_E_INVALID;
   }
-  for (int i = 0; i < 15; ++i) if (c[i] < 0 || c[i] > (1 << 26)) { fclose(fp); g_err = "template file: bad counts"; return OMGX_E_INVALID; }
+  for (int i = 0; i < 16; ++i) if (c[i] < 0 || c[i] > (1 << 26)) { fclose(fp); g_err = "template file: bad counts"; return OMGX_E_INVALID; }
   omgx_template* t = (omgx_template*)calloc(1, sizeof(omgx_template));
   if (!t) { fclose(fp); g_err = "out of memory"; return OMGX_E_INVALID; }
   t->n_var = c[0]; t->n_par = c[1]; t->n_con = c[2]; t->n_atoms = c[3]; t->n_slots = c[4]; t->n_terms = c[5]; t->n_prog = c[6];
   t->n_knots = c[7]; t->n_pp = c[8]; t->n_mono = c[9]; t->n_matom = c[10]; t->n_eq = c[11]; t->n_root_vars = c[12];
-  t->n_blocks = c[13]; t->block_names_len = c[14];
+  t->n_blocks = c[13]; t->block_names_len = c[14]; t->has_bounds = c[15];
   TplField f[24];
   const size_t nf = tpl_fields(*t, t, f);
   bool ok = true;

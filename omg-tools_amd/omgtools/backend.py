@@ -39,7 +39,8 @@ class CTemplate(C.Structure):
                 ('row_ptr', _I32P), ('t_coef', _F64P), ('t_slot', _I32P), ('t_var', _I32P)] + \
                [('n_eq', C.c_int32), ('eq_rows', _I32P), ('n_root_vars', C.c_int32), ('root_vars', _I32P)] + \
                [('n_blocks', C.c_int32), ('block_names_len', C.c_int32), ('block_names', C.c_char_p),
-                ('block_kind', _I32P), ('block_off', _I32P), ('block_rows', _I32P), ('block_cols', _I32P)]
+                ('block_kind', _I32P), ('block_off', _I32P), ('block_rows', _I32P), ('block_cols', _I32P)] + \
+               [('has_bounds', C.c_int32), ('lbg_def', _F64P), ('ubg_def', _F64P)]
 
 
 class CPlanInfo(C.Structure):
@@ -137,6 +138,8 @@ def make_ctemplate(tpl, plan=None):
     ct.n_blocks, ct.block_names_len, ct.block_names = len(names), len(blob), blob
     ct.block_kind, ct.block_off = i32(np.r_[kinds, 0]), i32(np.r_[offs, 0])
     ct.block_rows, ct.block_cols = i32(np.r_[rows, 0]), i32(np.r_[cols, 0])
+    # default bounds of g (LBG_DEF / UBG_DEF of the reference's generated C++)
+    ct.has_bounds, ct.lbg_def, ct.ubg_def = 1, f64(tpl.lb), f64(tpl.ub)
     return ct, keep
 
 
