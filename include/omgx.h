@@ -132,7 +132,8 @@ typedef struct omgx_options {
                            mu_init).  1 (default): the average complementarity of the point handed in (safe when the
                            problem changed between the solves: ADMM x-updates); 0: at tol / 10, where the previous solve
                            of the agent ended -- receding-horizon steps of one agent then need no barrier update of
-                           their own (BatchP2P sets it: fewer stragglers between knot crossings) */
+                           their own; BatchP2P sets 0.1 (tol / 10 unless the shifted point is far off that central
+                           path): fewer stragglers between knot crossings */
 } omgx_options;
 
 typedef struct omgx_batch omgx_batch;

@@ -28,7 +28,7 @@ def _build(n):
         be.create_nlp = saved
 
 
-def check_steps(solve_step):
+def check_steps(solve_step, f_tol=1e-5):
     from oracle.nlp_numpy import NumpyNLP
     from oracle.kkt_check import assert_kkt
     d = np.load(os.path.join(HERE, 'sol_mpc_cfg2.npz'))
@@ -51,7 +51,7 @@ def check_steps(solve_step):
         for b in range(n):
             assert_kkt(nlp, tpl, d['p'][k, b], res['x'][b], res['lam_g'][b], 10 * TOL, ('mpc', k, b))
             f = nlp.fg(res['x'][b], nlp.term_coefs(d['p'][k, b]))[0]
-            assert abs(f - d['f'][k, b]) < 1e-5 * (1 + abs(f)), (k, b, f, d['f'][k, b])
+            assert abs(f - d['f'][k, b]) < f_tol * (1 + abs(f)), (k, b, f, d['f'][k, b])
             dx = np.abs(res['x'][b, lo:hi] - d['x'][k, b, lo:hi]).reshape(-1, L)
             b0 = veh.basis.eval_basis([d['p'][k, b, o_t] / d['p'][k, b, o_T]])[0, 0]
             if b0 < 0.05:
@@ -65,26 +65,35 @@ def check_steps(solve_step):
     return tight, total
 
 
-def test_port_warm_steps_match_slsqp():
+# where the warm start begins on the central path (option warm_mu_factor) must not matter for where it ends: 0 = at
+# tol / 10 (the solve ends there too: objective within 1e-5 of SLSQP's), 0.1 = BatchP2P's setting (a solve may end as soon
+# as the complementarity is at the tolerance, a few barrier updates earlier: the objective then carries a gap of the order
+# (active rows) x mu, 1.7e-5 at most here)
+FACTORS = [(0.0, 1e-5), (0.1, 3e-5)]
+
+
+@pytest.mark.parametrize('factor,f_tol', FACTORS)
+def test_port_warm_steps_match_slsqp(factor, f_tol):
     from oracle import port_binding
 
     def solve_step(tpl, p, x0, lam):
         return port_binding.solve(tpl, p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32), warm_start=1,
-                                  n_threads=8, tol=TOL, max_iter=500, warm_mu_factor=0.0)        # (BatchP2P's setting)
-    check_steps(solve_step)
+                                  n_threads=8, tol=TOL, max_iter=500, warm_mu_factor=factor)
+    check_steps(solve_step, f_tol)
 
 
 @pytest.mark.gpu
-def test_hip_warm_steps_match_slsqp():
+@pytest.mark.parametrize('factor,f_tol', FACTORS)
+def test_hip_warm_steps_match_slsqp(factor, f_tol):
     from omgtools.backend import BatchSolver
     solver = {}
 
     def solve_step(tpl, p, x0, lam):
         if 's' not in solver:
-            solver['s'] = BatchSolver(tpl, len(p), options=dict(tol=TOL, max_iter=500, warm_start=1, warm_mu_factor=0.0))
+            solver['s'] = BatchSolver(tpl, len(p), options=dict(tol=TOL, max_iter=500, warm_start=1, warm_mu_factor=factor))
         return solver['s'].solve(p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32))
     try:
-        check_steps(solve_step)
+        check_steps(solve_step, f_tol)
     finally:
         if 's' in solver:
             solver['s'].close()
