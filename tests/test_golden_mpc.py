@@ -28,7 +28,7 @@ def _build(n):
         be.create_nlp = saved
 
 
-def check_steps(solve_step, f_tol=1e-5):
+def check_steps(solve_step, f_tol=1e-5, x_tol=2e-3):
     from oracle.nlp_numpy import NumpyNLP
     from oracle.kkt_check import assert_kkt
     d = np.load(os.path.join(HERE, 'sol_mpc_cfg2.npz'))
@@ -56,7 +56,7 @@ def check_steps(solve_step, f_tol=1e-5):
             b0 = veh.basis.eval_basis([d['p'][k, b, o_t] / d['p'][k, b, o_T]])[0, 0]
             if b0 < 0.05:
                 dx = dx[:, 1:]
-            assert dx.max() < 2e-3, (k, b, dx.max())
+            assert dx.max() < x_tol, (k, b, dx.max())
             tight += dx.max() < 1e-4
             total += 1
     assert tight >= 0.85 * total, (tight, total)
@@ -68,23 +68,24 @@ def check_steps(solve_step, f_tol=1e-5):
 # where the warm start begins on the central path (option warm_mu_factor) must not matter for where it ends: 0 = at
 # tol / 10 (the solve ends there too: objective within 1e-5 of SLSQP's), 0.1 = BatchP2P's setting (a solve may end as soon
 # as the complementarity is at the tolerance, a few barrier updates earlier: the objective then carries a gap of the order
-# (active rows) x mu, 1.7e-5 at most here)
-FACTORS = [(0.0, 1e-5), (0.1, 3e-5)]
+# (active rows) x mu, 1.7e-5 at most here, and the coefficients on a nearly flat face move with it: 2.6e-3 at most on the
+# HIP path, 6e-4 on the host build, which ends that solve an iteration later)
+FACTORS = [(0.0, 1e-5, 2e-3), (0.1, 3e-5, 4e-3)]
 
 
-@pytest.mark.parametrize('factor,f_tol', FACTORS)
-def test_port_warm_steps_match_slsqp(factor, f_tol):
+@pytest.mark.parametrize('factor,f_tol,x_tol', FACTORS)
+def test_port_warm_steps_match_slsqp(factor, f_tol, x_tol):
     from oracle import port_binding
 
     def solve_step(tpl, p, x0, lam):
         return port_binding.solve(tpl, p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32), warm_start=1,
                                   n_threads=8, tol=TOL, max_iter=500, warm_mu_factor=factor)
-    check_steps(solve_step, f_tol)
+    check_steps(solve_step, f_tol, x_tol)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('factor,f_tol', FACTORS)
-def test_hip_warm_steps_match_slsqp(factor, f_tol):
+@pytest.mark.parametrize('factor,f_tol,x_tol', FACTORS)
+def test_hip_warm_steps_match_slsqp(factor, f_tol, x_tol):
     from omgtools.backend import BatchSolver
     solver = {}
 
@@ -93,7 +94,7 @@ def test_hip_warm_steps_match_slsqp(factor, f_tol):
             solver['s'] = BatchSolver(tpl, len(p), options=dict(tol=TOL, max_iter=500, warm_start=1, warm_mu_factor=factor))
         return solver['s'].solve(p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32))
     try:
-        check_steps(solve_step, f_tol)
+        check_steps(solve_step, f_tol, x_tol)
     finally:
         if 's' in solver:
             solver['s'].close()
