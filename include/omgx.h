@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define OMGX_VERSION 3
+#define OMGX_VERSION 4
+#define OMGX_TERM_VARS 4      /* variables per term (version 3: three) */
 
 /* error codes */
 #define OMGX_OK            0
@@ -69,7 +70,8 @@ typedef struct omgx_template {
   const int32_t* row_ptr;   /* [n_con+2], row n_con = objective */
   const double*  t_coef;    /* [n_terms] */
   const int32_t* t_slot;    /* [n_terms] */
-  const int32_t* t_var;     /* [n_terms*3], -1 = unused */
+  const int32_t* t_var;     /* [n_terms*OMGX_TERM_VARS] variable indices of the term's factors (a repeated
+                             * index = a power), -1 = unused, unused entries last */
   /* row kinds: the rows with lbg == ubg (reference `optilayer.py:263-272`) */
   int32_t n_eq;
   const int32_t* eq_rows;   /* [n_eq] */

@@ -676,8 +676,11 @@ bool plan_for_mode(omgx::HostPlan& plan, const omgx_template& t, int* mode, size
       omgx::work_split(plan.dims, plan.kkt_doubles, cand[k], lds_doubles, hbm_doubles);
       if (*lds_doubles * sizeof(double) <= (size_t)kLdsHalf && !getenv("OMGX_ONE_PER_CU")) { *mode = cand[k]; *per_cu = 2; return true; }
     }
-    omgx::work_split(plan.dims, plan.kkt_doubles, omgx::WS_LDS, lds_doubles, hbm_doubles);
-    if (*lds_doubles * sizeof(double) <= (size_t)kLdsLimit) { *mode = omgx::WS_LDS; return true; }
+    // one agent per CU: everything in LDS, or the Jacobian values in a slab (the register-resident factorisation either way)
+    for (int k = 0; k < 2; ++k) {
+      omgx::work_split(plan.dims, plan.kkt_doubles, cand[k], lds_doubles, hbm_doubles);
+      if (*lds_doubles * sizeof(double) <= (size_t)kLdsLimit && !(k == 1 && getenv("OMGX_NO_JAC_ONLY_FULL"))) { *mode = cand[k]; return true; }
+    }
     plan = omgx::HostPlan();
     if (!plan.build(t)) return false;
   }
@@ -739,19 +742,17 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
     rc8 = upload(b, plan.sl_ell8.data(), plan.sl_ell8.size(), &dev8); if (rc8 != OMGX_OK) return rc8;
     b->dev.sl_ell = (const omgx::MonoRec*)dev8;
   } else { UP(pm_rec, plan.pm_rec.size()); UP(sl_ell, plan.sl_ell.size()); }
-  UP(row_ptr, d.n_con + 2); UP(t_coef, d.n_terms); UP(t_slot, d.n_terms); UP(t_var, 3 * d.n_terms);
-  UP(order, d.N); UP(pos, d.N); UP(leaf_off, d.n_leaf + 1); UP(leaf_bw, plan.leaf_bw.size()); UP(blk, d.N);
+  UP(row_ptr, d.n_con + 2); UP(t_coef, d.n_terms); UP(t_slot, d.n_terms); UP(t_var, OMGX_TERM_VARS * d.n_terms);
+  UP(order, d.N); UP(leaf_off, d.n_leaf + 1); UP(leaf_bw, plan.leaf_bw.size()); UP(blk, d.N);
   UP(eq_rows, d.n_eq); UP(eq_index, d.n_con);
-  UP(jr_ptr, d.n_con + 2); UP(jr_pos, d.nnz_j); UP(t_jidx, plan.t_jidx.size()); UP(row_leaf, d.n_con + 1);
   UP(cpl_ptr, d.n_leaf + 1); UP(cpl_idx, plan.cpl_idx.size()); UP(cpl_map, plan.cpl_map.size());
   UP(d_off, d.n_leaf + 1); UP(b_off, plan.b_off.size());
   UP(lf_w, plan.lf_w.size()); UP(lf_ldb, plan.lf_ldb.size()); UP(lf_band, plan.lf_band.size()); UP(lf_kind, plan.lf_kind.size()); UP(dl_pos, plan.dl_pos.size());
   UP(pair4, plan.pair4.size()); UP(eqe3, plan.eqe3.size());
-  UP(je_row, plan.je_row.size()); UP(jt_addr, plan.jt_addr.size()); UP(diag_addr, d.N); UP(tq_addr, plan.tq_addr.size());
-  UP(h_addr, plan.h_addr.size()); UP(t_row, plan.t_row.size()); UP(t_pos, plan.t_pos.size()); UP(reg_w, d.N);
-  UP(trec, plan.trec.size()); UP(hrec, plan.hrec.size()); UP(je_rp, plan.je_rp.size());
+  UP(je_row, plan.je_row.size()); UP(diag_addr, d.N); UP(tq_addr, plan.tq_addr.size());
+  UP(reg_w, d.N); UP(je_rp, plan.je_rp.size());
   UP(slot_rng, plan.slot_rng.size());
-  UP(je_ptr, plan.je_ptr.size()); UP(je_item, plan.je_item.size()); UP(jv_list, plan.jv_list.size());
+  UP(jv_list, plan.jv_list.size());
   UP(row_perm, plan.row_perm.size()); UP(cs_ptr, plan.cs_ptr.size()); UP(cs_rec, plan.cs_rec.size());
   UP(obj_ent, plan.obj_ent.size());
   UP(ka_rec, plan.ka_rec.size()); UP(kh_rec, plan.kh_rec.size()); UP(kg_rec, plan.kg_rec.size());
@@ -813,19 +814,19 @@ int omgx_plan_describe(const omgx_template* tpl, omgx_plan_info* info, int32_t* 
 // Template files: the counts and arrays of omgx_template, written by the Python front end
 // (omgtools.backend.save_template) once per problem class and read by C/C++ callers -- the role the
 // generated nlp.so plays for the reference's C++ export (`export/export.py:236-262`, loaded in
-// `Point2Point.cpp:80-91`).  Layout: "OMGXTPL3", 16 int32 counts (the last three: block-table entries, the length of
-// their names, whether default bounds follow), then the arrays in struct order, the block table last ("OMGXTPL2" files -- 13 counts, no table -- are still read).
+// `Point2Point.cpp:80-91`).  Layout: "OMGXTPL4", 16 int32 counts (the last three: block-table entries, the length of
+// their names, whether default bounds follow), then the arrays in struct order, the block table last ("OMGXTPL3" files -- three variables per term -- and "OMGXTPL2" files -- 13 counts, no table -- are still read).
 namespace {
 struct TplField { int kind; size_t count; const void* const* src; void** dst; };     // kind 0 int32, 1 double, 2 char
 
-size_t tpl_fields(const omgx_template& t, omgx_template* m, TplField* f) {
+size_t tpl_fields(const omgx_template& t, omgx_template* m, TplField* f, int term_vars = OMGX_TERM_VARS) {
   const omgx_template& s = t;
   size_t k = 0;
 #define OMGX_F(KD, NAME, CNT) f[k].kind = KD; f[k].count = (size_t)(CNT); f[k].src = (const void* const*)&s.NAME; f[k].dst = m ? (void**)&m->NAME : nullptr; ++k;
   OMGX_F(0, prog, 6 * (size_t)t.n_prog)      OMGX_F(1, knots, t.n_knots)       OMGX_F(0, pp_ptr, t.n_pp + 1)
   OMGX_F(1, pm_coef, t.n_mono)               OMGX_F(0, pm_ptr, t.n_mono + 1)   OMGX_F(0, pm_atom, t.n_matom)
   OMGX_F(0, slot_pp, t.n_slots)              OMGX_F(0, row_ptr, t.n_con + 2)   OMGX_F(1, t_coef, t.n_terms)
-  OMGX_F(0, t_slot, t.n_terms)               OMGX_F(0, t_var, 3 * (size_t)t.n_terms)
+  OMGX_F(0, t_slot, t.n_terms)               OMGX_F(0, t_var, (size_t)term_vars * t.n_terms)
   OMGX_F(0, eq_rows, t.n_eq)                 OMGX_F(0, root_vars, t.n_root_vars)
   OMGX_F(2, block_names, t.block_names_len)  OMGX_F(0, block_kind, t.n_blocks)        OMGX_F(0, block_off, t.n_blocks)
   OMGX_F(0, block_rows, t.n_blocks)          OMGX_F(0, block_cols, t.n_blocks)
@@ -844,7 +845,7 @@ int omgx_template_write(const omgx_template* tpl, const char* path) {
   const int32_t counts[16] = {tpl->n_var, tpl->n_par, tpl->n_con, tpl->n_atoms, tpl->n_slots, tpl->n_terms, tpl->n_prog,
                               tpl->n_knots, tpl->n_pp, tpl->n_mono, tpl->n_matom, tpl->n_eq, tpl->n_root_vars,
                               tpl->n_blocks, tpl->block_names_len, tpl->has_bounds ? 1 : 0};
-  bool ok = fwrite("OMGXTPL3", 1, 8, fp) == 8 && fwrite(counts, sizeof(int32_t), 16, fp) == 16;
+  bool ok = fwrite("OMGXTPL4", 1, 8, fp) == 8 && fwrite(counts, sizeof(int32_t), 16, fp) == 16;
   TplField f[24];
   const size_t nf = tpl_fields(*tpl, nullptr, f);
   for (size_t i = 0; i < nf && ok; ++i) {
@@ -872,7 +873,9 @@ int omgx_template_read(const char* path, omgx_template** out) {
   char magic[8];
   int32_t c[16] = {0};
   const bool head = fread(magic, 1, 8, fp) == 8;
-  const int n_counts = head && memcmp(magic, "OMGXTPL3", 8) == 0 ? 16 : (head && memcmp(magic, "OMGXTPL2", 8) == 0 ? 13 : 0);
+  const int file_version = !head ? 0 : (memcmp(magic, "OMGXTPL4", 8) == 0 ? 4 : (memcmp(magic, "OMGXTPL3", 8) == 0 ? 3 : (memcmp(magic, "OMGXTPL2", 8) == 0 ? 2 : 0)));
+  const int n_counts = file_version >= 3 ? 16 : (file_version == 2 ? 13 : 0);
+  const int file_tv = file_version >= 4 ? OMGX_TERM_VARS : 3;
   if (n_counts == 0 || fread(c, sizeof(int32_t), n_counts, fp) != (size_t)n_counts) {
     fclose(fp); g_err = std::string(path) + " is not an omgx template file"; return OMGX_E_INVALID;
   }
@@ -883,7 +886,7 @@ int omgx_template_read(const char* path, omgx_template** out) {
   t->n_knots = c[7]; t->n_pp = c[8]; t->n_mono = c[9]; t->n_matom = c[10]; t->n_eq = c[11]; t->n_root_vars = c[12];
   t->n_blocks = c[13]; t->block_names_len = c[14]; t->has_bounds = c[15];
   TplField f[24];
-  const size_t nf = tpl_fields(*t, t, f);
+  const size_t nf = tpl_fields(*t, t, f, file_tv);
   bool ok = true;
   for (size_t i = 0; i < nf; ++i) {
     const size_t sz = f[i].kind == 1 ? sizeof(double) : (f[i].kind == 2 ? 1 : sizeof(int32_t));
@@ -892,6 +895,17 @@ int omgx_template_read(const char* path, omgx_template** out) {
     if (ok && f[i].count && fread(*f[i].dst, sz, f[i].count, fp) != f[i].count) ok = false;
   }
   fclose(fp);
+  if (ok && file_tv != OMGX_TERM_VARS) {
+    // an older file: three variables per term
+    int32_t* wide = (int32_t*)calloc((size_t)OMGX_TERM_VARS * t->n_terms + 1, sizeof(int32_t));
+    if (!wide) ok = false;
+    else {
+      for (int i = 0; i < t->n_terms; ++i)
+        for (int k = 0; k < OMGX_TERM_VARS; ++k) wide[OMGX_TERM_VARS * i + k] = k < file_tv ? t->t_var[file_tv * i + k] : -1;
+      free((void*)t->t_var);
+      t->t_var = wide;
+    }
+  }
   if (!ok) { omgx_template_free(t); g_err = std::string("truncated template file ") + path; return OMGX_E_INVALID; }
   const int rc = check_template(t);
   if (rc != OMGX_OK) { omgx_template_free(t); return rc; }

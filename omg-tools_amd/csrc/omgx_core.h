@@ -56,7 +56,8 @@ struct Dims {
   int col_small;     // the same for the spill modes (left-looking leaf sweep only: inverse pivots + parked diagonal blocks per leaf): kept in LDS there
   int mono_packed;   // 1: every parameter monomial has <= 4 atoms, Tables::pm_rec / sl_ell hold MonoRec; 2: <= 8 atoms, MonoRec8; 0: CSR tables only
   int n_long;        // slots with more than OMGX_SLOT_CAP monomials (the first n_long entries of Tables::sl_list)
-  int n_hess;        // number of HessRec records
+  int n_hess;        // number of terms with >= 2 factors
+  int quartic;       // 1: some term has four factors (the passes over the item records multiply the fourth one in only then)
   int rp_packed;     // 1: rows and positions fit 16 bits each, Tables::je_rp is valid
   int n_knots;       // total length of the knot vectors of the atoms program (copied to LDS per solve)
   int wave_ok;       // 1: every panel of the KKT store fits one wave (register-resident factorisation, omgx_wave.h)
@@ -73,21 +74,19 @@ struct MonoRec { double coef; int16_t a0, a1, a2, a3; };
 // the same with up to eight atoms (Dims::mono_packed == 2: ADMM objectives multiply rho, multipliers and basis values)
 struct MonoRec8 { double coef; int16_t a0, a1, a2, a3, a4, a5, a6, a7; };
 
-// One polynomial term coef * slot * x_v0 x_v1 x_v2 as a single 40-byte record (v_k = -1: unused) with
-// its row and the Jacobian entries it feeds: one sequence of wide loads per term instead of nine
-// loads from five tables.  HessRec: the same for the terms with two or more variables (the only ones
-// the Lagrangian Hessian sees), with their KKT addresses and variable positions.
-struct TermRec { double coef; int32_t slot, row, j0, j1, j2; int16_t v0, v1, v2, pad; };
-struct HessRec { double coef; int32_t slot, row, ha0, ha1, ha2; int16_t v0, v1, v2, p0, p1, p2; };
-
-// Owner-computes records (omgx_plan.h): every sum of the solve has one owner thread and a fixed order.
-// JItem: one contribution coef * slot * x[va] * x[vb] (v = -1: factor 1) to a Jacobian entry.
-// HItem: one contribution of a nonlinear term to a KKT address (or, for the Gershgorin sums, to a
-// position): h = lambda_row * coef * slot * x[vthird]; kind 1 = both variables of the pair coincide.
-struct JItem { double coef; int32_t slot; int16_t va, vb; };
+// Owner-computes records (omgx_plan.h): every sum of the solve has one owner thread and a fixed order.  A term is
+// coef * slot * x_v0 x_v1 x_v2 x_v3 (OMGX_TERM_VARS = 4 factors, -1: unused; a repeated index is a power).
+// JItem: one contribution coef * slot * x[va] * x[vb] * x[vc] (v = -1: factor 1) to a Jacobian entry: the term without
+// one of its factors.
+// HItem: one contribution of a nonlinear term to a KKT address (or, for the Gershgorin sums, to a position): the term
+// without two of its factors, h = lambda_row * coef * slot * x[vthird] * x[vfourth]; kind 1 = the two factors that
+// were taken out are the same variable (a diagonal entry: both orders of the pair land on it).
+// (slot indices are 16 bit in the 16- and 24-byte records: the plan refuses templates with more than 32767 slots)
+#define OMGX_TV 4
+struct JItem { double coef; int16_t slot, va, vb, vc; };
 // one term of a row for the row-value passes (24 bytes; padding records have coef 0)
-struct RowTerm { double coef; int32_t slot; int16_t v0, v1, v2, pad; };
-struct HItem { double coef; int32_t slot, row, target; int16_t vthird, kind; };
+struct RowTerm { double coef; int32_t slot; int16_t v0, v1, v2, v3; };
+struct HItem { double coef; int32_t row, target; int16_t slot, vthird, vfourth, kind; };
 
 struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* prog; const double* knots;
@@ -96,9 +95,8 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const MonoRec* pm_rec;    // [n_mono] packed form of (pm_coef, pm_ptr, pm_atom); valid if Dims::mono_packed
   const int32_t* slot_rng;  // [n_slots][2] monomial range of every slot (= pp_ptr[slot_pp[s]], pp_ptr[slot_pp[s] + 1])
   const int32_t* row_ptr; const double* t_coef; const int32_t* t_slot; const int32_t* t_var;
-  const int32_t* order; const int32_t* pos; const int32_t* leaf_off; const int32_t* blk;
+  const int32_t* order; const int32_t* leaf_off; const int32_t* blk;
   const int32_t* eq_rows; const int32_t* eq_index;
-  const int32_t* jr_ptr; const int32_t* jr_pos; const int32_t* t_jidx; const int32_t* row_leaf;
   const int32_t* cpl_ptr; const int32_t* cpl_idx; const int32_t* cpl_map;
   const int32_t* d_off; const int32_t* b_off;   // panel offsets / leading dimensions inside the KKT store
   // compact store of the wave path (omgx_plan.h `compact`): per leaf the offset of its carried rows (sparse diagonal
@@ -108,18 +106,12 @@ struct Tables {   // read-only, shared by all agents (global memory)
   // precomputed KKT addresses (HostPlan): Jacobian pairs, t-column, diagonal, Hessian terms
   const int32_t* eqe3;      // [n_eqe][3] = {Jacobian entry, KKT address, row} of the equality-row entries
   const int32_t* pair4;     // [n_pairs][4] = {Jacobian entry a, entry b, KKT address, row}: one 16-byte record per pair
-  const int32_t* je_row; const int32_t* jt_addr; const int32_t* diag_addr;
-  const int32_t* h_addr; const int32_t* t_row;
-  const int32_t* t_pos;     // [n_terms][3] positions of the term's variables (-1: none)
+  const int32_t* je_row; const int32_t* diag_addr;
   const int32_t* je_rp;     // [nnz_j] (row << 16) | position of every Jacobian entry (valid if Dims::rp_packed)
-  const TermRec* trec;      // [n_terms] packed terms (rows 0..m-1 first, then the objective row m)
-  const HessRec* hrec;      // [n_hess] packed terms with >= 2 variables
   const double* reg_w;   // [N] position order: inertia-correction class (+1 nonlinear root variable, -1 nonlinear leaf variable, else the weight itself: OMGX_DW_LINEAR)
   const int32_t* leaf_bw;   // [n_leaf] half bandwidth of the leaf block in its (reverse Cuthill-McKee) order
   const int32_t* tq_addr;   // [n_var] KKT address of (t, q)
   // owner-computes tables
-  const int32_t* je_ptr;    // [nnz_j + 1] items of every Jacobian entry
-  const JItem* je_item;
   const int32_t* jv_list;   // [n_jv] entries that depend on x
   const int32_t* row_perm;  // [n_con] rows, longest term list first
   // ELL tables of the row / column / entry owners: record `step` of owner i at index step * n_owner + i
@@ -654,7 +646,8 @@ OMGX_FN double rec_coef(const Work& w, double coef, int slot) { return slot < 0 
 OMGX_FN double row_slack(const Work& w, int r, double t) { return t * w.vv[r] - w.hv[r]; }
 
 // sum of the items of the entry in slot i of an ELL item table (four at a time, all loads in flight)
-OMGX_FN double jac_entry_ell(const JItem* ell, const int32_t* glen, int n_owner, const Work& w, int i, const double* xv) {
+template <bool Q4>
+OMGX_FN double jac_entry_ell_t(const JItem* ell, const int32_t* glen, int n_owner, const Work& w, int i, const double* xv) {
   const int L = glen[i >> 6];
   double sj = 0.0;
   for (int s0 = 0; s0 < L; s0 += 4) {
@@ -666,17 +659,22 @@ OMGX_FN double jac_entry_ell(const JItem* ell, const int32_t* glen, int n_owner,
     for (int k = 0; k < 4; ++k) {
       const double xs = w.slots[q[k].slot < 0 ? 0 : q[k].slot], xa = xv[q[k].va < 0 ? 0 : q[k].va], xb = xv[q[k].vb < 0 ? 0 : q[k].vb];
       v[k] = q[k].coef * (q[k].slot < 0 ? 1.0 : xs) * (q[k].va < 0 ? 1.0 : xa) * (q[k].vb < 0 ? 1.0 : xb);
+      if (Q4) { const double xc = xv[q[k].vc < 0 ? 0 : q[k].vc]; v[k] *= (q[k].vc < 0 ? 1.0 : xc); }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) sj += v[k];
   }
   return sj;
 }
+OMGX_FN double jac_entry_ell(const Dims& d, const JItem* ell, const int32_t* glen, int n_owner, const Work& w, int i, const double* xv) {
+  return d.quartic ? jac_entry_ell_t<true>(ell, glen, n_owner, w, i, xv) : jac_entry_ell_t<false>(ell, glen, n_owner, w, i, xv);
+}
 
 // unscaled value of the row in slot i (row T.row_perm[i]) at xv: its terms from the ELL table, eight at a
 // time (all loads in flight together), summed in term order
 #define OMGX_ROW_BATCH 8
-OMGX_FN double row_value_ell(const Tables& T, const Work& w, int i, int m, const double* xv) {
+template <bool Q4>
+OMGX_FN double row_value_ell_t(const Tables& T, const Work& w, int i, int m, const double* xv) {
   const int L = T.rt_glen[i >> 6];
   double g = 0.0;
   for (int s0 = 0; s0 < L; s0 += OMGX_ROW_BATCH) {
@@ -689,11 +687,15 @@ OMGX_FN double row_value_ell(const Tables& T, const Work& w, int i, int m, const
       const double xs = w.slots[q[k].slot < 0 ? 0 : q[k].slot];
       const double x0 = xv[q[k].v0 < 0 ? 0 : q[k].v0], x1 = xv[q[k].v1 < 0 ? 0 : q[k].v1], x2 = xv[q[k].v2 < 0 ? 0 : q[k].v2];
       v[k] = q[k].coef * (q[k].slot < 0 ? 1.0 : xs) * (q[k].v0 < 0 ? 1.0 : x0) * (q[k].v1 < 0 ? 1.0 : x1) * (q[k].v2 < 0 ? 1.0 : x2);
+      if (Q4) { const double x3 = xv[q[k].v3 < 0 ? 0 : q[k].v3]; v[k] *= (q[k].v3 < 0 ? 1.0 : x3); }
     }
 #pragma unroll
     for (int k = 0; k < OMGX_ROW_BATCH; ++k) g += v[k];
   }
   return g;
+}
+OMGX_FN double row_value_ell(const Dims& d, const Tables& T, const Work& w, int i, int m, const double* xv) {
+  return d.quartic ? row_value_ell_t<true>(T, w, i, m, xv) : row_value_ell_t<false>(T, w, i, m, xv);
 }
 
 // this thread's share of row r (terms strided over the workgroup); the caller sums the shares
@@ -702,8 +704,8 @@ OMGX_FN double row_value_share(const C& c, const Tables& T, const Work& w, int r
   double g = 0.0;
   for (int t = T.row_ptr[r] + c.tid(); t < T.row_ptr[r + 1]; t += c.nthr()) {
     double v = term_coef(T, w, t);
-    const int32_t* tv = T.t_var + 3 * t;
-    if (tv[0] >= 0) { v *= xv[tv[0]]; if (tv[1] >= 0) { v *= xv[tv[1]]; if (tv[2] >= 0) v *= xv[tv[2]]; } }
+    const int32_t* tv = T.t_var + OMGX_TV * t;
+    for (int k = 0; k < OMGX_TV && tv[k] >= 0; ++k) v *= xv[tv[k]];
     g += v;
   }
   return g;
@@ -1742,7 +1744,8 @@ OMGX_FN void kkt_rhs(const C& c, const Dims& d, const Tables& T, Work& w, double
 // multiplier x signed scale (row m = objective: 1), summed per KKT address in table order and added to the store
 // (omgx_plan.h (4): ELL records, the target in the last record of its run, everything else to the dump slot).
 // Used by the assembly of the solve and by the verification entry (ipm_eval).
-OMGX_FN void hess_bin(const Dims& d, const Tables& T, Work& w, int m, int bin, int dump) {
+template <bool Q4>
+OMGX_FN void hess_bin_t(const Dims& d, const Tables& T, Work& w, int m, int bin, int dump) {
   double acc = 0.0;
   for (int e0 = 0; e0 < d.kh_len; e0 += OMGX_REC_BATCH) {
     HItem q[OMGX_REC_BATCH];
@@ -1755,6 +1758,7 @@ OMGX_FN void hess_bin(const Dims& d, const Tables& T, Work& w, int m, int bin, i
       const double lam = (q[i].row < m) ? w.ht[r] : 1.0;          // (row multiplier x signed scale, set below the residuals)
       const double xs = w.slots[q[i].slot < 0 ? 0 : q[i].slot], x3 = w.x[q[i].vthird < 0 ? 0 : q[i].vthird];
       h[i] = (q[i].kind ? 2.0 : 1.0) * lam * q[i].coef * (q[i].slot < 0 ? 1.0 : xs) * (q[i].vthird < 0 ? 1.0 : x3);
+      if (Q4) { const double x4 = w.x[q[i].vfourth < 0 ? 0 : q[i].vfourth]; h[i] *= (q[i].vfourth < 0 ? 1.0 : x4); }
     }
     // (the old values are read first, together: a thread's targets are distinct, only the dump
     // slot repeats, and what ends up there does not matter)
@@ -1768,6 +1772,10 @@ OMGX_FN void hess_bin(const Dims& d, const Tables& T, Work& w, int m, int bin, i
       acc = q[i].target >= 0 ? 0.0 : acc;
     }
   }
+}
+
+OMGX_FN void hess_bin(const Dims& d, const Tables& T, Work& w, int m, int bin, int dump) {
+  if (d.quartic) hess_bin_t<true>(d, T, w, m, bin, dump); else hess_bin_t<false>(d, T, w, m, bin, dump);
 }
 
 // ---------------------------------------------------------------------------
@@ -1804,8 +1812,8 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // (the unscaled entries go to the KKT store, which is idle during the setup, when that is LDS: the row classification
   // below reads every entry of its row, and with two agents per CU the Jacobian values themselves live in a slab)
   double* jtmp = (C::hbm || kkt_doubles < d.nnz_j + 1) ? w.jval : w.kkt;
-  OMGX_PFOR(i, d.nnz_j) jtmp[T.ja_list[i]] = jac_entry_ell(T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
-  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell(T, w, i, m, w.x); }
+  OMGX_PFOR(i, d.nnz_j) jtmp[T.ja_list[i]] = jac_entry_ell(d, T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
+  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell(d, T, w, i, m, w.x); }
   if (c.tid() == 0) { jtmp[d.nnz_j] = 0.0; w.jval[d.nnz_j] = 0.0; }      // the slot padding records point at
   c.sync();
   OMGX_TOC(PH_S_JAC0);
@@ -1932,7 +1940,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         const int e = T.jv_list[i];
         const int r = d.rp_packed ? (int)((uint32_t)T.je_rp[e] >> 16) : T.je_row[e];
         const double sc = (r < m) ? ((w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r]) : 1.0;
-        const double sj = jac_entry_ell(T.jv_ell, T.jv_glen, d.n_jv, w, i, w.x);
+        const double sj = jac_entry_ell(d, T.jv_ell, T.jv_glen, d.n_jv, w, i, w.x);
         w.jval[e] = sc * sj;
       }
     }
@@ -2160,7 +2168,8 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
               const int r = q[i].row < m ? q[i].row : 0;
               const double lam = (q[i].row < m) ? w.ht[r] : 1.0;
               const double xs = w.slots[q[i].slot < 0 ? 0 : q[i].slot], x3 = w.x[q[i].vthird < 0 ? 0 : q[i].vthird];
-              const double h = lam * q[i].coef * (q[i].slot < 0 ? 1.0 : xs) * (q[i].vthird < 0 ? 1.0 : x3);
+              double h = lam * q[i].coef * (q[i].slot < 0 ? 1.0 : xs) * (q[i].vthird < 0 ? 1.0 : x3);
+              if (d.quartic) { const double x4 = w.x[q[i].vfourth < 0 ? 0 : q[i].vfourth]; h *= (q[i].vfourth < 0 ? 1.0 : x4); }
               g[i] = q[i].kind ? (h < 0.0 ? -2.0 * h : 0.0) : fabs(h);
             }
 #pragma unroll
@@ -2364,7 +2373,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       OMGX_PFOR(i, m) {
         const int r = T.row_perm[i];
         const int ty = w.rtype[r];
-        const double gv = row_value_ell(T, w, i, m, w.xt);      // (also for free rows: the loop bound is per wave)
+        const double gv = row_value_ell(d, T, w, i, m, w.xt);      // (also for free rows: the loop bound is per wave)
         if (ty == ROW_FREE) { w.ht[r] = 0.0; continue; }
         const double h = w.rho[r] * (gv - ((ty == ROW_LOWER || ty == ROW_EQ) ? lb[r] : ub[r]));
         w.ht[r] = h;
@@ -2467,8 +2476,8 @@ OMGX_FN void ipm_eval(const C& c, const Dims& d, const Tables& T, Work& w, const
   OMGX_PFOR(i, n) w.x[i] = x[i];
   if (c.tid() == 0) w.x[n] = 0.0;
   eval_params(c, d, T, w, p);
-  OMGX_PFOR(i, d.nnz_j) w.jval[T.ja_list[i]] = jac_entry_ell(T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
-  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell(T, w, i, m, w.x); }
+  OMGX_PFOR(i, d.nnz_j) w.jval[T.ja_list[i]] = jac_entry_ell(d, T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
+  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell(d, T, w, i, m, w.x); }
   OMGX_PFOR(r, m) w.ht[r] = lam[r];
   OMGX_PFOR(i, kkt_doubles) w.kkt[i] = 0.0;
   const double f = c.rsum(row_value_share(c, T, w, m, w.x));

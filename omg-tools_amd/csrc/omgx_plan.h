@@ -32,13 +32,14 @@ struct HostPlan {
   std::vector<int32_t> lf_w, lf_ldb, lf_band, lf_kind, dl_pos;      // compact store of the wave path (Tables)
   std::vector<std::vector<std::vector<int>>> var_cpl;                // [leaf][variable]: root positions (but t) its entries of B_l can touch
   // ---- addresses and packed records ---------------------------------------------------------------
-  std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, h_addr, t_row, t_pos, tq_addr;
+  std::vector<int32_t> pair4, eqe3, je_row, jt_addr, diag_addr, t_row, tq_addr;
   std::vector<double> reg_w;
   std::vector<MonoRec> pm_rec;
   std::vector<MonoRec8> pm_rec8, sl_ell8;      // (Dims::mono_packed == 2: Tables::pm_rec / sl_ell point at these)
   std::vector<int32_t> je_rp, slot_rng;
-  std::vector<TermRec> trec;
-  std::vector<HessRec> hrec;
+  // host only: the terms with >= 2 factors and, per pair of factors, the KKT address of their Hessian entry
+  struct HessTerm { double coef; int32_t slot, row; int nv; int32_t v[OMGX_TV], p[OMGX_TV], ha[OMGX_TV * (OMGX_TV - 1) / 2]; };
+  std::vector<HessTerm> hrec;
   // ---- owner-computes tables ----------------------------------------------------------------------
   std::vector<int32_t> je_ptr, jv_list, row_perm, cs_ptr, cs_rec, obj_ent;
   std::vector<JItem> je_item;
@@ -71,13 +72,13 @@ struct HostPlan {
     for (int r = 0; r <= m; ++r) {
       std::set<int> s;
       for (int tt = t.row_ptr[r]; tt < t.row_ptr[r + 1]; ++tt)
-        for (int k = 0; k < 3; ++k) { const int v = t.t_var[3 * tt + k]; if (v >= n) return fail("term variable out of range"); if (v >= 0) s.insert(v); }
+        for (int k = 0; k < OMGX_TV; ++k) { const int v = t.t_var[OMGX_TV * tt + k]; if (v >= n) return fail("term variable out of range"); if (v >= 0) s.insert(v); }
       rows_vars[r].assign(s.begin(), s.end());
     }
     std::vector<std::vector<int>> obj_cpl;       // nonlinear objective terms couple their variables like a row
     for (int tt = t.row_ptr[m]; tt < t.row_ptr[m + 1]; ++tt) {
       std::set<int> s;
-      for (int k = 0; k < 3; ++k) if (t.t_var[3 * tt + k] >= 0) s.insert(t.t_var[3 * tt + k]);
+      for (int k = 0; k < OMGX_TV; ++k) if (t.t_var[OMGX_TV * tt + k] >= 0) s.insert(t.t_var[OMGX_TV * tt + k]);
       if (s.size() > 1) obj_cpl.emplace_back(s.begin(), s.end());
     }
     eq_rows.assign(t.eq_rows, t.eq_rows + t.n_eq);
@@ -160,7 +161,7 @@ struct HostPlan {
     std::vector<int> leaf_of(n + 1, -1);
     for (size_t l = 0; l < leaves.size(); ++l) for (int v : leaves[l]) leaf_of[v] = (int)l;
     // per-row Jacobian structure in position order, term -> entry index
-    jr_ptr.assign(1, 0); jr_pos.clear(); t_jidx.assign(3 * (size_t)std::max(1, t.n_terms), -1); row_leaf.assign(m + 1, -1);
+    jr_ptr.assign(1, 0); jr_pos.clear(); t_jidx.assign(OMGX_TV * (size_t)std::max(1, t.n_terms), -1); row_leaf.assign(m + 1, -1);
     for (int r = 0; r <= m; ++r) {
       std::vector<int> vs = rows_vars[r];
       std::sort(vs.begin(), vs.end(), [&](int a, int b) { return pos[a] < pos[b]; });
@@ -172,9 +173,9 @@ struct HostPlan {
       const int base = (int)jr_pos.size();
       for (int v : vs) jr_pos.push_back(pos[v]);
       for (int tt = t.row_ptr[r]; tt < t.row_ptr[r + 1]; ++tt)
-        for (int k = 0; k < 3; ++k) {
-          const int v = t.t_var[3 * tt + k];
-          if (v >= 0) t_jidx[3 * tt + k] = base + (int)(std::find(vs.begin(), vs.end(), v) - vs.begin());
+        for (int k = 0; k < OMGX_TV; ++k) {
+          const int v = t.t_var[OMGX_TV * tt + k];
+          if (v >= 0) t_jidx[OMGX_TV * tt + k] = base + (int)(std::find(vs.begin(), vs.end(), v) - vs.begin());
         }
       jr_ptr.push_back((int)jr_pos.size());
     }
@@ -262,6 +263,7 @@ struct HostPlan {
     d = Dims();
     d.n_var = t.n_var; d.n_par = t.n_par; d.n_con = t.n_con; d.n_atoms = t.n_atoms;
     d.n_slots = t.n_slots; d.n_terms = t.n_terms; d.n_prog = t.n_prog;
+    if (t.n_slots > 32767) return fail("more than 32767 parameter slots (16-bit slot indices in the item records)");
     d.N = t.n_var + 1; d.n_eq = t.n_eq; d.n_knots = t.n_knots;
     if (t.n_var <= 0 || t.n_con < 0 || t.n_terms < 0 || t.n_var >= 32767) return fail("bad dimensions");
     if (t.row_ptr[t.n_con + 1] != t.n_terms) return fail("row_ptr does not cover the terms");
@@ -353,9 +355,8 @@ struct HostPlan {
     T.prog = t.prog; T.knots = t.knots; T.pp_ptr = t.pp_ptr; T.pm_coef = t.pm_coef;
     T.pm_ptr = t.pm_ptr; T.pm_atom = t.pm_atom; T.slot_pp = t.slot_pp; T.row_ptr = t.row_ptr;
     T.t_coef = t.t_coef; T.t_slot = t.t_slot; T.t_var = t.t_var; T.order = order.data();
-    T.pos = pos.data(); T.leaf_off = leaf_off.data(); T.leaf_bw = leaf_bw.data(); T.blk = blk.data(); T.eq_rows = eq_rows.data();
-    T.eq_index = eq_index.data(); T.jr_ptr = jr_ptr.data(); T.jr_pos = jr_pos.data(); T.t_jidx = t_jidx.data();
-    T.row_leaf = row_leaf.data();
+    T.leaf_off = leaf_off.data(); T.leaf_bw = leaf_bw.data(); T.blk = blk.data(); T.eq_rows = eq_rows.data();
+    T.eq_index = eq_index.data();
     T.cpl_ptr = cpl_ptr.data(); T.cpl_idx = cpl_idx.data(); T.cpl_map = cpl_map.data();
     T.d_off = d_off.data(); T.b_off = b_off.data();
     T.lf_w = lf_w.data(); T.lf_ldb = lf_ldb.data(); T.lf_band = lf_band.data(); T.lf_kind = lf_kind.data(); T.dl_pos = dl_pos.data();
@@ -395,25 +396,32 @@ struct HostPlan {
     d.n_pairs = (int)pair4.size() / 4;
     diag_addr.assign(d.N, 0);
     for (int q = 0; q < d.N; ++q) diag_addr[q] = addr(q, q);
+    // terms with >= 2 factors: every pair of factors (i < j, OMGX_TV (OMGX_TV - 1) / 2 of them) owns a Hessian entry
     t_row.assign(d.n_terms > 0 ? d.n_terms : 1, 0);
-    h_addr.assign(3 * (size_t)(d.n_terms > 0 ? d.n_terms : 1), 0);
-    t_pos.assign(3 * (size_t)(d.n_terms > 0 ? d.n_terms : 1), -1);
-    for (int tt = 0; tt < d.n_terms; ++tt)
-      for (int k = 0; k < 3; ++k) if (t.t_var[3 * tt + k] >= 0) t_pos[3 * tt + k] = pos[t.t_var[3 * tt + k]];
+    hrec.clear();
     for (int r = 0; r <= m; ++r)
       for (int tt = t.row_ptr[r]; tt < t.row_ptr[r + 1]; ++tt) {
         t_row[tt] = r;
-        const int32_t* tv = t.t_var + 3 * tt;
-        const int pr[3][2] = {{0, 1}, {0, 2}, {1, 2}};
-        for (int k = 0; k < 3; ++k) {
-          const int va = tv[pr[k][0]], vb = tv[pr[k][1]];
-          if (va < 0 || vb < 0) continue;
-          const int pa = pos[va], pb = pos[vb];
+        const int32_t* tv = t.t_var + OMGX_TV * tt;
+        int nv = 0; while (nv < OMGX_TV && tv[nv] >= 0) ++nv;
+        for (int k = nv; k < OMGX_TV; ++k) if (tv[k] >= 0) return fail("unused term variables must come last");
+        if (nv < 2) continue;
+        HessTerm h; h.coef = t.t_coef[tt]; h.slot = t.t_slot[tt]; h.row = r; h.nv = nv;
+        for (int k = 0; k < OMGX_TV; ++k) { h.v[k] = tv[k]; h.p[k] = tv[k] >= 0 ? pos[tv[k]] : -1; }
+        int q = 0;
+        for (int i = 0; i < OMGX_TV; ++i) for (int j = i + 1; j < OMGX_TV; ++j, ++q) {
+          h.ha[q] = -1;
+          if (j >= nv) continue;
+          const int pa = h.p[i], pb = h.p[j];
           const int32_t ad = pa >= pb ? addr(pa, pb) : addr(pb, pa);
           if (ad < 0) return fail("no slot for a Hessian entry");
-          h_addr[3 * tt + k] = ad;
+          h.ha[q] = ad;
         }
+        hrec.push_back(h);
       }
+    d.n_hess = (int)hrec.size();
+    d.quartic = 0;
+    for (int tt = 0; tt < d.n_terms; ++tt) if (t.t_var[OMGX_TV * tt + OMGX_TV - 1] >= 0) d.quartic = 1;
     // flat tables of the parameter stage
     slot_rng.assign(2 * (size_t)(d.n_slots > 0 ? d.n_slots : 1), 0);
     for (int sl = 0; sl < d.n_slots; ++sl) { slot_rng[2 * sl] = t.pp_ptr[t.slot_pp[sl]]; slot_rng[2 * sl + 1] = t.pp_ptr[t.slot_pp[sl] + 1]; }
@@ -456,37 +464,15 @@ struct HostPlan {
     if (d.rp_packed)
       for (int e = 0; e < d.nnz_j; ++e) je_rp[e] = (int32_t)(((uint32_t)je_row[e] << 16) | (uint32_t)jr_pos[e]);
     T.je_rp = je_rp.data();
-    // packed term records
-    trec.assign(d.n_terms > 0 ? d.n_terms : 1, TermRec{0.0, -1, 0, 0, 0, 0, -1, -1, -1, 0});
-    hrec.clear();
-    for (int tt = 0; tt < d.n_terms; ++tt) {
-      const int32_t* tv = t.t_var + 3 * tt;
-      const int32_t* je = t_jidx.data() + 3 * tt;
-      TermRec& q = trec[tt];
-      q.coef = t.t_coef[tt]; q.slot = t.t_slot[tt]; q.row = t_row[tt];
-      q.j0 = je[0] < 0 ? 0 : je[0]; q.j1 = je[1] < 0 ? 0 : je[1]; q.j2 = je[2] < 0 ? 0 : je[2];
-      q.v0 = (int16_t)tv[0]; q.v1 = (int16_t)tv[1]; q.v2 = (int16_t)tv[2];
-      if (tv[1] >= 0) {
-        HessRec h;
-        h.coef = q.coef; h.slot = q.slot; h.row = q.row;
-        h.ha0 = h_addr[3 * tt]; h.ha1 = h_addr[3 * tt + 1]; h.ha2 = h_addr[3 * tt + 2];
-        h.v0 = q.v0; h.v1 = q.v1; h.v2 = q.v2;
-        h.p0 = (int16_t)t_pos[3 * tt]; h.p1 = (int16_t)t_pos[3 * tt + 1]; h.p2 = (int16_t)(tv[2] >= 0 ? t_pos[3 * tt + 2] : 0);
-        hrec.push_back(h);
-      }
-    }
-    d.n_hess = (int)hrec.size();
-    if (hrec.empty()) hrec.push_back(HessRec{0.0, -1, 0, 0, 0, 0, -1, -1, -1, 0, 0, 0});
-    T.trec = trec.data(); T.hrec = hrec.data();
     T.eqe3 = eqe3.data();
-    T.je_row = je_row.data(); T.jt_addr = jt_addr.data(); T.diag_addr = diag_addr.data(); T.tq_addr = tq_addr.data();
-    T.h_addr = h_addr.data(); T.t_row = t_row.data(); T.t_pos = t_pos.data(); T.pm_rec = dims.mono_packed == 2 ? (const MonoRec*)pm_rec8.data() : pm_rec.data();
+    T.je_row = je_row.data(); T.diag_addr = diag_addr.data(); T.tq_addr = tq_addr.data();
+    T.pm_rec = dims.mono_packed == 2 ? (const MonoRec*)pm_rec8.data() : pm_rec.data();
     reg_w.assign(d.N, OMGX_DW_LINEAR);
     for (int tt = 0; tt < t.row_ptr[m + 1]; ++tt) {
-      const int32_t* tv = t.t_var + 3 * tt;
+      const int32_t* tv = t.t_var + OMGX_TV * tt;
       if (tv[1] < 0) continue;                                  // constant or linear term
       // class markers, turned into weights by the kernel: -1 nonlinear leaf variable, +1 nonlinear root variable
-      for (int k = 0; k < 3; ++k) if (tv[k] >= 0) reg_w[pos[tv[k]]] = (pos[tv[k]] < d.root_off) ? -1.0 : 1.0;
+      for (int k = 0; k < OMGX_TV; ++k) if (tv[k] >= 0) reg_w[pos[tv[k]]] = (pos[tv[k]] < d.root_off) ? -1.0 : 1.0;
     }
     T.reg_w = reg_w.data();
 
@@ -495,13 +481,13 @@ struct HostPlan {
     {
       std::vector<std::vector<JItem>> items(d.nnz_j > 0 ? d.nnz_j : 1);
       for (int tt = 0; tt < d.n_terms; ++tt) {
-        const int32_t* tv = t.t_var + 3 * tt;
-        int nv = 0; while (nv < 3 && tv[nv] >= 0) ++nv;
+        const int32_t* tv = t.t_var + OMGX_TV * tt;
+        int nv = 0; while (nv < OMGX_TV && tv[nv] >= 0) ++nv;
         for (int k = 0; k < nv; ++k) {
-          JItem it; it.coef = t.t_coef[tt]; it.slot = t.t_slot[tt]; it.va = -1; it.vb = -1;
+          JItem it; it.coef = t.t_coef[tt]; it.slot = (int16_t)t.t_slot[tt]; it.va = -1; it.vb = -1; it.vc = -1;
           int o = 0;
-          for (int k2 = 0; k2 < nv; ++k2) if (k2 != k) { (o == 0 ? it.va : it.vb) = (int16_t)tv[k2]; ++o; }
-          items[t_jidx[3 * tt + k]].push_back(it);
+          for (int k2 = 0; k2 < nv; ++k2) if (k2 != k) { (o == 0 ? it.va : (o == 1 ? it.vb : it.vc)) = (int16_t)tv[k2]; ++o; }
+          items[t_jidx[OMGX_TV * tt + k]].push_back(it);
         }
       }
       je_ptr.assign(1, 0); je_item.clear(); jv_list.clear();
@@ -519,7 +505,7 @@ struct HostPlan {
         jv_glen.assign((no + 63) / 64 + 1, 0);
         int steps = 0;
         for (int i = 0; i < no; ++i) { const int len = (je_ptr[jv_list[i] + 1] - je_ptr[jv_list[i]] + 3) / 4 * 4; jv_glen[i >> 6] = std::max(jv_glen[i >> 6], len); steps = std::max(steps, len); }
-        jv_ell.assign((size_t)std::max(1, steps) * std::max(1, no), JItem{0.0, -1, -1, -1});
+        jv_ell.assign((size_t)std::max(1, steps) * std::max(1, no), JItem{0.0, -1, -1, -1, -1});
         for (int i = 0; i < no; ++i) for (int k = je_ptr[jv_list[i]]; k < je_ptr[jv_list[i] + 1]; ++k) jv_ell[(size_t)(k - je_ptr[jv_list[i]]) * no + i] = je_item[k];
         T.jv_ell = jv_ell.data(); T.jv_glen = jv_glen.data();
       }
@@ -532,13 +518,13 @@ struct HostPlan {
         ja_glen.assign((no + 63) / 64 + 1, 0);
         int steps = 0;
         for (int i = 0; i < no; ++i) { const int len = (je_ptr[ja_list[i] + 1] - je_ptr[ja_list[i]] + 3) / 4 * 4; ja_glen[i >> 6] = std::max(ja_glen[i >> 6], len); steps = std::max(steps, len); }
-        ja_ell.assign((size_t)std::max(1, steps) * std::max(1, no), JItem{0.0, -1, -1, -1});
+        ja_ell.assign((size_t)std::max(1, steps) * std::max(1, no), JItem{0.0, -1, -1, -1, -1});
         for (int i = 0; i < no; ++i) for (int k = je_ptr[ja_list[i]]; k < je_ptr[ja_list[i] + 1]; ++k) ja_ell[(size_t)(k - je_ptr[ja_list[i]]) * no + i] = je_item[k];
         T.ja_list = ja_list.data(); T.ja_ell = ja_ell.data(); T.ja_glen = ja_glen.data();
       }
-      if (je_item.empty()) je_item.push_back(JItem{0.0, -1, -1, -1});
+      if (je_item.empty()) je_item.push_back(JItem{0.0, -1, -1, -1, -1});
       if (jv_list.empty()) jv_list.push_back(0);
-      T.je_ptr = je_ptr.data(); T.je_item = je_item.data(); T.jv_list = jv_list.data();
+      T.jv_list = jv_list.data();
     }
     // (2) rows by decreasing term count: the threads of the first pass get the long rows
     {
@@ -552,12 +538,13 @@ struct HostPlan {
         rt_glen.assign((m + 63) / 64 + 1, 0);
         int steps = 0;
         for (int i = 0; i < m; ++i) { const int r = row_perm[i]; const int len = (t.row_ptr[r + 1] - t.row_ptr[r] + 7) / 8 * 8; rt_glen[i >> 6] = std::max(rt_glen[i >> 6], len); steps = std::max(steps, len); }
-        rt_ell.assign((size_t)std::max(1, steps) * std::max(1, m), RowTerm{0.0, -1, -1, -1, -1, 0});
+        rt_ell.assign((size_t)std::max(1, steps) * std::max(1, m), RowTerm{0.0, -1, -1, -1, -1, -1});
         for (int i = 0; i < m; ++i) {
           const int r = row_perm[i];
           for (int tt = t.row_ptr[r]; tt < t.row_ptr[r + 1]; ++tt) {
-            RowTerm q; q.coef = t.t_coef[tt]; q.slot = t.t_slot[tt]; q.pad = 0;
-            q.v0 = (int16_t)t.t_var[3 * tt]; q.v1 = (int16_t)t.t_var[3 * tt + 1]; q.v2 = (int16_t)t.t_var[3 * tt + 2];
+            RowTerm q; q.coef = t.t_coef[tt]; q.slot = t.t_slot[tt];
+            q.v0 = (int16_t)t.t_var[OMGX_TV * tt]; q.v1 = (int16_t)t.t_var[OMGX_TV * tt + 1]; q.v2 = (int16_t)t.t_var[OMGX_TV * tt + 2];
+            q.v3 = (int16_t)t.t_var[OMGX_TV * tt + 3];
             rt_ell[(size_t)(tt - t.row_ptr[r]) * m + i] = q;
           }
         }
@@ -682,17 +669,17 @@ struct HostPlan {
       // ---- Hessian items: one per (nonlinear term, variable pair), added to the store after the pairs
       struct HI { HItem it; int pa, pb; };
       std::vector<HI> his;
-      for (const HessRec& h : hrec) {
-        if (h.v0 < 0) continue;
-        const int16_t v[3] = {h.v0, h.v1, h.v2}, pp[3] = {h.p0, h.p1, h.p2};
-        const int32_t ha[3] = {h.ha0, h.ha1, h.ha2};
-        const int pr[3][3] = {{0, 1, 2}, {0, 2, 1}, {1, 2, 0}};
-        const int npair = h.v2 < 0 ? 1 : 3;
-        for (int k = 0; k < npair; ++k) {
-          HI x; x.it.coef = h.coef; x.it.slot = h.slot; x.it.row = h.row; x.it.target = ha[k];
-          x.it.vthird = h.v2 < 0 ? (int16_t)-1 : v[pr[k][2]];
-          x.it.kind = (v[pr[k][0]] == v[pr[k][1]]) ? 1 : 0;
-          x.pa = pp[pr[k][0]]; x.pb = pp[pr[k][1]];
+      for (const HessTerm& h : hrec) {
+        int q = 0;
+        for (int i = 0; i < OMGX_TV; ++i) for (int j = i + 1; j < OMGX_TV; ++j, ++q) {
+          if (j >= h.nv) continue;
+          HI x; x.it.coef = h.coef; x.it.slot = (int16_t)h.slot; x.it.row = h.row; x.it.target = h.ha[q];
+          // the factors that stay: the term without factors i and j
+          x.it.vthird = -1; x.it.vfourth = -1;
+          int o = 0;
+          for (int k = 0; k < h.nv; ++k) if (k != i && k != j) { (o == 0 ? x.it.vthird : x.it.vfourth) = (int16_t)h.v[k]; ++o; }
+          x.it.kind = (h.v[i] == h.v[j]) ? 1 : 0;
+          x.pa = h.p[i]; x.pb = h.p[j];
           his.push_back(x);
         }
       }
@@ -707,7 +694,7 @@ struct HostPlan {
         for (auto& run : runs) { Seg g; g.target = run.first; g.items = run.second; segs.push_back(g); }
         std::vector<std::vector<std::pair<int, int>>> per; deal(segs, per);
         d.kh_len = ell_len(per);
-        kh_rec.assign((size_t)OMGX_NBIN * std::max(1, d.kh_len), HItem{0.0, -1, 0, -1, -1, 0});
+        kh_rec.assign((size_t)OMGX_NBIN * std::max(1, d.kh_len), HItem{0.0, 0, -1, -1, -1, -1, 0});
         for (int bb = 0; bb < OMGX_NBIN; ++bb) for (size_t r = 0; r < per[bb].size(); ++r) {
           HItem it = his[per[bb][r].first].it; it.target = per[bb][r].second;
           kh_rec[r * OMGX_NBIN + bb] = it;
@@ -732,7 +719,7 @@ struct HostPlan {
         if (n_side_g > n_side) n_side = n_side_g;
         std::vector<std::vector<std::pair<int, int>>> per; deal(segs, per);
         d.kg_len = ell_len(per);
-        kg_rec.assign((size_t)OMGX_NBIN * std::max(1, d.kg_len), HItem{0.0, -1, 0, -1, -1, 0});
+        kg_rec.assign((size_t)OMGX_NBIN * std::max(1, d.kg_len), HItem{0.0, 0, -1, -1, -1, -1, 0});
         for (int bb = 0; bb < OMGX_NBIN; ++bb) for (size_t r = 0; r < per[bb].size(); ++r) {
           HItem it = gis[per[bb][r].first].it;
           const int tg = per[bb][r].second;

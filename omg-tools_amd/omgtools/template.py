@@ -10,7 +10,7 @@ vector p is a handful of integer/float arrays:
   ppolys     polynomials over atoms (CSR over monomials over atom indices)
   slots      per-agent scalars: slot s = ppoly[slot_pp[s]](a)
   terms      row r:  g_r(x) = sum_t  coef_t * S_t * prod_{v in vars_t} x_v,
-             S_t = 1 if slot_t < 0 else slot value; <= 3 variables per term;
+             S_t = 1 if slot_t < 0 else slot value; <= 4 variables per term;
              row n_con holds the objective.
 
 The x / p / g orderings are the reference's (`optilayer.py:225-272`).
@@ -20,7 +20,7 @@ import numpy as np
 from .symbolic import Poly, is_atom, _ATOM_BASE
 
 OP_DIV, OP_BSPL = 0, 1
-MAX_TERM_VARS = 3
+MAX_TERM_VARS = 4      # = OMGX_TERM_VARS of include/omgx.h
 
 
 class NLPTemplate(object):

@@ -317,7 +317,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
     # inertia correction acts on the variables that appear in a nonlinear term only: the rows
     # and columns of the Lagrangian Hessian of the others are zero, so negative curvature
     # cannot come from them (their block of J' Sigma J is positive definite)
-    tv = np.asarray(nlp.t_var).reshape(-1, 3)
+    tv = np.asarray(nlp.t_var)
     nl = np.zeros(N, bool)
     multi = (tv >= 0).sum(axis=1) >= 2
     nl[np.unique(tv[multi][tv[multi] >= 0])] = True

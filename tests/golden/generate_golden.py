@@ -214,6 +214,23 @@ def main():
     problem.init()
     dump(problem, 'freeend_holonomic', rng)
 
+    # free end time with the 2-norm velocity / acceleration limits and moving obstacles (`examples/p2p_holonomic_balls.py`):
+    # ddx^2 + ddy^2 <= (T^2 a_max)^2 is of degree 4 in the variables (`vehicles/holonomic.py:83-91`)
+    vehicle = Holonomic(shapes=sh.Circle(0.2), options={'syslimit': 'norm_2'})
+    vehicle.define_knots(knot_intervals=10)
+    vehicle.set_initial_conditions([-4., 0])
+    vehicle.set_terminal_conditions([4., 0])
+    environment = Environment(room={'shape': sh.Square(10.)})
+    environment.add_obstacle(Obstacle({'position': [0., -0.5]}, shape=sh.Circle(0.75), simulation={
+        'trajectories': {'velocity': {'time': [0, 4.5], 'values': [[0., 0.0], [0., 0.35]]}}}))
+    environment.add_obstacle(Obstacle({'position': [2., 0.5]}, shape=sh.Circle(0.75)))
+    environment.add_obstacle(Obstacle({'position': [-2., 0.5]}, shape=sh.Circle(0.75)))
+    environment.add_obstacle(Obstacle({'position': [0., -2.25]}, shape=sh.Circle(0.75), simulation={
+        'trajectories': {'velocity': {'time': [0, 5.], 'values': [[0., 0.0], [0., 0.25]]}}}))
+    problem = Point2point(vehicle, environment, options=quiet, freeT=True)
+    problem.init()
+    dump(problem, 'freeT_balls_norm2', rng)
+
     # spline known-answer matrices straight from the reference's spline algebra
     rs, rx = m['basics.spline'], m['basics.spline_extra']
     kats = {}

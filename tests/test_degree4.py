@@ -1,0 +1,152 @@
+"""Terms of degree 4 in the variables: a free end time with the 2-norm limits of
+`vehicles/holonomic.py:54-58, 67-72` -- ddx^2 + ddy^2 <= (T^2 a_max)^2 -- as in the reference's
+`examples/p2p_holonomic_balls.py` (free T, moving circles).  The NLP itself is pinned to the reference's construct code
+by tests/test_golden_nlp.py (`freeT_balls_norm2`); here:
+
+  CPU  the oracle's Jacobian and Hessian statements against central differences of its own g (the general-degree
+       restatement in oracle/nlp_numpy.py), the host build of the kernel source against scipy SLSQP from the reference's
+       initial guess, and iterate for iterate against the dense numpy solver;
+  GPU  the kernel's derivative tables (`omgx_batch_eval`) against the oracle, the HIP solve against SLSQP and the host
+       build, a template-file round trip of the wider term records."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope='module')
+def balls():
+    import omgtools.backend as be
+    from test_golden_nlp import build
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        pr = build('freeT_balls_norm2')
+        pr.reinitialize()
+    finally:
+        be.create_nlp = saved
+    fa, tpl = pr.father, pr.father.template
+    x0 = np.asarray(fa.get_variables()).reshape(-1).copy()
+    p = fa.set_parameters(0.).cat.copy()
+    sl = slice(*tpl.entry_range(pr.vehicles[0].label, 'splines_seg0', 'var'))
+    assert tpl.t_var.shape[1] == 4 and tpl.t_nv.max() == 4 and (tpl.t_nv == 4).sum() > 0
+    return pr, tpl, p, x0, sl
+
+
+def test_oracle_derivatives_of_quartic_terms(balls):
+    from oracle.nlp_numpy import NumpyNLP
+    pr, tpl, p, x0, sl = balls
+    nlp = NumpyNLP(tpl)
+    rng = np.random.default_rng(11)
+    x = x0 + rng.normal(scale=0.3, size=x0.shape)
+    lam = rng.normal(size=tpl.n_con)
+    c = nlp.term_coefs(p)
+    J, H = nlp.jac(x, c), nlp.hess(x, lam, c)
+    assert np.array_equal(H, H.T)
+    quartic = np.unique(tpl.t_var[tpl.t_nv == 4])
+    h = 1e-6
+    for j in list(quartic[:3]) + list(rng.choice(tpl.n_var, size=3, replace=False)):
+        e = np.zeros_like(x); e[j] = h
+        (fp, gp), (fm, gm) = nlp.fg(x + e, c), nlp.fg(x - e, c)
+        fd = np.r_[gp - gm, fp - fm] / (2 * h)
+        assert np.abs(fd - J[:, j]).max() < 1e-6 * max(1.0, np.abs(fd).max()), j
+        Jp, Jm = nlp.jac(x + e, c), nlp.jac(x - e, c)
+        fdh = ((Jp[-1] + lam @ Jp[:-1]) - (Jm[-1] + lam @ Jm[:-1])) / (2 * h)
+        assert np.abs(fdh - H[:, j]).max() < 1e-5 * max(1.0, np.abs(fdh).max()), j
+    # Gershgorin sums of the inertia correction: H + diag(G) is diagonally dominant term by term
+    G = nlp.hess_gershgorin(x, lam, c)
+    assert (G >= np.abs(H).sum(axis=1) - np.abs(np.diag(H)) - np.maximum(np.diag(H), 0.0) - 1e-9).all()
+
+
+def test_port_reaches_the_slsqp_minimum_and_follows_the_numpy_solver(balls):
+    from oracle import port_binding, ipm_numpy
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    from slsqp_reference import solve_slsqp
+    pr, tpl, p, x0, sl = balls
+    nlp = NumpyNLP(tpl)
+    xs, fs, ok = solve_slsqp(nlp, tpl, x0, p)
+    assert ok
+    res = port_binding.solve(tpl, p[None], x0[None], tol=1e-6, max_iter=500)
+    assert res['status'][0] == 0 and res['iters'][0] < 120
+    f = nlp.fg(res['x'][0], nlp.term_coefs(p))[0]
+    assert abs(f - fs) < 1e-5 * (1 + abs(f))                    # the objective is the motion time T
+    assert np.abs(res['x'][0][sl] - xs[sl]).max() < 1e-4
+    assert_kkt(nlp, tpl, p, res['x'][0], res['lam_g'][0], 1e-5, 'balls')
+    # the same iterates as the dense numpy restatement of the solver
+    for iters in (3, 12):
+        a = port_binding.solve(tpl, p[None], x0[None], tol=1e-12, max_iter=iters)
+        b = ipm_numpy.solve(nlp, x0, p, tpl.lb, tpl.ub, opts={'tol': 1e-12, 'max_iter': iters})
+        assert b['iters'] == a['iters'][0] == iters
+        assert np.abs(a['x'][0] - b['x']).max() < 1e-8 * max(1.0, np.abs(b['x']).max()), iters
+
+
+@pytest.mark.gpu
+def test_device_tables_of_quartic_terms(balls, tmp_path):
+    import omgtools.backend as be
+    from oracle.nlp_numpy import NumpyNLP
+    pr, tpl, p, x0, sl = balls
+    nlp = NumpyNLP(tpl)
+    rng = np.random.default_rng(12)
+    B = 3
+    x = x0[None] + rng.normal(scale=0.3, size=(B, tpl.n_var))
+    ps = np.repeat(p[None], B, axis=0)
+    lam = rng.normal(size=(B, tpl.n_con))
+    solver = be.BatchSolver(tpl, B)
+    try:
+        got = solver.eval(ps, x, lam)
+    finally:
+        solver.close()
+    c = nlp.term_coefs(p)
+    for b in range(B):
+        f, g = nlp.fg(x[b], c)
+        J, H = nlp.jac(x[b], c), nlp.hess(x[b], lam[b], c)
+        assert np.abs(got['g'][b] - g).max() < 1e-10 * max(1.0, np.abs(g).max())
+        assert abs(got['f'][b] - f) < 1e-10 * max(1.0, abs(f))
+        assert np.abs(got['jac'][b] - J).max() < 1e-10 * max(1.0, np.abs(J).max())
+        assert np.abs(got['hess'][b] - H).max() < 1e-10 * max(1.0, np.abs(H).max())
+    # the template file carries four variables per term
+    path = be.save_template(tpl, str(tmp_path / 'balls.omgx'))
+    assert open(path, 'rb').read(8) == b'OMGXTPL4'
+
+
+@pytest.mark.gpu
+def test_hip_solves_the_quartic_problem_like_slsqp_and_the_port(balls):
+    import omgtools.backend as be
+    from oracle import port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    from slsqp_reference import solve_slsqp
+    pr, tpl, p, x0, sl = balls
+    nlp = NumpyNLP(tpl)
+    xs, fs, ok = solve_slsqp(nlp, tpl, x0, p)
+    assert ok
+    # a batch: the reference's start and goal, and three more goals
+    B = 4
+    ps = np.repeat(p[None], B, axis=0)
+    o_T = tpl.entry_range(pr.vehicles[0].label, 'poseT', 'par')[0]
+    ps[1:, o_T + 1] += [0.6, -0.8, 1.5]
+    xb = np.repeat(x0[None], B, axis=0)
+    solver = be.BatchSolver(tpl, B, options=dict(tol=1e-6, max_iter=500))
+    try:
+        res = solver.solve(ps, xb)
+        again = solver.solve(ps, xb)
+    finally:
+        solver.close()
+    assert (res['status'] == 0).all(), res['status']
+    assert np.array_equal(res['x'], again['x'])                             # bit-identical between runs
+    f = nlp.fg(res['x'][0], nlp.term_coefs(p))[0]
+    assert abs(f - fs) < 1e-5 * (1 + abs(f))
+    assert np.abs(res['x'][0][sl] - xs[sl]).max() < 1e-4
+    for b in range(B):
+        assert_kkt(nlp, tpl, ps[b], res['x'][b], res['lam_g'][b], 1e-5, ('balls', b))
+    port = port_binding.solve(tpl, ps, xb, tol=1e-6, max_iter=500)
+    assert np.array_equal(port['status'], res['status'])
+    assert np.abs(port['x'][:, sl] - res['x'][:, sl]).max() < 1e-4
+    # iterate for iterate against the host build of the same source
+    for iters in (3, 12):
+        s2 = be.BatchSolver(tpl, B, options=dict(tol=1e-12, max_iter=iters))
+        try:
+            a = s2.solve(ps, xb)
+        finally:
+            s2.close()
+        b_ = port_binding.solve(tpl, ps, xb, tol=1e-12, max_iter=iters)
+        assert np.abs(a['x'] - b_['x']).max() < 1e-8 * max(1.0, np.abs(b_['x']).max()), iters

@@ -69,7 +69,7 @@ def check_steps(solve_step, f_tol=1e-5, x_tol=2e-3):
 # tol / 10 (the solve ends there too: objective within 1e-5 of SLSQP's), 0.1 = BatchP2P's setting (a solve may end as soon
 # as the complementarity is at the tolerance, a few barrier updates earlier: the objective then carries a gap of the order
 # (active rows) x mu, 1.7e-5 at most here, and the coefficients on a nearly flat face move with it: 2.6e-3 at most on the
-# HIP path, 6e-4 on the host build, which ends that solve an iteration later)
+# HIP path, 6e-4 on the host build, in the same number of iterations: rounding decides where on the face a solve ends)
 FACTORS = [(0.0, 1e-5, 2e-3), (0.1, 3e-5, 4e-3)]
 
 

@@ -105,12 +105,27 @@ def build(tag):
         environment = Environment(room={'shape': Square(5.)})
         environment.add_obstacle(Obstacle({'position': [0.2, -0.4]}, shape=Circle(0.4)))
         problem = FreeEndPoint2point(vehicle, environment, quiet, {vehicle: [0]})
+    elif tag == 'freeT_balls_norm2':
+        # `examples/p2p_holonomic_balls.py`: free end time, 2-norm limits (terms of degree 4 in the variables), moving circles
+        vehicle = Holonomic(shapes=Circle(0.2), options={'syslimit': 'norm_2'})
+        vehicle.define_knots(knot_intervals=10)
+        vehicle.set_initial_conditions([-4., 0])
+        vehicle.set_terminal_conditions([4., 0])
+        environment = Environment(room={'shape': Square(10.)})
+        environment.add_obstacle(Obstacle({'position': [0., -0.5]}, shape=Circle(0.75), simulation={
+            'trajectories': {'velocity': {'time': [0, 4.5], 'values': [[0., 0.0], [0., 0.35]]}}}))
+        environment.add_obstacle(Obstacle({'position': [2., 0.5]}, shape=Circle(0.75)))
+        environment.add_obstacle(Obstacle({'position': [-2., 0.5]}, shape=Circle(0.75)))
+        environment.add_obstacle(Obstacle({'position': [0., -2.25]}, shape=Circle(0.75), simulation={
+            'trajectories': {'velocity': {'time': [0, 5.], 'values': [[0., 0.0], [0., 0.25]]}}}))
+        problem = Point2point(vehicle, environment, options=quiet, freeT=True)
     problem.init()
     return problem
 
 
 TAGS = ['cfg1_p2p_holonomic', 'cfg2_holonomic_k11_o3', 'holonomic_rectangles',
-        'holonomic3d_spheres', 'quadrotor_k13_o2', 'freeT_holonomic', 'interveh_holonomic', 'freeend_holonomic']
+        'holonomic3d_spheres', 'quadrotor_k13_o2', 'freeT_holonomic', 'interveh_holonomic', 'freeend_holonomic',
+        'freeT_balls_norm2']
 
 
 @pytest.mark.parametrize('tag', TAGS)
