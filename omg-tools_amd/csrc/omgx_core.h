@@ -498,11 +498,31 @@ OMGX_FN void bspl_row(const double* k, int n_knots, int deg, double u, double* o
   const int n_fun = n_knots - deg - 1;
   int j = deg;                                               // first non-degenerate span
   for (int q = deg + 1; q < n_fun; ++q) if (k[q] < u) j = q;
+  const bool inside = (u >= k[0]) && (u <= k[n_knots - 1]);
+  if (deg > 5) {
+    // bases of products and integrals of splines (degree 10 in the tangent-half-angle models): the same recurrence with
+    // the values kept in the output row itself (N[r] ends up at out[j - deg + r]), left / right recomputed from the knots
+    for (int i = 0; i < n_fun; ++i) out[i] = 0.0;
+    if (!inside) return;
+    double* Nv = out + (j - deg);
+    Nv[0] = 1.0;
+    for (int r = 1; r <= deg; ++r) {
+      double saved = 0.0;
+      for (int q = 0; q < r; ++q) {
+        const double rgt = k[j + q + 1] - u, lft = u - k[j + 1 - (r - q)];
+        const double den = rgt + lft;
+        const double temp = den != 0.0 ? Nv[q] / den : 0.0;
+        Nv[q] = saved + rgt * temp;
+        saved = lft * temp;
+      }
+      Nv[r] = saved;
+    }
+    return;
+  }
   double N[6], left[6], right[6];
 #pragma unroll
   for (int r = 0; r < 6; ++r) { N[r] = 0.0; left[r] = 0.0; right[r] = 0.0; }
   N[0] = 1.0;
-  const bool inside = (u >= k[0]) && (u <= k[n_knots - 1]);
 #pragma unroll
   for (int r = 1; r <= 5; ++r) {
     if (r <= deg) {

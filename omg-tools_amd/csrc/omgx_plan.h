@@ -268,7 +268,7 @@ struct HostPlan {
     if (t.n_var <= 0 || t.n_con < 0 || t.n_terms < 0 || t.n_var >= 32767) return fail("bad dimensions");
     if (t.row_ptr[t.n_con + 1] != t.n_terms) return fail("row_ptr does not cover the terms");
     for (int k = 0; k < d.n_prog; ++k)                          // bspl_row holds a triangle of degree <= 5
-      if (t.prog[6 * k] == OP_BSPL && (t.prog[6 * k + 3] < 0 || t.prog[6 * k + 3] > 5)) return fail("basis degree > 5");
+      if (t.prog[6 * k] == OP_BSPL && (t.prog[6 * k + 3] < 0 || t.prog[6 * k + 3] > 32)) return fail("basis degree > 32");
     if (!build_structure(t)) return false;
     d.nr = d.n_root + d.n_eq;
     blk.assign(d.N, -1);

@@ -238,6 +238,40 @@ class NLPTemplate(object):
                     t_slot=self.t_slot, t_nv=self.t_nv, t_var=self.t_var)
 
 
+    # ------------------------------------------------------------- files
+    _SCALARS = ('n_var', 'n_par', 'n_con', 'n_atoms', 'n_slots', 'n_terms')
+
+    def to_npz(self, path, **extra):
+        """The template as one .npz (flat arrays, bounds, layouts): fixtures of problem classes whose front end is not in
+        this package (tests/golden/dubins_fixedT.npz comes from the reference's own Dubins class on `omgx_shim`)."""
+        lay = {}
+        for which in ('var', 'par', 'con'):
+            table = self.block_table(which)
+            lay[which + '_names'] = np.array(['%s\t%s' % (label, name) for label, name, _, _, _ in table])
+            lay[which + '_dims'] = np.array([[off, r, c] for _, _, off, r, c in table], dtype=np.int64).reshape(-1, 3)
+        np.savez_compressed(path, lb=self.lb, ub=self.ub, x_init=getattr(self, 'x_init', np.zeros(self.n_var)),
+                            scalars=np.array([getattr(self, k) for k in self._SCALARS], dtype=np.int64),
+                            **self.flat_arrays(), **lay, **extra)
+        return path
+
+    @classmethod
+    def from_npz(cls, path):
+        d = np.load(path)
+        self = cls()
+        for k, v in zip(cls._SCALARS, d['scalars']):
+            setattr(self, k, int(v))
+        for k in ('prog', 'knots', 'pp_ptr', 'pm_coef', 'pm_ptr', 'pm_atom', 'slot_pp', 'row_ptr', 't_coef', 't_slot',
+                  't_nv', 't_var', 'lb', 'ub', 'x_init'):
+            setattr(self, k, d[k])
+        for which in ('var', 'par', 'con'):
+            layout = {}
+            for key, (off, r, c) in zip(d[which + '_names'], d[which + '_dims']):
+                label, name = str(key).split('\t')
+                layout[(label, name)] = (int(off), int(r), int(c))
+            setattr(self, which + '_layout', layout)
+        return self
+
+
 def father_init_vector(father, attr, layout):
     out = np.zeros(sum(r * c for _, r, c in layout.values()))
     for label, child in father.children.items():

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""tests/golden/dubins_fixedT.npz: the NLP of the reference's OWN Dubins class (`vehicles/dubins.py:47`, tangent-half-angle
+model; `examples/p2p_dubins.py` with a fixed horizon and without the substituted velocity splines, so that the hyperplane
+rows a . integral(v_til (1 - tg_ha^2)) are of degree 4 in the variables) as a flat template, produced by executing the
+reference's modules on `omgx_shim` (tests/helpers/run_reference_on_shim.py, this container only), together with
+
+  p0, x0         parameters and initial guess of the first solve (`Problem.reinitialize`)
+  xs, ps, fs, gs values of the reference's own f / g graphs at three random points (the shim evaluates the closures the
+                 reference built; graph vs template agree to 1e-15 in the helper)
+  x_slsqp, f_slsqp   scipy SLSQP on the restated NLP from x0 (the independent solver of tests/slsqp_reference.py)
+
+Run in the build container:  python tests/golden/generate_dubins.py"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def main():
+    tmp = os.path.join(HERE, '_dubins_tmp.npz')
+    env = dict(os.environ, SHIM_TEMPLATE=tmp, DUBINS_SUBST='0', DUBINS_FREET='0', SHIM_DUMP=os.path.join(HERE, '_dubins_dump.npz'))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'helpers', 'run_reference_on_shim.py'), 'p2p_dubins'],
+                       capture_output=True, text=True, env=env)
+    print(r.stdout[-600:])
+    assert 'SHIM_RESULT' in r.stdout, r.stderr[-3000:]
+    from omgtools.template import NLPTemplate
+    from oracle.nlp_numpy import NumpyNLP
+    from slsqp_reference import solve_slsqp
+    tpl = NLPTemplate.from_npz(tmp)
+    d = dict(np.load(tmp))
+    nlp = NumpyNLP(tpl)
+    xs, fs, ok = solve_slsqp(nlp, tpl, d['x0'], d['p0'])
+    assert ok
+    print('SLSQP f', fs)
+    np.savez_compressed(os.path.join(HERE, 'dubins_fixedT.npz'), x_slsqp=xs, f_slsqp=fs, **d)
+    os.remove(tmp)
+    os.remove(env['SHIM_DUMP'])
+
+
+if __name__ == '__main__':
+    main()

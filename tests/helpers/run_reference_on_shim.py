@@ -62,6 +62,20 @@ elif which == 'p2p_holonomic_rect':
     environment.add_obstacle(Obstacle({'position': [1.7, -0.5]}, shape=rectangle))
     problem = Point2point(vehicle, environment, freeT=False)
     target = [2., 2.]
+elif which == 'p2p_dubins':
+    # body of the reference's examples/p2p_dubins.py:22-44: tangent-half-angle model with the substituted velocity
+    # splines (rows of degree 4 in the variables: T v_til tg_ha^2), free end time, a moving circle
+    vehicle = Dubins(bounds={'vmax': 0.7, 'wmax': np.pi/3., 'wmin': -np.pi/3.}, options={'substitution': os.environ.get('DUBINS_SUBST', '1') == '1'})
+    vehicle.define_knots(knot_intervals=5)
+    vehicle.set_initial_conditions([0., 0., 0.])
+    vehicle.set_terminal_conditions([3., 3., 0.])
+    environment = Environment(room={'shape': Square(5.), 'position': [1.5, 1.5]})
+    trajectories = {'velocity': {'time': [0.5], 'values': [[0.25, 0.0]]}}
+    environment.add_obstacle(Obstacle({'position': [1., 1.]}, shape=Circle(0.5),
+                                      simulation={'trajectories': trajectories}))
+    problem = Point2point(vehicle, environment, freeT=os.environ.get('DUBINS_FREET', '0') == '1')
+    vehicle.problem = problem
+    target = [3., 3., 0.]
 else:
     raise SystemExit('unknown case')
 problem.set_options({'verbose': 0})
@@ -95,9 +109,15 @@ out['graph_vs_template'] = err
 np.savez(os.environ.get('SHIM_DUMP', '/tmp/shim_dump.npz'), lb=tpl.lb, ub=tpl.ub, x0=x0, p0=p0,
          row_ptr=tpl.row_ptr, xs=np.array([q[0] for q in pts]), ps=np.array([q[1] for q in pts]),
          fs=np.array([q[2] for q in pts]), gs=np.array([q[3] for q in pts]))
-simulator = Simulator(problem)
-simulator.run()
-state = vehicle.signals['state'][:, -1]
-out.update(final_error=float(np.abs(state - np.array(target)).max()), steps=len(problem.update_times),
-           statuses_ok=True)
+if os.environ.get('SHIM_TEMPLATE'):
+    # the template itself as a fixture (tests/golden/generate_dubins.py): problem classes whose front end only the
+    # reference has travel to the GPU box this way
+    tpl.to_npz(os.environ['SHIM_TEMPLATE'], p0=p0, x0=x0, xs=np.array([q[0] for q in pts]), ps=np.array([q[1] for q in pts]),
+               fs=np.array([q[2] for q in pts]), gs=np.array([q[3] for q in pts]))
+if os.environ.get('SHIM_NO_SIM') != '1':
+    simulator = Simulator(problem)
+    simulator.run()
+    state = vehicle.signals['state'][:, -1]
+    out.update(final_error=float(np.abs(state - np.array(target)).max()), steps=len(problem.update_times),
+               statuses_ok=True)
 print('SHIM_RESULT ' + json.dumps(out))

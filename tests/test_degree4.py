@@ -150,3 +150,72 @@ def test_hip_solves_the_quartic_problem_like_slsqp_and_the_port(balls):
             s2.close()
         b_ = port_binding.solve(tpl, ps, xb, tol=1e-12, max_iter=iters)
         assert np.abs(a['x'] - b_['x']).max() < 1e-8 * max(1.0, np.abs(b_['x']).max()), iters
+
+
+# ---- the reference's own Dubins class (tangent-half-angle model) --------------------------------------------------------
+# tests/golden/dubins_fixedT.npz: the template `omgx_shim` derives from the reference's unmodified modules
+# (tests/golden/generate_dubins.py; the generator's full Simulator run reaches the target pose to 7e-3 in 119 updates on
+# the host build); 46,912 terms, 13,568 of them with four factors.
+@pytest.fixture(scope='module')
+def dubins():
+    import os
+    from omgtools.template import NLPTemplate
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'dubins_fixedT.npz')
+    tpl = NLPTemplate.from_npz(path)
+    d = np.load(path)
+    assert (tpl.n_var, tpl.n_con, tpl.n_par) == (105, 456, 19) and (tpl.t_nv == 4).sum() == 13568
+    return tpl, d
+
+
+def test_dubins_template_reproduces_the_reference_graphs_and_solves(dubins):
+    from oracle import port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    tpl, d = dubins
+    nlp = NumpyNLP(tpl)
+    for xv, pv, fs, gs in zip(d['xs'], d['ps'], d['fs'], d['gs']):          # values of the reference's f / g closures
+        f, g = nlp.fg(xv, nlp.term_coefs(pv))
+        assert abs(f - fs) < 1e-12 * (1 + abs(fs)) and np.abs(g - gs).max() < 1e-12 * (1 + np.abs(gs).max())
+    res = port_binding.solve(tpl, d['p0'][None], d['x0'][None], tol=1e-6, max_iter=500)
+    assert res['status'][0] == 0
+    f = nlp.fg(res['x'][0], nlp.term_coefs(d['p0']))[0]
+    assert abs(f - float(d['f_slsqp'])) < 1e-5 * (1 + abs(f))
+    off, end = [v for (lab, name), v in ((k, tpl.entry_range(k[0], k[1], 'var')) for k in tpl.var_layout)
+                if name.startswith('splines_seg')][0]
+    assert np.abs(res['x'][0][off:end] - d['x_slsqp'][off:end]).max() < 1e-4
+    assert_kkt(nlp, tpl, d['p0'], res['x'][0], res['lam_g'][0], 1e-5, 'dubins')
+
+
+@pytest.mark.gpu
+def test_dubins_on_the_device(dubins):
+    import omgtools.backend as be
+    from oracle import port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    tpl, d = dubins
+    nlp = NumpyNLP(tpl)
+    rng = np.random.default_rng(13)
+    B = 2
+    ps = np.repeat(d['p0'][None], B, axis=0)
+    x = d['x0'][None] + rng.normal(scale=0.2, size=(B, tpl.n_var))
+    lam = rng.normal(size=(B, tpl.n_con))
+    solver = be.BatchSolver(tpl, B, options=dict(tol=1e-6, max_iter=500))
+    try:
+        got = solver.eval(ps, x, lam)
+        res = solver.solve(ps, np.repeat(d['x0'][None], B, axis=0))
+    finally:
+        solver.close()
+    c = nlp.term_coefs(d['p0'])
+    for b in range(B):
+        f, g = nlp.fg(x[b], c)
+        J, H = nlp.jac(x[b], c), nlp.hess(x[b], lam[b], c)
+        assert np.abs(got['g'][b] - g).max() < 1e-10 * max(1.0, np.abs(g).max())
+        assert np.abs(got['jac'][b] - J).max() < 1e-10 * max(1.0, np.abs(J).max())
+        assert np.abs(got['hess'][b] - H).max() < 1e-10 * max(1.0, np.abs(H).max())
+    assert (res['status'] == 0).all() and np.array_equal(res['x'][0], res['x'][1])
+    f = nlp.fg(res['x'][0], c)[0]
+    assert abs(f - float(d['f_slsqp'])) < 1e-5 * (1 + abs(f))
+    assert_kkt(nlp, tpl, d['p0'], res['x'][0], res['lam_g'][0], 1e-5, 'dubins')
+    port = port_binding.solve(tpl, d['p0'][None], d['x0'][None], tol=1e-6, max_iter=500)
+    assert abs(int(port['iters'][0]) - int(res['iters'][0])) <= 6
+    assert np.abs(port['x'][0] - res['x'][0]).max() < 1e-4

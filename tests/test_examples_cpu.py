@@ -95,6 +95,46 @@ def test_free_T_point2point_reaches_target():
     check_free_T_run(*_free_T_run())
 
 
+def _balls_run():
+    """`examples/p2p_holonomic_balls.py:22-54`: free end time, 2-norm velocity / acceleration limits (rows of degree 4 in
+    the variables), two moving and two standing circles."""
+    from omgtools import Holonomic, Environment, Obstacle, Circle, Square, Point2point, Simulator
+    vehicle = Holonomic(shapes=Circle(0.2), options={'syslimit': 'norm_2'})
+    vehicle.define_knots(knot_intervals=10)
+    vehicle.set_initial_conditions([-4., 0])
+    vehicle.set_terminal_conditions([4., 0])
+    environment = Environment(room={'shape': Square(10.)})
+    trajectories1 = {'velocity': {'time': [0, 4.5], 'values': [[0., 0.0], [0., 0.35]]}}
+    trajectories2 = {'velocity': {'time': [0, 5.], 'values': [[0., 0.0], [0., 0.25]]}}
+    obstacles = [Obstacle({'position': [0., -0.5]}, shape=Circle(0.75), simulation={'trajectories': trajectories1}),
+                 Obstacle({'position': [2., 0.5]}, shape=Circle(0.75)),
+                 Obstacle({'position': [-2., 0.5]}, shape=Circle(0.75)),
+                 Obstacle({'position': [0., -2.25]}, shape=Circle(0.75), simulation={'trajectories': trajectories2})]
+    for obstacle in obstacles:
+        environment.add_obstacle(obstacle)
+    problem = Point2point(vehicle, environment, options={'verbose': 0}, freeT=True)
+    problem.init()
+    trajectories, signals = Simulator(problem).run()
+    return problem, signals, obstacles
+
+
+def check_balls_run(problem, signals, obstacles):
+    state = signals['state']
+    assert problem.father.template.t_nv.max() == 4
+    assert np.linalg.norm(state[:, -1] - np.array([4., 0.])) < 1e-2
+    assert np.linalg.norm(signals['input'], axis=0).max() <= 0.5 + 1e-3          # |v|_2 <= vmax (`holonomic.py:54-58`)
+    t_end = signals['time'][0, -1]
+    assert 16.0 < t_end < 30.0                                                   # 8 m at 0.5 m/s: >= 16 s
+    for obstacle in obstacles:
+        n = min(state.shape[1], obstacle.signals['position'].shape[1])
+        dist = np.linalg.norm(state[:, :n] - obstacle.signals['position'][:, :n], axis=0)
+        assert dist.min() >= 0.75 + 0.2 - 2e-2
+
+
+def test_free_T_with_two_norm_limits_and_moving_circles():
+    check_balls_run(*_balls_run())
+
+
 def _interveh_run(N=2):
     """`examples/p2p_holonomic_interveh_avoidance.py:22-48`: vehicles swap places through the centre."""
     from omgtools import Holonomic, Environment, Square, Point2point, Simulator

@@ -61,6 +61,12 @@ def test_free_T_point2point_runs_to_target():
     check_free_T_run(*_free_T_run())
 
 
+def test_balls_example_with_quartic_rows_runs_to_target():
+    """`examples/p2p_holonomic_balls.py` (free end time, 2-norm limits: rows of degree 4) on the HIP path."""
+    from test_examples_cpu import _balls_run, check_balls_run
+    check_balls_run(*_balls_run())
+
+
 def test_intervehicle_avoidance_example_runs_to_target():
     """`examples/p2p_holonomic_interveh_avoidance.py` on the HIP path."""
     from test_examples_cpu import _interveh_run, check_interveh_run
