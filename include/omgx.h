@@ -60,7 +60,10 @@ extern "C" {
 typedef struct omgx_template {
   int32_t n_var, n_par, n_con, n_atoms, n_slots, n_terms;
   int32_t n_prog, n_knots, n_pp, n_mono, n_matom;
-  const int32_t* prog;      /* [n_prog*6] derived-atom program */
+  const int32_t* prog;      /* [n_prog*6] derived-atom program, executed in order; entry = {op, a, b, c, d, e}:
+                             *   op 0  atom[c] = ppoly a / ppoly b
+                             *   op 1  atoms[e ..] = the basis functions of (knots[a .. a+b), degree c) at atom d
+                             *   op 2  atom[c] = cos(ppoly a)      op 3  atom[c] = sin(ppoly a) */
   const double*  knots;     /* [n_knots] */
   const int32_t* pp_ptr;    /* [n_pp+1] */
   const double*  pm_coef;   /* [n_mono] */

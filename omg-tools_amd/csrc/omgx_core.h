@@ -42,7 +42,7 @@ static std::atomic<long> omgx_dbg_cnt[8];      // 0 leaf failures, 1 root failur
 namespace omgx {
 
 enum { ROW_FREE = 0, ROW_UPPER = 1, ROW_LOWER = 2, ROW_EQ = 3, ROW_BAD = 4 };
-enum { OP_DIV = 0, OP_BSPL = 1 };
+enum { OP_DIV = 0, OP_BSPL = 1, OP_COS = 2, OP_SIN = 3 };
 
 struct Dims {
   int n_var, n_par, n_con, n_atoms, n_slots, n_terms, n_prog;
@@ -606,10 +606,13 @@ OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, co
   OMGX_TOC(PH_P_LOAD);
   for (int k = 0; k < d.n_prog;) {              // ops in order (an op may read atoms of earlier ones)
     const int32_t* op = T.prog + 6 * k;
-    if (op[0] == OP_DIV) {
-      if (c.tid() == 0)
-        w.atoms[op[3]] = d.mono_packed == 1 ? pp_eval_packed(T, op[1], w.atoms) / pp_eval_packed(T, op[2], w.atoms)
-                                       : pp_eval(T, op[1], w.atoms) / pp_eval(T, op[2], w.atoms);
+    if (op[0] != OP_BSPL) {
+      // quotient of two parameter polynomials, or cos / sin of one (orientation of a rotating obstacle)
+      if (c.tid() == 0) {
+        const double num = d.mono_packed == 1 ? pp_eval_packed(T, op[1], w.atoms) : pp_eval(T, op[1], w.atoms);
+        if (op[0] == OP_DIV) w.atoms[op[3]] = num / (d.mono_packed == 1 ? pp_eval_packed(T, op[2], w.atoms) : pp_eval(T, op[2], w.atoms));
+        else w.atoms[op[3]] = op[0] == OP_COS ? cos(num) : sin(num);
+      }
       ++k;
       c.sync();
       OMGX_TOC(PH_P_DIV);

@@ -267,8 +267,10 @@ struct HostPlan {
     d.N = t.n_var + 1; d.n_eq = t.n_eq; d.n_knots = t.n_knots;
     if (t.n_var <= 0 || t.n_con < 0 || t.n_terms < 0 || t.n_var >= 32767) return fail("bad dimensions");
     if (t.row_ptr[t.n_con + 1] != t.n_terms) return fail("row_ptr does not cover the terms");
-    for (int k = 0; k < d.n_prog; ++k)                          // bspl_row holds a triangle of degree <= 5
+    for (int k = 0; k < d.n_prog; ++k) {
       if (t.prog[6 * k] == OP_BSPL && (t.prog[6 * k + 3] < 0 || t.prog[6 * k + 3] > 32)) return fail("basis degree > 32");
+      if (t.prog[6 * k] < OP_DIV || t.prog[6 * k] > OP_SIN) return fail("unknown op in the derived-atom program");
+    }
     if (!build_structure(t)) return false;
     d.nr = d.n_root + d.n_eq;
     blk.assign(d.N, -1);

@@ -196,6 +196,21 @@ class Poly(object):
     def __rtruediv__(self, other):
         return Poly.lift(other) / self
 
+    def _unary_atom(self, kind, fun):
+        """cos / sin of a parameter-only polynomial (the orientation of a rotating obstacle, `environment/obstacle.py:299-306`:
+        cos(theta - t omega)) as a derived atom; numpy's ufuncs reach these methods on object arrays."""
+        if self.is_constant():
+            return Poly.const(float(fun(self.constant_value())))
+        if not self.is_param_only():
+            raise TypeError('%s is only defined for parameter-only polynomials' % kind)
+        return Poly.symbol(SymbolTable.current().new_fun_atom(kind, self))
+
+    def cos(self):
+        return self._unary_atom('cos', np.cos)
+
+    def sin(self):
+        return self._unary_atom('sin', np.sin)
+
     def __repr__(self):
         if not self.terms:
             return 'Poly(0)'
@@ -263,6 +278,7 @@ class SymbolTable(object):
     derived atoms evaluated in creation order by a straight-line program:
 
       ('div', num_poly, den_poly)             -> 1 atom
+      ('cos' | 'sin', arg_poly)               -> 1 atom
       ('bspl', knots, degree, u_atom)         -> len(basis) consecutive atoms,
                                                  B_i(u) with the reference's
                                                  interval convention
@@ -313,6 +329,17 @@ class SymbolTable(object):
         sym = _ATOM_BASE + self.n_atoms
         self.atom_info.append(('div', len(self.derived)))
         self.derived.append(('div', num, den, sym))
+        self.n_atoms += 1
+        self._div_cache[key] = sym
+        return sym
+
+    def new_fun_atom(self, kind, arg):
+        key = (kind, repr(arg))
+        if key in self._div_cache:
+            return self._div_cache[key]
+        sym = _ATOM_BASE + self.n_atoms
+        self.atom_info.append((kind, len(self.derived)))
+        self.derived.append((kind, arg, None, sym))
         self.n_atoms += 1
         self._div_cache[key] = sym
         return sym

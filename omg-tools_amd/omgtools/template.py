@@ -6,7 +6,7 @@ evaluate f, g, their Jacobian and the Lagrangian Hessian for *any* parameter
 vector p is a handful of integer/float arrays:
 
   atoms      a = [p (n_par) | derived atoms]; derived atoms come from a
-             straight-line program (`prog`): DIV(ppoly, ppoly) and BSPL(basis, u)
+             straight-line program (`prog`): DIV(ppoly, ppoly), BSPL(basis, u), COS(ppoly), SIN(ppoly)
   ppolys     polynomials over atoms (CSR over monomials over atom indices)
   slots      per-agent scalars: slot s = ppoly[slot_pp[s]](a)
   terms      row r:  g_r(x) = sum_t  coef_t * S_t * prod_{v in vars_t} x_v,
@@ -19,7 +19,7 @@ import numpy as np
 
 from .symbolic import Poly, is_atom, _ATOM_BASE
 
-OP_DIV, OP_BSPL = 0, 1
+OP_DIV, OP_BSPL, OP_COS, OP_SIN = 0, 1, 2, 3
 MAX_TERM_VARS = 4      # = OMGX_TERM_VARS of include/omgx.h
 
 
@@ -82,7 +82,7 @@ class NLPTemplate(object):
         self.n_con = sum(r * c for _, r, c in self.con_layout.values())
         n_atoms = self.n_par
         for entry in table.derived:
-            if entry[0] == 'div':
+            if entry[0] in ('div', 'cos', 'sin'):
                 atom_index[entry[3]] = n_atoms
                 n_atoms += 1
             else:
@@ -102,6 +102,9 @@ class NLPTemplate(object):
         for entry in table.derived:
             if entry[0] == 'div':
                 prog.append((OP_DIV, self._ppoly(entry[1]), self._ppoly(entry[2]),
+                             atom_index[entry[3]], 0, 0))
+            elif entry[0] in ('cos', 'sin'):
+                prog.append((OP_COS if entry[0] == 'cos' else OP_SIN, self._ppoly(entry[1]), 0,
                              atom_index[entry[3]], 0, 0))
             else:
                 _, kn, deg, u_sym, first = entry
@@ -199,6 +202,8 @@ class NLPTemplate(object):
         for op, i0, i1, i2, i3, i4 in self.prog:
             if op == OP_DIV:
                 a[i2] = self._pp_value(i0, a) / self._pp_value(i1, a)
+            elif op in (OP_COS, OP_SIN):
+                a[i2] = (np.cos if op == OP_COS else np.sin)(self._pp_value(i0, a))
             else:
                 basis = BSplineBasis(self.knots[i0:i0 + i1], i2)
                 a[i4:i4 + len(basis)] = basis.eval_basis([a[i3]])[0]

@@ -1,5 +1,10 @@
 #!/usr/bin/env python
-"""tests/golden/dubins_fixedT.npz: the NLP of the reference's OWN Dubins class (`vehicles/dubins.py:47`, tangent-half-angle
+"""Fixtures of problem classes only the reference's front end has, as flat templates.
+
+tests/golden/revolving_door.npz: `examples/revolving_door.py` (two rotating beams, `environment/obstacle.py:299-332`: the
+orientation enters through cos / sin of a parameter expression -- COS / SIN atoms of the template's parameter program).
+
+tests/golden/dubins_fixedT.npz: the NLP of the reference's OWN Dubins class (`vehicles/dubins.py:47`, tangent-half-angle
 model; `examples/p2p_dubins.py` with a fixed horizon and without the substituted velocity splines, so that the hyperplane
 rows a . integral(v_til (1 - tg_ha^2)) are of degree 4 in the variables) as a flat template, produced by executing the
 reference's modules on `omgx_shim` (tests/helpers/run_reference_on_shim.py, this container only), together with
@@ -9,7 +14,7 @@ reference's modules on `omgx_shim` (tests/helpers/run_reference_on_shim.py, this
                  reference built; graph vs template agree to 1e-15 in the helper)
   x_slsqp, f_slsqp   scipy SLSQP on the restated NLP from x0 (the independent solver of tests/slsqp_reference.py)
 
-Run in the build container:  python tests/golden/generate_dubins.py"""
+Run in the build container:  python tests/golden/generate_shim_fixtures.py"""
 import os
 import subprocess
 import sys
@@ -23,10 +28,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
-def main():
-    tmp = os.path.join(HERE, '_dubins_tmp.npz')
-    env = dict(os.environ, SHIM_TEMPLATE=tmp, DUBINS_SUBST='0', DUBINS_FREET='0', SHIM_DUMP=os.path.join(HERE, '_dubins_dump.npz'))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'helpers', 'run_reference_on_shim.py'), 'p2p_dubins'],
+def make(case, out_name):
+    tmp = os.path.join(HERE, '_shim_tmp.npz')
+    env = dict(os.environ, SHIM_TEMPLATE=tmp, DUBINS_SUBST='0', DUBINS_FREET='0', SHIM_DUMP=os.path.join(HERE, '_shim_dump.npz'))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'helpers', 'run_reference_on_shim.py'), case],
                        capture_output=True, text=True, env=env)
     print(r.stdout[-600:])
     assert 'SHIM_RESULT' in r.stdout, r.stderr[-3000:]
@@ -37,12 +42,15 @@ def main():
     d = dict(np.load(tmp))
     nlp = NumpyNLP(tpl)
     xs, fs, ok = solve_slsqp(nlp, tpl, d['x0'], d['p0'])
-    assert ok
-    print('SLSQP f', fs)
-    np.savez_compressed(os.path.join(HERE, 'dubins_fixedT.npz'), x_slsqp=xs, f_slsqp=fs, **d)
+    print('SLSQP f', fs, 'converged', ok)        # (slsqp_ok = 0: SLSQP gave up; the tests then rely on the KKT conditions)
+    np.savez_compressed(os.path.join(HERE, out_name), x_slsqp=xs, f_slsqp=fs, slsqp_ok=int(ok), **d)
     os.remove(tmp)
     os.remove(env['SHIM_DUMP'])
 
 
 if __name__ == '__main__':
-    main()
+    which = sys.argv[1:] or ['dubins', 'revolving_door']
+    if 'dubins' in which:
+        make('p2p_dubins', 'dubins_fixedT.npz')
+    if 'revolving_door' in which:
+        make('revolving_door', 'revolving_door.npz')

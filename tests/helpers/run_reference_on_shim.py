@@ -76,6 +76,26 @@ elif which == 'p2p_dubins':
     problem = Point2point(vehicle, environment, freeT=os.environ.get('DUBINS_FREET', '0') == '1')
     vehicle.problem = problem
     target = [3., 3., 0.]
+elif which == 'revolving_door':
+    # body of the reference's examples/revolving_door.py:23-47: two rotating beams (`environment/obstacle.py:299-332`:
+    # the hyperplane rows are multiplied by 1 + tg_ha^2 of the obstacle's orientation spline) between two standing ones
+    vehicle = Holonomic()
+    vehicle.set_initial_conditions([0., -2.0])
+    vehicle.set_terminal_conditions([0., 2.0])
+    environment = Environment(room={'shape': Square(5.)})
+    beam1 = Beam(width=2.2, height=0.2)
+    environment.add_obstacle(Obstacle({'position': [-2., 0.]}, shape=beam1))
+    environment.add_obstacle(Obstacle({'position': [2., 0.]}, shape=beam1))
+    beam2 = Beam(width=1.4, height=0.2)
+    horizon_time = 10.
+    omega = 1.5*(2*np.pi/horizon_time)
+    environment.add_obstacle(Obstacle({'position': [0., 0.], 'velocity': [0., 0.], 'angular_velocity': omega}, shape=beam2,
+                                      simulation={}, options={'horizon_time': horizon_time}))
+    environment.add_obstacle(Obstacle({'position': [0., 0.], 'velocity': [0., 0.], 'orientation': 0.5*np.pi,
+                                       'angular_velocity': omega}, shape=beam2, simulation={},
+                                      options={'horizon_time': horizon_time}))
+    problem = Point2point(vehicle, environment, freeT=False, options={'horizon_time': horizon_time})
+    target = [0., 2.]
 else:
     raise SystemExit('unknown case')
 problem.set_options({'verbose': 0})
@@ -99,6 +119,9 @@ pts = []
 for k in range(3):
     xv, pv = x0 + 0.1 * rng.standard_normal(tpl.n_var), p0.copy()
     pv[tpl.entry_range('p2p0', 't', 'par')[0]] = 0.03 * (k + 1)          # time since the last knot: exercises t/T and B(t/T)
+    for (label, name), (off, r_, c_) in tpl.par_layout.items():
+        if name == 'theta':                                               # orientation of a rotating obstacle: cos / sin atoms
+            pv[off] = rng.uniform(-3., 3.)
     env = {X: xv.reshape(-1, 1), Pm: pv.reshape(-1, 1)}
     g_ref = np.asarray(nlp_ref['g'].cat.eval(env), float).reshape(-1)
     f_ref = float(np.asarray(casadi.MX.lift(nlp_ref['f']).eval(env), float).reshape(-1)[0])
@@ -110,7 +133,7 @@ np.savez(os.environ.get('SHIM_DUMP', '/tmp/shim_dump.npz'), lb=tpl.lb, ub=tpl.ub
          row_ptr=tpl.row_ptr, xs=np.array([q[0] for q in pts]), ps=np.array([q[1] for q in pts]),
          fs=np.array([q[2] for q in pts]), gs=np.array([q[3] for q in pts]))
 if os.environ.get('SHIM_TEMPLATE'):
-    # the template itself as a fixture (tests/golden/generate_dubins.py): problem classes whose front end only the
+    # the template itself as a fixture (tests/golden/generate_shim_fixtures.py): problem classes whose front end only the
     # reference has travel to the GPU box this way
     tpl.to_npz(os.environ['SHIM_TEMPLATE'], p0=p0, x0=x0, xs=np.array([q[0] for q in pts]), ps=np.array([q[1] for q in pts]),
                fs=np.array([q[2] for q in pts]), gs=np.array([q[3] for q in pts]))

@@ -154,7 +154,7 @@ def test_hip_solves_the_quartic_problem_like_slsqp_and_the_port(balls):
 
 # ---- the reference's own Dubins class (tangent-half-angle model) --------------------------------------------------------
 # tests/golden/dubins_fixedT.npz: the template `omgx_shim` derives from the reference's unmodified modules
-# (tests/golden/generate_dubins.py; the generator's full Simulator run reaches the target pose to 7e-3 in 119 updates on
+# (tests/golden/generate_shim_fixtures.py; the generator's full Simulator run reaches the target pose to 7e-3 in 119 updates on
 # the host build); 46,912 terms, 13,568 of them with four factors.
 @pytest.fixture(scope='module')
 def dubins():
@@ -219,3 +219,58 @@ def test_dubins_on_the_device(dubins):
     port = port_binding.solve(tpl, d['p0'][None], d['x0'][None], tol=1e-6, max_iter=500)
     assert abs(int(port['iters'][0]) - int(res['iters'][0])) <= 6
     assert np.abs(port['x'][0] - res['x'][0]).max() < 1e-4
+
+
+# ---- rotating obstacles (`environment/obstacle.py:299-332`, `examples/revolving_door.py`) --------------------------------
+# tests/golden/revolving_door.npz: the template of the reference's own example on `omgx_shim`; the orientation of the two
+# rotating beams enters through cos / sin of (theta - t omega): COS / SIN atoms of the parameter program.
+@pytest.fixture(scope='module')
+def door():
+    import os
+    from omgtools.template import NLPTemplate
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'revolving_door.npz')
+    tpl = NLPTemplate.from_npz(path)
+    assert (tpl.prog[:, 0] >= 2).sum() >= 4                   # cos and sin of two beams
+    return tpl, np.load(path)
+
+
+def test_rotating_obstacle_template_reproduces_the_reference_graphs_and_solves(door):
+    from oracle import port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    tpl, d = door
+    nlp = NumpyNLP(tpl)
+    assert len(set(np.round(d['ps'][:, [off for (lab, name), (off, r, c) in tpl.par_layout.items() if name == 'theta'][0]], 6))) == 3
+    for xv, pv, fs, gs in zip(d['xs'], d['ps'], d['fs'], d['gs']):          # the reference's graphs at three orientations
+        f, g = nlp.fg(xv, nlp.term_coefs(pv))
+        assert abs(f - fs) < 1e-12 * (1 + abs(fs)) and np.abs(g - gs).max() < 1e-12 * (1 + np.abs(gs).max())
+    res = port_binding.solve(tpl, d['p0'][None], d['x0'][None], tol=1e-6, max_iter=500)
+    assert res['status'][0] == 0
+    assert_kkt(nlp, tpl, d['p0'], res['x'][0], res['lam_g'][0], 1e-5, 'door')
+
+
+@pytest.mark.gpu
+def test_rotating_obstacles_on_the_device(door):
+    import omgtools.backend as be
+    from oracle import port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    tpl, d = door
+    nlp = NumpyNLP(tpl)
+    B = 3
+    solver = be.BatchSolver(tpl, B, options=dict(tol=1e-6, max_iter=500))
+    try:
+        got = solver.eval(d['ps'], d['xs'], np.zeros((B, tpl.n_con)))        # three orientations of the beams
+        ps = np.repeat(d['p0'][None], B, axis=0)
+        res = solver.solve(ps, np.repeat(d['x0'][None], B, axis=0))
+    finally:
+        solver.close()
+    for b in range(B):
+        assert np.abs(got['g'][b] - d['gs'][b]).max() < 1e-10 * (1 + np.abs(d['gs'][b]).max())
+        J = nlp.jac(d['xs'][b], nlp.term_coefs(d['ps'][b]))
+        assert np.abs(got['jac'][b] - J).max() < 1e-10 * max(1.0, np.abs(J).max())
+    assert (res['status'] == 0).all()
+    assert_kkt(nlp, tpl, d['p0'], res['x'][0], res['lam_g'][0], 1e-5, 'door')
+    port = port_binding.solve(tpl, d['p0'][None], d['x0'][None], tol=1e-6, max_iter=500)
+    f_h, f_p = nlp.fg(res['x'][0], nlp.term_coefs(d['p0']))[0], nlp.fg(port['x'][0], nlp.term_coefs(d['p0']))[0]
+    assert abs(f_h - f_p) < 1e-5 * (1 + abs(f_p)) and abs(int(port['iters'][0]) - int(res['iters'][0])) <= 6

@@ -69,7 +69,7 @@ def test_reference_dubins_class_builds_and_solves_on_the_shim(tmp_path, monkeypa
     """a vehicle model this package's front end does not have -- the reference's own `Dubins`
     (`vehicles/dubins.py:47`, tangent-half-angle substitution; hyperplane rows of degree 4 in the variables) -- imported
     unchanged, built on the shim and solved; the committed fixture tests/golden/dubins_fixedT.npz (what the GPU tier
-    solves) is this template.  (The full Simulator run of tests/golden/generate_dubins.py takes two minutes on the host
+    solves) is this template.  (The full Simulator run of tests/golden/generate_shim_fixtures.py takes two minutes on the host
     build: 119 updates, target pose reached to 7e-3.)"""
     monkeypatch.setenv('SHIM_NO_SIM', '1')
     monkeypatch.setenv('DUBINS_SUBST', '0')
@@ -79,3 +79,15 @@ def test_reference_dubins_class_builds_and_solves_on_the_shim(tmp_path, monkeypa
     gold = np.load(os.path.join(ROOT, 'tests', 'golden', 'dubins_fixedT.npz'))
     assert np.array_equal(gold['row_ptr'], dump['row_ptr']) and np.array_equal(gold['lb'], dump['lb'])
     assert np.allclose(gold['x0'], dump['x0'], atol=1e-14) and np.allclose(gold['p0'], dump['p0'], atol=1e-14)
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason='the reference tree is only present in the build container')
+def test_reference_revolving_door_runs_on_the_shim(tmp_path):
+    """SURVEY 8(f)3, rotating obstacles: `examples/revolving_door.py` of the reference (two beams turning at 0.94 rad/s,
+    `environment/obstacle.py:299-332`) on the shim: COS / SIN atoms, the Simulator run ends at the target."""
+    out, dump = _run('revolving_door', tmp_path)
+    assert (out['n_var'], out['n_con'], out['n_par']) == (184, 862, 58)
+    assert out['first_status'] == 'Solve_Succeeded' and out['graph_vs_template'] < 1e-12
+    assert out['final_error'] < 2e-3 and out['steps'] > 50
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', 'revolving_door.npz'))
+    assert np.array_equal(gold['row_ptr'], dump['row_ptr']) and np.array_equal(gold['lb'], dump['lb'])
