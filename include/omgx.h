@@ -343,6 +343,28 @@ int  omgx_admm_communicate(omgx_batch* b, const omgx_admm_layout* lay, const int
                            const int32_t* slot, const double* z_ij_ext, const double* l_ij_ext,
                            double* p);
 
+
+/* ---- the same three steps for a fleet sharded over ranks (one process per GPU): no copies around the collectives -----
+ * The caller keeps two exchange buffers per rank, each [B + world * rows, width] with the local agents' rows on top and
+ * the all_gather result written straight behind them (nbr indexes the whole buffer):
+ *   x_all  [B + world*n_max_pub, ns]           center_ex writes the local rows and, into x_send, the published ones
+ *   zl_all [B + world*(n_max_pub + 1), 2 w]    w = n_nghb*ns; row = [z_ij | l_ij]; update_ex updates the local rows in
+ *                                               place (z_ij = zl_all, l_ij = zl_all + w, zl_stride = 2 w) and writes the
+ *                                               published rows into zl_send; `sums` may point at the extra row of
+ *                                               zl_send so that the residual sums ride along
+ *   communicate_ex reads the gathered rows (z_ij_ext = zl_all, l_ij_ext = zl_all + w) and adds up the sums rows of
+ *   all ranks (sum_rows = first extra row, sum_stride = rows * 2 w doubles between ranks) into sums_out [3].
+ * One multi-rank iteration = solve, center_ex, all_gather, update_ex, all_gather, communicate_ex. */
+int  omgx_admm_center_ex(omgx_batch* b, const omgx_admm_layout* lay, const double* x, const double* p, double* x_i,
+                         const int32_t* pub_rows, int32_t n_pub, double* x_send);
+int  omgx_admm_update_ex(omgx_batch* b, const omgx_admm_layout* lay, const double* x_ext, const int32_t* nbr,
+                         const double* M, const double* F, double rho, double* p, double* z_ij, double* l_ij,
+                         int32_t zl_stride, double* res, double* sums, const int32_t* pub_slot, double* zl_send,
+                         int32_t send_stride);
+int  omgx_admm_communicate_ex(omgx_batch* b, const omgx_admm_layout* lay, const int32_t* nbr, const int32_t* slot,
+                              const double* z_ij_ext, const double* l_ij_ext, int32_t zl_stride, double* p,
+                              const double* sum_rows, int32_t n_sum_rows, int32_t sum_stride, double* sums_out);
+
 #ifdef __cplusplus
 }
 #endif

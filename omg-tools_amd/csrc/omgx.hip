@@ -473,21 +473,27 @@ shift_kernel(double* __restrict__ x, int x_stride, const uint8_t* __restrict__ m
 // ---------------------------------------------------------------------------
 // Formation ADMM kernels (all pointers are device pointers; tiny, memory-bound)
 // ---------------------------------------------------------------------------
+// (elements [B ns, (B + n_pub) ns): the rows other ranks need, written to the send buffer of the exchange by the same
+// launch -- x_send[i] = row pub_rows[i])
 __global__ void admm_center_kernel(omgx_admm_layout lay, const double* __restrict__ x, int n_var,
-                                   const double* __restrict__ p, int n_par, double* __restrict__ x_i, int B) {
+                                   const double* __restrict__ p, int n_par, double* __restrict__ x_i, int B,
+                                   const int32_t* __restrict__ pub_rows, int n_pub, double* __restrict__ x_send) {
   const int ns = lay.n_dim * lay.L;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * ns) return;
-  const int b = i / ns, q = i - b * ns, k = q / lay.L;
-  x_i[i] = x[(size_t)b * n_var + lay.x_spl + q] + p[(size_t)b * n_par + lay.p_rel + k];
+  if (i >= (B + n_pub) * ns) return;
+  const int row = i / ns, q = i - row * ns, k = q / lay.L;
+  const int b = row < B ? row : pub_rows[row - B];
+  const double v = x[(size_t)b * n_var + lay.x_spl + q] + p[(size_t)b * n_par + lay.p_rel + k];
+  if (row < B) x_i[i] = v; else x_send[(size_t)(row - B) * ns + q] = v;
 }
 
 // one block per agent; thread r owns row r of the stacked vectors (n_all <= blockDim)
 __global__ void __launch_bounds__(256)
 admm_update_kernel(omgx_admm_layout lay, const double* __restrict__ x_ext, const int32_t* __restrict__ nbr,
                    const double* __restrict__ M, const double* __restrict__ F, double rho,
-                   double* __restrict__ p, int n_par, double* __restrict__ z_ij, double* __restrict__ l_ij,
-                   double* __restrict__ res, double* __restrict__ sums, int* __restrict__ done) {
+                   double* __restrict__ p, int n_par, double* __restrict__ z_ij, double* __restrict__ l_ij, int zl_stride,
+                   double* __restrict__ res, double* __restrict__ sums, int* __restrict__ done,
+                   const int32_t* __restrict__ pub_slot, double* __restrict__ zl_send, int send_stride) {
   extern __shared__ __align__(16) double lds[];
   const int ns = lay.n_dim * lay.L, nn = lay.n_nghb, na = (1 + nn) * ns;
   double* xa = lds; double* la = lds + na; double* zp = lds + 2 * na; double* va = lds + 3 * na;
@@ -500,8 +506,8 @@ admm_update_kernel(omgx_admm_layout lay, const double* __restrict__ x_ext, const
     else {
       const int j = nbr[b * nn + blk - 1];
       xa[r] = x_ext[(size_t)j * ns + q];
-      la[r] = l_ij[((size_t)b * nn + blk - 1) * ns + q];
-      zp[r] = z_ij[((size_t)b * nn + blk - 1) * ns + q];
+      la[r] = l_ij[(size_t)b * zl_stride + (blk - 1) * ns + q];
+      zp[r] = z_ij[(size_t)b * zl_stride + (blk - 1) * ns + q];
     }
     va[r] = xa[r] + la[r] / rho;
   }
@@ -514,7 +520,15 @@ admm_update_kernel(omgx_admm_layout lay, const double* __restrict__ x_ext, const
     d1[r] = xa[r] - zr; d2[r] = zr - zp[r];
     const int blk = r / ns, q = r - blk * ns;
     if (blk == 0) { pb[lay.p_zi + q] = zr; pb[lay.p_li + q] = lr; }
-    else { z_ij[((size_t)b * nn + blk - 1) * ns + q] = zr; l_ij[((size_t)b * nn + blk - 1) * ns + q] = lr; }
+    else {
+      z_ij[(size_t)b * zl_stride + (blk - 1) * ns + q] = zr; l_ij[(size_t)b * zl_stride + (blk - 1) * ns + q] = lr;
+      // a row another rank needs goes to the send buffer of the second exchange as well: [z_ij | l_ij]
+      const int ps = pub_slot ? pub_slot[b] : -1;
+      if (ps >= 0) {
+        zl_send[(size_t)ps * send_stride + (blk - 1) * ns + q] = zr;
+        zl_send[(size_t)ps * send_stride + nn * ns + (blk - 1) * ns + q] = lr;
+      }
+    }
   }
   __syncthreads();
   double pr = 0.0, dr = 0.0;
@@ -564,14 +578,22 @@ admm_update_kernel(omgx_admm_layout lay, const double* __restrict__ x_ext, const
   if (threadIdx.x == 0) { sums[0] = t3[0]; sums[1] = t3[256]; sums[2] = t3[512]; *done = 0; }
 }
 
+// (sum_rows: the residual sums every rank sent along with its rows, [n_sum_rows] rows of sum_stride doubles with the
+// three sums in front; their total over the ranks goes to sums_out -- rank order, the same bits on every rank)
 __global__ void admm_comm_kernel(omgx_admm_layout lay, const int32_t* __restrict__ nbr,
                                  const int32_t* __restrict__ slot, const double* __restrict__ z_ext,
-                                 const double* __restrict__ l_ext, double* __restrict__ p, int n_par, int B) {
+                                 const double* __restrict__ l_ext, int zl_stride, double* __restrict__ p, int n_par, int B,
+                                 const double* __restrict__ sum_rows, int n_sum_rows, int sum_stride, double* __restrict__ sums_out) {
   const int ns = lay.n_dim * lay.L, nn = lay.n_nghb;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 3 && sums_out) {
+    double acc = 0.0;
+    for (int r = 0; r < n_sum_rows; ++r) acc += sum_rows[(size_t)r * sum_stride + i];
+    sums_out[i] = acc;
+  }
   if (i >= B * nn * ns) return;
   const int b = i / (nn * ns), rem = i - b * nn * ns, k = rem / ns, q = rem - k * ns;
-  const size_t src = ((size_t)nbr[b * nn + k] * nn + slot[b * nn + k]) * ns + q;
+  const size_t src = (size_t)nbr[b * nn + k] * zl_stride + (size_t)slot[b * nn + k] * ns + q;
   p[(size_t)b * n_par + lay.p_zji + k * ns + q] = z_ext[src];
   p[(size_t)b * n_par + lay.p_lji + k * ns + q] = l_ext[src];
 }
@@ -686,10 +708,17 @@ bool plan_for_mode(omgx::HostPlan& plan, const omgx_template& t, int* mode, size
   }
   plan.dims.wave_ok = 0;      // the blocked routines (dense panels)
   *mode = pick_mode(plan.dims, plan.kkt_doubles, lds_doubles, hbm_doubles);
+  if (const char* e = getenv("OMGX_FORCE_MODE")) {      // (developer knob: a deeper spill mode than the class needs)
+    const int fm = atoi(e);
+    if (*mode != omgx::WS_MODES && fm > *mode && fm <= omgx::WS_ROWS_HBM) *mode = fm;
+  }
   if (*mode != omgx::WS_LDS && *mode != omgx::WS_MODES) {
     plan = omgx::HostPlan();
     if (!plan.build(t, true)) return false;
     omgx::work_split(plan.dims, plan.kkt_doubles, *mode, lds_doubles, hbm_doubles);
+    // a spill class is bound by dependent accesses to its slab: when the part that stays in LDS fits half a CU, two
+    // agents share the CU and hide each other's round trips
+    if (*lds_doubles * sizeof(double) <= (size_t)kLdsHalf && getenv("OMGX_SPILL_PER_CU") && atoi(getenv("OMGX_SPILL_PER_CU")) == 2) *per_cu = 2;
   }
   return true;
 }
@@ -715,8 +744,8 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
     return OMGX_E_TOOLARGE;
   }
   b->ws_mode = mode; b->lds_bytes = nl * sizeof(double); b->slab_doubles = ng;
-  if (const char* e = getenv("OMGX_THREADS")) { const int t2 = atoi(e); if (t2 == 256 || t2 == 512) b->threads = t2; }      // (developer knob)
   b->threads = b->per_cu >= 2 ? 256 : kThreads;
+  if (const char* e = getenv("OMGX_THREADS")) { const int t2 = atoi(e); if (t2 == 256 || t2 == 512) b->threads = t2; }      // (developer knob)
   if (b->per_cu >= 2) { b->prio_iter = 2; b->stagger = 0; }
   if (const char* e = getenv("OMGX_PRIO_ITER")) b->prio_iter = atoi(e);      // (developer knobs)
   if (const char* e = getenv("OMGX_STAGGER")) b->stagger = atoi(e);
@@ -1449,11 +1478,16 @@ int omgx_batch_predict(omgx_batch* b, const double* x, double* p, int32_t coeff_
 }
 
 int omgx_admm_center(omgx_batch* b, const omgx_admm_layout* lay, const double* x, const double* p, double* x_i) {
-  if (!b || !lay || !x || !p || !x_i) { g_err = "null argument"; return OMGX_E_INVALID; }
+  return omgx_admm_center_ex(b, lay, x, p, x_i, nullptr, 0, nullptr);
+}
+
+int omgx_admm_center_ex(omgx_batch* b, const omgx_admm_layout* lay, const double* x, const double* p, double* x_i,
+                        const int32_t* pub_rows, int32_t n_pub, double* x_send) {
+  if (!b || !lay || !x || !p || !x_i || n_pub < 0 || (n_pub > 0 && (!pub_rows || !x_send))) { g_err = "bad argument"; return OMGX_E_INVALID; }
   HIPCHK(hipSetDevice(b->device));
-  const int n = b->n_agents * lay->n_dim * lay->L;
+  const int n = (b->n_agents + n_pub) * lay->n_dim * lay->L;
   hipLaunchKernelGGL(admm_center_kernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, *lay, x, b->dims.n_var,
-                     p, b->dims.n_par, x_i, b->n_agents);
+                     p, b->dims.n_par, x_i, b->n_agents, pub_rows, n_pub, x_send);
   HIPCHK(hipGetLastError());
   return OMGX_OK;
 }
@@ -1467,7 +1501,17 @@ int omgx_admm_update(omgx_batch* b, const omgx_admm_layout* lay, const double* x
 int omgx_admm_update_sums(omgx_batch* b, const omgx_admm_layout* lay, const double* x_ext, const int32_t* nbr,
                           const double* M, const double* F, double rho, double* p, double* z_ij, double* l_ij,
                           double* res, double* sums) {
-  if (!b || !lay || !x_ext || !nbr || !M || !F || !p || !z_ij || !l_ij || !res || !(rho > 0)) {
+  if (!lay) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  return omgx_admm_update_ex(b, lay, x_ext, nbr, M, F, rho, p, z_ij, l_ij, lay->n_nghb * lay->n_dim * lay->L, res, sums,
+                             nullptr, nullptr, 0);
+}
+
+int omgx_admm_update_ex(omgx_batch* b, const omgx_admm_layout* lay, const double* x_ext, const int32_t* nbr,
+                        const double* M, const double* F, double rho, double* p, double* z_ij, double* l_ij,
+                        int32_t zl_stride, double* res, double* sums, const int32_t* pub_slot, double* zl_send,
+                        int32_t send_stride) {
+  if (!b || !lay || !x_ext || !nbr || !M || !F || !p || !z_ij || !l_ij || !res || !(rho > 0) ||
+      zl_stride < lay->n_nghb * lay->n_dim * lay->L || (pub_slot && (!zl_send || send_stride < 2 * lay->n_nghb * lay->n_dim * lay->L))) {
     g_err = "bad argument"; return OMGX_E_INVALID;
   }
   const int na = (1 + lay->n_nghb) * lay->n_dim * lay->L;
@@ -1479,18 +1523,27 @@ int omgx_admm_update_sums(omgx_batch* b, const omgx_admm_layout* lay, const doub
   }
   const size_t lds_doubles = (size_t)std::max(6 * na + 16, sums ? 3 * 256 : 0);
   hipLaunchKernelGGL(admm_update_kernel, dim3(b->n_agents), dim3(256), lds_doubles * sizeof(double), b->stream,
-                     *lay, x_ext, nbr, M, F, rho, p, b->dims.n_par, z_ij, l_ij, res, sums, b->d_admm_done);
+                     *lay, x_ext, nbr, M, F, rho, p, b->dims.n_par, z_ij, l_ij, (int)zl_stride, res, sums, b->d_admm_done,
+                     pub_slot, zl_send, (int)send_stride);
   HIPCHK(hipGetLastError());
   return OMGX_OK;
 }
 
 int omgx_admm_communicate(omgx_batch* b, const omgx_admm_layout* lay, const int32_t* nbr, const int32_t* slot,
                           const double* z_ij_ext, const double* l_ij_ext, double* p) {
-  if (!b || !lay || !nbr || !slot || !z_ij_ext || !l_ij_ext || !p) { g_err = "null argument"; return OMGX_E_INVALID; }
+  if (!lay) { g_err = "null argument"; return OMGX_E_INVALID; }
+  return omgx_admm_communicate_ex(b, lay, nbr, slot, z_ij_ext, l_ij_ext, lay->n_nghb * lay->n_dim * lay->L, p, nullptr, 0, 0, nullptr);
+}
+
+int omgx_admm_communicate_ex(omgx_batch* b, const omgx_admm_layout* lay, const int32_t* nbr, const int32_t* slot,
+                             const double* z_ij_ext, const double* l_ij_ext, int32_t zl_stride, double* p,
+                             const double* sum_rows, int32_t n_sum_rows, int32_t sum_stride, double* sums_out) {
+  if (!b || !lay || !nbr || !slot || !z_ij_ext || !l_ij_ext || !p || zl_stride < lay->n_nghb * lay->n_dim * lay->L ||
+      (sums_out && (!sum_rows || n_sum_rows <= 0 || sum_stride < 3))) { g_err = "bad argument"; return OMGX_E_INVALID; }
   HIPCHK(hipSetDevice(b->device));
-  const int n = b->n_agents * lay->n_nghb * lay->n_dim * lay->L;
+  const int n = std::max(3, b->n_agents * lay->n_nghb * lay->n_dim * lay->L);
   hipLaunchKernelGGL(admm_comm_kernel, dim3((n + 255) / 256), dim3(256), 0, b->stream, *lay, nbr, slot, z_ij_ext,
-                     l_ij_ext, p, b->dims.n_par, b->n_agents);
+                     l_ij_ext, (int)zl_stride, p, b->dims.n_par, b->n_agents, sum_rows, (int)n_sum_rows, (int)sum_stride, sums_out);
   HIPCHK(hipGetLastError());
   return OMGX_OK;
 }

@@ -58,6 +58,19 @@ class HaloPlan(object):
         lookup = {g: Bl + i for i, g in enumerate(self.needed)}
         lookup.update({g: g - self.lo for g in range(self.lo, self.hi)})
         self.nbr_local = np.vectorize(lookup.__getitem__)(nbr_global[self.lo:self.hi]).astype(np.int32)
+        # the copy-free exchange (`BatchADMM.iterate`, include/omgx.h omgx_admm_*_ex): a buffer holds the local rows on top
+        # and the all_gather result -- `rows` rows per rank -- straight behind them; a remote neighbour is addressed where
+        # its owner's published row lands.  rows_x = max_pub for the x_i rows, rows_zl = max_pub + 1 for [z_ij | l_ij]
+        # (the extra row of every rank carries its residual sums).
+        self.rows_x, self.rows_zl = self.max_pub, self.max_pub + 1
+        self.pub_slot = np.full(Bl, -1, dtype=np.int32)
+        self.pub_slot[self.publish_local] = np.arange(len(self.publish_local), dtype=np.int32)
+
+        def gathered(rows):
+            lk = {g: g - self.lo for g in range(self.lo, self.hi)}
+            lk.update({g: Bl + int(owner[g]) * rows + publish[owner[g]].index(g) for g in self.needed})
+            return np.vectorize(lk.__getitem__)(nbr_global[self.lo:self.hi]).astype(np.int32)
+        self.nbr_x, self.nbr_zl = gathered(self.rows_x), gathered(self.rows_zl)
 
 
 class BatchADMM(object):
@@ -109,6 +122,21 @@ class BatchADMM(object):
         ops, lay = self.ops, self.lay
         ops.set_time(lay, t_rel, self.rho)
         status = ops.solve()                                   # x-update
+        if self.exchanging() and not self.nesterov and getattr(ops, 'fused', False):
+            # sharded fleet, no copies around the collectives: four launches and two all_gathers per iteration, every
+            # kernel reads and writes the exchange buffers in place (include/omgx.h omgx_admm_*_ex)
+            ops.center(lay)                                    # x_i rows + the rows other ranks need -> send buffer
+            ops.gather_x(self.dist)                            # collective #1, straight behind the local rows
+            M, F = self.matrices(t_rel)
+            ops.update_fused(lay, M, F, self.rho)              # [z_ij | l_ij] in place; published rows and this rank's sums -> send buffer
+            ops.gather_zl(self.dist)                           # collective #2
+            sums = ops.communicate_fused(lay)                  # z_ji, l_ji from the gathered rows; the fleet's residual sums
+            self._res.append(sums)
+            self.iteration += 1
+            if not sync:
+                return status, None
+            s3 = ops.to_host(sums)
+            return status, (float(np.sqrt(s3[0])), float(np.sqrt(s3[1])), float(s3[2]))
         x_i = ops.center(lay)
         x_ext = self.extend(x_i)                               # collective #1
         M, F = self.matrices(t_rel)
@@ -242,6 +270,14 @@ class HipAdmmOps(object):
         lib.omgx_admm_update_sums.argtypes = [C.c_void_p, C.POINTER(AdmmLayoutC)] + [C.c_void_p] * 4 + \
             [C.c_double] + [C.c_void_p] * 5
         lib.omgx_admm_communicate.argtypes = [C.c_void_p, C.POINTER(AdmmLayoutC)] + [C.c_void_p] * 5
+        lib.omgx_admm_center_ex.argtypes = [C.c_void_p, C.POINTER(AdmmLayoutC)] + [C.c_void_p] * 4 + [C.c_int32, C.c_void_p]
+        lib.omgx_admm_update_ex.argtypes = [C.c_void_p, C.POINTER(AdmmLayoutC)] + [C.c_void_p] * 4 + [C.c_double] + \
+            [C.c_void_p] * 3 + [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32]
+        lib.omgx_admm_communicate_ex.argtypes = [C.c_void_p, C.POINTER(AdmmLayoutC)] + [C.c_void_p] * 4 + [C.c_int32] + \
+            [C.c_void_p] * 2 + [C.c_int32, C.c_int32, C.c_void_p]
+        self.zl_stride = self.nn * self.ns             # doubles between the z_ij (l_ij) rows of consecutive agents
+        self.fused = False
+        self.launches = self.collectives = 0           # kernel launches / collectives issued (tests count them per iteration)
         self._sum_blocks, self._sum_k, self._sums = [], 0, None     # fleet residual sums, one row per update (history)
         solver.set_stream(torch.cuda.current_stream().cuda_stream)
         self.zl = torch.zeros((B, 2 * self.nn * self.ns), **f64)      # [z_ij | l_ij] packed for the exchange
@@ -258,6 +294,32 @@ class HipAdmmOps(object):
         self._slot = t.as_tensor(np.ascontiguousarray(slot), dtype=t.int32, device=self.dev)
         self._pub = t.as_tensor(halo.publish_local, dtype=t.int64, device=self.dev)
         self._src = t.as_tensor(halo.src, dtype=t.int64, device=self.dev)
+        if halo.world > 1 and halo.any_halo and hasattr(self, 'z_ij'):
+            self._bind_fused(halo)
+
+    def _bind_fused(self, halo):
+        """Exchange buffers of the sharded iteration: x_i, z_ij, l_ij become views of them (row strides change: every
+        kernel call below passes `zl_stride`)."""
+        t = self.torch
+        f64 = dict(dtype=t.float64, device=self.dev)
+        B, ns, w = self.B, self.ns, self.nn * self.ns
+        self.halo = halo
+        self.x_all = t.zeros((B + halo.world * halo.rows_x, ns), **f64)
+        self.x_send = t.zeros((max(halo.rows_x, 1), ns), **f64)
+        self.zl_all = t.zeros((B + halo.world * halo.rows_zl, 2 * w), **f64)
+        self.zl_send = t.zeros((halo.rows_zl, 2 * w), **f64)
+        self.x_i = self.x_all[:B]
+        z_old, l_old = self.z_ij, self.l_ij
+        self.z_ij = self.zl_all[:B, :w].view(B, self.nn, ns)
+        self.l_ij = self.zl_all[:B, w:].view(B, self.nn, ns)
+        self.z_ij.copy_(z_old)
+        self.l_ij.copy_(l_old)
+        self.zl_stride = 2 * w
+        self._nbr_x = t.as_tensor(np.ascontiguousarray(halo.nbr_x), dtype=t.int32, device=self.dev)
+        self._nbr_zl = t.as_tensor(np.ascontiguousarray(halo.nbr_zl), dtype=t.int32, device=self.dev)
+        self._pub_rows = t.as_tensor(np.ascontiguousarray(halo.publish_local), dtype=t.int32, device=self.dev)
+        self._pub_slot = t.as_tensor(np.ascontiguousarray(halo.pub_slot), dtype=t.int32, device=self.dev)
+        self.fused = True
 
     def resident(self, M, F):
         t = self.torch
@@ -297,12 +359,58 @@ class HipAdmmOps(object):
         self.solver.solve_device(self.p, self.x, self.lb, self.ub, self.x_new, self.lam,
                                  self.status, self.iters, bounds_shared=True)
         self.x, self.x_new = self.x_new, self.x
+        self.launches += 1
         return self.status
 
     def center(self, lay):
-        self._chk(self.solver.lib.omgx_admm_center(self.solver._h, C.byref(self.layc), self.x.data_ptr(),
-                                                   self.p.data_ptr(), self.x_i.data_ptr()), 'omgx_admm_center')
+        n_pub = len(self.halo.publish_local) if self.fused else 0
+        self._chk(self.solver.lib.omgx_admm_center_ex(
+            self.solver._h, C.byref(self.layc), self.x.data_ptr(), self.p.data_ptr(), self.x_i.data_ptr(),
+            self._pub_rows.data_ptr() if n_pub else None, n_pub, self.x_send.data_ptr() if n_pub else None), 'omgx_admm_center_ex')
+        self.launches += 1
         return self.x_i
+
+    # -- the sharded iteration without copies (BatchADMM.iterate) -------------------------------------------------
+    def gather_x(self, dist):
+        dist.all_gather_into_tensor(self.x_all[self.B:], self.x_send[:self.halo.rows_x])
+        self.collectives += 1
+
+    def gather_zl(self, dist):
+        dist.all_gather_into_tensor(self.zl_all[self.B:], self.zl_send)
+        self.collectives += 1
+
+    def _history_row(self):
+        t = self.torch
+        if self._sum_k % 1024 == 0:
+            self._sum_blocks.append(t.zeros((1024, 3), dtype=t.float64, device=self.dev))
+            self._sum_blocks = self._sum_blocks[-1:]      # (rows of older blocks stay alive through the views BatchADMM holds until they are fetched)
+        row = self._sum_blocks[-1][self._sum_k % 1024]
+        self._sum_k += 1
+        return row
+
+    def update_fused(self, lay, M, F, rho):
+        if not self.torch.is_tensor(M):
+            M, F = self.resident(M, F)
+        w = self.nn * self.ns
+        self._chk(self.solver.lib.omgx_admm_update_ex(
+            self.solver._h, C.byref(self.layc), self.x_all.data_ptr(), self._nbr_x.data_ptr(), M.data_ptr(), F.data_ptr(),
+            float(rho), self.p.data_ptr(), self.z_ij.data_ptr(), self.l_ij.data_ptr(), self.zl_stride, self.res.data_ptr(),
+            self.zl_send[self.halo.rows_zl - 1].data_ptr(), self._pub_slot.data_ptr(), self.zl_send.data_ptr(), 2 * w),
+            'omgx_admm_update_ex')
+        self._keep = (M, F)
+        self.launches += 1
+
+    def communicate_fused(self, lay):
+        w, el = self.nn * self.ns, 8
+        halo = self.halo
+        sums = self._history_row()
+        base = self.zl_all.data_ptr()
+        self._chk(self.solver.lib.omgx_admm_communicate_ex(
+            self.solver._h, C.byref(self.layc), self._nbr_zl.data_ptr(), self._slot.data_ptr(), base, base + w * el,
+            2 * w, self.p.data_ptr(), base + (self.B + halo.rows_zl - 1) * 2 * w * el, halo.world, halo.rows_zl * 2 * w,
+            sums.data_ptr()), 'omgx_admm_communicate_ex')
+        self.launches += 1
+        return sums
 
     def update(self, lay, x_ext, nbr_local, M, F, rho):
         t = self.torch
@@ -313,16 +421,13 @@ class HipAdmmOps(object):
         x_ext = x_ext.contiguous()
         # the fleet sums of the residuals come out of the same launch (the workgroup that finishes last adds them up
         # in a fixed order); every update gets its own row, BatchADMM keeps them as the residual history
-        if self._sum_k % 1024 == 0:
-            self._sum_blocks.append(t.zeros((1024, 3), dtype=t.float64, device=self.dev))
-            self._sum_blocks = self._sum_blocks[-1:]      # (rows of older blocks stay alive through the views BatchADMM holds until they are fetched)
-        self._sums = self._sum_blocks[-1][self._sum_k % 1024]
-        self._sum_k += 1
-        self._chk(self.solver.lib.omgx_admm_update_sums(
+        self._sums = self._history_row()
+        self._chk(self.solver.lib.omgx_admm_update_ex(
             self.solver._h, C.byref(self.layc), x_ext.data_ptr(), self._nbr.data_ptr(), M.data_ptr(),
-            F.data_ptr(), float(rho), self.p.data_ptr(), self.z_ij.data_ptr(), self.l_ij.data_ptr(),
-            self.res.data_ptr(), self._sums.data_ptr()), 'omgx_admm_update_sums')
+            F.data_ptr(), float(rho), self.p.data_ptr(), self.z_ij.data_ptr(), self.l_ij.data_ptr(), self.zl_stride,
+            self.res.data_ptr(), self._sums.data_ptr(), None, None, 0), 'omgx_admm_update_ex')
         self._keep = (M, F, x_ext)
+        self.launches += 1
         return self.res
 
     def residual_sums(self, res):
@@ -351,17 +456,21 @@ class HipAdmmOps(object):
             self._nbr = t.as_tensor(np.ascontiguousarray(nbr_local), dtype=t.int32, device=self.dev)
             self._slot = t.as_tensor(np.ascontiguousarray(slot), dtype=t.int32, device=self.dev)
         w = self.nn * self.ns
-        z_ext, l_ext = zl_ext[:, :w].contiguous(), zl_ext[:, w:].contiguous()
-        self._chk(self.solver.lib.omgx_admm_communicate(
-            self.solver._h, C.byref(self.layc), self._nbr.data_ptr(), self._slot.data_ptr(), z_ext.data_ptr(),
-            l_ext.data_ptr(), self.p.data_ptr()), 'omgx_admm_communicate')
-        self._keep2 = (z_ext, l_ext)
+        # (the rows are read where they are: z_ij at column 0, l_ij at column w of the exchanged rows)
+        zl_ext = zl_ext if zl_ext.stride(1) == 1 else zl_ext.contiguous()
+        self._chk(self.solver.lib.omgx_admm_communicate_ex(
+            self.solver._h, C.byref(self.layc), self._nbr.data_ptr(), self._slot.data_ptr(), zl_ext.data_ptr(),
+            zl_ext.data_ptr() + w * zl_ext.element_size(), zl_ext.stride(0), self.p.data_ptr(), None, 0, 0, None),
+            'omgx_admm_communicate_ex')
+        self._keep2 = zl_ext
+        self.launches += 1
 
     def communicate_local(self, lay):
         """communicate when every neighbour is a local agent and nothing is extrapolated: z_ij, l_ij as they are."""
-        self._chk(self.solver.lib.omgx_admm_communicate(
+        self._chk(self.solver.lib.omgx_admm_communicate_ex(
             self.solver._h, C.byref(self.layc), self._nbr.data_ptr(), self._slot.data_ptr(), self.z_ij.data_ptr(),
-            self.l_ij.data_ptr(), self.p.data_ptr()), 'omgx_admm_communicate')
+            self.l_ij.data_ptr(), self.zl_stride, self.p.data_ptr(), None, 0, 0, None), 'omgx_admm_communicate_ex')
+        self.launches += 1
 
     # -- Nesterov acceleration (`admm.py:510-554`), branch-free on the device --------------------
     def save_previous(self, lay):
@@ -423,8 +532,8 @@ class HipAdmmOps(object):
         lib.omgx_shift_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_int32, C.c_void_p, C.c_int32]
         for data, stride, (ents, mats) in ((self.x, self.x.shape[1], shift_x), (self.p, self.p.shape[1], shift_p),
-                                           (self.z_ij, self.nn * self.ns, shift_side),
-                                           (self.l_ij, self.nn * self.ns, shift_side)):
+                                           (self.z_ij, self.zl_stride, shift_side),
+                                           (self.l_ij, self.zl_stride, shift_side)):
             ents = np.ascontiguousarray(ents, dtype=np.int32)
             mats = np.ascontiguousarray(mats, dtype=np.float64)
             if len(ents) == 0:

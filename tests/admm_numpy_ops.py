@@ -13,6 +13,56 @@ class NumpyAdmmOps(object):
         self.B, self.ns, self.nn = self.p.shape[0], layout.ns, layout.n_nghb
         self.z_ij = np.zeros((self.B, self.nn, self.ns))
         self.l_ij = np.zeros((self.B, self.nn, self.ns))
+        self.fused, self.launches, self.collectives = False, 0, 0
+
+    # -- the copy-free exchange of the sharded iteration (same buffers and indices as HipAdmmOps._bind_fused; the kernels
+    # of include/omgx.h omgx_admm_*_ex restated on numpy views of the torch CPU tensors the collectives work on) --------
+    def bind(self, halo, slot):
+        if not (halo.world > 1 and halo.any_halo) or not getattr(self, 'use_fused', True):
+            return
+        import torch
+        B, ns, w = self.B, self.ns, self.nn * self.ns
+        self.halo, self._slot = halo, np.asarray(slot)
+        self.t_x_all = torch.zeros((B + halo.world * halo.rows_x, ns), dtype=torch.float64)
+        self.t_x_send = torch.zeros((max(halo.rows_x, 1), ns), dtype=torch.float64)
+        self.t_zl_all = torch.zeros((B + halo.world * halo.rows_zl, 2 * w), dtype=torch.float64)
+        self.t_zl_send = torch.zeros((halo.rows_zl, 2 * w), dtype=torch.float64)
+        self.x_all, self.x_send = self.t_x_all.numpy(), self.t_x_send.numpy()
+        self.zl_all, self.zl_send = self.t_zl_all.numpy(), self.t_zl_send.numpy()
+        z_old, l_old = self.z_ij, self.l_ij
+        self.z_ij = self.zl_all[:B, :w].reshape(B, self.nn, ns)         # views: updated in place from here on
+        self.l_ij = self.zl_all[:B, w:].reshape(B, self.nn, ns)
+        assert np.shares_memory(self.z_ij, self.zl_all) and np.shares_memory(self.l_ij, self.zl_all)
+        self.z_ij[...], self.l_ij[...] = z_old, l_old
+        self.fused = True
+
+    def gather_x(self, dist):
+        dist.all_gather_into_tensor(self.t_x_all[self.B:], self.t_x_send[:self.halo.rows_x])
+        self.collectives += 1
+
+    def gather_zl(self, dist):
+        dist.all_gather_into_tensor(self.t_zl_all[self.B:], self.t_zl_send)
+        self.collectives += 1
+
+    def update_fused(self, lay, M, F, rho):
+        halo, w = self.halo, self.nn * self.ns
+        res = self.update(lay, self.x_all, halo.nbr_x, M, F, rho)
+        pub = halo.publish_local
+        self.zl_send[:len(pub), :w] = self.z_ij[pub].reshape(len(pub), w)
+        self.zl_send[:len(pub), w:] = self.l_ij[pub].reshape(len(pub), w)
+        self.zl_send[halo.rows_zl - 1, :3] = res.sum(axis=0)
+
+    def communicate_fused(self, lay):
+        halo, ns, nn = self.halo, self.ns, self.nn
+        w = nn * ns
+        z_ext, l_ext = self.zl_all[:, :w].reshape(-1, nn, ns), self.zl_all[:, w:].reshape(-1, nn, ns)
+        nbr, slot = halo.nbr_zl, self._slot
+        for k in range(nn):
+            self.p[:, lay.p_zji + k * ns:lay.p_zji + (k + 1) * ns] = z_ext[nbr[:, k], slot[:, k]]
+            self.p[:, lay.p_lji + k * ns:lay.p_lji + (k + 1) * ns] = l_ext[nbr[:, k], slot[:, k]]
+        rows = self.zl_all[self.B:].reshape(halo.world, halo.rows_zl, 2 * w)
+        self.launches += 1
+        return rows[:, halo.rows_zl - 1, :3].sum(axis=0)
 
     def init_consensus(self, lay):
         x_i = self.center(lay)
@@ -50,11 +100,19 @@ class NumpyAdmmOps(object):
         r = self.port.solve(self.tpl, self.p, self.x, tol=self.tol, max_iter=300, warm_start=1,
                             lam_g0=self.lam, status0=self.status, dw_state=self.dw)
         self.x, self.lam, self.status = r['x'], r['lam_g'], r['status']
+        self.launches += 1
         return r['status']
 
     def center(self, lay):
         c = self.x[:, lay.x_spl:lay.x_spl + self.ns].reshape(self.B, lay.n_dim, lay.L)
-        return (c + self.p[:, lay.p_rel:lay.p_rel + lay.n_dim][:, :, None]).reshape(self.B, self.ns)
+        x_i = (c + self.p[:, lay.p_rel:lay.p_rel + lay.n_dim][:, :, None]).reshape(self.B, self.ns)
+        self.launches += 1
+        if self.fused:
+            self.x_all[:self.B] = x_i
+            pub = self.halo.publish_local
+            self.x_send[:len(pub)] = x_i[pub]
+            return self.x_all[:self.B]
+        return x_i
 
     def update(self, lay, x_ext, nbr, M, F, rho):
         ns, nn, p = self.ns, self.nn, self.p
@@ -67,7 +125,8 @@ class NumpyAdmmOps(object):
         dr = rho * (((z_all - z_prev) @ F.T) ** 2).sum(axis=1)
         z_all, l_all = z_all.reshape(self.B, 1 + nn, ns), l_all.reshape(self.B, 1 + nn, ns)
         p[:, lay.p_zi:lay.p_zi + ns], p[:, lay.p_li:lay.p_li + ns] = z_all[:, 0], l_all[:, 0]
-        self.z_ij, self.l_ij = z_all[:, 1:].copy(), l_all[:, 1:].copy()
+        self.z_ij[...], self.l_ij[...] = z_all[:, 1:], l_all[:, 1:]        # (in place: they may be views of the exchange buffer)
+        self.launches += 1
         return np.stack([pr, dr, rho * pr + dr], axis=1)
 
     def upload_params(self, p_host, cols):
@@ -88,8 +147,9 @@ class NumpyAdmmOps(object):
         apply(self.x, *shift_x)
         apply(self.p, *shift_p)
         for side in (self.z_ij, self.l_ij):
-            flat = side.reshape(self.B, -1)
+            flat = side.reshape(self.B, -1).copy()
             apply(flat, *shift_side)
+            side[...] = flat.reshape(side.shape)              # (in place: z_ij, l_ij may be views of the exchange buffer)
 
     def z_ij_flat(self):
         return self.z_ij.reshape(self.B, -1)
@@ -111,6 +171,7 @@ class NumpyAdmmOps(object):
         for k in range(nn):
             self.p[:, lay.p_zji + k * ns:lay.p_zji + (k + 1) * ns] = z_ext[nbr[:, k], slot[:, k]]
             self.p[:, lay.p_lji + k * ns:lay.p_lji + (k + 1) * ns] = l_ext[nbr[:, k], slot[:, k]]
+        self.launches += 1
 
     def exchange(self, local, halo, dist, extra=None):
         import torch
@@ -172,6 +233,6 @@ class NumpyAdmmOps(object):
             z_i[:], l_i[:] = z_i_p, l_i_p
             z_ij, l_ij = z_ij_p, l_ij_p
             self.c_res_p = (1. / eta) * self.c_res_p
-        self.z_ij = z_ij[:B].reshape(B, nn, ns).copy()
-        self.l_ij = l_ij[:B].reshape(B, nn, ns).copy()
+        self.z_ij[...] = z_ij[:B].reshape(B, nn, ns)
+        self.l_ij[...] = l_ij[:B].reshape(B, nn, ns)
         return np.concatenate([z_ij, l_ij], axis=1)

@@ -101,11 +101,14 @@ def _worker(rank, world, port, q, n=6, sizes=None, kw=None):
     ops = NumpyAdmmOps(tpl, lay, P['p'][lo:hi], P['x0'][lo:hi])
     admm = BatchADMM(lay, nbr, ops, rank=rank, world=world, dist=dist, rho=1.0, **(kw or {}))
     admm.initialize()
+    counts = []
     for _ in range(4 if kw else 3):
+        l0, c0 = ops.launches, ops.collectives
         admm.iterate(0.0, sync=False)                         # nothing comes to the host inside the loop
+        counts.append((ops.launches - l0, ops.collectives - c0, bool(ops.fused)))
     x_all = gather_solutions(ops.x, n, dist=dist)
     if rank == 0:
-        q.put((admm.residuals, x_all))
+        q.put((admm.residuals, x_all, counts))
     dist.destroy_process_group()
 
 
@@ -127,7 +130,7 @@ def _sharded_vs_single(world, n=6, sizes=None, kw=None, port_off=0):
     for pr in procs:
         pr.start()
     try:
-        residuals, x_all = q.get(timeout=240)
+        residuals, x_all, counts = q.get(timeout=240)
     finally:
         for pr in procs:
             pr.join(timeout=60)
@@ -136,6 +139,10 @@ def _sharded_vs_single(world, n=6, sizes=None, kw=None, port_off=0):
     assert all(pr.exitcode == 0 for pr in procs)
     assert np.allclose(np.array(residuals), np.array(ref.residuals), rtol=1e-9, atol=1e-12)
     assert np.abs(x_all - ops.x).max() < 1e-9
+    if not kw:
+        # the sharded iteration without acceleration: x-update, centre (+ published rows), z / lambda update (+ published
+        # rows and residual sums), neighbour read-back = four launches around two all_gathers, nothing else
+        assert all(c == (4, 2, True) for c in counts), counts
     return ref
 
 
