@@ -160,7 +160,7 @@ __device__ void sample_agent(const double* coeffs, double* scratch, int n_spl, i
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-template <int MODE, bool WAVE_ONLY>
+template <int MODE, bool WAVE_ONLY, bool GEN>
 __global__ void __launch_bounds__(512)
 ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  const double* __restrict__ p, const double* __restrict__ x0,
@@ -175,7 +175,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   omgx::Work w;
     omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
                                d, kkt_doubles);
-  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_kkt_hbm(MODE)> c; c.red = w.red;
+  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_kkt_hbm(MODE), GEN> c; c.red = w.red;
 #ifdef OMGX_PROFILE
   __shared__ long long prof_lds[omgx::PH_COUNT];
   c.prof = prof_lds;
@@ -270,7 +270,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 // Verification entry (omgx_batch_eval): one workgroup evaluates the tables of the solve at a caller's point and dumps the
 // raw arrays -- row values, objective, Jacobian entries, the KKT store holding the Lagrangian Hessian -- to `out`
 // [agent][n_con + 1 + nnz_j + kkt_doubles]; the host scatters them into dense matrices.
-template <int MODE, bool WAVE_ONLY>
+template <int MODE, bool WAVE_ONLY, bool GEN>
 __global__ void __launch_bounds__(512)
 ipm_eval_kernel(omgx::Dims d, omgx::Tables T, int kkt_doubles, const double* __restrict__ p, const double* __restrict__ x,
                 const double* __restrict__ lam, int n_agents, double* __restrict__ slabs, size_t slab_doubles,
@@ -279,7 +279,7 @@ ipm_eval_kernel(omgx::Dims d, omgx::Tables T, int kkt_doubles, const double* __r
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
                                d, kkt_doubles);
-  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_kkt_hbm(MODE)> c; c.red = w.red; c.prof = nullptr;
+  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_kkt_hbm(MODE), GEN> c; c.red = w.red; c.prof = nullptr;
   const size_t stride = (size_t)d.n_con + 1 + d.nnz_j + kkt_doubles;
   for (int b = blockIdx.x; b < n_agents; b += gridDim.x) {
     double* o = out + (size_t)b * stride;
@@ -294,27 +294,37 @@ ipm_eval_kernel(omgx::Dims d, omgx::Tables T, int kkt_doubles, const double* __r
 
 typedef void (*ipm_eval_kernel_t)(omgx::Dims, omgx::Tables, int, const double*, const double*, const double*, int, double*,
                                   size_t, double*);
-static ipm_eval_kernel_t ipm_eval_kernel_for(int mode, int wave_ok) {
+template <bool GEN>
+static ipm_eval_kernel_t ipm_eval_kernel_gen(int mode, int wave_ok) {
   switch (mode) {
-    case omgx::WS_LDS: return wave_ok ? ipm_eval_kernel<omgx::WS_LDS, true> : ipm_eval_kernel<omgx::WS_LDS, false>;
-    case omgx::WS_KKT_HBM: return ipm_eval_kernel<omgx::WS_KKT_HBM, false>;
-    case omgx::WS_JAC_HBM: return ipm_eval_kernel<omgx::WS_JAC_HBM, false>;
-    case omgx::WS_JAC_ONLY: return ipm_eval_kernel<omgx::WS_JAC_ONLY, true>;
-    default: return ipm_eval_kernel<omgx::WS_ROWS_HBM, false>;
+    case omgx::WS_LDS: return wave_ok ? ipm_eval_kernel<omgx::WS_LDS, true, GEN> : ipm_eval_kernel<omgx::WS_LDS, false, GEN>;
+    case omgx::WS_KKT_HBM: return ipm_eval_kernel<omgx::WS_KKT_HBM, false, GEN>;
+    case omgx::WS_JAC_HBM: return ipm_eval_kernel<omgx::WS_JAC_HBM, false, GEN>;
+    case omgx::WS_JAC_ONLY: return ipm_eval_kernel<omgx::WS_JAC_ONLY, true, GEN>;
+    default: return ipm_eval_kernel<omgx::WS_ROWS_HBM, false, GEN>;
   }
+}
+static ipm_eval_kernel_t ipm_eval_kernel_for(int mode, int wave_ok, int general) {
+  return general ? ipm_eval_kernel_gen<true>(mode, wave_ok) : ipm_eval_kernel_gen<false>(mode, wave_ok);
 }
 
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
                              const int32_t*, const StoreArgs*, int, int*, const double*, int, int32_t*, unsigned long long*, int);
-static ipm_kernel_t ipm_kernel_for(int mode, int wave_ok) {
+// (GEN: the instance that carries the terms with four factors, the cos / sin atoms and the basis rows of any degree --
+// Dims::general; the other one is the kernel of the benchmark classes, free of that code)
+template <bool GEN>
+static ipm_kernel_t ipm_kernel_gen(int mode, int wave_ok) {
   switch (mode) {
-    case omgx::WS_LDS: return wave_ok ? ipm_solve_kernel<omgx::WS_LDS, true> : ipm_solve_kernel<omgx::WS_LDS, false>;
-    case omgx::WS_KKT_HBM: return ipm_solve_kernel<omgx::WS_KKT_HBM, false>;
-    case omgx::WS_JAC_HBM: return ipm_solve_kernel<omgx::WS_JAC_HBM, false>;
-    case omgx::WS_JAC_ONLY: return ipm_solve_kernel<omgx::WS_JAC_ONLY, true>;
-    default: return ipm_solve_kernel<omgx::WS_ROWS_HBM, false>;
+    case omgx::WS_LDS: return wave_ok ? ipm_solve_kernel<omgx::WS_LDS, true, GEN> : ipm_solve_kernel<omgx::WS_LDS, false, GEN>;
+    case omgx::WS_KKT_HBM: return ipm_solve_kernel<omgx::WS_KKT_HBM, false, GEN>;
+    case omgx::WS_JAC_HBM: return ipm_solve_kernel<omgx::WS_JAC_HBM, false, GEN>;
+    case omgx::WS_JAC_ONLY: return ipm_solve_kernel<omgx::WS_JAC_ONLY, true, GEN>;
+    default: return ipm_solve_kernel<omgx::WS_ROWS_HBM, false, GEN>;
   }
+}
+static ipm_kernel_t ipm_kernel_for(int mode, int wave_ok, int general) {
+  return general ? ipm_kernel_gen<true>(mode, wave_ok) : ipm_kernel_gen<false>(mode, wave_ok);
 }
 
 template <typename OutT>
@@ -694,10 +704,15 @@ bool plan_for_mode(omgx::HostPlan& plan, const omgx_template& t, int* mode, size
     plan = omgx::HostPlan();
     if (!plan.build(t, false, true)) return false;
     const int cand[2] = {omgx::WS_LDS, omgx::WS_JAC_ONLY};
+    // (two per CU = workgroups of four waves: the substitutions gather 64 doubles per wave in the scratch behind the
+    // matrix descriptors, four of the eight blocks suffice)
+    const int col_full = plan.dims.col_doubles, col_half = col_full - 4 * 64;
+    plan.dims.col_doubles = col_half;
     for (int k = 0; k < 2; ++k) {
       omgx::work_split(plan.dims, plan.kkt_doubles, cand[k], lds_doubles, hbm_doubles);
       if (*lds_doubles * sizeof(double) <= (size_t)kLdsHalf && !getenv("OMGX_ONE_PER_CU")) { *mode = cand[k]; *per_cu = 2; return true; }
     }
+    plan.dims.col_doubles = col_full;
     // one agent per CU: everything in LDS, or the Jacobian values in a slab (the register-resident factorisation either way)
     for (int k = 0; k < 2; ++k) {
       omgx::work_split(plan.dims, plan.kkt_doubles, cand[k], lds_doubles, hbm_doubles);
@@ -745,7 +760,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   }
   b->ws_mode = mode; b->lds_bytes = nl * sizeof(double); b->slab_doubles = ng;
   b->threads = b->per_cu >= 2 ? 256 : kThreads;
-  if (const char* e = getenv("OMGX_THREADS")) { const int t2 = atoi(e); if (t2 == 256 || t2 == 512) b->threads = t2; }      // (developer knob)
+  if (const char* e = getenv("OMGX_THREADS")) { const int t2 = atoi(e); if (t2 == 256 || (t2 == 512 && b->per_cu < 2)) b->threads = t2; }      // (developer knob; the workspace of two per CU is sized for four waves)
   if (b->per_cu >= 2) { b->prio_iter = 2; b->stagger = 0; }
   if (const char* e = getenv("OMGX_PRIO_ITER")) b->prio_iter = atoi(e);      // (developer knobs)
   if (const char* e = getenv("OMGX_STAGGER")) b->stagger = atoi(e);
@@ -1029,10 +1044,10 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
   b->stream = b->own_stream;
   if (hipMemset(b->d_dw, 0, (size_t)n_agents * sizeof(double)) != hipSuccess) { g_err = "hipMemset failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
   // (the attribute belongs to the kernel, not to the handle: keep the largest request of the process)
-  static int lds_reserved[2 * omgx::WS_MODES] = {0};
-  int& reserved = lds_reserved[2 * b->ws_mode + (b->dims.wave_ok ? 1 : 0)];
+  static int lds_reserved[4 * omgx::WS_MODES] = {0};
+  int& reserved = lds_reserved[4 * b->ws_mode + (b->dims.wave_ok ? 1 : 0) + (b->dims.general ? 2 : 0)];
   if ((int)b->lds_bytes > reserved) reserved = (int)b->lds_bytes;
-  if (hipFuncSetAttribute((const void*)ipm_kernel_for(b->ws_mode, b->dims.wave_ok), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute((const void*)ipm_kernel_for(b->ws_mode, b->dims.wave_ok, b->dims.general), hipFuncAttributeMaxDynamicSharedMemorySize,
                           reserved) != hipSuccess) {
     g_err = "cannot reserve dynamic LDS for ipm_solve_kernel"; omgx_batch_destroy(b); return OMGX_E_HIP;
   }
@@ -1166,7 +1181,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   b->timed = b->timing && !b->ext_ev0;
   b->ext_ev0 = b->ext_ev1 = nullptr;
   b->opts.prio_iter = b->prio_iter;
-  hipExtLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok), dim3(b->n_slabs), dim3(b->threads), (uint32_t)b->lds_bytes, b->stream,
+  hipExtLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok, b->dims.general), dim3(b->n_slabs), dim3(b->threads), (uint32_t)b->lds_bytes, b->stream,
                         e0, e1, 0u, d, b->dev,
                         b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
                         b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, (const StoreArgs*)(b->store.out ? b->d_store : nullptr), (flags & OMGX_ONLY_FAILED) ? 1 : 0,
@@ -1214,7 +1229,7 @@ int omgx_batch_eval(omgx_batch* b, const double* p, const double* x, const doubl
   if (e == hipSuccess) e = hipMemcpyAsync(b->d_x0, x, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_lam, lam_g, (size_t)B * d.n_con * sizeof(double), hipMemcpyHostToDevice, b->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(ipm_eval_kernel_for(b->ws_mode, b->dims.wave_ok), dim3(b->n_slabs), dim3(b->threads), (uint32_t)b->lds_bytes,
+    hipLaunchKernelGGL(ipm_eval_kernel_for(b->ws_mode, b->dims.wave_ok, b->dims.general), dim3(b->n_slabs), dim3(b->threads), (uint32_t)b->lds_bytes,
                        b->stream, d, b->dev, b->kkt_doubles, (const double*)b->d_p, (const double*)b->d_x0, (const double*)d_lam, B,
                        b->d_slabs, b->slab_doubles, d_out);
     e = hipGetLastError();

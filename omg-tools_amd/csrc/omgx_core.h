@@ -57,9 +57,12 @@ struct Dims {
   int mono_packed;   // 1: every parameter monomial has <= 4 atoms, Tables::pm_rec / sl_ell hold MonoRec; 2: <= 8 atoms, MonoRec8; 0: CSR tables only
   int n_long;        // slots with more than OMGX_SLOT_CAP monomials (the first n_long entries of Tables::sl_list)
   int n_hess;        // number of terms with >= 2 factors
-  int quartic;       // 1: some term has four factors (the passes over the item records multiply the fourth one in only then)
+  int quartic;       // 1: some term has four factors
+  int general;       // 1: quartic terms, cos / sin atoms or basis rows of degree > 5: the kernel instance that carries them
   int rp_packed;     // 1: rows and positions fit 16 bits each, Tables::je_rp is valid
   int n_knots;       // total length of the knot vectors of the atoms program (copied to LDS per solve)
+  int atoms_alias;   // 1: atoms and knots live in the space of gbar | sol (they are dead once the slots are evaluated, gbar and sol
+                     //    are first written inside the iteration): n_atoms + n_knots <= 2 N + n_eq
   int wave_ok;       // 1: every panel of the KKT store fits one wave (register-resident factorisation, omgx_wave.h)
   int n_jv;          // Jacobian entries whose value depends on x (the others are constant over a solve)
   int ka_len, kh_len, kg_len;   // records per owner bin (longest bin) of the pair / Hessian / Gershgorin passes
@@ -251,7 +254,7 @@ OMGX_HD size_t root_doubles(const Dims& d) { return ((size_t)(d.nr + 1) * (d.nr 
 
 OMGX_HD void work_split(const Dims& d, int kkt_doubles, int mode, size_t* lds, size_t* hbm) {
   size_t nl = 0, ng = 0;
-  nl += d.n_atoms + d.n_slots + d.n_knots;
+  nl += d.n_slots + (d.atoms_alias ? 0 : d.n_atoms + d.n_knots);
   nl += 2 * (size_t)d.N;
   nl += d.N + (d.N + d.n_eq);
   nl += d.N;                      // dinv
@@ -277,9 +280,11 @@ template <int MODE>
 OMGX_HD void work_carve_split(Work& w, double* lds, double* hbm, const Dims& d, int kkt_doubles) {
   double* p = lds;
   double* g = hbm;
-  w.atoms = p; p += d.n_atoms;   w.slots = p; p += d.n_slots;   w.knots = p; p += d.n_knots;
+  w.slots = p; p += d.n_slots;
+  if (!d.atoms_alias) { w.atoms = p; p += d.n_atoms; w.knots = p; p += d.n_knots; }
   w.x = p; p += d.N;             w.xt = p; p += d.N;
   w.gbar = p; p += d.N;          w.sol = p; p += d.N + d.n_eq;
+  if (d.atoms_alias) { w.atoms = w.gbar; w.knots = w.gbar + d.n_atoms; }
   w.dinv = p; p += d.N;
   w.red = p; p += 64;
   if (ws_rows_hbm(MODE)) {
@@ -309,7 +314,7 @@ OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
 // ---------------------------------------------------------------------------
 #ifdef OMGX_HOST_PORT
 struct Ctx {
-  static constexpr bool wave_only = false, hbm = false, no_wave = false, root_lds = false;
+  static constexpr bool wave_only = false, hbm = false, no_wave = false, root_lds = false, general = true;
   double* red;
   int tid() const { return 0; }
   int nthr() const { return 1; }
@@ -328,9 +333,12 @@ struct Ctx {
 #else
 // kWaveOnly: the kernel instance for templates whose panels all fit one wave (Dims::wave_ok): the blocked LDS
 // routines are not compiled into it
-template <bool kHbm, bool kWaveOnly = false, bool kRootLds = false>
+// kGeneral: the instance for templates with Dims::general set (terms with four factors, cos / sin atoms, basis rows of
+// degree > 5): the other instance does not carry that code -- at the 256-register cap of this kernel it cost spills
+template <bool kHbm, bool kWaveOnly = false, bool kRootLds = false, bool kGeneral = false>
 struct CtxT {
   static constexpr bool hbm = kHbm;
+  static constexpr bool general = kGeneral;
   static constexpr bool root_lds = kRootLds;      // Work::root holds the root block from the Schur step on (spill modes)
   static constexpr bool wave_only = kWaveOnly;
   // the wave-level routines address the KKT store as LDS: the spill-mode instances do not carry them
@@ -494,12 +502,13 @@ OMGX_FN double pp_eval_packed(const Tables& T, int pp, const double* a) {
 // the active span are computed together, the others are zero.  Span convention of the reference
 // (`basics/spline.py:131-136`): k_j < u <= k_{j+1}, closed on the left at the first knot.  Fully unrolled
 // with compile-time indices (no scratch).  out[0 .. n_fun) receives the row.
+template <bool GEN>
 OMGX_FN void bspl_row(const double* k, int n_knots, int deg, double u, double* out) {
   const int n_fun = n_knots - deg - 1;
   int j = deg;                                               // first non-degenerate span
   for (int q = deg + 1; q < n_fun; ++q) if (k[q] < u) j = q;
   const bool inside = (u >= k[0]) && (u <= k[n_knots - 1]);
-  if (deg > 5) {
+  if (GEN && deg > 5) {
     // bases of products and integrals of splines (degree 10 in the tangent-half-angle models): the same recurrence with
     // the values kept in the output row itself (N[r] ends up at out[j - deg + r]), left / right recomputed from the knots
     for (int i = 0; i < n_fun; ++i) out[i] = 0.0;
@@ -611,7 +620,7 @@ OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, co
       if (c.tid() == 0) {
         const double num = d.mono_packed == 1 ? pp_eval_packed(T, op[1], w.atoms) : pp_eval(T, op[1], w.atoms);
         if (op[0] == OP_DIV) w.atoms[op[3]] = num / (d.mono_packed == 1 ? pp_eval_packed(T, op[2], w.atoms) : pp_eval(T, op[2], w.atoms));
-        else w.atoms[op[3]] = op[0] == OP_COS ? cos(num) : sin(num);
+        else if constexpr (C::general) w.atoms[op[3]] = op[0] == OP_COS ? cos(num) : sin(num);
       }
       ++k;
       c.sync();
@@ -625,7 +634,7 @@ OMGX_FN void eval_params(const C& c, const Dims& d, const Tables& T, Work& w, co
       // one thread per basis row: the deg + 1 functions of the active span together (bspl_row)
       OMGX_PFOR(it, k2 - k) {
         const int32_t* oq = T.prog + 6 * (k + it);
-        bspl_row(w.knots + oq[1], oq[2], oq[3], w.atoms[oq[4]], w.atoms + oq[5]);
+        bspl_row<C::general>(w.knots + oq[1], oq[2], oq[3], w.atoms[oq[4]], w.atoms + oq[5]);
       }
       k = k2;
     }
@@ -689,8 +698,9 @@ OMGX_FN double jac_entry_ell_t(const JItem* ell, const int32_t* glen, int n_owne
   }
   return sj;
 }
+template <class C>
 OMGX_FN double jac_entry_ell(const Dims& d, const JItem* ell, const int32_t* glen, int n_owner, const Work& w, int i, const double* xv) {
-  return d.quartic ? jac_entry_ell_t<true>(ell, glen, n_owner, w, i, xv) : jac_entry_ell_t<false>(ell, glen, n_owner, w, i, xv);
+  return jac_entry_ell_t<C::general>(ell, glen, n_owner, w, i, xv);
 }
 
 // unscaled value of the row in slot i (row T.row_perm[i]) at xv: its terms from the ELL table, eight at a
@@ -717,8 +727,9 @@ OMGX_FN double row_value_ell_t(const Tables& T, const Work& w, int i, int m, con
   }
   return g;
 }
+template <class C>
 OMGX_FN double row_value_ell(const Dims& d, const Tables& T, const Work& w, int i, int m, const double* xv) {
-  return d.quartic ? row_value_ell_t<true>(T, w, i, m, xv) : row_value_ell_t<false>(T, w, i, m, xv);
+  return row_value_ell_t<C::general>(T, w, i, m, xv);
 }
 
 // this thread's share of row r (terms strided over the workgroup); the caller sums the shares
@@ -1797,8 +1808,9 @@ OMGX_FN void hess_bin_t(const Dims& d, const Tables& T, Work& w, int m, int bin,
   }
 }
 
+template <class C>
 OMGX_FN void hess_bin(const Dims& d, const Tables& T, Work& w, int m, int bin, int dump) {
-  if (d.quartic) hess_bin_t<true>(d, T, w, m, bin, dump); else hess_bin_t<false>(d, T, w, m, bin, dump);
+  hess_bin_t<C::general>(d, T, w, m, bin, dump);
 }
 
 // ---------------------------------------------------------------------------
@@ -1835,8 +1847,8 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // (the unscaled entries go to the KKT store, which is idle during the setup, when that is LDS: the row classification
   // below reads every entry of its row, and with two agents per CU the Jacobian values themselves live in a slab)
   double* jtmp = (C::hbm || kkt_doubles < d.nnz_j + 1) ? w.jval : w.kkt;
-  OMGX_PFOR(i, d.nnz_j) jtmp[T.ja_list[i]] = jac_entry_ell(d, T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
-  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell(d, T, w, i, m, w.x); }
+  OMGX_PFOR(i, d.nnz_j) jtmp[T.ja_list[i]] = jac_entry_ell<C>(d, T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
+  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell<C>(d, T, w, i, m, w.x); }
   if (c.tid() == 0) { jtmp[d.nnz_j] = 0.0; w.jval[d.nnz_j] = 0.0; }      // the slot padding records point at
   c.sync();
   OMGX_TOC(PH_S_JAC0);
@@ -1963,7 +1975,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         const int e = T.jv_list[i];
         const int r = d.rp_packed ? (int)((uint32_t)T.je_rp[e] >> 16) : T.je_row[e];
         const double sc = (r < m) ? ((w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r]) : 1.0;
-        const double sj = jac_entry_ell(d, T.jv_ell, T.jv_glen, d.n_jv, w, i, w.x);
+        const double sj = jac_entry_ell<C>(d, T.jv_ell, T.jv_glen, d.n_jv, w, i, w.x);
         w.jval[e] = sc * sj;
       }
     }
@@ -2177,7 +2189,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       OMGX_TOC(PH_A_TCOL);
       for (int bin = c.tid(); bin < OMGX_NBIN; bin += c.nthr()) {
         const int dump = d.dump_off + (bin & 63);
-        hess_bin(d, T, w, m, bin, dump);
+        hess_bin<C>(d, T, w, m, bin, dump);
         if (first_trial) {
           // Gershgorin row sums of the Hessian, term by term (no cancellation), owner = position
           double acc = 0.0;
@@ -2192,7 +2204,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
               const double lam = (q[i].row < m) ? w.ht[r] : 1.0;
               const double xs = w.slots[q[i].slot < 0 ? 0 : q[i].slot], x3 = w.x[q[i].vthird < 0 ? 0 : q[i].vthird];
               double h = lam * q[i].coef * (q[i].slot < 0 ? 1.0 : xs) * (q[i].vthird < 0 ? 1.0 : x3);
-              if (d.quartic) { const double x4 = w.x[q[i].vfourth < 0 ? 0 : q[i].vfourth]; h *= (q[i].vfourth < 0 ? 1.0 : x4); }
+              if constexpr (C::general) { const double x4 = w.x[q[i].vfourth < 0 ? 0 : q[i].vfourth]; h *= (q[i].vfourth < 0 ? 1.0 : x4); }
               g[i] = q[i].kind ? (h < 0.0 ? -2.0 * h : 0.0) : fabs(h);
             }
 #pragma unroll
@@ -2396,7 +2408,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       OMGX_PFOR(i, m) {
         const int r = T.row_perm[i];
         const int ty = w.rtype[r];
-        const double gv = row_value_ell(d, T, w, i, m, w.xt);      // (also for free rows: the loop bound is per wave)
+        const double gv = row_value_ell<C>(d, T, w, i, m, w.xt);      // (also for free rows: the loop bound is per wave)
         if (ty == ROW_FREE) { w.ht[r] = 0.0; continue; }
         const double h = w.rho[r] * (gv - ((ty == ROW_LOWER || ty == ROW_EQ) ? lb[r] : ub[r]));
         w.ht[r] = h;
@@ -2499,14 +2511,14 @@ OMGX_FN void ipm_eval(const C& c, const Dims& d, const Tables& T, Work& w, const
   OMGX_PFOR(i, n) w.x[i] = x[i];
   if (c.tid() == 0) w.x[n] = 0.0;
   eval_params(c, d, T, w, p);
-  OMGX_PFOR(i, d.nnz_j) w.jval[T.ja_list[i]] = jac_entry_ell(d, T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
-  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell(d, T, w, i, m, w.x); }
+  OMGX_PFOR(i, d.nnz_j) w.jval[T.ja_list[i]] = jac_entry_ell<C>(d, T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
+  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell<C>(d, T, w, i, m, w.x); }
   OMGX_PFOR(r, m) w.ht[r] = lam[r];
   OMGX_PFOR(i, kkt_doubles) w.kkt[i] = 0.0;
   const double f = c.rsum(row_value_share(c, T, w, m, w.x));
   if (c.tid() == 0) *f_out = f;
   c.sync();
-  for (int bin = c.tid(); bin < OMGX_NBIN; bin += c.nthr()) hess_bin(d, T, w, m, bin, d.dump_off + (bin & 63));
+  for (int bin = c.tid(); bin < OMGX_NBIN; bin += c.nthr()) hess_bin<C>(d, T, w, m, bin, d.dump_off + (bin & 63));
   c.sync();
 }
 

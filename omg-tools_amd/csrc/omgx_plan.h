@@ -265,6 +265,7 @@ struct HostPlan {
     d.n_slots = t.n_slots; d.n_terms = t.n_terms; d.n_prog = t.n_prog;
     if (t.n_slots > 32767) return fail("more than 32767 parameter slots (16-bit slot indices in the item records)");
     d.N = t.n_var + 1; d.n_eq = t.n_eq; d.n_knots = t.n_knots;
+    d.atoms_alias = (getenv("OMGX_NO_ATOMS_ALIAS") == nullptr && d.n_atoms + d.n_knots <= 2 * d.N + d.n_eq) ? 1 : 0;
     if (t.n_var <= 0 || t.n_con < 0 || t.n_terms < 0 || t.n_var >= 32767) return fail("bad dimensions");
     if (t.row_ptr[t.n_con + 1] != t.n_terms) return fail("row_ptr does not cover the terms");
     for (int k = 0; k < d.n_prog; ++k) {
@@ -424,6 +425,9 @@ struct HostPlan {
     d.n_hess = (int)hrec.size();
     d.quartic = 0;
     for (int tt = 0; tt < d.n_terms; ++tt) if (t.t_var[OMGX_TV * tt + OMGX_TV - 1] >= 0) d.quartic = 1;
+    d.general = d.quartic;
+    for (int k = 0; k < d.n_prog; ++k)
+      if (t.prog[6 * k] == OP_COS || t.prog[6 * k] == OP_SIN || (t.prog[6 * k] == OP_BSPL && t.prog[6 * k + 3] > 5)) d.general = 1;
     // flat tables of the parameter stage
     slot_rng.assign(2 * (size_t)(d.n_slots > 0 ? d.n_slots : 1), 0);
     for (int sl = 0; sl < d.n_slots; ++sl) { slot_rng[2 * sl] = t.pp_ptr[t.slot_pp[sl]]; slot_rng[2 * sl + 1] = t.pp_ptr[t.slot_pp[sl] + 1]; }

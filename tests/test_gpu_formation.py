@@ -10,4 +10,4 @@ def test_formation_holonomic_example_hip():
     from test_formation_cpu import formation_example, check_formation_run
     out = formation_example('hip')
     check_formation_run(*out)
-    assert out[0].ops.solver.workspace()['mode'] in (0, 1)
+    assert out[0].ops.solver.workspace()['mode'] in (0, 1, 4)       # (4: two agents per CU, the Jacobian values in a slab)
