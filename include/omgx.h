@@ -232,9 +232,10 @@ int  omgx_batch_eval(omgx_batch* b, const double* p, const double* x, const doub
  * largest iteration count, agents it solved} -- integer atomics from inside the solve kernel.  A monitoring hook for
  * resident receding-horizon loops (the reference prints these per solve, `problems/problem.py:113-127`). */
 int  omgx_batch_set_stats(omgx_batch* b, int64_t* stats_device, int32_t n_slots);
-/* Attach two hipEvent_t (as void*, created by the caller with timing enabled) to the NEXT solve launch only: they
- * receive the begin and end stamps of the solve kernel itself (carried by its dispatch packet, no extra packets on
- * the stream).  hipEventElapsedTime(start, stop) after the launch completed = the kernel's duration. */
+/* Attach two hipEvent_t (as void*, created by the caller with timing enabled) to the NEXT solve (or
+ * omgx_batch_sample) launch only: they receive the begin and end stamps of that kernel itself (carried by its dispatch
+ * packet, no extra packets on the stream).  hipEventElapsedTime(start, stop) after the launch completed = the kernel's
+ * duration. */
 int  omgx_batch_set_launch_events(omgx_batch* b, void* start_event, void* stop_event);
 /* Device time (ms) of the last solve kernel from the handle's own event pair (attached to the dispatch like the
  * caller's pair above).  omgx_batch_set_timing(b, 0) switches it off: omgx_batch_last_kernel_ms then fails until

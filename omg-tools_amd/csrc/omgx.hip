@@ -1394,12 +1394,16 @@ int omgx_batch_sample(omgx_batch* b, const double* x, int32_t coeff_off, int32_t
   const int n_span = n_knots - 2 * degree - 1, D1 = degree + 1;
   const size_t lds = sample_scratch_doubles(n_spl, degree, n_knots, n_der) * sizeof(double);
   (void)L; (void)n_span; (void)D1;
+  // (the caller's one-shot event pair of omgx_batch_set_launch_events stamps this launch as well: the duration of a
+  // 20 us kernel cannot be taken with events recorded around the call)
+  hipEvent_t e0 = b->ext_ev0, e1 = b->ext_ev1;
+  b->ext_ev0 = b->ext_ev1 = nullptr;
   if (as_f32)
-    hipLaunchKernelGGL(sample_kernel<float>, grid, block, lds, b->stream, d_xx, d.n_var, coeff_off, n_spl, degree,
-                       kn, n_knots, n_der, d_t0, dt, 1.0, n_samp, (float*)d_out, (float*)nullptr);
+    hipExtLaunchKernelGGL(sample_kernel<float>, grid, block, lds, b->stream, e0, e1, 0, d_xx, d.n_var, coeff_off, n_spl, degree,
+                          kn, n_knots, n_der, d_t0, dt, 1.0, n_samp, (float*)d_out, (float*)nullptr);
   else
-    hipLaunchKernelGGL(sample_kernel<double>, grid, block, lds, b->stream, d_xx, d.n_var, coeff_off, n_spl, degree,
-                       kn, n_knots, n_der, d_t0, dt, 1.0, n_samp, (double*)d_out, (double*)nullptr);
+    hipExtLaunchKernelGGL(sample_kernel<double>, grid, block, lds, b->stream, e0, e1, 0, d_xx, d.n_var, coeff_off, n_spl, degree,
+                          kn, n_knots, n_der, d_t0, dt, 1.0, n_samp, (double*)d_out, (double*)nullptr);
   HIPCHK(hipGetLastError());
   if (!dev) {
     HIPCHK(hipMemcpyAsync(out, d_out, out_elems * esz, hipMemcpyDeviceToHost, b->stream));
