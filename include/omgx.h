@@ -139,6 +139,15 @@ typedef struct omgx_options {
                            of the agent ended -- receding-horizon steps of one agent then need no barrier update of
                            their own; BatchP2P sets 0.1 (tol / 10 unless the shifted point is far off that central
                            path): fewer stragglers between knot crossings */
+  double  warm_z_floor;        /* multipliers handed to a warm start are lifted to warm_z_floor * tol (default 0.1; IPOPT:
+                           warm_start_mult_bound_push): after a horizon shift a row may come with a small slack and a
+                           vanished multiplier, which the Newton system does not see until the step runs into it
+                           (hundreds of iterations at step lengths of 1e-2 observed on knot-crossing x-updates) ... */
+  double  warm_z_cap;          /* ... but to no more than warm_z_cap * tol / slack (default 0.01; 0: no cap): only rows close to
+                           their bound are lifted.  Without the cap the lift of all the inactive rows raises the average
+                           complementarity and costs an ADMM x-update three iterations (formation bench: 4.3 instead of 1.2
+                           per x-update); BatchP2P sets 0 -- its steps begin at tol / 10 whatever the complementarity
+                           (warm_mu_factor 0.1), and the plain floor saves its crossing steps an iteration or two */
 } omgx_options;
 
 typedef struct omgx_batch omgx_batch;

@@ -155,6 +155,8 @@ struct Opts {
   double dw_leaf_ratio_cold;   // cold starts: inertia-correction weight of nonlinear leaf variables (root: its inverse)
   int prio_iter;               // device: iteration from which a solve runs at raised wave priority (0: never)
   double warm_mu_factor;       // warm starts: mu_0 = clamp(warm_mu_factor * mean(s z), tol / 10, mu_init)
+  double warm_z_floor;         // warm starts: multipliers lifted to max(OMGX_WARM_ZMIN, min(warm_z_floor * tol, warm_z_cap * tol / slack))
+  double warm_z_cap;           // (0: no cap)
 };
 
 // fixed constants of the iteration (same values in oracle/ipm_numpy.py DEFAULTS)
@@ -202,9 +204,6 @@ struct Opts {
 #define OMGX_STALL_ITERS 20
 #endif
 #define OMGX_WARM_ZMIN   1e-8
-#ifndef OMGX_WARM_ZREL
-#define OMGX_WARM_ZREL   0.1     // multipliers handed to a warm start are lifted to OMGX_WARM_ZREL * tol (IPOPT: warm_start_mult_bound_push)
-#endif
 #define OMGX_MAX_LEAF    16
 #define OMGX_BMAT_DOUBLES 5      // sizeof(BMat) / 8
 #define OMGX_PAN_LD 5      // panel buffer row stride: U[4] + pad (odd: conflict-free row-per-lane access)
@@ -1922,8 +1921,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         // (a row with a small slack AND a vanishing multiplier is invisible to the Newton system -- Sigma = z / s -- until the
         // step runs into it: hundreds of iterations with step lengths of 1e-2 on a knot-crossing x-update; the floor keeps
         // such rows in the picture)
-        w.z[r] = fmax(w.ds[r] / w.rho[r], fmax(OMGX_WARM_ZMIN, OMGX_WARM_ZREL * o.tol));
-        sz += row_slack(w, r, t) * w.z[r]; cnt0 += 1.0;
+        const double s_r = row_slack(w, r, t);
+        w.z[r] = fmax(w.ds[r] / w.rho[r], fmax(OMGX_WARM_ZMIN, fmin(o.warm_z_floor * o.tol, o.warm_z_cap > 0.0 ? o.warm_z_cap * o.tol / s_r : 1e300)));
+        sz += s_r * w.z[r]; cnt0 += 1.0;
       } else if (ty == ROW_EQ) {
         w.z[r] = w.ds[r] / w.rho[r];
       }

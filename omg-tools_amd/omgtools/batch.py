@@ -117,7 +117,7 @@ class BatchP2P(object):
         # (warm_mu_factor 0.1: a step starts at the barrier parameter the previous solve of the agent ended with, tol / 10,
         # unless the shifted point is far off that central path -- a tenth of its average complementarity then: at tol 1e-3
         # the same iterates as factor 0, at 1e-6 0.03 % instead of 0.4 % of the steps end at the iteration cap)
-        self.opts = dict(tol=1e-3, max_iter=300, warm_mu_factor=0.1)
+        self.opts = dict(tol=1e-3, max_iter=300, warm_mu_factor=0.1, warm_z_floor=0.1, warm_z_cap=0.0)
         self.opts.update(options or {})
         self.max_iter_cold = self.opts['max_iter']
         from .backend import DEFAULT_OPTIONS

@@ -292,6 +292,10 @@ class FormationPoint2point(object):
             from .backend import BatchSolver, options_from_problem
             opts = options_from_problem(self.options)
             opts['tol'] = self.xupdate_tol()
+            # (x-updates at 1e-6: the plain multiplier floor of a warm start, no slack cap -- over 24 updates of the host
+            # study one x-update ends at the iteration cap with it, two with the cap; at 1e-3, the bench, the cap saves
+            # three iterations per x-update: include/omgx.h warm_z_cap)
+            opts['warm_z_cap'] = 0.0
             self.solver = BatchSolver(tpl, N, options=opts)
             self.ops = HipAdmmOps(self.solver, tpl, lay, p0, x0, torch.device('cuda', 0))
         else:

@@ -25,7 +25,7 @@ DEFAULTS = dict(dw_cap_floor=0.03, tol=1e-8, max_iter=200, mu_init=0.1, kappa_ep
                 theta_mu=1.5, tau_min=0.99, s_push=1.0, delta_c=1e-8, eta=1e-4,
                 rho=0.1, dw_first=1e-4, dw_inc=10.0, dw_dec=1. / 3., dw_max=1e10, dw_zero=1e-9, dw_heavy=10.0, kappa_eps_heavy=100.0,
                 s_max=100.0, kappa_sigma=1e10, max_backtrack=25, max_soc=2,
-                slack_reset=True, kappa_push=1.0, stall_iters=20, warm_zmin=1e-8, warm_zrel=0.1, nu_init=100.0, nu_max=1e8, e_push=1.0, scale_gmax=100.0, s_phi=2.3, s_theta=1.1, delta_sw=1.0,
+                slack_reset=True, kappa_push=1.0, stall_iters=20, warm_zmin=1e-8, warm_z_floor=0.1, warm_z_cap=0.01, nu_init=100.0, nu_max=1e8, e_push=1.0, scale_gmax=100.0, s_phi=2.3, s_theta=1.1, delta_sw=1.0,
                 gamma_theta=1e-5, gamma_phi=1e-5, filter_size=8, warm_mu_factor=1.0,
                 expand_max=16.0, expand_dw=1e-2, expand_from=2)
 
@@ -302,7 +302,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         # primal-dual warm start: multipliers of the previous solve (unscaled lam_g),
         # barrier parameter from the average complementarity
         lam0 = np.asarray(z0, float) / rho
-        z = np.maximum(sig * lam0[iH], max(o['warm_zmin'], o['warm_zrel'] * o['tol']))
+        z = np.maximum(sig * lam0[iH], np.maximum(o['warm_zmin'], np.minimum(o['warm_z_floor'] * o['tol'], o['warm_z_cap'] * o['tol'] / s if o['warm_z_cap'] > 0 else np.inf)))
         y = lam0[iE].copy()
         mu = float(min(o['mu_init'], max(o['tol'] / 10., o['warm_mu_factor'] * (s * z).mean())))
     # multiplier of t >= 0: dual feasible in t (nu - v'z - c0'y - zt = 0) rather than on the central

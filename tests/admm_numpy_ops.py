@@ -98,7 +98,8 @@ class NumpyAdmmOps(object):
         if not self.warm:
             self.status[:] = 1
         r = self.port.solve(self.tpl, self.p, self.x, tol=self.tol, max_iter=300, warm_start=1,
-                            lam_g0=self.lam, status0=self.status, dw_state=self.dw)
+                            lam_g0=self.lam, status0=self.status, dw_state=self.dw,
+                            warm_z_cap=0.0 if self.tol < 1e-4 else 0.01)      # (as FormationPoint2point sets it for its 1e-6 x-updates)
         self.x, self.lam, self.status = r['x'], r['lam_g'], r['status']
         self.launches += 1
         return r['status']

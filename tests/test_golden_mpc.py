@@ -79,7 +79,7 @@ def test_port_warm_steps_match_slsqp(factor, f_tol, x_tol):
 
     def solve_step(tpl, p, x0, lam):
         return port_binding.solve(tpl, p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32), warm_start=1,
-                                  n_threads=8, tol=TOL, max_iter=500, warm_mu_factor=factor)
+                                  n_threads=8, tol=TOL, max_iter=500, warm_mu_factor=factor, warm_z_floor=0.1, warm_z_cap=0.0)
     check_steps(solve_step, f_tol, x_tol)
 
 
@@ -91,7 +91,7 @@ def test_hip_warm_steps_match_slsqp(factor, f_tol, x_tol):
 
     def solve_step(tpl, p, x0, lam):
         if 's' not in solver:
-            solver['s'] = BatchSolver(tpl, len(p), options=dict(tol=TOL, max_iter=500, warm_start=1, warm_mu_factor=factor))
+            solver['s'] = BatchSolver(tpl, len(p), options=dict(tol=TOL, max_iter=500, warm_start=1, warm_mu_factor=factor, warm_z_floor=0.1, warm_z_cap=0.0))
         return solver['s'].solve(p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32))
     try:
         check_steps(solve_step, f_tol, x_tol)
