@@ -296,7 +296,7 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
     mpc.initialize()
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
     crossings = 0
@@ -323,7 +323,7 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
         print({p_: round(float(prof[:, k].mean()) / 1e3, 1) for k, p_ in enumerate(_PH) if prof[:, k].mean() > 500}, file=sys.stderr)
     n_ok = int((status == 0).sum().item())
     res = admm.residuals[-1]
-    elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist if world > 1 else None)
+    elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist)
     if rank != 0:
         return
     print(json.dumps({
@@ -363,7 +363,7 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
     x0_init, p_init = mpc.x.clone(), mpc.p.clone()
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
     # one step = the cold solve of the whole batch from the reference's initial guess, restarts of the agents whose
@@ -383,7 +383,7 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
     status, iters = mpc.status, mpc.iters
     n_ok = int((status == 0).sum().item())
     it_sum = int(iters.sum().item())
-    elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist if world > 1 else None)
+    elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist)
     # receding-horizon steps of the same batch (the protocol of the headline: cold solve, warm-up, timed steps)
     rh_steps = max(args.steps, 10)
     for _ in range(args.warmup):
@@ -400,7 +400,7 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
     barrier()
     rh_elapsed = time.perf_counter() - t0
     rh_ok, rh_it = int((st_log == 0).sum().item()), int(it_log.sum().item())
-    rh_elapsed, rh_ok_all = reduce_report(rh_elapsed, rh_ok, device=dev, dist=dist if world > 1 else None)
+    rh_elapsed, rh_ok_all = reduce_report(rh_elapsed, rh_ok, device=dev, dist=dist)
     if rank != 0:
         return
     n = tpl.n_var
@@ -451,8 +451,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     dist = None
-    if world > 1:
+    # (OMGX_FORCE_DIST=1: the process group, the barriers and the report's all_reduces also with one rank -- the RCCL
+    # path of `--gpus N` exercised on a one-GPU box, e.g. under `python -m torch.distributed.run --nproc-per-node 1`)
+    if world > 1 or os.environ.get('OMGX_FORCE_DIST') == '1':
         import torch.distributed as dist
+        if 'MASTER_ADDR' not in os.environ:
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT', '29533'),
+                              RANK=str(rank), WORLD_SIZE=str(world))
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -476,7 +481,7 @@ def main():
     solver = mpc.solver
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -543,7 +548,7 @@ def main():
     # every launch of the solve kernel in this process (what `rocprofv3 --stats` averages over)
     launches_ms = cold_kernel_all + all_ms            # (restart passes, if any, are further launches: not in this list)
     launches_iters = len(cold_kernel_all) * cold_iters + int(stats[:, 1].sum())
-    elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist if world > 1 else None)
+    elapsed, n_ok_all = reduce_report(elapsed, n_ok, device=dev, dist=dist)
     if rank != 0:
         return
     value = n_ok_all * args.steps / elapsed
@@ -613,7 +618,6 @@ if __name__ == '__main__':
     try:
         main()
     finally:
-        if int(os.environ.get('WORLD_SIZE', 1)) > 1:
-            import torch.distributed as _dist
-            if _dist.is_initialized():
-                _dist.destroy_process_group()
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            _dist.destroy_process_group()

@@ -18,7 +18,7 @@ def shard_range(n_total, rank, world):
 
 def reduce_report(elapsed_s, n_solved, device=None, dist=None):
     """(max elapsed over ranks, total solved over ranks)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(elapsed_s), int(n_solved)
     import torch
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
