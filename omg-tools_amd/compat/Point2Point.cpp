@@ -20,7 +20,7 @@ typedef std::map<std::string, std::map<std::string, std::vector<double>>> Dict;
 
 Point2Point::Point2Point(Vehicle* vehicle, double update_time, double sample_time, double horizon_time, int trajectory_length,
                          bool initialize)
-    : tpl(nullptr), problem(nullptr), _recover(false) {
+    : _recover(false), tpl(nullptr), problem(nullptr) {
     if (trajectory_length > int(horizon_time / sample_time)) std::cerr << "trajectory_length > (horizon_time/sample_time)!" << std::endl;
     const int n_samp = std::max(trajectory_length, int(update_time / sample_time)) + 1;
     time.resize(n_samp);

@@ -35,19 +35,22 @@ typedef struct obstacle {
 
 class Point2Point {
   private:
+    bool _recover;
+    void readBlockTable();
+
+  protected:
+    // (protected rather than private: the ADMM classes of the export derive from this one and add entries of their own)
     omgx_template* tpl;
     omgx_batch* problem;
     bool solve(double, std::vector<obstacle_t>&);
-    bool _recover;
     struct Block { std::string label, name; int kind, off, rows, cols; };
     std::vector<Block> blocks;
     std::string vehicle_lbl, p2p_lbl;
     std::vector<std::string> obstacle_lbl;
     std::map<int, std::vector<double>> shift_T;          // spline degree -> shift matrix of its basis
     const Block* find(int kind, const std::string& label, const std::string& name) const;
-    void readBlockTable();
+    int last_iters = 0;
 
-  protected:
     Vehicle* vehicle;
     std::vector<double> spline_coeffs_vec;
     double current_time = 0.0;
@@ -97,8 +100,6 @@ class Point2Point {
     void getCoefficients(std::vector<double>& coeffs);
     int getLenBasis();
     int getIterations() const { return last_iters; }        // (extension: interior-point iterations of the last update)
-  private:
-    int last_iters = 0;
 };
 
 }  // namespace omg

@@ -497,6 +497,30 @@ class BatchSolver(object):
             tmats.size, PTR_DEVICE if device else 0), 'omgx_batch_shift')
 
 
+def save_admm_tables(path, layout, horizon_time, knot_time, update_time):
+    """The z-update tables the C++ ADMM classes of `omg-tools_amd/compat` read (OMG_ADMM_TABLES): for every time since the
+    last knot an update can happen at (multiples of update_time modulo knot_time), the consensus projector M and the knot
+    transform F of `formation.zupdate_matrices` -- what the reference's exporter generates as updz.so / updres.so
+    (`export/export_admm.py`).  Layout: "OMGXADM1", int32 {n_all, n_keys}, per key: t_rel, M, F (row-major doubles)."""
+    from .formation import zupdate_matrices
+    n_steps = int(round(knot_time / update_time))
+    keys = sorted(set(round((k * update_time) % knot_time, 6) for k in range(max(1, n_steps))))
+    with open(path, 'wb') as fp:
+        blobs = []
+        for t_rel in keys:
+            if hasattr(layout, 'zupdate'):
+                M, F = layout.zupdate(round(t_rel / horizon_time, 12))
+            else:
+                M, F = zupdate_matrices(layout.basis, layout.n_dim, layout.n_nghb, round(t_rel / horizon_time, 12))
+            blobs.append((t_rel, np.ascontiguousarray(M, dtype=np.float64), np.ascontiguousarray(F, dtype=np.float64)))
+        na = blobs[0][1].shape[0]
+        fp.write(b'OMGXADM1')
+        fp.write(np.array([na, len(blobs)], dtype=np.int32).tobytes())
+        for t_rel, M, F in blobs:
+            fp.write(np.float64(t_rel).tobytes()); fp.write(M.tobytes()); fp.write(F.tobytes())
+    return path
+
+
 class NlpSolver(object):
     """Single-agent solver object with the reference's `nlpsol` call shape."""
 

@@ -84,3 +84,81 @@ def test_replay_of_the_export_example_matches_the_python_path(compat_lib, tmp_pa
     text = out.stdout.decode()
     assert out.returncode == 0, text[-3000:]
     assert 'replayed %d updates' % n_iter in text
+
+
+@pytest.mark.gpu
+def test_formation_classes_of_the_export_match_the_batched_path(compat_lib, tmp_path):
+    """`omg::FormationPoint2Point` / `omg::ADMMPoint2Point` (`export/point2point/admm/...`): four vehicle objects run the
+    two-phase ADMM update in C++ (update1 -> x_i to the neighbours -> update2 -> z_ij / l_ij back) over libomgx.so, with
+    the x-update template and the z-update tables written by the Python front end; the shared variables and residuals of
+    every iteration equal the batched device path (`FormationMPC` on `HipAdmmOps`): init_iter + 1 iterations at the
+    start time, then one iteration per update across a knot crossing, the moving circle advanced."""
+    import torch
+    import omgtools.backend as be
+    from omgtools import scenarios
+    from omgtools.admm import BatchADMM, HipAdmmOps, FormationMPC
+    N, init_iter, n_updates, tol = 4, 5, 12, 1e-3
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        problem, updater, father, lay, P = scenarios.formation_holonomic(N)
+    finally:
+        be.create_nlp = saved
+    tpl = father.template
+    T, knot_time = float(problem.options['horizon_time']), float(problem.knot_time)
+    tpl_path = be.save_template(tpl, str(tmp_path / 'updx.omgx'))
+    tab_path = be.save_admm_tables(str(tmp_path / 'tables.omgx'), lay, T, knot_time, 0.1)
+    veh = problem.vehicles[0]
+    rng = lambda lab, nm: tpl.entry_range(lab, nm, 'par')
+    # the scenario for the C++ program
+    with open(str(tmp_path / 'scenario.bin'), 'wb') as fp:
+        n_iter = init_iter + 1 + n_updates
+        obstacles = problem.environment.obstacles
+        fp.write(np.array([N, lay.n_nghb, n_iter, init_iter, len(obstacles)], dtype=np.int32).tobytes())
+        fp.write(np.float64(1.0).tobytes())
+        for b in range(N):
+            for nm in ('state0', 'poseT', 'rel_pos_c'):
+                a, e = rng(veh.label, nm)
+                fp.write(np.ascontiguousarray(P['p'][b, a:e]).tobytes())
+        fp.write(np.ascontiguousarray(P['nbr'], dtype=np.int32).tobytes())
+        for obs in obstacles:
+            (ax, ex), (av, ev), (ac, ec), (ar, er) = rng(obs.label, 'x'), rng(obs.label, 'v'), rng(obs.label, 'checkpoints'), rng(obs.label, 'rad')
+            fp.write(np.ascontiguousarray(P['p'][0, ax:ex]).tobytes()); fp.write(np.ascontiguousarray(P['p'][0, av:ev]).tobytes())
+            fp.write(np.int32(er - ar).tobytes())
+            fp.write(np.ascontiguousarray(P['p'][0, ac:ec]).tobytes()); fp.write(np.ascontiguousarray(P['p'][0, ar:er]).tobytes())
+    # the batched device path, same protocol
+    solver = be.BatchSolver(tpl, N, options=dict(tol=tol, max_iter=500))
+    ops = HipAdmmOps(solver, tpl, lay, P['p'], P['x0'], torch.device('cuda', 0))
+    admm = BatchADMM(lay, P['nbr'], ops, rho=1.0)
+    moving = []
+    for obs in problem.environment.obstacles:
+        ox, ov, oa = (tpl.entry_range(obs.label, nm, 'par') for nm in ('x', 'v', 'a'))
+        if np.any(P['p'][:, ov[0]:ov[1]] != 0.):
+            moving.append((ox[0], ov[0], oa[0], ox[1] - ox[0]))
+    mpc = FormationMPC(admm, father, tpl, lay, veh, obstacles=moving, update_time=0.1, init_iter=init_iter + 1, knot_time=knot_time)
+    want_x, crossings = [], 0
+    admm.initialize()
+    for _ in range(init_iter + 1):
+        st, _ = admm.iterate(0.0, sync=False)
+        want_x.append(ops.center(lay).cpu().numpy().copy())
+    for _ in range(n_updates):
+        st, crossed = mpc.step()
+        crossings += int(crossed)
+        assert (st.cpu().numpy() == 0).all()
+        want_x.append(ops.center(lay).cpu().numpy().copy())
+    want_res = np.array(admm.residuals)
+    solver.close()
+    assert crossings == 1
+    exe = str(tmp_path / 'formation')
+    subprocess.check_call(['g++', '-std=c++14', '-O1', os.path.join(ROOT, 'tests', 'cpp', 'formation.cpp'), '-I', COMPAT, '-L', COMPAT,
+                           '-lomg_compat', '-L', CSRC, '-lomgx', '-Wl,-rpath,' + COMPAT, '-Wl,-rpath,' + CSRC, '-o', exe])
+    env = dict(os.environ, OMG_TEMPLATE=tpl_path, OMG_ADMM_TABLES=tab_path, OMG_TOL=str(tol))
+    out = subprocess.run([exe, str(tmp_path / 'scenario.bin'), str(tmp_path / 'out.bin')], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=300)
+    assert out.returncode == 0, out.stdout.decode()[-3000:]
+    got = np.frombuffer(open(str(tmp_path / 'out.bin'), 'rb').read()).reshape(n_iter, N, lay.ns + 3)
+    for it in range(n_iter):
+        assert np.abs(got[it, :, :lay.ns] - want_x[it]).max() < 1e-4, (it, np.abs(got[it, :, :lay.ns] - want_x[it]).max())
+        pr, dr = np.sqrt(got[it, :, lay.ns].sum()), np.sqrt(got[it, :, lay.ns + 1].sum())
+        assert abs(pr - want_res[it][0]) < 1e-4 * (1 + want_res[it][0]) + 1e-6, (it, pr, want_res[it])
+        assert abs(dr - want_res[it][1]) < 1e-4 * (1 + want_res[it][1]) + 1e-6, (it, dr, want_res[it])
