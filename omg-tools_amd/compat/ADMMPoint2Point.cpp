@@ -7,6 +7,7 @@
 // does this class (it is what the test compares with).
 #include "ADMMPoint2Point.hpp"
 #include "FormationPoint2Point.hpp"
+#include "RendezVous.hpp"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -157,7 +158,7 @@ bool ADMMPoint2Point::update2(std::vector<std::vector<double>>& x_j_var, std::ve
 bool ADMMPoint2Point::solveUpdx(double now, std::vector<obstacle_t>& obstacles) {
     Point2Point::setParameters(obstacles);                          // (before initVariablesADMM: the vehicle's conditions)
     if (iteration == 0) {
-        Point2Point::initVariables();
+        initVariables();                                            // (virtual: RendezVous adds its free end point)
         initVariablesADMM();
         Point2Point::setParameters(obstacles);                      // again, with the initial consensus variables
     }
@@ -330,6 +331,64 @@ void FormationPoint2Point::retrieveSharedVariables(Dict& var_dict) {
     std::vector<double>& x_i = variables_admm["x_i"];
     x_i.resize(c.size());
     for (size_t q = 0; q < c.size(); ++q) x_i[q] = c[q] + rel_pos_c[q / L];
+}
+
+// ---- RendezVous ------------------------------------------------------------------------------------------------------
+RendezVous::RendezVous(Vehicle* vehicle, double update_time, double sample_time, double horizon_time, int trajectory_length,
+                       int init_iter, double rho)
+    : ADMMPoint2Point(vehicle, update_time, sample_time, horizon_time, trajectory_length, init_iter, rho), rel_pos_c(n_dim, 0.0) {
+    for (const Block& b : blocks) if (b.kind == OMGX_BLOCK_VAR && b.name == "conT0") free_lbl = b.label;
+    if (free_lbl.empty()) throw std::runtime_error("omg::RendezVous: the template has no free end point (conT0)");
+}
+RendezVous::RendezVous(Vehicle* vehicle, double update_time, double sample_time, double horizon_time)
+    : RendezVous(vehicle, update_time, sample_time, horizon_time, int(update_time / sample_time), OMG_INITITER, OMG_RHO) {}
+RendezVous::RendezVous(Vehicle* vehicle, double update_time, double sample_time, double horizon_time, int trajectory_length)
+    : RendezVous(vehicle, update_time, sample_time, horizon_time, trajectory_length, OMG_INITITER, OMG_RHO) {}
+RendezVous::RendezVous(Vehicle* vehicle, double update_time, double sample_time, double horizon_time, int trajectory_length, int init_iter)
+    : RendezVous(vehicle, update_time, sample_time, horizon_time, trajectory_length, init_iter, OMG_RHO) {}
+
+bool RendezVous::update1(std::vector<double>& condition0, std::vector<double>& conditionT,
+                         std::vector<std::vector<double>>& state_traj, std::vector<std::vector<double>>& input_traj,
+                         std::vector<double>& x_var, std::vector<std::vector<double>>& z_ji_var,
+                         std::vector<std::vector<double>>& l_ji_var, std::vector<obstacle_t>& obstacles, std::vector<double>& rel_pos_c) {
+    return update1(condition0, conditionT, state_traj, input_traj, x_var, z_ji_var, l_ji_var, obstacles, rel_pos_c, 0);
+}
+
+bool RendezVous::update1(std::vector<double>& condition0, std::vector<double>& conditionT,
+                         std::vector<std::vector<double>>& state_traj, std::vector<std::vector<double>>& input_traj,
+                         std::vector<double>& x_var, std::vector<std::vector<double>>& z_ji_var,
+                         std::vector<std::vector<double>>& l_ji_var, std::vector<obstacle_t>& obstacles,
+                         std::vector<double>& rel_pos_c, int predict_shift) {
+    this->rel_pos_c = rel_pos_c;
+    return ADMMPoint2Point::update1(condition0, conditionT, state_traj, input_traj, x_var, z_ji_var, l_ji_var, obstacles, predict_shift);
+}
+
+bool RendezVous::update2(std::vector<std::vector<double>>& x_j_var, std::vector<std::vector<double>>& z_ij_var,
+                         std::vector<std::vector<double>>& l_ij_var, std::vector<double>& res) {
+    return ADMMPoint2Point::update2(x_j_var, z_ij_var, l_ij_var, res);
+}
+
+void RendezVous::fillParameterDict(std::vector<obstacle_t>& obstacles, Dict& par_dict) {
+    ADMMPoint2Point::fillParameterDict(obstacles, par_dict);
+    par_dict[vehicle_lbl]["rel_pos_c"] = rel_pos_c;
+}
+
+// the first guess of the free end point is the terminal condition the caller handed in (`point2point.py:391-399`)
+void RendezVous::initVariables() {
+    Point2Point::initVariables();
+    std::map<std::string, std::vector<double>> veh;
+    vehicle->setParameters(veh);
+    Dict var_dict;
+    var_dict[free_lbl]["conT0"] = veh["poseT"];
+    getVariableVector(variables, var_dict);
+}
+
+// the meeting point this vehicle believes in: its free end point + its position relative to it
+void RendezVous::retrieveSharedVariables(Dict& var_dict) {
+    const std::vector<double>& c = var_dict[free_lbl]["conT0"];
+    std::vector<double>& x_i = variables_admm["x_i"];
+    x_i.resize(c.size());
+    for (size_t q = 0; q < c.size(); ++q) x_i[q] = c[q] + rel_pos_c[q];
 }
 
 }  // namespace omg

@@ -72,7 +72,7 @@ class Point2Point {
     const int freeT = 0;
 
     void setParameters(std::vector<obstacle_t>&);
-    void initVariables();
+    virtual void initVariables();          // (virtual here: RendezVous also initialises its free end point)
     void updateBounds(double, std::vector<obstacle_t>&);
     void retrieveTrajectories(std::vector<std::vector<double>>&);
     void getParameterVector(std::vector<double>&, std::map<std::string, std::map<std::string, std::vector<double>>>&);

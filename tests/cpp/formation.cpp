@@ -3,20 +3,23 @@
 // process -- update1 of every vehicle, the x_i handed to the neighbours, update2 of every vehicle, the z_ij / l_ij handed
 // back as z_ji / l_ji -- and write the shared variables and residuals of every iteration for the Python test to compare
 // with the batched path.
-//   formation <scenario.bin> <out.bin>
+//   formation <scenario.bin> <out.bin> [rendezvous]      (third argument: omg::RendezVous objects instead)
 // scenario: int32 {N, n_nghb, n_iter, init_iter, n_obs}, double rho, then per vehicle start[2] goal[2] rel_pos_c[2], the
 // neighbour table int32 [N][n_nghb], per obstacle pos[2] vel[2], int32 n_chk, checkpoints[2 n_chk], radii[n_chk].
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <iostream>
+#include <string>
 #include <vector>
 #include "FormationPoint2Point.hpp"
+#include "RendezVous.hpp"
 #include "Holonomic.hpp"
 
 using namespace std;
 
-int main(int argc, char** argv) {
+template <class Problem>
+static int run(int argc, char** argv) {
     if (argc < 3) { cerr << "usage: formation scenario.bin out.bin" << endl; return 2; }
     FILE* fp = fopen(argv[1], "rb");
     int32_t hdr[5];
@@ -42,11 +45,11 @@ int main(int argc, char** argv) {
     const double horizon_time = 10, sample_time = 0.01, update_time = 0.1;
     const int trajectory_length = 20;
     vector<omg::Holonomic*> vehicles(N);
-    vector<omg::FormationPoint2Point*> problems(N);
+    vector<Problem*> problems(N);
     for (int i = 0; i < N; ++i) {
         vehicles[i] = new omg::Holonomic();
         vehicles[i]->setIdealPrediction(true);
-        problems[i] = new omg::FormationPoint2Point(vehicles[i], update_time, sample_time, horizon_time, trajectory_length, init_iter, rho);
+        problems[i] = new Problem(vehicles[i], update_time, sample_time, horizon_time, trajectory_length, init_iter, rho);
     }
     const int ns = problems[0]->n_shared;
     vector<vector<double>> x_var(N, vector<double>(ns));
@@ -80,4 +83,9 @@ int main(int argc, char** argv) {
     fclose(fo);
     cout << "ran " << n_iter << " ADMM iterations of " << N << " vehicles, time " << problems[0]->getCurrentTime() << endl;
     return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 3 && string(argv[3]) == "rendezvous") return run<omg::RendezVous>(argc, argv);
+    return run<omg::FormationPoint2Point>(argc, argv);
 }

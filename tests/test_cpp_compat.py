@@ -162,3 +162,69 @@ def test_formation_classes_of_the_export_match_the_batched_path(compat_lib, tmp_
         pr, dr = np.sqrt(got[it, :, lay.ns].sum()), np.sqrt(got[it, :, lay.ns + 1].sum())
         assert abs(pr - want_res[it][0]) < 1e-4 * (1 + want_res[it][0]) + 1e-6, (it, pr, want_res[it])
         assert abs(dr - want_res[it][1]) < 1e-4 * (1 + want_res[it][1]) + 1e-6, (it, dr, want_res[it])
+
+
+@pytest.mark.gpu
+def test_rendezvous_class_of_the_export_matches_the_batched_path(compat_lib, tmp_path):
+    """`omg::RendezVous` (`export/point2point/admm/rendezvous/RendezVous.hpp`): four vehicle objects agree on a meeting
+    point through update1 / update2 in C++ -- shared variable = free end point + rel_pos_c, a plain vector (no knot
+    transform of the consensus) -- like the batched device path (`FormationMPC(consensus_is_spline=False)`)."""
+    import torch
+    import omgtools.backend as be
+    from omgtools import scenarios
+    from omgtools.admm import BatchADMM, HipAdmmOps, FormationMPC
+    N, init_iter, n_updates, tol, rho = 4, 5, 12, 1e-3, 2.0
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        problem, updater, father, lay, P = scenarios.rendezvous_holonomic(N)
+    finally:
+        be.create_nlp = saved
+    tpl = father.template
+    T, knot_time = float(problem.options['horizon_time']), float(problem.knot_time)
+    tpl_path = be.save_template(tpl, str(tmp_path / 'updx.omgx'))
+    tab_path = be.save_admm_tables(str(tmp_path / 'tables.omgx'), lay, T, knot_time, 0.1)
+    veh = problem.vehicles[0]
+    rng = lambda lab, nm: tpl.entry_range(lab, nm, 'par')
+    n_iter = init_iter + 1 + n_updates
+    with open(str(tmp_path / 'scenario.bin'), 'wb') as fp:
+        obstacles = problem.environment.obstacles
+        fp.write(np.array([N, lay.n_nghb, n_iter, init_iter, len(obstacles)], dtype=np.int32).tobytes())
+        fp.write(np.float64(rho).tobytes())
+        for b in range(N):
+            for nm in ('state0', 'poseT', 'rel_pos_c'):
+                a, e = rng(veh.label, nm)
+                fp.write(np.ascontiguousarray(P['p'][b, a:e]).tobytes())
+        fp.write(np.ascontiguousarray(P['nbr'], dtype=np.int32).tobytes())
+        for obs in obstacles:
+            (ax, ex), (ac, ec), (ar, er) = rng(obs.label, 'x'), rng(obs.label, 'checkpoints'), rng(obs.label, 'rad')
+            fp.write(np.ascontiguousarray(P['p'][0, ax:ex]).tobytes()); fp.write(np.zeros(2).tobytes())
+            fp.write(np.int32(er - ar).tobytes())
+            fp.write(np.ascontiguousarray(P['p'][0, ac:ec]).tobytes()); fp.write(np.ascontiguousarray(P['p'][0, ar:er]).tobytes())
+    solver = be.BatchSolver(tpl, N, options=dict(tol=tol, max_iter=500))
+    ops = HipAdmmOps(solver, tpl, lay, P['p'], P['x0'], torch.device('cuda', 0))
+    admm = BatchADMM(lay, P['nbr'], ops, rho=rho)
+    mpc = FormationMPC(admm, father, tpl, lay, veh, update_time=0.1, init_iter=init_iter + 1, knot_time=knot_time,
+                       consensus_is_spline=False)
+    want_x = []
+    admm.initialize()
+    for _ in range(init_iter + 1):
+        admm.iterate(0.0, sync=False)
+        want_x.append(ops.center(lay).cpu().numpy().copy())
+    for _ in range(n_updates):
+        st, crossed = mpc.step()
+        assert (st.cpu().numpy() == 0).all()
+        want_x.append(ops.center(lay).cpu().numpy().copy())
+    solver.close()
+    exe = str(tmp_path / 'formation')
+    subprocess.check_call(['g++', '-std=c++14', '-O1', os.path.join(ROOT, 'tests', 'cpp', 'formation.cpp'), '-I', COMPAT, '-L', COMPAT,
+                           '-lomg_compat', '-L', CSRC, '-lomgx', '-Wl,-rpath,' + COMPAT, '-Wl,-rpath,' + CSRC, '-o', exe])
+    env = dict(os.environ, OMG_TEMPLATE=tpl_path, OMG_ADMM_TABLES=tab_path, OMG_TOL=str(tol))
+    out = subprocess.run([exe, str(tmp_path / 'scenario.bin'), str(tmp_path / 'out.bin'), 'rendezvous'], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert out.returncode == 0, out.stdout.decode()[-3000:]
+    got = np.frombuffer(open(str(tmp_path / 'out.bin'), 'rb').read()).reshape(n_iter, N, lay.ns + 3)
+    for it in range(n_iter):
+        assert np.abs(got[it, :, :lay.ns] - want_x[it]).max() < 1e-4, (it, np.abs(got[it, :, :lay.ns] - want_x[it]).max())
+    # the four meeting points (shared variables) end close to each other
+    assert np.abs(got[-1, :, :lay.ns] - got[-1, :, :lay.ns].mean(axis=0)).max() < 0.2
