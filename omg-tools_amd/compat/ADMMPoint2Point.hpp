@@ -21,31 +21,33 @@ class ADMMPoint2Point : public Point2Point {
     int init_iter;
     int32_t status = 1;                                   // of the previous x-update (1: the next one starts cold)
     double t_update = 0.0;                                // time of the last x-update (the z-update's)
-    std::vector<double> residuals;
-    std::vector<double> tab_t, tab_M, tab_F;              // [n_keys], [n_keys][na x na] each
-    bool solveUpdx(double, std::vector<obstacle_t>&);
+    vec_t residuals;
+    vec_t tab_t, tab_M, tab_F;              // [n_keys], [n_keys][na x na] each
+    bool solveUpdx(double, obstacles_t&);
     bool solveUpdz();
     bool solveUpdl();
     bool computeResiduals();
     void initVariablesADMM();
     void loadTables();
-    const double* table(const std::vector<double>& tab) const;
+    const double* table(const vec_t& tab) const;
     void transformSharedSplines(double, double);
 
   protected:
     double rho;
     int n_nghb = 0;
     std::string admm_lbl;
-    std::map<std::string, std::vector<double>> variables_admm;
+    std::map<std::string, vec_t> variables_admm;
     virtual void generateProblem();
     virtual void extractData();
-    virtual void fillParameterDict(std::vector<obstacle_t>&, std::map<std::string, std::map<std::string, std::vector<double>>>&);
+    virtual void fillParameterDict(obstacles_t&, dict_t&);
     // the shared variable of this vehicle from its solution (`@retrieveSharedVariables@` of the exporter): the trajectory
     // splines themselves here, the fleet centre in FormationPoint2Point
-    virtual void retrieveSharedVariables(std::map<std::string, std::map<std::string, std::vector<double>>>&);
-    virtual bool update1(std::vector<double>&, std::vector<double>&, std::vector<std::vector<double>>&, std::vector<std::vector<double>>&, std::vector<double>&, std::vector<std::vector<double>>&, std::vector<std::vector<double>>&, std::vector<obstacle_t>&);
-    virtual bool update1(std::vector<double>&, std::vector<double>&, std::vector<std::vector<double>>&, std::vector<std::vector<double>>&, std::vector<double>&, std::vector<std::vector<double>>&, std::vector<std::vector<double>>&, std::vector<obstacle_t>&, int);
-    virtual bool update2(std::vector<std::vector<double>>&, std::vector<std::vector<double>>&, std::vector<std::vector<double>>&, std::vector<double>&);
+    virtual void retrieveSharedVariables(dict_t&);
+    virtual bool update1(vec_t& condition0, vec_t& conditionT, mat_t& state_trajectory, mat_t& input_trajectory, vec_t& x_i,
+                         mat_t& z_ji, mat_t& l_ji, obstacles_t& obstacles);
+    virtual bool update1(vec_t& condition0, vec_t& conditionT, mat_t& state_trajectory, mat_t& input_trajectory, vec_t& x_i,
+                         mat_t& z_ji, mat_t& l_ji, obstacles_t& obstacles, int predict_shift);
+    virtual bool update2(mat_t& x_j, mat_t& z_ij, mat_t& l_ij, vec_t& residuals);
 
   public:
     int n_shared = 0;

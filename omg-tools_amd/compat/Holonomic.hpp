@@ -9,19 +9,19 @@ namespace omg {
 
 class Holonomic : public Vehicle {
   private:
-    std::vector<double> poseT;
+    vec_t poseT;
 
   public:
     Holonomic();
-    void setInitialConditions(std::vector<double>& conditions);
-    void setTerminalConditions(std::vector<double>& conditions);
-    void setParameters(std::map<std::string, std::vector<double>>& par_dict);
-    void ode(std::vector<double>& state, std::vector<double>& input, std::vector<double>& dstate);
-    void getInitSplineValue(std::vector<std::vector<double>>& init_value);
-    void splines2State(std::vector<std::vector<double>>& spline_coeffs, std::vector<double> time,
-                       std::vector<std::vector<double>>& state);
-    void splines2Input(std::vector<std::vector<double>>& spline_coeffs, std::vector<double> time,
-                       std::vector<std::vector<double>>& input);
+    void setInitialConditions(vec_t& conditions);
+    void setTerminalConditions(vec_t& conditions);
+    void setParameters(std::map<std::string, vec_t>& par_dict);
+    void ode(vec_t& state, vec_t& input, vec_t& dstate);
+    void getInitSplineValue(mat_t& init_value);
+    void splines2State(mat_t& spline_coeffs, vec_t time,
+                       mat_t& state);
+    void splines2Input(mat_t& spline_coeffs, vec_t time,
+                       mat_t& input);
 };
 
 }  // namespace omg

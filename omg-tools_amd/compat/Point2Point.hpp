@@ -24,14 +24,15 @@ namespace omg {
 const double inf = std::numeric_limits<double>::infinity();
 
 typedef struct obstacle {
-    std::vector<double> position;
-    std::vector<double> velocity;
-    std::vector<double> acceleration;
-    std::vector<double> checkpoints;
-    std::vector<double> radii;
-    std::vector<double> traj_coeffs;     // (kept for datatype compatibility; not used by fixed-T problems)
+    vec_t position;
+    vec_t velocity;
+    vec_t acceleration;
+    vec_t checkpoints;
+    vec_t radii;
+    vec_t traj_coeffs;     // (kept for datatype compatibility; not used by fixed-T problems)
     bool avoid;
 } obstacle_t;
+typedef std::vector<obstacle_t> obstacles_t;
 
 class Point2Point {
   private:
@@ -42,46 +43,46 @@ class Point2Point {
     // (protected rather than private: the ADMM classes of the export derive from this one and add entries of their own)
     omgx_template* tpl;
     omgx_batch* problem;
-    bool solve(double, std::vector<obstacle_t>&);
+    bool solve(double, obstacles_t&);
     struct Block { std::string label, name; int kind, off, rows, cols; };
     std::vector<Block> blocks;
     std::string vehicle_lbl, p2p_lbl;
     std::vector<std::string> obstacle_lbl;
-    std::map<int, std::vector<double>> shift_T;          // spline degree -> shift matrix of its basis
+    std::map<int, vec_t> shift_T;          // spline degree -> shift matrix of its basis
     const Block* find(int kind, const std::string& label, const std::string& name) const;
     int last_iters = 0;
 
     Vehicle* vehicle;
-    std::vector<double> spline_coeffs_vec;
+    vec_t spline_coeffs_vec;
     double current_time = 0.0;
     double current_time_prev = 0.0;
     double horizon_time;
     double update_time;
     double sample_time;
     int trajectory_length;
-    std::vector<double> parameters;
-    std::vector<double> variables;
-    std::vector<double> multipliers;
-    std::vector<double> lbg;
-    std::vector<double> ubg;
-    std::vector<double> time;
-    std::vector<std::vector<double>> state_trajectory;
-    std::vector<std::vector<double>> input_trajectory;
+    vec_t parameters;
+    vec_t variables;
+    vec_t multipliers;
+    vec_t lbg;
+    vec_t ubg;
+    vec_t time;
+    mat_t state_trajectory;
+    mat_t input_trajectory;
     std::string solver_output;
     int n_var, n_par, n_con;
     const int freeT = 0;
 
-    void setParameters(std::vector<obstacle_t>&);
+    void setParameters(obstacles_t&);
     virtual void initVariables();          // (virtual here: RendezVous also initialises its free end point)
-    void updateBounds(double, std::vector<obstacle_t>&);
-    void retrieveTrajectories(std::vector<std::vector<double>>&);
-    void getParameterVector(std::vector<double>&, std::map<std::string, std::map<std::string, std::vector<double>>>&);
-    void getVariableVector(std::vector<double>&, std::map<std::string, std::map<std::string, std::vector<double>>>&);
-    void getVariableDict(std::vector<double>&, std::map<std::string, std::map<std::string, std::vector<double>>>&);
+    void updateBounds(double, obstacles_t&);
+    void retrieveTrajectories(mat_t&);
+    void getParameterVector(vec_t&, dict_t&);
+    void getVariableVector(vec_t&, dict_t&);
+    void getVariableDict(vec_t&, dict_t&);
     void transformSplines(double, double);
 
     virtual void generateProblem();
-    virtual void fillParameterDict(std::vector<obstacle_t>&, std::map<std::string, std::map<std::string, std::vector<double>>>&);
+    virtual void fillParameterDict(obstacles_t&, dict_t&);
     virtual void extractData();
     virtual void initialize();
 
@@ -95,9 +96,10 @@ class Point2Point {
     virtual void reset();
     virtual void resetTime();
     virtual void recover();
-    bool update(std::vector<double>&, std::vector<double>&, std::vector<std::vector<double>>&, std::vector<std::vector<double>>&, std::vector<obstacle_t>&);
-    bool update(std::vector<double>&, std::vector<double>&, std::vector<std::vector<double>>&, std::vector<std::vector<double>>&, std::vector<obstacle_t>&, int);
-    void getCoefficients(std::vector<double>& coeffs);
+    bool update(vec_t& condition0, vec_t& conditionT, mat_t& state_trajectory, mat_t& input_trajectory, obstacles_t& obstacles);
+    bool update(vec_t& condition0, vec_t& conditionT, mat_t& state_trajectory, mat_t& input_trajectory, obstacles_t& obstacles,
+                int predict_shift);
+    void getCoefficients(vec_t& coeffs);
     int getLenBasis();
     int getIterations() const { return last_iters; }        // (extension: interior-point iterations of the last update)
 };

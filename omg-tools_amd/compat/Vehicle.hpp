@@ -14,46 +14,51 @@
 
 namespace omg {
 
+// (shorthands of this layer; the reference's headers spell the types out, callers' code compiles against either)
+typedef std::vector<double> vec_t;
+typedef std::vector<std::vector<double>> mat_t;
+typedef std::map<std::string, std::map<std::string, std::vector<double>>> dict_t;
+
 class Vehicle {
   private:
     int n_st, n_in, n_spl, degree, len_basis, knot_intervals;
     bool ideal_prediction, provide_prediction;
     double horizon_time;
-    std::vector<double> knots;                       // on [0, 1]: degree + 1 zeros, the interior breaks, degree + 1 ones
-    std::vector<double> predicted_state, predicted_input;
+    vec_t knots;                       // on [0, 1]: degree + 1 zeros, the interior breaks, degree + 1 ones
+    vec_t predicted_state, predicted_input;
     // coefficients of the o-th derivative (w.r.t. the normalised time) = derivative_T[o] * coefficients
-    std::vector<std::vector<std::vector<double>>> derivative_T;
+    std::vector<mat_t> derivative_T;
 
-    void integrate(std::vector<double>& state0, std::vector<std::vector<double>>& input, std::vector<double>& stateT,
+    void integrate(vec_t& state0, mat_t& input, vec_t& stateT,
                    double sample_time, int steps);
     void createDerivativeMatrices();
 
   protected:
-    double evalSpline(double x, const std::vector<double>& knots, const std::vector<double>& coeffs, int degree);
-    void sampleSplines(std::vector<std::vector<double>>& spline_coeffs, std::vector<double> time, int derivative,
-                       std::vector<std::vector<double>>& spline_sampled);
-    void sampleSplines(std::vector<std::vector<double>>& spline_coeffs, std::vector<double> time,
-                       std::vector<std::vector<double>>& spline_sampled);
-    void getPrediction(std::vector<double>& state, std::vector<double>& input);
-    void setPrediction(std::vector<double>& state, std::vector<double>& input);
+    double evalSpline(double x, const vec_t& knots, const vec_t& coeffs, int degree);
+    void sampleSplines(mat_t& spline_coeffs, vec_t time, int derivative,
+                       mat_t& spline_sampled);
+    void sampleSplines(mat_t& spline_coeffs, vec_t time,
+                       mat_t& spline_sampled);
+    void getPrediction(vec_t& state, vec_t& input);
+    void setPrediction(vec_t& state, vec_t& input);
 
   public:
-    virtual void setInitialConditions(std::vector<double>& conditions) = 0;
-    virtual void setTerminalConditions(std::vector<double>& conditions) = 0;
-    virtual void getInitSplineValue(std::vector<std::vector<double>>& init_value) = 0;
-    virtual void setParameters(std::map<std::string, std::vector<double>>& par_dict) = 0;
-    virtual void ode(std::vector<double>& state, std::vector<double>& input, std::vector<double>& dstate) = 0;
-    virtual void splines2State(std::vector<std::vector<double>>& spline_coeffs, std::vector<double> time,
-                               std::vector<std::vector<double>>& state) = 0;
-    virtual void splines2Input(std::vector<std::vector<double>>& spline_coeffs, std::vector<double> time,
-                               std::vector<std::vector<double>>& input) = 0;
+    virtual void setInitialConditions(vec_t& conditions) = 0;
+    virtual void setTerminalConditions(vec_t& conditions) = 0;
+    virtual void getInitSplineValue(mat_t& init_value) = 0;
+    virtual void setParameters(std::map<std::string, vec_t>& par_dict) = 0;
+    virtual void ode(vec_t& state, vec_t& input, vec_t& dstate) = 0;
+    virtual void splines2State(mat_t& spline_coeffs, vec_t time,
+                               mat_t& state) = 0;
+    virtual void splines2Input(mat_t& spline_coeffs, vec_t time,
+                               mat_t& input) = 0;
     virtual ~Vehicle() {}
 
     Vehicle(int n_st, int n_in, int n_spl, int degree, int knot_intervals);
     Vehicle(int n_st, int n_in, int n_spl, int degree);
 
-    void predict(std::vector<double>& state0, std::vector<std::vector<double>>& state_trajectory,
-                 std::vector<std::vector<double>>& input_trajectory, double predict_time, double sample_time,
+    void predict(vec_t& state0, mat_t& state_trajectory,
+                 mat_t& input_trajectory, double predict_time, double sample_time,
                  int predict_shift);
     void setKnotHorizon(double horizon_time);
     void setIdealPrediction(bool ideal_prediction);
@@ -67,13 +72,13 @@ class Vehicle {
 };
 
 // B-spline helpers shared with Point2Point (clamped uniform basis on [0, 1])
-std::vector<double> clampedUniformKnots(int degree, int knot_intervals);
+vec_t clampedUniformKnots(int degree, int knot_intervals);
 // all basis functions of the span that holds x (reference convention `basics/spline.py:131-136`: spans are
 // (k_j, k_{j+1}], closed on the left at the first knot); returns the index of the first non-zero function
-int basisFunctions(const std::vector<double>& knots, int degree, double x, std::vector<double>& values);
+int basisFunctions(const vec_t& knots, int degree, double x, vec_t& values);
 // Horizon shift by one knot interval (`basics/spline_extra.py:165-191` shiftoverknot_T): c' = T c describes
 // s(tau + 1 / knot_intervals) on the same knots, the last span continuing the last polynomial piece.  Row-major L x L.
-std::vector<double> shiftOverKnot(int degree, int knot_intervals);
+vec_t shiftOverKnot(int degree, int knot_intervals);
 
 }  // namespace omg
 #endif
