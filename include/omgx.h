@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define OMGX_VERSION 4
+#define OMGX_VERSION 5
 #define OMGX_TERM_VARS 4      /* variables per term (version 3: three) */
 
 /* error codes */
@@ -148,6 +148,11 @@ typedef struct omgx_options {
                            complementarity and costs an ADMM x-update three iterations (formation bench: 4.3 instead of 1.2
                            per x-update); BatchP2P sets 0 -- its steps begin at tol / 10 whatever the complementarity
                            (warm_mu_factor 0.1), and the plain floor saves its crossing steps an iteration or two */
+  int32_t max_soc;             /* (version 5) 1 (default): a line search whose first trial is rejected offers the step once more with a
+                           second-order correction -- one more solve with the factors of the iteration for the amount the rows
+                           moved beyond their linearisation (the bilinear hyperplane rows) -- before it halves the step (IPOPT:
+                           max_soc, the component replaced behind `basics/optilayer.py:60`); 0: plain backtracking.  Templates
+                           whose KKT panels fit the register-resident wave routines (omgx_plan_info.wave_path) */
 } omgx_options;
 
 typedef struct omgx_batch omgx_batch;

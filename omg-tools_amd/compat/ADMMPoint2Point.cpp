@@ -58,7 +58,7 @@ void ADMMPoint2Point::generateProblem() {
     opt.tol = getenv("OMG_TOL") ? atof(getenv("OMG_TOL")) : 1e-3;
     opt.max_iter = 500;
     opt.warm_start = 1;
-    if (opt.tol < 1e-4) opt.warm_z_cap = 0.0;          // (as `formation.FormationPoint2point` sets it for tight x-updates)
+    if (opt.tol < 1e-4) { opt.warm_z_cap = 0.0; opt.max_soc = 0; }          // (as `formation.FormationPoint2point` sets it for tight x-updates)
     if (omgx_batch_set_options(problem, &opt) != OMGX_OK) throw std::runtime_error(omgx_last_error());
 }
 

@@ -296,6 +296,9 @@ typedef void (*ipm_eval_kernel_t)(omgx::Dims, omgx::Tables, int, const double*, 
                                   size_t, double*);
 template <bool GEN>
 static ipm_eval_kernel_t ipm_eval_kernel_gen(int mode, int wave_ok) {
+#ifdef OMGX_ONLY_HEADLINE
+  return ipm_eval_kernel<omgx::WS_JAC_ONLY, true, false>;
+#else
   switch (mode) {
     case omgx::WS_LDS: return wave_ok ? ipm_eval_kernel<omgx::WS_LDS, true, GEN> : ipm_eval_kernel<omgx::WS_LDS, false, GEN>;
     case omgx::WS_KKT_HBM: return ipm_eval_kernel<omgx::WS_KKT_HBM, false, GEN>;
@@ -303,6 +306,7 @@ static ipm_eval_kernel_t ipm_eval_kernel_gen(int mode, int wave_ok) {
     case omgx::WS_JAC_ONLY: return ipm_eval_kernel<omgx::WS_JAC_ONLY, true, GEN>;
     default: return ipm_eval_kernel<omgx::WS_ROWS_HBM, false, GEN>;
   }
+#endif
 }
 static ipm_eval_kernel_t ipm_eval_kernel_for(int mode, int wave_ok, int general) {
   return general ? ipm_eval_kernel_gen<true>(mode, wave_ok) : ipm_eval_kernel_gen<false>(mode, wave_ok);
@@ -315,6 +319,9 @@ typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const do
 // Dims::general; the other one is the kernel of the benchmark classes, free of that code)
 template <bool GEN>
 static ipm_kernel_t ipm_kernel_gen(int mode, int wave_ok) {
+#ifdef OMGX_ONLY_HEADLINE      // developer builds (register counts of one instance in a third of the compile time): only the kernel of the benchmark class
+  return ipm_solve_kernel<omgx::WS_JAC_ONLY, true, false>;
+#else
   switch (mode) {
     case omgx::WS_LDS: return wave_ok ? ipm_solve_kernel<omgx::WS_LDS, true, GEN> : ipm_solve_kernel<omgx::WS_LDS, false, GEN>;
     case omgx::WS_KKT_HBM: return ipm_solve_kernel<omgx::WS_KKT_HBM, false, GEN>;
@@ -322,6 +329,7 @@ static ipm_kernel_t ipm_kernel_gen(int mode, int wave_ok) {
     case omgx::WS_JAC_ONLY: return ipm_solve_kernel<omgx::WS_JAC_ONLY, true, GEN>;
     default: return ipm_solve_kernel<omgx::WS_ROWS_HBM, false, GEN>;
   }
+#endif
 }
 static ipm_kernel_t ipm_kernel_for(int mode, int wave_ok, int general) {
   return general ? ipm_kernel_gen<true>(mode, wave_ok) : ipm_kernel_gen<false>(mode, wave_ok);
@@ -1013,7 +1021,7 @@ int omgx_template_block(const omgx_template* tpl, int32_t kind, const char* name
 void omgx_default_options(omgx_options* o) {
   o->tol = 1e-3; o->max_iter = 300; o->mu_init = 0.1; o->kappa_push = 1.0;
   o->nu_init = 100.0; o->scale_gmax = 100.0; o->warm_start = 0; o->kappa_warm = 1e-3;
-  o->dw_leaf_ratio_cold = 1.0; o->warm_mu_factor = 1.0; o->warm_z_floor = 0.1; o->warm_z_cap = 0.01;
+  o->dw_leaf_ratio_cold = 1.0; o->warm_mu_factor = 1.0; o->warm_z_floor = 0.1; o->warm_z_cap = 0.01; o->max_soc = 1;
 }
 
 int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device, omgx_batch** out) {
@@ -1028,7 +1036,7 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
   omgx_batch* b = new omgx_batch();
   b->device = device; b->n_agents = n_agents;
   omgx_options o; omgx_default_options(&o);
-  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm, o.dw_leaf_ratio_cold, 0, o.warm_mu_factor, o.warm_z_floor, o.warm_z_cap};
+  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm, o.dw_leaf_ratio_cold, 0, o.warm_mu_factor, o.warm_z_floor, o.warm_z_cap, o.max_soc};
   int rc = build_batch(b, tpl);
   if (rc != OMGX_OK) { omgx_batch_destroy(b); return rc; }
   const omgx::Dims& d = b->dims;
@@ -1089,7 +1097,7 @@ int omgx_batch_set_options(omgx_batch* b, const omgx_options* o) {
   if (!b || !o || !(o->tol > 0) || o->max_iter < 0) { g_err = "bad options"; return OMGX_E_INVALID; }
   b->opts = {o->tol, o->max_iter, o->mu_init, o->kappa_push, o->nu_init, o->scale_gmax, o->warm_start, o->kappa_warm,
              o->dw_leaf_ratio_cold > 0 ? o->dw_leaf_ratio_cold : 1.0, 0, o->warm_mu_factor >= 0 ? o->warm_mu_factor : 0.0,
-             o->warm_z_floor >= 0 ? o->warm_z_floor : 0.0, o->warm_z_cap >= 0 ? o->warm_z_cap : 0.0};
+             o->warm_z_floor >= 0 ? o->warm_z_floor : 0.0, o->warm_z_cap >= 0 ? o->warm_z_cap : 0.0, o->max_soc > 0 ? 1 : 0};
   return OMGX_OK;
 }
 

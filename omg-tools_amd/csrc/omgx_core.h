@@ -37,7 +37,7 @@ static thread_local std::vector<double> omgx_rbak;      // root block before its
 #ifdef OMGX_COUNT_FACT
 #include <atomic>
 static std::atomic<long> omgx_dbg_nfact(0);
-static std::atomic<long> omgx_dbg_cnt[8];      // 0 leaf failures, 1 root failures, 2 dw=0 attempts that failed, 3 decrease attempts that failed, 4 iterations
+static std::atomic<long> omgx_dbg_cnt[12];      // 0 leaf failures, 1 root failures, 2 dw=0 attempts that failed, 3 decrease attempts that failed, 4 iterations
 #endif
 namespace omgx {
 
@@ -157,6 +157,7 @@ struct Opts {
   double warm_mu_factor;       // warm starts: mu_0 = clamp(warm_mu_factor * mean(s z), tol / 10, mu_init)
   double warm_z_floor;         // warm starts: multipliers lifted to max(OMGX_WARM_ZMIN, min(warm_z_floor * tol, warm_z_cap * tol / slack))
   double warm_z_cap;           // (0: no cap)
+  int max_soc;                 // 1: a rejected first trial of the line search is answered by a second-order correction (wave-path templates)
 };
 
 // fixed constants of the iteration (same values in oracle/ipm_numpy.py DEFAULTS)
@@ -179,7 +180,9 @@ struct Opts {
 #define OMGX_DW_MAX      1e10
 #define OMGX_DW_ZERO     1e-9
 #define OMGX_DW_HEAVY    10.0
-#define OMGX_KAPPA_EPS_HEAVY 100.0
+#ifndef OMGX_KAPPA_EPS_HEAVY
+#define OMGX_KAPPA_EPS_HEAVY 30.0     // (round 4: 100 let mu drop while the iterate was still far from optimal -- the slowest cold agents of config 2 then crawl along the boundary at step lengths of 1e-3: 85 -> 60 iterations; Quadrotor class mean 79 -> 68)
+#endif
 #ifndef OMGX_DW_BACKOFF_MAX
 #define OMGX_DW_BACKOFF_MAX 8
 #endif
@@ -196,6 +199,9 @@ struct Opts {
 #define OMGX_LS_RETRY_DW 100.0
 #define OMGX_DW_CAP_FLOOR 0.03  // share of dw every nonlinear variable keeps under the Gershgorin cap
 #define OMGX_DW_LINEAR   1e-8   // relative inertia correction of variables that only appear linearly
+#ifndef OMGX_FTB_ACTUAL
+#define OMGX_FTB_ACTUAL  0.5     // share of the linear fraction-to-boundary bound (1 - tau) s the slack of a row must really keep at an accepted trial point
+#endif
 #define OMGX_S_MAX       100.0
 #define OMGX_KAPPA_SIGMA 1e10
 #define OMGX_MAX_BACKTRACK 25
@@ -318,6 +324,7 @@ struct Ctx {
   int tid() const { return 0; }
   int nthr() const { return 1; }
   void sync() const {}
+  double uni(double v) const { return v; }
   double rsum(double v) const { return v; }
   double wave_sum(double v) const { return v; }
   double rmax(double v) const { return v; }
@@ -377,6 +384,12 @@ struct CtxT {
   static __device__ __forceinline__ double rl(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
   }
+  // a value that is the same in every lane, moved to scalar registers: the scalars of the iteration (mu, t, f, step lengths,
+  // ...) come out of LDS reductions as per-lane copies, and ~30 of them live across the whole iteration -- as vector
+  // registers they are what pushes the kernel over its 256
+  static __device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  }
   template <int OP> __device__ double reduce(double v) const {
     v = wave_reduce<OP>(v);
     const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -385,7 +398,7 @@ struct CtxT {
     double r = red[0];
     for (int i = 1; i < nw; ++i) r = comb<OP>(r, red[i]);
     __syncthreads();
-    return r;
+    return uni(r);
   }
   template <int I, int N, int OP0, int... OPS>
   __device__ __forceinline__ void red_wave(double (&v)[N]) const {
@@ -398,7 +411,7 @@ struct CtxT {
     const int nw = (blockDim.x + 63) >> 6;
     double r = red[I];
     for (int k = 1; k < nw; ++k) r = comb<OP0>(r, red[k * N + I]);
-    v[I] = r;
+    v[I] = uni(r);
     if constexpr (sizeof...(OPS) > 0) red_block<I + 1, N, OPS...>(v);
   }
   template <int... OPS> __device__ __forceinline__ void reduce_ops(double (&v)[sizeof...(OPS)]) const {
@@ -1487,6 +1500,114 @@ OMGX_FN void kkt_solve_wave(const C& c, const Dims& d, const Kkt& K, Work& w, do
   c.sync();
   OMGX_TOC(PH_K_BWD);
 }
+
+// One more solve with the factors kkt_factor_wave left in the store (the factorisation carries the right-hand side of the
+// Newton system along; a second-order correction solves once more with the same factors).  In: the raw right-hand side
+// where kkt_rhs writes it (last carried row of every leaf, row nr of the root).  Leaf waves substitute forwards in
+// registers (wave_fwd_r) and form their share W Delta^{-1} y of the root's right-hand side; wave 0 subtracts the shares in
+// leaf order (fixed order of the sums), substitutes the root forwards and backwards; the leaves finish as in
+// kkt_solve_wave.  out [N]: the solution in position order (the equality multipliers of this solve are dropped).
+template <class C>
+OMGX_FN void kkt_solve2_wave(const C& c, const Dims& d, const Kkt& K, Work& w, double* out) {
+  const BMat* Ms = (const BMat*)w.col;
+  const int lane = c.lane(), wave = c.wave(), nw = c.nwaves();
+  const int koff = (int)(w.kkt - omgx_lds);
+  double* xg0 = w.col + OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1);
+  double* R = K.R();
+  const int rrow = tri(d.nr, 0);
+  for (int base = 0; base < d.n_leaf; base += nw) {
+    const int l = base + wave;
+    double* xg = xg0 + wave * 64;
+    if (l < d.n_leaf && __builtin_amdgcn_readfirstlane(Ms[l].bw) >= 0) {
+      const BMat M = Ms[l];
+      const WPanel P = wpanel_uniform(wpanel_leaf(M));
+      const int n = P.n, nc = P.nreg + 1 - P.n, ld = P.ld;
+      const int j = lane < n ? lane : 0;
+      double* Wt = w.kkt + P.wbase;
+      const int dv = __builtin_amdgcn_readfirstlane(M.dinv);
+      const double dl = w.dinv[dv + j];
+      const double y = wave_fwd_r<true>(koff, P, dl, Wt[nc * ld + j]);
+      if (lane < n) { Wt[nc * ld + lane] = y; xg[lane] = y * dl; }
+      wave_fence();
+      // share of coupling row a: sum_j W_aj y_j / d_j
+      const int a = lane < nc ? lane : 0;
+      double acc = 0.0;
+#pragma unroll 4
+      for (int q = 0; q < n; ++q) acc = fma(Wt[a * ld + q], xg[q], acc);
+      wave_fence();
+      if (lane < nc) xg[lane] = acc;
+    }
+    c.sync();
+    if (wave == 0) {
+      const int lend = base + nw < d.n_leaf ? base + nw : d.n_leaf;
+      for (int lr = base; lr < lend; ++lr) {
+        const BMat M = Ms[lr];
+        if (__builtin_amdgcn_readfirstlane(M.bw) >= 0) {
+          const int nc = __builtin_amdgcn_readfirstlane(M.rows) - 1 - __builtin_amdgcn_readfirstlane(M.nfact);
+          const int32_t* ci = K.cpl_idx + __builtin_amdgcn_readfirstlane(M.cpl);
+          const double* xs = xg0 + (lr - base) * 64;
+          if (lane < nc) R[rrow + ci[lane]] -= xs[lane];
+        } else {
+          // sparse diagonal leaf: y = r; lane j owns variable j and the root positions it is coupled to
+          const DiagLeaf L = diag_leaf(M);
+          const int j = lane < L.n ? lane : 0;
+          const bool on = lane < L.n;
+          const double* A = w.kkt + L.base + j;
+          const double u = A[(2 + L.S) * L.n] * w.dinv[L.dinv + j];
+          for (int s = 0; s < L.S; ++s) {
+            const int ps = K.dl_pos[L.dl + s * L.n + j];
+            if (on && ps >= 0) R[rrow + ps] -= A[(1 + s) * L.n] * u;
+          }
+          const double st = c.wave_sum(on ? A[(1 + L.S) * L.n] * u : 0.0);
+          if (lane == 0) R[rrow + d.n_root - 1] -= st;
+        }
+        wave_fence();
+      }
+    }
+    c.sync();
+  }
+  if (wave == 0) {
+    const WPanel P = wpanel_root(Ms[d.n_leaf], d.n_root);
+    const double dl = wave_dinv<false>(w.kkt, P);
+    const int j = lane < P.n ? lane : 0;
+    const double y = wave_fwd_r<false>(koff, P, dl, w.kkt[wcarried<false>(P, P.n) + j]);
+    const double x = wave_bwd_r<false>(koff, P, dl, y * dl);
+    if (lane < d.n_root) out[d.root_off + lane] = x;
+  }
+  c.sync();
+  double* xg = xg0 + wave * 64;
+  for (int l = wave; l < d.n_leaf; l += nw) {
+    const BMat M = Ms[l];
+    if (__builtin_amdgcn_readfirstlane(M.bw) < 0) {
+      const DiagLeaf L = diag_leaf(M);
+      const int j = lane < L.n ? lane : 0;
+      const double* A = w.kkt + L.base + j;
+      double acc = A[(2 + L.S) * L.n] - A[(1 + L.S) * L.n] * out[d.root_off + d.n_root - 1];
+      for (int s = 0; s < L.S; ++s) {
+        const int ps = K.dl_pos[L.dl + s * L.n + j];
+        acc = fma(-A[(1 + s) * L.n], out[d.root_off + (ps < 0 ? 0 : ps)] * (ps < 0 ? 0.0 : 1.0), acc);
+      }
+      if (lane < L.n) out[L.dinv + lane] = acc * w.dinv[L.dinv + j];
+      continue;
+    }
+    const WPanel P = wpanel_uniform(wpanel_leaf(M));
+    const int n = P.n, nc = P.nreg + 1 - P.n, ld = P.ld;
+    const int32_t* ci = K.cpl_idx + __builtin_amdgcn_readfirstlane(M.cpl);
+    if (lane < nc) xg[lane] = out[d.root_off + ci[lane]];
+    wave_fence();
+    const int j = lane < n ? lane : 0;
+    const double* Wt = w.kkt + P.wbase + j;
+    double acc = Wt[nc * ld];
+#pragma unroll 4
+    for (int a = 0; a < nc; ++a) acc = fma(-Wt[a * ld], xg[a], acc);
+    const int dv = __builtin_amdgcn_readfirstlane(M.dinv);
+    const double dl = w.dinv[dv + j];
+    const double x = wave_bwd_r<true>(koff, P, dl, acc * dl);
+    if (lane < n) out[dv + lane] = x;
+    wave_fence();
+  }
+  c.sync();
+}
 #endif
 
 // Factorise the assembled block-arrow matrix in place.  Returns 0 if the
@@ -1773,6 +1894,64 @@ OMGX_FN void kkt_rhs(const C& c, const Dims& d, const Tables& T, Work& w, double
   }
 }
 
+// where kkt_rhs puts the right-hand side entry of position q (< N) in the store
+template <class C>
+OMGX_FN int kkt_rhs_slot(const Dims& d, const BMat* Ms, int q) {
+  if (q >= d.root_off) return Ms[d.n_leaf].pad_ + tri(d.nr, q - d.root_off);
+  int l = 0;
+  while (q >= Ms[l].dinv + Ms[l].nfact) ++l;
+  const BMat M = Ms[l];
+  if constexpr (C::wave_only) return M.bw < 0 ? M.a + (2 + M.pan) * M.nfact + (q - M.dinv) : M.pan + (M.rows - 1 - M.nfact) * M.ld + (q - M.dinv);
+  else { OMGX_PANEL_STRIDES(C, M, sr, sc); return M.a + (M.rows - 1) * sr + (q - M.dinv) * sc; }
+}
+
+#ifdef OMGX_HOST_PORT
+static thread_local std::vector<double> omgx_sol2;       // output of a second solve (position order + equality multipliers)
+#endif
+// One more solve with the factors of the iteration (second-order correction): the caller wrote the right-hand side into
+// the slots of kkt_rhs; out [N] receives the solution in position order (the equality multipliers of this solve are
+// dropped).  Templates on the wave path only (Dims::wave_ok): device by the wave routines, host port by plain loops
+// over the storage its blocked routines leave (leaf panels U = L D with inverse pivots aside, root L with the pivots
+// on the diagonal).
+template <class C>
+OMGX_FN void kkt_solve2(const C& c, const Dims& d, const Kkt& K, Work& w, double* out) {
+#ifndef OMGX_HOST_PORT
+  if constexpr (C::wave_only) {
+    kkt_solve2_wave(c, d, K, w, out);
+  }
+#else
+  const BMat* Ms = (const BMat*)w.col;
+  double* R = w.kkt + Ms[d.n_leaf].a;
+  const int nr = d.nr;
+  for (int l = 0; l < d.n_leaf; ++l) {
+    const BMat M = Ms[l];
+    const int n = M.nfact, nc = M.rows - 1 - n, ld = M.ld;
+    double* P = w.kkt + M.a;
+    double* y = P + (M.rows - 1) * ld;
+    const double* iv = w.dinv + M.dinv;
+    for (int i = 0; i < n; ++i) {
+      double acc = y[i];
+      for (int j = 0; j < i; ++j) acc -= P[i * ld + j] * iv[j] * y[j];
+      y[i] = acc;
+    }
+    const int32_t* ci = K.cpl_idx + M.cpl;
+    for (int a = 0; a < nc; ++a) {
+      double acc = 0.0;
+      for (int j = 0; j < n; ++j) acc += P[(n + a) * ld + j] * (y[j] * iv[j]);
+      R[tri(nr, ci[a])] -= acc;
+    }
+  }
+  for (int i = 0; i < nr; ++i) {
+    double acc = R[tri(nr, i)];
+    for (int j = 0; j < i; ++j) acc -= R[tri(i, j)] * R[tri(nr, j)];
+    R[tri(nr, i)] = acc;
+  }
+  omgx_sol2.resize((size_t)d.N + d.n_eq);
+  kkt_solve(c, d, K, w, omgx_sol2.data());
+  for (int q = 0; q < d.N; ++q) out[q] = omgx_sol2[q];
+#endif
+}
+
 // Lagrangian Hessian, the share of owner bin `bin`: the items of the terms with >= 2 variables, weight w.ht[row] =
 // multiplier x signed scale (row m = objective: 1), summed per KKT address in table order and added to the store
 // (omgx_plan.h (4): ELL records, the target in the last record of its run, everything else to the dump slot).
@@ -1887,7 +2066,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     const double h = (ty == ROW_FREE) ? 0.0 : w.rho[r] * (g - bnd);
     w.hv[r] = h;
     double v = 0.0;
-    if (ty == ROW_UPPER || ty == ROW_LOWER) v = fmax(h + kpush, 0.0);
+    if (ty == ROW_UPPER || ty == ROW_LOWER) {
+      v = fmax(h + kpush, 0.0);
+    }
     else if (ty == ROW_EQ) v = h;
     w.vv[r] = v;
   }
@@ -1929,7 +2110,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       }
     }
     { double rv[2] = {sz, cnt0}; c.template reduce_ops<0, 0>(rv); sz = rv[0]; cnt0 = rv[1]; }
-    mu = fmin(o.mu_init, fmax(o.tol / 10.0, o.warm_mu_factor * sz / fmax(1.0, cnt0)));
+    mu = c.uni(fmin(o.mu_init, fmax(o.tol / 10.0, o.warm_mu_factor * sz / fmax(1.0, cnt0))));
     // multiplier of t >= 0: dual feasible in t (nu - v'z - zt = 0) rather than on the central path,
     // so that the first Newton step in t is O(t) instead of O(nu t^2 / mu)
   }
@@ -1938,12 +2119,12 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     double rv[2] = {0.0, row_value_share(c, T, w, m, w.x)};
     OMGX_PFOR(r, m) if (w.rtype[r] != ROW_FREE) rv[0] += w.vv[r] * w.z[r];
     c.template reduce_ops<0, 0>(rv);
-    zt = use_t ? fmax(mu / t, nu - rv[0]) : 0.0;
+    zt = c.uni(use_t ? fmax(mu / t, nu - rv[0]) : 0.0);
     f = rv[1];
   }
   // a warm start also inherits the inertia correction the previous solve of this agent ended with
   // (first factorisation at that value instead of climbing 0, 1e-4, 1e-3, ... again)
-  double dw_last = (warm && dw_prev > 0.0) ? dw_prev : 0.0, t_check = t;
+  double dw_last = c.uni((warm && dw_prev > 0.0) ? dw_prev : 0.0), t_check = t;
   int dw_hold = dw_last > 0.0 ? 1 : 0, dw_backoff = 1;   // inertia-correction tracking (see the factorisation loop)
   // cold starts may damp the leaf (hyperplane) variables less and the root (trajectory) variables more
   // than dw (same product: the same bilinear negative curvature is covered); warm starts use dw on both
@@ -2047,7 +2228,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       rd_max = rv[0]; lam_sum = rv[1]; vz = rv[2]; cnt = rv[3]; viol = rv[4]; zh = rv[5]; rE_max = rv[6]; rE_sum = rv[7];
     }
     OMGX_TOC(PH_LS);                                      // (error measures and their reduction)
-    const double sd = fmax(OMGX_S_MAX, lam_sum / fmax(1.0, cnt)) / OMGX_S_MAX;
+    const double sd = c.uni(fmax(OMGX_S_MAX, lam_sum / fmax(1.0, cnt)) / OMGX_S_MAX);
     const double err0 = fmax(rd_max / sd, fmax(viol, zh / sd));
     res.f = f; res.mu = mu; res.t = t; res.iters = it;
     if (err0 <= o.tol) { status = 0; break; }
@@ -2068,12 +2249,12 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       const double rd_t = use_t ? (nu - vz - zt) : 0.0;
       const double emu = fmax(fmax(rd_max, fabs(rd_t)) / sd, fmax(rE_max, comp / sd));
       if (mu > o.tol / 10.0 && emu <= keps * mu) {
-        mu = fmax(o.tol / 10.0, fmin(OMGX_KAPPA_MU * mu, pow(mu, OMGX_THETA_MU)));
+        mu = c.uni(fmax(o.tol / 10.0, fmin(OMGX_KAPPA_MU * mu, pow(mu, OMGX_THETA_MU))));
         continue;
       }
       if (use_t && zt < 0.1 * nu && t > o.tol && emu <= 100.0 * OMGX_KAPPA_EPS * mu) {
         if (nu >= OMGX_NU_MAX) { infeasible = 1; break; }   // phase I stalls at t > 0: local infeasibility
-        nu *= 10.0; zt += 0.9 * nu;
+        nu = c.uni(nu * 10.0); zt = c.uni(zt + 0.9 * nu);
         continue;
       }
       break;
@@ -2088,7 +2269,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       // that counts as phase I not finishing)
       if (t > fmax(o.tol, 10.0 * mu / nu) && t > 0.9 * t_check) {
         if (nu >= nu_stall_max) infeasible = 1;
-        else { nu *= 10.0; zt += 0.9 * nu; }
+        else { nu = c.uni(nu * 10.0); zt = c.uni(zt + 0.9 * nu); }
       }
       t_check = t;
     }
@@ -2098,7 +2279,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     double vms = 0.0;
     OMGX_PFOR(r, m) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) vms += w.vv[r] * (mu / row_slack(w, r, t));
     vms = c.rsum(vms);
-    const double gbar_t = use_t ? (nu - vms - mu / t) : 0.0;
+    const double gbar_t = c.uni(use_t ? (nu - vms - mu / t) : 0.0);
     if (c.tid() == 0) w.gbar[N - 1] = gbar_t;
     c.sync();
 
@@ -2116,7 +2297,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     double dw; int decreasing = 0;
     if (dw_last < OMGX_DW_ZERO) dw = 0.0;
     else if (dw_hold > 0) { dw = dw_last; --dw_hold; }
-    else { dw = dw_last * OMGX_DW_DEC; decreasing = 1; }
+    else { dw = c.uni(dw_last * OMGX_DW_DEC); decreasing = 1; }
     int failed = 0;
     // Gershgorin row sums g_q of the Lagrangian Hessian (term by term, position order; w.xt is free
     // until the line search): H + diag(g) is diagonally dominant, so no variable ever needs more
@@ -2279,7 +2460,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
             dw_backoff = dw_backoff < OMGX_DW_BACKOFF_MAX ? 2 * dw_backoff : OMGX_DW_BACKOFF_MAX;
             dw_hold = dw_backoff;
           } else {
-            dwr = (dwr == 0.0) ? OMGX_DW_FIRST : dwr * OMGX_DW_INC;
+            dwr = c.uni((dwr == 0.0) ? OMGX_DW_FIRST : dwr * OMGX_DW_INC);
           }
           if (dwr > OMGX_DW_MAX) { failed = 1; break; }
           c.sync();
@@ -2312,7 +2493,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         dw_backoff = dw_backoff < OMGX_DW_BACKOFF_MAX ? 2 * dw_backoff : OMGX_DW_BACKOFF_MAX;
         dw_hold = dw_backoff;
       } else {
-        dw = (dw == 0.0) ? OMGX_DW_FIRST : dw * OMGX_DW_INC;
+        dw = c.uni((dw == 0.0) ? OMGX_DW_FIRST : dw * OMGX_DW_INC);
       }
       if (dw > OMGX_DW_MAX) { failed = 1; break; }
       c.sync();
@@ -2325,10 +2506,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     OMGX_TOC(PH_SOLVE);
     if (!use_t && c.tid() == 0) w.sol[N - 1] = 0.0;
     c.sync();
-    const double dt = w.sol[N - 1];
+    const double dt = c.uni(w.sol[N - 1]);
     // (the primal boundary step is collected up to OMGX_EXPAND_MAX: a heavily regularised step may be lengthened, below)
     double ap_l = OMGX_EXPAND_MAX, ad_l = 1.0, ymax = 0.0, gdx = 0.0, ysum = 0.0;
-    const double tau = fmax(OMGX_TAU_MIN, 1.0 - mu);
+    const double tau = c.uni(fmax(OMGX_TAU_MIN, 1.0 - mu));
     OMGX_PFOR(ir, m) {
       const int r = T.row_perm[ir];
       const int ty = w.rtype[r];
@@ -2369,17 +2550,18 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     }
     double dzt = 0.0;
     if (use_t) {
-      dzt = mu / t - zt - (zt / t) * dt;
+      dzt = c.uni(mu / t - zt - (zt / t) * dt);
       if (dt < 0.0) a_p = fmin(a_p, -tau * t / dt);
       if (dzt < 0.0) a_d = fmin(a_d, -tau * zt / dzt);
+      a_p = c.uni(a_p); a_d = c.uni(a_d);
     }
-    const double nuE = 2.0 * fmax(1.0, ymax);
-    const double phi0 = f + nu * t - mu * lns - (use_t ? mu * log(t) : 0.0) + nuE * rE_sum;
+    const double nuE = c.uni(2.0 * fmax(1.0, ymax));
+    const double phi0 = c.uni(f + nu * t - mu * lns - (use_t ? mu * log(t) : 0.0) + nuE * rE_sum);
     // The equality block carries -delta_c I (quasi-definite system): the linearised equality residual after the full
     // step is delta_c * y_new, not zero -- the penalty term can only promise the difference.  (Without this the
     // Armijo test asks, at the end of a tight solve, for a decrease of nuE * 2e-8 that no step can deliver, the
     // step length collapses and the solve stalls a factor 1.2 above a tolerance of 1e-6.)
-    const double dphi = gdx - nuE * fmax(0.0, rE_sum - OMGX_DELTA_C * ysum);
+    const double dphi = c.uni(gdx - nuE * fmax(0.0, rE_sum - OMGX_DELTA_C * ysum));
 
     OMGX_TOC(PH_STEP);
     // ---- Armijo backtracking on the barrier function, iterate stays strictly feasible ----
@@ -2391,18 +2573,29 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     // the Armijo test on the barrier function decides.  Only in that regime: after OMGX_EXPAND_FROM iterations in a row
     // whose full step was accepted at once; undamped Newton steps (dw = 0) are never lengthened.
     const double a_bnd = a_p;
-    a_p = fmin(a_bnd, 1.0);
+    a_p = c.uni(fmin(a_bnd, 1.0));
     const bool phi_noise = fabs(a_p * dphi) <= OMGX_PHI_NOISE * (1.0 + fabs(phi0));
     if (!phi_noise && dw_last > OMGX_EXPAND_DW && full_steps >= OMGX_EXPAND_FROM) {
       double ex = 1.0;
       while (2.0 * ex <= a_bnd && 2.0 * ex <= OMGX_EXPAND_MAX) ex *= 2.0;
-      a_p = fmin(a_bnd, ex);
+      a_p = c.uni(fmin(a_bnd, ex));
     }
     double alpha = a_p, ft = f, tt = t; int ok = 0;
+    // Second-order correction (o.max_soc; templates on the wave path): when the first trial is rejected, the rows have
+    // moved by e = (s + alpha ds) - s(x + alpha dx) more than their linearisation said (the bilinear hyperplane rows: a term
+    // of second order in the step, which is what cuts a step along an active face to a few per cent).  One more solve
+    // with the factors of this iteration, K d_c = -[J' Sigma e; e_E], gives the step alpha d + d_c that accounts for it;
+    // it is offered once, before the halving starts, and accepted by the same Armijo test (IPOPT does the same inside
+    // its filter line search).  The correction lives in w.gbar (free once the directional derivative is formed).
+#ifndef OMGX_SOC_COMPILED
+#define OMGX_SOC_COMPILED 1
+#endif
+    int soc = (OMGX_SOC_COMPILED && o.max_soc > 0 && d.wave_ok) ? 0 : 2;      // 0: not tried yet, 1: the trial under way is the corrected one, 2: done
     for (int bt = 0; bt < OMGX_MAX_BACKTRACK; ++bt) {
-      OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + alpha * w.sol[q]; }
+      if (soc == 1) { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + (alpha * w.sol[q] + w.gbar[q]); } }
+      else { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + alpha * w.sol[q]; } }
       c.sync();
-      tt = use_t ? w.xt[n] : 0.0;
+      tt = use_t ? c.uni(w.xt[n]) : 0.0;
       // row values at the trial point: one thread per row (long rows first), terms in table order
       double smin = 1e300, lnst = 0.0, rEt = 0.0;
       OMGX_PFOR(i, m) {
@@ -2413,7 +2606,12 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         const double h = w.rho[r] * (gv - ((ty == ROW_LOWER || ty == ROW_EQ) ? lb[r] : ub[r]));
         w.ht[r] = h;
         if (ty == ROW_EQ) rEt += fabs(h - tt * w.vv[r]);
-        else { const double st = tt * w.vv[r] - h; smin = fmin(smin, st); if (st > 0.0) lnst += log(st); }
+        else {
+          // (the fraction-to-boundary rule on the slack the row really has at the trial point, not only on its linear
+          // prediction: along a curved row a trial may keep a billionth of the slack, and with a small barrier parameter
+          // the merit function does not mind -- the next steps then start on the boundary)
+          const double st = tt * w.vv[r] - h; smin = fmin(smin, st - OMGX_FTB_ACTUAL * (1.0 - tau) * row_slack(w, r, t)); if (st > 0.0) lnst += log(st);
+        }
       }
       OMGX_TOC(PH_L_TERMS);
       {
@@ -2421,14 +2619,85 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         c.template reduce_ops<2, 0, 0, 0>(rv);
         smin = rv[0]; lnst = rv[1]; rEt = rv[2]; ft = rv[3];
       }
-      if (smin > 0.0) {
+#ifdef OMGX_COUNT_FACT
+      ++omgx_dbg_cnt[8];
+#endif
+#if defined(OMGX_HOST_PORT) && defined(OMGX_TRACE_LS)
+      {
+        int rmin = -1; double sm = 1e300;
+        for (int r = 0; r < m; ++r) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) { const double st = tt * w.vv[r] - w.ht[r]; if (st < sm) { sm = st; rmin = r; } }
+        const double phit_ = ft + nu * tt - mu * lnst - (use_t ? mu * log(tt) : 0.0) + nuE * rEt;
+        fprintf(stderr, "        bt %d soc %d alpha %.3e smin %.3e (row %d: s0 %.3e ds %.3e z %.3e) tt %.3e dphi_pred %.3e dphi_act %.3e\n", bt, soc, alpha, sm, rmin,
+                rmin >= 0 ? row_slack(w, rmin, t) : 0.0, rmin >= 0 ? w.ds[rmin] : 0.0, rmin >= 0 ? w.z[rmin] : 0.0, tt, OMGX_ETA * alpha * dphi, phit_ - phi0);
+      }
+#endif
+      if (smin > 0.0 && (!use_t || tt > 0.0)) {
         const double phit = ft + nu * tt - mu * lnst - (use_t ? mu * log(tt) : 0.0) + nuE * rEt;
         // (near the solution the decrease a Newton step predicts, ~ error^2, drops below what the merit function can
         // resolve -- its value is a sum of ~n_con terms of size 1 -- and the Armijo test then compares rounding
         // noise: such a step is taken as it is, like IPOPT's tiny-step rule; the error test decides about the rest)
         if (phi_noise || phit <= phi0 + OMGX_ETA * alpha * dphi || phit - phi0 <= 10.0 * 2.220446049250313e-16 * fabs(phi0)) { ok = 1; break; }
       }
-      alpha *= 0.5;
+      if (soc == 1) {       // the corrected trial failed too: plain backtracking from here
+        soc = 2;
+        alpha = c.uni(alpha * 0.5);
+        c.sync(); continue;
+      }
+      if (soc == 0) {
+        soc = 1;
+#ifdef OMGX_COUNT_FACT
+        ++omgx_dbg_cnt[9];
+#endif
+        // per row: Sigma_r e_r (inequality rows) -> w.ht; the equality rows' part of the right-hand side goes straight to the store
+        const BMat* Ms = (const BMat*)w.col;
+        const int rbase = Ms[d.n_leaf].pad_, nr = d.nr;
+        double vte = 0.0;
+        OMGX_PFOR(r, m) {
+          const int ty = w.rtype[r];
+          double v = 0.0;
+          if (ty == ROW_UPPER || ty == ROW_LOWER) {
+            const double s0 = row_slack(w, r, t);
+            const double e = (s0 + alpha * w.ds[r]) - (tt * w.vv[r] - w.ht[r]);
+            v = (w.z[r] / s0) * e;
+            vte += w.vv[r] * v;
+          } else if (ty == ROW_EQ) {
+            // what the row is off its linear prediction (1 - alpha) r_E (zero for the linear initial / terminal conditions)
+            w.kkt[rbase + tri(nr, d.n_root + T.eq_index[r])] = -((w.ht[r] - tt * w.vv[r]) - (1.0 - alpha) * (w.hv[r] - t * w.vv[r]));
+          }
+          w.ht[r] = v;
+        }
+        OMGX_PFOR(k, d.n_eq) { const int r = T.eq_rows[k]; if (w.rtype[r] != ROW_EQ) w.kkt[rbase + tri(nr, d.n_root + k)] = 0.0; }
+        vte = c.rsum(vte);
+        // -J' (Sigma e): one thread per column over its strided shares in part order (the records of the column sums)
+        {
+          const int parts = d.cs_parts;
+          OMGX_PFOR(j, n) {
+            double acc = 0.0;
+            for (int k = 0; k < parts; ++k) {
+              const int ow = j * parts + k;
+              const int L = T.cs_glen[ow >> 6];
+              for (int s0 = 0; s0 < L; s0 += 8) {
+                int32_t e[8], r[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const int32_t* q = T.cs_ell + 2 * ((s0 + i) * (n * parts) + ow); e[i] = q[0]; r[i] = q[1]; }
+                double jv[8], ve[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { jv[i] = w.jval[e[i]]; ve[i] = w.ht[r[i]]; }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc += jv[i] * ve[i];
+              }
+            }
+            w.kkt[kkt_rhs_slot<C>(d, Ms, T.cs_col[j])] = -acc;
+          }
+          if (c.tid() == 0) w.kkt[kkt_rhs_slot<C>(d, Ms, N - 1)] = use_t ? vte : 0.0;
+        }
+        c.sync();
+        kkt_solve2(c, d, K, w, w.gbar);
+        if (!use_t && c.tid() == 0) w.gbar[N - 1] = 0.0;
+        c.sync();
+        continue;
+      }
+      alpha = c.uni(alpha * 0.5);
       c.sync();
     }
     OMGX_TOC(PH_L_ROWS);
@@ -2454,7 +2723,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       // steepest descent of the barrier function -- up to OMGX_LS_RETRY times in a row.
       if (ls_fail < OMGX_LS_RETRY) {
         ++ls_fail;
-        dw_last = fmax(dw_last, OMGX_DW_FIRST) * OMGX_LS_RETRY_DW;
+        dw_last = c.uni(fmax(dw_last, OMGX_DW_FIRST) * OMGX_LS_RETRY_DW);
         dw_hold = 2; dw_backoff = OMGX_DW_BACKOFF_MAX;
         c.sync();
         continue;
@@ -2488,7 +2757,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     }
     if (use_t) {
       zt = warm ? fmax(zt + dzt, (1.0 - tau) * zt) : zt + a_d * dzt;
-      zt = fmin(fmax(zt, mu / (OMGX_KAPPA_SIGMA * t)), OMGX_KAPPA_SIGMA * mu / t);
+      zt = c.uni(fmin(fmax(zt, mu / (OMGX_KAPPA_SIGMA * t)), OMGX_KAPPA_SIGMA * mu / t));
     }
     c.sync();
     OMGX_TOC(PH_UPDATE);

@@ -205,4 +205,72 @@ __device__ __forceinline__ double wave_bwd(int off, const WPanel Pin, double din
   return x;
 }
 
+// Substitutions for a right-hand side that did NOT ride through the factorisation (second-order correction of a trial
+// step: one more solve with the factors of the iteration).  Rolled forms -- a run-time loop over chunks of eight columns,
+// the broadcast lane a scalar register -- on purpose: they are called from inside the line search, where the scalars of
+// the step are alive on top of the iteration's, and n steps of ~15 cycles do not need the straight-line treatment of the
+// n^2 / 2 steps of wave_ldl (a second fully unrolled instance of wave_bwd there cost 35 KB of code and spilled).
+//
+// wave_fwd_r: y <- L^{-1} r.  Lane i reads row i of the symmetric block (u_ij, j < i), scales column j by the inverse
+// pivot of lane j (dinvl: lane c holds 1 / d_c).  r: component `lane` (lanes >= n ignored); returns y_lane.
+template <bool BANDED>
+__device__ __forceinline__ double wave_fwd_r(int off, const WPanel Pin, double dinvl, double r) {
+  const double* A = omgx_lds + off;
+  const WPanel P = wpanel_uniform(Pin);
+  const int lane = threadIdx.x & 63;
+  const int n = P.n;
+  const int rl = lane < n ? lane : 0;
+  const int ra = wsym<BANDED>(P, rl);
+  const int klo = (BANDED && rl > P.band) ? rl - P.band : 0;
+  double y = lane < n ? r : 0.0;
+  for (int j0 = 0; j0 < n; j0 += 8) {
+    double l[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                      // unconditional loads on clamped addresses, masked afterwards
+      const int j = j0 + q;
+      const int kk = j < klo ? klo : (j > rl ? rl : j);
+      const double v = A[ra + kk];
+      const double dk = readlane_d(dinvl, j);          // (j < 48: n <= OMGX_WAVE_COLS)
+      l[q] = (lane < n && j >= klo && j < rl) ? v * dk : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = j0 + q;
+      const double yj = readlane_d(y, j);
+      y = fma(-l[q], j < n ? yj : 0.0, y);
+    }
+  }
+  return y;
+}
+
+// wave_bwd_r: x <- L^{-T} z, the rolled twin of wave_bwd (lane j reads column j and scales it by its own inverse pivot)
+template <bool BANDED>
+__device__ __forceinline__ double wave_bwd_r(int off, const WPanel Pin, double dinvl, double z) {
+  const double* A = omgx_lds + off;
+  const WPanel P = wpanel_uniform(Pin);
+  const int lane = threadIdx.x & 63;
+  const int n = P.n;
+  const int c = lane < n ? lane : 0;
+  double x = lane < n ? z : 0.0;
+  for (int i0 = ((n + 7) & ~7) - 8; i0 >= 0; i0 -= 8) {
+    double l[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + q;
+      const int ic = i < n ? i : n - 1;
+      const bool in = !BANDED || ic - c <= P.band;     // (banded: entry (i, c) exists for i - c <= band)
+      const int cc = in ? c : ic - P.band;
+      const double v = A[wsym<BANDED>(P, ic) + cc];
+      l[q] = (i < n && lane < i && in) ? v * dinvl : 0.0;
+    }
+#pragma unroll
+    for (int q = 7; q >= 0; --q) {
+      const int i = i0 + q;
+      const double xi = readlane_d(x, i);
+      x = fma(-l[q], i < n ? xi : 0.0, x);
+    }
+  }
+  return x;
+}
+
 }  // namespace omgx

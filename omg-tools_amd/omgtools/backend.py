@@ -56,12 +56,12 @@ class COptions(C.Structure):
     _fields_ = [('tol', C.c_double), ('max_iter', C.c_int32), ('mu_init', C.c_double),
                 ('kappa_push', C.c_double), ('nu_init', C.c_double), ('scale_gmax', C.c_double),
                 ('warm_start', C.c_int32), ('kappa_warm', C.c_double),
-                ('dw_leaf_ratio_cold', C.c_double), ('warm_mu_factor', C.c_double), ('warm_z_floor', C.c_double), ('warm_z_cap', C.c_double)]
+                ('dw_leaf_ratio_cold', C.c_double), ('warm_mu_factor', C.c_double), ('warm_z_floor', C.c_double), ('warm_z_cap', C.c_double), ('max_soc', C.c_int32)]
 
 
 DEFAULT_OPTIONS = dict(tol=1e-3, max_iter=300, mu_init=0.1, kappa_push=1.0,
                        nu_init=100.0, scale_gmax=100.0, warm_start=0, kappa_warm=1e-3,
-                       dw_leaf_ratio_cold=1.0, warm_mu_factor=1.0, warm_z_floor=0.1, warm_z_cap=0.01)
+                       dw_leaf_ratio_cold=1.0, warm_mu_factor=1.0, warm_z_floor=0.1, warm_z_cap=0.01, max_soc=int(__import__("os").environ.get("OMGX_MAX_SOC", "1")))
 
 
 def make_options(**kw):

@@ -296,6 +296,9 @@ class FormationPoint2point(object):
             # study one x-update ends at the iteration cap with it, two with the cap; at 1e-3, the bench, the cap saves
             # three iterations per x-update: include/omgx.h warm_z_cap)
             opts['warm_z_cap'] = 0.0
+            # (and plain backtracking: at 1e-6 a second-order correction changes which x-updates end in the rounding noise of the
+            # merit function -- 92 instead of 33 of 660 x-updates of examples/formation_holonomic.py on the host build)
+            opts['max_soc'] = 0
             self.solver = BatchSolver(tpl, N, options=opts)
             self.ops = HipAdmmOps(self.solver, tpl, lay, p0, x0, torch.device('cuda', 0))
         else:

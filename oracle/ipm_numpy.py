@@ -23,7 +23,7 @@ import numpy as np
 
 DEFAULTS = dict(dw_cap_floor=0.03, tol=1e-8, max_iter=200, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2,
                 theta_mu=1.5, tau_min=0.99, s_push=1.0, delta_c=1e-8, eta=1e-4,
-                rho=0.1, dw_first=1e-4, dw_inc=10.0, dw_dec=1. / 3., dw_max=1e10, dw_zero=1e-9, dw_heavy=10.0, kappa_eps_heavy=100.0,
+                rho=0.1, dw_first=1e-4, dw_inc=10.0, dw_dec=1. / 3., dw_max=1e10, dw_zero=1e-9, dw_heavy=10.0, kappa_eps_heavy=30.0,
                 s_max=100.0, kappa_sigma=1e10, max_backtrack=25, max_soc=2,
                 slack_reset=True, kappa_push=1.0, stall_iters=20, warm_zmin=1e-8, warm_z_floor=0.1, warm_z_cap=0.01, nu_init=100.0, nu_max=1e8, e_push=1.0, scale_gmax=100.0, s_phi=2.3, s_theta=1.1, delta_sw=1.0,
                 gamma_theta=1e-5, gamma_phi=1e-5, filter_size=8, warm_mu_factor=1.0,
@@ -527,17 +527,39 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                 ex *= 2.0
             a_p = min(a_bnd, ex)
         alpha, ok = a_p, False
+        # second-order correction (omgx_core.h, option max_soc; templates on the wave path like there): when the first
+        # trial is rejected, one more solve with the factors of the iteration for what the rows moved beyond their
+        # linearisation; the corrected step is offered once before the halving starts
+        soc = 0 if (o['max_soc'] > 0 and getattr(nlp, 'wave_ok', False)) else 2
+        d_c = None
         for bt in range(o['max_backtrack']):
-            xt = x + alpha * dxt[:n]
-            tt = t + alpha * dt
+            step = alpha * dxt + d_c if soc == 1 else alpha * dxt
+            xt = x + step[:n]
+            tt = t + step[n]
             ft, ht, cEt = evaluate(xt)
             st = tt * v - ht
-            if st.min() > 0 and st.min() >= (1 - tau) * 0.0:
+            # (omgx_core.h OMGX_FTB_ACTUAL: every row really keeps half of what the linear fraction-to-boundary rule leaves it)
+            if (st - o.get('ftb_actual', 0.5) * (1.0 - tau) * s).min() > 0 and (not use_t or tt > 0):
                 phit = ft + nu * tt - mu * np.log(st).sum() - (mu * np.log(tt) if use_t else 0.0) \
                     + nuE * np.abs(cEt - tt * cE0).sum()
                 if phi_noise or phit <= phi0 + o['eta'] * alpha * dphi or phit - phi0 <= 10 * np.finfo(float).eps * abs(phi0):
                     ok = True
                     break
+            if soc == 1:
+                soc = 2
+                alpha *= 0.5
+                continue
+            if soc == 0:
+                soc = 1
+                e = (s + alpha * ds) - st
+                eE = (cEt - tt * cE0) - (1.0 - alpha) * rE
+                rhs2 = np.r_[-(Jh.T @ (Sig * e)), -eE]
+                if not use_t:
+                    rhs2[n] = 0.0
+                d_c = ldl_solve(L, d, rhs2)[:N]
+                if not use_t:
+                    d_c[n] = 0.0
+                continue
             alpha *= 0.5
         if trace is not None:
             trace[-1].update(alpha=alpha, a_p=a_p, a_d=a_d, ok=ok, tries=tries, bt=bt, dphi=dphi)

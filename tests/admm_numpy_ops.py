@@ -99,7 +99,7 @@ class NumpyAdmmOps(object):
             self.status[:] = 1
         r = self.port.solve(self.tpl, self.p, self.x, tol=self.tol, max_iter=300, warm_start=1,
                             lam_g0=self.lam, status0=self.status, dw_state=self.dw,
-                            warm_z_cap=0.0 if self.tol < 1e-4 else 0.01)      # (as FormationPoint2point sets it for its 1e-6 x-updates)
+                            warm_z_cap=0.0 if self.tol < 1e-4 else 0.01, max_soc=0 if self.tol < 1e-4 else 1)      # (as FormationPoint2point sets it for its 1e-6 x-updates)
         self.x, self.lam, self.status = r['x'], r['lam_g'], r['status']
         self.launches += 1
         return r['status']

@@ -19,12 +19,24 @@ t0 = time.time()
 mpc.solve_cold(bends=())
 print('cold: ok %d / %d, mean iters %.1f  (%.1f s)' % ((mpc.status == 0).sum(), B, mpc.iters.mean(), time.time() - t0))
 tot = 0
+tail = tail_x = 0
+quiet = bool(os.environ.get('STUDY_QUIET'))
 for k in range(steps):
     crossed = mpc.step()
     it = np.asarray(mpc.iters)
     tot += it.sum()
     worst = np.argsort(-it)[:4]
-    print('step %2d%s  t_rel %.2f  mean %.2f  max %2d  >2: %3d  >5: %3d  fail %d   worst agents %s' % (
+    tail += it.max() - 1
+    tail_x += (it.max() - 1) if crossed else 0
+    if not quiet or crossed: print('step %2d%s  t_rel %.2f  mean %.2f  max %2d  >2: %3d  >5: %3d  fail %d   worst agents %s' % (
         k, '*' if crossed else ' ', np.round(mpc.time, 6) % mpc.knot_time, it.mean(), it.max(), (it > 2).sum(), (it > 5).sum(),
         (np.asarray(mpc.status) != 0).sum(), list(zip(worst.tolist(), it[worst].tolist()))))
-print('mean iterations per solve %.3f' % (tot / float(steps * B)))
+print('mean iterations per solve %.3f   tail (sum over steps of max - 1) %d, of which on crossing steps %d' % (tot / float(steps * B), tail, tail_x))
+
+try:
+    _lib = port_binding.load()
+    _lib.omgx_port_cnt.restype = __import__('ctypes').c_long
+    print('   counters: factorisations %d, iterations %d, line-search trials %d (%.2f per iteration), corrections %d' % (
+        _lib.omgx_port_nfact(0), _lib.omgx_port_cnt(4, 0), _lib.omgx_port_cnt(8, 0), _lib.omgx_port_cnt(8, 0) / max(1.0, float(_lib.omgx_port_cnt(4, 0))), _lib.omgx_port_cnt(9, 0)))
+except AttributeError:
+    pass
