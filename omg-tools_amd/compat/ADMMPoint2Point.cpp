@@ -55,7 +55,9 @@ void ADMMPoint2Point::generateProblem() {
     Point2Point::generateProblem();
     omgx_options opt;
     omgx_default_options(&opt);
-    opt.tol = getenv("OMG_TOL") ? atof(getenv("OMG_TOL")) : 1e-3;
+    // (x-updates are solved three digits tighter than ipopt.tol = 1e-3, like `FormationPoint2point.xupdate_tol` of the Python
+    // classes: at 1e-3 the consensus keeps a residual velocity at the goal and the run never ends)
+    opt.tol = getenv("OMG_TOL") ? atof(getenv("OMG_TOL")) : 1e-6;
     opt.max_iter = 500;
     opt.warm_start = 1;
     if (opt.tol < 1e-4) { opt.warm_z_cap = 0.0; opt.max_soc = 0; }          // (as `formation.FormationPoint2point` sets it for tight x-updates)
@@ -83,10 +85,17 @@ void ADMMPoint2Point::loadTables() {
 
 const double* ADMMPoint2Point::table(const std::vector<double>& tab) const {
     const double knot_time = horizon_time / vehicle->getKnotIntervals();
-    const double t_rel = std::fmod(std::round(t_update * 1000.) / 1000., knot_time);
+    // the same rounding as the keys (omgtools/backend.py admm_table_keys): time since the last knot to 1e-6, a time on a knot is 0
+    double t_rel = std::fmod(t_update, knot_time);
+    if (t_rel < 0.) t_rel += knot_time;
+    t_rel = std::round(t_rel * 1e6) / 1e6;
+    if (knot_time - t_rel < 5e-7) t_rel = 0.;
     const int na = (1 + n_nghb) * n_shared;
-    for (size_t k = 0; k < tab_t.size(); ++k) if (std::fabs(tab_t[k] - t_rel) < 1e-7) return &tab[k * na * na];
-    throw std::runtime_error("omg::ADMMPoint2Point: no z-update table for this time since the last knot");
+    for (size_t k = 0; k < tab_t.size(); ++k) if (std::fabs(tab_t[k] - t_rel) < 1.5e-6) return &tab[k * na * na];
+    char msg[256];
+    snprintf(msg, sizeof(msg), "omg::ADMMPoint2Point: no z-update table for %.6f s since the last knot (%zu tables: written for another "
+             "update_time / sample_time? -- omgtools.backend.save_admm_tables covers the multiples of one step)", t_rel, tab_t.size());
+    throw std::runtime_error(msg);
 }
 
 void ADMMPoint2Point::reset() { Point2Point::reset(); }

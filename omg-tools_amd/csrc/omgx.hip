@@ -750,6 +750,22 @@ int check_template(const omgx_template* t) {
   if (!t || t->n_var <= 0 || t->n_par < 0 || t->n_con < 0 || t->n_terms < 0 || t->n_eq < 0 || t->n_root_vars < 0 ||
       !t->row_ptr || (t->n_terms > 0 && (!t->t_coef || !t->t_slot || !t->t_var)) || (t->n_eq > 0 && !t->eq_rows) ||
       (t->n_root_vars > 0 && !t->root_vars)) { g_err = "bad template"; return OMGX_E_INVALID; }
+  // the block table (optional): every entry inside its flat vector -- callers fill p / x0 and read x through these offsets
+  // (`Point2Point::fillParameterDict / extractData`, export/point2point/Point2Point.cpp:263-294)
+  if (t->n_blocks > 0) {
+    if (!t->block_kind || !t->block_off || !t->block_rows || !t->block_cols) { g_err = "bad template: block table without its arrays"; return OMGX_E_INVALID; }
+    for (int i = 0; i < t->n_blocks; ++i) {
+      const int k = t->block_kind[i];
+      const long long n = k == OMGX_BLOCK_VAR ? t->n_var : (k == OMGX_BLOCK_PAR ? t->n_par : (k == OMGX_BLOCK_CON ? t->n_con : -1));
+      const long long off = t->block_off[i], sz = (long long)t->block_rows[i] * t->block_cols[i];
+      if (n < 0 || off < 0 || t->block_rows[i] < 0 || t->block_cols[i] < 0 || off + sz > n) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "bad template: block %d (kind %d, offset %lld, %d x %d) reaches outside its vector of %lld", i, k, off,
+                 t->block_rows[i], t->block_cols[i], n);
+        g_err = buf; return OMGX_E_INVALID;
+      }
+    }
+  }
   return OMGX_OK;
 }
 
@@ -1539,7 +1555,8 @@ int omgx_admm_update_ex(omgx_batch* b, const omgx_admm_layout* lay, const double
                         int32_t zl_stride, double* res, double* sums, const int32_t* pub_slot, double* zl_send,
                         int32_t send_stride) {
   if (!b || !lay || !x_ext || !nbr || !M || !F || !p || !z_ij || !l_ij || !res || !(rho > 0) ||
-      zl_stride < lay->n_nghb * lay->n_dim * lay->L || (pub_slot && (!zl_send || send_stride < 2 * lay->n_nghb * lay->n_dim * lay->L))) {
+      zl_stride < lay->n_nghb * lay->n_dim * lay->L || (pub_slot && (!zl_send || send_stride < 2 * lay->n_nghb * lay->n_dim * lay->L)) ||
+      (pub_slot && sums && send_stride < 3)) {      // (sharded callers keep the three residual sums in a row of zl_send)
     g_err = "bad argument"; return OMGX_E_INVALID;
   }
   const int na = (1 + lay->n_nghb) * lay->n_dim * lay->L;

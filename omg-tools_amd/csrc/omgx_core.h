@@ -2147,7 +2147,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 #ifndef OMGX_HOST_PORT
     // a solve that is still running after this many iterations is one the rest of the batch will wait for: its waves win
     // the issue arbitration against the agent that shares the CU from here on (reset by the kernel after the solve)
-    if (it == o.prio_iter) __builtin_amdgcn_s_setprio(2);
+    if (o.prio_iter > 0 && it == o.prio_iter) __builtin_amdgcn_s_setprio(2);
 #endif
     OMGX_TIC();
     // ---- Jacobian (scaled): one thread per entry; only the entries that depend on x ------------
@@ -2556,12 +2556,17 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       a_p = c.uni(a_p); a_d = c.uni(a_d);
     }
     const double nuE = c.uni(2.0 * fmax(1.0, ymax));
-    const double phi0 = c.uni(f + nu * t - mu * lns - (use_t ? mu * log(t) : 0.0) + nuE * rE_sum);
     // The equality block carries -delta_c I (quasi-definite system): the linearised equality residual after the full
     // step is delta_c * y_new, not zero -- the penalty term can only promise the difference.  (Without this the
     // Armijo test asks, at the end of a tight solve, for a decrease of nuE * 2e-8 that no step can deliver, the
-    // step length collapses and the solve stalls a factor 1.2 above a tolerance of 1e-6.)
-    const double dphi = c.uni(gdx - nuE * fmax(0.0, rE_sum - OMGX_DELTA_C * ysum));
+    // step length collapses and the solve stalls a factor 1.2 above a tolerance of 1e-6.)  Round 4: the merit function
+    // itself counts the equality residual only above that floor.  Once the rows are satisfied to 1e-13 every step of the
+    // regularised system puts delta_c * |y| ~ 1e-8 of residual back: the penalty term then GROWS by nuE * 4e-8 per unit step
+    // against a predicted decrease of 1e-11, every trial is an ascent step and the solve ends in Numerical_Failure (seen on
+    // the quartic free-end-time problem and on 1e-6 formation x-updates).
+    const double floorE = c.uni(OMGX_DELTA_C * ysum);
+    const double phi0 = c.uni(f + nu * t - mu * lns - (use_t ? mu * log(t) : 0.0) + nuE * fmax(0.0, rE_sum - floorE));
+    const double dphi = c.uni(gdx - nuE * fmax(0.0, rE_sum - floorE));
 
     OMGX_TOC(PH_STEP);
     // ---- Armijo backtracking on the barrier function, iterate stays strictly feasible ----
@@ -2626,13 +2631,13 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       {
         int rmin = -1; double sm = 1e300;
         for (int r = 0; r < m; ++r) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) { const double st = tt * w.vv[r] - w.ht[r]; if (st < sm) { sm = st; rmin = r; } }
-        const double phit_ = ft + nu * tt - mu * lnst - (use_t ? mu * log(tt) : 0.0) + nuE * rEt;
+        const double phit_ = ft + nu * tt - mu * lnst - (use_t ? mu * log(tt) : 0.0) + nuE * fmax(0.0, rEt - floorE);
         fprintf(stderr, "        bt %d soc %d alpha %.3e smin %.3e (row %d: s0 %.3e ds %.3e z %.3e) tt %.3e dphi_pred %.3e dphi_act %.3e\n", bt, soc, alpha, sm, rmin,
                 rmin >= 0 ? row_slack(w, rmin, t) : 0.0, rmin >= 0 ? w.ds[rmin] : 0.0, rmin >= 0 ? w.z[rmin] : 0.0, tt, OMGX_ETA * alpha * dphi, phit_ - phi0);
       }
 #endif
       if (smin > 0.0 && (!use_t || tt > 0.0)) {
-        const double phit = ft + nu * tt - mu * lnst - (use_t ? mu * log(tt) : 0.0) + nuE * rEt;
+        const double phit = ft + nu * tt - mu * lnst - (use_t ? mu * log(tt) : 0.0) + nuE * fmax(0.0, rEt - floorE);
         // (near the solution the decrease a Newton step predicts, ~ error^2, drops below what the merit function can
         // resolve -- its value is a sum of ~n_con terms of size 1 -- and the Armijo test then compares rounding
         // noise: such a step is taken as it is, like IPOPT's tiny-step rule; the error test decides about the rest)

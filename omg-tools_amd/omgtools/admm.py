@@ -294,7 +294,10 @@ class HipAdmmOps(object):
         self._slot = t.as_tensor(np.ascontiguousarray(slot), dtype=t.int32, device=self.dev)
         self._pub = t.as_tensor(halo.publish_local, dtype=t.int64, device=self.dev)
         self._src = t.as_tensor(halo.src, dtype=t.int64, device=self.dev)
-        if halo.world > 1 and halo.any_halo and hasattr(self, 'z_ij'):
+        # (the fused path lets the update launch put this rank's three residual sums into one more row of the second
+        # exchange buffer: a fleet whose shared vector has a single number and one neighbour -- row width 2 -- takes the
+        # general exchange)
+        if halo.world > 1 and halo.any_halo and hasattr(self, 'z_ij') and 2 * self.nn * self.ns >= 3:
             self._bind_fused(halo)
 
     def _bind_fused(self, halo):

@@ -497,14 +497,36 @@ class BatchSolver(object):
             tmats.size, PTR_DEVICE if device else 0), 'omgx_batch_shift')
 
 
-def save_admm_tables(path, layout, horizon_time, knot_time, update_time):
-    """The z-update tables the C++ ADMM classes of `omg-tools_amd/compat` read (OMG_ADMM_TABLES): for every time since the
+ADMM_TABLE_MAX_KEYS = 4096
+
+
+def admm_table_keys(knot_time, step, max_keys=ADMM_TABLE_MAX_KEYS):
+    """Times since the last knot at which an update can happen: the multiples of `step` modulo knot_time over one full
+    period (until a multiple lands on a knot again), rounded to 1e-6 -- the rounding `omg::ADMMPoint2Point::table`
+    applies to its clock.  The reference's generated updz takes the time as a continuous input (`export/export_admm.py`);
+    a table needs the two times to be commensurable and raises otherwise."""
+    keys, k = [0.0], 1
+    while True:
+        t = (k * step) % knot_time
+        if knot_time - t < 5e-7 or t < 5e-7:
+            break                                           # back on a knot: the period is complete
+        keys.append(round(t, 6))
+        k += 1
+        if len(keys) > max_keys:
+            raise ValueError('z-update tables: no multiple of the step %g lands on a knot (knot_time %g) within %d '
+                             'updates -- update_time / sample_time and knot_time must be commensurable' % (step, knot_time, max_keys))
+    return sorted(set(keys))
+
+
+def save_admm_tables(path, layout, horizon_time, knot_time, update_time, sample_time=None):
+    """(sample_time: give it when updates may be shifted by whole samples -- `update1(..., predict_shift)` of the export
+    classes advances the clock by predict_shift * sample_time -- the tables then cover its multiples.)
+    The z-update tables the C++ ADMM classes of `omg-tools_amd/compat` read (OMG_ADMM_TABLES): for every time since the
     last knot an update can happen at (multiples of update_time modulo knot_time), the consensus projector M and the knot
     transform F of `formation.zupdate_matrices` -- what the reference's exporter generates as updz.so / updres.so
     (`export/export_admm.py`).  Layout: "OMGXADM1", int32 {n_all, n_keys}, per key: t_rel, M, F (row-major doubles)."""
     from .formation import zupdate_matrices
-    n_steps = int(round(knot_time / update_time))
-    keys = sorted(set(round((k * update_time) % knot_time, 6) for k in range(max(1, n_steps))))
+    keys = admm_table_keys(knot_time, update_time if sample_time is None else sample_time)
     with open(path, 'wb') as fp:
         blobs = []
         for t_rel in keys:

@@ -30,6 +30,12 @@ def is_atom(sym):
     return sym >= _ATOM_BASE
 
 
+def _exact_key(v):
+    """Hashable identity of a Poly (every term with its exact coefficient) or of a number."""
+    terms = getattr(v, 'terms', None)
+    return tuple(sorted(terms.items())) if terms is not None else ('num', float(v))
+
+
 class Poly(object):
     """Sparse multivariate polynomial with float coefficients."""
     __slots__ = ('terms',)
@@ -323,7 +329,7 @@ class SymbolTable(object):
         return ids
 
     def new_div_atom(self, num, den):
-        key = (repr(num), repr(den))
+        key = (_exact_key(num), _exact_key(den))      # (repr prints six digits: two offsets that differ beyond them would share an atom)
         if key in self._div_cache:
             return self._div_cache[key]
         sym = _ATOM_BASE + self.n_atoms
@@ -334,7 +340,7 @@ class SymbolTable(object):
         return sym
 
     def new_fun_atom(self, kind, arg):
-        key = (kind, repr(arg))
+        key = (kind, _exact_key(arg))
         if key in self._div_cache:
             return self._div_cache[key]
         sym = _ATOM_BASE + self.n_atoms

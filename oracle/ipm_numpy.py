@@ -514,9 +514,11 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                 a_d = min(a_d, -tau * zt / dzt)
         thE = np.abs(rE).sum()
         nuE = 2.0 * max(1.0, np.abs(y_new).max() if mE else 0.0)
-        phi0 = f + nu * t - mu * np.log(s).sum() - (mu * np.log(t) if use_t else 0.0) + nuE * thE
-        # (quasi-definite system: the linearised equality residual after the full step is delta_c * y_new)
-        dphi = g_bar @ dxt - nuE * max(0.0, thE - o['delta_c'] * (np.abs(y_new).sum() if mE else 0.0))
+        # (quasi-definite system: the linearised equality residual after the full step is delta_c * y_new; the merit
+        # function counts the equality residual only above that floor -- omgx_core.h)
+        floorE = o['delta_c'] * (np.abs(y_new).sum() if mE else 0.0)
+        phi0 = f + nu * t - mu * np.log(s).sum() - (mu * np.log(t) if use_t else 0.0) + nuE * max(0.0, thE - floorE)
+        dphi = g_bar @ dxt - nuE * max(0.0, thE - floorE)
         # a step of the regularised system may be offered longer (omgx_core.h: the crawl of the proximal iteration)
         a_bnd = a_p
         a_p = min(a_bnd, 1.0)
@@ -541,7 +543,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             # (omgx_core.h OMGX_FTB_ACTUAL: every row really keeps half of what the linear fraction-to-boundary rule leaves it)
             if (st - o.get('ftb_actual', 0.5) * (1.0 - tau) * s).min() > 0 and (not use_t or tt > 0):
                 phit = ft + nu * tt - mu * np.log(st).sum() - (mu * np.log(tt) if use_t else 0.0) \
-                    + nuE * np.abs(cEt - tt * cE0).sum()
+                    + nuE * max(0.0, np.abs(cEt - tt * cE0).sum() - floorE)
                 if phi_noise or phit <= phi0 + o['eta'] * alpha * dphi or phit - phi0 <= 10 * np.finfo(float).eps * abs(phi0):
                     ok = True
                     break

@@ -207,3 +207,22 @@ def test_library_plan_agrees_with_the_oracle_partition(cfg2_small):
     got = [sorted(lib['order'][off[l]:off[l + 1]].tolist()) for l in range(lib['n_leaf'])]
     assert got == [sorted(l) for l in ref.leaves]
     assert sorted(lib['order'][off[-1]:].tolist()) == sorted(ref.order[ref.root_off:].tolist())
+
+
+def test_admm_table_keys_cover_the_full_period():
+    """The z-update tables of the C++ ADMM classes (`omgtools.backend.save_admm_tables`): one key per time since the
+    last knot an update can happen at, over the whole period -- also when update_time does not divide knot_time (the
+    reference's generated updz takes the time as a continuous input, `export/export_admm.py`)."""
+    import omgtools.backend as be
+    assert be.admm_table_keys(1.0, 0.1) == [round(0.1 * k, 6) for k in range(10)]
+    keys = be.admm_table_keys(1.0, 0.3)                       # 0.3 does not divide 1.0: the period is 10 updates long
+    assert keys == [round(0.1 * k, 6) for k in range(10)]
+    keys = be.admm_table_keys(10.0 / 11.0, 0.1)               # horizon 10 s, 11 knot intervals: 100 updates per period
+    assert len(keys) == 100 and keys[0] == 0.0 and all(0.0 <= t < 10.0 / 11.0 for t in keys)
+    for k in (1, 37, 99, 101, 250):                           # every update time is in the table, with the C++ side's rounding
+        t_rel = round((k * 0.1) % (10.0 / 11.0), 6)
+        if 10.0 / 11.0 - t_rel < 5e-7:
+            t_rel = 0.0
+        assert min(abs(t_rel - q) for q in keys) < 1.5e-6
+    with pytest.raises(ValueError):
+        be.admm_table_keys(1.0, 0.1 * 2 ** 0.5)

@@ -47,3 +47,4 @@ it = np.array([l[0] for l in log[n_init:]]); st = np.array([l[1] for l in log[n_
 print('%s %d agents tol %g opts %s: %d updates (%d crossings): mean iterations per x-update %.3f, max %d, sum over updates of the max %d, failures %d  (init: mean %.1f)  %.1f s' % (
     'rendezvous' if rendezvous else 'formation', N, tol, extra, steps, cross, it.mean(), it.max(), it.max(axis=1).sum(), (st != 0).sum(),
     np.mean([l[0].mean() for l in log[:n_init]]), time.time() - t0))
+print('   statuses', dict(zip(*[a.tolist() for a in np.unique(st, return_counts=True)])), ' updates with a failure:', np.nonzero((st != 0).any(axis=1))[0][:30].tolist())
