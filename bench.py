@@ -244,18 +244,33 @@ def store_leg(mpc, problem, tpl, x0_init, p_init, n_steps, dev):
             'note': 'state / input / dinput / v_tot of every agent on 1001 samples, written by the solve kernel (A11 fused)'}
 
 
-def unedited_rule(args, dev, seed):
-    """SURVEY 8d's obstacle rule as written (discs rejected only when they overlap; omgtools/scenarios.py adds
-    a passable-gap rule for the headline workload): solved fractions of the same protocol on that generator."""
-    from omgtools.scenarios import holonomic_p2p
-    from omgtools.batch import BatchP2P
+def without_solver_objects(fn, *a, **kw):
+    """A front-end builder called for its template only (`Point2point.init` would create a solver object of its own)."""
     import omgtools.backend as be
     saved = be.create_nlp
     be.create_nlp = lambda tpl, opt, name='': (None, 0.)
     try:
-        problem, P = holonomic_p2p(args.agents, seed=seed, gap=0.0)
+        return fn(*a, **kw)
     finally:
         be.create_nlp = saved
+
+
+def p2p_workload(args, seed, gap=0.25):
+    """BASELINE configs[1] from its committed problem bundle (`omgtools.workloads`: template + seeded parameters, no front-end
+    module imported); other knot counts / obstacle numbers (developer options) are built through the front end."""
+    if args.knot_intervals == 11 and args.obstacles == 3:
+        from omgtools import workloads
+        return workloads.holonomic_p2p(args.agents, seed=seed, gap=gap)
+    from omgtools import scenarios
+    return without_solver_objects(scenarios.holonomic_p2p, args.agents, knot_intervals=args.knot_intervals, n_obs=args.obstacles,
+                                  seed=seed, gap=gap)
+
+
+def unedited_rule(args, dev, seed):
+    """SURVEY 8d's obstacle rule as written (discs rejected only when they overlap; omgtools/scenarios.py adds
+    a passable-gap rule for the headline workload): solved fractions of the same protocol on that generator."""
+    from omgtools.batch import BatchP2P
+    problem, P = p2p_workload(args, seed, gap=0.0)
     mpc = BatchP2P(problem, P, ops='hip', device=dev, options=dict(tol=args.tol, max_iter=300))
     mpc.solve_cold()
     cold_ok = int((mpc.status == 0).sum().item())
@@ -274,13 +289,18 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
     iterations at the start time, then one step = one update: time advanced by update_time = 0.1 s, the initial
     conditions predicted from the current plan (on the device), the moving obstacle advanced, the knot-crossing shift of
     x and of the consensus state, and ONE ADMM iteration (x-update + exchanges + z / l / residuals)."""
-    from omgtools.scenarios import formation_holonomic, rendezvous_holonomic
+    from omgtools import workloads
     from omgtools.backend import BatchSolver
     from omgtools.admm import BatchADMM, HipAdmmOps, FormationMPC
     from omgtools.distributed import shard_range, reduce_report
     N = 512 if args.agents == 1024 else args.agents
     rendezvous = args.workload == 'rendezvous'
-    problem, updater, father, lay, P = (rendezvous_holonomic if rendezvous else formation_holonomic)(N)
+    # (the problem bundle of the fleet size, omgtools/data; another size: the front end builds its template)
+    if workloads.have(('rendezvous' if rendezvous else 'formation') + '_holonomic_k10_%d' % N):
+        problem, updater, father, lay, P = (workloads.rendezvous_holonomic if rendezvous else workloads.formation_holonomic)(N)
+    else:
+        from omgtools import scenarios
+        problem, updater, father, lay, P = without_solver_objects(scenarios.rendezvous_holonomic if rendezvous else scenarios.formation_holonomic, N)
     tpl = father.template
     lo, hi = shard_range(N, rank, world)
     solver = BatchSolver(tpl, hi - lo, device=local_rank, options=dict(tol=args.tol, max_iter=300))
@@ -347,16 +367,12 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
     """configs[2] / configs[4] (parity-test configurations, not the headline): cold solves of a
     batch of Quadrotor (K=13, 5 moving circles) or Holonomic3D (K=15, 10 spheres) agents.  Their
     per-agent arrays exceed one CU's LDS; the library spills to HBM slabs (omgx_batch_workspace)."""
-    from omgtools import scenarios
+    from omgtools import workloads
     from omgtools.backend import BatchSolver
     from omgtools.distributed import reduce_report
-    import omgtools.backend as be
-    fn = {'quadrotor': scenarios.quadrotor_p2p, 'holonomic3d': scenarios.holonomic3d_p2p}[args.workload]
+    fn = {'quadrotor': workloads.quadrotor_p2p, 'holonomic3d': workloads.holonomic3d_p2p}[args.workload]
     B = args.agents
-    saved = be.create_nlp
-    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
     problem, P = fn(B, seed=20240807 + (3 if args.workload == 'quadrotor' else 5) + 1000 * rank)
-    be.create_nlp = saved
     tpl = problem.father.template
     from omgtools.batch import BatchP2P
     mpc = BatchP2P(problem, P, ops='hip', device=dev, options=dict(P.get('solver_options', {}), tol=args.tol, max_iter=300))
@@ -466,15 +482,10 @@ def main():
         return bench_formation(args, rank, local_rank, world, dist, dev)
     if args.workload in ('quadrotor', 'holonomic3d'):
         return bench_cold(args, rank, local_rank, world, dist, dev)
-    from omgtools.scenarios import holonomic_p2p
     from omgtools.batch import BatchP2P
     from omgtools.distributed import reduce_report
-    import omgtools.backend as be
     B = args.agents
-    saved = be.create_nlp
-    be.create_nlp = lambda tpl, opt, name='': (None, 0.)      # BatchP2P below owns the product-path solver
-    problem, P = holonomic_p2p(B, knot_intervals=args.knot_intervals, n_obs=args.obstacles, seed=20240807 + 2 + 1000 * rank)
-    be.create_nlp = saved
+    problem, P = p2p_workload(args, 20240807 + 2 + 1000 * rank)
     tpl = problem.father.template
     opts = dict(tol=args.tol, max_iter=300)
     mpc = BatchP2P(problem, P, ops='hip', device=dev, options=opts)

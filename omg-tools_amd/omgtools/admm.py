@@ -19,7 +19,7 @@ import ctypes as C
 import numpy as np
 
 from .distributed import shard_range
-from .formation import zupdate_matrices, reverse_slots
+from .consensus import zupdate_matrices, reverse_slots
 
 
 class AdmmLayoutC(C.Structure):
@@ -196,7 +196,7 @@ class FormationMPC(object):
 
     def __init__(self, admm, father, tpl, lay, vehicle, obstacles=(), update_time=0.1, init_iter=5, iters_per_update=1,
                  knot_time=None, consensus_is_spline=True):
-        from .formation import shift_tables
+        from .consensus import shift_tables
         self.admm, self.ops, self.lay, self.tpl = admm, admm.ops, lay, tpl
         self.T, self.update_time = admm.T, float(update_time)
         # the plan the prediction reads: the vehicle's own splines (the consensus quantity may be something else: RendezVous)

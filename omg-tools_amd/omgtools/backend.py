@@ -525,7 +525,7 @@ def save_admm_tables(path, layout, horizon_time, knot_time, update_time, sample_
     last knot an update can happen at (multiples of update_time modulo knot_time), the consensus projector M and the knot
     transform F of `formation.zupdate_matrices` -- what the reference's exporter generates as updz.so / updres.so
     (`export/export_admm.py`).  Layout: "OMGXADM1", int32 {n_all, n_keys}, per key: t_rel, M, F (row-major doubles)."""
-    from .formation import zupdate_matrices
+    from .consensus import zupdate_matrices
     keys = admm_table_keys(knot_time, update_time if sample_time is None else sample_time)
     with open(path, 'wb') as fp:
         blobs = []

@@ -102,7 +102,8 @@ class BatchP2P(object):
             oa = tpl.entry_range(obs.label, 'a', 'par')
             if np.any(P['p'][:, ov[0]:ov[1]] != 0.) or np.any(P['p'][:, oa[0]:oa[1]] != 0.):     # static obstacles: nothing to do
                 self.obst.append((ox[0], ov[0], oa[0], ox[1] - ox[0]))
-        self.perm = dual_shift_perm(father)
+        # (a problem loaded from a bundle, `omgtools.workloads`, brings the multiplier map of a knot crossing with it)
+        self.perm = father.dual_perm if hasattr(father, 'dual_perm') else dual_shift_perm(father)
         ents, mats, off = [], [], 0
         for label, name, spl in father.shifted_entries(every_spline=shift_every_spline):
             lo, rows, cols = tpl.var_layout[(label, name)]

@@ -36,6 +36,7 @@ tests/golden/admm_rendezvous.npz (generator tests/golden/generate_golden_admm.py
 import numpy as np
 
 from .formation import FormationPoint2point
+from .consensus import consensus_matrix, RendezVousLayout      # noqa: F401
 from .opti import OptiChild, OptiFather
 from .problems import FreeEndPoint2point
 from .symbolic import Poly
@@ -88,44 +89,6 @@ def build_rendezvous_template(vehicle, environment, n_nghb, options=None):
             be.create_nlp = saved
     father.init_transformations(problem.init_primal_transform, problem.init_dual_transform)
     return problem, updater, father
-
-
-def consensus_matrix(ns, n_nghb):
-    """A of the z-update's equality constraints (`rendezvous.py:47-58` seen through `admm.py:313-354`):
-    z_i - z_ij = 0 for every neighbour; unknown vector [z_i | z_ij (neighbour by neighbour)]."""
-    A = np.zeros((n_nghb * ns, (1 + n_nghb) * ns))
-    for j in range(n_nghb):
-        A[j * ns:(j + 1) * ns, :ns] = np.eye(ns)
-        A[j * ns:(j + 1) * ns, (1 + j) * ns:(2 + j) * ns] = -np.eye(ns)
-    return A
-
-
-class RendezVousLayout(object):
-    """Offsets of everything the ADMM kernels touch inside x and p (same fields as FormationLayout; the shared
-    vector is n_dim blocks of L = 1 coefficient)."""
-
-    def __init__(self, template, vehicle, problem, updater, n_nghb):
-        t = template
-        self.n_dim, self.L, self.degree = vehicle.n_dim, 1, 0
-        self.ns, self.n_nghb = self.n_dim, n_nghb
-        self.x_spl = t.entry_range(problem.label, 'conT0', 'var')[0]           # what omgx_admm_center reads
-        self.x_traj = t.entry_range(vehicle.label, 'splines_seg0', 'var')[0]
-        par = lambda child, name: t.entry_range(child.label, name, 'par')[0]
-        self.p_rel = par(vehicle, 'rel_pos_c')
-        self.p_state0, self.p_input0 = par(vehicle, 'state0'), par(vehicle, 'input0')
-        self.p_poseT = par(vehicle, 'poseT')
-        self.p_T, self.p_t = par(problem, 'T'), par(problem, 't')
-        self.p_zi, self.p_zji = par(updater, 'z_i'), par(updater, 'z_ji')
-        self.p_li, self.p_lji = par(updater, 'l_i'), par(updater, 'l_ji')
-        self.p_rho = par(updater, 'rho')
-        self.basis = vehicle.basis
-        A = consensus_matrix(self.ns, n_nghb)
-        self._M = np.eye(A.shape[1]) - A.T @ np.linalg.solve(A @ A.T, A)
-
-    def zupdate(self, t0):
-        """(M, F) of the closed-form z-update z_all = M (x_all + l_all / rho) (`admm.py:144-162`); nothing depends
-        on the time: the shared vector is not a spline."""
-        return self._M, np.eye(self._M.shape[0])
 
 
 class RendezVous(FormationPoint2point):

@@ -19,7 +19,7 @@ def test_batch_admm_matches_numpy_backend():
     from omgtools.backend import BatchSolver
     tpl, lay, P = _scenario(8)
     dev = torch.device('cuda', 0)
-    solver = BatchSolver(tpl, 8, options=dict(tol=1e-6, max_iter=200, warm_z_cap=0.0))
+    solver = BatchSolver(tpl, 8, options=dict(tol=1e-6, max_iter=200, warm_z_cap=0.0, max_soc=0))
     gpu = BatchADMM(lay, P['nbr'], HipAdmmOps(solver, tpl, lay, P['p'], P['x0'], dev), rho=1.0)
     cpu_ops = NumpyAdmmOps(tpl, lay, P['p'], P['x0'])
     cpu = BatchADMM(lay, P['nbr'], cpu_ops, rho=1.0)
@@ -52,7 +52,7 @@ def test_nesterov_acceleration_matches_numpy_backend():
     dev = torch.device('cuda', 0)
     for kw in (dict(nesterov_acceleration=True), dict(nesterov_acceleration=True, nesterov_reset=True, eta=0.9),
                dict(nesterov_acceleration=True, AMA=True)):
-        solver = BatchSolver(tpl, 8, options=dict(tol=1e-6, max_iter=200, warm_z_cap=0.0))
+        solver = BatchSolver(tpl, 8, options=dict(tol=1e-6, max_iter=200, warm_z_cap=0.0, max_soc=0))
         gpu = BatchADMM(lay, P['nbr'], HipAdmmOps(solver, tpl, lay, P['p'], P['x0'], dev), rho=1.0, **kw)
         cpu_ops = NumpyAdmmOps(tpl, lay, P['p'], P['x0'])
         cpu = BatchADMM(lay, P['nbr'], cpu_ops, rho=1.0, **kw)

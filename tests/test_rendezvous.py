@@ -137,7 +137,8 @@ def test_rendezvous_hip_matches_numpy_backend():
     from admm_numpy_ops import NumpyAdmmOps
     problem, updater, father, lay, P = _fleet(8)
     tpl = father.template
-    solver = BatchSolver(tpl, 8, options=dict(tol=1e-6, max_iter=200))
+    # (the options NumpyAdmmOps hands its x-update solver at 1e-6: plain multiplier floor, plain backtracking)
+    solver = BatchSolver(tpl, 8, options=dict(tol=1e-6, max_iter=200, warm_z_cap=0.0, max_soc=0))
     gpu = BatchADMM(lay, P['nbr'], HipAdmmOps(solver, tpl, lay, P['p'], P['x0'], torch.device('cuda', 0)), rho=2.0)
     cpu_ops = NumpyAdmmOps(tpl, lay, P['p'], P['x0'])
     cpu = BatchADMM(lay, P['nbr'], cpu_ops, rho=2.0)
