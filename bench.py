@@ -332,6 +332,14 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
     barrier()
     elapsed = time.perf_counter() - t0
     solver.set_stats(None)
+    # where an update's time goes (a second, untimed pass with an event after every phase of the iteration: x-update,
+    # centre, the two collectives, z / lambda update, read-back -- what a multi-GPU run needs to be diagnosable)
+    ops.timeline = []
+    for _ in range(min(args.steps, 20)):
+        mpc.step()
+    barrier()
+    phases = ops.phase_times()
+    ops.timeline = None
     stats = stats.cpu().numpy()
     if os.environ.get('OMGX_PHASES'):                      # developer: per-phase cycles of the last x-update (profiling build)
         import ctypes
@@ -360,7 +368,9 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
                    'parallelism': 'agents sharded contiguously; two all_gathers per iteration (x_i rows; [z_ij | l_ij] rows + residual sums)'},
         'solved_fraction': n_ok_all / float(N), 'residuals': list(res), 'knot_crossings_in_timed_steps': crossings,
         'protocol': 'init_iter=5, then per step: update_time 0.1 s, device-side prediction, moving obstacle advanced, knot-crossing shift, 1 ADMM iteration',
-        'x_update_mean_iters': float(stats[:, 1].sum()) / max(1, int(stats[:, 3].sum())), 'x_update_max_iters': int(stats[:, 2].max())}))
+        'x_update_mean_iters': float(stats[:, 1].sum()) / max(1, int(stats[:, 3].sum())), 'x_update_max_iters': int(stats[:, 2].max()),
+        'phase_ms': dict((k, round(v, 4)) for k, v in phases.items()),
+        'phase_note': 'rank 0, mean over a separate untimed pass of the same protocol with an event after every phase of the iteration; x_update includes the prediction / shift glue of the step'}))
 
 
 def bench_cold(args, rank, local_rank, world, dist, dev):

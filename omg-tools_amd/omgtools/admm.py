@@ -116,21 +116,34 @@ class BatchADMM(object):
     def initialize(self):
         self.ops.init_consensus(self.lay)
 
+    def _mark(self, tag):
+        """Phase stamp for a caller that asked for a timeline (`ops.timeline` = a list: bench.py --workload formation
+        reports x-update / exchange / update times per iteration): an event on the stream, nothing waits for it."""
+        if getattr(self.ops, 'timeline', None) is not None:
+            self.ops.mark(tag)
+
     def iterate(self, t_rel=0.0, sync=True):
         """One ADMM iteration (`admm.py:584-611`).  sync=False returns (status, None) and leaves the
         residuals on the device (`residuals` fetches the whole history at once)."""
         ops, lay = self.ops, self.lay
+        self._mark('begin')
         ops.set_time(lay, t_rel, self.rho)
         status = ops.solve()                                   # x-update
+        self._mark('x_update')
         if self.exchanging() and not self.nesterov and getattr(ops, 'fused', False):
             # sharded fleet, no copies around the collectives: four launches and two all_gathers per iteration, every
             # kernel reads and writes the exchange buffers in place (include/omgx.h omgx_admm_*_ex)
             ops.center(lay)                                    # x_i rows + the rows other ranks need -> send buffer
+            self._mark('centre')
             ops.gather_x(self.dist)                            # collective #1, straight behind the local rows
+            self._mark('collective_x')
             M, F = self.matrices(t_rel)
             ops.update_fused(lay, M, F, self.rho)              # [z_ij | l_ij] in place; published rows and this rank's sums -> send buffer
+            self._mark('z_l_update')
             ops.gather_zl(self.dist)                           # collective #2
+            self._mark('collective_zl')
             sums = ops.communicate_fused(lay)                  # z_ji, l_ji from the gathered rows; the fleet's residual sums
+            self._mark('read_back')
             self._res.append(sums)
             self.iteration += 1
             if not sync:
@@ -138,12 +151,15 @@ class BatchADMM(object):
             s3 = ops.to_host(sums)
             return status, (float(np.sqrt(s3[0])), float(np.sqrt(s3[1])), float(s3[2]))
         x_i = ops.center(lay)
+        self._mark('centre')
         x_ext = self.extend(x_i)                               # collective #1
+        self._mark('collective_x')
         M, F = self.matrices(t_rel)
         if self.nesterov:
             ops.save_previous(lay)                             # z_p, l_p of `admm.py:409-410, 450-451`
         res = ops.update(lay, x_ext, self.halo.nbr_local, M, F, self.rho)
         sums = ops.residual_sums(res)                          # [3], backend array, no host copy
+        self._mark('z_l_update')
         # with acceleration the previous z_ij, l_ij travel too: the extrapolation is elementwise with fleet-wide
         # scalars, so every rank applies it to the rows it received instead of waiting for a third collective
         if not self.nesterov and not self.exchanging() and getattr(ops, '_slot', None) is not None:
@@ -151,6 +167,7 @@ class BatchADMM(object):
             if self.dist is not None and self.halo.world > 1:
                 sums = ops.allreduce(sums, self.dist)
             ops.communicate_local(lay)
+            self._mark('read_back')
             self._res.append(sums)
             self.iteration += 1
             if not sync:
@@ -164,6 +181,7 @@ class BatchADMM(object):
             sums = ops.allreduce(sums, self.dist)              # (no halo anywhere: disjoint groups still share the sums)
         zl_ext = ops.accelerate(lay, sums, buf, self.eta, self.nesterov_reset, self.AMA) if self.nesterov else buf
         ops.communicate(lay, self.halo.nbr_local, self.slot, zl_ext)
+        self._mark('read_back')
         self._res.append(sums)
         self.iteration += 1
         if not sync:
@@ -183,6 +201,104 @@ class BatchADMM(object):
         if len(self._res_host) > self.history_cap:
             del self._res_host[:len(self._res_host) - self.history_cap]
         return list(self._res_host)
+
+
+class FullConsensusADMM(object):
+    """Formation ADMM of a fleet with `interconnection='full'` (`vehicles/fleet.py:55-56`: every vehicle is every other's
+    neighbour) with ONE collective per iteration -- BASELINE.json's "all-reduce of z / lambda" (SURVEY.md §8e).
+
+    With every pair coupled, the copies z_i, z_ij of one agent's z-update (`problems/admm.py:407-445`) are all equal to one
+    vector, c_i = Pi (1/N) sum_k (x_k + l_ik / rho) (Pi: the projector of the terminal rows), and -- whatever the initial
+    guess -- from the first z-update on the c_i of all agents are the same c: the multipliers an agent keeps for agent k's
+    copy, l_ik = rho sum_t (x_k - c)_t, do not depend on i.  The N - 1 neighbour blocks of the x-update objective
+    (`admm.py:63-107`) then all hold (c, l_i) and add up to N [l_i'(x - c) + rho / 2 |x - c|^2].  So the iteration needs
+    the fleet only through sum_k (x_k + l_k / rho): an all_reduce(sum) of n_shared doubles, with the three residual sums of
+    the previous iteration riding along (n_shared + 3 doubles per iteration, nothing else crosses ranks).
+
+    Runs on the x-update template of ANY neighbour count n (the usual one has 2): the 1 + n blocks get the weights
+    N rho / (1 + n) and N l_i / (1 + n).  `ops`: NumpyAdmmOps / HipAdmmOps (x-update, centre; the rest is array
+    arithmetic on the backend's arrays).  tests/test_admm_cpu.py: equal to the general iteration (`BatchADMM` on the
+    template with N - 1 neighbour blocks) on a four-vehicle fleet, and 2 gloo ranks == 1 rank."""
+
+    def __init__(self, layout, ops, n_agents, rank=0, world=1, dist=None, rho=1.0):
+        self.lay, self.ops, self.N, self.rho = layout, ops, int(n_agents), float(rho)
+        self.rank, self.world, self.dist = rank, world, dist
+        basis, d, L, nd = layout.basis, layout.degree, layout.L, layout.n_dim
+        # projector of the terminal rows (d^o/dtau^o centre)(1) = 0, o = 1..degree, per dimension (`formation.py:46-65`)
+        P_term = np.array([basis.derivative(o)[1][-1, :] for o in range(1, d + 1)]).reshape(d, L)
+        Pi1 = np.eye(L) - P_term.T @ np.linalg.solve(P_term @ P_term.T, P_term) if d > 0 else np.eye(L)
+        self.Pi = ops.asarray(np.kron(np.eye(nd), Pi1))
+        self.iteration = 0
+        self.collectives = 0
+        self._pending = None          # local residual partials of the last iteration (they travel with the next all_reduce)
+        self._res = []
+
+    def initialize(self):
+        """`admm.py:360-370`: every copy starts at its agent's own centre, multipliers zero."""
+        ops, lay = self.ops, self.lay
+        ops.init_consensus(lay)
+        x_i = ops.center(lay)
+        self.z_prev = x_i * 1.0          # what the fleet's copies of agent k hold
+        self.c = None
+        self.l = x_i * 0.0
+
+    def _set_consensus(self):
+        """(c, l_i) into the 1 + n blocks of the x-update's parameters, with the weights that make them stand for N copies."""
+        ops, lay = self.ops, self.lay
+        ns, nn = lay.ns, lay.n_nghb
+        w = self.N / float(1 + nn)
+        z = self.z_prev if self.c is None else self.c
+        ops.p[:, lay.p_zi:lay.p_zi + ns] = z
+        ops.p[:, lay.p_li:lay.p_li + ns] = w * self.l
+        for j in range(nn):
+            ops.p[:, lay.p_zji + j * ns:lay.p_zji + (j + 1) * ns] = z
+            ops.p[:, lay.p_lji + j * ns:lay.p_lji + (j + 1) * ns] = w * self.l
+        ops.p[:, lay.p_rho] = w * self.rho
+
+    def iterate(self, t_rel=0.0):
+        ops, lay, rho, N = self.ops, self.lay, self.rho, self.N
+        ops.set_time(lay, t_rel, rho)
+        self._set_consensus()
+        status = ops.solve()                                      # x-update
+        x_i = ops.center(lay)
+        ns = lay.ns
+        buf = ops.asarray(np.zeros(ns + 3))
+        buf[:ns] = (x_i + self.l / rho).sum(0)
+        if self._pending is not None:
+            buf[ns:] = self._pending
+        if self.dist is not None and self.world > 1:
+            buf = ops.allreduce(buf, self.dist)                   # the one collective of the iteration
+            self.collectives += 1
+        if self._pending is not None:
+            self._res.append(buf[ns:] * 1.0)
+        c = self.Pi @ (buf[:ns] / N)
+        self.l = self.l + rho * (x_i - c)
+        s_p = ((x_i - c) ** 2).sum()
+        # what the general iteration reports (`admm.py:493-508` summed over the fleet): every agent counts all N copies.
+        # (Before the first z-update an agent's own copy holds its centre and its copies of the others hold zero,
+        # `admm.py:360-370`; afterwards every copy holds the previous c.)
+        if self.iteration == 0:
+            dual = ((c - self.z_prev) ** 2).sum() + x_i.shape[0] * (N - 1) * (c ** 2).sum()
+        else:
+            dual = N * ((c - self.z_prev) ** 2).sum()
+        self._pending = ops.asarray(np.zeros(3))
+        self._pending[0], self._pending[1], self._pending[2] = N * s_p, rho * dual, rho * N * s_p + rho * dual
+        self.c = c
+        self.z_prev = x_i * 0.0 + c
+        self.iteration += 1
+        return status
+
+    @property
+    def residuals(self):
+        """[(primal, dual, combined)] per iteration; the sums of the last iteration are still local: one more all_reduce."""
+        rows = list(self._res)
+        if self._pending is not None:
+            last = self._pending * 1.0
+            if self.dist is not None and self.world > 1:
+                last = self.ops.allreduce(last, self.dist)
+            rows.append(last)
+        arr = self.ops.to_host_stack(rows) if rows else np.zeros((0, 3))
+        return [(float(np.sqrt(r[0])), float(np.sqrt(r[1])), float(r[2])) for r in arr]
 
 
 class FormationMPC(object):
@@ -287,6 +403,24 @@ class HipAdmmOps(object):
         self.c_res_p = None
         self._prev = None
 
+    # -- phase timeline (bench.py): `timeline = []` switches it on, `phase_times()` reads it after a synchronisation ----
+    timeline = None
+
+    def mark(self, tag):
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.timeline.append((tag, ev))
+
+    def phase_times(self):
+        """Mean milliseconds per iteration between consecutive marks, by the tag of the mark that ends the span."""
+        tot, cnt, prev = {}, {}, None
+        for tag, ev in self.timeline:
+            if tag != 'begin' and prev is not None:
+                tot[tag] = tot.get(tag, 0.0) + prev.elapsed_time(ev)
+                cnt[tag] = cnt.get(tag, 0) + 1
+            prev = ev
+        return dict((k, tot[k] / cnt[k]) for k in tot)
+
     def bind(self, halo, slot):
         """Index tensors that never change: uploaded once."""
         t = self.torch
@@ -323,6 +457,9 @@ class HipAdmmOps(object):
         self._pub_rows = t.as_tensor(np.ascontiguousarray(halo.publish_local), dtype=t.int32, device=self.dev)
         self._pub_slot = t.as_tensor(np.ascontiguousarray(halo.pub_slot), dtype=t.int32, device=self.dev)
         self.fused = True
+
+    def asarray(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a), dtype=self.torch.float64, device=self.dev)
 
     def resident(self, M, F):
         t = self.torch

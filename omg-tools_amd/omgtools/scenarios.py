@@ -95,7 +95,7 @@ def _obstacle_facts(environment, with_velocity=True):
 
 
 def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0, horizon_time=10.,
-                        with_obstacles=True, obstacles=None):
+                        with_obstacles=True, obstacles=None, interconnection='circular'):
     """Config 4: `n_agents` Holonomic vehicles keeping a regular-polygon formation
     (circular interconnection), shape of `examples/formation_holonomic.py:22-57`
     scaled to the fleet size.  Returns (problem, updater, father,
@@ -118,12 +118,15 @@ def formation_holonomic(n_agents, knot_intervals=10, seed=20240807 + 4, rho=1.0,
         # the moving circle of `examples/formation_holonomic.py:41-44` (there it is pushed at t = 3 s by a
         # simulation trajectory; the synthetic workload gives it that velocity from the start)
         environment.add_obstacle(Obstacle({'position': [1.5, 0.5], 'velocity': [-0.15, 0.0]}, shape=Circle(0.4)))
+    # (`vehicles/fleet.py:49-60`: 'circular' = next and previous vehicle, 'full' = every other vehicle)
+    n_nghb = 2 if interconnection == 'circular' else n_agents - 1
     problem, updater, father = build_updx_template(
-        vehicle, environment, 2, {'horizon_time': horizon_time})
+        vehicle, environment, n_nghb, {'horizon_time': horizon_time})
     tpl = father.template
-    lay = FormationLayout(tpl, vehicle, problem, updater, 2)
+    lay = FormationLayout(tpl, vehicle, problem, updater, n_nghb)
     P = wl.fill_formation(tpl, lay, _obstacle_facts(environment), n_agents, horizon_time, rho)
-    P['nbr'] = circular_neighbors(n_agents)
+    P['nbr'] = circular_neighbors(n_agents) if interconnection == 'circular' else \
+        np.array([[j for j in range(n_agents) if j != i] for i in range(n_agents)], dtype=np.int32)
     return problem, updater, father, lay, P
 
 

@@ -191,6 +191,9 @@ class NumpyAdmmOps(object):
         out = np.concatenate([local, allp[halo.src[:, 0], halo.src[:, 1], :wl]], axis=0) if len(halo.needed) else local
         return out, summed
 
+    def asarray(self, a):
+        return np.array(a, float)
+
     def allreduce(self, sums, dist):
         import torch
         s = torch.from_numpy(np.asarray(sums, float).copy())

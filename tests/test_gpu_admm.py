@@ -92,3 +92,30 @@ def test_shift_rows_on_consensus_state():
     want = np.einsum('ij,bkdj->bkdi', T, z.reshape(4, 2, lay.n_dim, lay.L)).reshape(4, 2, lay.ns)
     assert np.abs(zd.cpu().numpy() - want).max() < 1e-13
     solver.close()
+
+
+def test_full_interconnection_fused_form_on_the_device():
+    """`FullConsensusADMM` (interconnection 'full': one fleet sum per iteration) on the HIP ops -- x-update and centre by the
+    library, the consensus arithmetic on device tensors -- against the numpy backend."""
+    import torch
+    from test_admm_cpu import _full_scenario
+    from admm_numpy_ops import NumpyAdmmOps
+    from omgtools.admm import FullConsensusADMM, HipAdmmOps
+    from omgtools.backend import BatchSolver
+    n = 8
+    tpl, lay, P = _full_scenario(n, 'circular')
+    dev = torch.device('cuda', 0)
+    solver = BatchSolver(tpl, n, options=dict(tol=1e-6, max_iter=200, warm_z_cap=0.0, max_soc=0))
+    gpu = FullConsensusADMM(lay, HipAdmmOps(solver, tpl, lay, P['p'], P['x0'], dev), n, rho=1.0)
+    cpu_ops = NumpyAdmmOps(tpl, lay, P['p'], P['x0'])
+    cpu = FullConsensusADMM(lay, cpu_ops, n, rho=1.0)
+    gpu.initialize()
+    cpu.initialize()
+    for it in range(4):
+        st_g, st_c = gpu.iterate(0.0), cpu.iterate(0.0)
+        assert np.all(st_g.cpu().numpy() == 0) and np.all(st_c == 0)
+        lo = lay.x_spl
+        assert np.abs(gpu.ops.x.cpu().numpy()[:, lo:lo + lay.ns] - cpu_ops.x[:, lo:lo + lay.ns]).max() < 1e-6
+        assert np.abs(gpu.c.cpu().numpy() - cpu.c).max() < 1e-6
+    assert np.allclose(np.array(gpu.residuals), np.array(cpu.residuals), rtol=1e-5, atol=1e-8)
+    solver.close()
