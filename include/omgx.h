@@ -300,6 +300,19 @@ int  omgx_batch_predict_ex(omgx_batch* b, const double* x, double* p, int32_t co
                            int32_t n_out, const int32_t* p_off, int32_t p_t, double t_value, int32_t mode,
                            const double* state_in, int32_t n_sub, double dtau);
 
+/* The same for the Quadrotor's own model (non-ideal prediction, `vehicles/vehicle.py:323-337` with `vehicles/quadrotor.py:
+ * 149-152`: state (x, y, dx, dy, theta), inputs thrust and pitch rate, which the plan holds through its second and third
+ * derivatives, `quadrotor.py:121-140`).  state_in [B, 5] (device): the vehicles' current states; they are integrated over the
+ * n_sub sample intervals of length dtau (spline domain) that end at tau -- classical Runge-Kutta per interval, the inputs
+ * taken linearly between the samples like the reference's interpolated odeint (`vehicle.py:412-423`) -- and written to
+ * state_out [B, 5] (optional, may be state_in).  p[p_off[0] + {0, 1}] <- position of the integrated state (`quadrotor.py:
+ * 110-114`: spl0 = prediction['state'][:2]), p[p_off[o] + k] <- o-th time derivative of the plan at tau for o >= 1 (dspl0,
+ * ddspl0), p[p_t] <- t_value.  g: gravity. */
+int  omgx_batch_predict_quadrotor(omgx_batch* b, const double* x, double* p, int32_t coeff_off, int32_t degree,
+                                  const double* knots, int32_t n_knots, double tau, double inv_T, int32_t n_out,
+                                  const int32_t* p_off, int32_t p_t, double t_value, const double* state_in, double* state_out,
+                                  int32_t n_sub, double dtau, double g);
+
 /* `Vehicle.store` (reference `vehicles/vehicle.py:250-300` -> `splines2signals`, e.g.
  * `vehicles/holonomic.py:116-124`) for the whole batch, device pointers only:
  *   out[b, o, k, i] = d^o/dt^o spline_k(t0[b] + i*dt)   (o < n_der: state, input, dinput ...; time

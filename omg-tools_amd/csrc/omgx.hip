@@ -462,6 +462,69 @@ predict_kernel(const double* __restrict__ x, int n_var, double* __restrict__ p, 
   if (k == 0 && a.p_t >= 0) pb[a.p_t] = a.t_value;
 }
 
+// Non-ideal prediction of the Quadrotor (`vehicles/vehicle.py:323-337` with the model's own `ode`,
+// `vehicles/quadrotor.py:149-152`: state (x, y, dx, dy, theta), inputs (u1, u2) = thrust and pitch rate, which the plan
+// holds as functions of its second and third derivatives, `quadrotor.py:121-140`).  One thread per agent: the inputs at
+// the n_sub + 1 sample points that end at tau, classical Runge-Kutta over the sample intervals with the input taken
+// linearly between the samples (the reference integrates with odeint on a linear interpolation of the sampled inputs,
+// `vehicle.py:412-423`), the position of the integrated state into spl0, the plan's own derivatives at tau into
+// dspl0 / ddspl0 (`quadrotor.py:110-114`: only state[:2] of the prediction enters the parameters).
+__device__ __forceinline__ void quad_inputs(const double* cx, const double* cy, const PredictArgs& a, double u, double g, double* u1, double* u2) {
+  const int j = span_of(a.kn.k, a.degree, a.n_knots, u);
+  const double s2 = a.inv_T * a.inv_T, s3 = s2 * a.inv_T;
+  const double ddx = spline_der_at(cx, a.kn.k, a.degree, j, u, 2) * s2, ddy = spline_der_at(cy, a.kn.k, a.degree, j, u, 2) * s2;
+  const double dddx = spline_der_at(cx, a.kn.k, a.degree, j, u, 3) * s3, dddy = spline_der_at(cy, a.kn.k, a.degree, j, u, 3) * s3;
+  const double n2 = (ddy + g) * (ddy + g) + ddx * ddx;
+  *u1 = sqrt(n2);
+  *u2 = (dddx * (ddy + g) - ddx * dddy) / n2;
+}
+
+__device__ __forceinline__ void quad_ode(const double* s, double u1, double u2, double g, double* k) {
+  k[0] = s[2]; k[1] = s[3]; k[2] = u1 * sin(s[4]); k[3] = u1 * cos(s[4]) - g; k[4] = u2;
+}
+
+__global__ void __launch_bounds__(256)
+predict_quadrotor_kernel(const double* __restrict__ x, int n_var, double* __restrict__ p, int n_par, int B, PredictArgs a,
+                         double g, double* __restrict__ state_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int L = a.n_knots - a.degree - 1;
+  const double* cx = x + (size_t)b * n_var + a.coeff_off;
+  const double* cy = cx + L;
+  double* pb = p + (size_t)b * n_par;
+  const double h = a.dtau / a.inv_T;
+  double s[5];
+  for (int q = 0; q < 5; ++q) s[q] = a.state_in[(size_t)b * 5 + q];
+  double u1a, u2a;
+  quad_inputs(cx, cy, a, a.tau - a.n_sub * a.dtau, g, &u1a, &u2a);
+  for (int i = 0; i < a.n_sub; ++i) {
+    double u1b, u2b, k1[5], k2[5], k3[5], k4[5], st[5];
+    quad_inputs(cx, cy, a, a.tau - (a.n_sub - 1 - i) * a.dtau, g, &u1b, &u2b);
+    const double u1m = 0.5 * (u1a + u1b), u2m = 0.5 * (u2a + u2b);
+    quad_ode(s, u1a, u2a, g, k1);
+    for (int q = 0; q < 5; ++q) st[q] = s[q] + 0.5 * h * k1[q];
+    quad_ode(st, u1m, u2m, g, k2);
+    for (int q = 0; q < 5; ++q) st[q] = s[q] + 0.5 * h * k2[q];
+    quad_ode(st, u1m, u2m, g, k3);
+    for (int q = 0; q < 5; ++q) st[q] = s[q] + h * k3[q];
+    quad_ode(st, u1b, u2b, g, k4);
+    for (int q = 0; q < 5; ++q) s[q] += (h / 6.0) * (k1[q] + 2.0 * k2[q] + 2.0 * k3[q] + k4[q]);
+    u1a = u1b; u2a = u2b;
+  }
+  if (state_out) for (int q = 0; q < 5; ++q) state_out[(size_t)b * 5 + q] = s[q];
+  const int j = span_of(a.kn.k, a.degree, a.n_knots, a.tau);
+  if (a.p_off[0] >= 0) { pb[a.p_off[0]] = s[0]; pb[a.p_off[0] + 1] = s[1]; }
+  double sc = a.inv_T;
+  for (int o = 1; o < a.n_out; ++o) {
+    if (a.p_off[o] >= 0) {
+      pb[a.p_off[o]] = spline_der_at(cx, a.kn.k, a.degree, j, a.tau, o) * sc;
+      pb[a.p_off[o] + 1] = spline_der_at(cy, a.kn.k, a.degree, j, a.tau, o) * sc;
+    }
+    sc *= a.inv_T;
+  }
+  if (a.p_t >= 0) pb[a.p_t] = a.t_value;
+}
+
 __global__ void __launch_bounds__(1024)
 order_kernel(const int32_t* __restrict__ iters, int32_t* __restrict__ order, int B) { order_block(iters, order, B); }
 
@@ -1481,6 +1544,28 @@ int omgx_batch_set_store(omgx_batch* b, const omgx_store_spec* sp) {
   if (!b->d_store) HIPCHK(hipMalloc((void**)&b->d_store, sizeof(StoreArgs)));
   b->store = st;
   HIPCHK(hipMemcpyAsync(b->d_store, &b->store, sizeof(StoreArgs), hipMemcpyHostToDevice, b->stream));
+  return OMGX_OK;
+}
+
+int omgx_batch_predict_quadrotor(omgx_batch* b, const double* x, double* p, int32_t coeff_off, int32_t degree, const double* knots,
+                                 int32_t n_knots, double tau, double inv_T, int32_t n_out, const int32_t* p_off, int32_t p_t,
+                                 double t_value, const double* state_in, double* state_out, int32_t n_sub, double dtau, double g) {
+  if (!b || !x || !p || !knots || !p_off || !state_in || n_knots > 40 || degree > 5 || degree < 3 || n_out < 1 || n_out > 4 ||
+      n_out > degree + 1 || n_sub < 1 || !(dtau > 0.0) || !(g > 0.0)) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  const omgx::Dims& d = b->dims;
+  const int L = n_knots - degree - 1;
+  if (coeff_off < 0 || coeff_off + 2 * L > d.n_var || p_t >= d.n_par) { g_err = "predict: offsets outside x / p"; return OMGX_E_INVALID; }
+  PredictArgs a;
+  for (int o = 0; o < 4; ++o) {
+    a.p_off[o] = o < n_out ? p_off[o] : -1;
+    if (a.p_off[o] >= 0 && a.p_off[o] + 2 > d.n_par) { g_err = "predict: offsets outside p"; return OMGX_E_INVALID; }
+  }
+  HIPCHK(hipSetDevice(b->device));
+  for (int i = 0; i < 40; ++i) a.kn.k[i] = i < n_knots ? knots[i] : 0.0;
+  a.coeff_off = coeff_off; a.n_spl = 2; a.degree = degree; a.n_knots = n_knots; a.n_out = n_out;
+  a.tau = tau; a.inv_T = inv_T; a.p_t = p_t; a.t_value = t_value; a.mode = OMGX_PREDICT_RK4; a.state_in = state_in; a.n_sub = n_sub; a.dtau = dtau;
+  hipLaunchKernelGGL(predict_quadrotor_kernel, dim3((b->n_agents + 255) / 256), dim3(256), 0, b->stream, x, d.n_var, p, d.n_par, b->n_agents, a, g, state_out);
+  HIPCHK(hipGetLastError());
   return OMGX_OK;
 }
 

@@ -167,7 +167,7 @@ struct Opts {
 #define OMGX_KAPPA_MU    0.2
 #define OMGX_THETA_MU    1.5
 #define OMGX_TAU_MIN     0.99
-#define OMGX_DELTA_C     1e-8
+#define OMGX_DELTA_C     1e-8    // regularisation of the equality block: delta_c = OMGX_DELTA_C * mu^(1/4) (IPOPT's delta_c_bar mu^kappa_c)
 #define OMGX_ETA         1e-4
 #define OMGX_PHI_NOISE   1e-10   // predicted merit decrease (relative) below which the Armijo test is skipped
 #define OMGX_DW_FIRST    1e-4
@@ -2287,6 +2287,11 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
     if (c.tid() == 0) { c.prof[PH_RESID] += c.prof[PH_LA] + c.prof[PH_LS] + c.prof[PH_LB] - resid_seen_; resid_seen_ = c.prof[PH_LA] + c.prof[PH_LS] + c.prof[PH_LB]; }
 #endif
+    // The equality block of the quasi-definite system carries -delta_c I.  A step leaves delta_c |y| of equality residual
+    // behind, so a fixed 1e-8 is a floor under the feasibility a solve can reach: with multipliers of ~100 (an ADMM
+    // x-update whose consensus weight is large) 1.3e-6, and a solve at 1e-6 never ends.  Like IPOPT the regularisation
+    // follows the barrier parameter: 1e-8 mu^(1/4) (1.8e-10 at mu = 1e-7).
+    const double delta_c = c.uni(OMGX_DELTA_C * sqrt(sqrt(mu)));
     // ---- assemble + factorise with inertia correction --------------------------------
     // Tracking of the inertia correction dw.  When the previous iteration needed dw > 0 the
     // (doomed) dw = 0 attempt is skipped.  A decrease dw_last/3 is attempted only every
@@ -2364,7 +2369,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         const int r = T.eq_rows[k];
         double* Rr = K.R();
         if (use_t && w.rtype[r] == ROW_EQ) Rr[tri(d.n_root + k, d.n_root - 1)] = -w.vv[r];
-        Rr[tri(d.n_root + k, d.n_root + k)] = -OMGX_DELTA_C;
+        Rr[tri(d.n_root + k, d.n_root + k)] = -delta_c;
       }
       c.sync();
       OMGX_TOC(PH_A_TCOL);
@@ -2564,7 +2569,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     // regularised system puts delta_c * |y| ~ 1e-8 of residual back: the penalty term then GROWS by nuE * 4e-8 per unit step
     // against a predicted decrease of 1e-11, every trial is an ascent step and the solve ends in Numerical_Failure (seen on
     // the quartic free-end-time problem and on 1e-6 formation x-updates).
-    const double floorE = c.uni(OMGX_DELTA_C * ysum);
+    const double floorE = c.uni(delta_c * ysum);
     const double phi0 = c.uni(f + nu * t - mu * lns - (use_t ? mu * log(t) : 0.0) + nuE * fmax(0.0, rE_sum - floorE));
     const double dphi = c.uni(gdx - nuE * fmax(0.0, rE_sum - floorE));
 

@@ -233,6 +233,9 @@ def load_library(path=None):
     lib.omgx_batch_predict_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_void_p,
                                           C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_int32, C.c_double]
+    lib.omgx_batch_predict_quadrotor.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                                 C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_void_p,
+                                                 C.c_void_p, C.c_int32, C.c_double, C.c_double]
     lib.omgx_batch_store.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CStoreSpec)]
     lib.omgx_batch_set_store.argtypes = [C.c_void_p, C.POINTER(CStoreSpec)]
     if path == LIB_PATH:
@@ -447,6 +450,19 @@ class BatchSolver(object):
             self._h, ptr(x), ptr(p), int(coeff_off), int(n_spl), int(degree), knots.ctypes.data, len(knots),
             float(tau), float(inv_T), len(off), off.ctypes.data, int(p_t), float(t_value), int(mode), ptr(state_in),
             int(n_sub), float(dtau)), 'omgx_batch_predict_ex')
+
+    def predict_quadrotor(self, x, p, coeff_off, degree, knots, tau, inv_T, p_off, p_t, t_value, state_in, state_out, n_sub, dtau, g=9.81):
+        """Non-ideal prediction of the Quadrotor model: state_in [B, 5] integrated over the n_sub sample intervals that end at tau
+        with the inputs the plan holds there (include/omgx.h omgx_batch_predict_quadrotor).  Device tensors / pointers."""
+        knots = np.ascontiguousarray(knots, dtype=np.float64)
+        off = np.ascontiguousarray(p_off, dtype=np.int32)
+
+        def ptr(a):
+            return None if a is None else (a.data_ptr() if hasattr(a, 'data_ptr') else int(a))
+        _check(self.lib, self.lib.omgx_batch_predict_quadrotor(
+            self._h, ptr(x), ptr(p), int(coeff_off), int(degree), knots.ctypes.data, len(knots), float(tau), float(inv_T), len(off),
+            off.ctypes.data, int(p_t), float(t_value), ptr(state_in), ptr(state_out), int(n_sub), float(dtau), float(g)),
+            'omgx_batch_predict_quadrotor')
 
     def _store_spec(self, out, v_tot, t0, coeff_off, n_spl, degree, knots, n_der, n_samp, dt, inv_T):
         knots = np.ascontiguousarray(knots, dtype=np.float64)

@@ -392,6 +392,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         if status == 2:
             break
         gf[n] = nu
+        delta_c = o['delta_c'] * mu ** 0.25          # (omgx_core.h: the equality block's regularisation follows the barrier parameter)
         lam = np.zeros(nlp.n_con)
         lam[iH] = sig * z
         lam[iE] = y
@@ -433,7 +434,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             K[:N, :N] = M + np.diag(shift(dw_vec))
             K[N:, :N] = Je
             K[:N, N:] = Je.T
-            K[N:, N:] = -o['delta_c'] * np.eye(mE)
+            K[N:, N:] = -delta_c * np.eye(mE)
             L, d = ldl_nopivot(K)
             return K, L, d, bool(np.all(d[:N] > 0) and np.all(d[N:] < 0))
         while True:
@@ -495,7 +496,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         sol = ldl_solve(L, d, rhs)
         for _ in range(o.get('n_refine', 0)):
             res_ = rhs - K @ sol
-            res_[N:] -= o['delta_c'] * sol[N:]
+            res_[N:] -= delta_c * sol[N:]
             sol += ldl_solve(L, d, res_)
         dxt, y_new = sol[:N], sol[N:]
         if not use_t:
@@ -516,7 +517,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         nuE = 2.0 * max(1.0, np.abs(y_new).max() if mE else 0.0)
         # (quasi-definite system: the linearised equality residual after the full step is delta_c * y_new; the merit
         # function counts the equality residual only above that floor -- omgx_core.h)
-        floorE = o['delta_c'] * (np.abs(y_new).sum() if mE else 0.0)
+        floorE = delta_c * (np.abs(y_new).sum() if mE else 0.0)
         phi0 = f + nu * t - mu * np.log(s).sum() - (mu * np.log(t) if use_t else 0.0) + nuE * max(0.0, thE - floorE)
         dphi = g_bar @ dxt - nuE * max(0.0, thE - floorE)
         # a step of the regularised system may be offered longer (omgx_core.h: the crawl of the proximal iteration)

@@ -301,3 +301,77 @@ def test_launch_statistics_match_the_per_agent_outputs():
     mpc.step()
     assert np.array_equal(stats.cpu().numpy(), got)
     mpc.solver.close()
+
+
+def test_quadrotor_ode_prediction_matches_the_reference_statements():
+    """Non-ideal prediction of the Quadrotor model on the device (`omgx_batch_predict_quadrotor`) against the reference's
+    statements replayed in numpy / scipy: inputs from the plan's sampled derivatives (`vehicles/quadrotor.py:121-140`),
+    `integrate_ode` = odeint on their linear interpolation (`vehicles/vehicle.py:412-423`) with the model's ode
+    (`quadrotor.py:149-152`), spl0 from the integrated state, dspl0 / ddspl0 from the plan (`quadrotor.py:110-114`)."""
+    import torch
+    from scipy.integrate import odeint
+    from scipy.interpolate import interp1d
+    from omgtools import workloads
+    from omgtools.backend import BatchSolver
+    B = 6
+    problem, P = workloads.quadrotor_p2p(B)
+    tpl = problem.father.template
+    veh = problem.vehicles[0]
+    basis, T, g = veh.basis, float(problem.options['horizon_time']), 9.81
+    L = len(basis)
+    o_spl = tpl.entry_range(veh.label, 'splines_seg0', 'var')[0]
+    rng = np.random.default_rng(5)
+    x = P['x0'].copy()
+    x[:, o_spl:o_spl + 2 * L] += 0.05 * rng.normal(size=(B, 2 * L))         # a plan with some curvature
+    dev = torch.device('cuda', 0)
+    solver = BatchSolver(tpl, B)
+    f64 = dict(dtype=torch.float64, device=dev)
+    xd, pd = torch.as_tensor(x, **f64), torch.as_tensor(P['p'].copy(), **f64)
+    p_offs = [tpl.entry_range(veh.label, nm, 'par')[0] for nm in ('spl0', 'dspl0', 'ddspl0')]
+    o_t = tpl.entry_range(problem.label, 't', 'par')[0]
+    sample_time, update_time, t0 = 0.01, 0.1, 0.2
+    n_sub = int(round(update_time / sample_time))
+    tau = (t0 + update_time) / T
+    state0 = np.zeros((B, 5))
+    state_in = torch.as_tensor(state0, **f64)
+    state_out = torch.zeros((B, 5), **f64)
+    # the vehicles' current states: on the plan at t0 (position, velocity, pitch) plus a small disturbance
+    der = [basis.eval_basis([t0 / T])[0]]
+    for o in (1, 2, 3):
+        db, Po = basis.derivative(o)
+        der.append(db.eval_basis([t0 / T])[0] @ Po / T ** o)
+    c = x[:, o_spl:o_spl + 2 * L].reshape(B, 2, L)
+    pos, vel, acc = c @ der[0], c @ der[1], c @ der[2]
+    state0 = np.c_[pos, vel, np.arctan2(acc[:, 0], acc[:, 1] + g)] + 1e-3 * rng.normal(size=(B, 5))
+    state_in.copy_(torch.as_tensor(state0, **f64))
+    try:
+        solver.predict_quadrotor(xd, pd, o_spl, basis.degree, basis.knots, tau, 1.0 / T, p_offs, o_t, 0.3, state_in, state_out, n_sub,
+                                 sample_time / T, g)
+        torch.cuda.synchronize()
+    finally:
+        got_p, got_s = pd.cpu().numpy(), state_out.cpu().numpy()
+        solver.close()
+    times = t0 + sample_time * np.arange(n_sub + 1)
+    rows = []
+    for o in (0, 1, 2, 3):
+        if o == 0:
+            rows.append(basis.eval_basis(times / T))
+        else:
+            db, Po = basis.derivative(o)
+            rows.append(db.eval_basis(times / T) @ Po / T ** o)
+    for b in range(B):
+        cx, cy = c[b]
+        ddx, ddy, dddx, dddy = rows[2] @ cx, rows[2] @ cy, rows[3] @ cx, rows[3] @ cy
+        u1 = np.sqrt(ddx ** 2 + (ddy + g) ** 2)
+        u2 = (dddx * (ddy + g) - ddx * dddy) / ((ddy + g) ** 2 + ddx ** 2)
+        inp = interp1d(times - t0, np.c_[u1, u2].T, kind='linear', bounds_error=False, fill_value=np.r_[u1[-1], u2[-1]])
+
+        def ode(s, t):
+            u = inp(t)
+            return np.r_[s[2:4], u[0] * np.sin(s[4]), u[0] * np.cos(s[4]) - g, u[1]]
+        ref = odeint(ode, state0[b], times - t0, rtol=1e-12, atol=1e-12)[-1]
+        assert np.abs(got_s[b] - ref).max() < 1e-7, (b, np.abs(got_s[b] - ref).max())
+        assert np.abs(got_p[b, p_offs[0]:p_offs[0] + 2] - ref[:2]).max() < 1e-7
+        assert np.abs(got_p[b, p_offs[1]:p_offs[1] + 2] - np.r_[rows[1][-1] @ cx, rows[1][-1] @ cy]).max() < 1e-9
+        assert np.abs(got_p[b, p_offs[2]:p_offs[2] + 2] - np.r_[rows[2][-1] @ cx, rows[2][-1] @ cy]).max() < 1e-8
+        assert got_p[b, o_t] == 0.3
