@@ -227,6 +227,38 @@ class FormationPoint2point(object):
         from .backend import options_from_problem
         return 1e-3 * options_from_problem(self.options).get('tol', 1e-3)
 
+    device_predictions = 0
+
+    def _device_prediction(self, current_time, update_time, crossing):
+        """Whether this update's initial conditions can be predicted on the device: every vehicle predicts ideally, the update
+        moves the clock forward (not a start-up iteration), and no vehicle was handed another state or target since the last
+        update (option 'device_prediction': True by default, False = always pack on the host)."""
+        if not self.options.get('device_prediction', True) or not hasattr(self.ops, 'predict'):
+            return False
+        if not (current_time > self._time_prev + 1e-9) or self.iteration < self.options['init_iter']:
+            return False
+        if not all(v.options.get('ideal_prediction', False) for v in self.vehicles):
+            return False
+        if not hasattr(self, '_shared_cols'):
+            tpl, lay = self.tpl, self.lay
+            per_agent = np.zeros(tpl.n_par, dtype=bool)
+            per_agent[self.host_cols] = True
+            own = np.zeros(tpl.n_par, dtype=bool)
+            veh = self.vehicles[0]
+            for (label, name), (off, r, c) in tpl.par_layout.items():
+                if label == veh.label or (label, name) == (self.subs[0][1].label, 'rho'):
+                    own[off:off + r * c] = True                      # a vehicle's own entries (state0, input0, poseT, rel_pos_c) and rho
+            own[lay.p_t] = True
+            self._shared_cols = np.nonzero(per_agent & ~own)[0]
+            self._o_plan = tpl.entry_range(veh.label, 'splines_seg0', 'var')[0]
+            self._targets = None
+        # a new target (`set_terminal_conditions`) or a state handed in from outside: back to the host for this update
+        targets = np.array([np.asarray(v.poseT, float) for v in self.vehicles])
+        if self._targets is None or targets.shape != self._targets.shape or not np.array_equal(targets, self._targets):
+            self._targets = targets
+            return False
+        return True
+
     def _host_parameters(self, current_time):
         return np.stack([father.set_parameters(current_time).cat for _, _, father in self.subs])
 
@@ -258,11 +290,28 @@ class FormationPoint2point(object):
         import time
         t0 = time.time()
         # knot crossing: shift the warm start of x and the whole consensus state (`admm.py:477-491`)
-        if int(np.round(self._time_prev / self.knot_time, 6)) < int(np.round(current_time / self.knot_time, 6)):
-            self.ops.shift(self._shift_x, self._shift_p, self._shift_side)
-        self._time_prev = current_time
-        self.ops.upload_params(self._host_parameters(current_time), self.host_cols)
+        crossing = int(np.round(self._time_prev / self.knot_time, 6)) < int(np.round(current_time / self.knot_time, 6))
         t_rel = float(np.round(current_time, 6) % self.knot_time)
+        if self._device_prediction(current_time, update_time, crossing):
+            # Nobody disturbs the vehicles (`ideal_prediction`, `vehicles/vehicle.py:323-326`): the initial conditions of this
+            # update are the current plan `update_time` ahead -- one launch on the resident plan (`FormationMPC.step`) instead
+            # of packing every vehicle's parameter vector on the host.  What the fleet shares (obstacle motion, T) comes from
+            # ONE sub-problem's parameters and is written to all rows; rel_pos_c, poseT and rho do not change between updates.
+            rel_prev = np.round(self._time_prev, 6) % self.knot_time
+            tau = (rel_prev + (current_time - self._time_prev)) / float(self.options['horizon_time'])
+            veh = self.vehicles[0]
+            self.ops.predict(self._o_plan, veh.n_spl, veh.basis, tau, 1.0 / float(self.options['horizon_time']),
+                             [self.lay.p_state0, self.lay.p_input0], self.lay.p_t, t_rel)
+            row = self.subs[0][2].set_parameters(current_time).cat
+            self.ops.upload_params(np.tile(np.asarray(row, float)[None], (len(self.subs), 1)), self._shared_cols)
+            if crossing:
+                self.ops.shift(self._shift_x, self._shift_p, self._shift_side)
+            self.device_predictions += 1
+        else:
+            if crossing:
+                self.ops.shift(self._shift_x, self._shift_p, self._shift_side)
+            self.ops.upload_params(self._host_parameters(current_time), self.host_cols)
+        self._time_prev = current_time
         status, (pr, dr, cr) = self.admm.iterate(t_rel)
         x = self.ops.download_x()
         for l, (_, _, father) in enumerate(self.subs):

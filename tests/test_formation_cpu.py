@@ -5,10 +5,10 @@ the same script on the product path, tests/test_gpu_formation.py)."""
 import numpy as np
 
 
-def formation_example(ops, n=4, verbose=0, extra={}):
+def formation_example(ops, n=4, verbose=0, extra={}, vehicle_options=None):
     from omgtools import (Holonomic, Fleet, Environment, Obstacle, RegularPolyhedron, Rectangle, Circle, Square,
                           FormationPoint2point, Simulator)
-    vehicles = [Holonomic() for _ in range(n)]
+    vehicles = [Holonomic(options=vehicle_options) for _ in range(n)]
     fleet = Fleet(vehicles)
     configuration = RegularPolyhedron(0.2, n, np.pi / 4.).vertices.T
     init_positions = [-1.5, -1.5] + configuration
@@ -58,3 +58,38 @@ def test_formation_tight_with_larger_rho():
     from admm_numpy_ops import NumpyAdmmOps
     out = formation_example(lambda tpl, lay, p, x0, tol: NumpyAdmmOps(tpl, lay, p, x0, tol=tol), extra={'rho': 5.})
     check_formation_run(*out, max_dev=0.1, mean_dev=0.01)
+
+
+def test_device_side_prediction_equals_host_packing():
+    """`FormationPoint2point` under `Simulator` with ideal prediction: the initial conditions of an update are predicted from
+    the resident plan (one launch; the drop-in then packs ONE sub-problem's parameters instead of every vehicle's).  At every
+    update the parameter block the device path leaves is the one the host packing would upload (`problems/admm.py:477-491`,
+    `vehicles/vehicle.py:323-326`) -- through the knot crossings and the push of the moving obstacle."""
+    import omgtools.admm as A
+    import omgtools.formation as F
+    from admm_numpy_ops import NumpyAdmmOps
+    seen = dict(worst=0.0, n=0, problem=None, time=None)
+    orig_iter, orig_du = A.BatchADMM.iterate, F.FormationPoint2point.dual_update
+
+    def iterate(self, t_rel, sync=True):
+        pr = seen['problem']
+        if pr is not None and pr.device_predictions > seen['n']:          # this update was predicted on the device
+            seen['n'] = pr.device_predictions
+            P = pr._host_parameters(seen['time'])
+            rho_col = pr.lay.p_rho                                          # (set by the iteration itself)
+            cols = pr.host_cols[pr.host_cols != rho_col]
+            seen['worst'] = max(seen['worst'], float(np.abs(P[:, cols] - self.ops.p[:, cols]).max()))
+        return orig_iter(self, t_rel, sync)
+
+    def dual_update(self, current_time, update_time):
+        seen['problem'], seen['time'] = self, current_time
+        return orig_du(self, current_time, update_time)
+    A.BatchADMM.iterate, F.FormationPoint2point.dual_update = iterate, dual_update
+    try:
+        problem, vehicles, _, _ = formation_example(lambda tpl, lay, p, x0, tol: NumpyAdmmOps(tpl, lay, p, x0, tol=tol),
+                                                    extra={'max_iter': 60}, vehicle_options={'ideal_prediction': True})
+    finally:
+        A.BatchADMM.iterate, F.FormationPoint2point.dual_update = orig_iter, orig_du
+    assert problem.device_predictions >= 50 and seen['n'] == problem.device_predictions
+    assert seen['worst'] < 1e-9, seen['worst']
+    assert vehicles[0].signals['time'][0, -1] > 5.0                         # past the crossings at 1 s ... 5 s and the push at 3 s

@@ -15,12 +15,14 @@ are unobtainable here; the stand-ins:
   Quadrotor class (sol_cfg3_ms.npz, same generator): 8 agents, 9 starting points each, 2-4 distinct minima per agent;
   same criteria -- 8 of 8 agents land in a stored minimum, coefficients to 1e-4.
 
-  Holonomic3D class (sol_cfg5_ms.npz): 8 agents, 25 starting points each (ten spheres in 3-D: many ways round), 1-4
-  distinct minima per agent.  6 of 8 agents land in a stored minimum (coefficients to 3e-5); the other two end in
-  local minima that none of the 25 SLSQP starts visits -- one 0.9 % above the best stored minimum, one 19 % above it (a
-  longer way round an obstacle; every SLSQP start finds the shorter one): KKT points of the reference's NLP, not the best
-  ones.  For this class a point outside the stored set is accepted when it is not worse than the best stored minimum
-  by more than 0.25 (1 + |f|), and at least 70 % of the agents must be inside.
+  Holonomic3D class (sol_cfg5_ms.npz): 8 agents, 25 starting points each + (round 4) twelve more bent along BOTH
+  perpendiculars of start -> goal (ten spheres in 3-D: the ways round are not only left and right), 1-6 distinct minima per
+  agent.  7 of 8 agents land in a stored minimum (coefficients to 3e-5).  Agent 5 ends in a local minimum 19 % above the
+  only minimum SLSQP finds for it from 137 starts (the 37 of the fixture and a 10 x 10 grid of bends up to 4 m: a longer way
+  round an obstacle): the interior-point iteration leaves the straight-line guess on the other side.  A point outside the
+  stored set is accepted only if the independent solver CONFIRMS it as a local minimum -- SLSQP started at the returned
+  point stays there (objective 1e-5, coefficients 1e-3) -- and it is not worse than the best stored minimum by more than
+  0.25 (1 + |f|); at least 85 % of the agents must be inside the stored set.
 
 CPU tier: host build of the kernel source (same-source check of the host logic); GPU tier: the HIP path
 through the C ABI."""
@@ -31,7 +33,7 @@ import pytest
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 CASES = [('sol_cfg2_ms.npz', 'holonomic_p2p', 64, 0.95), ('sol_cfg3_ms.npz', 'quadrotor_p2p', 8, 0.9),
-         ('sol_cfg5_ms.npz', 'holonomic3d_p2p', 8, 0.7)]
+         ('sol_cfg5_ms.npz', 'holonomic3d_p2p', 8, 0.85)]
 ESCAPE = {'sol_cfg5_ms.npz': 0.25}          # how much worse than the best stored minimum a point outside the set may be
 TOL = 1e-6
 
@@ -74,6 +76,12 @@ def check_case(fixture, scenario, n, min_match, solve):
             else:
                 best = np.nanmin(d['f_min'][b])
                 assert f < best + ESCAPE.get(fixture, 1e-3) * (1 + abs(best)), (fixture, b, f, best)
+                if fixture in ESCAPE:
+                    # a minimum the multi-start did not visit: the independent solver has to confirm it as one
+                    from slsqp_reference import solve_slsqp
+                    xs, fs, ok = solve_slsqp(nlp, tpl, res['x'][b], P['p'][b], maxiter=1500, accept=(0, 8), viol_tol=1e-7)
+                    assert ok and abs(fs - f) < 1e-5 * (1 + abs(f)), (fixture, b, f, fs)
+                    assert np.abs(xs[lo:hi] - res['x'][b, lo:hi]).max() < 1e-3, (fixture, b)
         assert matched >= min_match * n, (fixture, matched, n)
         assert tight >= 0.85 * matched, (fixture, tight, matched)
         return matched, n

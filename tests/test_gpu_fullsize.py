@@ -117,7 +117,7 @@ def test_config2_full_batch_receding_horizon_properties():
     assert gain.min() > 0.1 and gain.mean() > 0.4               # 1.2 s from rest at amax 1, vmax 0.5 (detours included)
 
 
-@pytest.mark.parametrize('name,B,min_ok,n_check', [('quadrotor_p2p', 4096, 0.93, 48), ('holonomic3d_p2p', 8192, 0.99, 24)])
+@pytest.mark.parametrize('name,B,min_ok,n_check', [('quadrotor_p2p', 4096, 0.93, 48), ('holonomic3d_p2p', 8192, 0.999, 24)])
 def test_config3_and_5_full_batch(name, B, min_ok, n_check):
     from omgtools import scenarios
     from omgtools.backend import BatchSolver
@@ -140,3 +140,27 @@ def test_config3_and_5_full_batch(name, B, min_ok, n_check):
     assert np.array_equal(res_p['status'], res['status'][perm]) and np.array_equal(res_p['iters'], res['iters'][perm])
     assert np.array_equal(res_p['x'], res['x'][perm])
     solver.close()
+
+
+@pytest.mark.parametrize('name,B', [('quadrotor_p2p', 4096), ('holonomic3d_p2p', 8192)])
+def test_config3_and_5_cold_solve_with_restarts_converges_every_agent(name, B):
+    """What bench.py reports as "100 %" for these classes is `BatchP2P.solve_cold`: the cold solve from the reference's
+    straight-line guess with the restart guesses handed to the same launch (`omgx_batch_set_restarts`: an agent whose phase I
+    stalls is solved again from the guess bent to another side of the obstacles).  At BASELINE.json's batch sizes at least
+    99.9 % of the agents must end in `Solve_Succeeded`, and a sample of them -- restarted agents included -- must satisfy the
+    optimality conditions of the reference's NLP."""
+    import torch
+    from omgtools import workloads
+    from omgtools.batch import BatchP2P
+    problem, P = getattr(workloads, name)(B)
+    tpl = problem.father.template
+    mpc = BatchP2P(problem, P, ops='hip', device=torch.device('cuda', 0), options=dict(P.get('solver_options', {}), tol=TOL, max_iter=300))
+    restarts = mpc.solve_cold()
+    st = mpc.host('status')
+    assert (st == 0).mean() >= 0.999, ((st == 0).mean(), np.bincount(st))
+    res = {'x': mpc.host('x'), 'lam_g': mpc.host('lam'), 'status': st}
+    rng = np.random.default_rng(11)
+    ok = np.nonzero(st == 0)[0]
+    check_optimality(tpl, P, res, rng.choice(ok, size=16, replace=False))
+    if name == 'quadrotor_p2p':
+        assert restarts >= 1                       # (this class needs them: ~5 % of the agents stall from the first guess)
