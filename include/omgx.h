@@ -197,8 +197,9 @@ int  omgx_batch_set_stream(omgx_batch* b, void* hip_stream);
  * most iterations in the previous receding-horizon step) can start them first. */
 int  omgx_batch_set_order(omgx_batch* b, const int32_t* order_device);
 /* Fill order_device [n_agents] from the iteration counts of the previous solve (iters_device, as
- * written by omgx_batch_solve), largest first, on the handle's stream, and install it as the
- * launch order (the receding-horizon loop calls this before every warm-started solve).  The work is
+ * written by omgx_batch_solve), largest first (counts above 15 form one class; within a class the agents that carry the
+ * heavier inertia correction from their previous solve come first: they are the slow ones), on the handle's stream, and
+ * install it as the launch order (the receding-horizon loop calls this before every warm-started solve).  The work is
  * deferred to the next launch of the handle: an omgx_batch_predict(_ex) launch carries it as one more
  * workgroup, otherwise the next omgx_batch_solve or omgx_batch_sync runs it first -- iters_device must stay as it
  * is until then. */

@@ -409,29 +409,32 @@ __device__ __forceinline__ int span_of(const double* kk, int degree, int n_knots
 // Launch order for the next solve: agents bucketed by the iteration count of their previous solve,
 // largest first (64 buckets, counting sort in LDS by one workgroup; the order inside a bucket is
 // arbitrary).  Replaces a device-wide sort: this is ~10 us.
-__device__ __forceinline__ void order_block(const int32_t* __restrict__ iters, int32_t* __restrict__ order, int B) {
+// Round 4: among the agents with the same previous count (most have 1) those that carry a heavy inertia correction go
+// first -- a large dw is the signature of the slow ones (multipliers of 5-20 on bilinear rows: the regularised Newton
+// iteration converges linearly).  On the host model of the step (512 slots, greedy queue) the total time of 20 headline
+// steps drops by 4 % against the count alone; the perfect order would gain 6.6 %.
+__device__ __forceinline__ int order_bucket(int it, double dw) {
+  const int a = it < 0 ? 0 : (it > 15 ? 15 : it);
+  const int q = dw > 10.0 ? 3 : (dw > 1.0 ? 2 : (dw > 0.1 ? 1 : 0));
+  return 63 - (4 * a + q);
+}
+__device__ __forceinline__ void order_block(const int32_t* __restrict__ iters, const double* __restrict__ dw, int32_t* __restrict__ order, int B) {
   __shared__ int cnt[64], off[64];
   if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    const int it = iters[b];
-    atomicAdd(&cnt[63 - (it < 0 ? 0 : (it > 63 ? 63 : it))], 1);
-  }
+  for (int b = threadIdx.x; b < B; b += blockDim.x) atomicAdd(&cnt[order_bucket(iters[b], dw ? dw[b] : 0.0)], 1);
   __syncthreads();
   if (threadIdx.x == 0) { int a = 0; for (int k = 0; k < 64; ++k) { off[k] = a; a += cnt[k]; } }
   __syncthreads();
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    const int it = iters[b];
-    order[atomicAdd(&off[63 - (it < 0 ? 0 : (it > 63 ? 63 : it))], 1)] = b;
-  }
+  for (int b = threadIdx.x; b < B; b += blockDim.x) order[atomicAdd(&off[order_bucket(iters[b], dw ? dw[b] : 0.0)], 1)] = b;
 }
 
 // (ord_iters != nullptr: the launch carries one more workgroup, which computes the launch order of the next solve --
 // the receding-horizon step then has one launch less in front of its solve kernel)
 __global__ void __launch_bounds__(256)
 predict_kernel(const double* __restrict__ x, int n_var, double* __restrict__ p, int n_par, int B, PredictArgs a,
-               const int32_t* __restrict__ ord_iters, int32_t* __restrict__ ord_out) {
-  if (ord_iters && blockIdx.x == gridDim.x - 1) { order_block(ord_iters, ord_out, B); return; }
+               const int32_t* __restrict__ ord_iters, int32_t* __restrict__ ord_out, const double* __restrict__ ord_dw) {
+  if (ord_iters && blockIdx.x == gridDim.x - 1) { order_block(ord_iters, ord_dw, ord_out, B); return; }
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= B * a.n_spl) return;
   const int b = id / a.n_spl, k = id - b * a.n_spl;
@@ -526,7 +529,7 @@ predict_quadrotor_kernel(const double* __restrict__ x, int n_var, double* __rest
 }
 
 __global__ void __launch_bounds__(1024)
-order_kernel(const int32_t* __restrict__ iters, int32_t* __restrict__ order, int B) { order_block(iters, order, B); }
+order_kernel(const int32_t* __restrict__ iters, const double* __restrict__ dw, int32_t* __restrict__ order, int B) { order_block(iters, dw, order, B); }
 
 __global__ void __launch_bounds__(64)
 shift_kernel(double* __restrict__ x, int x_stride, const uint8_t* __restrict__ mask,
@@ -696,6 +699,7 @@ struct omgx_batch {
   size_t slab_doubles = 0;
   double* d_slabs = nullptr;
   double* d_dw = nullptr;          // per-agent inertia correction carried between warm-started solves
+  int order_dw = 1;                // omgx_batch_order_by_iters: ties of the iteration count broken by the carried inertia correction (OMGX_ORDER_DW=0: developer switch)
   const int32_t* d_order = nullptr; // optional launch order (device pointer owned by the caller)
   const int32_t* pend_iters = nullptr; int32_t* pend_order = nullptr;   // omgx_batch_order_by_iters not launched yet
   int* d_next = nullptr;            // spill modes: counter of the dynamic slot hand-out
@@ -851,6 +855,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   if (b->per_cu >= 2) { b->prio_iter = 2; b->stagger = 0; }
   if (const char* e = getenv("OMGX_PRIO_ITER")) b->prio_iter = atoi(e);      // (developer knobs)
   if (const char* e = getenv("OMGX_STAGGER")) b->stagger = atoi(e);
+  if (const char* e = getenv("OMGX_ORDER_DW")) b->order_dw = atoi(e);
   const omgx::Tables& H = plan.tables;
   const omgx::Dims& d = plan.dims;
   {
@@ -1188,7 +1193,7 @@ int omgx_batch_set_stream(omgx_batch* b, void* s) {
 
 static int flush_order(omgx_batch* b) {
   if (!b->pend_iters) return OMGX_OK;
-  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, b->stream, b->pend_iters, b->pend_order, b->n_agents);
+  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, b->stream, b->pend_iters, (const double*)(b->order_dw ? b->d_dw : nullptr), b->pend_order, b->n_agents);
   b->pend_iters = nullptr; b->pend_order = nullptr;
   HIPCHK(hipGetLastError());
   return OMGX_OK;
@@ -1593,7 +1598,7 @@ int omgx_batch_predict_ex(omgx_batch* b, const double* x, double* p, int32_t coe
   const int n = b->n_agents * n_spl;
   const int32_t* oi = b->pend_iters; int32_t* oo = b->pend_order;
   b->pend_iters = nullptr; b->pend_order = nullptr;
-  hipLaunchKernelGGL(predict_kernel, dim3((n + 255) / 256 + (oi ? 1 : 0)), dim3(256), 0, b->stream, x, d.n_var, p, d.n_par, b->n_agents, a, oi, oo);
+  hipLaunchKernelGGL(predict_kernel, dim3((n + 255) / 256 + (oi ? 1 : 0)), dim3(256), 0, b->stream, x, d.n_var, p, d.n_par, b->n_agents, a, oi, oo, (const double*)(b->order_dw ? b->d_dw : nullptr));
   HIPCHK(hipGetLastError());
   return OMGX_OK;
 }

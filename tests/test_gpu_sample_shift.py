@@ -143,8 +143,9 @@ def test_predict_matches_basis_evaluation(cfg2_small):
 
 
 def test_order_by_iters_is_a_bucketed_permutation(cfg2_small):
-    """`omgx_batch_order_by_iters`: a permutation of the agents, iteration counts (clamped to 63)
-    non-increasing along it; installing it as the launch order does not change any result."""
+    """`omgx_batch_order_by_iters`: a permutation of the agents, iteration counts (clamped to 15: sixteen classes, each split
+    four ways by the inertia correction the agent carries -- none here: a fresh handle) non-increasing along it; installing it
+    as the launch order does not change any result."""
     import torch
     from omgtools.backend import BatchSolver
     problem, P = cfg2_small
@@ -155,11 +156,11 @@ def test_order_by_iters_is_a_bucketed_permutation(cfg2_small):
     dev = torch.device('cuda', 0)
     solver.set_stream(torch.cuda.current_stream().cuda_stream)
     rng = np.random.default_rng(3)
-    iters = torch.as_tensor(rng.integers(0, 120, size=B).astype(np.int32), device=dev)
+    iters = torch.as_tensor(rng.integers(0, 40, size=B).astype(np.int32), device=dev)
     order = torch.zeros(B, dtype=torch.int32, device=dev)
     solver.order_by_iters(iters, order)
     solver.sync()
-    o = order.cpu().numpy(); it = np.minimum(iters.cpu().numpy(), 63)
+    o = order.cpu().numpy(); it = np.minimum(iters.cpu().numpy(), 15)
     assert sorted(o.tolist()) == list(range(B))
     assert np.all(np.diff(it[o]) <= 0)
     res = solver.solve(p, x0)                       # launched in that order
