@@ -370,4 +370,4 @@ if __name__ == '__main__':
     if 'mpc3' in which:
         run_mpc_class(4, 6, workers, 'quadrotor_p2p', 'sol_mpc_cfg3.npz')
     if 'admm' in which:
-        run_formation(4, 12, workers)
+        run_formation(6, 12, workers)

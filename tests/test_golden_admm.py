@@ -128,3 +128,71 @@ def test_lambda_update_and_residuals_equal_the_reference(fix, updx):
         pr = np.sum((fw(x_i, x_j) - fw(z_i, z_ij)) ** 2)
         dr = rho * np.sum((fw(z_i, z_ij) - fw(z_i_p, z_ij_p)) ** 2)
         assert np.abs(np.array([pr, dr, rho * pr + dr]) - vout).max() < 1e-9 * (1 + np.abs(vout).max())
+
+
+# ---- round 4: a sequence of x-updates against an independent solver ------------------------------------------------------
+def _check_xupdates(solve_step, f_tol=1e-5, x_tol=1e-3, tight_tol=3e-4, tight_share=0.9):
+    """tests/golden/sol_admm_xupdate.npz (generator tests/golden/generate_multistart.py `run_formation`): twelve updates of a
+    six-vehicle formation in the receding-horizon protocol of bench.py --workload formation (one knot crossing, the moving
+    circle), the inputs of every x-update dumped -- parameters with the consensus state z, l and rho, the warm-start plan,
+    the multipliers -- and every one of these NLPs (`problems/admm.py:390`: 151 variables, 671 rows) solved by scipy SLSQP.
+    A warm-started product solve from the dumped inputs must return SLSQP's solution."""
+    import os
+    import omgtools.backend as be
+    from omgtools import scenarios
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sol_admm_xupdate.npz'))
+    steps, n = d['x'].shape[:2]
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        problem, updater, father, lay, P = scenarios.formation_holonomic(n)
+    finally:
+        be.create_nlp = saved
+    tpl = father.template
+    assert (int(d['n_var']), int(d['n_con'])) == (tpl.n_var, tpl.n_con) == (151, 671) and d['ok'].all() and d['crossed'].sum() == 1
+    nlp = NumpyNLP(tpl)
+    lo, hi = d['spl']
+    worst_f = worst_x = 0.0
+    tight = total = 0
+    for k in range(steps):
+        res = solve_step(tpl, d['p'][k], d['x0'][k], d['lam'][k])
+        assert (res['status'] == 0).all(), (k, res['status'])
+        for b in range(n):
+            assert_kkt(nlp, tpl, d['p'][k, b], res['x'][b], res['lam_g'][b], 1e-5, ('x-update', k, b))
+            f = nlp.fg(res['x'][b], nlp.term_coefs(d['p'][k, b]))[0]
+            worst_f = max(worst_f, abs(f - d['f'][k, b]) / (1 + abs(f)))
+            dx = np.abs(res['x'][b, lo:hi] - d['x'][k, b, lo:hi]).max()
+            worst_x = max(worst_x, dx)
+            tight += dx < tight_tol
+            total += 1
+    assert worst_f < f_tol, worst_f
+    assert worst_x < x_tol, worst_x
+    assert tight >= tight_share * total, (tight, total)
+    return worst_f, worst_x, tight, total
+
+
+def test_port_xupdates_match_slsqp():
+    from oracle import port_binding
+
+    def solve_step(tpl, p, x0, lam):
+        return port_binding.solve(tpl, p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32), warm_start=1, n_threads=4,
+                                  tol=1e-6, max_iter=500, warm_z_cap=0.0, max_soc=0)
+    _check_xupdates(solve_step)
+
+
+@pytest.mark.gpu
+def test_hip_xupdates_match_slsqp():
+    from omgtools.backend import BatchSolver
+    solver = {}
+
+    def solve_step(tpl, p, x0, lam):
+        if 's' not in solver:
+            solver['s'] = BatchSolver(tpl, len(p), options=dict(tol=1e-6, max_iter=500, warm_start=1, warm_z_cap=0.0, max_soc=0))
+        return solver['s'].solve(p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32))
+    try:
+        _check_xupdates(solve_step)
+    finally:
+        if 's' in solver:
+            solver['s'].close()

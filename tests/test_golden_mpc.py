@@ -98,3 +98,68 @@ def test_hip_warm_steps_match_slsqp(factor, f_tol, x_tol):
     finally:
         if 's' in solver:
             solver['s'].close()
+
+
+# ---- the Quadrotor class (round 4): 4 agents x 6 steps, five moving circles, one knot crossing ---------------------------
+def check_steps_class(fixture, scenario, solve_step, f_tol, x_tol, tight_tol, tight_share):
+    """The same check on another vehicle class: every dumped step solved again, warm-started from the dumped inputs, must
+    return the solution scipy SLSQP found for that step's NLP (for these sizes SLSQP stops with 'positive directional
+    derivative' at a feasibility of 1e-7: its own accuracy on the coefficients is ~1e-4)."""
+    import omgtools.backend as be
+    from omgtools import scenarios
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    d = np.load(os.path.join(HERE, fixture))
+    steps, n = d['x'].shape[:2]
+    saved = be.create_nlp
+    be.create_nlp = lambda tpl, opt, name='': (None, 0.)
+    try:
+        problem, P = getattr(scenarios, scenario)(n)
+    finally:
+        be.create_nlp = saved
+    tpl = problem.father.template
+    assert (int(d['n_var']), int(d['n_con'])) == (tpl.n_var, tpl.n_con) and d['ok'].all() and d['crossed'].sum() == 1
+    nlp = NumpyNLP(tpl)
+    lo, hi = d['spl']
+    worst_f, worst_x, tight, total, iters = 0.0, 0.0, 0, 0, []
+    for k in range(steps):
+        res = solve_step(tpl, d['p'][k], d['x0'][k], d['lam'][k], P.get('solver_options', {}))
+        assert (res['status'] == 0).all(), (k, res['status'])
+        iters.append(res['iters'].mean())
+        for b in range(n):
+            assert_kkt(nlp, tpl, d['p'][k, b], res['x'][b], res['lam_g'][b], 10 * TOL, (fixture, k, b))
+            f = nlp.fg(res['x'][b], nlp.term_coefs(d['p'][k, b]))[0]
+            worst_f = max(worst_f, abs(f - d['f'][k, b]) / (1 + abs(f)))
+            dx = np.abs(res['x'][b, lo:hi] - d['x'][k, b, lo:hi]).max()
+            worst_x = max(worst_x, dx)
+            tight += dx < tight_tol
+            total += 1
+    assert worst_f < f_tol, worst_f
+    assert worst_x < x_tol, worst_x
+    assert tight >= tight_share * total, (tight, total)
+    return worst_f, worst_x, tight, total, np.mean(iters)
+
+
+def test_port_quadrotor_warm_steps_match_slsqp():
+    from oracle import port_binding
+
+    def solve_step(tpl, p, x0, lam, so):
+        return port_binding.solve(tpl, p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32), warm_start=1,
+                                  n_threads=4, **dict(so, tol=TOL, max_iter=500, warm_mu_factor=0.1, warm_z_floor=0.1, warm_z_cap=0.0))
+    check_steps_class('sol_mpc_cfg3.npz', 'quadrotor_p2p', solve_step, 2e-5, 2e-3, 3e-4, 0.85)
+
+
+@pytest.mark.gpu
+def test_hip_quadrotor_warm_steps_match_slsqp():
+    from omgtools.backend import BatchSolver
+    solver = {}
+
+    def solve_step(tpl, p, x0, lam, so):
+        if 's' not in solver:
+            solver['s'] = BatchSolver(tpl, len(p), options=dict(so, tol=TOL, max_iter=500, warm_start=1, warm_mu_factor=0.1, warm_z_floor=0.1, warm_z_cap=0.0))
+        return solver['s'].solve(p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32))
+    try:
+        check_steps_class('sol_mpc_cfg3.npz', 'quadrotor_p2p', solve_step, 2e-5, 2e-3, 3e-4, 0.85)
+    finally:
+        if 's' in solver:
+            solver['s'].close()
