@@ -225,7 +225,13 @@ int  omgx_batch_workspace(const omgx_batch* b, int32_t* mode, int64_t* lds_bytes
  *   result = solver(x0=, p=, lbg=, ubg=)  ->  x, lam_g, return_status.
  * p [B,n_par], x0 [B,n_var], lbg/ubg [B,n_con] (or [n_con] with
  * OMGX_BOUNDS_SHARED), x [B,n_var], lam_g [B,n_con], status/iters [B].
- * Asynchronous w.r.t. the host when OMGX_PTR_DEVICE is set; call omgx_batch_sync. */
+ * Asynchronous w.r.t. the host when OMGX_PTR_DEVICE is set; call omgx_batch_sync.
+ * Rows: lbg == ubg is an equality row (the rows of omgx_template.eq_rows), one finite bound an inequality row, both
+ * infinite a free row.  Two-sided rows lb < g < ub (`basics/optilayer.py:634-666`; version 5) are accepted where the
+ * template's default bounds (has_bounds) mark them: the library solves with such a row doubled -- once per side -- and maps
+ * bounds and multipliers between the caller's n_con rows and its own; lam_g of such a row is positive when the upper
+ * bound is active, negative for the lower one.  A two-sided row that the default bounds do not announce ends the solve
+ * with Unsupported_Bounds. */
 int  omgx_batch_solve(omgx_batch* b, const double* p, const double* x0,
                       const double* lbg, const double* ubg,
                       double* x, double* lam_g, int32_t* status, int32_t* iters,

@@ -719,6 +719,12 @@ struct omgx_batch {
   bool timing = true;              // bracket every solve kernel with events (omgx_batch_set_timing)
   // staging buffers for host-pointer calls
   double *d_p = nullptr, *d_x0 = nullptr, *d_lb = nullptr, *d_ub = nullptr, *d_x = nullptr, *d_lam = nullptr;
+  // Two-sided rows lb < g < ub (`basics/optilayer.py:634-666`): the solve kernel knows one-sided rows, so the library hands it
+  // the template with every such row twice -- row r as g <= ub, a copy behind the last row as g >= lb -- and maps bounds and
+  // multipliers between the caller's n_con_user rows and the kernel's dims.n_con rows around every solve (range_* kernels).
+  int n_con_user = 0, n_range = 0;
+  int32_t *d_range_src = nullptr, *d_range_dup = nullptr;      // [n_range] source row of copy k; [n_con_user] copy of row r (-1: none)
+  double *d_lam_user = nullptr, *d_lb_user = nullptr, *d_ub_user = nullptr;   // staging of the caller's arrays (host-pointer calls)
   int32_t *d_status = nullptr, *d_iters = nullptr;
   long long* d_prof = nullptr;
   // shift tables (entries + T matrices) live in the handle: uploaded when they change (a receding-horizon loop
@@ -834,6 +840,78 @@ int check_template(const omgx_template* t) {
     }
   }
   return OMGX_OK;
+}
+
+// ---- two-sided rows: caller's rows <-> the kernel's rows ----------------------------------------------------------
+__global__ void range_expand_bounds(const double* __restrict__ lb_u, const double* __restrict__ ub_u, double* __restrict__ lb_i,
+                                    double* __restrict__ ub_i, int sets, int nu, int ni, const int32_t* __restrict__ src,
+                                    const int32_t* __restrict__ dup) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= sets * ni) return;
+  const int s = id / ni, r = id - s * ni;
+  if (r < nu) {                                  // a two-sided row keeps its upper bound here
+    lb_i[id] = dup[r] >= 0 ? -INFINITY : lb_u[(size_t)s * nu + r];
+    ub_i[id] = ub_u[(size_t)s * nu + r];
+  } else {                                       // its copy carries the lower bound
+    lb_i[id] = lb_u[(size_t)s * nu + src[r - nu]];
+    ub_i[id] = INFINITY;
+  }
+}
+// multipliers in: lam_g of a two-sided row is positive when its upper bound is active, negative for the lower one
+__global__ void range_expand_lam(const double* __restrict__ lam_u, double* __restrict__ lam_i, int B, int nu, int ni,
+                                 const int32_t* __restrict__ src, const int32_t* __restrict__ dup) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * ni) return;
+  const int b = id / ni, r = id - b * ni;
+  if (r < nu) { const double v = lam_u[(size_t)b * nu + r]; lam_i[id] = dup[r] >= 0 ? fmax(v, 0.0) : v; }
+  else lam_i[id] = fmin(lam_u[(size_t)b * nu + src[r - nu]], 0.0);
+}
+__global__ void range_contract_lam(const double* __restrict__ lam_i, double* __restrict__ lam_u, int B, int nu, int ni,
+                                   const int32_t* __restrict__ dup) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * nu) return;
+  const int b = id / nu, r = id - b * nu;
+  lam_u[id] = lam_i[(size_t)b * ni + r] + (dup[r] >= 0 ? lam_i[(size_t)b * ni + dup[r]] : 0.0);
+}
+
+// The template with every two-sided row of its default bounds twice (see omgx_batch::n_range).  Host arrays owned by `own`.
+struct ExpandedTemplate {
+  omgx_template t;
+  std::vector<int32_t> row_ptr, t_slot, t_var, src, dup;
+  std::vector<double> t_coef, lb, ub;
+};
+static bool expand_range_rows(const omgx_template* in, ExpandedTemplate& e) {
+  e.src.clear(); e.dup.assign(in->n_con, -1);
+  if (!in->has_bounds || !in->lbg_def || !in->ubg_def) return false;
+  std::vector<char> is_eq(in->n_con, 0);
+  for (int k = 0; k < in->n_eq; ++k) if (in->eq_rows[k] >= 0 && in->eq_rows[k] < in->n_con) is_eq[in->eq_rows[k]] = 1;
+  for (int r = 0; r < in->n_con; ++r)
+    if (!is_eq[r] && std::isfinite(in->lbg_def[r]) && std::isfinite(in->ubg_def[r]) && in->lbg_def[r] < in->ubg_def[r]) {
+      e.dup[r] = in->n_con + (int)e.src.size(); e.src.push_back(r);
+    }
+  if (e.src.empty()) return false;
+  const int nu = in->n_con, ni = nu + (int)e.src.size(), W = OMGX_TERM_VARS;
+  e.t = *in;
+  e.row_ptr.assign(ni + 2, 0);
+  auto put_row = [&](int from) {
+    for (int i = in->row_ptr[from]; i < in->row_ptr[from + 1]; ++i) {
+      e.t_coef.push_back(in->t_coef[i]); e.t_slot.push_back(in->t_slot[i]);
+      for (int q = 0; q < W; ++q) e.t_var.push_back(in->t_var[(size_t)W * i + q]);
+    }
+  };
+  int out = 0;
+  for (int r = 0; r < nu; ++r) { put_row(r); e.row_ptr[++out] = (int)e.t_coef.size(); }
+  for (int k = 0; k < (int)e.src.size(); ++k) { put_row(e.src[k]); e.row_ptr[++out] = (int)e.t_coef.size(); }
+  put_row(nu); e.row_ptr[++out] = (int)e.t_coef.size();                 // the objective row stays last
+  e.lb.resize(ni); e.ub.resize(ni);
+  for (int r = 0; r < nu; ++r) { e.lb[r] = e.dup[r] >= 0 ? -INFINITY : in->lbg_def[r]; e.ub[r] = in->ubg_def[r]; }
+  for (int k = 0; k < (int)e.src.size(); ++k) { e.lb[nu + k] = in->lbg_def[e.src[k]]; e.ub[nu + k] = INFINITY; }
+  e.t_coef.push_back(0.0); e.t_slot.push_back(0); e.t_var.push_back(0);
+  e.t.n_con = ni; e.t.n_terms = (int)e.t_coef.size() - 1;
+  e.t.row_ptr = e.row_ptr.data(); e.t.t_coef = e.t_coef.data(); e.t.t_slot = e.t_slot.data(); e.t.t_var = e.t_var.data();
+  e.t.lbg_def = e.lb.data(); e.t.ubg_def = e.ub.data();
+  e.t.n_blocks = 0; e.t.block_names_len = 0;                            // (the block table describes the caller's rows)
+  return true;
 }
 
 int build_batch(omgx_batch* b, const omgx_template* t) {
@@ -1121,9 +1199,22 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
   b->device = device; b->n_agents = n_agents;
   omgx_options o; omgx_default_options(&o);
   b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm, o.dw_leaf_ratio_cold, 0, o.warm_mu_factor, o.warm_z_floor, o.warm_z_cap, o.max_soc};
-  int rc = build_batch(b, tpl);
+  ExpandedTemplate ex;
+  const bool ranged = expand_range_rows(tpl, ex);
+  b->n_con_user = tpl->n_con; b->n_range = ranged ? (int)ex.src.size() : 0;
+  int rc = build_batch(b, ranged ? &ex.t : tpl);
   if (rc != OMGX_OK) { omgx_batch_destroy(b); return rc; }
   const omgx::Dims& d = b->dims;
+  if (ranged) {
+    if (hipMalloc((void**)&b->d_range_src, ex.src.size() * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&b->d_range_dup, ex.dup.size() * sizeof(int32_t)) != hipSuccess ||
+        hipMemcpy(b->d_range_src, ex.src.data(), ex.src.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(b->d_range_dup, ex.dup.data(), ex.dup.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+      g_err = "hipMalloc failed"; omgx_batch_destroy(b); return OMGX_E_HIP;
+    }
+    if ((rc = dalloc(b, (size_t)n_agents * b->n_con_user, &b->d_lam_user)) || (rc = dalloc(b, (size_t)n_agents * b->n_con_user, &b->d_lb_user)) ||
+        (rc = dalloc(b, (size_t)n_agents * b->n_con_user, &b->d_ub_user))) { omgx_batch_destroy(b); return rc; }
+  }
   if ((rc = dalloc(b, (size_t)n_agents * d.n_par, &b->d_p)) || (rc = dalloc(b, (size_t)n_agents * d.n_var, &b->d_x0)) ||
       (rc = dalloc(b, (size_t)n_agents * d.n_con, &b->d_lb)) || (rc = dalloc(b, (size_t)n_agents * d.n_con, &b->d_ub)) ||
       (rc = dalloc(b, (size_t)n_agents * d.n_var, &b->d_x)) || (rc = dalloc(b, (size_t)n_agents * d.n_con, &b->d_lam)) ||
@@ -1168,6 +1259,8 @@ void omgx_batch_destroy(omgx_batch* b) {
   (void)hipSetDevice(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
   if (b->d_store) (void)hipFree(b->d_store);
+  if (b->d_range_src) (void)hipFree(b->d_range_src);
+  if (b->d_range_dup) (void)hipFree(b->d_range_dup);
   if (b->d_shift_ent) (void)hipFree(b->d_shift_ent);
   if (b->d_shift_T) (void)hipFree(b->d_shift_T);
   if (b->d_mask) (void)hipFree(b->d_mask);
@@ -1242,27 +1335,47 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   const int B = b->n_agents;
   const bool dev = flags & OMGX_PTR_DEVICE, shared = flags & OMGX_BOUNDS_SHARED;
   const bool bdev = (flags & OMGX_BOUNDS_DEVICE) != 0;
-  const size_t nb = (shared ? 1 : (size_t)B) * d.n_con;
+  // (nu: rows of the caller's arrays; d.n_con: rows of the kernel's -- more when two-sided rows were doubled, omgx_batch::n_range)
+  const int nu = b->n_con_user, ni = d.n_con;
+  const bool ranged = b->n_range > 0;
+  const size_t nb = (shared ? 1 : (size_t)B) * nu;
   const double *kp = p, *kx0 = x0, *klb = lbg, *kub = ubg;
   double *kx = x, *klam = lam_g; int32_t *kst = status, *kit = iters;
+  const bool lam_in = b->opts.warm_start || (flags & OMGX_ONLY_FAILED);
+  double* lam_user_dev = ranged ? (dev ? lam_g : b->d_lam_user) : nullptr;       // the caller's multipliers on the device
   if (!dev) {
     HIPCHK(hipMemcpyAsync(b->d_p, p, (size_t)B * d.n_par * sizeof(double), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->d_x0, x0, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    double* lam_to = ranged ? b->d_lam_user : b->d_lam;
     if (b->opts.warm_start) {
-      HIPCHK(hipMemcpyAsync(b->d_lam, lam_g, (size_t)B * d.n_con * sizeof(double), hipMemcpyHostToDevice, b->stream));
+      HIPCHK(hipMemcpyAsync(lam_to, lam_g, (size_t)B * nu * sizeof(double), hipMemcpyHostToDevice, b->stream));
       HIPCHK(hipMemcpyAsync(b->d_status, status, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
     }
     if (flags & OMGX_ONLY_FAILED) {       // the skipped agents keep what the caller's buffers hold
       HIPCHK(hipMemcpyAsync(b->d_x, x, (size_t)B * d.n_var * sizeof(double), hipMemcpyHostToDevice, b->stream));
-      HIPCHK(hipMemcpyAsync(b->d_lam, lam_g, (size_t)B * d.n_con * sizeof(double), hipMemcpyHostToDevice, b->stream));
+      HIPCHK(hipMemcpyAsync(lam_to, lam_g, (size_t)B * nu * sizeof(double), hipMemcpyHostToDevice, b->stream));
       HIPCHK(hipMemcpyAsync(b->d_status, status, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
       HIPCHK(hipMemcpyAsync(b->d_iters, iters, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
     }
     kp = b->d_p; kx0 = b->d_x0; kx = b->d_x; klam = b->d_lam; kst = b->d_status; kit = b->d_iters;
   }
+  if (ranged) {
+    klam = b->d_lam;
+    if (lam_in)
+      hipLaunchKernelGGL(range_expand_lam, dim3((B * ni + 255) / 256), dim3(256), 0, b->stream, (const double*)lam_user_dev, b->d_lam, B, nu, ni,
+                         (const int32_t*)b->d_range_src, (const int32_t*)b->d_range_dup);
+  }
   if (!bdev) {
-    HIPCHK(hipMemcpyAsync(b->d_lb, lbg, nb * sizeof(double), hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(b->d_ub, ubg, nb * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    double* lb_to = ranged ? b->d_lb_user : b->d_lb;
+    double* ub_to = ranged ? b->d_ub_user : b->d_ub;
+    HIPCHK(hipMemcpyAsync(lb_to, lbg, nb * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(ub_to, ubg, nb * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    klb = lb_to; kub = ub_to;
+  }
+  if (ranged) {
+    const int sets = shared ? 1 : B;
+    hipLaunchKernelGGL(range_expand_bounds, dim3((sets * ni + 255) / 256), dim3(256), 0, b->stream, klb, kub, b->d_lb, b->d_ub, sets, nu, ni,
+                       (const int32_t*)b->d_range_src, (const int32_t*)b->d_range_dup);
     klb = b->d_lb; kub = b->d_ub;
   }
   { const int rc_o = flush_order(b); if (rc_o != OMGX_OK) return rc_o; }
@@ -1282,9 +1395,12 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
                         (unsigned long long*)(b->d_stats ? b->d_stats + 4 * (size_t)(b->stats_launch++ % b->stats_slots) : nullptr),
                         b->stagger);
   HIPCHK(hipGetLastError());
+  if (ranged)
+    hipLaunchKernelGGL(range_contract_lam, dim3((B * nu + 255) / 256), dim3(256), 0, b->stream, (const double*)b->d_lam, lam_user_dev, B, nu, ni,
+                       (const int32_t*)b->d_range_dup);
   if (!dev) {
     HIPCHK(hipMemcpyAsync(x, b->d_x, (size_t)B * d.n_var * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipMemcpyAsync(lam_g, b->d_lam, (size_t)B * d.n_con * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(lam_g, ranged ? b->d_lam_user : b->d_lam, (size_t)B * nu * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipMemcpyAsync(status, b->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipMemcpyAsync(iters, b->d_iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1310,6 +1426,7 @@ int omgx_batch_sync(omgx_batch* b) {
 int omgx_batch_eval(omgx_batch* b, const double* p, const double* x, const double* lam_g, double* g, double* f,
                     double* jac, double* hess) {
   if (!b || !p || !x || !lam_g) { g_err = "null argument"; return OMGX_E_INVALID; }
+  if (b->n_range > 0) { g_err = "omgx_batch_eval: not available for a template with two-sided rows (the kernel's rows are not the caller's)"; return OMGX_E_INVALID; }
   HIPCHK(hipSetDevice(b->device));
   const omgx::Dims& d = b->dims;
   const int B = b->n_agents;

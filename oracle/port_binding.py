@@ -44,6 +44,16 @@ def solve(template, p, x0, lbg=None, ubg=None, plan=None, lam_g0=None, status0=N
     be = _backend()
     make_ctemplate, make_options = be.make_ctemplate, be.make_options
     lib = load()
+    # two-sided rows lb < g < ub: solved with every such row doubled, like the library does around its kernel (oracle/range_rows.py)
+    from oracle import range_rows as rr
+    if len(rr.range_rows(template)):
+        t2, src, dup = rr.expand_template(template)
+        lb2, ub2 = rr.expand_bounds(template.lb if lbg is None else lbg, template.ub if ubg is None else ubg, src, dup)
+        shared = lb2.shape[0] == 1
+        res = solve(t2, p, x0, lb2[0] if shared else lb2, ub2[0] if shared else ub2, None,
+                    None if lam_g0 is None else rr.expand_lam(lam_g0, src, dup), status0, n_threads, dw_state, **options)
+        res['lam_g'] = rr.contract_lam(res['lam_g'], template.n_con, src, dup)
+        return res
     ct, keep = make_ctemplate(template, plan)
     opt = make_options(**options)
     p = np.ascontiguousarray(np.atleast_2d(np.asarray(p, float)))
