@@ -181,7 +181,7 @@ struct Opts {
 #define OMGX_DW_ZERO     1e-9
 #define OMGX_DW_HEAVY    10.0
 #ifndef OMGX_KAPPA_EPS_HEAVY
-#define OMGX_KAPPA_EPS_HEAVY 30.0     // (round 4: 100 let mu drop while the iterate was still far from optimal -- the slowest cold agents of config 2 then crawl along the boundary at step lengths of 1e-3: 85 -> 60 iterations; Quadrotor class mean 79 -> 68)
+#define OMGX_KAPPA_EPS_HEAVY 100.0    // (round 4 tried 30: same-box A/B, 4096 agents: config 2 cold 91.4k vs 90.0k solves/s -- noise -- but the Quadrotor class 12.2k vs 15.7k cold, 25.2 vs 21.7 ms per warm step: kept at 100)
 #endif
 #ifndef OMGX_DW_BACKOFF_MAX
 #define OMGX_DW_BACKOFF_MAX 8

@@ -23,7 +23,7 @@ import numpy as np
 
 DEFAULTS = dict(dw_cap_floor=0.03, tol=1e-8, max_iter=200, mu_init=0.1, kappa_eps=10.0, kappa_mu=0.2,
                 theta_mu=1.5, tau_min=0.99, s_push=1.0, delta_c=1e-8, eta=1e-4,
-                rho=0.1, dw_first=1e-4, dw_inc=10.0, dw_dec=1. / 3., dw_max=1e10, dw_zero=1e-9, dw_heavy=10.0, kappa_eps_heavy=30.0,
+                rho=0.1, dw_first=1e-4, dw_inc=10.0, dw_dec=1. / 3., dw_max=1e10, dw_zero=1e-9, dw_heavy=10.0, kappa_eps_heavy=100.0,
                 s_max=100.0, kappa_sigma=1e10, max_backtrack=25, max_soc=2,
                 slack_reset=True, kappa_push=1.0, stall_iters=20, warm_zmin=1e-8, warm_z_floor=0.1, warm_z_cap=0.01, nu_init=100.0, nu_max=1e8, e_push=1.0, scale_gmax=100.0, s_phi=2.3, s_theta=1.1, delta_sw=1.0,
                 gamma_theta=1e-5, gamma_phi=1e-5, filter_size=8, warm_mu_factor=1.0,
