@@ -67,8 +67,15 @@ def test_merged_velocity_rows_give_the_same_solution():
         b.solve_device(p, x0, lb, ub, x, lam, status, iters, bounds_shared=True)
         torch.cuda.synchronize()
         assert (status.cpu().numpy() == 0).all() and np.median(iters.cpu().numpy()) <= 3      # warm from the solution: it stays (most agents: no iteration)
-        assert np.abs(x.cpu().numpy() - rb['x']).max() < 1e-4
-        assert np.abs(lam.cpu().numpy() - rb['lam_g']).max() < 1e-3
+        # ... the plan, that is: the separating hyperplanes float on flat faces, and the multipliers of their rows with them
+        lo_s, hi_s = tpl.entry_range(problem.vehicles[0].label, 'splines_seg0', 'var')
+        xw = x.cpu().numpy()
+        assert np.abs(xw[:, lo_s:hi_s] - rb['x'][:, lo_s:hi_s]).max() < 1e-4
+        for i in range(B):
+            fa, fb = (nlp.fg(v[i], nlp.term_coefs(P['p'][i]))[0] for v in (xw, rb['x']))
+            assert abs(fa - fb) < 1e-5 * (1 + abs(fb))
+        for up, lo in pairs:
+            assert np.abs(lam.cpu().numpy()[:, up] - rb['lam_g'][:, up]).max() < 1e-3
         # a two-sided row the template's default bounds did not announce is still refused, loudly
         bad_lb = tpl.lb.copy(); bad_lb[0] = -5.0
         rc = a.solve(P['p'], P['x0'], lbg=bad_lb, ubg=tpl.ub)
