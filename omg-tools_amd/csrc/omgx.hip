@@ -783,17 +783,18 @@ bool plan_for_mode(omgx::HostPlan& plan, const omgx_template& t, int* mode, size
   if (plan.dims.wave_ok && !getenv("OMGX_NO_COMPACT")) {
     // (built in place: HostPlan::tables points into the plan's own vectors)
     plan = omgx::HostPlan();
+    plan.owners = 256;        // (the assembly records dealt to the 256 threads of a two-per-CU workgroup)
     if (!plan.build(t, false, true)) return false;
     const int cand[2] = {omgx::WS_LDS, omgx::WS_JAC_ONLY};
     // (two per CU = workgroups of four waves: the substitutions gather 64 doubles per wave in the scratch behind the
     // matrix descriptors, four of the eight blocks suffice)
-    const int col_full = plan.dims.col_doubles, col_half = col_full - 4 * 64;
-    plan.dims.col_doubles = col_half;
+    plan.dims.col_doubles -= 4 * 64;
     for (int k = 0; k < 2; ++k) {
       omgx::work_split(plan.dims, plan.kkt_doubles, cand[k], lds_doubles, hbm_doubles);
       if (*lds_doubles * sizeof(double) <= (size_t)kLdsHalf && !getenv("OMGX_ONE_PER_CU")) { *mode = cand[k]; *per_cu = 2; return true; }
     }
-    plan.dims.col_doubles = col_full;
+    plan = omgx::HostPlan();
+    if (!plan.build(t, false, true)) return false;
     // one agent per CU: everything in LDS, or the Jacobian values in a slab (the register-resident factorisation either way)
     for (int k = 0; k < 2; ++k) {
       omgx::work_split(plan.dims, plan.kkt_doubles, cand[k], lds_doubles, hbm_doubles);

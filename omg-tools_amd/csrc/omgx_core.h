@@ -69,6 +69,8 @@ struct Dims {
   int n_kafix, n_kgfix;         // targets whose run was cut (fix-up records)
   int side_off, dump_off;       // side slots / per-lane dump slots behind the KKT store
   int cs_parts;      // threads per column in the column sums J'w
+  int kg_side_dinv;  // 1: the side sums of the Gershgorin pass live in w.dinv, 0: in the side slots behind the KKT store
+  int n_owner;       // owner bins in use (<= OMGX_NBIN, the stride of the record tables): the threads of the workgroup the plan was made for
 };
 
 // one parameter monomial coef * prod atoms[a_k] as a single 16-byte record (a_k = -1: unused): one
@@ -2310,6 +2312,8 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     // trajectory coefficient whose bilinear rows are all inactive (multipliers ~ mu / s) is then
     // practically undamped even while dw covers the active hyperplane rows elsewhere.
     int first_trial = 1;
+    // (side sums of cut runs: w.dinv -- the dual residual has been read, the factorisation has not started -- or the pairs' side slots)
+    double* const gside = d.kg_side_dinv ? w.dinv : w.kkt + d.side_off;
     OMGX_PFOR(q, N) w.xt[q] = 0.0;
     // weight of every row in the Lagrangian Hessian (multiplier x signed scale): one read per Hessian item instead of
     // three (w.ht -- 1/s during the residual phase -- is free until the line search)
@@ -2325,7 +2329,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       // (branch-free loop bodies -- the store of a record that does not end a segment goes to a dump slot
       // behind the store -- and the records of a batch loaded first, all in flight together: left to itself
       // the compiler issues every load right before its use, behind the previous LDS store, ~1000 cycles each)
-      for (int bin = c.tid(); bin < OMGX_NBIN; bin += c.nthr()) {
+      for (int bin = c.tid(); bin < d.n_owner; bin += c.nthr()) {
         const int dump = d.dump_off + (bin & 63);       // (a slot per lane behind the store: nothing lives there)
         struct PairRec { int32_t a, b, ad, r; };
         const PairRec* recs = (const PairRec*)T.ka_rec;
@@ -2373,7 +2377,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       }
       c.sync();
       OMGX_TOC(PH_A_TCOL);
-      for (int bin = c.tid(); bin < OMGX_NBIN; bin += c.nthr()) {
+      for (int bin = c.tid(); bin < d.n_owner; bin += c.nthr()) {
         const int dump = d.dump_off + (bin & 63);
         hess_bin<C>(d, T, w, m, bin, dump);
         if (first_trial) {
@@ -2397,7 +2401,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
             for (int i = 0; i < OMGX_REC_BATCH; ++i) {
               acc += g[i];
               const int tg = q[i].target;
-              double* dst = tg >= N ? w.kkt + d.side_off + (tg - N) : (tg >= 0 ? w.xt + tg : w.kkt + dump);
+              double* dst = tg >= N ? gside + (tg - N) : (tg >= 0 ? w.xt + tg : w.kkt + dump);
               *dst = acc;
               acc = tg >= 0 ? 0.0 : acc;
             }
@@ -2412,7 +2416,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         OMGX_PFOR(i, d.n_kgfix) {
           const int32_t* f = T.kg_fix + 3 * i;
           double a = w.xt[f[0]];
-          for (int k = 0; k < f[2]; ++k) a += w.kkt[d.side_off + f[1] + k];
+          for (int k = 0; k < f[2]; ++k) a += gside[f[1] + k];
           w.xt[f[0]] = a;
         }
         c.sync();
@@ -2797,7 +2801,7 @@ OMGX_FN void ipm_eval(const C& c, const Dims& d, const Tables& T, Work& w, const
   const double f = c.rsum(row_value_share(c, T, w, m, w.x));
   if (c.tid() == 0) *f_out = f;
   c.sync();
-  for (int bin = c.tid(); bin < OMGX_NBIN; bin += c.nthr()) hess_bin<C>(d, T, w, m, bin, d.dump_off + (bin & 63));
+  for (int bin = c.tid(); bin < d.n_owner; bin += c.nthr()) hess_bin<C>(d, T, w, m, bin, d.dump_off + (bin & 63));
   c.sync();
 }
 

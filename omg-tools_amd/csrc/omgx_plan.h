@@ -10,6 +10,9 @@
 #pragma once
 #include <stdlib.h>
 #include <algorithm>
+#include <array>
+#include <cmath>
+#include <map>
 #include <functional>
 #include <numeric>
 #include <queue>
@@ -209,13 +212,14 @@ struct HostPlan {
   }
 
   // LPT assignment of weighted items to OMGX_NBIN bins (heaviest first, to the lightest bin)
-  static std::vector<int> lpt_bins(const std::vector<int>& weight) {
+  int owners = OMGX_NBIN;      // owner bins the assembly records are dealt to (= threads of the solve workgroup; set before build)
+  std::vector<int> lpt_bins(const std::vector<int>& weight) const {
     std::vector<int> idx(weight.size()), bin(weight.size(), 0);
     std::iota(idx.begin(), idx.end(), 0);
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return weight[a] > weight[b]; });
     typedef std::pair<long, int> LB;     // (load, bin)
     std::priority_queue<LB, std::vector<LB>, std::greater<LB>> heap;
-    for (int b = 0; b < OMGX_NBIN; ++b) heap.push(LB(0, b));
+    for (int b = 0; b < owners; ++b) heap.push(LB(0, b));
     for (int i : idx) { LB lb = heap.top(); heap.pop(); bin[i] = lb.second; lb.first += weight[i]; heap.push(lb); }
     return bin;
   }
@@ -622,10 +626,10 @@ struct HostPlan {
     {
       struct Seg { int target; std::vector<int> items; };
       // items of one target in table order -> segments, side slots and fix-ups
-      auto cut = [&](const std::vector<std::pair<int, std::vector<int>>>& runs, std::vector<Seg>& segs, std::vector<int32_t>& fix, int& n_side) {
+      auto cut = [&](const std::vector<std::pair<int, std::vector<int>>>& runs, std::vector<Seg>& segs, std::vector<int32_t>& fix, int& n_side, int cap = OMGX_RUN_CAP) {
         for (auto& run : runs) {
           const std::vector<int>& it = run.second;
-          const int nseg = ((int)it.size() + OMGX_RUN_CAP - 1) / OMGX_RUN_CAP;
+          const int nseg = ((int)it.size() + cap - 1) / cap;
           if (nseg > 1) { fix.push_back(run.first); fix.push_back(n_side); fix.push_back(nseg - 1); }
           for (int sg = 0; sg < nseg; ++sg) {
             Seg g; g.target = sg == 0 ? run.first : -2 - (n_side++);       // (-2 - k: side slot k)
@@ -706,25 +710,49 @@ struct HostPlan {
           kh_rec[r * OMGX_NBIN + bb] = it;
         }
       }
-      // ---- Gershgorin row sums: target = position (w.xt), side slots shared with the pairs' (the pass runs
-      // after the pair fix-up has consumed them)
+      // ---- Gershgorin row sums: target = position (w.xt), side sums in w.dinv (free between the dual residual and the
+      // factorisation)
       {
         struct GI { HItem it; int p; };
         std::vector<GI> gis;
+        // Off-diagonal items contribute |lambda coef slot x3 x4| to the sums of both their positions: items of one row that
+        // differ only in the coefficient (a bilinear row of two splines meets position q once per coefficient of the
+        // other spline) are one record with the sum of the |coef| -- the same sum, a fraction of the records (config 2:
+        // 16 -> 8 per owner).  Diagonal items (kind 1) count by sign and stay as they are.
+        std::map<std::array<int, 5>, int> seen;
         for (auto& x : his) {
-          GI g; g.it = x.it; g.p = x.pa; gis.push_back(g);
-          if (!x.it.kind) { g.p = x.pb; gis.push_back(g); }
+          for (int side = 0; side < (x.it.kind ? 1 : 2); ++side) {
+            GI g; g.it = x.it; g.p = side ? x.pb : x.pa;
+            if (!x.it.kind) {
+              const std::array<int, 5> key = {g.p, x.it.row, x.it.slot, x.it.vthird, x.it.vfourth};
+              auto f = seen.find(key);
+              if (f != seen.end()) { gis[f->second].it.coef += std::fabs(x.it.coef); continue; }
+              seen[key] = (int)gis.size();
+              g.it.coef = std::fabs(x.it.coef);
+            }
+            gis.push_back(g);
+          }
         }
         std::vector<int> og(gis.size());
         std::iota(og.begin(), og.end(), 0);
         std::stable_sort(og.begin(), og.end(), [&](int x, int y) { return gis[x].p < gis[y].p; });
         std::vector<std::pair<int, std::vector<int>>> runs;
         for (int i : og) { const int q = gis[i].p; if (runs.empty() || runs.back().first != q) runs.push_back(std::make_pair(q, std::vector<int>())); runs.back().second.push_back(i); }
+        // (a hundred positions with a dozen records each leave most owners idle: the runs are cut shorter while that
+        // shortens the longest owner and the side sums fit, never below four records)
         int n_side_g = 0;
-        std::vector<Seg> segs; cut(runs, segs, kg_fix, n_side_g);
-        if (n_side_g > n_side) n_side = n_side_g;
-        std::vector<std::vector<std::pair<int, int>>> per; deal(segs, per);
+        std::vector<Seg> segs; std::vector<std::vector<std::pair<int, int>>> per;
+        for (int cap = 1 << 20; cap >= 4; cap = cap > 4 * OMGX_RUN_CAP ? 4 * OMGX_RUN_CAP : cap / 2) {      // uncut, 64, 32, 16, 8, 4
+          int ns = 0; std::vector<Seg> sg; std::vector<int32_t> fx; std::vector<std::vector<std::pair<int, int>>> pr;
+          cut(runs, sg, fx, ns, cap); deal(sg, pr);
+          // (the side sums of this pass live in w.dinv [N] -- free between the dual residual and the factorisation -- or,
+          // when they are more, in the side slots of the pairs, which the pair fix-up has consumed by then)
+          if (ns > d.N && ns > n_side) break;
+          if (per.empty() || ell_len(pr) < ell_len(per)) { segs = sg; kg_fix = fx; per = pr; n_side_g = ns; }
+        }
+        d.kg_side_dinv = n_side_g <= d.N ? 1 : 0;
         d.kg_len = ell_len(per);
+        if (getenv("OMGX_PLAN_DEBUG")) { size_t mx = 0; for (auto& v : per) mx = std::max(mx, v.size()); fprintf(stderr, "[plan] hessian items %zu, gershgorin records %zu (longest owner %zu), runs %zu, side slots %d (pairs %d), owners %d\n", his.size(), gis.size(), mx, runs.size(), n_side_g, n_side, owners); }
         kg_rec.assign((size_t)OMGX_NBIN * std::max(1, d.kg_len), HItem{0.0, 0, -1, -1, -1, -1, 0});
         for (int bb = 0; bb < OMGX_NBIN; ++bb) for (size_t r = 0; r < per[bb].size(); ++r) {
           HItem it = gis[per[bb][r].first].it;
@@ -737,6 +765,7 @@ struct HostPlan {
       if (ka_fix.empty()) ka_fix.assign(3, 0);
       if (kg_fix.empty()) kg_fix.assign(3, 0);
       d.side_off = side0;
+      d.n_owner = owners;
       kkt_doubles = side0 + n_side + 64;              // + side slots + one dump slot per lane (owner passes store there
                                                       //   whatever is not the end of a segment; distinct banks)
       d.dump_off = side0 + n_side;

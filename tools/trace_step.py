@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd')); sys.path.insert(0, ROOT)
 import numpy as np
 import omgtools.backend as be
-from omgtools.scenarios import holonomic_p2p
+from omgtools.workloads import holonomic_p2p
 from omgtools.batch import BatchP2P
 from oracle import port_binding
 
@@ -23,7 +23,7 @@ snap = dict(p=mpc.p.copy(), x=mpc.x.copy(), lam=mpc.lam.copy(), status=mpc.statu
 real_solve = port_binding.solve
 captured = {}
 def fake(tpl, p, x, **kw):
-    captured.update(p=p.copy(), x=x.copy(), kw=dict(kw))
+    captured.update(p=p.copy(), x=x.copy(), kw=dict((k, v.copy() if hasattr(v, 'copy') else v) for k, v in kw.items()))
     return real_solve(tpl, p, x, **kw)
 port_binding.solve = fake
 crossed = mpc.step()
@@ -39,7 +39,7 @@ code = r'''
 import os, sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import omgtools.backend as be
-from omgtools.scenarios import holonomic_p2p
+from omgtools.workloads import holonomic_p2p
 from oracle import port_binding
 be.create_nlp = lambda tpl, opt, name='': (None, 0.)
 problem, P = holonomic_p2p(1)
