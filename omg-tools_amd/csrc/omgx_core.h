@@ -65,6 +65,7 @@ struct Dims {
                      //    are first written inside the iteration): n_atoms + n_knots <= 2 N + n_eq
   int wave_ok;       // 1: every panel of the KKT store fits one wave (register-resident factorisation, omgx_wave.h)
   int n_jv;          // Jacobian entries whose value depends on x (the others are constant over a solve)
+  int n_jv4, n_ja4;  // owners of the Jacobian item tables (four entries each): x-dependent entries, all entries
   int ka_len, kh_len, kg_len;   // records per owner bin (longest bin) of the pair / Hessian / Gershgorin passes
   int n_kafix, n_kgfix;         // targets whose run was cut (fix-up records)
   int side_off, dump_off;       // side slots / per-lane dump slots behind the KKT store
@@ -117,7 +118,6 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* leaf_bw;   // [n_leaf] half bandwidth of the leaf block in its (reverse Cuthill-McKee) order
   const int32_t* tq_addr;   // [n_var] KKT address of (t, q)
   // owner-computes tables
-  const int32_t* jv_list;   // [n_jv] entries that depend on x
   const int32_t* row_perm;  // [n_con] rows, longest term list first
   // ELL tables of the row / column / entry owners: record `step` of owner i at index step * n_owner + i
   // (coalesced across the lanes), padded with null records; *_glen[i >> 6] = steps the 64 owners of a
@@ -129,10 +129,12 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* cs_ell;    // [cs_steps][n_var * cs_parts][2] {Jacobian entry, row} of column-sum owner o = j * cs_parts + k
   const int32_t* cs_glen;
   const int32_t* cs_col;    // [n_var] column (position) of slot j (columns by decreasing length)
-  const JItem* jv_ell;      // [jv_steps][n_jv] items of entry jv_list[i] (entries by decreasing item count)
-  const int32_t* jv_glen;
-  const int32_t* ja_list;   // [nnz_j] all entries by decreasing item count (the setup evaluates every entry once)
-  const JItem* ja_ell;      // [ja_steps][nnz_j]
+  // Jacobian items, four entries per owner (jac_entries4): the x-dependent entries (every iteration) and all entries (setup)
+  const JItem* jv_ell;      // [jv_steps][4][n_jv4] items of the owner's k-th entry (entries by decreasing item count, four in a row per owner)
+  const int32_t* jv_own;    // [4][n_jv4][2] {entry, row} (-1: the owner has no k-th entry)
+  const int32_t* jv_glen;   // [n_jv4 / 64] items per entry the group walks (1 or even)
+  const JItem* ja_ell;      // [ja_steps][4][n_ja4]
+  const int32_t* ja_own;
   const int32_t* ja_glen;
   const int32_t* sl_list;   // [n_slots] slots by decreasing monomial count
   const MonoRec* sl_ell;    // [sl_steps][n_slots] monomials of slot sl_list[i] (padding: coef 0)
@@ -691,30 +693,52 @@ OMGX_FN double rec_coef(const Work& w, double coef, int slot) { return slot < 0 
 // accept step), so it is recomputed where it is needed instead of being stored
 OMGX_FN double row_slack(const Work& w, int r, double t) { return t * w.vv[r] - w.hv[r]; }
 
-// sum of the items of the entry in slot i of an ELL item table (four at a time, all loads in flight)
+// value of one Jacobian item at xv
 template <bool Q4>
-OMGX_FN double jac_entry_ell_t(const JItem* ell, const int32_t* glen, int n_owner, const Work& w, int i, const double* xv) {
-  const int L = glen[i >> 6];
-  double sj = 0.0;
-  for (int s0 = 0; s0 < L; s0 += 4) {
-    JItem q[4];
+OMGX_FN double jitem_value(const JItem& q, const Work& w, const double* xv) {
+  const double xs = w.slots[q.slot < 0 ? 0 : q.slot], xa = xv[q.va < 0 ? 0 : q.va], xb = xv[q.vb < 0 ? 0 : q.vb];
+  double v = q.coef * (q.slot < 0 ? 1.0 : xs) * (q.va < 0 ? 1.0 : xa) * (q.vb < 0 ? 1.0 : xb);
+  if (Q4) { const double xc = xv[q.vc < 0 ? 0 : q.vc]; v *= (q.vc < 0 ? 1.0 : xc); }
+  return v;
+}
+// Jacobian entries from an item table, OMGX_JE_OWN = 4 entries per owner: item `step` of the owner's k-th entry at index
+// (step * 4 + k) * n_own + o, {entry, row} of that entry at own[2 * (k * n_own + o)].  Most entries are one item (config 2:
+// 1784 of 2636; 672 have two, 180 three): with one entry per thread the passes were a chain of single loads -- 10 passes of
+// the workgroup over all entries, 5 over the x-dependent ones; here a thread has the items of four entries in flight, a
+// group of 64 owners whose entries are all single items loads just those.  fn(entry, row, value); items summed in step
+// order.  glen[o >> 6]: items per entry the group walks (1, or a multiple of 2).
+#define OMGX_JE_OWN 4
+template <class C, class F>
+OMGX_FN void jac_entries4(const C& c, const JItem* ell, const int32_t* own, const int32_t* glen, int n_own, const Work& w, const double* xv, F fn) {
+  OMGX_PFOR(o, n_own) {
+    const int L = glen[o >> 6];
+    int32_t er[OMGX_JE_OWN][2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) q[k] = ell[(s0 + k) * n_owner + i];
-    double v[4];
+    for (int k = 0; k < OMGX_JE_OWN; ++k) { const int32_t* q = own + 2 * (k * n_own + o); er[k][0] = q[0]; er[k][1] = q[1]; }
+    double sj[OMGX_JE_OWN];
+    if (L == 1) {
+      JItem q[OMGX_JE_OWN];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const double xs = w.slots[q[k].slot < 0 ? 0 : q[k].slot], xa = xv[q[k].va < 0 ? 0 : q[k].va], xb = xv[q[k].vb < 0 ? 0 : q[k].vb];
-      v[k] = q[k].coef * (q[k].slot < 0 ? 1.0 : xs) * (q[k].va < 0 ? 1.0 : xa) * (q[k].vb < 0 ? 1.0 : xb);
-      if (Q4) { const double xc = xv[q[k].vc < 0 ? 0 : q[k].vc]; v[k] *= (q[k].vc < 0 ? 1.0 : xc); }
+      for (int k = 0; k < OMGX_JE_OWN; ++k) q[k] = ell[k * n_own + o];
+#pragma unroll
+      for (int k = 0; k < OMGX_JE_OWN; ++k) sj[k] = jitem_value<C::general>(q[k], w, xv);
+    } else {
+#pragma unroll
+      for (int k = 0; k < OMGX_JE_OWN; ++k) sj[k] = 0.0;
+      for (int s0 = 0; s0 < L; s0 += 2) {
+        JItem q[2 * OMGX_JE_OWN];
+#pragma unroll
+        for (int k = 0; k < 2 * OMGX_JE_OWN; ++k) q[k] = ell[(s0 * OMGX_JE_OWN + k) * n_own + o];
+        double v[2 * OMGX_JE_OWN];
+#pragma unroll
+        for (int k = 0; k < 2 * OMGX_JE_OWN; ++k) v[k] = jitem_value<C::general>(q[k], w, xv);
+#pragma unroll
+        for (int k = 0; k < OMGX_JE_OWN; ++k) { sj[k] += v[k]; sj[k] += v[OMGX_JE_OWN + k]; }
+      }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sj += v[k];
+    for (int k = 0; k < OMGX_JE_OWN; ++k) if (er[k][0] >= 0) fn(er[k][0], er[k][1], sj[k]);
   }
-  return sj;
-}
-template <class C>
-OMGX_FN double jac_entry_ell(const Dims& d, const JItem* ell, const int32_t* glen, int n_owner, const Work& w, int i, const double* xv) {
-  return jac_entry_ell_t<C::general>(ell, glen, n_owner, w, i, xv);
 }
 
 // unscaled value of the row in slot i (row T.row_perm[i]) at xv: its terms from the ELL table, eight at a
@@ -2027,7 +2051,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // (the unscaled entries go to the KKT store, which is idle during the setup, when that is LDS: the row classification
   // below reads every entry of its row, and with two agents per CU the Jacobian values themselves live in a slab)
   double* jtmp = (C::hbm || kkt_doubles < d.nnz_j + 1) ? w.jval : w.kkt;
-  OMGX_PFOR(i, d.nnz_j) jtmp[T.ja_list[i]] = jac_entry_ell<C>(d, T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
+  jac_entries4(c, T.ja_ell, T.ja_own, T.ja_glen, d.n_ja4, w, w.x, [&](int e, int, double v) { jtmp[e] = v; });
   OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell<C>(d, T, w, i, m, w.x); }
   if (c.tid() == 0) { jtmp[d.nnz_j] = 0.0; w.jval[d.nnz_j] = 0.0; }      // the slot padding records point at
   c.sync();
@@ -2154,13 +2178,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     OMGX_TIC();
     // ---- Jacobian (scaled): one thread per entry; only the entries that depend on x ------------
     if (it > 0) {        // (iteration 0: left by the setup)
-      OMGX_PFOR(i, d.n_jv) {
-        const int e = T.jv_list[i];
-        const int r = d.rp_packed ? (int)((uint32_t)T.je_rp[e] >> 16) : T.je_row[e];
+      jac_entries4(c, T.jv_ell, T.jv_own, T.jv_glen, d.n_jv4, w, w.x, [&](int e, int r, double sj) {
         const double sc = (r < m) ? ((w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r]) : 1.0;
-        const double sj = jac_entry_ell<C>(d, T.jv_ell, T.jv_glen, d.n_jv, w, i, w.x);
         w.jval[e] = sc * sj;
-      }
+      });
     }
     // per row: 1/s (-> ht) and Sigma = z/s (-> ds; stays there for the assembly)
     OMGX_PFOR(r, m) {
@@ -2794,7 +2815,7 @@ OMGX_FN void ipm_eval(const C& c, const Dims& d, const Tables& T, Work& w, const
   OMGX_PFOR(i, n) w.x[i] = x[i];
   if (c.tid() == 0) w.x[n] = 0.0;
   eval_params(c, d, T, w, p);
-  OMGX_PFOR(i, d.nnz_j) w.jval[T.ja_list[i]] = jac_entry_ell<C>(d, T.ja_ell, T.ja_glen, d.nnz_j, w, i, w.x);
+  jac_entries4(c, T.ja_ell, T.ja_own, T.ja_glen, d.n_ja4, w, w.x, [&](int e, int, double v) { w.jval[e] = v; });
   OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell<C>(d, T, w, i, m, w.x); }
   OMGX_PFOR(r, m) w.ht[r] = lam[r];
   OMGX_PFOR(i, kkt_doubles) w.kkt[i] = 0.0;

@@ -50,7 +50,7 @@ struct HostPlan {
   std::vector<RowTerm> rt_ell;
   std::vector<JItem> jv_ell, ja_ell;
   std::vector<MonoRec> sl_ell;
-  std::vector<int32_t> ja_list, ja_glen, sl_list, sl_glen;
+  std::vector<int32_t> ja_own, jv_own, ja_glen, sl_list, sl_glen;
   std::vector<int32_t> rt_glen, jp_ell, jp_glen, cs_ell, cs_glen, cs_col, jv_glen;
   std::vector<HItem> kh_rec, kg_rec;
   std::string error;
@@ -261,6 +261,13 @@ struct HostPlan {
   // dense behind it, a diagonal leaf whose variables meet the root through a few entries each (the terminal slacks)
   // as plain arrays -- config 2: 80 KB -> 42 KB, which is what lets two agents share a CU
   bool compact = false;
+  // (developer print, OMGX_PLAN_DEBUG: how full an ELL table is -- owners, real records, records the groups of 64 walk)
+  static void ell_stats(const char* name, int owners, long real, const std::vector<int32_t>& glen) {
+    if (!getenv("OMGX_PLAN_DEBUG")) return;
+    long walked = 0; std::string g;
+    for (int i = 0; i < (owners + 63) / 64; ++i) { walked += 64L * glen[i]; g += std::to_string(glen[i]) + " "; }
+    fprintf(stderr, "[plan] %-8s owners %5d real %6ld walked %6ld (%.0f %%) group lengths %s\n", name, owners, real, walked, walked ? 100.0 * real / walked : 0.0, g.c_str());
+  }
   bool build(const omgx_template& t, bool col_major_panels = false, bool compact_store = false) {
     col_major = col_major_panels; compact = compact_store;
     Dims& d = dims;
@@ -508,33 +515,39 @@ struct HostPlan {
         if (varying) jv_list.push_back(e);
       }
       d.n_jv = (int)jv_list.size();
-      // x-dependent entries by decreasing item count (homogeneous groups of 64 owners), their items in ELL form
-      std::stable_sort(jv_list.begin(), jv_list.end(), [&](int x, int y) { return (je_ptr[x + 1] - je_ptr[x]) > (je_ptr[y + 1] - je_ptr[y]); });
+      // item tables of jac_entries4: entries by decreasing item count, four in a row per owner (homogeneous groups of 64
+      // owners), {entry, row} beside them
+      auto table4 = [&](std::vector<int>& list, std::vector<JItem>& ell, std::vector<int32_t>& own, std::vector<int32_t>& glen, const char* name) {
+        std::stable_sort(list.begin(), list.end(), [&](int x, int y) { return (je_ptr[x + 1] - je_ptr[x]) > (je_ptr[y + 1] - je_ptr[y]); });
+        const int ne = (int)list.size(), no = (ne + OMGX_JE_OWN - 1) / OMGX_JE_OWN;
+        glen.assign((no + 63) / 64 + 1, 0);
+        int steps = 1; long real = 0;
+        for (int i = 0; i < ne; ++i) {
+          const int cnt = je_ptr[list[i] + 1] - je_ptr[list[i]], len = cnt <= 1 ? 1 : (cnt + 1) / 2 * 2, g = (i / OMGX_JE_OWN) >> 6;
+          glen[g] = std::max(glen[g], len); steps = std::max(steps, len); real += cnt;
+        }
+        ell.assign((size_t)steps * OMGX_JE_OWN * std::max(1, no), JItem{0.0, -1, -1, -1, -1});
+        own.assign((size_t)2 * OMGX_JE_OWN * std::max(1, no), -1);
+        for (int i = 0; i < ne; ++i) {
+          const int o = i / OMGX_JE_OWN, k = i % OMGX_JE_OWN, e = list[i];
+          own[2 * ((size_t)k * no + o)] = e; own[2 * ((size_t)k * no + o) + 1] = je_row[e];
+          for (int q = je_ptr[e]; q < je_ptr[e + 1]; ++q) ell[((size_t)(q - je_ptr[e]) * OMGX_JE_OWN + k) * no + o] = je_item[q];
+        }
+        if (getenv("OMGX_PLAN_DEBUG")) {
+          long walked = 0; for (int g = 0; g < (no + 63) / 64; ++g) walked += 64L * OMGX_JE_OWN * glen[g];
+          fprintf(stderr, "[plan] %-8s entries %5d owners %5d items %6ld walked %6ld\n", name, ne, no, real, walked);
+        }
+        return no;
+      };
+      d.n_jv4 = table4(jv_list, jv_ell, jv_own, jv_glen, "jv");
       {
-        const int no = d.n_jv;
-        jv_glen.assign((no + 63) / 64 + 1, 0);
-        int steps = 0;
-        for (int i = 0; i < no; ++i) { const int len = (je_ptr[jv_list[i] + 1] - je_ptr[jv_list[i]] + 3) / 4 * 4; jv_glen[i >> 6] = std::max(jv_glen[i >> 6], len); steps = std::max(steps, len); }
-        jv_ell.assign((size_t)std::max(1, steps) * std::max(1, no), JItem{0.0, -1, -1, -1, -1});
-        for (int i = 0; i < no; ++i) for (int k = je_ptr[jv_list[i]]; k < je_ptr[jv_list[i] + 1]; ++k) jv_ell[(size_t)(k - je_ptr[jv_list[i]]) * no + i] = je_item[k];
-        T.jv_ell = jv_ell.data(); T.jv_glen = jv_glen.data();
+        std::vector<int> all(d.nnz_j);
+        std::iota(all.begin(), all.end(), 0);
+        d.n_ja4 = table4(all, ja_ell, ja_own, ja_glen, "ja");
       }
-      {
-        // the same for all entries (setup pass)
-        const int no = d.nnz_j;
-        ja_list.resize(std::max(1, no));
-        std::iota(ja_list.begin(), ja_list.end(), 0);
-        std::stable_sort(ja_list.begin(), ja_list.begin() + no, [&](int x, int y) { return (je_ptr[x + 1] - je_ptr[x]) > (je_ptr[y + 1] - je_ptr[y]); });
-        ja_glen.assign((no + 63) / 64 + 1, 0);
-        int steps = 0;
-        for (int i = 0; i < no; ++i) { const int len = (je_ptr[ja_list[i] + 1] - je_ptr[ja_list[i]] + 3) / 4 * 4; ja_glen[i >> 6] = std::max(ja_glen[i >> 6], len); steps = std::max(steps, len); }
-        ja_ell.assign((size_t)std::max(1, steps) * std::max(1, no), JItem{0.0, -1, -1, -1, -1});
-        for (int i = 0; i < no; ++i) for (int k = je_ptr[ja_list[i]]; k < je_ptr[ja_list[i] + 1]; ++k) ja_ell[(size_t)(k - je_ptr[ja_list[i]]) * no + i] = je_item[k];
-        T.ja_list = ja_list.data(); T.ja_ell = ja_ell.data(); T.ja_glen = ja_glen.data();
-      }
+      T.jv_ell = jv_ell.data(); T.jv_own = jv_own.data(); T.jv_glen = jv_glen.data();
+      T.ja_ell = ja_ell.data(); T.ja_own = ja_own.data(); T.ja_glen = ja_glen.data();
       if (je_item.empty()) je_item.push_back(JItem{0.0, -1, -1, -1, -1});
-      if (jv_list.empty()) jv_list.push_back(0);
-      T.jv_list = jv_list.data();
     }
     // (2) rows by decreasing term count: the threads of the first pass get the long rows
     {
@@ -559,6 +572,7 @@ struct HostPlan {
           }
         }
         T.rt_ell = rt_ell.data(); T.rt_glen = rt_glen.data();
+        ell_stats("rt", m, (long)t.row_ptr[m], rt_glen);
         // {Jacobian entry, position} of every row for J dx; padding points at the zero slot jval[nnz_j]
         jp_glen.assign((m + 63) / 64 + 1, 0);
         steps = 0;
@@ -573,6 +587,7 @@ struct HostPlan {
           }
         }
         T.jp_ell = jp_ell.data(); T.jp_glen = jp_glen.data();
+        ell_stats("jp", m, (long)jr_ptr[m], jp_glen);
       }
     }
     // (3) column sums J'w: entries of every column (position) in row order, objective entry apart
@@ -611,6 +626,7 @@ struct HostPlan {
           if (st < (int)own[o].size()) { q[0] = own[o][st].first; q[1] = own[o][st].second; } else { q[0] = d.nnz_j; q[1] = 0; }
         }
         T.cs_ell = cs_ell.data(); T.cs_glen = cs_glen.data(); T.cs_col = cs_col.data();
+        ell_stats("cs", no, (long)cs_rec.size() / 2, cs_glen);
       }
     }
     // (4) KKT assembly.  Every target (a KKT address; for the Gershgorin sums a position) has its records
