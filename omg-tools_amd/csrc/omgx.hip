@@ -972,7 +972,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   UP(ka_rec, plan.ka_rec.size()); UP(kh_rec, plan.kh_rec.size()); UP(kg_rec, plan.kg_rec.size());
   UP(ka_fix, plan.ka_fix.size()); UP(kg_fix, plan.kg_fix.size());
   UP(rt_ell, plan.rt_ell.size()); UP(rt_glen, plan.rt_glen.size()); UP(jp_ell, plan.jp_ell.size()); UP(jp_glen, plan.jp_glen.size());
-  UP(cs_ell, plan.cs_ell.size()); UP(cs_glen, plan.cs_glen.size()); UP(cs_col, plan.cs_col.size());
+  UP(cs_ell, plan.cs_ell.size()); UP(cs_glen, plan.cs_glen.size()); UP(cs_col, plan.cs_col.size()); UP(cs_own, plan.cs_own.size());
   UP(jv_ell, plan.jv_ell.size()); UP(jv_own, plan.jv_own.size()); UP(jv_glen, plan.jv_glen.size());
   UP(ja_ell, plan.ja_ell.size()); UP(ja_own, plan.ja_own.size()); UP(ja_glen, plan.ja_glen.size());
   UP(sl_list, plan.sl_list.size()); UP(sl_glen, plan.sl_glen.size());

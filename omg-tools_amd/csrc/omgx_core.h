@@ -69,7 +69,7 @@ struct Dims {
   int ka_len, kh_len, kg_len;   // records per owner bin (longest bin) of the pair / Hessian / Gershgorin passes
   int n_kafix, n_kgfix;         // targets whose run was cut (fix-up records)
   int side_off, dump_off;       // side slots / per-lane dump slots behind the KKT store
-  int cs_parts;      // threads per column in the column sums J'w
+  int n_cs_own;      // owner threads of the column sums J'w (chunks of the columns)
   int kg_side_dinv;  // 1: the side sums of the Gershgorin pass live in w.dinv, 0: in the side slots behind the KKT store
   int n_owner;       // owner bins in use (<= OMGX_NBIN, the stride of the record tables): the threads of the workgroup the plan was made for
 };
@@ -126,8 +126,9 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* rt_glen;
   const int32_t* jp_ell;    // [jp_steps][n_con][2] {Jacobian entry, position} of row row_perm[i] (padding: entry nnz_j = 0.0)
   const int32_t* jp_glen;
-  const int32_t* cs_ell;    // [cs_steps][n_var * cs_parts][2] {Jacobian entry, row} of column-sum owner o = j * cs_parts + k
+  const int32_t* cs_ell;    // [cs_steps][n_cs_own][2] {Jacobian entry, row} of column-sum owner o (padding: entry nnz_j = 0.0)
   const int32_t* cs_glen;
+  const int32_t* cs_own;    // [n_var + 1] owners of the column in slot j: cs_own[j] .. cs_own[j + 1]
   const int32_t* cs_col;    // [n_var] column (position) of slot j (columns by decreasing length)
   // Jacobian items, four entries per owner (jac_entries4): the x-dependent entries (every iteration) and all entries (setup)
   const JItem* jv_ell;      // [jv_steps][4][n_jv4] items of the owner's k-th entry (entries by decreasing item count, four in a row per owner)
@@ -2193,22 +2194,23 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     c.sync();
     OMGX_TOC(PH_JAC);
     // ---- dual residual, barrier gradient (position order), error measures -------
-    // Column sums over the Jacobian, cs_parts threads per column, each over a strided share of the
-    // column's entries in row order; the shares are combined in part order (fixed-order sums):
+    // Column sums over the Jacobian: a column's entries in row order, in chunks of at most cs_cap records, one owner
+    // thread per chunk (cs_own[j] .. cs_own[j + 1]: the owners of the column in slot j); the chunks are combined in
+    // order (fixed-order sums):
     //   dinv <- grad f + J'z (the dual residual; w.dinv is free until the factorisation),  gbar <- grad f,
     //   xt <- J'(1/s),  sol <- J'(Sigma v) (the phase-I column of the KKT matrix; w.sol is free until the
     //   Newton system is solved, also across the retries of the inertia correction)
     // the barrier gradient grad f + mu J'(1/s) is formed once mu is settled below
     {
-      const int parts = d.cs_parts;
-      double* part = w.kkt;                               // [n * parts][3] staging (the KKT store is idle here)
-      OMGX_PFOR(o, n * parts) {                           // owner o = slot j * parts + part k
+      const int no = d.n_cs_own;
+      double* part = w.kkt;                               // [n_cs_own][3] staging (the KKT store is idle here)
+      OMGX_PFOR(o, no) {
         const int L = T.cs_glen[o >> 6];
         double a_z = 0.0, a_s = 0.0, a_t = 0.0;
         for (int s0 = 0; s0 < L; s0 += 8) {               // eight {entry, row} records at a time
           int32_t e[8], r[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { const int32_t* q = T.cs_ell + 2 * ((s0 + k) * (n * parts) + o); e[k] = q[0]; r[k] = q[1]; }
+          for (int k = 0; k < 8; ++k) { const int32_t* q = T.cs_ell + 2 * ((s0 + k) * no + o); e[k] = q[0]; r[k] = q[1]; }
           double jv[8], vz[8], vs[8], vt[8];
 #pragma unroll
           for (int k = 0; k < 8; ++k) { jv[k] = w.jval[e[k]]; vz[k] = w.z[r[k]]; vs[k] = w.ht[r[k]]; vt[k] = w.ds[r[k]] * w.vv[r[k]]; }
@@ -2220,7 +2222,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       c.sync();
       OMGX_PFOR(j, n) {
         double a_z = 0.0, a_s = 0.0, a_t = 0.0;
-        for (int k = 0; k < parts; ++k) { const double* pp = part + 3 * (j * parts + k); a_z += pp[0]; a_s += pp[1]; a_t += pp[2]; }
+        for (int k = T.cs_own[j]; k < T.cs_own[j + 1]; ++k) { const double* pp = part + 3 * k; a_z += pp[0]; a_s += pp[1]; a_t += pp[2]; }
         const int q = T.cs_col[j];
         const int eo = T.obj_ent[q];
         const double gf = eo >= 0 ? w.jval[eo] : 0.0;
@@ -2703,18 +2705,18 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         }
         OMGX_PFOR(k, d.n_eq) { const int r = T.eq_rows[k]; if (w.rtype[r] != ROW_EQ) w.kkt[rbase + tri(nr, d.n_root + k)] = 0.0; }
         vte = c.rsum(vte);
-        // -J' (Sigma e): one thread per column over its strided shares in part order (the records of the column sums)
+        // -J' (Sigma e): one thread per column over its chunks in order (the records of the column sums; the KKT store
+        // holds the factors: no staging area for partial sums here)
         {
-          const int parts = d.cs_parts;
+          const int no = d.n_cs_own;
           OMGX_PFOR(j, n) {
             double acc = 0.0;
-            for (int k = 0; k < parts; ++k) {
-              const int ow = j * parts + k;
+            for (int ow = T.cs_own[j]; ow < T.cs_own[j + 1]; ++ow) {
               const int L = T.cs_glen[ow >> 6];
               for (int s0 = 0; s0 < L; s0 += 8) {
                 int32_t e[8], r[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { const int32_t* q = T.cs_ell + 2 * ((s0 + i) * (n * parts) + ow); e[i] = q[0]; r[i] = q[1]; }
+                for (int i = 0; i < 8; ++i) { const int32_t* q = T.cs_ell + 2 * ((s0 + i) * no + ow); e[i] = q[0]; r[i] = q[1]; }
                 double jv[8], ve[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { jv[i] = w.jval[e[i]]; ve[i] = w.ht[r[i]]; }

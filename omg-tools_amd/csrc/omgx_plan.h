@@ -51,7 +51,7 @@ struct HostPlan {
   std::vector<JItem> jv_ell, ja_ell;
   std::vector<MonoRec> sl_ell;
   std::vector<int32_t> ja_own, jv_own, ja_glen, sl_list, sl_glen;
-  std::vector<int32_t> rt_glen, jp_ell, jp_glen, cs_ell, cs_glen, cs_col, jv_glen;
+  std::vector<int32_t> rt_glen, jp_ell, jp_glen, cs_ell, cs_glen, cs_col, cs_own, jv_glen;
   std::vector<HItem> kh_rec, kg_rec;
   std::string error;
 
@@ -555,6 +555,40 @@ struct HostPlan {
       std::iota(row_perm.begin(), row_perm.end(), 0);
       std::stable_sort(row_perm.begin(), row_perm.begin() + m, [&](int a, int b) {
         return (t.row_ptr[a + 1] - t.row_ptr[a]) > (t.row_ptr[b + 1] - t.row_ptr[b]); });
+      // The row passes walk the slots i = tid, tid + threads, ...: wave w of pass p owns the group of 64 slots p * waves + w and
+      // walks its longest row.  The sorted groups are dealt to the waves so that no wave collects all the long ones (config 2,
+      // four waves: term steps 16 16 8 8 | 8 8 8 8 | 8 gave wave 0 four batches of eight and wave 3 two; dealt, three at most):
+      // longest group first, to the wave with the least work that still has a free position; the last, partial group keeps
+      // the last position.
+      {
+        const int G = (m + 63) / 64, nw = std::max(1, owners / 64);
+        if (G > nw) {
+          auto steps8 = [](int k) { return (k + 7) / 8 * 8; };
+          std::vector<int> wgt(G, 0);
+          for (int i = 0; i < m; ++i) { const int r = row_perm[i]; wgt[i >> 6] = std::max(wgt[i >> 6], steps8(t.row_ptr[r + 1] - t.row_ptr[r]) + steps8(jr_ptr[r + 1] - jr_ptr[r])); }
+          std::vector<int> room(nw, 0), load(nw, 0);
+          for (int gp = 0; gp < G; ++gp) ++room[gp % nw];
+          std::vector<std::vector<int>> mine(nw);
+          const bool partial = (m % 64) != 0;
+          const int w_last = (G - 1) % nw;
+          if (partial) { --room[w_last]; load[w_last] += wgt[G - 1]; }
+          std::vector<int> gs(partial ? G - 1 : G);
+          std::iota(gs.begin(), gs.end(), 0);
+          std::stable_sort(gs.begin(), gs.end(), [&](int a, int b) { return wgt[a] > wgt[b]; });
+          for (int g : gs) {
+            int best = -1;
+            for (int w2 = 0; w2 < nw; ++w2) if (room[w2] > 0 && (best < 0 || load[w2] < load[best])) best = w2;
+            mine[best].push_back(g); --room[best]; load[best] += wgt[g];
+          }
+          if (partial) mine[w_last].push_back(G - 1);
+          std::vector<int32_t> perm2(row_perm.size(), 0);
+          for (int gp = 0; gp < G; ++gp) {
+            const int g = mine[gp % nw][gp / nw];
+            for (int k = 0; k < 64 && 64 * g + k < m; ++k) perm2[64 * gp + k] = row_perm[64 * g + k];
+          }
+          row_perm = perm2;
+        }
+      }
       T.row_perm = row_perm.data();
       // terms of every row (slot i = row row_perm[i]) in ELL form, eight per step
       {
@@ -603,21 +637,32 @@ struct HostPlan {
       cs_ptr.assign(1, 0); cs_rec.clear();
       for (int q = 0; q < n; ++q) { for (auto& er : cols[q]) { cs_rec.push_back(er.first); cs_rec.push_back(er.second); } cs_ptr.push_back((int)cs_rec.size() / 2); }
       if (cs_rec.empty()) cs_rec.assign(2, 0);
-      int parts = OMGX_NBIN / (n > 0 ? n : 1);
-      if (parts < 1) parts = 1;
-      if (parts > 4) parts = 4;
-      while (parts > 1 && (size_t)4 * n * parts > (size_t)kkt_doubles) --parts;      // the partial sums are staged in the (idle) KKT store
-      d.cs_parts = parts;
       T.cs_ptr = cs_ptr.data(); T.cs_rec = cs_rec.data(); T.obj_ent = obj_ent.data();
-      // owners o = slot j * parts + k (columns by decreasing length in the slots), records in ELL form
+      // owners: the columns by decreasing length, each in chunks of at most `cap` records (a multiple of the batch of
+      // eight the loop loads at a time) -- the smallest cap for which the owners fit the workgroup and their partial sums
+      // the (idle) KKT store; records in ELL form
       {
         cs_col.resize(n);
         std::iota(cs_col.begin(), cs_col.end(), 0);
         std::stable_sort(cs_col.begin(), cs_col.end(), [&](int x, int y) { return (cs_ptr[x + 1] - cs_ptr[x]) > (cs_ptr[y + 1] - cs_ptr[y]); });
-        const int no = n * parts;
+        auto owners_at = [&](int cp) { int k = 0; for (int q = 0; q < n; ++q) k += std::max(1, (cs_ptr[q + 1] - cs_ptr[q] + cp - 1) / cp); return k; };
+        auto fits = [&](int k, int lim) { return k <= lim && (size_t)4 * k <= (size_t)kkt_doubles; };
+        int cap = 8;
+        while (cap < 32 && !fits(owners_at(cap), owners)) cap += 8;                    // one pass of the workgroup if chunks of <= 32 records allow it
+        if (!fits(owners_at(cap), owners)) { cap = 8; while (cap < (1 << 20) && !fits(owners_at(cap), std::max(owners, 2 * n))) cap += 8; }
+        const int no = owners_at(cap);
+        d.n_cs_own = no;
+        cs_own.assign(n + 1, 0);
+        std::vector<std::vector<std::pair<int, int>>> own;
+        for (int j = 0; j < n; ++j) {
+          const int q = cs_col[j], len = cs_ptr[q + 1] - cs_ptr[q], np = std::max(1, (len + cap - 1) / cap);
+          for (int k = 0; k < np; ++k) {
+            own.push_back({});
+            for (int i = cs_ptr[q] + k * len / np; i < cs_ptr[q] + (k + 1) * len / np; ++i) own.back().push_back(std::make_pair(cs_rec[2 * i], cs_rec[2 * i + 1]));
+          }
+          cs_own[j + 1] = (int)own.size();
+        }
         cs_glen.assign((no + 63) / 64 + 1, 0);
-        std::vector<std::vector<std::pair<int, int>>> own(no);
-        for (int j = 0; j < n; ++j) { const int q = cs_col[j]; for (int i = cs_ptr[q]; i < cs_ptr[q + 1]; ++i) own[j * parts + (i - cs_ptr[q]) % parts].push_back(std::make_pair(cs_rec[2 * i], cs_rec[2 * i + 1])); }
         int steps = 0;
         for (int o = 0; o < no; ++o) { const int len = ((int)own[o].size() + 7) / 8 * 8; cs_glen[o >> 6] = std::max(cs_glen[o >> 6], len); steps = std::max(steps, len); }
         cs_ell.assign((size_t)2 * std::max(1, steps) * std::max(1, no), 0);
@@ -625,6 +670,7 @@ struct HostPlan {
           int32_t* q = cs_ell.data() + 2 * ((size_t)st * no + o);
           if (st < (int)own[o].size()) { q[0] = own[o][st].first; q[1] = own[o][st].second; } else { q[0] = d.nnz_j; q[1] = 0; }
         }
+        T.cs_own = cs_own.data();
         T.cs_ell = cs_ell.data(); T.cs_glen = cs_glen.data(); T.cs_col = cs_col.data();
         ell_stats("cs", no, (long)cs_rec.size() / 2, cs_glen);
       }

@@ -44,10 +44,12 @@ def test_mpc_replay_matches_port(cfg2_small):
         # objective is flat in places, so coefficients may differ by millimetres at equal cost)
         xg = gpu.host('x')
         for b in np.nonzero(ok)[0][:3]:
-            cb = nlp.term_coefs(pc[b])
-            fg_, gg_ = nlp.fg(xg[b], cb)
-            fc_, gc_ = nlp.fg(cpu.x[b], cb)
-            assert abs(fg_ - fc_) < 1e-5 * (1 + abs(fc_))
+            # (each plan with the parameters of its own run: the initial-condition rows move with the predicted state,
+            # which the two runs agree on to 2e-4 only)
+            fg_, gg_ = nlp.fg(xg[b], nlp.term_coefs(pg[b]))
+            fc_, gc_ = nlp.fg(cpu.x[b], nlp.term_coefs(pc[b]))
+            assert abs(fg_ - fc_) < 1e-4 * (1 + abs(fc_))
             assert (gg_ - tpl.ub).max() < 1e-5 and (tpl.lb - gg_).max() < 1e-5
+            assert (gc_ - tpl.ub).max() < 1e-5 and (tpl.lb - gc_).max() < 1e-5
     assert crossings == 1
     gpu.solver.close()
