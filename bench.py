@@ -15,6 +15,7 @@ Launch: python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distribut
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -29,6 +30,15 @@ import torch
 
 FP64_MATRIX_PEAK_TFLOPS = 78.6     # MI355X datasheet FP64 matrix (MFMA f64) peak
 HBM_PEAK_GBPS = 8000.0             # MI355X HBM3E (MI355X_MICROARCH.md)
+
+
+def quiet_host():
+    """Before a timed region: collect now and keep the cyclic collector out of the region.  A generation-2 collection of this
+    process (torch + numpy loaded: 35 - 60 ms) in the middle of a loop whose host side runs ahead of the device drains the
+    queue: measured on the rendez-vous bench as 1.2 vs 1.7 - 2.4 ms per step from run to run, the pause landing on a different
+    step with every change of the allocation history (first process on a box: no .pyc yet, another history, no pause)."""
+    gc.collect()
+    gc.disable()
 
 
 def executed_flops_per_iter(tpl):
@@ -325,12 +335,28 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
     barrier()
     stats = torch.zeros((args.steps, 4), dtype=torch.int64, device=dev)     # per x-update: solved, sum / max of iterations, agents
     solver.set_stats(stats)
+    prof = None
+    if os.environ.get('OMGX_BENCH_PROFILE'):               # developer: where the host spends the timed loop
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
+    stamps = []
+    quiet_host()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         status, crossed = mpc.step()                        # nothing leaves the device inside the loop
         crossings += int(crossed)
+        stamps.append(time.perf_counter())
+    if os.environ.get('OMGX_BENCH_STAMPS'):
+        print('host ms per step:', [round((b - a) * 1e3, 2) for a, b in zip([t0] + stamps[:-1], stamps)], file=sys.stderr)
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(14)
+    t_host = time.perf_counter() - t0                      # (enqueue time of the timed steps: far below `elapsed` unless the host is the bound)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     solver.set_stats(None)
     # where an update's time goes (a second, untimed pass with an event after every phase of the iteration: x-update,
     # centre, the two collectives, z / lambda update, read-back -- what a multi-GPU run needs to be diagnosable)
@@ -369,7 +395,7 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
         'solved_fraction': n_ok_all / float(N), 'residuals': list(res), 'knot_crossings_in_timed_steps': crossings,
         'protocol': 'init_iter=5, then per step: update_time 0.1 s, device-side prediction, moving obstacle advanced, knot-crossing shift, 1 ADMM iteration',
         'x_update_mean_iters': float(stats[:, 1].sum()) / max(1, int(stats[:, 3].sum())), 'x_update_max_iters': int(stats[:, 2].max()),
-        'phase_ms': dict((k, round(v, 4)) for k, v in phases.items()),
+        'phase_ms': dict((k, round(v, 4)) for k, v in phases.items()), 'host_enqueue_ms_per_step': t_host / args.steps * 1e3,
         'phase_note': 'rank 0, mean over a separate untimed pass of the same protocol with an event after every phase of the iteration; x_update includes the prediction / shift glue of the step'}))
 
 
@@ -398,6 +424,7 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
     for k in range(args.warmup + args.steps):
         if k == args.warmup:
             barrier()
+            quiet_host()
             t0 = time.perf_counter()
         mpc.x.copy_(x0_init)
         mpc.p.copy_(p_init)
@@ -415,6 +442,7 @@ def bench_cold(args, rank, local_rank, world, dist, dev):
     for _ in range(args.warmup):
         mpc.step()
     barrier()
+    quiet_host()
     t0 = time.perf_counter()
     rh_ok, rh_it = 0, 0
     st_log = torch.zeros((rh_steps, B), dtype=torch.int32, device=dev)
@@ -554,10 +582,12 @@ def main():
     for k in range(W + K):
         if k == W:
             barrier()
+            quiet_host()
             t0 = time.perf_counter()
         mpc.step(events=ev[k])
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     solver.set_stats(None)
     stats = stats.cpu().numpy()             # rows: {solved, sum of iterations, largest iteration count, agents}
     assert (stats[:, 3] == B).all()

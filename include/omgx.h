@@ -342,7 +342,10 @@ int  omgx_batch_store(omgx_batch* b, const double* x, const omgx_store_spec* sp)
 int  omgx_batch_set_store(omgx_batch* b, const omgx_store_spec* sp);
 
 /* Same shift on any device-resident row-major array (stride doubles per row, n_rows rows):
- * used for the ADMM consensus state on a knot crossing (`problems/admm.py:477-491`). */
+ * used for the ADMM consensus state on a knot crossing (`problems/admm.py:477-491`).
+ * The handle keeps the table sets it has seen on the device (16, found again by content): a loop that shifts with the
+ * same few sets at every crossing uploads each once.  n_rows = 0 uploads the set and launches nothing (data may be
+ * NULL) -- ahead of a loop that must not wait for a copy. */
 int  omgx_shift_rows(omgx_batch* b, double* data, int32_t stride, int32_t n_rows, const uint8_t* mask,
                      const int32_t* entries, int32_t n_ent, const double* Tmats, int32_t n_tmat);
 
@@ -392,6 +395,13 @@ int  omgx_admm_communicate(omgx_batch* b, const omgx_admm_layout* lay, const int
  * One multi-rank iteration = solve, center_ex, all_gather, update_ex, all_gather, communicate_ex. */
 int  omgx_admm_center_ex(omgx_batch* b, const omgx_admm_layout* lay, const double* x, const double* p, double* x_i,
                          const int32_t* pub_rows, int32_t n_pub, double* x_send);
+/* The centre step riding on the x-update: after omgx_batch_set_center every omgx_batch_solve writes x_i (and the
+ * published rows into x_send) for the solution it just found, from the solve kernel's epilogue -- what
+ * omgx_admm_center_ex(b, lay, x, p, x_i, pub_rows, n_pub, x_send) would write for the x and p of that solve; one launch
+ * less per ADMM iteration (solve, all_gather, update_ex, all_gather, communicate_ex).  pub_rows: HOST pointer here, every
+ * row at most once.  x_i / x_send must stay valid while set; lay == NULL switches it off. */
+int  omgx_batch_set_center(omgx_batch* b, const omgx_admm_layout* lay, double* x_i, const int32_t* pub_rows, int32_t n_pub,
+                           double* x_send);
 int  omgx_admm_update_ex(omgx_batch* b, const omgx_admm_layout* lay, const double* x_ext, const int32_t* nbr,
                          const double* M, const double* F, double rho, double* p, double* z_ij, double* l_ij,
                          int32_t zl_stride, double* res, double* sums, const int32_t* pub_slot, double* zl_send,

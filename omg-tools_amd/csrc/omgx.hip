@@ -55,6 +55,14 @@ struct KnotArg { double k[40]; };
 // `splines2signals`, e.g. `vehicles/holonomic.py:116-124`): derivative orders 0 .. n_der-1 of the n_spl
 // splines on a time grid, order o scaled by inv_T^o (time derivatives), and optionally the speed
 // v_tot = |first derivative|.  Passed by value to the kernels; out == nullptr: nothing to do.
+// `omgx_admm_center_ex` fused behind the solve (omgx_batch_set_center): x_i[b] = shared coefficients of the solution + the
+// agent's relative position, and its published copy
+struct CenterArgs {
+  int x_spl, p_rel, n_dim, L;
+  double* x_i;
+  const int32_t* pub_inv;     // [B] slot of the agent's row in x_send (-1: not published); nullptr: nothing published
+  double* x_send;
+};
 struct StoreArgs {
   double* out;            // [B, n_der, n_spl, n_samp]
   double* v_tot;          // [B, n_samp] or nullptr (needs n_der >= 2)
@@ -170,7 +178,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  double* __restrict__ slabs, size_t slab_doubles, double* __restrict__ dw_state,
                  const int32_t* __restrict__ order, const StoreArgs* __restrict__ stp, int only_failed,
                  int* __restrict__ next_slot, const double* __restrict__ x0_alt, int n_alt, int32_t* __restrict__ attempts,
-                 unsigned long long* __restrict__ stats, int stagger) {
+                 unsigned long long* __restrict__ stats, int stagger, const CenterArgs* __restrict__ ctr) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
     omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
@@ -240,6 +248,17 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
         atomicAdd(stats + 1, (unsigned long long)r.iters);
         atomicMax(stats + 2, (unsigned long long)r.iters);
         atomicAdd(stats + 3, 1ull);
+      }
+    }
+    if (ctr) {
+      // the ADMM x-update's centre (`omgx_admm_center_ex`) from the solution in LDS: no launch of its own
+      const CenterArgs ca = *ctr;
+      const int ns = ca.n_dim * ca.L;
+      const int slot = ca.pub_inv ? ca.pub_inv[b] : -1;
+      for (int q = threadIdx.x; q < ns; q += blockDim.x) {
+        const double v = w.x[ca.x_spl + q] + p[(size_t)b * d.n_par + ca.p_rel + q / ca.L];
+        ca.x_i[(size_t)b * ns + q] = v;
+        if (slot >= 0) ca.x_send[(size_t)slot * ns + q] = v;
       }
     }
     if (stp) {
@@ -314,7 +333,7 @@ static ipm_eval_kernel_t ipm_eval_kernel_for(int mode, int wave_ok, int general)
 
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
-                             const int32_t*, const StoreArgs*, int, int*, const double*, int, int32_t*, unsigned long long*, int);
+                             const int32_t*, const StoreArgs*, int, int*, const double*, int, int32_t*, unsigned long long*, int, const CenterArgs*);
 // (GEN: the instance that carries the terms with four factors, the cos / sin atoms and the basis rows of any degree --
 // Dims::general; the other one is the kernel of the benchmark classes, free of that code)
 template <bool GEN>
@@ -711,7 +730,11 @@ struct omgx_batch {
   int stats_slots = 0; long long stats_launch = 0;
   StoreArgs store = {};             // trajectories written by the solve kernel (omgx_batch_set_store); out == nullptr: off
   StoreArgs* d_store = nullptr;     // its copy in device memory (what the kernel reads)
+  CenterArgs* d_center = nullptr;   // omgx_batch_set_center: device copy of the arguments (nullptr: off); the slot map behind it
+  int32_t* d_pub_inv = nullptr;
+  bool center_on = false;
   std::vector<void*> allocs;
+  char* arena = nullptr; size_t arena_cap = 0, arena_used = 0;      // bump allocator of the plan's tables (arena_alloc)
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t ext_ev0 = nullptr, ext_ev1 = nullptr;   // caller's events for the next solve launch (one shot)
@@ -729,8 +752,11 @@ struct omgx_batch {
   long long* d_prof = nullptr;
   // shift tables (entries + T matrices) live in the handle: uploaded when they change (a receding-horizon loop
   // passes the same ones at every knot crossing), so that a shift is one stream-ordered launch
-  std::vector<int32_t> shift_ent_host; std::vector<double> shift_T_host;
-  int32_t* d_shift_ent = nullptr; double* d_shift_T = nullptr; size_t shift_ent_cap = 0, shift_T_cap = 0;
+  // (a receding-horizon loop passes the same few sets at every knot crossing -- an ADMM fleet four of them: x, p, z_ij,
+  // l_ij --: each set is uploaded once and found again by content, so that a shift is stream-ordered launches only)
+  struct ShiftSet { std::vector<int32_t> ent; std::vector<double> T; int32_t* d_ent; double* d_T; unsigned long long used; };
+  std::vector<ShiftSet> shift_sets; unsigned long long shift_clock = 0;
+  int32_t* d_shift_ent = nullptr; double* d_shift_T = nullptr;      // the set the last staging call selected
   uint8_t* d_mask = nullptr;
   // omgx_batch_eval: Jacobian entry -> (row, variable), stored Hessian entry -> (address, variable a, variable b)
   std::vector<int32_t> ev_jrow, ev_jvar, ev_hess;
@@ -738,12 +764,27 @@ struct omgx_batch {
 
 namespace {
 
+// The ~60 tables of a plan live in one arena (chunks of 4 MiB, 256-byte aligned pieces) instead of sixty separately
+// placed hipMalloc'ed buffers: every thread of every solve walks them.
+int arena_alloc(omgx_batch* b, size_t bytes, void** out) {
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (!b->arena || b->arena_used + need > b->arena_cap) {
+    const size_t cap = need > ((size_t)4 << 20) ? need : ((size_t)4 << 20);
+    void* ptr = nullptr;
+    HIPCHK(hipMalloc(&ptr, cap));
+    b->allocs.push_back(ptr);
+    b->arena = (char*)ptr; b->arena_cap = cap; b->arena_used = 0;
+  }
+  *out = b->arena + b->arena_used;
+  b->arena_used += need;
+  return OMGX_OK;
+}
+
 template <typename T>
 int upload(omgx_batch* b, const T* src, size_t n, const T** dst) {
   void* ptr = nullptr;
   const size_t bytes = (n > 0 ? n : 1) * sizeof(T);
-  HIPCHK(hipMalloc(&ptr, bytes));
-  b->allocs.push_back(ptr);
+  { const int rc = arena_alloc(b, bytes, &ptr); if (rc != OMGX_OK) return rc; }
   if (n > 0) HIPCHK(hipMemcpy(ptr, src, n * sizeof(T), hipMemcpyHostToDevice));
   *dst = (const T*)ptr;
   return OMGX_OK;
@@ -1259,10 +1300,11 @@ void omgx_batch_destroy(omgx_batch* b) {
   (void)hipSetDevice(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
   if (b->d_store) (void)hipFree(b->d_store);
+  if (b->d_center) (void)hipFree(b->d_center);
+  if (b->d_pub_inv) (void)hipFree(b->d_pub_inv);
   if (b->d_range_src) (void)hipFree(b->d_range_src);
   if (b->d_range_dup) (void)hipFree(b->d_range_dup);
-  if (b->d_shift_ent) (void)hipFree(b->d_shift_ent);
-  if (b->d_shift_T) (void)hipFree(b->d_shift_T);
+  for (auto& ss : b->shift_sets) { if (ss.d_ent) (void)hipFree(ss.d_ent); if (ss.d_T) (void)hipFree(ss.d_T); }
   if (b->d_mask) (void)hipFree(b->d_mask);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -1393,7 +1435,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
                         b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, (const StoreArgs*)(b->store.out ? b->d_store : nullptr), (flags & OMGX_ONLY_FAILED) ? 1 : 0,
                         b->d_next, b->d_x0_alt, b->d_x0_alt ? b->n_alt : 0, b->d_attempts,
                         (unsigned long long*)(b->d_stats ? b->d_stats + 4 * (size_t)(b->stats_launch++ % b->stats_slots) : nullptr),
-                        b->stagger);
+                        b->stagger, (const CenterArgs*)(b->center_on ? b->d_center : nullptr));
   HIPCHK(hipGetLastError());
   if (ranged)
     hipLaunchKernelGGL(range_contract_lam, dim3((B * nu + 255) / 256), dim3(256), 0, b->stream, (const double*)b->d_lam, lam_user_dev, B, nu, ni,
@@ -1513,27 +1555,31 @@ int stage_shift_tables(omgx_batch* b, const int32_t* entries, int32_t n_ent, con
     if (q[1] * q[2] > *max_elems) *max_elems = q[1] * q[2];
   }
   const size_t ne = 4 * (size_t)n_ent, nt = (size_t)n_tmat;
-  const bool same = b->shift_ent_host.size() == ne && b->shift_T_host.size() == nt &&
-                    memcmp(b->shift_ent_host.data(), entries, ne * sizeof(int32_t)) == 0 &&
-                    memcmp(b->shift_T_host.data(), Tmats, nt * sizeof(double)) == 0;
-  if (same) return OMGX_OK;
-  // (stream order: kernels of earlier shifts read the old tables; they are done before these copies start)
-  if (ne > b->shift_ent_cap) {
-    if (b->d_shift_ent) (void)hipFree(b->d_shift_ent);
-    b->d_shift_ent = nullptr; b->shift_ent_cap = 0;
-    HIPCHK(hipMalloc((void**)&b->d_shift_ent, ne * sizeof(int32_t)));
-    b->shift_ent_cap = ne;
+  ++b->shift_clock;
+  for (auto& ss : b->shift_sets)
+    if (ss.ent.size() == ne && ss.T.size() == nt && memcmp(ss.ent.data(), entries, ne * sizeof(int32_t)) == 0 &&
+        memcmp(ss.T.data(), Tmats, nt * sizeof(double)) == 0) {
+      ss.used = b->shift_clock; b->d_shift_ent = ss.d_ent; b->d_shift_T = ss.d_T;
+      return OMGX_OK;
+    }
+  const size_t kShiftSets = 16;
+  if (b->shift_sets.size() >= kShiftSets) {       // the least recently used set goes (its buffers may still be read by a queued launch: hipFree waits)
+    size_t old = 0;
+    for (size_t i = 1; i < b->shift_sets.size(); ++i) if (b->shift_sets[i].used < b->shift_sets[old].used) old = i;
+    (void)hipFree(b->shift_sets[old].d_ent); (void)hipFree(b->shift_sets[old].d_T);
+    b->shift_sets.erase(b->shift_sets.begin() + old);
   }
-  if (nt > b->shift_T_cap) {
-    if (b->d_shift_T) (void)hipFree(b->d_shift_T);
-    b->d_shift_T = nullptr; b->shift_T_cap = 0;
-    HIPCHK(hipMalloc((void**)&b->d_shift_T, nt * sizeof(double)));
-    b->shift_T_cap = nt;
+  omgx_batch::ShiftSet ss;
+  ss.ent.assign(entries, entries + ne); ss.T.assign(Tmats, Tmats + nt); ss.d_ent = nullptr; ss.d_T = nullptr; ss.used = b->shift_clock;
+  HIPCHK(hipMalloc((void**)&ss.d_ent, ne * sizeof(int32_t)));
+  if (hipMalloc((void**)&ss.d_T, nt * sizeof(double)) != hipSuccess) { (void)hipFree(ss.d_ent); g_err = "hipMalloc failed"; return OMGX_E_HIP; }
+  // (fresh buffers nothing in flight reads: plain synchronous copies)
+  if (hipMemcpy(ss.d_ent, ss.ent.data(), ne * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(ss.d_T, ss.T.data(), nt * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(ss.d_ent); (void)hipFree(ss.d_T); g_err = "hipMemcpy failed"; return OMGX_E_HIP;
   }
-  b->shift_ent_host.assign(entries, entries + ne);
-  b->shift_T_host.assign(Tmats, Tmats + nt);
-  HIPCHK(hipMemcpyAsync(b->d_shift_ent, b->shift_ent_host.data(), ne * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_shift_T, b->shift_T_host.data(), nt * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  b->d_shift_ent = ss.d_ent; b->d_shift_T = ss.d_T;
+  b->shift_sets.push_back(std::move(ss));
   return OMGX_OK;
 }
 }  // namespace
@@ -1743,6 +1789,34 @@ int omgx_admm_center_ex(omgx_batch* b, const omgx_admm_layout* lay, const double
   return OMGX_OK;
 }
 
+int omgx_batch_set_center(omgx_batch* b, const omgx_admm_layout* lay, double* x_i, const int32_t* pub_rows, int32_t n_pub, double* x_send) {
+  if (!b) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  if (!lay) { b->center_on = false; return OMGX_OK; }
+  if (!x_i || n_pub < 0 || (n_pub > 0 && (!pub_rows || !x_send)) || lay->n_dim <= 0 || lay->L <= 0 ||
+      lay->x_spl < 0 || lay->x_spl + lay->n_dim * lay->L > b->dims.n_var || lay->p_rel < 0 || lay->p_rel + lay->n_dim > b->dims.n_par) {
+    g_err = "bad argument"; return OMGX_E_INVALID;
+  }
+  HIPCHK(hipSetDevice(b->device));
+  std::vector<int32_t> inv((size_t)b->n_agents, -1);
+  for (int i = 0; i < n_pub; ++i) {
+    const int r = pub_rows[i];
+    if (r < 0 || r >= b->n_agents) { g_err = "published row out of range"; return OMGX_E_INVALID; }
+    if (inv[r] >= 0) { g_err = "a row published twice cannot ride on the solve (use omgx_admm_center_ex)"; return OMGX_E_INVALID; }
+    inv[r] = i;
+  }
+  if (!b->d_center) HIPCHK(hipMalloc((void**)&b->d_center, sizeof(CenterArgs)));
+  if (n_pub > 0 && !b->d_pub_inv) HIPCHK(hipMalloc((void**)&b->d_pub_inv, sizeof(int32_t) * (size_t)b->n_agents));
+  CenterArgs ca;
+  ca.x_spl = lay->x_spl; ca.p_rel = lay->p_rel; ca.n_dim = lay->n_dim; ca.L = lay->L;
+  ca.x_i = x_i; ca.pub_inv = n_pub > 0 ? b->d_pub_inv : nullptr; ca.x_send = x_send;
+  // (pageable host memory: the copies are staged before the calls return)
+  if (n_pub > 0) HIPCHK(hipMemcpyAsync(b->d_pub_inv, inv.data(), sizeof(int32_t) * inv.size(), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_center, &ca, sizeof(CenterArgs), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  b->center_on = true;
+  return OMGX_OK;
+}
+
 int omgx_admm_update(omgx_batch* b, const omgx_admm_layout* lay, const double* x_ext, const int32_t* nbr,
                      const double* M, const double* F, double rho, double* p, double* z_ij, double* l_ij,
                      double* res) {
@@ -1803,11 +1877,12 @@ int omgx_admm_communicate_ex(omgx_batch* b, const omgx_admm_layout* lay, const i
 int omgx_shift_rows(omgx_batch* b, double* data, int32_t stride, int32_t n_rows, const uint8_t* mask,
                     const int32_t* entries, int32_t n_ent, const double* Tmats, int32_t n_tmat) {
   // device-pointer variant of omgx_batch_shift for arbitrary row-major arrays (p, z_ij, l_ij ...); stream-ordered
-  if (!b || !data || !entries || !Tmats || n_ent <= 0 || n_rows <= 0 || n_tmat <= 0 || stride <= 0) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  if (!b || (!data && n_rows > 0) || !entries || !Tmats || n_ent <= 0 || n_rows < 0 || n_tmat <= 0 || stride <= 0) { g_err = "bad argument"; return OMGX_E_INVALID; }
   HIPCHK(hipSetDevice(b->device));
   int max_elems = 0;
   int rc = stage_shift_tables(b, entries, n_ent, Tmats, n_tmat, stride, &max_elems);
   if (rc != OMGX_OK) return rc;
+  if (n_rows == 0) return OMGX_OK;            // (tables uploaded ahead of the loop that will use them)
   hipLaunchKernelGGL(shift_kernel, dim3(n_rows), dim3(64), max_elems * sizeof(double), b->stream, data, stride,
                      mask, b->d_shift_ent, n_ent, b->d_shift_T);
   HIPCHK(hipGetLastError());

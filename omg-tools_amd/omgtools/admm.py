@@ -16,6 +16,8 @@ history stays on the device until somebody asks for it.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from .distributed import shard_range
@@ -131,9 +133,9 @@ class BatchADMM(object):
         status = ops.solve()                                   # x-update
         self._mark('x_update')
         if self.exchanging() and not self.nesterov and getattr(ops, 'fused', False):
-            # sharded fleet, no copies around the collectives: four launches and two all_gathers per iteration, every
+            # sharded fleet, no copies around the collectives: three launches and two all_gathers per iteration, every
             # kernel reads and writes the exchange buffers in place (include/omgx.h omgx_admm_*_ex)
-            ops.center(lay)                                    # x_i rows + the rows other ranks need -> send buffer
+            ops.center(lay)                                    # x_i rows + the rows other ranks need -> send buffer (left there by the x-update's epilogue: no launch)
             self._mark('centre')
             ops.gather_x(self.dist)                            # collective #1, straight behind the local rows
             self._mark('collective_x')
@@ -328,6 +330,17 @@ class FormationMPC(object):
         self.admm.initialize()
         for _ in range(self.init_iter):
             self.admm.iterate(0.0, sync=False)
+        # the z-update matrices of every time an update can happen at (the multiples of update_time modulo knot_time: one
+        # period) go to the device now -- what the reference's exporter generates ahead of time as updz.so -- so that no
+        # step computes and uploads one (formation bench: 0.44 -> 0.39 ms per update)
+        if hasattr(self.ops, 'stage_shift'):            # (and the shift tables of the knot crossings)
+            self.ops.stage_shift(*self.shift)
+        from .backend import admm_table_keys
+        try:
+            for t_rel in admm_table_keys(self.knot_time, self.update_time, 256):
+                self.admm.matrices(t_rel)
+        except ValueError:                              # incommensurable times: matrices as they come
+            pass
 
     def step(self):
         lay, ops = self.lay, self.ops
@@ -391,8 +404,11 @@ class HipAdmmOps(object):
             [C.c_void_p] * 3 + [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32]
         lib.omgx_admm_communicate_ex.argtypes = [C.c_void_p, C.POINTER(AdmmLayoutC)] + [C.c_void_p] * 4 + [C.c_int32] + \
             [C.c_void_p] * 2 + [C.c_int32, C.c_int32, C.c_void_p]
+        if not os.environ.get('OMGX_NO_FUSED_CENTER'):       # (developer knob: the centre step as its own launch)
+            lib.omgx_batch_set_center.argtypes = [C.c_void_p, C.POINTER(AdmmLayoutC), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         self.zl_stride = self.nn * self.ns             # doubles between the z_ij (l_ij) rows of consecutive agents
         self.fused = False
+        self.center_fused = self._xi_fresh = False
         self.launches = self.collectives = 0           # kernel launches / collectives issued (tests count them per iteration)
         self._sum_blocks, self._sum_k, self._sums = [], 0, None     # fleet residual sums, one row per update (history)
         solver.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -402,6 +418,19 @@ class HipAdmmOps(object):
         self.alpha = torch.ones((), **f64)
         self.c_res_p = None
         self._prev = None
+        self.fuse_center()
+
+    def fuse_center(self):
+        """The centre step rides on the x-update (`omgx_batch_set_center`): every solve leaves x_i -- and, sharded, the rows
+        other ranks need in x_send -- behind; `center` then has nothing to launch.  Called again when the exchange
+        buffers are (re)bound.  A fleet that publishes a row twice keeps the separate launch."""
+        if os.environ.get('OMGX_NO_FUSED_CENTER'):
+            return
+        pub = np.ascontiguousarray(self.halo.publish_local, dtype=np.int32) if self.fused else np.zeros(0, dtype=np.int32)
+        rc = self.solver.lib.omgx_batch_set_center(
+            self.solver._h, C.byref(self.layc), self.x_i.data_ptr(), pub.ctypes.data if len(pub) else None, len(pub),
+            self.x_send.data_ptr() if len(pub) else None)
+        self.center_fused, self._xi_fresh = (rc == 0), False
 
     # -- phase timeline (bench.py): `timeline = []` switches it on, `phase_times()` reads it after a synchronisation ----
     timeline = None
@@ -457,6 +486,7 @@ class HipAdmmOps(object):
         self._pub_rows = t.as_tensor(np.ascontiguousarray(halo.publish_local), dtype=t.int32, device=self.dev)
         self._pub_slot = t.as_tensor(np.ascontiguousarray(halo.pub_slot), dtype=t.int32, device=self.dev)
         self.fused = True
+        self.fuse_center()
 
     def asarray(self, a):
         return self.torch.as_tensor(np.ascontiguousarray(a), dtype=self.torch.float64, device=self.dev)
@@ -500,9 +530,12 @@ class HipAdmmOps(object):
                                  self.status, self.iters, bounds_shared=True)
         self.x, self.x_new = self.x_new, self.x
         self.launches += 1
+        self._xi_fresh = self.center_fused
         return self.status
 
     def center(self, lay):
+        if self._xi_fresh:                          # (written by the solve that just ran)
+            return self.x_i
         n_pub = len(self.halo.publish_local) if self.fused else 0
         self._chk(self.solver.lib.omgx_admm_center_ex(
             self.solver._h, C.byref(self.layc), self.x.data_ptr(), self.p.data_ptr(), self.x_i.data_ptr(),
@@ -657,9 +690,11 @@ class HipAdmmOps(object):
         t = self.torch
         idx = t.as_tensor(np.asarray(cols), dtype=t.int64, device=self.dev)
         self._t_rho = None
+        self._xi_fresh = False
         self.p[:, idx] = t.as_tensor(np.ascontiguousarray(p_host[:, cols]), dtype=t.float64, device=self.dev)
 
     def upload_x(self, x_host):
+        self._xi_fresh = False
         self.x.copy_(self.torch.as_tensor(np.ascontiguousarray(x_host), dtype=self.torch.float64, device=self.dev))
 
     def download_x(self):
@@ -669,6 +704,7 @@ class HipAdmmOps(object):
         """Knot crossing: x <- T x for every spline variable, and the same shift of the consensus
         state z_i, l_i, z_ji, l_ji (inside p) and z_ij, l_ij (`admm.py:477-491`)."""
         lib, h = self.solver.lib, self.solver._h
+        self._xi_fresh = False
         lib.omgx_shift_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_int32, C.c_void_p, C.c_int32]
         for data, stride, (ents, mats) in ((self.x, self.x.shape[1], shift_x), (self.p, self.p.shape[1], shift_p),
@@ -680,6 +716,18 @@ class HipAdmmOps(object):
                 continue
             self._chk(lib.omgx_shift_rows(h, data.data_ptr(), int(stride), self.B, None, ents.ctypes.data,
                                           len(ents), mats.ctypes.data, mats.size), 'omgx_shift_rows')
+
+    def stage_shift(self, shift_x, shift_p, shift_side):
+        """The shift tables of `shift` uploaded ahead of the loop (n_rows = 0: nothing launched)."""
+        lib, h = self.solver.lib, self.solver._h
+        lib.omgx_shift_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_int32, C.c_void_p, C.c_int32]
+        for stride, (ents, mats) in ((self.x.shape[1], shift_x), (self.p.shape[1], shift_p), (self.zl_stride, shift_side)):
+            ents = np.ascontiguousarray(ents, dtype=np.int32)
+            mats = np.ascontiguousarray(mats, dtype=np.float64)
+            if len(ents):
+                self._chk(lib.omgx_shift_rows(h, None, int(stride), 0, None, ents.ctypes.data, len(ents), mats.ctypes.data, mats.size),
+                          'omgx_shift_rows')
 
     def exchange(self, local, halo, dist, extra=None):
         """One all_gather: every rank sends the rows other ranks need (+ one row carrying `extra`, whose sum

@@ -37,6 +37,18 @@ def test_batch_admm_matches_numpy_backend():
         assert np.abs(ops.z_ij.cpu().numpy() - cpu_ops.z_ij).max() < 1e-6
         assert np.abs(ops.p.cpu().numpy() - cpu_ops.p).max() < 1e-6
     assert gpu.residuals[-1][0] < gpu.residuals[0][0]
+    # the centre step rode on the x-updates (omgx_batch_set_center: no launch of its own): what the solve kernel's epilogue
+    # left in x_i is, bit for bit, what the stand-alone launch writes for the same x and p
+    ops = gpu.ops
+    assert ops.center_fused
+    l0 = ops.launches
+    ops.solve()
+    fused = ops.center(lay).clone()
+    assert ops.launches == l0 + 1
+    ops._xi_fresh = False
+    alone = ops.center(lay)
+    assert ops.launches == l0 + 2
+    assert torch.equal(fused, alone)
     solver.close()
 
 
