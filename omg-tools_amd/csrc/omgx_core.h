@@ -1263,11 +1263,15 @@ OMGX_FN void ldl_blocked(const C& c, const BMat* Ms, int nm, double* A, double* 
 // by the workgroup; the plan tables they come from are global memory, i.e. a chain of dependent
 // loads per look-up), followed by the staging area and the panel buffers.
 template <class C>
-OMGX_FN void kkt_describe(const C& c, const Dims& d, const Kkt& K, Work& w) {
+OMGX_FN void kkt_describe(const C& c, const Dims& d, const Kkt& K, Work& w, bool sync_after = true) {
+  // (one thread, a chain of table loads: the first thread of the SECOND wave, so that a caller whose next stage is serial work
+  // of thread 0 -- the parameter program -- can let the two chains run side by side: sync_after = false, the barriers of
+  // that stage make the descriptors visible)
+  const int who = c.nthr() > 64 ? 64 : 0;
   BMat* Ms = (BMat*)w.col;
   double* stage = w.col + OMGX_BMAT_DOUBLES * (OMGX_MAX_LEAF + 1);
   const int pan0 = (int)(stage + OMGX_STAGE_LD * (OMGX_MAX_LEAF + 1) - w.col);
-  if (c.tid() == 0) {
+  if (c.tid() == who) {
     int pan = pan0;
     for (int l = 0; l < d.n_leaf; ++l) {
       BMat& M = Ms[l];
@@ -1285,7 +1289,7 @@ OMGX_FN void kkt_describe(const C& c, const Dims& d, const Kkt& K, Work& w) {
     Mr.a = C::root_lds ? 0 : K.d_off[d.n_leaf]; Mr.ld = 0; Mr.nfact = d.nr; Mr.rows = d.nr + 1; Mr.npos = d.n_root; Mr.dinv = -1; Mr.pan = pan0; Mr.cpl = 0; Mr.bw = d.nr;
     Mr.pad_ = K.d_off[d.n_leaf];      // where the assembly writes the root block (Mr.a: where the factorisation reads it)
   }
-  c.sync();
+  if (sync_after) c.sync();
 }
 
 #ifndef OMGX_HOST_PORT
@@ -2031,8 +2035,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   Result res; res.status = 1; res.iters = 0; res.f = 0; res.mu = o.mu_init; res.t = 0; res.dw = 0;
   Kkt K; K.bind(d, T, w.kkt);
   OMGX_TIC();
-  kkt_describe(c, d, K, w);
-  OMGX_TOC(PH_S_DESC);
+  kkt_describe(c, d, K, w, false);      // (beside the parameter program of eval_params, whose barriers publish it)
 
   // the per-agent inputs come from HBM (~1 us each if loaded where they are first needed): all of
   // them are requested here, so that their latencies overlap with each other and with the parameter
@@ -2053,7 +2056,6 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // below reads every entry of its row, and with two agents per CU the Jacobian values themselves live in a slab)
   double* jtmp = (C::hbm || kkt_doubles < d.nnz_j + 1) ? w.jval : w.kkt;
   jac_entries4(c, T.ja_ell, T.ja_own, T.ja_glen, d.n_ja4, w, w.x, [&](int e, int, double v) { jtmp[e] = v; });
-  OMGX_PFOR(i, m) { const int r = T.row_perm[i]; w.hv[r] = row_value_ell<C>(d, T, w, i, m, w.x); }
   if (c.tid() == 0) { jtmp[d.nnz_j] = 0.0; w.jval[d.nnz_j] = 0.0; }      // the slot padding records point at
   c.sync();
   OMGX_TOC(PH_S_JAC0);
@@ -2065,6 +2067,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     const int r = T.row_perm[ir];
     const int Lr = T.jp_glen[ir >> 6];
     const double l = lb[r], u = ub[r];
+    const double g = row_value_ell<C>(d, T, w, ir, m, w.x);      // (the row's value in the same pass: its term loads fly with the bounds and the entry list)
     const bool fl = isfinite(l), fu = isfinite(u);
     int ty = ROW_FREE;
     if (fl && fu) ty = (l == u) ? ROW_EQ : ROW_BAD;
@@ -2089,7 +2092,6 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     const double sg = (ty == ROW_LOWER) ? -1.0 : 1.0;
     w.rho[r] = sg * rho;                                  // signed scale: h = rho*(g - bound)
     const double bnd = (ty == ROW_LOWER || ty == ROW_EQ) ? l : (ty == ROW_UPPER ? u : 0.0);
-    const double g = w.hv[r];
     const double h = (ty == ROW_FREE) ? 0.0 : w.rho[r] * (g - bnd);
     w.hv[r] = h;
     double v = 0.0;
