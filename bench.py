@@ -113,12 +113,12 @@ def sample_roofline(torch, tpl, veh, dev, n_agents, horizon_time, reps=20):
 
 def measured_traffic(n_agents):
     """HBM bytes per launch of ipm_solve_kernel over receding-horizon steps, from the committed PMC
-    passes (profiles/r02_pmc_hbm.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    passes (profiles/r04_pmc_hbm.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
     this bench at 1024 agents; launches 0-3 are the cold solves, the rest warm steps); None for
     other batch sizes.  Counter unit KB; FETCH_SIZE doubled: on gfx950 rocprofv3 reports half the bytes of wide
     coalesced reads (MI355X_MICROARCH.md, HBM section) -- the table records are 16-byte-per-lane loads -- so this is
     an upper bound for the mixed access widths of this kernel; WRITE_SIZE as reported."""
-    path = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm.json')          # (collected by tools/run_profiles.sh with this round's kernel)
+    path = os.path.join(ROOT, 'profiles', 'r04_pmc_hbm.json')          # (collected by tools/run_profiles.sh with this round's kernel)
     if n_agents != 1024 or not os.path.exists(path):
         return None
     d = json.load(open(path))
