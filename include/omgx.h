@@ -216,8 +216,10 @@ int  omgx_batch_set_restarts(omgx_batch* b, const double* x0_alt_device, int32_t
 int  omgx_batch_lds_bytes(const omgx_batch* b);
 /* Workspace placement chosen at create: mode 0 = every per-agent array in LDS; 1 = KKT store in an
  * HBM slab (leaf panels by columns); 2 = + Jacobian values; 3 = + the per-row arrays (the O(n_var)
- * vectors, the matrix descriptors and a copy of the root block stay in LDS).  Spill modes run
- * min(n_agents, n_slabs) persistent workgroups that take their agents from an atomic counter. */
+ * vectors, the matrix descriptors and a copy of the root block stay in LDS); 4 = compact KKT store and row arrays in
+ * LDS, Jacobian values and row values in the slab; 5 = as 4 with the row values in LDS (4 and 5: templates on the wave
+ * path, two agents per CU when the rest fits half a CU).  Every mode runs min(n_agents, n_slabs) persistent workgroups
+ * that take their agents from an atomic counter. */
 int  omgx_batch_workspace(const omgx_batch* b, int32_t* mode, int64_t* lds_bytes,
                           int64_t* hbm_bytes_per_slab, int32_t* n_slabs);
 

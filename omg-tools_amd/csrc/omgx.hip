@@ -316,13 +316,14 @@ typedef void (*ipm_eval_kernel_t)(omgx::Dims, omgx::Tables, int, const double*, 
 template <bool GEN>
 static ipm_eval_kernel_t ipm_eval_kernel_gen(int mode, int wave_ok) {
 #ifdef OMGX_ONLY_HEADLINE
-  return ipm_eval_kernel<omgx::WS_JAC_ONLY, true, false>;
+  return ipm_eval_kernel<omgx::WS_JAC_HV, true, false>;
 #else
   switch (mode) {
     case omgx::WS_LDS: return wave_ok ? ipm_eval_kernel<omgx::WS_LDS, true, GEN> : ipm_eval_kernel<omgx::WS_LDS, false, GEN>;
     case omgx::WS_KKT_HBM: return ipm_eval_kernel<omgx::WS_KKT_HBM, false, GEN>;
     case omgx::WS_JAC_HBM: return ipm_eval_kernel<omgx::WS_JAC_HBM, false, GEN>;
     case omgx::WS_JAC_ONLY: return ipm_eval_kernel<omgx::WS_JAC_ONLY, true, GEN>;
+    case omgx::WS_JAC_HV: return ipm_eval_kernel<omgx::WS_JAC_HV, true, GEN>;
     default: return ipm_eval_kernel<omgx::WS_ROWS_HBM, false, GEN>;
   }
 #endif
@@ -339,13 +340,14 @@ typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const do
 template <bool GEN>
 static ipm_kernel_t ipm_kernel_gen(int mode, int wave_ok) {
 #ifdef OMGX_ONLY_HEADLINE      // developer builds (register counts of one instance in a third of the compile time): only the kernel of the benchmark class
-  return ipm_solve_kernel<omgx::WS_JAC_ONLY, true, false>;
+  return ipm_solve_kernel<omgx::WS_JAC_HV, true, false>;
 #else
   switch (mode) {
     case omgx::WS_LDS: return wave_ok ? ipm_solve_kernel<omgx::WS_LDS, true, GEN> : ipm_solve_kernel<omgx::WS_LDS, false, GEN>;
     case omgx::WS_KKT_HBM: return ipm_solve_kernel<omgx::WS_KKT_HBM, false, GEN>;
     case omgx::WS_JAC_HBM: return ipm_solve_kernel<omgx::WS_JAC_HBM, false, GEN>;
     case omgx::WS_JAC_ONLY: return ipm_solve_kernel<omgx::WS_JAC_ONLY, true, GEN>;
+    case omgx::WS_JAC_HV: return ipm_solve_kernel<omgx::WS_JAC_HV, true, GEN>;
     default: return ipm_solve_kernel<omgx::WS_ROWS_HBM, false, GEN>;
   }
 #endif
@@ -816,7 +818,7 @@ int pick_mode(const omgx::Dims& d, int kkt_doubles, size_t* lds_doubles, size_t*
 // The plan of a template for the workspace mode it gets: the spill modes store the leaf panels by columns
 // (omgx_plan.h `col_major`), so their plan is built a second time once the mode is known.
 // Templates on the register-resident wave path get the compact store; when their workspace then fits half a CU -- all
-// of it, or with the Jacobian values and hv in a slab (WS_JAC_ONLY) -- two agents share a CU: *per_cu = 2, workgroups
+// of it, or with the Jacobian values (WS_JAC_HV) and the row values hv (WS_JAC_ONLY) in a slab -- two agents share a CU: *per_cu = 2, workgroups
 // of 256 threads (a solve is latency bound: four waves are as fast as eight, and the second agent fills the gaps).
 bool plan_for_mode(omgx::HostPlan& plan, const omgx_template& t, int* mode, size_t* lds_doubles, size_t* hbm_doubles, int* per_cu) {
   *per_cu = 1;
@@ -826,20 +828,20 @@ bool plan_for_mode(omgx::HostPlan& plan, const omgx_template& t, int* mode, size
     plan = omgx::HostPlan();
     plan.owners = 256;        // (the assembly records dealt to the 256 threads of a two-per-CU workgroup)
     if (!plan.build(t, false, true)) return false;
-    const int cand[2] = {omgx::WS_LDS, omgx::WS_JAC_ONLY};
+    const int cand[3] = {omgx::WS_LDS, omgx::WS_JAC_HV, omgx::WS_JAC_ONLY};
     // (two per CU = workgroups of four waves: the substitutions gather 64 doubles per wave in the scratch behind the
     // matrix descriptors, four of the eight blocks suffice)
     plan.dims.col_doubles -= 4 * 64;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
       omgx::work_split(plan.dims, plan.kkt_doubles, cand[k], lds_doubles, hbm_doubles);
       if (*lds_doubles * sizeof(double) <= (size_t)kLdsHalf && !getenv("OMGX_ONE_PER_CU")) { *mode = cand[k]; *per_cu = 2; return true; }
     }
     plan = omgx::HostPlan();
     if (!plan.build(t, false, true)) return false;
     // one agent per CU: everything in LDS, or the Jacobian values in a slab (the register-resident factorisation either way)
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
       omgx::work_split(plan.dims, plan.kkt_doubles, cand[k], lds_doubles, hbm_doubles);
-      if (*lds_doubles * sizeof(double) <= (size_t)kLdsLimit && !(k == 1 && getenv("OMGX_NO_JAC_ONLY_FULL"))) { *mode = cand[k]; return true; }
+      if (*lds_doubles * sizeof(double) <= (size_t)kLdsLimit && !(k >= 1 && getenv("OMGX_NO_JAC_ONLY_FULL"))) { *mode = cand[k]; return true; }
     }
     plan = omgx::HostPlan();
     if (!plan.build(t)) return false;
@@ -1283,7 +1285,7 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_err = "hipGetDeviceProperties failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
     int per_cu = (int)((size_t)kLdsLimit / (b->lds_bytes > 0 ? b->lds_bytes : 1));
     per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
-    if (b->ws_mode == omgx::WS_LDS || b->ws_mode == omgx::WS_JAC_ONLY) per_cu = b->per_cu;      // (bound by the registers of 512-thread workgroups otherwise)
+    if (b->ws_mode == omgx::WS_LDS || b->ws_mode == omgx::WS_JAC_ONLY || b->ws_mode == omgx::WS_JAC_HV) per_cu = b->per_cu;      // (bound by the registers of 512-thread workgroups otherwise)
     int slabs = prop.multiProcessorCount * per_cu;
     if (slabs > n_agents) slabs = n_agents;
     b->n_slabs = slabs;

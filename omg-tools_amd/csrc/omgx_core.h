@@ -254,7 +254,9 @@ struct Work {
 // Mode 4 is the other direction: templates on the register-resident wave path whose workspace then fits HALF a CU --
 // two workgroups (agents) per CU -- put the Jacobian values and the row values hv into the slab and keep the
 // (compact) KKT store and every array the owner passes gather from in LDS.
-enum { WS_LDS = 0, WS_KKT_HBM = 1, WS_JAC_HBM = 2, WS_ROWS_HBM = 3, WS_JAC_ONLY = 4, WS_MODES = 5 };
+// Mode 5 (round 4) is mode 4 with the row values hv back in LDS, for templates that still fit half a CU then (config 2: 80,280 B):
+// hv is read by a dozen row passes per iteration, each a dependent global load per pass of the workgroup (+2 % solves/s).
+enum { WS_LDS = 0, WS_KKT_HBM = 1, WS_JAC_HBM = 2, WS_ROWS_HBM = 3, WS_JAC_ONLY = 4, WS_JAC_HV = 5, WS_MODES = 6 };
 OMGX_HD constexpr bool ws_kkt_hbm(int mode) { return mode >= WS_KKT_HBM && mode <= WS_ROWS_HBM; }
 OMGX_HD constexpr bool ws_jac_hbm(int mode) { return mode >= WS_JAC_HBM; }
 OMGX_HD constexpr bool ws_rows_hbm(int mode) { return mode == WS_ROWS_HBM; }
