@@ -254,6 +254,38 @@ def store_leg(mpc, problem, tpl, x0_init, p_init, n_steps, dev):
             'note': 'state / input / dinput / v_tot of every agent on 1001 samples, written by the solve kernel (A11 fused)'}
 
 
+def rollout_leg(mpc, x0_init, p_init, n_steps, warmup, dev):
+    """The same protocol -- cold solve, `warmup` steps, `n_steps` timed steps -- with the timed steps in ONE launch
+    (`omgx_batch_rollout`): every agent runs its own predict / shift / solve loop without the barrier between the steps of
+    different agents (they are independent problems).  Bit-identical plans to the stepwise loop (tests/test_gpu_rollout.py).
+    Not the headline: a deployment that feeds measured states back needs the per-step launch."""
+    B = mpc.B
+    mpc.x.copy_(x0_init); mpc.p.copy_(p_init); mpc.time = 0.0
+    mpc.solve_cold(bends=())
+    for _ in range(warmup):
+        mpc.step()
+    stats = torch.zeros((n_steps, 4), dtype=torch.int64, device=dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); b.record()
+    torch.cuda.synchronize()
+    mpc.solver.set_stats(stats)
+    mpc.solver.set_launch_events(a, b)
+    quiet_host()
+    t_0 = time.perf_counter()
+    crossings = mpc.rollout(n_steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t_0
+    gc.enable()
+    mpc.solver.set_stats(None)
+    st = stats.cpu().numpy()
+    assert (st[:, 3] == B).all()
+    n_ok = float(st[:, 0].sum()) / n_steps
+    return {'solves_per_s': n_ok * n_steps / wall, 'ms_per_step': wall / n_steps * 1e3, 'kernel_ms_per_step': a.elapsed_time(b) / n_steps,
+            'steps': n_steps, 'warmup': warmup, 'solved_fraction': n_ok / B, 'mean_iters': float(st[:, 1].sum()) / (n_steps * B),
+            'step_max_iters': [int(v) for v in st[:, 2]], 'knot_crossings': crossings,
+            'note': 'the timed steps in one launch (omgx_batch_rollout): no barrier between the steps of different agents; the same bits as the stepwise loop'}
+
+
 def without_solver_objects(fn, *a, **kw):
     """A front-end builder called for its template only (`Point2point.init` would create a solver object of its own)."""
     import omgtools.backend as be
@@ -654,6 +686,7 @@ def main():
         out['latency_host_boundary'] = latency_episodes(mpc, x0_init, p_init, 5, 40, host=True)
         out['survey_8d_obstacle_rule'] = unedited_rule(args, dev, 20240807 + 2)
         out['trajectory_store_fused'] = store_leg(mpc, problem, tpl, x0_init, p_init, 20, dev)
+        out['rollout'] = rollout_leg(mpc, x0_init, p_init, args.steps, args.warmup, dev)
     if world == 1:
         # trajectory extraction (A11) against the HBM roofline, at the workload's batch and at 16x (the
         # 49 MB of one 1024-agent launch last ~10 us: launch-latency bound)

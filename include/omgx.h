@@ -322,6 +322,39 @@ int  omgx_batch_predict_quadrotor(omgx_batch* b, const double* x, double* p, int
                                   const int32_t* p_off, int32_t p_t, double t_value, const double* state_in, double* state_out,
                                   int32_t n_sub, double dtau, double g);
 
+/* K receding-horizon steps of every agent in ONE launch.  The agents of a point-to-point batch are independent
+ * (`Simulator.run` -> `Deployer.update`, `execution/deployer.py:43-79`, loops over update times for its vehicles; nothing
+ * couples two problems), so a persistent workgroup runs the whole loop of an agent -- ideal prediction of the initial
+ * conditions from the current plan (omgx_batch_predict_ex, ideal mode), moving obstacles advanced by
+ * x += dt v + dt^2 / 2 a, v += dt a (`environment/obstacle.py:246-264`), on a knot crossing the plan shifted (omgx_batch_shift)
+ * and the multipliers moved by index (lam_perm[r] = row whose multiplier warm-starts row r, -1: none), warm-started solve --
+ * n_steps times before it takes the next agent: per agent the same statements, the same bits, as n_steps rounds of the
+ * separate calls; what goes is the barrier between the steps of different agents.  p, x, lam_g, status, iters are updated
+ * in place (device pointers: OMGX_PTR_DEVICE | OMGX_BOUNDS_DEVICE required; OMGX_BOUNDS_SHARED as for omgx_batch_solve);
+ * the handle's options apply (warm_start = 1 expected), cross_options (optional) to the solves right after a crossing.
+ * With omgx_batch_set_stats step k of the call fills the next free row.  iters_log / status_log (optional, device,
+ * [n_steps][n_agents]) keep the per-step values.  Templates of the wave path without two-sided rows only (config 1 / 2
+ * class, ADMM x-update templates); others return OMGX_E_INVALID -- step with omgx_batch_solve.  Host arrays are read
+ * during the call. */
+typedef struct omgx_rollout_spec {
+  int32_t n_steps;
+  const double* tau;            /* [n_steps] host: spline-domain time of the prediction */
+  const double* t_rel;          /* [n_steps] host: value written to p[p_t] (time since the last knot) */
+  const uint8_t* crossed;       /* [n_steps] host: 1 = the step crosses a knot (shift before its solve) */
+  int32_t coeff_off, n_spl, degree, n_knots, n_out;      /* the plan: as omgx_batch_predict_ex */
+  const double* knots;          /* [n_knots] host */
+  const int32_t* p_off;         /* [n_out] host: p offset of the o-th time derivative (-1: skip) */
+  int32_t p_t; double inv_T;
+  int32_t n_obst; const int32_t* obst;      /* [n_obst][4] host = {p_x, p_v, p_a, n_dim} of the obstacles that move (<= 8) */
+  double dt;                                /* update time */
+  const int32_t* shift_entries; int32_t n_ent; const double* shift_T; int32_t n_tmat;     /* as omgx_batch_shift (host) */
+  const int32_t* lam_perm;      /* [n_con] host */
+  const omgx_options* cross_options;        /* NULL: the handle's */
+  int32_t* iters_log; int32_t* status_log;  /* device or NULL */
+} omgx_rollout_spec;
+int  omgx_batch_rollout(omgx_batch* b, const omgx_rollout_spec* sp, double* p, double* x, const double* lbg, const double* ubg,
+                        double* lam_g, int32_t* status, int32_t* iters, int32_t flags);
+
 /* `Vehicle.store` (reference `vehicles/vehicle.py:250-300` -> `splines2signals`, e.g.
  * `vehicles/holonomic.py:116-124`) for the whole batch, device pointers only:
  *   out[b, o, k, i] = d^o/dt^o spline_k(t0[b] + i*dt)   (o < n_der: state, input, dinput ...; time

@@ -552,28 +552,156 @@ predict_quadrotor_kernel(const double* __restrict__ x, int n_var, double* __rest
 __global__ void __launch_bounds__(1024)
 order_kernel(const int32_t* __restrict__ iters, const double* __restrict__ dw, int32_t* __restrict__ order, int B) { order_block(iters, dw, order, B); }
 
-__global__ void __launch_bounds__(64)
-shift_kernel(double* __restrict__ x, int x_stride, const uint8_t* __restrict__ mask,
-             const int32_t* __restrict__ entries, int n_ent, const double* __restrict__ Tm) {
-  extern __shared__ __align__(16) double lds[];
-  const int b = blockIdx.x;
-  if (mask && !mask[b]) return;
+// warm-start shift of one row: every entry block <- T * block (`spline_extra.py:165-191`); scratch: LDS doubles for the
+// largest block; all threads of the workgroup take part (barriers inside)
+__device__ __forceinline__ void shift_row(double* __restrict__ xrow, const int32_t* __restrict__ entries, int n_ent,
+                                          const double* __restrict__ Tm, double* scratch) {
   for (int e = 0; e < n_ent; ++e) {
     const int off = entries[4 * e], rows = entries[4 * e + 1], cols = entries[4 * e + 2];
     const double* Tmat = Tm + entries[4 * e + 3];
-    double* xe = x + (size_t)b * x_stride + off;
-    for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) lds[i] = xe[i];
+    double* xe = xrow + off;
+    for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) scratch[i] = xe[i];
     __syncthreads();
     for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
       const int k = i / rows, r = i - k * rows;
       double acc = 0.0;
-      for (int q = 0; q < rows; ++q) acc += Tmat[r * rows + q] * lds[k * rows + q];
+      for (int q = 0; q < rows; ++q) acc += Tmat[r * rows + q] * scratch[k * rows + q];
       xe[i] = acc;
     }
     __syncthreads();
   }
 }
 
+__global__ void __launch_bounds__(64)
+shift_kernel(double* __restrict__ x, int x_stride, const uint8_t* __restrict__ mask,
+             const int32_t* __restrict__ entries, int n_ent, const double* __restrict__ Tm) {
+  extern __shared__ __align__(16) double lds[];
+  const int b = blockIdx.x;
+  if (mask && !mask[b]) return;
+  shift_row(x + (size_t)b * x_stride, entries, n_ent, Tm, lds);
+}
+
+// ---------------------------------------------------------------------------
+// Rollout: K receding-horizon steps of every agent in ONE launch (omgx_batch_rollout).  Agents of a point-to-point batch
+// are independent, so nothing in the protocol asks for a barrier between the steps of different agents: a persistent
+// workgroup takes an agent and runs its whole loop -- ideal prediction from the current plan, obstacles advanced, the
+// knot-crossing shift of the plan and of the multipliers, warm-started solve -- K times, statement for statement what
+// `BatchP2P.step` issues as separate launches (predict_kernel, tensor updates, shift_kernel, index_select, solve): the same
+// bits per agent (tests/test_gpu_rollout.py).  What it removes is the step barrier: with 1024 agents on 512 resident
+// workgroups a step launched on its own is two rounds plus a third for whoever a straggler displaced.
+// ---------------------------------------------------------------------------
+struct RolloutStep { double tau, t_rel; int32_t crossed, pad; };
+struct RolloutArgs {
+  KnotArg kn;
+  int coeff_off, n_spl, degree, n_knots, n_out, p_off[4], p_t;
+  double inv_T, dt;
+  int n_obst, obst[8][4];
+  const int32_t* sh_ent; int n_ent; const double* sh_T;
+  const int32_t* lam_perm;
+  const RolloutStep* steps; int K;
+  omgx::Opts o_cross;
+  unsigned long long* stats;            // [K][4] {solved, sum of iterations, max, agents} or nullptr
+  int32_t* iters_log; int32_t* status_log;     // [K][n_agents] or nullptr
+};
+
+template <int MODE, bool WAVE_ONLY, bool GEN>
+__global__ void __launch_bounds__(512)
+ipm_rollout_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles, double* __restrict__ p, double* __restrict__ x,
+                   const double* __restrict__ lb, const double* __restrict__ ub, int bounds_shared, double* __restrict__ lam,
+                   int32_t* __restrict__ status, int32_t* __restrict__ iters, int n_agents, double* __restrict__ slabs,
+                   size_t slab_doubles, double* __restrict__ dw_state, int* __restrict__ next_slot,
+                   const RolloutArgs* __restrict__ rop, int stagger) {
+  extern __shared__ __align__(16) double lds[];
+  omgx::Work w;
+  omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles, d, kkt_doubles);
+  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_kkt_hbm(MODE), GEN> c; c.red = w.red;
+  c.prof = nullptr;
+  __shared__ int slot_lds;
+  if (stagger > 0 && (__builtin_amdgcn_s_getreg(6148) & 1))
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  const int K = rop->K;
+  for (int slot = blockIdx.x; slot < n_agents;) {
+    const int b = slot;
+    if (threadIdx.x == 0) slot_lds = gridDim.x + atomicAdd(next_slot, 1);
+    __syncthreads();
+    slot = slot_lds;
+    __syncthreads();
+    double* pb = p + (size_t)b * d.n_par;
+    double* xb = x + (size_t)b * d.n_var;
+    double* lamb = lam + (size_t)b * d.n_con;
+    const double* lbb = lb + (bounds_shared ? 0 : (size_t)b * d.n_con);
+    const double* ubb = ub + (bounds_shared ? 0 : (size_t)b * d.n_con);
+    for (int k = 0; k < K; ++k) {
+      const RolloutStep st = rop->steps[k];
+      // (1) ideal prediction (predict_kernel): the plan and its time derivatives at tau, the new t
+      {
+        const int n_spl = rop->n_spl, degree = rop->degree, n_knots = rop->n_knots, n_out = rop->n_out;
+        const int L = n_knots - degree - 1;
+        if ((int)threadIdx.x < n_spl) {
+          const int ks = threadIdx.x;
+          const double* cc = xb + rop->coeff_off + ks * L;
+          const int j = span_of(rop->kn.k, degree, n_knots, st.tau);
+          double sc = 1.0;
+          for (int q = 0; q < n_out; ++q) {
+            if (rop->p_off[q] >= 0) pb[rop->p_off[q] + ks] = spline_der_at(cc, rop->kn.k, degree, j, st.tau, q) * sc;
+            sc *= rop->inv_T;
+          }
+          if (ks == 0 && rop->p_t >= 0) pb[rop->p_t] = st.t_rel;
+        }
+      }
+      // (2) obstacles move on: x <- x + (dt v + dt^2 / 2 a), v <- v + dt a (each product and sum rounded on its own, as the
+      //     tensor statements of BatchP2P.step are)
+      for (int q = 0; q < rop->n_obst; ++q) {
+        const int ox = rop->obst[q][0], ov = rop->obst[q][1], oa = rop->obst[q][2], nd = rop->obst[q][3];
+        if ((int)threadIdx.x < nd) {
+#pragma clang fp contract(off)      // (no fused multiply-add here: the tensor statements round every product)
+          const int i = threadIdx.x;
+          const double dt = rop->dt, c2 = 0.5 * dt * dt;
+          const double pv = pb[ov + i], pa = pb[oa + i];
+          const double m1 = dt * pv, m2 = c2 * pa, m3 = dt * pa;
+          const double s1 = m1 + m2;
+          pb[ox + i] = pb[ox + i] + s1;
+          pb[ov + i] = pv + m3;
+        }
+      }
+      __syncthreads();
+      // (3) knot crossing: plan <- T plan, multipliers by index (the KKT store is idle between two solves: scratch)
+      if (st.crossed) {
+        shift_row(xb, rop->sh_ent, rop->n_ent, rop->sh_T, w.kkt);
+        for (int i = threadIdx.x; i < d.n_con; i += blockDim.x) w.kkt[i] = lamb[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < d.n_con; i += blockDim.x) { const int s = rop->lam_perm[i]; lamb[i] = s >= 0 ? w.kkt[s] : 0.0; }
+        __syncthreads();
+      }
+      // (4) warm-started solve, results back to the agent's rows
+      const omgx::Result r = omgx::ipm_solve(c, d, T, st.crossed ? rop->o_cross : o, w, pb, xb, lbb, ubb, o.warm_start ? lamb : nullptr,
+                                             o.warm_start ? status[b] : 0, kkt_doubles, o.warm_start ? dw_state[b] : 0.0);
+      __builtin_amdgcn_s_setprio(0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < d.n_var; i += blockDim.x) xb[i] = w.x[i];
+      for (int q = threadIdx.x; q < d.n_con; q += blockDim.x)
+        lamb[q] = (r.status == 3 || w.rtype[q] == omgx::ROW_FREE) ? 0.0 : w.rho[q] * w.z[q];
+      if (threadIdx.x == 0) {
+        status[b] = r.status; iters[b] = r.iters; dw_state[b] = r.dw;
+        if (rop->stats) {
+          unsigned long long* sk = rop->stats + 4 * (size_t)k;
+          atomicAdd(sk + 0, r.status == 0 ? 1ull : 0ull);
+          atomicAdd(sk + 1, (unsigned long long)r.iters);
+          atomicMax(sk + 2, (unsigned long long)r.iters);
+          atomicAdd(sk + 3, 1ull);
+        }
+        if (rop->iters_log) rop->iters_log[(size_t)k * n_agents + b] = r.iters;
+        if (rop->status_log) rop->status_log[(size_t)k * n_agents + b] = r.status;
+      }
+      __syncthreads();
+    }
+  }
+  // (the last workgroup out resets the queue counter for the next launch, as in the solve kernel)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(next_slot + 1, 1) == (int)gridDim.x - 1) { next_slot[0] = 0; next_slot[1] = 0; }
+  }
+}
 
 // ---------------------------------------------------------------------------
 // Formation ADMM kernels (all pointers are device pointers; tiny, memory-bound)
@@ -732,6 +860,8 @@ struct omgx_batch {
   int stats_slots = 0; long long stats_launch = 0;
   StoreArgs store = {};             // trajectories written by the solve kernel (omgx_batch_set_store); out == nullptr: off
   StoreArgs* d_store = nullptr;     // its copy in device memory (what the kernel reads)
+  RolloutArgs* d_rollout = nullptr; RolloutStep* d_ro_steps = nullptr; int ro_steps_cap = 0; int32_t* d_ro_perm = nullptr;      // omgx_batch_rollout
+  std::vector<int32_t> ro_perm_host;
   CenterArgs* d_center = nullptr;   // omgx_batch_set_center: device copy of the arguments (nullptr: off); the slot map behind it
   int32_t* d_pub_inv = nullptr;
   bool center_on = false;
@@ -861,6 +991,19 @@ bool plan_for_mode(omgx::HostPlan& plan, const omgx_template& t, int* mode, size
     if (*lds_doubles * sizeof(double) <= (size_t)kLdsHalf && getenv("OMGX_SPILL_PER_CU") && atoi(getenv("OMGX_SPILL_PER_CU")) == 2) *per_cu = 2;
   }
   return true;
+}
+
+typedef void (*ipm_rollout_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, double*, double*, const double*, const double*, int, double*,
+                              int32_t*, int32_t*, int, double*, size_t, double*, int*, const RolloutArgs*, int);
+// (the classes of the wave path without quartic terms / cos / sin atoms: the receding-horizon classes that fit LDS)
+static ipm_rollout_t rollout_kernel_for(int mode, int wave_ok, int general) {
+  if (!wave_ok || general) return nullptr;
+  switch (mode) {
+    case omgx::WS_LDS: return ipm_rollout_kernel<omgx::WS_LDS, true, false>;
+    case omgx::WS_JAC_ONLY: return ipm_rollout_kernel<omgx::WS_JAC_ONLY, true, false>;
+    case omgx::WS_JAC_HV: return ipm_rollout_kernel<omgx::WS_JAC_HV, true, false>;
+    default: return nullptr;
+  }
 }
 
 int check_template(const omgx_template* t) {
@@ -1277,6 +1420,11 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
                           reserved) != hipSuccess) {
     g_err = "cannot reserve dynamic LDS for ipm_solve_kernel"; omgx_batch_destroy(b); return OMGX_E_HIP;
   }
+  if (ipm_rollout_t rk = rollout_kernel_for(b->ws_mode, b->dims.wave_ok, b->dims.general)) {
+    if (hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, reserved) != hipSuccess) {
+      g_err = "cannot reserve dynamic LDS for ipm_rollout_kernel"; omgx_batch_destroy(b); return OMGX_E_HIP;
+    }
+  }
   {
     // Persistent workgroups, as many as fit the chip at once (one or two per CU), that take their agents from an atomic
     // counter -- in every mode: solves differ by a factor of several in their iteration counts.  The workgroups of the
@@ -1303,6 +1451,9 @@ void omgx_batch_destroy(omgx_batch* b) {
   for (void* p : b->allocs) (void)hipFree(p);
   if (b->d_store) (void)hipFree(b->d_store);
   if (b->d_center) (void)hipFree(b->d_center);
+  if (b->d_rollout) (void)hipFree(b->d_rollout);
+  if (b->d_ro_steps) (void)hipFree(b->d_ro_steps);
+  if (b->d_ro_perm) (void)hipFree(b->d_ro_perm);
   if (b->d_pub_inv) (void)hipFree(b->d_pub_inv);
   if (b->d_range_src) (void)hipFree(b->d_range_src);
   if (b->d_range_dup) (void)hipFree(b->d_range_dup);
@@ -1735,6 +1886,97 @@ int omgx_batch_predict_quadrotor(omgx_batch* b, const double* x, double* p, int3
   a.coeff_off = coeff_off; a.n_spl = 2; a.degree = degree; a.n_knots = n_knots; a.n_out = n_out;
   a.tau = tau; a.inv_T = inv_T; a.p_t = p_t; a.t_value = t_value; a.mode = OMGX_PREDICT_RK4; a.state_in = state_in; a.n_sub = n_sub; a.dtau = dtau;
   hipLaunchKernelGGL(predict_quadrotor_kernel, dim3((b->n_agents + 255) / 256), dim3(256), 0, b->stream, x, d.n_var, p, d.n_par, b->n_agents, a, g, state_out);
+  HIPCHK(hipGetLastError());
+  return OMGX_OK;
+}
+
+int omgx_batch_rollout(omgx_batch* b, const omgx_rollout_spec* sp, double* p, double* x, const double* lbg, const double* ubg,
+                       double* lam_g, int32_t* status, int32_t* iters, int32_t flags) {
+  if (!b || !sp || !p || !x || !lbg || !ubg || !lam_g || !status || !iters) { g_err = "null argument"; return OMGX_E_INVALID; }
+  if (!(flags & OMGX_PTR_DEVICE) || !(flags & OMGX_BOUNDS_DEVICE)) { g_err = "rollout: device pointers only (OMGX_PTR_DEVICE | OMGX_BOUNDS_DEVICE)"; return OMGX_E_INVALID; }
+  const omgx::Dims& d = b->dims;
+  ipm_rollout_t kern = rollout_kernel_for(b->ws_mode, d.wave_ok, d.general);
+  if (!kern || b->n_range > 0 || !b->d_next) {
+    g_err = "rollout: not available for this template class (spill modes, general instance, two-sided rows): step with omgx_batch_solve";
+    return OMGX_E_INVALID;
+  }
+  if (sp->n_steps <= 0 || !sp->tau || !sp->t_rel || !sp->crossed || !sp->knots || !sp->p_off || sp->n_knots > 40 || sp->degree > 5 ||
+      sp->degree < 1 || sp->n_spl <= 0 || sp->n_spl > 64 || sp->n_out < 1 || sp->n_out > 4 || sp->n_out > sp->degree + 1 || sp->n_obst < 0 ||
+      sp->n_obst > 8 || (sp->n_obst > 0 && !sp->obst) || sp->n_ent < 0 || (sp->n_ent > 0 && (!sp->shift_entries || !sp->shift_T || !sp->lam_perm))) {
+    g_err = "rollout: bad specification"; return OMGX_E_INVALID;
+  }
+  const int L = sp->n_knots - sp->degree - 1;
+  if (sp->coeff_off < 0 || sp->coeff_off + sp->n_spl * L > d.n_var || sp->p_t >= d.n_par) { g_err = "rollout: offsets outside x / p"; return OMGX_E_INVALID; }
+  HIPCHK(hipSetDevice(b->device));
+  RolloutArgs a;
+  memset(&a, 0, sizeof a);
+  for (int i = 0; i < 40; ++i) a.kn.k[i] = i < sp->n_knots ? sp->knots[i] : 0.0;
+  a.coeff_off = sp->coeff_off; a.n_spl = sp->n_spl; a.degree = sp->degree; a.n_knots = sp->n_knots; a.n_out = sp->n_out; a.p_t = sp->p_t;
+  for (int o = 0; o < 4; ++o) {
+    a.p_off[o] = o < sp->n_out ? sp->p_off[o] : -1;
+    if (a.p_off[o] >= 0 && a.p_off[o] + sp->n_spl > d.n_par) { g_err = "rollout: offsets outside p"; return OMGX_E_INVALID; }
+  }
+  a.inv_T = sp->inv_T; a.dt = sp->dt; a.n_obst = sp->n_obst;
+  for (int q = 0; q < sp->n_obst; ++q) {
+    for (int k = 0; k < 4; ++k) a.obst[q][k] = sp->obst[4 * q + k];
+    const int nd = a.obst[q][3];
+    if (nd <= 0 || nd > 64 || a.obst[q][0] < 0 || a.obst[q][1] < 0 || a.obst[q][2] < 0 || a.obst[q][0] + nd > d.n_par || a.obst[q][1] + nd > d.n_par ||
+        a.obst[q][2] + nd > d.n_par) { g_err = "rollout: obstacle entries outside p"; return OMGX_E_INVALID; }
+  }
+  // knot-crossing tables: the shift set (cached on the device by content) and the multiplier map
+  a.n_ent = sp->n_ent;
+  bool any_cross = false;
+  for (int k = 0; k < sp->n_steps; ++k) any_cross = any_cross || sp->crossed[k] != 0;
+  if (any_cross && sp->n_ent <= 0) { g_err = "rollout: a step crosses a knot but no shift tables were given"; return OMGX_E_INVALID; }
+  if (sp->n_ent > 0) {
+    int max_elems = 0;
+    const int rc = stage_shift_tables(b, sp->shift_entries, sp->n_ent, sp->shift_T, sp->n_tmat, d.n_var, &max_elems);
+    if (rc != OMGX_OK) return rc;
+    if (max_elems > b->kkt_doubles || d.n_con > b->kkt_doubles) { g_err = "rollout: shift scratch exceeds the KKT store"; return OMGX_E_INVALID; }
+    a.sh_ent = b->d_shift_ent; a.sh_T = b->d_shift_T;
+    for (int i = 0; i < d.n_con; ++i) if (sp->lam_perm[i] >= d.n_con) { g_err = "rollout: multiplier map out of range"; return OMGX_E_INVALID; }
+    if (b->ro_perm_host.size() != (size_t)d.n_con || memcmp(b->ro_perm_host.data(), sp->lam_perm, d.n_con * sizeof(int32_t)) != 0) {
+      if (!b->d_ro_perm) HIPCHK(hipMalloc((void**)&b->d_ro_perm, sizeof(int32_t) * (size_t)d.n_con));
+      b->ro_perm_host.assign(sp->lam_perm, sp->lam_perm + d.n_con);
+      HIPCHK(hipMemcpy(b->d_ro_perm, b->ro_perm_host.data(), sizeof(int32_t) * (size_t)d.n_con, hipMemcpyHostToDevice));
+    }
+    a.lam_perm = b->d_ro_perm;
+  }
+  if (sp->n_steps > b->ro_steps_cap) {
+    if (b->d_ro_steps) (void)hipFree(b->d_ro_steps);
+    b->d_ro_steps = nullptr; b->ro_steps_cap = 0;
+    HIPCHK(hipMalloc((void**)&b->d_ro_steps, sizeof(RolloutStep) * (size_t)sp->n_steps));
+    b->ro_steps_cap = sp->n_steps;
+  }
+  std::vector<RolloutStep> steps((size_t)sp->n_steps);
+  for (int k = 0; k < sp->n_steps; ++k) { steps[k].tau = sp->tau[k]; steps[k].t_rel = sp->t_rel[k]; steps[k].crossed = sp->crossed[k] ? 1 : 0; steps[k].pad = 0; }
+  a.steps = b->d_ro_steps; a.K = sp->n_steps;
+  b->opts.prio_iter = b->prio_iter;
+  a.o_cross = b->opts;
+  if (sp->cross_options) {
+    const omgx_options& co = *sp->cross_options;
+    a.o_cross.kappa_warm = co.kappa_warm; a.o_cross.warm_mu_factor = co.warm_mu_factor; a.o_cross.warm_z_floor = co.warm_z_floor;
+    a.o_cross.warm_z_cap = co.warm_z_cap; a.o_cross.max_iter = co.max_iter; a.o_cross.tol = co.tol; a.o_cross.max_soc = co.max_soc;
+  }
+  // per-step statistics: the slots the next n_steps single launches would have taken (omgx_batch_set_stats)
+  a.stats = nullptr;
+  if (b->d_stats) {
+    if (sp->n_steps > b->stats_slots - (int)(b->stats_launch % b->stats_slots)) { g_err = "rollout: the stats array has fewer free slots than steps"; return OMGX_E_INVALID; }
+    a.stats = (unsigned long long*)b->d_stats + 4 * (size_t)(b->stats_launch % b->stats_slots);
+    b->stats_launch += sp->n_steps;
+  }
+  a.iters_log = sp->iters_log; a.status_log = sp->status_log;
+  if (!b->d_rollout) HIPCHK(hipMalloc((void**)&b->d_rollout, sizeof(RolloutArgs)));
+  // (two small synchronous copies per call: one call is n_steps steps of the whole batch)
+  HIPCHK(hipMemcpy(b->d_ro_steps, steps.data(), sizeof(RolloutStep) * steps.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->d_rollout, &a, sizeof(RolloutArgs), hipMemcpyHostToDevice));
+  const bool shared = flags & OMGX_BOUNDS_SHARED;
+  hipEvent_t e0 = b->ext_ev0, e1 = b->ext_ev0 ? b->ext_ev1 : nullptr;
+  b->ext_ev0 = b->ext_ev1 = nullptr;
+  b->timed = false;
+  hipExtLaunchKernelGGL(kern, dim3(b->n_slabs < b->n_agents ? b->n_slabs : b->n_agents), dim3(b->threads), (uint32_t)b->lds_bytes, b->stream, e0, e1, 0u,
+                        d, b->dev, b->opts, b->kkt_doubles, p, x, lbg, ubg, shared ? 1 : 0, lam_g, status, iters, b->n_agents,
+                        b->d_slabs, b->slab_doubles, b->d_dw, b->d_next, (const RolloutArgs*)b->d_rollout, b->stagger);
   HIPCHK(hipGetLastError());
   return OMGX_OK;
 }

@@ -59,6 +59,16 @@ class COptions(C.Structure):
                 ('dw_leaf_ratio_cold', C.c_double), ('warm_mu_factor', C.c_double), ('warm_z_floor', C.c_double), ('warm_z_cap', C.c_double), ('max_soc', C.c_int32)]
 
 
+class CRolloutSpec(C.Structure):
+    """include/omgx.h omgx_rollout_spec"""
+    _fields_ = [('n_steps', C.c_int32), ('tau', C.c_void_p), ('t_rel', C.c_void_p), ('crossed', C.c_void_p),
+                ('coeff_off', C.c_int32), ('n_spl', C.c_int32), ('degree', C.c_int32), ('n_knots', C.c_int32), ('n_out', C.c_int32),
+                ('knots', C.c_void_p), ('p_off', C.c_void_p), ('p_t', C.c_int32), ('inv_T', C.c_double),
+                ('n_obst', C.c_int32), ('obst', C.c_void_p), ('dt', C.c_double),
+                ('shift_entries', C.c_void_p), ('n_ent', C.c_int32), ('shift_T', C.c_void_p), ('n_tmat', C.c_int32),
+                ('lam_perm', C.c_void_p), ('cross_options', C.c_void_p), ('iters_log', C.c_void_p), ('status_log', C.c_void_p)]
+
+
 DEFAULT_OPTIONS = dict(tol=1e-3, max_iter=300, mu_init=0.1, kappa_push=1.0,
                        nu_init=100.0, scale_gmax=100.0, warm_start=0, kappa_warm=1e-3,
                        dw_leaf_ratio_cold=1.0, warm_mu_factor=1.0, warm_z_floor=0.1, warm_z_cap=0.01, max_soc=int(__import__("os").environ.get("OMGX_MAX_SOC", "1")))
@@ -450,6 +460,39 @@ class BatchSolver(object):
             self._h, ptr(x), ptr(p), int(coeff_off), int(n_spl), int(degree), knots.ctypes.data, len(knots),
             float(tau), float(inv_T), len(off), off.ctypes.data, int(p_t), float(t_value), int(mode), ptr(state_in),
             int(n_sub), float(dtau)), 'omgx_batch_predict_ex')
+
+    def rollout(self, p, x, lbg, ubg, lam_g, status, iters, tau, t_rel, crossed, coeff_off, n_spl, degree, knots, inv_T, p_off, p_t,
+                obstacles=(), dt=0.0, shift_entries=None, shift_T=None, lam_perm=None, cross_options=None, iters_log=None,
+                status_log=None, bounds_shared=True):
+        """n_steps = len(tau) receding-horizon steps of every agent in one launch (include/omgx.h omgx_batch_rollout): device
+        tensors p, x, lam_g, status, iters updated in place; tau / t_rel / crossed: per-step host arrays; the rest as
+        `predict_ex` / `shift`; obstacles: [(p_x, p_v, p_a, n_dim)] of the ones that move; lam_perm: multiplier map of a crossing."""
+        def ptr(a):
+            return None if a is None else (a.data_ptr() if hasattr(a, 'data_ptr') else int(a))
+        keep = dict(tau=np.ascontiguousarray(tau, dtype=np.float64), t_rel=np.ascontiguousarray(t_rel, dtype=np.float64),
+                    crossed=np.ascontiguousarray(crossed, dtype=np.uint8), knots=np.ascontiguousarray(knots, dtype=np.float64),
+                    p_off=np.ascontiguousarray(p_off, dtype=np.int32),
+                    obst=np.ascontiguousarray(np.array(list(obstacles), dtype=np.int32).reshape(-1, 4)))
+        sp = CRolloutSpec()
+        sp.n_steps = len(keep['tau'])
+        sp.tau, sp.t_rel, sp.crossed = keep['tau'].ctypes.data, keep['t_rel'].ctypes.data, keep['crossed'].ctypes.data
+        sp.coeff_off, sp.n_spl, sp.degree, sp.n_knots, sp.n_out = int(coeff_off), int(n_spl), int(degree), len(keep['knots']), len(keep['p_off'])
+        sp.knots, sp.p_off, sp.p_t, sp.inv_T = keep['knots'].ctypes.data, keep['p_off'].ctypes.data, int(p_t), float(inv_T)
+        sp.n_obst, sp.obst, sp.dt = len(keep['obst']), (keep['obst'].ctypes.data if len(keep['obst']) else None), float(dt)
+        if shift_entries is not None and len(shift_entries):
+            keep['ents'] = np.ascontiguousarray(shift_entries, dtype=np.int32)
+            keep['mats'] = np.ascontiguousarray(shift_T, dtype=np.float64)
+            keep['perm'] = np.ascontiguousarray(lam_perm, dtype=np.int32)
+            sp.shift_entries, sp.n_ent, sp.shift_T, sp.n_tmat = keep['ents'].ctypes.data, len(keep['ents']), keep['mats'].ctypes.data, keep['mats'].size
+            sp.lam_perm = keep['perm'].ctypes.data
+        if cross_options:
+            keep['copt'] = COptions(**dict(self.options, **cross_options))
+            sp.cross_options = C.addressof(keep['copt'])
+        sp.iters_log, sp.status_log = ptr(iters_log), ptr(status_log)
+        self.lib.omgx_batch_rollout.argtypes = [C.c_void_p, C.POINTER(CRolloutSpec)] + [C.c_void_p] * 7 + [C.c_int32]
+        flags = PTR_DEVICE | BOUNDS_DEVICE | (BOUNDS_SHARED if bounds_shared else 0)
+        _check(self.lib, self.lib.omgx_batch_rollout(self._h, C.byref(sp), ptr(p), ptr(x), ptr(lbg), ptr(ubg), ptr(lam_g), ptr(status),
+                                                     ptr(iters), flags), 'omgx_batch_rollout')
 
     def predict_quadrotor(self, x, p, coeff_off, degree, knots, tau, inv_T, p_off, p_t, t_value, state_in, state_out, n_sub, dtau, g=9.81):
         """Non-ideal prediction of the Quadrotor model: state_in [B, 5] integrated over the n_sub sample intervals that end at tau

@@ -283,6 +283,31 @@ class BatchP2P(object):
         self._solve(True, events, ordered=self.kind == 'hip' and self.straggler_first, extra=self.cross_options if crossed else None)
         return crossed
 
+    def rollout(self, n_steps, iters_log=None, status_log=None):
+        """`n_steps` receding-horizon steps of every agent in ONE launch (`omgx_batch_rollout`): per agent the statements of
+        `step` -- prediction, obstacles, knot-crossing shift, warm-started solve -- in the same order with the same numbers,
+        without the barrier between the steps of different agents (they are independent problems: each vehicle of the
+        reference runs its own `Deployer.update` loop).  For simulation / evaluation runs with ideal prediction; a deployment
+        that feeds measured states back steps with `step`.  Returns the number of knot crossings."""
+        if self.kind != 'hip':
+            raise NotImplementedError('rollout is a device launch')
+        tau, t_rel, crossed = [], [], []
+        t = self.time
+        for _ in range(int(n_steps)):                      # (the clock of `step`, statement for statement)
+            t_prev, t_now = t, t + self.update_time
+            rel_prev = np.round(t_prev, 6) % self.knot_time
+            tau.append((rel_prev + self.update_time) / self.T)
+            crossed.append(int(np.round(t_prev / self.knot_time, 6)) < int(np.round(t_now / self.knot_time, 6)))
+            t_rel.append(float(np.round(t_now, 6) % self.knot_time))
+            t = t_now
+        self.solver.set_options(warm_start=1, max_iter=self.max_iter_step, **self._base_extra)
+        self.solver.rollout(self.p, self.x, self.lb, self.ub, self.lam, self.status, self.iters, tau, t_rel, crossed,
+                            self.o_spl, self.n_spl, self.basis.degree, self.basis.knots, 1.0 / self.T, self.p_offs, self.o_t,
+                            obstacles=self.obst, dt=self.update_time, shift_entries=self.shift_entries, shift_T=self.shift_mats,
+                            lam_perm=self.perm, cross_options=self.cross_options or None, iters_log=iters_log, status_log=status_log)
+        self.time = t
+        return int(sum(crossed))
+
     def _eval_rows(self, tau):
         """[E_0, E_1, ...]: c @ E_o = o-th time derivative of the plan at tau."""
         rows = [self.basis.eval_basis([tau])[0]]

@@ -1,0 +1,88 @@
+"""`omgx_batch_rollout` (K receding-horizon steps of every agent in one launch) against the stepwise loop `BatchP2P.step`
+(`execution/deployer.py:43-79`: one update per call): per agent the same statements in the same order, so plans, multipliers,
+parameters, statuses and iteration counts of every step must be THE SAME BITS -- across a knot crossing, with moving
+obstacles, and when the batch is not a multiple of the resident workgroups."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(n, mutate=None, **kw):
+    import torch
+    from omgtools import workloads
+    from omgtools.batch import BatchP2P
+    out = []
+    for _ in range(2):
+        problem, P = workloads.holonomic_p2p(n, **kw)
+        if mutate is not None:
+            mutate(problem, P)
+        mpc = BatchP2P(problem, P, ops='hip', device=torch.device('cuda', 0), options=dict(tol=1e-3, max_iter=300))
+        mpc.solve_cold(bends=())
+        out.append(mpc)
+    return out
+
+
+@pytest.mark.parametrize('n', [40, 1024])
+def test_rollout_equals_the_stepwise_loop_bit_for_bit(n):
+    import torch
+    a, b = _pair(n)
+    K = 12                                               # update_time 0.1 s, knot_time 1 s: one crossing inside
+    it_log = torch.zeros((K, n), dtype=torch.int32, device=a.dev)
+    st_log = torch.full((K, n), -1, dtype=torch.int32, device=a.dev)
+    crossings = a.rollout(K, iters_log=it_log, status_log=st_log)
+    it_ref, st_ref, crossed_ref = [], [], 0
+    for _ in range(K):
+        crossed_ref += int(b.step())
+        it_ref.append(b.iters.clone()); st_ref.append(b.status.clone())
+    torch.cuda.synchronize()
+    assert crossings == crossed_ref == 1
+    assert abs(a.time - b.time) < 1e-12
+    assert torch.equal(it_log, torch.stack(it_ref)) and torch.equal(st_log, torch.stack(st_ref))
+    assert (st_log == 0).all()
+    for name in ('x', 'lam', 'p', 'status', 'iters'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    # and the loop goes on from there either way
+    a.step(); b.rollout(1)
+    torch.cuda.synchronize()
+    assert torch.equal(a.x, b.x) and torch.equal(a.lam, b.lam)
+    a.solver.close(); b.solver.close()
+
+
+def test_rollout_fills_the_per_step_statistics():
+    import torch
+    (a, b) = _pair(64)
+    K = 5
+    stats = torch.zeros((K + 2, 4), dtype=torch.int64, device=a.dev)
+    a.solver.set_stats(stats)
+    a.rollout(K)
+    a.step()
+    a.solver.set_stats(None)
+    torch.cuda.synchronize()
+    s = stats.cpu().numpy()
+    assert (s[:K + 1, 3] == 64).all() and (s[:K + 1, 0] == 64).all() and s[K + 1].sum() == 0
+    assert (s[:K + 1, 2] >= 1).all() and (s[:K + 1, 1] >= 64).all()
+    a.solver.close(); b.solver.close()
+
+
+def test_rollout_with_moving_obstacles():
+    """Obstacles with a velocity and an acceleration are advanced inside the launch exactly as the tensor statements of `step` do
+    (each product and sum rounded on its own)."""
+    import torch
+
+    def drift(problem, P):
+        tpl = problem.father.template
+        rng = np.random.default_rng(5)
+        for obs in problem.environment.obstacles:
+            ov, oa = (tpl.entry_range(obs.label, nm, 'par') for nm in ('v', 'a'))
+            P['p'][:, ov[0]:ov[1]] = rng.uniform(-0.03, 0.03, size=(len(P['p']), ov[1] - ov[0]))
+            P['p'][:, oa[0]:oa[1]] = rng.uniform(-0.01, 0.01, size=(len(P['p']), oa[1] - oa[0]))
+    a, b = _pair(32, mutate=drift)
+    assert len(a.obst) == 3
+    a.rollout(6)
+    for _ in range(6):
+        b.step()
+    torch.cuda.synchronize()
+    for name in ('x', 'lam', 'p', 'status', 'iters'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    a.solver.close(); b.solver.close()
