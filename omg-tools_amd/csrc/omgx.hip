@@ -610,7 +610,7 @@ ipm_rollout_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles, 
                    const double* __restrict__ lb, const double* __restrict__ ub, int bounds_shared, double* __restrict__ lam,
                    int32_t* __restrict__ status, int32_t* __restrict__ iters, int n_agents, double* __restrict__ slabs,
                    size_t slab_doubles, double* __restrict__ dw_state, int* __restrict__ next_slot,
-                   const RolloutArgs* __restrict__ rop, int stagger) {
+                   const RolloutArgs* __restrict__ rop, int stagger, const int32_t* __restrict__ order) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles, d, kkt_doubles);
@@ -620,8 +620,10 @@ ipm_rollout_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles, 
   if (stagger > 0 && (__builtin_amdgcn_s_getreg(6148) & 1))
     for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
   const int K = rop->K;
+  // (agents in the caller's order -- the ones whose last solve was slow first: a workgroup that gets a long loop early is
+  // given a short one by the queue afterwards)
   for (int slot = blockIdx.x; slot < n_agents;) {
-    const int b = slot;
+    const int b = order ? order[slot] : slot;
     if (threadIdx.x == 0) slot_lds = gridDim.x + atomicAdd(next_slot, 1);
     __syncthreads();
     slot = slot_lds;
@@ -994,7 +996,7 @@ bool plan_for_mode(omgx::HostPlan& plan, const omgx_template& t, int* mode, size
 }
 
 typedef void (*ipm_rollout_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, double*, double*, const double*, const double*, int, double*,
-                              int32_t*, int32_t*, int, double*, size_t, double*, int*, const RolloutArgs*, int);
+                              int32_t*, int32_t*, int, double*, size_t, double*, int*, const RolloutArgs*, int, const int32_t*);
 // (the classes of the wave path without quartic terms / cos / sin atoms: the receding-horizon classes that fit LDS)
 static ipm_rollout_t rollout_kernel_for(int mode, int wave_ok, int general) {
   if (!wave_ok || general) return nullptr;
@@ -1970,13 +1972,14 @@ int omgx_batch_rollout(omgx_batch* b, const omgx_rollout_spec* sp, double* p, do
   // (two small synchronous copies per call: one call is n_steps steps of the whole batch)
   HIPCHK(hipMemcpy(b->d_ro_steps, steps.data(), sizeof(RolloutStep) * steps.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->d_rollout, &a, sizeof(RolloutArgs), hipMemcpyHostToDevice));
+  { const int rc_o = flush_order(b); if (rc_o != OMGX_OK) return rc_o; }
   const bool shared = flags & OMGX_BOUNDS_SHARED;
   hipEvent_t e0 = b->ext_ev0, e1 = b->ext_ev0 ? b->ext_ev1 : nullptr;
   b->ext_ev0 = b->ext_ev1 = nullptr;
   b->timed = false;
   hipExtLaunchKernelGGL(kern, dim3(b->n_slabs < b->n_agents ? b->n_slabs : b->n_agents), dim3(b->threads), (uint32_t)b->lds_bytes, b->stream, e0, e1, 0u,
                         d, b->dev, b->opts, b->kkt_doubles, p, x, lbg, ubg, shared ? 1 : 0, lam_g, status, iters, b->n_agents,
-                        b->d_slabs, b->slab_doubles, b->d_dw, b->d_next, (const RolloutArgs*)b->d_rollout, b->stagger);
+                        b->d_slabs, b->slab_doubles, b->d_dw, b->d_next, (const RolloutArgs*)b->d_rollout, b->stagger, b->d_order);
   HIPCHK(hipGetLastError());
   return OMGX_OK;
 }

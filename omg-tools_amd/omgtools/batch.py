@@ -301,6 +301,8 @@ class BatchP2P(object):
             t_rel.append(float(np.round(t_now, 6) % self.knot_time))
             t = t_now
         self.solver.set_options(warm_start=1, max_iter=self.max_iter_step, **self._base_extra)
+        if self.straggler_first:
+            self.solver.order_by_iters(self.iters, self._order)
         self.solver.rollout(self.p, self.x, self.lb, self.ub, self.lam, self.status, self.iters, tau, t_rel, crossed,
                             self.o_spl, self.n_spl, self.basis.degree, self.basis.knots, 1.0 / self.T, self.p_offs, self.o_t,
                             obstacles=self.obst, dt=self.update_time, shift_entries=self.shift_entries, shift_T=self.shift_mats,
