@@ -367,24 +367,11 @@ def bench_formation(args, rank, local_rank, world, dist, dev):
     barrier()
     stats = torch.zeros((args.steps, 4), dtype=torch.int64, device=dev)     # per x-update: solved, sum / max of iterations, agents
     solver.set_stats(stats)
-    prof = None
-    if os.environ.get('OMGX_BENCH_PROFILE'):               # developer: where the host spends the timed loop
-        import cProfile
-        prof = cProfile.Profile()
-        prof.enable()
-    stamps = []
     quiet_host()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         status, crossed = mpc.step()                        # nothing leaves the device inside the loop
         crossings += int(crossed)
-        stamps.append(time.perf_counter())
-    if os.environ.get('OMGX_BENCH_STAMPS'):
-        print('host ms per step:', [round((b - a) * 1e3, 2) for a, b in zip([t0] + stamps[:-1], stamps)], file=sys.stderr)
-    if prof is not None:
-        import pstats
-        prof.disable()
-        pstats.Stats(prof, stream=sys.stderr).sort_stats('tottime').print_stats(14)
     t_host = time.perf_counter() - t0                      # (enqueue time of the timed steps: far below `elapsed` unless the host is the bound)
     barrier()
     elapsed = time.perf_counter() - t0
