@@ -673,7 +673,10 @@ def main():
         out['latency_host_boundary'] = latency_episodes(mpc, x0_init, p_init, 5, 40, host=True)
         out['survey_8d_obstacle_rule'] = unedited_rule(args, dev, 20240807 + 2)
         out['trajectory_store_fused'] = store_leg(mpc, problem, tpl, x0_init, p_init, 20, dev)
-        out['rollout'] = rollout_leg(mpc, x0_init, p_init, args.steps, args.warmup, dev)
+        try:
+            out['rollout'] = rollout_leg(mpc, x0_init, p_init, args.steps, args.warmup, dev)
+        except Exception as e:                            # (a second metric must never cost the headline line)
+            out['rollout'] = {'error': repr(e)}
     if world == 1:
         # trajectory extraction (A11) against the HBM roofline, at the workload's batch and at 16x (the
         # 49 MB of one 1024-agent launch last ~10 us: launch-latency bound)
