@@ -14,6 +14,10 @@ reference's modules on `omgx_shim` (tests/helpers/run_reference_on_shim.py, this
                  reference built; graph vs template agree to 1e-15 in the helper)
   x_slsqp, f_slsqp   scipy SLSQP on the restated NLP from x0 (the independent solver of tests/slsqp_reference.py)
 
+tests/golden/dubins_subst.npz (round 4): the same class with `options['substitution']` (`vehicles/dubins.py:92-115`): the position is
+the integral of separate velocity splines, tied to the tangent-half-angle expressions by TWO-SIDED rows  -1e-3 <= x - int(v_til (1 -
+tg_ha^2)) <= 1e-3  (`basics/optilayer.py:634-666`) -- 118 range rows; what the library could not take before ABI 5.
+
 Run in the build container:  python tests/golden/generate_shim_fixtures.py"""
 import os
 import subprocess
@@ -28,9 +32,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
-def make(case, out_name):
+def make(case, out_name, subst='0'):
     tmp = os.path.join(HERE, '_shim_tmp.npz')
-    env = dict(os.environ, SHIM_TEMPLATE=tmp, DUBINS_SUBST='0', DUBINS_FREET='0', SHIM_DUMP=os.path.join(HERE, '_shim_dump.npz'))
+    env = dict(os.environ, SHIM_TEMPLATE=tmp, DUBINS_SUBST=subst, DUBINS_FREET='0', SHIM_NO_SIM='1' if subst == '1' else '0',
+               SHIM_DUMP=os.path.join(HERE, '_shim_dump.npz'))
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'helpers', 'run_reference_on_shim.py'), case],
                        capture_output=True, text=True, env=env)
     print(r.stdout[-600:])
@@ -52,5 +57,7 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['dubins', 'revolving_door']
     if 'dubins' in which:
         make('p2p_dubins', 'dubins_fixedT.npz')
+    if 'dubins_subst' in which:
+        make('p2p_dubins', 'dubins_subst.npz', subst='1')
     if 'revolving_door' in which:
         make('revolving_door', 'revolving_door.npz')

@@ -221,6 +221,63 @@ def test_dubins_on_the_device(dubins):
     assert np.abs(port['x'][0] - res['x'][0]).max() < 1e-4
 
 
+# ---- the same class with the substituted velocity splines: two-sided rows (round 4) -------------------------------------
+# tests/golden/dubins_subst.npz: `options['substitution']` of the reference's Dubins class (`vehicles/dubins.py:92-115`): the
+# position is the integral of separate velocity splines, tied to the tangent-half-angle expressions by 118 rows
+# -1e-3 <= x - int(v_til (1 - tg_ha^2)) <= 1e-3 (`basics/optilayer.py:634-666`).  The library solves such a row doubled (ABI 5).  A
+# tube of quartic rows 2e-3 wide is hard ground for an interior-point iteration: 717 iterations from the reference's guess at
+# tol 1e-3 (at 1e-6 the stall test of phase I gives up at iteration 60: step lengths of 1e-3 inside the tube) -- the fixture
+# pins that the class builds, reproduces the reference's graphs and is solved to the optimum SLSQP finds, not that it is fast.
+@pytest.fixture(scope='module')
+def dubins_subst():
+    import os
+    from omgtools.template import NLPTemplate
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'dubins_subst.npz')
+    tpl = NLPTemplate.from_npz(path)
+    d = np.load(path)
+    two_sided = np.isfinite(tpl.lb) & np.isfinite(tpl.ub) & (tpl.lb < tpl.ub)
+    assert (tpl.n_var, tpl.n_con, tpl.n_par) == (96, 414, 19) and two_sided.sum() == 118 and int(d['slsqp_ok']) == 1
+    return tpl, d
+
+
+def _check_subst(tpl, d, res):
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    nlp = NumpyNLP(tpl)
+    assert res['status'][0] == 0 and res['lam_g'].shape[1] == tpl.n_con
+    f, g = nlp.fg(res['x'][0], nlp.term_coefs(d['p0']))
+    assert (g - tpl.ub).max() < 1e-6 and (tpl.lb - g).max() < 1e-6                 # inside every tube
+    assert abs(f - float(d['f_slsqp'])) < 1e-2 * (1 + abs(f))                      # (tol 1e-3: the barrier's share of the objective)
+    assert_kkt(nlp, tpl, d['p0'], res['x'][0], res['lam_g'][0], 1e-2, 'dubins_subst')
+
+
+def test_substituted_dubins_reproduces_the_reference_graphs_and_solves(dubins_subst):
+    from oracle import port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    tpl, d = dubins_subst
+    nlp = NumpyNLP(tpl)
+    for xv, pv, fs, gs in zip(d['xs'], d['ps'], d['fs'], d['gs']):          # values of the reference's f / g closures
+        f, g = nlp.fg(xv, nlp.term_coefs(pv))
+        assert abs(f - fs) < 1e-12 * (1 + abs(fs)) and np.abs(g - gs).max() < 1e-12 * (1 + np.abs(gs).max())
+    _check_subst(tpl, d, port_binding.solve(tpl, d['p0'][None], d['x0'][None], tol=1e-3, max_iter=3000))
+
+
+@pytest.mark.gpu
+def test_substituted_dubins_on_the_device(dubins_subst):
+    import omgtools.backend as be
+    from oracle import port_binding
+    tpl, d = dubins_subst
+    solver = be.BatchSolver(tpl, 2, options=dict(tol=1e-3, max_iter=3000))
+    try:
+        res = solver.solve(np.repeat(d['p0'][None], 2, axis=0), np.repeat(d['x0'][None], 2, axis=0), lbg=tpl.lb, ubg=tpl.ub)
+    finally:
+        solver.close()
+    assert np.array_equal(res['x'][0], res['x'][1])
+    _check_subst(tpl, d, res)
+    port = port_binding.solve(tpl, d['p0'][None], d['x0'][None], tol=1e-3, max_iter=3000)
+    assert abs(int(port['iters'][0]) - int(res['iters'][0])) <= 40 and np.abs(port['x'][0] - res['x'][0]).max() < 1e-2
+
+
 # ---- rotating obstacles (`environment/obstacle.py:299-332`, `examples/revolving_door.py`) --------------------------------
 # tests/golden/revolving_door.npz: the template of the reference's own example on `omgx_shim`; the orientation of the two
 # rotating beams enters through cos / sin of (theta - t omega): COS / SIN atoms of the parameter program.
