@@ -1832,6 +1832,39 @@ OMGX_FN void trsv_bwd4(const C& c, const double* A, Addr L, int n, double* y, co
   }
 }
 
+// y <- L^{-1} y for the same storage, by one wave (the forward twin of trsv_bwd4: blocks of four columns, the 4 x 4
+// diagonal block solved redundantly in every lane, the rows below updated one per lane).  With `iv` the storage holds
+// U = L D (leaf panels), L_ij = U_ij iv_j; without, L itself with the pivots on the diagonal (root).  Used by the
+// second solve of an iteration (kkt_solve2_blocked): the first right-hand side goes through the factorisation instead.
+template <class C, class Addr>
+OMGX_FN void trsv_fwd4(const C& c, const double* A, Addr L, int n, double* y, const double* iv = nullptr) {
+  const int lane = c.lane(), nln = c.nlanes();
+  const int nblk = (n + 3) >> 2;
+  for (int bk = 0; bk < nblk; ++bk) {
+    const int jb = 4 * bk;
+    const int nb = (n - jb) < 4 ? (n - jb) : 4;
+    const int q1 = nb > 1 ? 1 : 0, q2 = nb > 2 ? 2 : 0, q3 = nb > 3 ? 3 : 0;
+    const double m1 = nb > 1 ? 1.0 : 0.0, m2 = nb > 2 ? 1.0 : 0.0, m3 = nb > 3 ? 1.0 : 0.0;
+    const double s0 = iv ? iv[jb] : 1.0, s1 = iv ? iv[jb + q1] : 1.0, s2 = iv ? iv[jb + q2] : 1.0, s3 = iv ? iv[jb + q3] : 1.0;
+    const double l10 = m1 * A[L(jb + q1, jb)] * s0;
+    const double l20 = m2 * A[L(jb + q2, jb)] * s0, l21 = m2 * A[L(jb + q2, jb + (q2 ? 1 : 0))] * s1;
+    const double l30 = m3 * A[L(jb + q3, jb)] * s0, l31 = m3 * A[L(jb + q3, jb + (q3 ? 1 : 0))] * s1,
+                 l32 = m3 * A[L(jb + q3, jb + (q3 ? 2 : 0))] * s2;
+    const double x0 = y[jb], x1 = m1 * (y[jb + q1] - l10 * x0), x2 = m2 * (y[jb + q2] - l20 * x0 - l21 * x1),
+                 x3 = m3 * (y[jb + q3] - l30 * x0 - l31 * x1 - l32 * x2);
+    c.wave_sync();                                  // (every lane has read the block before anybody writes it)
+    for (int i = jb + lane; i < n; i += nln) {
+      if (i >= jb + nb) {
+        y[i] -= A[L(i, jb)] * s0 * x0 + m1 * A[L(i, jb + q1)] * s1 * x1 + m2 * A[L(i, jb + q2)] * s2 * x2 + m3 * A[L(i, jb + q3)] * s3 * x3;
+      } else {
+        const int q = i - jb;
+        y[i] = q == 0 ? x0 : (q == 1 ? x1 : (q == 2 ? x2 : x3));
+      }
+    }
+    c.wave_sync();
+  }
+}
+
 // Finish the solve of K sol = rhs.  The right-hand side went through the factorisation as the carried
 // last row of every leaf panel and of the root (kkt_rhs wrote it there), so the forward substitutions
 // are done: the rows hold L^{-1} r.  What is left: scale by the inverse pivots, the root's backward
@@ -1943,7 +1976,7 @@ static thread_local std::vector<double> omgx_sol2;       // output of a second s
 #endif
 // One more solve with the factors of the iteration (second-order correction): the caller wrote the right-hand side into
 // the slots of kkt_rhs; out [N] receives the solution in position order (the equality multipliers of this solve are
-// dropped).  Templates on the wave path only (Dims::wave_ok): device by the wave routines, host port by plain loops
+// dropped).  Device: the wave routines on the wave path (Dims::wave_ok), the blocked form below otherwise; host port: plain loops
 // over the storage its blocked routines leave (leaf panels U = L D with inverse pivots aside, root L with the pivots
 // on the diagonal).
 template <class C>
@@ -1951,6 +1984,76 @@ OMGX_FN void kkt_solve2(const C& c, const Dims& d, const Kkt& K, Work& w, double
 #ifndef OMGX_HOST_PORT
   if constexpr (C::wave_only) {
     kkt_solve2_wave(c, d, K, w, out);
+  } else {
+    // Blocked storage (templates off the wave path, spill modes included): leaf right-hand sides from their carried rows into
+    // `out` (LDS), a wave per leaf substitutes forwards, the leaves subtract W Delta^-1 y from the root's right-hand side one
+    // after the other (fixed order), wave 0 substitutes the root forwards and backwards in its right-hand-side row, the leaves
+    // finish as in kkt_solve.
+    const BMat* Ms = (const BMat*)w.col;
+    const int nr = d.nr, rbase = Ms[d.n_leaf].a;
+    double* rootp = C::root_lds ? w.root : w.kkt;
+    double* rr = rootp + rbase + tri(nr, 0);
+    if constexpr (C::root_lds) { OMGX_PFOR(k, nr) rr[k] = w.kkt[Ms[d.n_leaf].pad_ + tri(nr, k)]; }
+    OMGX_PFOR(q, d.root_off) {
+      int l = 0;
+      while (q >= Ms[l].dinv + Ms[l].nfact) ++l;
+      const BMat M = Ms[l];
+      OMGX_PANEL_STRIDES(C, M, sr, sc);
+      out[q] = w.kkt[M.a + (M.rows - 1) * sr + (q - M.dinv) * sc];
+    }
+    c.sync();
+    for (int l = c.wave(); l < d.n_leaf; l += c.nwaves()) {
+      const BMat M = Ms[l];
+      const int base = M.a;
+      OMGX_PANEL_STRIDES(C, M, sr, sc);
+      trsv_fwd4(c, w.kkt, [=](int i, int j) { return base + i * sr + j * sc; }, M.nfact, out + M.dinv, w.dinv + M.dinv);
+    }
+    c.sync();
+    for (int l = 0; l < d.n_leaf; ++l) {
+      const BMat M = Ms[l];
+      const int n = M.nfact, nc = M.rows - 1 - n;
+      OMGX_PANEL_STRIDES(C, M, sr, sc);
+      const int32_t* ci = K.cpl_idx + M.cpl;
+      const double* yl = out + M.dinv;
+      const double* iv = w.dinv + M.dinv;
+      OMGX_PFOR(a, nc) {
+        const double* Pa = w.kkt + M.a + (n + a) * sr;
+        double acc = 0.0;
+#pragma unroll 4
+        for (int j = 0; j < n; ++j) acc += Pa[j * sc] * (yl[j] * iv[j]);
+        rr[ci[a]] -= acc;
+      }
+      c.sync();
+    }
+    if (c.wave() == 0) trsv_fwd4(c, rootp, [=](int i, int j) { return rbase + tri(i, j); }, nr, rr);
+    c.sync();
+    OMGX_PFOR(q, d.root_off) out[q] *= w.dinv[q];
+    OMGX_PFOR(k, nr) rr[k] = rr[k] / rootp[rbase + tri(k, k)];
+    c.sync();
+    if (c.wave() == 0) trsv_bwd4(c, rootp, [=](int i, int j) { return rbase + tri(i, j); }, nr, rr);
+    c.sync();
+    OMGX_PFOR(q, d.root_off) {
+      int l = 0;
+      while (q >= Ms[l].dinv + Ms[l].nfact) ++l;
+      const BMat M = Ms[l];
+      const int n = M.nfact, nc = M.rows - 1 - M.nfact, j = q - M.dinv;
+      OMGX_PANEL_STRIDES(C, M, sr, sc);
+      const double* Pn = w.kkt + M.a + n * sr + j * sc;
+      const int32_t* ci = K.cpl_idx + M.cpl;
+      double acc = 0.0;
+#pragma unroll 4
+      for (int a = 0; a < nc; ++a) acc += Pn[a * sr] * rr[ci[a]];
+      out[q] -= acc * w.dinv[q];
+    }
+    c.sync();
+    for (int l = c.wave(); l < d.n_leaf; l += c.nwaves()) {
+      const BMat M = Ms[l];
+      const int base = M.a;
+      OMGX_PANEL_STRIDES(C, M, sr, sc);
+      trsv_bwd4(c, w.kkt, [=](int i, int j) { return base + i * sr + j * sc; }, M.nfact, out + M.dinv, w.dinv + M.dinv);
+    }
+    OMGX_PFOR(k, d.n_root) out[d.root_off + k] = rr[k];
+    c.sync();
   }
 #else
   const BMat* Ms = (const BMat*)w.col;
@@ -2631,7 +2734,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
 #ifndef OMGX_SOC_COMPILED
 #define OMGX_SOC_COMPILED 1
 #endif
-    int soc = (OMGX_SOC_COMPILED && o.max_soc > 0 && d.wave_ok) ? 0 : 2;      // 0: not tried yet, 1: the trial under way is the corrected one, 2: done
+    // (wave path: kkt_solve2_wave; every other template: kkt_solve2's blocked form -- round 4: the spill classes gain most,
+    // 39 -> 33 cold iterations on the 3-D class, and a tube of quartic range rows 717 -> 149)
+    int soc = (OMGX_SOC_COMPILED && o.max_soc > 0) ? 0 : 2;      // 0: not tried yet, 1: the trial under way is the corrected one, 2: done
     for (int bt = 0; bt < OMGX_MAX_BACKTRACK; ++bt) {
       if (soc == 1) { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + (alpha * w.sol[q] + w.gbar[q]); } }
       else { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + alpha * w.sol[q]; } }

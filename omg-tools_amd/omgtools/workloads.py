@@ -174,8 +174,10 @@ def fill_quadrotor_p2p(tpl, veh_label, problem_label, obstacle_labels, L, degree
         _set(tpl, p, b, problem_label, 'T', horizon_time)
         straight_line(tpl, x0, b, veh_label, L, start, goal, clamp=degree)
     # cold starts of this class: barrier parameter from 1 instead of 0.1 (82 -> 57 iterations on average, the
-    # same agents converge)
-    return {'p': p, 'x0': x0, 'solver_options': {'mu_init': 1.0}}
+    # same agents converge); no second-order correction: with the KKT store in the slab (mode 1) the extra forward
+    # substitution costs more than the 4 % of the iterations it saves (4096 agents: 17.2 k cold solves/s without, 14.0 k with;
+    # the 3-D class, mode 3, gains 15 % of its iterations and keeps it)
+    return {'p': p, 'x0': x0, 'solver_options': {'mu_init': 1.0, 'max_soc': 0}}
 
 
 def fill_holonomic3d_p2p(tpl, veh_label, problem_label, obstacle_labels, L, n_agents, seed, horizon_time):

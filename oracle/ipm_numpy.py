@@ -533,7 +533,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         # second-order correction (omgx_core.h, option max_soc; templates on the wave path like there): when the first
         # trial is rejected, one more solve with the factors of the iteration for what the rows moved beyond their
         # linearisation; the corrected step is offered once before the halving starts
-        soc = 0 if (o['max_soc'] > 0 and getattr(nlp, 'wave_ok', False)) else 2
+        soc = 0 if o['max_soc'] > 0 else 2
         d_c = None
         for bt in range(o['max_backtrack']):
             step = alpha * dxt + d_c if soc == 1 else alpha * dxt
