@@ -86,3 +86,25 @@ def test_rollout_with_moving_obstacles():
     for name in ('x', 'lam', 'p', 'status', 'iters'):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     a.solver.close(); b.solver.close()
+
+
+def test_rollout_refuses_what_it_cannot_do():
+    """A crossing without shift tables, and a template class without a rollout kernel (spill mode), are errors -- not silent
+    fallbacks."""
+    import torch
+    from omgtools import workloads
+    from omgtools.backend import OmgxError
+    from omgtools.batch import BatchP2P
+    (a, b) = _pair(8)
+    with pytest.raises(OmgxError):
+        a.solver.rollout(a.p, a.x, a.lb, a.ub, a.lam, a.status, a.iters, [0.05], [0.0], [1], a.o_spl, a.n_spl, a.basis.degree,
+                         a.basis.knots, 1.0 / a.T, a.p_offs, a.o_t)
+    a.solver.close(); b.solver.close()
+    problem, P = workloads.quadrotor_p2p(4)
+    q = BatchP2P(problem, P, ops='hip', device=torch.device('cuda', 0), options=dict(P['solver_options'], tol=1e-3, max_iter=300))
+    q.solve_cold(bends=())
+    with pytest.raises(OmgxError):
+        q.rollout(2)
+    q.step()                                             # the stepwise loop is what such a class uses
+    torch.cuda.synchronize()
+    q.solver.close()

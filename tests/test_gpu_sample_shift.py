@@ -105,6 +105,28 @@ def test_shift_matches_matrix(cfg2_small):
     solver.close()
 
 
+def test_shift_table_sets_are_cached_and_evicted(cfg2_small):
+    """The handle keeps the table sets it has seen on the device (16, found again by content; the least recently used one goes):
+    twenty different sets, then the first ones again -- every shift equals the matrix product."""
+    problem, P, solver = _solver(cfg2_small)
+    tpl = problem.father.template
+    rng = np.random.default_rng(11)
+    lo, rows, cols = tpl.var_layout[(problem.vehicles[0].label, 'splines_seg0')]
+    mask = np.ones(8, dtype=np.uint8)
+    sets = [rng.normal(size=(rows, rows)) for _ in range(20)]
+    for k in list(range(20)) + [0, 1, 19, 5]:
+        Tm = sets[k]
+        x = rng.normal(size=(8, tpl.n_var))
+        want = x.copy()
+        for b in range(8):
+            blk = x[b, lo:lo + rows * cols].reshape((rows, cols), order='F')
+            want[b, lo:lo + rows * cols] = (Tm @ blk).reshape(-1, order='F')
+        got = x.copy()
+        solver.shift(got, mask, np.array([[lo, rows, cols, 0]]), Tm.reshape(-1))
+        assert np.abs(got - want).max() < 1e-12, k
+    solver.close()
+
+
 def test_predict_matches_basis_evaluation(cfg2_small):
     """`omgx_batch_predict` (ideal prediction, `vehicles/vehicle.py:323-326`): state0 = spline(tau),
     input0 = spline'(tau)/T, t written into p -- against the host basis matrices."""
