@@ -291,32 +291,23 @@ def two_streams_leg(problem, P, opts, n_steps, warmup, dev):
     HIP stream: the steps of the two halves are not ordered against each other, so while one half waits for a straggler the
     other half's next step fills the idle workgroup slots (per-step launches as in the headline: a deployment that feeds
     measured states back can use it).  Reported next to the headline, not as it."""
-    from omgtools.batch import BatchP2P
+    from omgtools.batch import StreamedP2P
     B = P['p'].shape[0]
     n = B // 2
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    halves = []
-    for s in range(2):
-        Ps = dict(P, p=P['p'][s * n:(s + 1) * n], x0=P['x0'][s * n:(s + 1) * n])
-        with torch.cuda.stream(streams[s]):
-            m = BatchP2P(problem, Ps, ops='hip', device=dev, options=opts)
-            m.solve_cold(bends=())
-            for _ in range(warmup):
-                m.step()
-        halves.append(m)
-    torch.cuda.synchronize()
+    pair = StreamedP2P(problem, P, n_streams=2, device=dev, options=opts)
+    pair.solve_cold(bends=())
+    for _ in range(warmup):
+        pair.step()
+    pair.synchronize()
     quiet_host()
     t_0 = time.perf_counter()
     for _ in range(n_steps):
-        for m, st in zip(halves, streams):
-            with torch.cuda.stream(st):
-                m.step()
-    torch.cuda.synchronize()
+        pair.step()
+    pair.synchronize()
     wall = time.perf_counter() - t_0
     gc.enable()
-    ok = sum(int((m.status == 0).sum().item()) for m in halves)
-    for m in halves:
-        m.solver.close()
+    ok = int((pair.gather('status') == 0).sum().item())
+    pair.close()
     return {'solves_per_s': B * n_steps / wall, 'ms_per_step': wall / n_steps * 1e3, 'steps': n_steps, 'warmup': warmup,
             'solved_in_last_step': ok, 'note': 'two sub-batches of %d agents on two HIP streams, per-step launches' % n}
 

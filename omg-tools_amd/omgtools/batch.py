@@ -354,3 +354,53 @@ class BatchP2P(object):
     def host(self, name):
         a = getattr(self, name)
         return a.cpu().numpy() if self.kind == 'hip' else np.asarray(a)
+
+
+class StreamedP2P(object):
+    """The batch as `n_streams` sub-batches, each a `BatchP2P` with its own library handle on its own HIP stream.  The problems of
+    a point-to-point batch are independent, so nothing orders the steps of one sub-batch against those of another: while one waits
+    for a straggler of its step, the next step of the other fills the idle workgroup slots (1024 agents, two streams: 2.07 M
+    solves/s against 1.74 M on one stream; more streams lose again -- every handle launches a full grid of persistent workgroups).
+    Per agent the same launches in the same order as `BatchP2P`: the same bits (tests/test_gpu_rollout.py).  `step` returns
+    whether the step crossed a knot; `gather(name)` concatenates an attribute of the sub-batches (x, p, lam, status, iters)."""
+
+    def __init__(self, problem, P, n_streams=2, device=None, **kw):
+        import torch
+        self.torch = torch
+        B = P['p'].shape[0]
+        if n_streams < 1 or B % n_streams:
+            raise ValueError('%d agents do not split into %d equal sub-batches' % (B, n_streams))
+        n = B // n_streams
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        self.parts = []
+        for s, st in enumerate(self.streams):
+            Ps = dict(P, p=P['p'][s * n:(s + 1) * n], x0=P['x0'][s * n:(s + 1) * n])
+            with torch.cuda.stream(st):
+                self.parts.append(BatchP2P(problem, Ps, ops='hip', device=device, **kw))
+        self.B = B
+
+    def _each(self, fn):
+        out = []
+        for part, st in zip(self.parts, self.streams):
+            with self.torch.cuda.stream(st):
+                out.append(fn(part))
+        return out
+
+    def solve_cold(self, **kw):
+        return max(self._each(lambda m: m.solve_cold(**kw)))
+
+    def step(self):
+        return any(self._each(lambda m: m.step()))
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def gather(self, name):
+        self.synchronize()
+        return self.torch.cat([getattr(m, name) for m in self.parts])
+
+    def close(self):
+        for m in self.parts:
+            m.solver.close()
+

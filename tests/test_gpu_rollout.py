@@ -108,3 +108,26 @@ def test_rollout_refuses_what_it_cannot_do():
     q.step()                                             # the stepwise loop is what such a class uses
     torch.cuda.synchronize()
     q.solver.close()
+
+
+def test_two_streams_give_the_same_plans():
+    """`StreamedP2P`: two sub-batches on two HIP streams -- per agent the launches of `BatchP2P`, so the same bits."""
+    import torch
+    from omgtools import workloads
+    from omgtools.batch import BatchP2P, StreamedP2P
+    n = 64
+    problem, P = workloads.holonomic_p2p(n)
+    one = BatchP2P(problem, P, ops='hip', device=torch.device('cuda', 0), options=dict(tol=1e-3, max_iter=300))
+    problem2, P2 = workloads.holonomic_p2p(n)
+    two = StreamedP2P(problem2, P2, n_streams=2, device=torch.device('cuda', 0), options=dict(tol=1e-3, max_iter=300))
+    one.solve_cold(bends=()); two.solve_cold(bends=())
+    crossed = 0
+    for _ in range(11):
+        c1, c2 = one.step(), two.step()
+        assert bool(c1) == bool(c2)
+        crossed += int(bool(c1))
+    torch.cuda.synchronize()
+    assert crossed == 1
+    for name in ('x', 'lam', 'p', 'status', 'iters'):
+        assert torch.equal(getattr(one, name), two.gather(name)), name
+    one.solver.close(); two.close()
