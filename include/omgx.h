@@ -332,7 +332,8 @@ int  omgx_batch_predict_quadrotor(omgx_batch* b, const double* x, double* p, int
  * separate calls; what goes is the barrier between the steps of different agents.  p, x, lam_g, status, iters are updated
  * in place (device pointers: OMGX_PTR_DEVICE | OMGX_BOUNDS_DEVICE required; OMGX_BOUNDS_SHARED as for omgx_batch_solve);
  * the handle's options apply (warm_start = 1 expected), cross_options (optional) to the solves right after a crossing.
- * With omgx_batch_set_stats step k of the call fills the next free row.  iters_log / status_log (optional, device,
+ * With omgx_batch_set_stats step k of the call fills the next free row; with omgx_batch_set_store every step writes the
+ * agent's sampled trajectories as a single solve would (the last step's stay).  iters_log / status_log (optional, device,
  * [n_steps][n_agents]) keep the per-step values.  Templates of the wave path without two-sided rows only (config 1 / 2
  * class, ADMM x-update templates); others return OMGX_E_INVALID -- step with omgx_batch_solve.  Host arrays are read
  * during the call. */

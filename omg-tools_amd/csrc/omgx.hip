@@ -610,7 +610,8 @@ ipm_rollout_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles, 
                    const double* __restrict__ lb, const double* __restrict__ ub, int bounds_shared, double* __restrict__ lam,
                    int32_t* __restrict__ status, int32_t* __restrict__ iters, int n_agents, double* __restrict__ slabs,
                    size_t slab_doubles, double* __restrict__ dw_state, int* __restrict__ next_slot,
-                   const RolloutArgs* __restrict__ rop, int stagger, const int32_t* __restrict__ order) {
+                   const RolloutArgs* __restrict__ rop, int stagger, const int32_t* __restrict__ order,
+                   const StoreArgs* __restrict__ stp) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles, d, kkt_doubles);
@@ -694,6 +695,13 @@ ipm_rollout_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles, 
         }
         if (rop->iters_log) rop->iters_log[(size_t)k * n_agents + b] = r.iters;
         if (rop->status_log) rop->status_log[(size_t)k * n_agents + b] = r.status;
+      }
+      if (stp) {      // `Vehicle.store` of this step (omgx_batch_set_store), as in the solve kernel's epilogue
+        const StoreArgs st2 = *stp;
+        __syncthreads();
+        sample_agent<double>(w.x + st2.coeff_off, w.kkt, st2.n_spl, st2.degree, st2.knots, st2.n_knots, st2.n_der, st2.t0[b],
+                             st2.dt, st2.inv_T, st2.n_samp, 0, st2.n_samp, st2.out + (size_t)b * st2.n_der * st2.n_spl * st2.n_samp,
+                             st2.v_tot ? st2.v_tot + (size_t)b * st2.n_samp : nullptr);
       }
       __syncthreads();
     }
@@ -996,7 +1004,7 @@ bool plan_for_mode(omgx::HostPlan& plan, const omgx_template& t, int* mode, size
 }
 
 typedef void (*ipm_rollout_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, double*, double*, const double*, const double*, int, double*,
-                              int32_t*, int32_t*, int, double*, size_t, double*, int*, const RolloutArgs*, int, const int32_t*);
+                              int32_t*, int32_t*, int, double*, size_t, double*, int*, const RolloutArgs*, int, const int32_t*, const StoreArgs*);
 // (the classes of the wave path without quartic terms / cos / sin atoms: the receding-horizon classes that fit LDS)
 static ipm_rollout_t rollout_kernel_for(int mode, int wave_ok, int general) {
   if (!wave_ok || general) return nullptr;
@@ -1979,7 +1987,8 @@ int omgx_batch_rollout(omgx_batch* b, const omgx_rollout_spec* sp, double* p, do
   b->timed = false;
   hipExtLaunchKernelGGL(kern, dim3(b->n_slabs < b->n_agents ? b->n_slabs : b->n_agents), dim3(b->threads), (uint32_t)b->lds_bytes, b->stream, e0, e1, 0u,
                         d, b->dev, b->opts, b->kkt_doubles, p, x, lbg, ubg, shared ? 1 : 0, lam_g, status, iters, b->n_agents,
-                        b->d_slabs, b->slab_doubles, b->d_dw, b->d_next, (const RolloutArgs*)b->d_rollout, b->stagger, b->d_order);
+                        b->d_slabs, b->slab_doubles, b->d_dw, b->d_next, (const RolloutArgs*)b->d_rollout, b->stagger, b->d_order,
+                        (const StoreArgs*)(b->store.out ? b->d_store : nullptr));
   HIPCHK(hipGetLastError());
   return OMGX_OK;
 }

@@ -131,3 +131,25 @@ def test_two_streams_give_the_same_plans():
     for name in ('x', 'lam', 'p', 'status', 'iters'):
         assert torch.equal(getattr(one, name), two.gather(name)), name
     one.solver.close(); two.close()
+
+
+def test_rollout_writes_the_stored_trajectories():
+    """`omgx_batch_set_store` holds for the rollout launch too: after K steps the sampled state / input / dinput of every agent are
+    those the stepwise loop leaves (the same routine in both epilogues: the same bits)."""
+    import torch
+    a, b = _pair(16)
+    outs = []
+    for m in (a, b):
+        veh, tpl = m.veh, m.tpl
+        f64 = dict(dtype=torch.float64, device=m.dev)
+        out, vt, t0 = torch.zeros((16, 3, veh.n_dim, 101), **f64), torch.zeros((16, 101), **f64), torch.zeros(16, **f64)
+        m.solver.set_store(out, vt, t0, m.o_spl, veh.n_dim, m.basis.degree, m.basis.knots, 3, 101, 0.1 / m.T, 1.0 / m.T)
+        outs.append((out, vt, t0))
+    a.rollout(5)
+    for _ in range(5):
+        b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and float(outs[0][0].abs().max()) > 0.1
+    for m in (a, b):
+        m.solver.set_store(None)
+        m.solver.close()
