@@ -151,8 +151,9 @@ typedef struct omgx_options {
   int32_t max_soc;             /* (version 5) 1 (default): a line search whose first trial is rejected offers the step once more with a
                            second-order correction -- one more solve with the factors of the iteration for the amount the rows
                            moved beyond their linearisation (the bilinear hyperplane rows) -- before it halves the step (IPOPT:
-                           max_soc, the component replaced behind `basics/optilayer.py:60`); 0: plain backtracking.  Templates
-                           whose KKT panels fit the register-resident wave routines (omgx_plan_info.wave_path) */
+                           max_soc, the component replaced behind `basics/optilayer.py:60`); 0: plain backtracking.  Every template
+                           class: the register-resident wave routines where the KKT panels fit them (omgx_plan_info.wave_path),
+                           the blocked second solve elsewhere (spill modes included) */
 } omgx_options;
 
 typedef struct omgx_batch omgx_batch;

@@ -1948,7 +1948,8 @@ int omgx_batch_rollout(omgx_batch* b, const omgx_rollout_spec* sp, double* p, do
     if (b->ro_perm_host.size() != (size_t)d.n_con || memcmp(b->ro_perm_host.data(), sp->lam_perm, d.n_con * sizeof(int32_t)) != 0) {
       if (!b->d_ro_perm) HIPCHK(hipMalloc((void**)&b->d_ro_perm, sizeof(int32_t) * (size_t)d.n_con));
       b->ro_perm_host.assign(sp->lam_perm, sp->lam_perm + d.n_con);
-      HIPCHK(hipMemcpy(b->d_ro_perm, b->ro_perm_host.data(), sizeof(int32_t) * (size_t)d.n_con, hipMemcpyHostToDevice));
+      // (stream-ordered like the two copies below: a rollout still running on a non-blocking caller stream reads the old map)
+      HIPCHK(hipMemcpyAsync(b->d_ro_perm, b->ro_perm_host.data(), sizeof(int32_t) * (size_t)d.n_con, hipMemcpyHostToDevice, b->stream));
     }
     a.lam_perm = b->d_ro_perm;
   }
@@ -1977,9 +1978,11 @@ int omgx_batch_rollout(omgx_batch* b, const omgx_rollout_spec* sp, double* p, do
   }
   a.iters_log = sp->iters_log; a.status_log = sp->status_log;
   if (!b->d_rollout) HIPCHK(hipMalloc((void**)&b->d_rollout, sizeof(RolloutArgs)));
-  // (two small synchronous copies per call: one call is n_steps steps of the whole batch)
-  HIPCHK(hipMemcpy(b->d_ro_steps, steps.data(), sizeof(RolloutStep) * steps.size(), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(b->d_rollout, &a, sizeof(RolloutArgs), hipMemcpyHostToDevice));
+  // Two small copies per call (one call is n_steps steps of the whole batch), ORDERED ON THE HANDLE'S STREAM: the persistent
+  // kernel of a previous rollout reads these tables for its whole run, and on a non-blocking caller stream a null-stream
+  // hipMemcpy would overwrite them under it (pageable sources: staged before the calls return, executed in stream order).
+  HIPCHK(hipMemcpyAsync(b->d_ro_steps, steps.data(), sizeof(RolloutStep) * steps.size(), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_rollout, &a, sizeof(RolloutArgs), hipMemcpyHostToDevice, b->stream));
   { const int rc_o = flush_order(b); if (rc_o != OMGX_OK) return rc_o; }
   const bool shared = flags & OMGX_BOUNDS_SHARED;
   hipEvent_t e0 = b->ext_ev0, e1 = b->ext_ev0 ? b->ext_ev1 : nullptr;
@@ -2048,6 +2051,8 @@ int omgx_admm_center_ex(omgx_batch* b, const omgx_admm_layout* lay, const double
 int omgx_batch_set_center(omgx_batch* b, const omgx_admm_layout* lay, double* x_i, const int32_t* pub_rows, int32_t n_pub, double* x_send) {
   if (!b) { g_err = "bad argument"; return OMGX_E_INVALID; }
   if (!lay) { b->center_on = false; return OMGX_OK; }
+  // (a failed registration leaves the epilogue OFF: the previous x_i may be a buffer the caller has released since)
+  b->center_on = false;
   if (!x_i || n_pub < 0 || (n_pub > 0 && (!pub_rows || !x_send)) || lay->n_dim <= 0 || lay->L <= 0 ||
       lay->x_spl < 0 || lay->x_spl + lay->n_dim * lay->L > b->dims.n_var || lay->p_rel < 0 || lay->p_rel + lay->n_dim > b->dims.n_par) {
     g_err = "bad argument"; return OMGX_E_INVALID;

@@ -162,7 +162,7 @@ struct Opts {
   double warm_mu_factor;       // warm starts: mu_0 = clamp(warm_mu_factor * mean(s z), tol / 10, mu_init)
   double warm_z_floor;         // warm starts: multipliers lifted to max(OMGX_WARM_ZMIN, min(warm_z_floor * tol, warm_z_cap * tol / slack))
   double warm_z_cap;           // (0: no cap)
-  int max_soc;                 // 1: a rejected first trial of the line search is answered by a second-order correction (wave-path templates)
+  int max_soc;                 // 1: a rejected first trial of the line search is answered by a second-order correction (every template class: kkt_solve2_wave / kkt_solve2)
 };
 
 // fixed constants of the iteration (same values in oracle/ipm_numpy.py DEFAULTS)

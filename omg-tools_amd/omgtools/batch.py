@@ -245,7 +245,10 @@ class BatchP2P(object):
         return passes
 
     # -- one receding-horizon step ---------------------------------------------------------
-    def step(self, events=None):
+    def step(self, events=None, before_solve=None):
+        """before_solve(self): called between the glue of the step (prediction, obstacles, shift: p and x are what the
+        solve will read) and the solve -- where a caller with host buffers uploads its parameters (bench.py's pipelined
+        host-boundary leg)."""
         B, L, nd = self.B, self.L, self.n_dim
         t_prev = self.time
         t_now = t_prev + self.update_time
@@ -279,6 +282,8 @@ class BatchP2P(object):
         if crossed:
             self._shift()
         self.time = t_now
+        if before_solve is not None:
+            before_solve(self)
         # (3) warm-started solve
         self._solve(True, events, ordered=self.kind == 'hip' and self.straggler_first, extra=self.cross_options if crossed else None)
         return crossed
@@ -361,8 +366,10 @@ class StreamedP2P(object):
     a point-to-point batch are independent, so nothing orders the steps of one sub-batch against those of another: while one waits
     for a straggler of its step, the next step of the other fills the idle workgroup slots (1024 agents, two streams: 2.07 M
     solves/s against 1.74 M on one stream; more streams lose again -- every handle launches a full grid of persistent workgroups).
-    Per agent the same launches in the same order as `BatchP2P`: the same bits (tests/test_gpu_rollout.py).  `step` returns
-    whether the step crossed a knot; `gather(name)` concatenates an attribute of the sub-batches (x, p, lam, status, iters)."""
+    Per agent the same launches in the same order as `BatchP2P`: the same bits (tests/test_gpu_rollout.py).  Since round 5 this is
+    what `receding_horizon_batch` hands out for a batch of at least two rounds of resident workgroups: the per-step product path.
+    `step` returns whether the step crossed a knot; `x, p, lam, status, iters` join the streams and concatenate the sub-batches
+    (`gather`); `parts[k]` / `streams[k]` give the sub-batches to callers that attach events, statistics or copies per stream."""
 
     def __init__(self, problem, P, n_streams=2, device=None, **kw):
         import torch
@@ -371,13 +378,19 @@ class StreamedP2P(object):
         if n_streams < 1 or B % n_streams:
             raise ValueError('%d agents do not split into %d equal sub-batches' % (B, n_streams))
         n = B // n_streams
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        self.dev = device if device is not None else torch.device('cuda', 0)
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(n_streams)]
         self.parts = []
+        # (the caller's stream may still be writing what the sub-batches read, and the other way round at the end)
+        ready = torch.cuda.current_stream(self.dev).record_event()
         for s, st in enumerate(self.streams):
             Ps = dict(P, p=P['p'][s * n:(s + 1) * n], x0=P['x0'][s * n:(s + 1) * n])
+            st.wait_event(ready)
             with torch.cuda.stream(st):
-                self.parts.append(BatchP2P(problem, Ps, ops='hip', device=device, **kw))
-        self.B = B
+                self.parts.append(BatchP2P(problem, Ps, ops='hip', device=self.dev, **kw))
+        self.B, self.n_sub = B, n
+        self.kind = 'hip'
+        self.tpl, self.problem = self.parts[0].tpl, problem
 
     def _each(self, fn):
         out = []
@@ -389,18 +402,88 @@ class StreamedP2P(object):
     def solve_cold(self, **kw):
         return max(self._each(lambda m: m.solve_cold(**kw)))
 
-    def step(self):
-        return any(self._each(lambda m: m.step()))
+    def restart_failed(self, *a, **kw):
+        return max(self._each(lambda m: m.restart_failed(*a, **kw)))
+
+    def step(self, events=None, before_solve=None):
+        """events: one (start, stop) pair per sub-batch (stamped on that sub-batch's solve kernel)."""
+        evs = events if events is not None else [None] * len(self.parts)
+        hooks = before_solve if isinstance(before_solve, (list, tuple)) else [before_solve] * len(self.parts)
+        out = []
+        for part, st, ev, hk in zip(self.parts, self.streams, evs, hooks):
+            with self.torch.cuda.stream(st):
+                out.append(part.step(events=ev, before_solve=hk))
+        return any(out)
+
+    @property
+    def time(self):
+        return self.parts[0].time
+
+    @time.setter
+    def time(self, t):
+        for m in self.parts:
+            m.time = t
 
     def synchronize(self):
         for st in self.streams:
             st.synchronize()
 
+    def join(self):
+        """The caller's current stream waits for everything enqueued on the sub-batches' streams (no host sync)."""
+        cur = self.torch.cuda.current_stream(self.dev)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def fork(self):
+        """The sub-batches' streams wait for what the caller's current stream has enqueued so far (e.g. a reset of x / p)."""
+        cur = self.torch.cuda.current_stream(self.dev)
+        for st in self.streams:
+            st.wait_stream(cur)
+
     def gather(self, name):
-        self.synchronize()
+        self.join()
         return self.torch.cat([getattr(m, name) for m in self.parts])
 
+    def load(self, x=None, p=None):
+        """x / p of the whole batch -> the sub-batches (device tensors [B, *]), ordered behind the caller's stream."""
+        self.fork()
+        n = self.n_sub
+        for k, (m, st) in enumerate(zip(self.parts, self.streams)):
+            with self.torch.cuda.stream(st):
+                if x is not None:
+                    m.x.copy_(x[k * n:(k + 1) * n])
+                if p is not None:
+                    m.p.copy_(p[k * n:(k + 1) * n])
+
+    x = property(lambda self: self.gather('x'))
+    p = property(lambda self: self.gather('p'))
+    lam = property(lambda self: self.gather('lam'))
+    status = property(lambda self: self.gather('status'))
+    iters = property(lambda self: self.gather('iters'))
+
+    def host(self, name):
+        return self.gather(name).cpu().numpy()
+
     def close(self):
+        self.synchronize()
         for m in self.parts:
             m.solver.close()
 
+
+def receding_horizon_batch(problem, P, device=None, n_streams='auto', **kw):
+    """The per-step product path for a batch of independent agents: a `BatchP2P`, or -- when the batch is at least two rounds
+    of resident workgroups (1024 agents of config 2 on 512 slots) -- the same batch as two stream-ordered half-launches
+    (`StreamedP2P`): a step of the whole batch is quantised in rounds of the resident workgroups and one straggler costs the
+    batch a whole extra round; with two halves on two streams the next step of one half fills the slots the
+    other half's straggler leaves idle.  Per agent the same launches, the same bits."""
+    import torch
+    dev = device if device is not None else torch.device('cuda', 0)
+    B = P['p'].shape[0]
+    if n_streams == 'auto' or n_streams <= 1:
+        whole = BatchP2P(problem, P, ops='hip', device=dev, **kw)
+        # (the launch grid of the handle = the workgroups the chip holds at once, capped at the batch)
+        if n_streams != 'auto' or B % 2 or B < 2 * whole.solver.workspace()['n_slabs']:
+            return whole
+        whole.solver.close()
+        n_streams = 2
+    return StreamedP2P(problem, P, n_streams=n_streams, device=dev, **kw)

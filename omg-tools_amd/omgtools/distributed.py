@@ -16,6 +16,19 @@ def shard_range(n_total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_workload(P, rank, world):
+    """Strong scaling of one batch: the per-agent arrays of a workload (`p`, `x0`, ... -- every array whose first axis is the
+    agent axis) cut to the contiguous block of `rank`; everything else shared.  The agents are independent problems, so a
+    rank's block solved alone gives the bits it gives inside the whole batch (tests/test_distributed_cpu.py)."""
+    n_total = P['p'].shape[0]
+    lo, hi = shard_range(n_total, rank, world)
+    out = dict(P)
+    for k, v in P.items():
+        if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == n_total:
+            out[k] = v[lo:hi]
+    return out, (lo, hi)
+
+
 def reduce_report(elapsed_s, n_solved, device=None, dist=None):
     """(max elapsed over ranks, total solved over ranks)."""
     if dist is None or not dist.is_initialized():

@@ -153,3 +153,60 @@ def test_rollout_writes_the_stored_trajectories():
     for m in (a, b):
         m.solver.set_store(None)
         m.solver.close()
+
+
+def test_back_to_back_rollouts_on_a_caller_stream():
+    """Round-4 advisor: the rollout's step table, its argument block and the multiplier map were written with null-stream
+    copies; on a non-blocking caller stream (`set_stream`) a second rollout issued without a sync rewrote them under the first
+    one's persistent kernel.  The copies are ordered on the handle's stream now: two rollouts of different step tables issued
+    back to back on a side stream (different tau / t_rel / crossed per call) equal the stepwise loop bit for bit."""
+    import torch
+    from omgtools import workloads
+    from omgtools.batch import BatchP2P
+    n = 600                                              # (more agents than resident workgroups: the first rollout is still under way when the second is issued)
+    side = torch.cuda.Stream()
+    objs = []
+    for st in (side, torch.cuda.current_stream()):
+        problem, P = workloads.holonomic_p2p(n)
+        with torch.cuda.stream(st):
+            m = BatchP2P(problem, P, ops='hip', device=torch.device('cuda', 0), options=dict(tol=1e-3, max_iter=300))
+            m.solve_cold(bends=())
+        objs.append(m)
+    a, b = objs
+    with torch.cuda.stream(side):
+        c1 = a.rollout(7)                                # steps 1-7
+        c2 = a.rollout(6)                                # steps 8-13: crosses the knot at t = 1 s, issued while the first is running
+    crossed = sum(int(b.step()) for _ in range(13))
+    side.synchronize(); torch.cuda.synchronize()
+    assert c1 + c2 == crossed == 1
+    for name in ('x', 'lam', 'p', 'status', 'iters'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    a.solver.close(); b.solver.close()
+
+
+def test_the_per_step_product_path_picks_two_half_launches_for_two_rounds_of_workgroups():
+    """`receding_horizon_batch`: one handle for a batch below two rounds of resident workgroups, two stream-ordered half-launches
+    at 1024 agents (512 resident workgroups) -- with the plans of the single handle, bit for bit, also across the crossing."""
+    import torch
+    from omgtools import workloads
+    from omgtools.batch import BatchP2P, StreamedP2P, receding_horizon_batch
+    dev = torch.device('cuda', 0)
+    opts = dict(tol=1e-3, max_iter=300)
+    problem, P = workloads.holonomic_p2p(64)
+    small = receding_horizon_batch(problem, P, device=dev, options=opts)
+    assert isinstance(small, BatchP2P)
+    small.solver.close()
+    n = 1024
+    problem, P = workloads.holonomic_p2p(n)
+    rh = receding_horizon_batch(problem, P, device=dev, options=opts)
+    assert isinstance(rh, StreamedP2P) and len(rh.parts) == 2 and rh.B == n
+    problem1, P1 = workloads.holonomic_p2p(n)
+    one = receding_horizon_batch(problem1, P1, device=dev, n_streams=1, options=opts)
+    assert isinstance(one, BatchP2P)
+    rh.solve_cold(bends=()); one.solve_cold(bends=())
+    for _ in range(11):
+        assert bool(rh.step()) == bool(one.step())
+    for name in ('x', 'lam', 'p', 'status', 'iters'):
+        assert torch.equal(getattr(rh, name), getattr(one, name)), name       # (the properties join the streams)
+    assert abs(rh.time - one.time) < 1e-12
+    rh.close(); one.solver.close()

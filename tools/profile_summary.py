@@ -31,9 +31,56 @@ def pmc(name):
                 min=min(vals), max=max(vals), per_launch_kb=vals)
 
 
+def issue_passes(tag, out, n_cold=5):
+    """Instruction-fetch / issue decomposition (round 5): every counter of the passes gpurun_out/prof/issue*/, mean per launch
+    of ipm_solve_kernel, cold launches (the first `n_cold`: bench.py --streams 1 solves the batch cold five times) and
+    receding-horizon steps apart, plus the ratios that decompose the wave-wait share."""
+    res = {}
+    for d in sorted(glob.glob(os.path.join(PROF, 'issue*'))):
+        if not os.path.isdir(d):
+            continue
+        files = sorted(glob.glob(os.path.join(d, '*', '*_counter_collection.csv')), key=os.path.getmtime)
+        if not files:
+            continue
+        per = {}
+        for row in csv.DictReader(open(files[-1])):
+            if 'ipm_solve_kernel' in row['Kernel_Name']:
+                per.setdefault(row['Counter_Name'], []).append(float(row['Counter_Value']))
+        for n, v in per.items():
+            res[n] = {'launches': len(v), 'mean_cold': sum(v[:n_cold]) / max(1, len(v[:n_cold])),
+                      'mean_warm': sum(v[n_cold:]) / max(1, len(v[n_cold:])), 'pass': os.path.basename(d)}
+    def ratio(a, b, k):
+        return res[a][k] / max(1.0, res[b][k]) if a in res and b in res else None
+    der = {}
+    for k in ('mean_cold', 'mean_warm'):
+        s_ = k[5:]
+        der['wait_any_over_wave_cycles_' + s_] = ratio('SQ_WAIT_ANY', 'SQ_WAVE_CYCLES', k)
+        der['wait_inst_any_over_wave_cycles_' + s_] = ratio('SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES', k)
+        der['wait_inst_lds_over_wave_cycles_' + s_] = ratio('SQ_WAIT_INST_LDS', 'SQ_WAVE_CYCLES', k)
+        der['active_inst_over_wave_cycles_' + s_] = ratio('SQ_ACTIVE_INST_ANY', 'SQ_WAVE_CYCLES', k)
+        der['salu_share_of_instructions_' + s_] = (res['SQ_INSTS_SALU'][k] / max(1.0, res['SQ_INSTS_SALU'][k] + res['SQ_INSTS_VALU'][k])
+                                                    if 'SQ_INSTS_SALU' in res and 'SQ_INSTS_VALU' in res else None)
+        der['icache_miss_ratio_' + s_] = ratio('SQC_ICACHE_MISSES', 'SQC_ICACHE_REQ', k)
+        der['ifetch_per_wave_cycle_' + s_] = ratio('SQ_IFETCH', 'SQ_WAVE_CYCLES', k)
+        der['salu_cycles_over_wave_cycles_' + s_] = ratio('SQ_INST_CYCLES_SALU', 'SQ_WAVE_CYCLES', k)
+    res['derived'] = der
+    res['note'] = ('separate rocprofv3 --pmc passes (counters only, no trace domain) of `python bench.py --streams 1 --no-cpu '
+                   '--no-extras --steps 5 --warmup 1`: launches 0-%d are cold solves of the 1024-agent batch, the rest '
+                   'receding-horizon steps; counters the box does not know are absent' % (n_cold - 1))
+    json.dump(res, open(os.path.join(out, '%s_pmc_issue.json' % tag), 'w'), indent=1)
+    for k, v in der.items():
+        print(k, v)
+    for k, v in res.items():
+        if isinstance(v, dict) and 'mean_warm' in v:
+            print('%-28s cold %.4g warm %.4g' % (k, v['mean_cold'], v['mean_warm']))
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
     out = os.path.join(ROOT, 'profiles')
+    if len(sys.argv) > 2 and sys.argv[2] == 'issue':
+        os.makedirs(os.path.join(ROOT, 'gpurun_out', 'profiles'), exist_ok=True)
+        return issue_passes(tag, os.path.join(ROOT, 'gpurun_out', 'profiles'))
     stats = newest(os.path.join(PROF, 'stats', '*', '*_kernel_stats.csv'))
     rows = list(csv.reader(open(stats)))
     with open(os.path.join(out, '%s_kernel_stats.csv' % tag), 'w', newline='') as f:
