@@ -1,0 +1,100 @@
+"""Generates tests/golden/closed_loop_cfg2.npz: a CLOSED receding-horizon loop of config 2 (Holonomic, K = 11, 3 circles) with
+an independent solver in the loop -- the reference's replay test (`export/tests/point2point/test.cpp:84-141`: the sampled state
+and input trajectories of every update compared with a run of the other implementation) with scipy SLSQP in the role CasADi /
+IPOPT cannot take here.
+
+Per agent (64 seeded agents of the bench workload, `omgtools.workloads.holonomic_p2p`):
+  step 0   the cold solve: host build of the solver at 1e-6 from the reference's guess (this fixes the BASIN the way the bench
+           protocol does), then SLSQP from that point -- its minimiser is the plan the loop starts from;
+  step k   `BatchP2P.step` on the host with SLSQP as the solver object: ideal prediction on SLSQP's previous plan, horizon
+           bookkeeping, knot-crossing shift, SLSQP from the shifted plan (ftol 1e-12).  25 steps, two crossings.
+Stored per step: the plan (all variables), its objective, the parameters the step was solved for, whether it crossed a knot.
+No number of the loop after step 0 comes from the product's algorithm; step 0 only takes its basin from it.
+
+Run from the repository root:  python tests/golden/generate_closed_loop.py   (about 10 min on 8 cores)"""
+import os
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+N_AGENTS, N_STEPS = 64, 25
+
+
+class SlsqpOps(object):
+    """The `ops` shape of BatchP2P's host protocol with SLSQP behind it."""
+
+    def __init__(self, tpl):
+        from oracle.nlp_numpy import NumpyNLP
+        self.nlp = NumpyNLP(tpl)
+        self.f, self.ok = None, None
+
+    def solve(self, tpl, p, x, **kw):
+        from oracle.slsqp_numpy import solve_slsqp
+        B = p.shape[0]
+        xs, st = np.array(x, dtype=float), np.zeros(B, dtype=np.int32)
+        self.f, self.ok = np.zeros(B), np.zeros(B, dtype=bool)
+        for b in range(B):
+            xb, fb, ok = solve_slsqp(self.nlp, tpl, x[b], p[b], maxiter=800)
+            xs[b], self.f[b], self.ok[b] = xb, fb, ok
+            st[b] = 0 if ok else 1
+        return {'x': xs, 'lam_g': np.zeros((B, tpl.n_con)), 'status': st, 'iters': np.zeros(B, dtype=np.int32)}
+
+
+def run_agents(job):
+    lo, hi = job
+    from omgtools import workloads
+    from omgtools.batch import BatchP2P
+    from oracle import port_binding
+    problem, P = workloads.holonomic_p2p(N_AGENTS)
+    sub = {'p': P['p'][lo:hi], 'x0': P['x0'][lo:hi]}
+    tpl = problem.father.template
+    ops = SlsqpOps(tpl)
+    # step 0: the basin from the host build of the solver (cold, 1e-6), the plan from SLSQP started there
+    cold = port_binding.solve(tpl, sub['p'], sub['x0'], tol=1e-6, max_iter=500)
+    assert (cold['status'] == 0).all(), cold['status']
+    mpc = BatchP2P(problem, dict(sub, x0=cold['x']), ops=ops, options=dict(tol=1e-6, max_iter=500))
+    mpc.solve_cold()
+    n = hi - lo
+    x = np.zeros((N_STEPS + 1, n, tpl.n_var)); f = np.zeros((N_STEPS + 1, n)); ok = np.zeros((N_STEPS + 1, n), dtype=bool)
+    p = np.zeros((N_STEPS + 1, n, tpl.n_par)); crossed = np.zeros(N_STEPS + 1, dtype=bool)
+    x[0], f[0], ok[0], p[0] = mpc.x, ops.f, ops.ok, mpc.p
+    moved = float(np.abs(mpc.x - cold['x']).max())
+    for k in range(1, N_STEPS + 1):
+        crossed[k] = bool(mpc.step())
+        x[k], f[k], ok[k], p[k] = mpc.x, ops.f, ops.ok, mpc.p
+    return lo, hi, x, f, ok, p, crossed, cold['x'], moved
+
+
+def main():
+    t0 = time.time()
+    workers = int(os.environ.get('WORKERS', '8'))
+    chunk = 2
+    jobs = [(lo, min(lo + chunk, N_AGENTS)) for lo in range(0, N_AGENTS, chunk)]
+    with ProcessPoolExecutor(workers) as ex:
+        res = list(ex.map(run_agents, jobs, chunksize=1))
+    from omgtools import workloads
+    problem, P = workloads.holonomic_p2p(N_AGENTS)
+    tpl = problem.father.template
+    x = np.zeros((N_STEPS + 1, N_AGENTS, tpl.n_var)); f = np.zeros((N_STEPS + 1, N_AGENTS)); ok = np.zeros((N_STEPS + 1, N_AGENTS), dtype=bool)
+    p = np.zeros((N_STEPS + 1, N_AGENTS, tpl.n_par)); x_cold = np.zeros((N_AGENTS, tpl.n_var))
+    moved = 0.0
+    for lo, hi, xs, fs, oks, ps, crossed, xc, mv in res:
+        x[:, lo:hi], f[:, lo:hi], ok[:, lo:hi], p[:, lo:hi], x_cold[lo:hi] = xs, fs, oks, ps, xc
+        moved = max(moved, mv)
+    veh = problem.vehicles[0]
+    lo, hi = tpl.entry_range(veh.label, 'splines_seg0', 'var')
+    np.savez_compressed(os.path.join(HERE, 'closed_loop_cfg2.npz'), p0=P['p'], x0=P['x0'], x=x, f=f, ok=ok, p=p, crossed=crossed,
+                        x_cold_port=x_cold, spl=np.array([lo, hi]), n_var=tpl.n_var, n_con=tpl.n_con, n_par=tpl.n_par,
+                        update_time=0.1, sample_time=0.01)
+    print('closed_loop_cfg2.npz: %d agents x %d steps, %d / %d SLSQP solves converged, crossings at steps %s, SLSQP moved the cold '
+          'plan by at most %.2e, %.0f s' % (N_AGENTS, N_STEPS, int(ok.sum()), ok.size, np.nonzero(crossed)[0].tolist(), moved, time.time() - t0))
+
+
+if __name__ == '__main__':
+    main()

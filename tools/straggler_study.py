@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd')); sys.path.insert(0, ROOT)
 import numpy as np
 import omgtools.backend as be
-from omgtools.scenarios import holonomic_p2p
+from omgtools.workloads import holonomic_p2p
 from omgtools.batch import BatchP2P
 from oracle import port_binding
 
