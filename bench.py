@@ -370,14 +370,16 @@ def stepwise_leg(problem, P, opts, n_steps, warmup, dev, n_streams):
             'note': '%d sub-batch(es) of %d agents, per-step launches' % (len(parts), B // len(parts))}
 
 
-def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev):
+def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev, engine='kernel'):
     """SURVEY 8d's span as worded -- "device time incl. parameter upload and coefficient download" -- as a THROUGHPUT: the
     caller keeps p and x in (pinned) host memory.  Per step and per half of the batch, on that half's own HIP stream:
     the step's glue on the device (prediction: stands for the plant), the parameters DOWN to the host (the caller's copy of
     the measured state), the parameters UP again from pinned memory, the warm-started solve, then x, status and iteration
     counts DOWN into one of two pinned buffer sets.  Nothing syncs the host inside a step: it waits for the event of step
     k - 2 before it hands buffer set k % 2 out again (double buffering: the host reads step k - 1 while step k runs), and the
-    copies of one half overlap the solve of the other.  Solved agents are counted from the downloaded status words."""
+    transfers of one half overlap the solve of the other.  Solved agents are counted from the downloaded status words.
+    engine='kernel': the transfers are `omgx_batch_transfer` launches (the kernel reads / writes the pinned buffers over the
+    host link: no hand-over to a copy engine); engine='memcpy': hipMemcpyAsync through torch (`copy_(non_blocking=True)`)."""
     from omgtools.batch import StreamedP2P
     B = P['p'].shape[0]
     n_streams = 2 if B % 2 == 0 else 1
@@ -393,14 +395,19 @@ def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev):
     for _ in range(warmup):
         rh.step()
     rh.synchronize()
+    kern = engine == 'kernel'
 
     def hook(k_part):
         def up_down(m):
-            p_h[k_part].copy_(m.p, non_blocking=True)      # the caller's copy of the parameters (measured state) ...
-            m.p.copy_(p_h[k_part], non_blocking=True)      # ... and their upload: what the solve reads came over PCIe
+            if kern:
+                m.solver.transfer([(p_h[k_part], m.p)])        # the caller's copy of the parameters (measured state) ...
+                m.solver.transfer([(m.p, p_h[k_part])])        # ... and their upload: what the solve reads came over the host link
+            else:
+                p_h[k_part].copy_(m.p, non_blocking=True)
+                m.p.copy_(p_h[k_part], non_blocking=True)
         return up_down
     hooks = [hook(k) for k in range(len(rh.parts))]
-    ok, lat = 0, []
+    ok = 0
     quiet_host()
     t_0 = time.perf_counter()
     for k in range(n_steps):
@@ -412,10 +419,15 @@ def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev):
         rh.step(before_solve=hooks)
         for kp, (m, st) in enumerate(zip(rh.parts, rh.streams)):
             with torch.cuda.stream(st):
-                bufs[kp][s]['x'].copy_(m.x, non_blocking=True)
-                bufs[kp][s]['status'].copy_(m.status, non_blocking=True)
-                bufs[kp][s]['iters'].copy_(m.iters, non_blocking=True)
+                bf = bufs[kp][s]
+                if kern:
+                    m.solver.transfer([(bf['x'], m.x), (bf['status'], m.status), (bf['iters'], m.iters)])
+                else:
+                    bf['x'].copy_(m.x, non_blocking=True)
+                    bf['status'].copy_(m.status, non_blocking=True)
+                    bf['iters'].copy_(m.iters, non_blocking=True)
                 done[kp][s] = st.record_event()
+    t_host = time.perf_counter() - t_0
     rh.synchronize()
     wall = time.perf_counter() - t_0
     gc.enable()
@@ -423,11 +435,13 @@ def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev):
         for kp in range(len(rh.parts)):
             ok += int((bufs[kp][k % 2]['status'] == 0).sum())
     rh.close()
-    mb = (2 * tpl.n_par + tpl.n_var) * 8 * B / 1e6
+    mb = (2 * tpl.n_par + tpl.n_var + 1) * 8 * B / 1e6
     return {'solves_per_s': ok / wall, 'ms_per_step': wall / n_steps * 1e3, 'steps': n_steps, 'warmup': warmup,
-            'solved_fraction': ok / float(n_steps * B), 'pcie_MB_per_step': mb,
+            'solved_fraction': ok / float(n_steps * B), 'host_link_MB_per_step': mb, 'engine': engine,
+            'host_enqueue_ms_per_step': t_host / n_steps * 1e3,
             'note': 'per step and half-batch on its own stream: p down + p up (pinned), solve, x / status / iters down into double-buffered '
-                    'pinned memory; no host sync inside a step (the host waits for step k - 2 before reusing a buffer set)'}
+                    'pinned memory; no host sync inside a step (the host waits for step k - 2 before reusing a buffer set); transfers by '
+                    + ('omgx_batch_transfer kernels (no copy engine)' if kern else 'hipMemcpyAsync (copy engine)')}
 
 
 def without_solver_objects(fn, *a, **kw):
@@ -888,10 +902,12 @@ def main():
             out['one_stream' if n_parts > 1 else 'two_streams'] = stepwise_leg(problem, P, opts, args.steps, args.warmup, dev, 1 if n_parts > 1 else 2)
         except Exception as e:
             out['one_stream' if n_parts > 1 else 'two_streams'] = {'error': repr(e)}
-        try:
-            out['host_boundary_pipelined'] = host_boundary_pipelined(problem, P, opts, max(args.steps, 40), args.warmup, dev)
-        except Exception as e:
-            out['host_boundary_pipelined'] = {'error': repr(e)}
+        for eng in ('kernel', 'memcpy'):
+            key = 'host_boundary_pipelined' + ('' if eng == 'kernel' else '_memcpy')
+            try:
+                out[key] = host_boundary_pipelined(problem, P, opts, max(args.steps, 40), args.warmup, dev, engine=eng)
+            except Exception as e:
+                out[key] = {'error': repr(e)}
         try:
             out['rollout'] = rollout_leg(mpc, x0_init, p_init, args.steps, args.warmup, dev)
         except Exception as e:                            # (a second metric must never cost the headline line)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define OMGX_VERSION 5
+#define OMGX_VERSION 6
 #define OMGX_TERM_VARS 4      /* variables per term (version 3: three) */
 
 /* error codes */
@@ -240,6 +240,18 @@ int  omgx_batch_solve(omgx_batch* b, const double* p, const double* x0,
                       double* x, double* lam_g, int32_t* status, int32_t* iters,
                       int32_t flags);
 int  omgx_batch_sync(omgx_batch* b);
+
+/* (version 6) The host boundary without the copy engine.  SURVEY.md 8d times "device time incl. parameter upload and
+ * coefficient download": a caller that keeps p and x in host memory (`problems/problem.py:113` hands numpy arrays to the solver
+ * object, C++ `Point2Point::update` std::vectors, `export/point2point/Point2Point.cpp:207-231`) would wrap every solve in
+ * hipMemcpyAsync calls -- on this platform each of them is a hand-over between the compute queue and an SDMA engine, ~100 us of
+ * latency per step at these sizes (0.1 - 0.7 MB).  omgx_batch_transfer moves up to OMGX_TRANSFER_MAX segments
+ * dst[i] <- src[i] (bytes[i] bytes each, 8-byte aligned) with ONE small kernel on the handle's stream: ordered like every
+ * other call of the handle, no engine hand-over.  Either side of a segment may be device memory or PINNED host memory
+ * (hipHostMalloc / hipHostRegister, e.g. a torch pin_memory() tensor: mapped into the device's address space): the kernel
+ * reads or writes it over the host link.  Pageable host memory is an error the device reports, not this call. */
+#define OMGX_TRANSFER_MAX 6
+int  omgx_batch_transfer(omgx_batch* b, int32_t n_seg, const void* const* src, void* const* dst, const int64_t* bytes);
 
 /* Verification entry (host pointers, not a hot path): what the solve kernel's own tables evaluate at
  * the caller's point x [B, n_var] with parameters p [B, n_par] and multipliers lam_g [B, n_con] -- by the device code

@@ -1621,6 +1621,48 @@ int omgx_batch_phase_cycles(omgx_batch* b, long long* out) {   // profiling buil
 }
 #endif
 
+// omgx_batch_transfer: up to OMGX_TRANSFER_MAX segments moved by one launch (device <-> pinned host memory over the host link, or
+// device <-> device): a workgroup range per segment in proportion to its size, 16-byte words, coalesced
+struct TransferArgs { const double* src[OMGX_TRANSFER_MAX]; double* dst[OMGX_TRANSFER_MAX]; long long n8[OMGX_TRANSFER_MAX]; int blk0[OMGX_TRANSFER_MAX + 1]; int n_seg; };
+__global__ void __launch_bounds__(256)
+transfer_kernel(TransferArgs a) {
+  int sg = 0;
+  while (sg + 1 < a.n_seg && (int)blockIdx.x >= a.blk0[sg + 1]) ++sg;
+  const int nb = a.blk0[sg + 1] - a.blk0[sg], lb = blockIdx.x - a.blk0[sg];
+  const long long n8 = a.n8[sg], n16 = n8 >> 1;
+  const bool wide = ((((size_t)a.src[sg]) | ((size_t)a.dst[sg])) & 15) == 0;
+  if (wide) {
+    const double2* s = (const double2*)a.src[sg];
+    double2* d = (double2*)a.dst[sg];
+    for (long long i = (long long)lb * 256 + threadIdx.x; i < n16; i += (long long)nb * 256) d[i] = s[i];
+    if ((n8 & 1) && lb == 0 && threadIdx.x == 0) a.dst[sg][n8 - 1] = a.src[sg][n8 - 1];
+  } else {
+    for (long long i = (long long)lb * 256 + threadIdx.x; i < n8; i += (long long)nb * 256) a.dst[sg][i] = a.src[sg][i];
+  }
+}
+
+int omgx_batch_transfer(omgx_batch* b, int32_t n_seg, const void* const* src, void* const* dst, const int64_t* bytes) {
+  if (!b || n_seg < 0 || n_seg > OMGX_TRANSFER_MAX || (n_seg > 0 && (!src || !dst || !bytes))) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  if (n_seg == 0) return OMGX_OK;
+  TransferArgs a;
+  memset(&a, 0, sizeof a);
+  a.n_seg = n_seg;
+  int blocks = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    if (!src[i] || !dst[i] || bytes[i] < 0 || (bytes[i] & 7) || (((size_t)src[i] | (size_t)dst[i]) & 7)) { g_err = "transfer: segments are 8-byte aligned multiples of 8 bytes"; return OMGX_E_INVALID; }
+    a.src[i] = (const double*)src[i]; a.dst[i] = (double*)dst[i]; a.n8[i] = bytes[i] / 8;
+    a.blk0[i] = blocks;
+    // (a workgroup per 16 KB, at least one, at most 256 per segment: enough requests in flight to fill the host link)
+    long long nb = (bytes[i] + 16383) / 16384;
+    blocks += (int)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+  }
+  a.blk0[n_seg] = blocks;
+  HIPCHK(hipSetDevice(b->device));
+  hipLaunchKernelGGL(transfer_kernel, dim3(blocks), dim3(256), 0, b->stream, a);
+  HIPCHK(hipGetLastError());
+  return OMGX_OK;
+}
+
 int omgx_batch_sync(omgx_batch* b) {
   if (!b) return OMGX_E_INVALID;
   { const int rc_o = flush_order(b); if (rc_o != OMGX_OK) return rc_o; }      // (a deferred omgx_batch_order_by_iters)

@@ -203,6 +203,9 @@ struct Opts {
 #define OMGX_LS_RETRY    3       // line-search failures in a row that are answered by a heavier inertia correction
 #define OMGX_LS_RETRY_DW 100.0
 #define OMGX_DW_CAP_FLOOR 0.03  // share of dw every nonlinear variable keeps under the Gershgorin cap
+#ifndef OMGX_DW_CLAMP_FROM
+#define OMGX_DW_CLAMP_FROM 1.0  // an inertia correction above this is compared with the Gershgorin guarantee (round 5, see the factorisation loop)
+#endif
 #define OMGX_DW_LINEAR   1e-8   // relative inertia correction of variables that only appear linearly
 #ifndef OMGX_FTB_ACTUAL
 #define OMGX_FTB_ACTUAL  0.5     // share of the linear fraction-to-boundary bound (1 - tau) s the slack of a row must really keep at an accepted trial point
@@ -2132,6 +2135,19 @@ OMGX_FN void hess_bin(const Dims& d, const Tables& T, Work& w, int m, int bin, i
 // ---------------------------------------------------------------------------
 struct Result { int status, iters; double f, mu, t, dw; };
 
+// The inertia correction at which every nonlinear variable gets at least its Gershgorin row sum g_q (w.xt, position order) under
+// the cap min(dw f_q, g_q + 0.03 dw): max_q g_q / f_q, with a margin of 1 % and the smallest correction on top
+template <class C>
+OMGX_FN double gersh_cap(const C& c, int N, const Tables& T, const Work& w, double reg_root, double reg_leaf) {
+  double g = 0.0;
+  OMGX_PFOR(q, N) {
+    const double wq = T.reg_w[q];
+    if (wq == 1.0) g = fmax(g, w.xt[q] / reg_root);
+    else if (wq == -1.0) g = fmax(g, w.xt[q] / reg_leaf);
+  }
+  return c.uni(1.01 * c.rmax(g) + OMGX_DW_FIRST);
+}
+
 template <class C>
 OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts& o, Work& w,
                          const double* p, const double* x0, const double* lb, const double* ub,
@@ -2442,6 +2458,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     // trajectory coefficient whose bilinear rows are all inactive (multipliers ~ mu / s) is then
     // practically undamped even while dw covers the active hyperplane rows elsewhere.
     int first_trial = 1;
+    double gcap = -1.0;      // the Gershgorin guarantee of this iteration (computed when first needed)
     // (side sums of cut runs: w.dinv -- the dual residual has been read, the factorisation has not started -- or the pairs' side slots)
     double* const gside = d.kg_side_dinv ? w.dinv : w.kkt + d.side_off;
     OMGX_PFOR(q, N) w.xt[q] = 0.0;
@@ -2552,6 +2569,17 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         c.sync();
       }
       OMGX_TOC(PH_A_REST);
+      // Round 5: the Gershgorin guarantee.  With dw >= g_q / f_q for every nonlinear variable (f_q: its weight) the capped
+      // correction min(dw f_q, g_q + 0.03 dw) is at least g_q everywhere, H + D is diagonally dominant and the primal
+      // block positive definite: no iteration needs more than gcap = max_q g_q / f_q.  The escalation ladder (x10 per failed
+      // attempt) is cut there, and a correction carried over from an earlier iteration that exceeds it (> OMGX_DW_CLAMP_FROM:
+      // normal operation never pays the reduction) is taken back to it -- a knot-crossing step whose multipliers blew up for
+      // one iteration climbed to 6e4 and then walked down by thirds for ten iterations with g_max = 0.3 all along.  Not after
+      // a failed line search: that retry WANTS the heavier, steepest-descent-like direction.
+      if (first_trial && ls_fail == 0 && dw > OMGX_DW_CLAMP_FROM) {
+        gcap = gersh_cap(c, N, T, w, reg_root, reg_leaf);
+        if (dw > gcap) dw = gcap;
+      }
       OMGX_PFOR(q, N) {
         // variables without a nonlinear term have zero rows in the Lagrangian Hessian: negative
         // curvature cannot come from them, and damping them would stall LP-like directions
@@ -2578,6 +2606,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       if (bad && decreasing) ++omgx_dbg_cnt[3];
 #endif
       OMGX_TOC(PH_FACTOR);
+#if defined(OMGX_HOST_PORT) && defined(OMGX_TRACE)
+      { double gmx = 0.0; int qg = -1; for (int q = 0; q < N; ++q) if (w.xt[q] > gmx) { gmx = w.xt[q]; qg = q; }
+        fprintf(stderr, "      factorisation: dw %.3e decreasing %d -> bad %d   (largest Gershgorin sum %.3e at x[%d])\n", dw, decreasing, bad, gmx, qg >= 0 ? T.order[qg] : -1); }
+#endif
       first_trial = 0;
       if (!bad) { if (decreasing) dw_backoff = 1; break; }
       if (bad == 2 && d.wave_ok && warm) {
@@ -2592,6 +2624,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         // iteration but sends 2 of 1024 agents of config 2 into a phase-I stall that the plain rule avoids, and
         // their restart costs more than was saved (cold solve of the batch 69 ms instead of 15.7 ms).
         double dwr = dw;
+        int leave_root = 0;
         for (;;) {
           const double dw_prev_try = dwr;
           if (decreasing) {          // back to the last value that worked, try less often
@@ -2599,7 +2632,12 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
             dw_backoff = dw_backoff < OMGX_DW_BACKOFF_MAX ? 2 * dw_backoff : OMGX_DW_BACKOFF_MAX;
             dw_hold = dw_backoff;
           } else {
-            dwr = c.uni((dwr == 0.0) ? OMGX_DW_FIRST : dwr * OMGX_DW_INC);
+            // (the root at the Gershgorin guarantee and still the wrong inertia: it is the LEAVES that lack damping -- positive
+            // definite but nearly singular, their Schur complements swamp the root; back to the full factorisation at gcap)
+            if (gcap < 0.0) gcap = gersh_cap(c, N, T, w, reg_root, reg_leaf);
+            if (ls_fail == 0 && dwr >= gcap && dw < gcap) { leave_root = 1; break; }
+            const double nxt = (dwr == 0.0) ? OMGX_DW_FIRST : dwr * OMGX_DW_INC;
+            dwr = c.uni((ls_fail == 0 && dwr < gcap && nxt > gcap) ? gcap : nxt);
           }
           if (dwr > OMGX_DW_MAX) { failed = 1; break; }
           c.sync();
@@ -2624,6 +2662,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
           if (!bad) break;
         }
         if (failed) break;
+        if (leave_root) { dw = c.uni(gcap); decreasing = 0; c.sync(); continue; }      // (full reassembly at the guarantee)
         dw = dwr;                    // what the next iteration starts from
         break;
       }
@@ -2632,7 +2671,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         dw_backoff = dw_backoff < OMGX_DW_BACKOFF_MAX ? 2 * dw_backoff : OMGX_DW_BACKOFF_MAX;
         dw_hold = dw_backoff;
       } else {
-        dw = c.uni((dw == 0.0) ? OMGX_DW_FIRST : dw * OMGX_DW_INC);
+        if (gcap < 0.0) gcap = gersh_cap(c, N, T, w, reg_root, reg_leaf);
+        const double nxt = (dw == 0.0) ? OMGX_DW_FIRST : dw * OMGX_DW_INC;
+        dw = c.uni((ls_fail == 0 && dw < gcap && nxt > gcap) ? gcap : nxt);
       }
       if (dw > OMGX_DW_MAX) { failed = 1; break; }
       c.sync();
@@ -2859,6 +2900,11 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       int rb = -1; double best = 1e300;
       for (int r = 0; r < m; ++r) if ((w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) && w.ds[r] < 0.0) { const double q_ = -row_slack(w, r, t) / w.ds[r]; if (q_ < best) { best = q_; rb = r; } }
       if (rb >= 0) fprintf(stderr, "      blocking row %d ratio %.3e s %.3e ds %.3e z %.3e vv %.3e | dt %.3e t %.3e\n", rb, best, row_slack(w, rb, t), w.ds[rb], w.z[rb], w.vv[rb], dt, t);
+    }
+    {
+      int q1 = -1, q2 = -1; double b1 = 0.0, b2 = 0.0;      // the two largest components of the Newton step (variable index, value)
+      for (int q = 0; q < N; ++q) { const double a_ = fabs(w.sol[q]); if (a_ > b1) { b2 = b1; q2 = q1; b1 = a_; q1 = q; } else if (a_ > b2) { b2 = a_; q2 = q; } }
+      fprintf(stderr, "      largest step components: x[%d] %.3e, x[%d] %.3e\n", q1 >= 0 ? T.order[q1] : -1, q1 >= 0 ? w.sol[q1] : 0.0, q2 >= 0 ? T.order[q2] : -1, q2 >= 0 ? w.sol[q2] : 0.0);
     }
     fprintf(stderr, "it %3d mu %.2e t %.3e nu %.1e zt %.2e err %.2e (rd %.2e viol %.2e zh %.2e sd %.1e) dw %.2e alpha %.2e rE %.2e f %.4e\n", it, mu, t, nu, zt, err0, rd_max, viol, zh, sd, dw_last, alpha, rE_sum, f);
 #endif

@@ -231,6 +231,7 @@ def load_library(path=None):
                                          C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.omgx_batch_solve.argtypes = [C.c_void_p] + [C.c_void_p] * 8 + [C.c_int32]
     lib.omgx_batch_sync.argtypes = [C.c_void_p]
+    lib.omgx_batch_transfer.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.omgx_batch_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.omgx_batch_shift.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
@@ -420,6 +421,21 @@ class BatchSolver(object):
         _check(self.lib, self.lib.omgx_batch_eval(self._h, p.ctypes.data, x.ctypes.data, lam.ctypes.data, g.ctypes.data,
                                                   f.ctypes.data, jac.ctypes.data, hess.ctypes.data), 'omgx_batch_eval')
         return dict(g=g, f=f, jac=jac, hess=hess)
+
+    def transfer(self, pairs):
+        """[(dst, src), ...] (at most 6): dst <- src for tensors that live in device memory or in PINNED host memory, by one small
+        kernel on the handle's stream (`omgx_batch_transfer`: no copy-engine hand-over; a pinned tensor is read / written over
+        the host link by the kernel itself)."""
+        n = len(pairs)
+        srcs, dsts, nbytes = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
+        for i, (dst, src) in enumerate(pairs):
+            if dst.numel() != src.numel() or dst.dtype != src.dtype or not dst.is_contiguous() or not src.is_contiguous():
+                raise ValueError('transfer: contiguous tensors of equal size and type')
+            for t in (dst, src):
+                if not (t.is_cuda or t.is_pinned()):
+                    raise ValueError('transfer: device or pinned host tensors only')
+            srcs[i], dsts[i], nbytes[i] = src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size()
+        _check(self.lib, self.lib.omgx_batch_transfer(self._h, C.c_int32(n), srcs, dsts, nbytes), 'omgx_batch_transfer')
 
     def sync(self):
         _check(self.lib, self.lib.omgx_batch_sync(self._h), 'omgx_batch_sync')

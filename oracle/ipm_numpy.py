@@ -437,6 +437,17 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             K[N:, N:] = -delta_c * np.eye(mE)
             L, d = ldl_nopivot(K)
             return K, L, d, bool(np.all(d[:N] > 0) and np.all(d[N:] < 0))
+        # the Gershgorin guarantee (omgx_core.h gersh_cap, round 5): with dw >= g_q / f_q for every nonlinear variable the capped
+        # correction is at least g_q everywhere and the primal block is positive definite -- the escalation ladder is cut at
+        # that value, and a correction carried over that exceeds it (> dw_clamp_from) is taken back to it; not after a failed
+        # line search (that retry wants the heavier direction)
+        gcap = 1.01 * (np.max(gersh[nl] / reg[nl]) if nl.any() else 0.0) + o['dw_first']
+        if ls_fail == 0 and dw > o.get('dw_clamp_from', 1.0):
+            dw = min(dw, gcap)
+
+        def escalated(v, floor_v):
+            nxt = o['dw_first'] if v == 0.0 else v * o['dw_inc']
+            return gcap if (ls_fail == 0 and v < gcap and nxt > gcap) else nxt
         while True:
             K, L, d, ok = factor(np.full(N, dw))
             nfact += 1
@@ -455,6 +466,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                 # (omgx_core.h: the leaf blocks are positive definite at this dw, the root alone has the wrong
                 # inertia: raise the inertia correction of the root variables only)
                 dwr = dw
+                leave_root = False
                 while True:
                     if decreasing:
                         decreasing = False
@@ -462,7 +474,12 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                         dw_backoff = min(2 * dw_backoff, o.get('dw_backoff_max', 8))
                         dw_hold = dw_backoff
                     else:
-                        dwr = o['dw_first'] if dwr == 0.0 else dwr * o['dw_inc']
+                        # (the root at the guarantee and still the wrong inertia: the leaves lack damping -- back to the
+                        # full factorisation at gcap)
+                        if ls_fail == 0 and dwr >= gcap and dw < gcap:
+                            leave_root = True
+                            break
+                        dwr = escalated(dwr, None)
                     if dwr > o['dw_max']:
                         status = 4
                         break
@@ -472,6 +489,10 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                         break
                 if status == 4:
                     break
+                if leave_root:
+                    dw = gcap
+                    decreasing = False
+                    continue
                 dw = dwr
                 break
             if decreasing:
@@ -480,7 +501,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                 dw_backoff = min(2 * dw_backoff, o.get('dw_backoff_max', 8))
                 dw_hold = dw_backoff
             else:
-                dw = o['dw_first'] if dw == 0.0 else dw * o['dw_inc']
+                dw = escalated(dw, None)
             tries += 1
             if dw > o['dw_max']:
                 status = 4

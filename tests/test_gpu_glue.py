@@ -375,3 +375,39 @@ def test_quadrotor_ode_prediction_matches_the_reference_statements():
         assert np.abs(got_p[b, p_offs[1]:p_offs[1] + 2] - np.r_[rows[1][-1] @ cx, rows[1][-1] @ cy]).max() < 1e-9
         assert np.abs(got_p[b, p_offs[2]:p_offs[2] + 2] - np.r_[rows[2][-1] @ cx, rows[2][-1] @ cy]).max() < 1e-8
         assert got_p[b, o_t] == 0.3
+
+
+def test_transfer_moves_segments_between_device_and_pinned_host_memory():
+    """`omgx_batch_transfer` (ABI 6): the host boundary without the copy engine -- one launch on the handle's stream moves up
+    to six segments between device memory and pinned host memory, in either direction, ordered with the handle's other calls."""
+    import torch
+    from omgtools import workloads
+    from omgtools.backend import BatchSolver, OmgxError
+    problem, P = workloads.holonomic_p2p(4)
+    solver = BatchSolver(problem.father.template, 4)
+    solver.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device='cpu').manual_seed(3)
+    a_d = torch.randn((512, 164), dtype=torch.float64, generator=g).to(dev)
+    b_d = torch.arange(514, dtype=torch.int32, device=dev)
+    c_d = torch.randn(7, dtype=torch.float64, generator=g).to(dev)                      # an odd number of doubles
+    a_h, b_h, c_h = (torch.zeros(t.shape, dtype=t.dtype).pin_memory() for t in (a_d, b_d, c_d))
+    solver.transfer([(a_h, a_d), (b_h, b_d), (c_h, c_d)])                              # down: the kernel writes host memory
+    solver.sync()
+    assert torch.equal(a_h, a_d.cpu()) and torch.equal(b_h, b_d.cpu()) and torch.equal(c_h, c_d.cpu())
+    a2, b2 = torch.zeros_like(a_d), torch.zeros_like(b_d)
+    a_h.mul_(2.0)
+    solver.transfer([(a2, a_h), (b2, b_h)])                                            # up: the kernel reads host memory
+    a3 = a2 + 1.0                                                                       # (stream order: a torch kernel behind it sees the data)
+    torch.cuda.synchronize()
+    assert torch.equal(a2.cpu(), a_h) and torch.equal(b2, b_d) and torch.equal(a3.cpu(), a_h + 1.0)
+    v = a_d.view(-1)[1:1 + 6 * 164]                                                     # 8-byte aligned only: the narrow path
+    w_h = torch.zeros(6 * 164, dtype=torch.float64).pin_memory()
+    solver.transfer([(w_h, v.contiguous().view(-1)[:]), ])
+    solver.sync()
+    assert torch.equal(w_h, v.cpu())
+    with pytest.raises(ValueError):
+        solver.transfer([(torch.zeros(4, dtype=torch.float64), c_d[:4].contiguous())])  # pageable host memory
+    with pytest.raises(OmgxError):
+        solver.transfer([(torch.zeros(3, dtype=torch.int32).pin_memory(), b_d[:3].contiguous())])   # not a multiple of 8 bytes
+    solver.close()

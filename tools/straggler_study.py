@@ -14,7 +14,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 23
 be.create_nlp = lambda tpl, opt, name='': (None, 0.)
 problem, P = holonomic_p2p(B)
 import json
-mpc = BatchP2P(problem, P, ops=port_binding, options=dict(dict(tol=1e-3, max_iter=300), **json.loads(os.environ.get('STUDY_OPTS', '{}'))))
+mpc = BatchP2P(problem, P, ops=port_binding, options=dict(dict(tol=1e-3, max_iter=300), **json.loads(os.environ.get('STUDY_OPTS', '{}'))),
+               cross_options=json.loads(os.environ.get('STUDY_CROSS', '{}')) or None)
 t0 = time.time()
 mpc.solve_cold(bends=())
 print('cold: ok %d / %d, mean iters %.1f  (%.1f s)' % ((mpc.status == 0).sum(), B, mpc.iters.mean(), time.time() - t0))
