@@ -395,13 +395,30 @@ def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev, engine='kern
     for _ in range(warmup):
         rh.step()
     rh.synchronize()
-    kern = engine == 'kernel'
+    kern = engine in ('kernel', 'mapped')
+    if engine == 'mapped':
+        # the parameters LIVE in pinned host memory (mapped into the device's address space): the prediction kernel writes them
+        # there over the host link -- the caller's copy of the measured state -- and the solve kernel reads them from there:
+        # upload and download of p without a transfer of their own (static obstacles: no torch arithmetic touches p)
+        for kp, m in enumerate(rh.parts):
+            p_h[kp].copy_(m.p)
+            m.p = p_h[kp]
+        torch.cuda.synchronize()
+
+    plans = {}
+
+    def plan(m, key, pairs):                               # (prepared transfers: the pointer checks once, one library call per use)
+        if key not in plans:
+            plans[key] = m.solver.transfer_plan(pairs)
+        return plans[key]
 
     def hook(k_part):
         def up_down(m):
+            if engine == 'mapped':
+                return
             if kern:
-                m.solver.transfer([(p_h[k_part], m.p)])        # the caller's copy of the parameters (measured state) ...
-                m.solver.transfer([(m.p, p_h[k_part])])        # ... and their upload: what the solve reads came over the host link
+                plan(m, (k_part, 'down'), [(p_h[k_part], m.p)]).run()      # the caller's copy of the parameters (measured state) ...
+                plan(m, (k_part, 'up'), [(m.p, p_h[k_part])]).run()        # ... and their upload: what the solve reads came over the host link
             else:
                 p_h[k_part].copy_(m.p, non_blocking=True)
                 m.p.copy_(p_h[k_part], non_blocking=True)
@@ -420,8 +437,8 @@ def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev, engine='kern
         for kp, (m, st) in enumerate(zip(rh.parts, rh.streams)):
             with torch.cuda.stream(st):
                 bf = bufs[kp][s]
-                if kern:
-                    m.solver.transfer([(bf['x'], m.x), (bf['status'], m.status), (bf['iters'], m.iters)])
+                if kern:                                     # (m.x alternates between two buffers: a plan per buffer)
+                    plan(m, (kp, s, m.x.data_ptr()), [(bf['x'], m.x), (bf['status'], m.status), (bf['iters'], m.iters)]).run()
                 else:
                     bf['x'].copy_(m.x, non_blocking=True)
                     bf['status'].copy_(m.status, non_blocking=True)
@@ -441,7 +458,9 @@ def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev, engine='kern
             'host_enqueue_ms_per_step': t_host / n_steps * 1e3,
             'note': 'per step and half-batch on its own stream: p down + p up (pinned), solve, x / status / iters down into double-buffered '
                     'pinned memory; no host sync inside a step (the host waits for step k - 2 before reusing a buffer set); transfers by '
-                    + ('omgx_batch_transfer kernels (no copy engine)' if kern else 'hipMemcpyAsync (copy engine)')}
+                    + ({'kernel': 'omgx_batch_transfer kernels (no copy engine)', 'memcpy': 'hipMemcpyAsync (copy engine)',
+                        'mapped': 'p lives in pinned host memory (written by the prediction kernel, read by the solve kernel over the host '
+                                  'link: no transfer of its own), x / status / iters by one omgx_batch_transfer kernel'}[engine])}
 
 
 def without_solver_objects(fn, *a, **kw):
@@ -902,8 +921,8 @@ def main():
             out['one_stream' if n_parts > 1 else 'two_streams'] = stepwise_leg(problem, P, opts, args.steps, args.warmup, dev, 1 if n_parts > 1 else 2)
         except Exception as e:
             out['one_stream' if n_parts > 1 else 'two_streams'] = {'error': repr(e)}
-        for eng in ('kernel', 'memcpy'):
-            key = 'host_boundary_pipelined' + ('' if eng == 'kernel' else '_memcpy')
+        for eng in ('mapped', 'kernel', 'memcpy'):
+            key = 'host_boundary_pipelined' + ('' if eng == 'mapped' else '_' + eng)
             try:
                 out[key] = host_boundary_pipelined(problem, P, opts, max(args.steps, 40), args.warmup, dev, engine=eng)
             except Exception as e:

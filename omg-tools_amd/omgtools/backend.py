@@ -422,10 +422,9 @@ class BatchSolver(object):
                                                   f.ctypes.data, jac.ctypes.data, hess.ctypes.data), 'omgx_batch_eval')
         return dict(g=g, f=f, jac=jac, hess=hess)
 
-    def transfer(self, pairs):
-        """[(dst, src), ...] (at most 6): dst <- src for tensors that live in device memory or in PINNED host memory, by one small
-        kernel on the handle's stream (`omgx_batch_transfer`: no copy-engine hand-over; a pinned tensor is read / written over
-        the host link by the kernel itself)."""
+    def transfer_plan(self, pairs):
+        """A prepared `transfer` of fixed tensors: the argument checks (pinned? contiguous?) and the ctypes arrays once, every
+        `run()` one library call -- for per-step loops (`is_pinned()` alone asks the runtime about the pointer every time)."""
         n = len(pairs)
         srcs, dsts, nbytes = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
         for i, (dst, src) in enumerate(pairs):
@@ -435,7 +434,19 @@ class BatchSolver(object):
                 if not (t.is_cuda or t.is_pinned()):
                     raise ValueError('transfer: device or pinned host tensors only')
             srcs[i], dsts[i], nbytes[i] = src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size()
-        _check(self.lib, self.lib.omgx_batch_transfer(self._h, C.c_int32(n), srcs, dsts, nbytes), 'omgx_batch_transfer')
+        solver, keep = self, list(pairs)                    # (the tensors stay alive with the plan)
+
+        class Plan(object):
+            def run(self_):
+                _check(solver.lib, solver.lib.omgx_batch_transfer(solver._h, C.c_int32(n), srcs, dsts, nbytes), 'omgx_batch_transfer')
+            tensors = keep
+        return Plan()
+
+    def transfer(self, pairs):
+        """[(dst, src), ...] (at most 6): dst <- src for tensors that live in device memory or in PINNED host memory, by one small
+        kernel on the handle's stream (`omgx_batch_transfer`: no copy-engine hand-over; a pinned tensor is read / written over
+        the host link by the kernel itself)."""
+        self.transfer_plan(pairs).run()
 
     def sync(self):
         _check(self.lib, self.lib.omgx_batch_sync(self._h), 'omgx_batch_sync')
