@@ -231,8 +231,8 @@ class FormationPoint2point(object):
 
     def _device_prediction(self, current_time, update_time, crossing):
         """Whether this update's initial conditions can be predicted on the device: every vehicle predicts ideally, the update
-        moves the clock forward (not a start-up iteration), and no vehicle was handed another state or target since the last
-        update (option 'device_prediction': True by default, False = always pack on the host)."""
+        moves the clock forward (not a start-up iteration), and no vehicle was handed another state, input or target since the
+        last update (option 'device_prediction': True by default, False = always pack on the host)."""
         if not self.options.get('device_prediction', True) or not hasattr(self.ops, 'predict'):
             return False
         if not (current_time > self._time_prev + 1e-9) or self.iteration < self.options['init_iter']:
@@ -252,10 +252,14 @@ class FormationPoint2point(object):
             self._shared_cols = np.nonzero(per_agent & ~own)[0]
             self._o_plan = tpl.entry_range(veh.label, 'splines_seg0', 'var')[0]
             self._targets = None
-        # a new target (`set_terminal_conditions`) or a state handed in from outside: back to the host for this update
+        # a new target (`set_terminal_conditions`) or a state / input handed in from outside since the last update
+        # (`set_initial_conditions`, `overrule_state`, `overrule_input`: every such call bumps the vehicle's `_ic_version`):
+        # back to the host for this update -- the resident plan does not know about it
         targets = np.array([np.asarray(v.poseT, float) for v in self.vehicles])
-        if self._targets is None or targets.shape != self._targets.shape or not np.array_equal(targets, self._targets):
-            self._targets = targets
+        handed_in = [getattr(v, '_ic_version', 0) for v in self.vehicles]
+        if (self._targets is None or targets.shape != self._targets.shape or not np.array_equal(targets, self._targets)
+                or handed_in != getattr(self, '_handed_in', None)):
+            self._targets, self._handed_in = targets, handed_in
             return False
         return True
 

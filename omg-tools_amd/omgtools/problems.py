@@ -1,37 +1,19 @@
-# This file is derived from OMG-tools (meco-group/omg-tools, `omgtools/problems/problem.py`, `point2point.py`).
-#
-# OMG-tools -- Optimal Motion Generation-tools
-# Copyright (C) 2016 Ruben Van Parys & Tim Mercy, KU Leuven.
-# All rights reserved.
-#
-# OMG-tools is free software; you can redistribute it and/or
-# modify it under the terms of the GNU Lesser General Public
-# License as published by the Free Software Foundation; either
-# version 3 of the License, or (at your option) any later version.
-# This software is distributed in the hope that it will be useful,
-# but WITHOUT ANY WARRANTY; without even the implied warranty of
-# MERCHANTABILITY or FITNESS FOR A PARTICULAR PURPOSE. See the GNU
-# Lesser General Public License for more details.
-#
-# You should have received a copy of the GNU Lesser General Public
-# License along with this program; if not, write to the Free Software
-# Foundation, Inc., 51 Franklin Street, Fifth Floor, Boston, MA 02110-1301 USA
-#
-# Modifications: the public classes, option names, method order and messages of the files named
-# above are kept so that scripts written for OMG-tools run unchanged where the original package is
-# not installed (benchmark and test tiers of this repository); the CasADi expression layer underneath
-# is replaced by explicit polynomials (symbolic.py) and the solver call by the HIP path (backend.py).
-# Where the original package IS installed, use omgx_shim instead: it runs the original classes themselves.
+"""`Problem` and the point-to-point family (`Point2point` factory, `FixedTPoint2point`, `FreeEndPoint2point`,
+`FreeTPoint2point`): what one receding-horizon solve IS -- written for this package against the behaviour of the reference's
+`problems/problem.py` (options 54-74, init 85-91, solve 103-136, predict 138-163, reset_init_guess 165-181, simulate 187-192)
+and `problems/point2point.py` (factory 28-35, construct 53-62, initial rows 64-70, fixed T 126-266, free T 269-369, free end
+376-418): same class names, constructor arguments, option keys, variable / parameter names and ORDER of definitions (the flat
+layouts are pinned by tests/golden/nlp_*.npz).
 
-"""`Problem`, `Point2point` (fixed-T) -- the receding-horizon solve.
+`Problem.solve` is the call this whole repository exists for: it keeps the reference's shape
+`result = self.problem(x0=, p=, lbg=, ubg=)` / `self.problem.stats()['return_status']` (`problems/problem.py:113-119`), and
+`self.problem` is the HIP solver object of backend.py where the reference holds a CasADi `nlpsol`.
 
-Behavioural spec: reference `problems/problem.py` (options 54-74, init 85-91,
-solve 103-136, predict 138-163, reset_init_guess 165-181, simulate 187-192) and
-`problems/point2point.py` (factory 28-35, construct 53-62, init constraints
-64-70, FixedTPoint2point 126-266).  `solve()` keeps the reference's call shape
-`self.problem(x0=, p=, lbg=, ubg=) -> {'x','lam_g'}` + `stats()['return_status']`;
-behind it sits the HIP batch solver (backend.py) instead of CasADi/IPOPT.
-"""
+The formulation, in this package's words.  Time runs in spline time tau in [0, 1] over a horizon of T seconds; the plan began
+t seconds ago (t0 = t / T), so the vehicle is at tau = t0 NOW: initial conditions are rows at t0, the objective integrates from
+t0, and when t passes a knot the plan is re-expressed on a horizon that starts one knot interval later (`init_step`).  Reaching
+the target is soft: |spline - target| <= g with the slack spline g integrated in the objective; the terminal derivatives are
+pinned to zero.  With a free end time T is itself the variable and the objective."""
 import time
 
 import numpy as np
@@ -41,62 +23,58 @@ from .plotting import PlotLayer
 from .vehicles import get_fleet_vehicles
 from .splines import definite_integral, evalspline, shiftoverknot_T
 
+_NESTED_OPTIONS = ('solver_options', 'codegen')
+
 
 class Problem(OptiChild, PlotLayer):
 
     def __init__(self, fleet, environment, options=None, label='problem'):
         OptiChild.__init__(self, label)
         PlotLayer.__init__(self)
-        self.fleet, self.vehicles = get_fleet_vehicles(fleet)
         self.environment = environment
+        self.fleet, self.vehicles = get_fleet_vehicles(fleet)
+        self.iteration, self.update_times = 0, []
         self.set_default_options()
         self.set_options(options or {})
-        self.iteration = 0
-        self.update_times = []
-        children = [vehicle for vehicle in self.vehicles]
-        children += [obstacle for obstacle in self.environment.obstacles]
-        children += [self, self.environment]
-        self.father = OptiFather(children)
+        # the order of the children is the order of their blocks in x, p and g (`problem.py:45-48`)
+        self.father = OptiFather(list(self.vehicles) + list(environment.obstacles) + [self, environment])
 
     def set_default_options(self):
-        self.options = {'verbose': 2, 'solver': 'ipopt'}
-        # the option names of the reference are kept; the HIP interior-point
-        # solver maps 'ipopt.tol' / 'ipopt.max_iter' onto its own settings
-        self.options['solver_options'] = {'ipopt': {
-            'ipopt.tol': 1e-3, 'ipopt.warm_start_init_point': 'yes',
-            'ipopt.print_level': 0, 'print_time': 0,
-            'ipopt.fixed_variable_treatment': 'make_constraint'}}
-        self.options['codegen'] = {'build': None, 'flags': '-O0'}
+        # (the reference's option names: the HIP solver reads 'ipopt.tol' / 'ipopt.max_iter' and ignores the rest)
+        ipopt = {'ipopt.tol': 1e-3, 'ipopt.warm_start_init_point': 'yes', 'ipopt.fixed_variable_treatment': 'make_constraint'}
+        ipopt.update({'ipopt.print_level': 0, 'print_time': 0})
+        self.options = {'verbose': 2, 'solver': 'ipopt', 'solver_options': {'ipopt': ipopt}, 'codegen': {'build': None, 'flags': '-O0'}}
 
     def set_options(self, options):
-        if 'solver_options' in options:
-            for key, value in options['solver_options'].items():
-                self.options['solver_options'].setdefault(key, {}).update(value)
-        if 'codegen' in options:
-            self.options['codegen'].update(options['codegen'])
-        for key in options:
-            if key not in ['solver_options', 'codegen']:
-                self.options[key] = options[key]
+        for key, value in options.items():
+            if key == 'solver_options':
+                for solver, settings in value.items():
+                    self.options['solver_options'].setdefault(solver, {}).update(settings)
+            elif key == 'codegen':
+                self.options['codegen'].update(value)
+            else:
+                self.options[key] = value
 
-    # -- construction -------------------------------------------------------------
+    # ---- building the NLP ----------------------------------------------------------------------------------------------
     def construct(self):
         self.environment.init()
-        for vehicle in self.vehicles:
-            vehicle.init()
+        for veh in self.vehicles:
+            veh.init()
 
     def init(self):
+        """Define everything (`construct`), hand the template to the solver factory; returns the build time."""
         self.father.reset()
         with self.father.table:
             self.construct()
-            self.problem, buildtime = self.father.construct_problem(self.options)
-        self.father.init_transformations(self.init_primal_transform,
-                                         self.init_dual_transform)
-        return buildtime
+            self.problem, seconds = self.father.construct_problem(self.options)
+        self.father.init_transformations(self.init_primal_transform, self.init_dual_transform)
+        return seconds
 
     def init_primal_transform(self, basis):
         return None
 
-    init_dual_transform = init_primal_transform
+    def init_dual_transform(self, basis):
+        return None
 
     def init_step(self, current_time, update_time):
         pass
@@ -105,75 +83,71 @@ class Problem(OptiChild, PlotLayer):
         pass
 
     def reinitialize(self, father=None):
-        father = self.father if father is None else father
-        father.init_variables()
-        father.init_parameters()
+        target = father if father is not None else self.father
+        target.init_variables()
+        target.init_parameters()
 
-    # -- the hot call ----------------------------------------------------------------
+    # ---- the hot call ------------------------------------------------------------------------------------------------------
     def solve(self, current_time, update_time):
-        current_time -= self.start_time
-        self.init_step(current_time, update_time)
-        var = self.father.get_variables()
-        par = self.father.set_parameters(current_time)
-        lb, ub = self.father.update_bounds(current_time)
-        t0 = time.time()
-        result = self.problem(x0=var, p=par, lbg=lb, ubg=ub)
-        t_upd = time.time() - t0
-        self.father.set_variables(result['x'])
-        self.father.set_dual_variables(result['lam_g'])
-        stats = self.problem.stats()
-        if stats['return_status'] != 'Solve_Succeeded':
-            if stats['return_status'] == 'Maximum_CpuTime_Exceeded':
-                if current_time != 0.0:
-                    print('Maximum solving time exceeded, resetting initial guess')
-                    self.reset_init_guess()
-                    print(stats['return_status'])
-            else:
-                print(stats['return_status'])
+        now = current_time - self.start_time
+        self.init_step(now, update_time)
+        fa = self.father
+        x0, p = fa.get_variables(), fa.set_parameters(now)
+        lbg, ubg = fa.update_bounds(now)
+        tic = time.time()
+        result = self.problem(x0=x0, p=p, lbg=lbg, ubg=ubg)
+        spent = time.time() - tic
+        fa.set_variables(result['x'])
+        fa.set_dual_variables(result['lam_g'])
+        outcome = self.problem.stats()['return_status']
+        if outcome == 'Maximum_CpuTime_Exceeded':
+            if now != 0.0:
+                print('Maximum solving time exceeded, resetting initial guess')
+                self.reset_init_guess()
+                print(outcome)
+        elif outcome != 'Solve_Succeeded':
+            print(outcome)
         if self.options['verbose'] >= 2:
+            if self.iteration % 20 == 0:
+                rule = '----|------------|------------'
+                print('\n'.join((rule, '%3s | %10s | %10s ' % ('It', 't upd', 'time'), rule)))
             self.iteration += 1
-            if (self.iteration - 1) % 20 == 0:
-                print("----|------------|------------")
-                print("%3s | %10s | %10s " % ("It", "t upd", "time"))
-                print("----|------------|------------")
-            print("%3d | %.4e | %.4e " % (self.iteration, t_upd, current_time))
-        self.update_times.append(t_upd)
+            print('%3d | %.4e | %.4e ' % (self.iteration, spent, now))
+        self.update_times.append(spent)
 
-    def predict(self, current_time, predict_time, sample_time, states=None, inputs=None,
-                dinputs=None, delay=0, enforce_states=False, enforce_inputs=False):
+    def predict(self, current_time, predict_time, sample_time, states=None, inputs=None, dinputs=None, delay=0,
+                enforce_states=False, enforce_inputs=False):
         n = len(self.vehicles)
 
-        def per_vehicle(values):
+        def spread(values):
+            """None, one vehicle's value, or a list over the vehicles -> a list over the vehicles"""
             if values is None:
                 return [None] * n
-            if n == 1 and (not isinstance(values, list) or isinstance(values[0], float)):
-                return [values]
-            return values
-        states, inputs, dinputs = per_vehicle(states), per_vehicle(inputs), per_vehicle(dinputs)
-        if current_time == self.start_time:
-            enforce_states = True
-        for k, vehicle in enumerate(self.vehicles):
-            vehicle.predict(current_time, predict_time, sample_time, states[k], inputs[k],
-                            dinputs[k], delay, enforce_states, enforce_inputs)
+            single = n == 1 and (not isinstance(values, list) or isinstance(values[0], float))
+            return [values] if single else values
+        per = [spread(v) for v in (states, inputs, dinputs)]
+        first = current_time == self.start_time                 # the first update starts from the state the user set
+        for k, veh in enumerate(self.vehicles):
+            veh.predict(current_time, predict_time, sample_time, per[0][k], per[1][k], per[2][k], delay,
+                        enforce_states or first, enforce_inputs)
 
     def reset_init_guess(self, init_guess=None):
         if init_guess is None:
-            init_guess = [vehicle.get_init_spline_value() for vehicle in self.vehicles]
-        elif not isinstance(init_guess, list):
-            init_guess = [init_guess]
-        for k, vehicle in enumerate(self.vehicles):
-            guess = init_guess[k] if isinstance(init_guess[k], list) else [init_guess[k]]
-            if len(guess) != vehicle.n_seg:
-                raise ValueError('Each spline segment of the vehicle should receive an '
-                                 'initial guess.')
-            for l in range(vehicle.n_seg):
-                if guess[l].shape[1] != vehicle.n_spl:
+            guesses = [veh.get_init_spline_value() for veh in self.vehicles]
+        else:
+            guesses = init_guess if isinstance(init_guess, list) else [init_guess]
+        for veh, guess in zip(self.vehicles, guesses):
+            segments = guess if isinstance(guess, list) else [guess]
+            if len(segments) != veh.n_seg:
+                raise ValueError('Each spline segment of the vehicle should receive an initial guess.')
+            for l, coeffs in enumerate(segments):
+                if coeffs.shape[1] != veh.n_spl:
                     raise ValueError('Each vehicle spline should receive an initial guess.')
-                self.father.set_variables(guess[l], child=vehicle, name='splines_seg' + str(l))
+                self.father.set_variables(coeffs, child=veh, name='splines_seg%d' % l)
 
     def simulate(self, current_time, simulation_time, sample_time):
-        for vehicle in self.vehicles:
-            vehicle.simulate(simulation_time, sample_time)
+        for veh in self.vehicles:
+            veh.simulate(simulation_time, sample_time)
         self.environment.simulate(simulation_time, sample_time)
         self.fleet.update_plots()
         self.update_plots()
@@ -187,57 +161,65 @@ class Problem(OptiChild, PlotLayer):
     def store(self, current_time, update_time, sample_time):
         pass
 
+    # ---- helpers of the subclasses ---------------------------------------------------------------------------------------
+    def _plan_of(self, veh):
+        return [self.father.get_variables(veh, 'splines_seg%d' % k) for k in range(veh.n_seg)]
+
+    def _hand_plan_over(self, veh, current_time, sample_time, first, horizon):
+        """`veh.store` of the plan over `horizon` seconds, sampled on first, first + sample_time, ... up to its end."""
+        n = int(round((horizon - first) / sample_time, 6)) + 1
+        grid = np.linspace(first, first + (n - 1) * sample_time, n)
+        veh.store(current_time, sample_time, self._plan_of(veh), horizon, grid)
+
 
 class Point2point(object):
-    """Factory selecting fixed-T vs free-T (`point2point.py:28-35`)."""
+    """`Point2point(fleet, environment, options, freeT=False)`: the fixed- or the free-end-time class (`point2point.py:28-35`)."""
 
     def __new__(cls, fleet, environment, options=None, freeT=False):
-        if freeT:
-            return FreeTPoint2point(fleet, environment, options)
-        return FixedTPoint2point(fleet, environment, options)
+        return (FreeTPoint2point if freeT else FixedTPoint2point)(fleet, environment, options)
 
 
 class Point2pointProblem(Problem):
 
     def __init__(self, fleet, environment, options):
         Problem.__init__(self, fleet, environment, options, label='p2p')
-        self.init_time = None
-        self.start_time = 0.
+        self.init_time, self.start_time = None, 0.
 
     def set_default_options(self):
         Problem.set_default_options(self)
         self.options['inter_vehicle_avoidance'] = False
 
     def define_time(self):
-        """T, t and t0 = t/T (`point2point.py:53-55`); FreeT overrides."""
-        self.T, self.t = self.define_parameter('T'), self.define_parameter('t')
+        """Parameters T (horizon) and t (time since the plan began), t0 = t / T (`point2point.py:53-55`)."""
+        self.T = self.define_parameter('T')
+        self.t = self.define_parameter('t')
         self.t0 = self.t / self.T
 
     def construct(self):
         self.define_time()
         Problem.construct(self)
-        for vehicle in self.vehicles:
-            splines = vehicle.define_splines(n_seg=1)
-            vehicle.define_trajectory_constraints(splines[0], self.T)
-            self.environment.define_collision_constraints(vehicle, splines, self.T)
-        if len(self.vehicles) > 1 and self.options['inter_vehicle_avoidance']:
+        for veh in self.vehicles:
+            segments = veh.define_splines(n_seg=1)
+            veh.define_trajectory_constraints(segments[0], self.T)
+            self.environment.define_collision_constraints(veh, segments, self.T)
+        if self.options['inter_vehicle_avoidance'] and len(self.vehicles) > 1:
             self.environment.define_intervehicle_collision_constraints(self.vehicles, self.T)
 
     def define_init_constraints(self):
-        for vehicle in self.vehicles:
-            for spline, condition in vehicle.get_initial_constraints(vehicle.splines[0], self.T):
-                self.define_constraint(evalspline(spline, self.t0) - condition, 0., 0.)
+        """The plan passes through the predicted state NOW: rows at tau = t0."""
+        for veh in self.vehicles:
+            for spline, value in veh.get_initial_constraints(veh.splines[0], self.T):
+                self.define_constraint(evalspline(spline, self.t0) - value, 0., 0.)
 
     def initialize(self, current_time):
         self.start_time = current_time
 
     def reinitialize(self, father=None):
-        father = self.father if father is None else father
+        target = father if father is not None else self.father
         Problem.reinitialize(self)
-        for vehicle in self.vehicles:
-            init = vehicle.get_init_spline_value()
-            for k in range(vehicle.n_seg):
-                father.set_variables(init[k], vehicle, 'splines_seg' + str(k))
+        for veh in self.vehicles:
+            for k, coeffs in enumerate(veh.get_init_spline_value()[:veh.n_seg]):
+                target.set_variables(coeffs, veh, 'splines_seg%d' % k)
 
     def set_init_time(self, time):
         self.init_time = time
@@ -246,20 +228,26 @@ class Point2pointProblem(Problem):
         self.init_time = None
 
     def stop_criterium(self, current_time, update_time):
-        return all(vehicle.check_terminal_conditions() for vehicle in self.vehicles)
+        return all(veh.check_terminal_conditions() for veh in self.vehicles)
 
     def final(self):
         self.reset_init_time()
-        obj = self.compute_objective()
+        total = self.compute_objective()
         if self.options['verbose'] >= 1:
+            ms = 1000. * np.asarray(self.update_times)
             print('\nWe reached our target!')
-            print('%-18s %6g' % ('Objective:', obj))
-            print('%-18s %6g ms' % ('Max update time:', max(self.update_times) * 1000.))
-            print('%-18s %6g ms' % ('Av update time:',
-                                    sum(self.update_times) * 1000. / len(self.update_times)))
+            for name, value, unit in (('Objective:', total, ''), ('Max update time:', ms.max(), ' ms'), ('Av update time:', ms.sum() / len(ms), ' ms')):
+                print('%-18s %6g%s' % (name, value, unit))
 
     def compute_objective(self):
         raise NotImplementedError('Please implement this method!')
+
+    def _reach_softly(self, k, spline, target):
+        """Slack spline g<k> with |spline - target| <= g; returns its share of the objective (integral of g from t0)."""
+        g = self.define_spline_variable('g%d' % k, 1, basis=spline.basis)[0]
+        self.define_constraint(spline - target - g, -inf, 0.)
+        self.define_constraint(-spline + target - g, -inf, 0.)
+        return definite_integral(g, self.t0, 1.)
 
 
 class FixedTPoint2point(Point2pointProblem):
@@ -267,17 +255,15 @@ class FixedTPoint2point(Point2pointProblem):
     def __init__(self, fleet, environment, options):
         Point2pointProblem.__init__(self, fleet, environment, options)
         self.objective = 0.
-        if self.vehicles[0].knot_intervals is None:
-            raise ValueError('A constant knot interval should be used for a fixed T '
-                             'point2point problem.')
-        self.knot_time = (int(self.options['horizon_time'] * 1000.) /
-                          self.vehicles[0].knot_intervals) / 1000.
+        intervals = self.vehicles[0].knot_intervals
+        if intervals is None:
+            raise ValueError('A constant knot interval should be used for a fixed T point2point problem.')
+        # (seconds per knot interval, in whole milliseconds of the horizon like the reference)
+        self.knot_time = (int(self.options['horizon_time'] * 1000.) / intervals) / 1000.
 
     def set_default_options(self):
         Point2pointProblem.set_default_options(self)
-        self.options['horizon_time'] = 10.
-        self.options['hard_term_con'] = False
-        self.options['no_term_con_der'] = False
+        self.options.update(horizon_time=10., hard_term_con=False, no_term_con_der=False)
 
     def construct(self):
         Point2pointProblem.construct(self)
@@ -285,158 +271,120 @@ class FixedTPoint2point(Point2pointProblem):
         self.define_terminal_constraints()
 
     def define_terminal_constraints(self):
-        objective = 0.
+        cost = 0.
         self.term_con_len = []
-        for vehicle in self.vehicles:
-            term_con, term_con_der = vehicle.get_terminal_constraints(vehicle.splines[0])
-            if self.options.get('no_term_con_der'):
-                term_con_der = []
-            self.term_con_len.append(len(term_con))
-            for k, (spline, condition) in enumerate(term_con):
-                g = self.define_spline_variable('g' + str(k), 1, basis=spline.basis)[0]
-                objective = objective + definite_integral(g, self.t0, 1.)
-                self.define_constraint(spline - condition - g, -inf, 0.)
-                self.define_constraint(-spline + condition - g, -inf, 0.)
+        for veh in self.vehicles:
+            reach, rest = veh.get_terminal_constraints(veh.splines[0])
+            self.term_con_len.append(len(reach))
+            for k, (spline, target) in enumerate(reach):
+                cost = cost + self._reach_softly(k, spline, target)
                 if self.options['hard_term_con']:
-                    self.define_constraint(spline(1.) - condition, 0., 0.)
-            for spline, condition in term_con_der:
-                self.define_constraint(spline(1.) - condition, 0., 0.)
-        self.define_objective(objective)
+                    self.define_constraint(spline(1.) - target, 0., 0.)
+            for spline, target in ([] if self.options.get('no_term_con_der') else rest):
+                self.define_constraint(spline(1.) - target, 0., 0.)
+        self.define_objective(cost)
+
+    def _since_knot(self, elapsed):
+        """t: seconds since the last knot the plan passed (or the time the user pinned with `set_init_time`)."""
+        return np.round(elapsed, 6) % self.knot_time if self.init_time is None else self.init_time
 
     def set_parameters(self, current_time):
-        parameters = {self: {}}
-        if self.init_time is None:
-            parameters[self]['t'] = np.round(current_time, 6) % self.knot_time
-        else:
-            parameters[self]['t'] = self.init_time
-        parameters[self]['T'] = self.options['horizon_time']
-        return parameters
+        return {self: {'t': self._since_knot(current_time), 'T': self.options['horizon_time']}}
 
-    # -- deployment --------------------------------------------------------------------
-    def init_step(self, current_time, update_time):
-        if not hasattr(self, 'current_time_prev'):
-            self.current_time_prev = 0
-        interval_prev = int(np.round(self.current_time_prev / self.knot_time, 6))
-        interval_now = int(np.round(current_time / self.knot_time, 6))
-        if interval_prev < interval_now:      # a knot was passed: shift the warm start
-            self.father.transform_primal_splines(lambda coeffs, basis, T: T.dot(coeffs))
-        self.current_time_prev = current_time
-
+    # ---- between two solves ----------------------------------------------------------------------------------------------
     def init_primal_transform(self, basis):
         return shiftoverknot_T(basis)
-
-    def init_dual_transform(self, basis):
-        return None
 
     def initialize(self, current_time):
         Point2pointProblem.initialize(self, current_time)
         self.current_time_prev = current_time
 
-    def _rel_time(self, current_time):
-        if self.init_time is None:
-            return np.round(current_time - self.start_time, 6) % self.knot_time
-        return self.init_time
+    def init_step(self, current_time, update_time):
+        """A knot was passed since the previous solve: move the warm start to the horizon that begins one interval later."""
+        before = getattr(self, 'current_time_prev', 0)
+        passed = lambda when: int(np.round(when / self.knot_time, 6))
+        if passed(before) < passed(current_time):
+            self.father.transform_primal_splines(lambda coeffs, basis, T: T.dot(coeffs))
+        self.current_time_prev = current_time
 
     def store(self, current_time, update_time, sample_time):
-        horizon_time = self.options['horizon_time']
-        rel = self._rel_time(current_time)
-        for vehicle in self.vehicles:
-            n_samp = int(round((horizon_time - rel) / sample_time, 6)) + 1
-            time_axis = np.linspace(rel, rel + (n_samp - 1) * sample_time, n_samp)
-            segments = [self.father.get_variables(vehicle, 'splines_seg' + str(k))
-                        for k in range(vehicle.n_seg)]
-            vehicle.store(current_time, sample_time, segments, horizon_time, time_axis)
+        begun = self._since_knot(current_time - self.start_time)
+        for veh in self.vehicles:
+            self._hand_plan_over(veh, current_time, sample_time, begun, self.options['horizon_time'])
 
     def simulate(self, current_time, simulation_time, sample_time):
-        horizon_time = self.options['horizon_time']
-        rel = self._rel_time(current_time)
-        if horizon_time - rel < simulation_time:
-            simulation_time = horizon_time - rel
-        self.compute_partial_objective(current_time, simulation_time)
-        Problem.simulate(self, current_time, simulation_time, sample_time)
+        left = self.options['horizon_time'] - self._since_knot(current_time - self.start_time)
+        span = min(simulation_time, left)
+        self.compute_partial_objective(current_time, span)
+        Problem.simulate(self, current_time, span, sample_time)
+
+    def _slacks(self):
+        for count in self.term_con_len:
+            for k in range(count):
+                yield self.father.get_variables(self, 'g%d' % k)[0]
 
     def compute_partial_objective(self, current_time, update_time):
-        horizon_time = self.options['horizon_time']
-        t0 = (np.round(current_time - self.start_time, 6) % self.knot_time) / horizon_time
-        t1 = t0 + update_time / horizon_time
-        part = 0.
-        for v in range(len(self.vehicles)):
-            for k in range(self.term_con_len[v]):
-                g = self.father.get_variables(self, 'g' + str(k))[0]
-                part += horizon_time * definite_integral(g, t0, t1)
-        self.objective += part
+        """What the part of the plan that is executed now costs (summed up over the run as `self.objective`)."""
+        T = self.options['horizon_time']
+        a = (np.round(current_time - self.start_time, 6) % self.knot_time) / T
+        b = a + update_time / T
+        self.objective += sum(T * definite_integral(g, a, b) for g in self._slacks())
 
     def compute_objective(self):
-        if self.objective == 0:
-            obj = 0.
-            for v in range(len(self.vehicles)):
-                for k in range(self.term_con_len[v]):
-                    g = self.father.get_variables(self, 'g' + str(k))[0]
-                    obj += self.options['horizon_time'] * g.integral()
-            return obj
-        return self.objective
+        if self.objective != 0:
+            return self.objective
+        return sum(self.options['horizon_time'] * g.integral() for g in self._slacks()) if self.term_con_len else 0.
 
 
 class FreeEndPoint2point(FixedTPoint2point):
-    """Fixed horizon, free end point (`problems/point2point.py:376-418`): the terminal conditions
-    listed in `free_ind[vehicle]` become the variable `conT<l>`; the building block of the
-    reference's RendezVous problem (`problems/rendezvous.py:29-35`)."""
+    """Fixed horizon, free end point (`problems/point2point.py:376-418`): the terminal conditions listed in `free_ind[vehicle]`
+    become the variable `conT<l>` -- the building block of the rendez-vous problem (`problems/rendezvous.py:29-35`)."""
 
     def __init__(self, fleet, environment, options, free_ind=None):
         FixedTPoint2point.__init__(self, fleet, environment, options)
         self.free_ind = free_ind
 
     def construct(self):
-        if self.free_ind is None:
-            self.free_ind = {}
-            for vehicle in self.vehicles:
-                term_con = vehicle.get_terminal_constraints(vehicle.splines[0])
-                self.free_ind[vehicle] = list(range(len(term_con)))
+        if self.free_ind is None:               # every terminal condition of every vehicle is free
+            self.free_ind = dict((veh, list(range(len(veh.get_terminal_constraints(veh.splines[0]))))) for veh in self.vehicles)
         FixedTPoint2point.construct(self)
 
     def define_terminal_constraints(self):
-        objective = 0.
+        cost = 0.
         self.term_con_len = []
-        for l, vehicle in enumerate(self.vehicles):
-            term_con, term_con_der = vehicle.get_terminal_constraints(vehicle.splines[0])
-            conditions = np.atleast_1d(self.define_variable('conT' + str(l), len(self.free_ind[vehicle])))
-            cnt = 0
-            self.term_con_len.append(len(term_con))
-            for k, con in enumerate(term_con):
-                if k in self.free_ind[vehicle]:
-                    spline, condition = con[0], conditions[cnt]
-                    cnt += 1
+        for l, veh in enumerate(self.vehicles):
+            reach, rest = veh.get_terminal_constraints(veh.splines[0])
+            free = list(self.free_ind[veh])
+            ends = np.atleast_1d(self.define_variable('conT%d' % l, len(free)))
+            self.term_con_len.append(len(reach))
+            taken = 0
+            for k, (spline, fixed) in enumerate(reach):
+                if k in free:
+                    target, taken = ends[taken], taken + 1
                 else:
-                    spline, condition = con[0], con[1]
-                g = self.define_spline_variable('g' + str(k), 1, basis=spline.basis)[0]
-                objective = objective + definite_integral(g, self.t0, 1.)
-                self.define_constraint(spline - condition - g, -inf, 0.)
-                self.define_constraint(-spline + condition - g, -inf, 0.)
-            # as in the reference (`point2point.py:416-417`): the loop over the derivative conditions
-            # re-uses `spline, condition` of the last position condition, i.e. it pins the end point of
-            # the LAST position spline len(term_con_der) times -- kept, the NLP has to be the same
-            for con in term_con_der:
-                self.define_constraint(spline(1.) - condition, 0., 0.)
-        self.define_objective(objective)
+                    target = fixed
+                cost = cost + self._reach_softly(k, spline, target)
+            # The reference's loop over the derivative conditions (`point2point.py:416-417`) re-uses the spline and the target
+            # of the LAST position condition: it pins the end point of that spline len(rest) times.  Kept: the NLP has to be the same.
+            for _ in rest:
+                self.define_constraint(spline(1.) - target, 0., 0.)
+        self.define_objective(cost)
 
 
 class FreeTPoint2point(Point2pointProblem):
-    """Free end time (`point2point.py:269-369`): the motion time T is a variable and the
-    objective; hard terminal constraints; after every update the spline is re-expressed on the
-    remaining horizon (`shift_spline`) and T reduced by the update time.
+    """Free end time (`point2point.py:269-369`): the motion time T is a variable and the objective, the terminal conditions
+    are hard; after every update the plan is re-expressed on what is left of it and T reduced by the update time.
 
-    The reference resolves symbols by name, so that the parameter `T` the base class defines first
-    ends up unused (every `T` becomes the variable) but stays in the parameter vector; that
-    layout is kept.  Its `t` is always 0 for this problem class (the time axis resets every
-    update, `point2point.py:299-306`), so t0 = t/T is the constant 0 here; `set_init_time` is not
-    supported for free-T problems."""
+    The reference resolves symbols by name: the parameter `T` its base class defines first ends up unused (every `T` is the
+    variable) but keeps its place in the parameter vector -- so it does here.  Its `t` is 0 throughout (the time axis starts
+    anew with every update, `point2point.py:299-306`), so t0 = 0; `set_init_time` has no meaning for this class."""
 
     def __init__(self, fleet, environment, options):
         Point2pointProblem.__init__(self, fleet, environment, options)
         self.objective = 0.
 
     def define_time(self):
-        self.define_parameter('T')                       # kept for the reference's parameter layout
+        self.define_parameter('T')                       # (the unused slot of the reference's parameter layout)
         self.t = self.define_parameter('t')
         self.T = self.define_variable('T', value=10.)
         self.t0 = 0.
@@ -444,69 +392,58 @@ class FreeTPoint2point(Point2pointProblem):
     def construct(self):
         Point2pointProblem.construct(self)
         self.define_objective(self.T)
-        self.define_constraint(-self.T, -inf, 0.)          # positive motion time
+        self.define_constraint(-self.T, -inf, 0.)          # a motion time is positive
         self.define_init_constraints()
         self.define_terminal_constraints()
 
     def define_terminal_constraints(self):
-        for vehicle in self.vehicles:
-            term_con, term_con_der = vehicle.get_terminal_constraints(vehicle.splines[0])
-            if self.options.get('no_term_con_der'):
-                term_con_der = []
-            for spline, condition in term_con + term_con_der:
-                self.define_constraint(spline(1.) - condition, 0., 0.)
+        for veh in self.vehicles:
+            reach, rest = veh.get_terminal_constraints(veh.splines[0])
+            for spline, target in reach + ([] if self.options.get('no_term_con_der') else rest):
+                self.define_constraint(spline(1.) - target, 0., 0.)
 
     def set_parameters(self, current_time):
         if self.init_time is not None:
             raise NotImplementedError('set_init_time is not supported for free-T problems')
         return {self: {'t': 0.}}
 
-    # -- deployment --------------------------------------------------------------------
+    # ---- between two solves ----------------------------------------------------------------------------------------------
     def horizon(self):
         return float(np.asarray(self.father.get_variables(self, 'T')).reshape(-1)[0])
 
     def init_step(self, current_time, update_time):
-        if (current_time - self.start_time) > 0:
-            T = self.horizon()
-            if T < 2 * update_time:            # almost arrived: lower the update time
-                update_time = T - update_time
-                target_time = T
-            else:
-                target_time = T - update_time
-            from .splines import shift_spline_T
-            cache = {}
+        if not (current_time - self.start_time) > 0:
+            return
+        from .splines import shift_spline_T
+        T = self.horizon()
+        if T < 2 * update_time:                # almost there: a shorter update, the horizon stays
+            update_time, remaining = T - update_time, T
+        else:
+            remaining = T - update_time
+        moved = {}
 
-            def shift(coeffs, basis, _T=None):
-                key = id(basis)
-                if key not in cache:
-                    cache[key] = shift_spline_T(basis, update_time / target_time)
-                return cache[key].dot(coeffs)
-            self.father.transform_primal_splines(shift)
-            self.father.set_variables(target_time, self, 'T')
+        def onto_the_rest(coeffs, basis, _T=None):
+            if id(basis) not in moved:
+                moved[id(basis)] = shift_spline_T(basis, update_time / remaining)
+            return moved[id(basis)].dot(coeffs)
+        self.father.transform_primal_splines(onto_the_rest)
+        self.father.set_variables(remaining, self, 'T')
 
     def store(self, current_time, update_time, sample_time):
-        horizon_time = self.horizon()
-        if horizon_time < sample_time:
-            return
-        for vehicle in self.vehicles:
-            n_samp = int(round(horizon_time / sample_time, 6)) + 1
-            time_axis = np.linspace(0., (n_samp - 1) * sample_time, n_samp)
-            segments = [self.father.get_variables(vehicle, 'splines_seg' + str(k))
-                        for k in range(vehicle.n_seg)]
-            vehicle.store(current_time, sample_time, segments, horizon_time, time_axis)
+        T = self.horizon()
+        if T >= sample_time:
+            for veh in self.vehicles:
+                self._hand_plan_over(veh, current_time, sample_time, 0., T)
 
     def simulate(self, current_time, simulation_time, sample_time):
-        horizon_time = self.horizon()
-        if horizon_time < sample_time:
-            return
-        simulation_time = min(simulation_time, horizon_time)
-        self.objective = current_time + simulation_time - self.start_time
-        Problem.simulate(self, current_time, simulation_time, sample_time)
+        T = self.horizon()
+        if T >= sample_time:
+            span = min(simulation_time, T)
+            self.objective = current_time + span - self.start_time
+            Problem.simulate(self, current_time, span, sample_time)
 
     def stop_criterium(self, current_time, update_time):
-        if self.horizon() < update_time:
-            return True
-        return Point2pointProblem.stop_criterium(self, current_time, update_time)
+        return self.horizon() < update_time or Point2pointProblem.stop_criterium(self, current_time, update_time)
 
     def compute_objective(self):
         return self.objective
