@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Generate golden vectors by executing the REFERENCE's own problem-construction
-code (read-only, from /root/reference) under the numeric casadi stand-in in
-tests/golden/fake_casadi.  Run in the build container only:
+code (read-only, from /root/reference) under this repository's casadi stand-in
+(omg-tools_amd/omgx_shim/casadi: lazily evaluated closures, here evaluated on numbers; its
+operations are pinned against numpy by tests/test_shim_casadi_kats.py).  Run in the build container only:
 
     python tests/golden/generate_golden.py
 

@@ -8,6 +8,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_COLD = 5      # bench.py --streams 1: four timed cold solves of the side-leg handle + the cold solve of the headline's own handle
 PROF = os.path.join(ROOT, 'gpurun_out', 'prof')
 
 
@@ -31,7 +32,7 @@ def pmc(name):
                 min=min(vals), max=max(vals), per_launch_kb=vals)
 
 
-def issue_passes(tag, out, n_cold=5):
+def issue_passes(tag, out, n_cold=N_COLD):
     """Instruction-fetch / issue decomposition (round 5): every counter of the passes gpurun_out/prof/issue*/, mean per launch
     of ipm_solve_kernel, cold launches (the first `n_cold`: bench.py --streams 1 solves the batch cold five times) and
     receding-horizon steps apart, plus the ratios that decompose the wave-wait share."""
@@ -79,18 +80,17 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
     out = os.path.join(ROOT, 'profiles')
     if len(sys.argv) > 2 and sys.argv[2] == 'issue':
-        os.makedirs(os.path.join(ROOT, 'gpurun_out', 'profiles'), exist_ok=True)
-        return issue_passes(tag, os.path.join(ROOT, 'gpurun_out', 'profiles'))
+        return issue_passes(tag, out)
     stats = newest(os.path.join(PROF, 'stats', '*', '*_kernel_stats.csv'))
     rows = list(csv.reader(open(stats)))
     with open(os.path.join(out, '%s_kernel_stats.csv' % tag), 'w', newline='') as f:
         csv.writer(f).writerows(rows[:12])                      # header + the ten largest kernels
     fetch, write = pmc('FETCH_SIZE'), pmc('WRITE_SIZE')
     hbm = (fetch['mean_kb_per_launch'] + write['mean_kb_per_launch']) * 1024.0
-    json.dump({'FETCH_SIZE': fetch, 'WRITE_SIZE': write, 'hbm_bytes_per_launch': hbm,
+    json.dump({'FETCH_SIZE': fetch, 'WRITE_SIZE': write, 'hbm_bytes_per_launch': hbm, 'cold_launches': N_COLD, 'launches_per_step': 1,
                'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes '
-                       '(python bench.py --no-cpu --no-extras --steps 5 --warmup 1: 4 cold solves + 6 receding-horizon '
-                       'steps), kernel ipm_solve_kernel (the instance of the workspace mode, see VGPR / LDS / workgroup columns), 1024 agents; counter unit KB; mean over those launches.'},
+                       '(python bench.py --streams 1 --no-cpu --no-extras --steps 5 --warmup 1: 5 cold solves of the 1024-agent batch + 6 '
+                       'receding-horizon steps, one launch per step), kernel ipm_solve_kernel (the instance of the workspace mode, see VGPR / LDS / workgroup columns), 1024 agents; counter unit KB; mean over those launches.'},
               open(os.path.join(out, '%s_pmc_hbm.json' % tag), 'w'), indent=1)
     # further counter passes: mean per launch of every counter, cold launches (the first 4) and warm ones apart
     def multi(sub, names):
@@ -99,13 +99,13 @@ def main():
         for row in csv.DictReader(open(path)):
             if 'ipm_solve_kernel' in row['Kernel_Name'] and row['Counter_Name'] in per:
                 per[row['Counter_Name']].append(float(row['Counter_Value']))
-        return {n: {'launches': len(v), 'mean_cold': sum(v[:4]) / max(1, len(v[:4])),
-                    'mean_warm': sum(v[4:]) / max(1, len(v[4:]))} for n, v in per.items()}
+        return {n: {'launches': len(v), 'mean_cold': sum(v[:N_COLD]) / max(1, len(v[:N_COLD])),
+                    'mean_warm': sum(v[N_COLD:]) / max(1, len(v[N_COLD:]))} for n, v in per.items()}
     mf = multi('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CU_CYCLES', 'SQ_INSTS_VALU_MFMA_MOPS_F64'])
     for k in ('mean_cold', 'mean_warm'):
         mf['mfma_busy_over_cu_busy_' + k[5:]] = mf['SQ_VALU_MFMA_BUSY_CYCLES'][k] / max(1.0, mf['SQ_BUSY_CU_CYCLES'][k])
     mf['note'] = ('rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 -- python bench.py '
-                  '--no-cpu --no-extras --steps 5 --warmup 1; launches 0-3 are the cold solves of the batch, the rest '
+                  '--streams 1 --no-cpu --no-extras --steps 5 --warmup 1; launches 0-4 are the cold solves of the batch, the rest '
                   'receding-horizon steps; 1024 agents')
     json.dump(mf, open(os.path.join(out, '%s_pmc_mfma.json' % tag), 'w'), indent=1)
     lw = multi('lds', ['SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_INSTS_LDS'])
