@@ -382,13 +382,14 @@ def stepwise_leg(problem, P, opts, n_steps, warmup, dev, n_streams):
             'note': '%d sub-batch(es) of %d agents, per-step launches' % (len(parts), B // len(parts))}
 
 
-def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev, engine='kernel'):
+def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev, engine='kernel', depth=4):
     """SURVEY 8d's span as worded -- "device time incl. parameter upload and coefficient download" -- as a THROUGHPUT: the
     caller keeps p and x in (pinned) host memory.  Per step and per half of the batch, on that half's own HIP stream:
     the step's glue on the device (prediction: stands for the plant), the parameters DOWN to the host (the caller's copy of
     the measured state), the parameters UP again from pinned memory, the warm-started solve, then x, status and iteration
-    counts DOWN into one of two pinned buffer sets.  Nothing syncs the host inside a step: it waits for the event of step
-    k - 2 before it hands buffer set k % 2 out again (double buffering: the host reads step k - 1 while step k runs), and the
+    counts DOWN into one of `depth` pinned buffer sets.  Nothing syncs the host inside a step: it waits for the event of step
+    k - depth before it hands buffer set k % depth out again (a ring: the host consumes step k - depth + 1 .. k - 1 while step k
+    runs; depth 2 left the device queue two steps deep and every wake-up of the blocked host thread showed), and the
     transfers of one half overlap the solve of the other.  Solved agents are counted from the downloaded status words.
     engine='kernel': the transfers are `omgx_batch_transfer` launches (the kernel reads / writes the pinned buffers over the
     host link: no hand-over to a copy engine); engine='memcpy': hipMemcpyAsync through torch (`copy_(non_blocking=True)`)."""
@@ -401,8 +402,8 @@ def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev, engine='kern
     pin = lambda *shape, **kw: torch.empty(shape, **kw).pin_memory()
     p_h = [pin(n, tpl.n_par, dtype=torch.float64) for _ in rh.parts]
     bufs = [[dict(x=pin(n, tpl.n_var, dtype=torch.float64), status=pin(n, dtype=torch.int32), iters=pin(n, dtype=torch.int32))
-             for _ in range(2)] for _ in rh.parts]
-    done = [[None, None] for _ in rh.parts]
+             for _ in range(depth)] for _ in rh.parts]
+    done = [[None] * depth for _ in rh.parts]
     rh.solve_cold(bends=())
     for _ in range(warmup):
         rh.step()
@@ -440,8 +441,8 @@ def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev, engine='kern
     quiet_host()
     t_0 = time.perf_counter()
     for k in range(n_steps):
-        s = k % 2
-        for kp in range(len(rh.parts)):                    # buffer set s was handed out at step k - 2: its consumer is done when ...
+        s = k % depth
+        for kp in range(len(rh.parts)):                    # buffer set s was handed out at step k - depth: its consumer is done when ...
             if done[kp][s] is not None:
                 done[kp][s].synchronize()                  # ... that step's downloads have landed
                 ok += int((bufs[kp][s]['status'] == 0).sum())
@@ -460,16 +461,16 @@ def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev, engine='kern
     rh.synchronize()
     wall = time.perf_counter() - t_0
     gc.enable()
-    for k in range(max(0, n_steps - 2), n_steps):         # the last two steps' buffers
+    for k in range(max(0, n_steps - depth), n_steps):     # the last steps' buffers
         for kp in range(len(rh.parts)):
-            ok += int((bufs[kp][k % 2]['status'] == 0).sum())
+            ok += int((bufs[kp][k % depth]['status'] == 0).sum())
     rh.close()
     mb = (2 * tpl.n_par + tpl.n_var + 1) * 8 * B / 1e6
     return {'solves_per_s': ok / wall, 'ms_per_step': wall / n_steps * 1e3, 'steps': n_steps, 'warmup': warmup,
-            'solved_fraction': ok / float(n_steps * B), 'host_link_MB_per_step': mb, 'engine': engine,
+            'solved_fraction': ok / float(n_steps * B), 'host_link_MB_per_step': mb, 'engine': engine, 'ring_depth': depth,
             'host_enqueue_ms_per_step': t_host / n_steps * 1e3,
             'note': 'per step and half-batch on its own stream: p down + p up (pinned), solve, x / status / iters down into double-buffered '
-                    'pinned memory; no host sync inside a step (the host waits for step k - 2 before reusing a buffer set); transfers by '
+                    'pinned memory; no host sync inside a step (the host waits for step k - depth before reusing a buffer set of the ring); transfers by '
                     + ({'kernel': 'omgx_batch_transfer kernels (no copy engine)', 'memcpy': 'hipMemcpyAsync (copy engine)',
                         'mapped': 'p lives in pinned host memory (written by the prediction kernel, read by the solve kernel over the host '
                                   'link: no transfer of its own), x / status / iters by one omgx_batch_transfer kernel'}[engine])}

@@ -1,4 +1,6 @@
-"""Generates tests/golden/closed_loop_cfg2.npz: a CLOSED receding-horizon loop of config 2 (Holonomic, K = 11, 3 circles) with
+"""Generates tests/golden/closed_loop_cfg2.npz (and, with the argument `cfg3`, closed_loop_cfg3.npz: 8 agents of the Quadrotor class
+-- K = 13, five moving circles -- over 12 updates with three knot crossings; SLSQP stops on that class with 'positive directional
+derivative' at a feasibility of 1e-7, accepted as for tests/golden/sol_cfg3_ms.npz): a CLOSED receding-horizon loop of config 2 (Holonomic, K = 11, 3 circles) with
 an independent solver in the loop -- the reference's replay test (`export/tests/point2point/test.cpp:84-141`: the sampled state
 and input trajectories of every update compared with a run of the other implementation) with scipy SLSQP in the role CasADi /
 IPOPT cannot take here.
@@ -11,7 +13,7 @@ Per agent (64 seeded agents of the bench workload, `omgtools.workloads.holonomic
 Stored per step: the plan (all variables), its objective, the parameters the step was solved for, whether it crossed a knot.
 No number of the loop after step 0 comes from the product's algorithm; step 0 only takes its basin from it.
 
-Run from the repository root:  python tests/golden/generate_closed_loop.py   (about 10 min on 8 cores)"""
+Run from the repository root:  python tests/golden/generate_closed_loop.py [cfg2 | cfg3]   (1 min / about 10 min on 8 cores)"""
 import os
 import sys
 import time
@@ -23,15 +25,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
 sys.path.insert(0, ROOT)
 HERE = os.path.dirname(os.path.abspath(__file__))
-N_AGENTS, N_STEPS = 64, 25
+CONFIGS = {'cfg2': dict(workload='holonomic_p2p', agents=64, steps=25, chunk=2, slsqp=dict(maxiter=800)),
+           'cfg3': dict(workload='quadrotor_p2p', agents=8, steps=12, chunk=1, slsqp=dict(maxiter=1500, accept=(0, 8), viol_tol=1e-7))}
+CFG = CONFIGS['cfg2']
 
 
 class SlsqpOps(object):
     """The `ops` shape of BatchP2P's host protocol with SLSQP behind it."""
 
-    def __init__(self, tpl):
+    def __init__(self, tpl, slsqp):
         from oracle.nlp_numpy import NumpyNLP
         self.nlp = NumpyNLP(tpl)
+        self.slsqp = slsqp
         self.f, self.ok = None, None
 
     def solve(self, tpl, p, x, **kw):
@@ -40,23 +45,25 @@ class SlsqpOps(object):
         xs, st = np.array(x, dtype=float), np.zeros(B, dtype=np.int32)
         self.f, self.ok = np.zeros(B), np.zeros(B, dtype=bool)
         for b in range(B):
-            xb, fb, ok = solve_slsqp(self.nlp, tpl, x[b], p[b], maxiter=800)
+            xb, fb, ok = solve_slsqp(self.nlp, tpl, x[b], p[b], **self.slsqp)
             xs[b], self.f[b], self.ok[b] = xb, fb, ok
             st[b] = 0 if ok else 1
         return {'x': xs, 'lam_g': np.zeros((B, tpl.n_con)), 'status': st, 'iters': np.zeros(B, dtype=np.int32)}
 
 
 def run_agents(job):
-    lo, hi = job
+    name, lo, hi = job
+    cfg = CONFIGS[name]
+    N_AGENTS, N_STEPS = cfg['agents'], cfg['steps']
     from omgtools import workloads
     from omgtools.batch import BatchP2P
     from oracle import port_binding
-    problem, P = workloads.holonomic_p2p(N_AGENTS)
+    problem, P = getattr(workloads, cfg['workload'])(N_AGENTS)
     sub = {'p': P['p'][lo:hi], 'x0': P['x0'][lo:hi]}
     tpl = problem.father.template
-    ops = SlsqpOps(tpl)
+    ops = SlsqpOps(tpl, cfg['slsqp'])
     # step 0: the basin from the host build of the solver (cold, 1e-6), the plan from SLSQP started there
-    cold = port_binding.solve(tpl, sub['p'], sub['x0'], tol=1e-6, max_iter=500)
+    cold = port_binding.solve(tpl, sub['p'], sub['x0'], **dict(P.get('solver_options', {}), tol=1e-6, max_iter=500))
     assert (cold['status'] == 0).all(), cold['status']
     mpc = BatchP2P(problem, dict(sub, x0=cold['x']), ops=ops, options=dict(tol=1e-6, max_iter=500))
     mpc.solve_cold()
@@ -73,13 +80,15 @@ def run_agents(job):
 
 def main():
     t0 = time.time()
+    name = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
+    cfg = CONFIGS[name]
+    N_AGENTS, N_STEPS, chunk = cfg['agents'], cfg['steps'], cfg['chunk']
     workers = int(os.environ.get('WORKERS', '8'))
-    chunk = 2
-    jobs = [(lo, min(lo + chunk, N_AGENTS)) for lo in range(0, N_AGENTS, chunk)]
+    jobs = [(name, lo, min(lo + chunk, N_AGENTS)) for lo in range(0, N_AGENTS, chunk)]
     with ProcessPoolExecutor(workers) as ex:
         res = list(ex.map(run_agents, jobs, chunksize=1))
     from omgtools import workloads
-    problem, P = workloads.holonomic_p2p(N_AGENTS)
+    problem, P = getattr(workloads, cfg['workload'])(N_AGENTS)
     tpl = problem.father.template
     x = np.zeros((N_STEPS + 1, N_AGENTS, tpl.n_var)); f = np.zeros((N_STEPS + 1, N_AGENTS)); ok = np.zeros((N_STEPS + 1, N_AGENTS), dtype=bool)
     p = np.zeros((N_STEPS + 1, N_AGENTS, tpl.n_par)); x_cold = np.zeros((N_AGENTS, tpl.n_var))
@@ -89,10 +98,10 @@ def main():
         moved = max(moved, mv)
     veh = problem.vehicles[0]
     lo, hi = tpl.entry_range(veh.label, 'splines_seg0', 'var')
-    np.savez_compressed(os.path.join(HERE, 'closed_loop_cfg2.npz'), p0=P['p'], x0=P['x0'], x=x, f=f, ok=ok, p=p, crossed=crossed,
+    np.savez_compressed(os.path.join(HERE, 'closed_loop_%s.npz' % name), p0=P['p'], x0=P['x0'], x=x, f=f, ok=ok, p=p, crossed=crossed,
                         x_cold_port=x_cold, spl=np.array([lo, hi]), n_var=tpl.n_var, n_con=tpl.n_con, n_par=tpl.n_par,
                         update_time=0.1, sample_time=0.01)
-    print('closed_loop_cfg2.npz: %d agents x %d steps, %d / %d SLSQP solves converged, crossings at steps %s, SLSQP moved the cold '
+    print('closed_loop_' + name + '.npz: %d agents x %d steps, %d / %d SLSQP solves converged, crossings at steps %s, SLSQP moved the cold '
           'plan by at most %.2e, %.0f s' % (N_AGENTS, N_STEPS, int(ok.sum()), ok.size, np.nonzero(crossed)[0].tolist(), moved, time.time() - t0))
 
 

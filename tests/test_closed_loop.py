@@ -35,6 +35,12 @@ MAX_PARTED = 4
 # a different solver at 1e-3 can meet against a converged one; these are the figures a user of the replacement gets.
 BOUNDS = {1e-3: (6.0e-2, 1.0e-1, 1.0),
           1e-6: (1.0e-3, 4.0e-3, 2.0e-2)}
+# the Quadrotor class (closed_loop_cfg3.npz: 8 agents, 12 updates, three knot crossings, five moving circles; SLSQP's own accuracy on
+# this class is ~1e-4 on the coefficients: it stops with 'positive directional derivative' at a feasibility of 1e-7)
+# measured (host build): 1e-3: 5.4e-2 m (median at the end 2.0e-2), 0.18 m/s (the class flies at 1-2 m/s), relative 0.39;
+# 1e-6: 2.3e-4 m (median 6.5e-5), 1.2e-3 m/s, relative 2.3e-3; after the cold solve alone 1.6e-6 m
+BOUNDS_CFG3 = {1e-3: (1.2e-1, 4.0e-1, 1.0),
+               1e-6: (1.0e-3, 4.0e-3, 1.0e-2)}
 
 
 def sampled(problem, tpl, x, p, spl, sample_time):
@@ -54,21 +60,24 @@ def sampled(problem, tpl, x, p, spl, sample_time):
     return st, inp
 
 
-def run_loop(make_mpc, tol):
+def run_loop(make_mpc, tol, cfg='cfg2'):
     from omgtools import workloads
     from oracle.nlp_numpy import NumpyNLP
-    d = np.load(os.path.join(HERE, 'closed_loop_cfg2.npz'))
+    d = np.load(os.path.join(HERE, 'closed_loop_%s.npz' % cfg))
     steps, n = d['x'].shape[0] - 1, d['x'].shape[1]
-    problem, P = workloads.holonomic_p2p(n)
+    problem, P = {'cfg2': workloads.holonomic_p2p, 'cfg3': workloads.quadrotor_p2p}[cfg](n)
     tpl = problem.father.template
     nlp = NumpyNLP(tpl)
-    assert np.array_equal(P['p'], d['p0']) and np.array_equal(P['x0'], d['x0']) and d['ok'].all()
-    assert (int(d['n_var']), int(d['n_con'])) == (tpl.n_var, tpl.n_con) and d['crossed'].sum() == 2
+    # (agents whose reference loop holds a step SLSQP did not finish -- 2 of the 8 Quadrotor agents: feasibility above 1e-7 at its
+    # 'positive directional derivative' exit -- are left out of the comparison, not out of the product's loop)
+    usable = d['ok'].all(axis=0)
+    assert np.array_equal(P['p'], d['p0']) and np.array_equal(P['x0'], d['x0']) and usable.sum() >= {'cfg2': n, 'cfg3': 6}[cfg]
+    assert (int(d['n_var']), int(d['n_con'])) == (tpl.n_var, tpl.n_con) and d['crossed'].sum() == {'cfg2': 2, 'cfg3': 3}[cfg]
     spl, dt_s = d['spl'], float(d['sample_time'])
-    mpc = make_mpc(problem, P, dict(tol=tol, max_iter=300))
+    mpc = make_mpc(problem, P, dict(P.get('solver_options', {}), tol=tol, max_iter=300))
     mpc.solve_cold(bends=())
     assert (mpc.host('status') == 0).all()
-    parted = np.zeros(n, dtype=bool)
+    parted = ~usable
     parted_at = {}
     capped = 0
     e_state, e_input, e_rel = np.zeros((steps + 1, n)), np.zeros((steps + 1, n)), np.zeros((steps + 1, n))
@@ -98,19 +107,23 @@ def run_loop(make_mpc, tol):
     return worst, first, parted_at, np.median(e_state[-1, keep])
 
 
-def check(make_mpc, tol, who):
-    worst, first, parted_at, med = run_loop(make_mpc, tol)
-    print('\n%s closed loop, tol %g, 64 agents x 25 updates (two crossings) against SLSQP in the loop: %d agents parted from the reference '
+def check(make_mpc, tol, who, cfg='cfg2'):
+    worst, first, parted_at, med = run_loop(make_mpc, tol, cfg)
+    print('\n%s closed loop, %s, tol %g, against SLSQP in the loop: %d agents parted from the reference '
           'loop %s; the others: position %.2e m (median at the end %.1e), velocity %.2e m/s, two-sided relative %.2e (floor %.0e); after the cold '
           'solve alone: %.2e m / %.2e m/s / %.2e'
-          % ((who, tol, len(parted_at), parted_at) + (worst[0], med, worst[1], worst[2], FLOOR) + tuple(first)))
-    b = BOUNDS[tol]
-    assert len(parted_at) <= MAX_PARTED, parted_at
+          % ((who, {'cfg2': '64 Holonomic agents x 25 updates (two crossings)', 'cfg3': '8 Quadrotor agents x 12 updates (three crossings)'}[cfg],
+              tol, len(parted_at), parted_at) + (worst[0], med, worst[1], worst[2], FLOOR) + tuple(first)))
+    b = BOUNDS[tol] if cfg == 'cfg2' else BOUNDS_CFG3[tol]
+    assert len(parted_at) <= (MAX_PARTED if cfg == 'cfg2' else 1), parted_at
     assert worst[0] < b[0] and worst[1] < b[1] and worst[2] < b[2], (worst, b)
 
 
-@pytest.mark.parametrize('tol', [1e-3, 1e-6])
-def test_port_closed_loop_follows_slsqp_in_the_loop(tol):
+CASES = [('cfg2', 1e-3), ('cfg2', 1e-6), ('cfg3', 1e-3), ('cfg3', 1e-6)]
+
+
+@pytest.mark.parametrize('cfg,tol', CASES)
+def test_port_closed_loop_follows_slsqp_in_the_loop(cfg, tol):
     from omgtools.batch import BatchP2P
     from oracle import port_binding
 
@@ -118,12 +131,12 @@ def test_port_closed_loop_follows_slsqp_in_the_loop(tol):
         m = BatchP2P(problem, P, ops=port_binding, options=opts)
         m.n_threads = 8
         return m
-    check(make, tol, 'host build')
+    check(make, tol, 'host build', cfg)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tol', [1e-3, 1e-6])
-def test_hip_closed_loop_follows_slsqp_in_the_loop(tol):
+@pytest.mark.parametrize('cfg,tol', CASES)
+def test_hip_closed_loop_follows_slsqp_in_the_loop(cfg, tol):
     import torch
     from omgtools.batch import BatchP2P
     mpcs = []
@@ -132,7 +145,7 @@ def test_hip_closed_loop_follows_slsqp_in_the_loop(tol):
         mpcs.append(BatchP2P(problem, P, ops='hip', device=torch.device('cuda', 0), options=opts))
         return mpcs[-1]
     try:
-        check(make, tol, 'HIP')
+        check(make, tol, 'HIP', cfg)
     finally:
         for m in mpcs:
             m.solver.close()

@@ -28,7 +28,7 @@ def _build(n):
         be.create_nlp = saved
 
 
-def check_steps(solve_step, f_tol=1e-5, x_tol=2e-3):
+def check_steps(solve_step, f_tol=1e-5, x_tol=2e-3, tight_share=0.85, who=''):
     from oracle.nlp_numpy import NumpyNLP
     from oracle.kkt_check import assert_kkt
     d = np.load(os.path.join(HERE, 'sol_mpc_cfg2.npz'))
@@ -42,7 +42,7 @@ def check_steps(solve_step, f_tol=1e-5, x_tol=2e-3):
     L = len(veh.basis)
     o_t = tpl.entry_range(problem.label, 't', 'par')[0]
     o_T = tpl.entry_range(problem.label, 'T', 'par')[0]
-    tight, total, iters = 0, 0, []
+    tight, total, iters, worst_dx, worst_f = 0, 0, [], 0.0, 0.0
     assert d['crossed'].sum() == 1
     for k in range(steps):
         res = solve_step(tpl, d['p'][k], d['x0'][k], d['lam'][k])
@@ -52,14 +52,18 @@ def check_steps(solve_step, f_tol=1e-5, x_tol=2e-3):
             assert_kkt(nlp, tpl, d['p'][k, b], res['x'][b], res['lam_g'][b], 10 * TOL, ('mpc', k, b))
             f = nlp.fg(res['x'][b], nlp.term_coefs(d['p'][k, b]))[0]
             assert abs(f - d['f'][k, b]) < f_tol * (1 + abs(f)), (k, b, f, d['f'][k, b])
+            worst_f = max(worst_f, abs(f - d['f'][k, b]) / (1 + abs(f)))
             dx = np.abs(res['x'][b, lo:hi] - d['x'][k, b, lo:hi]).reshape(-1, L)
             b0 = veh.basis.eval_basis([d['p'][k, b, o_t] / d['p'][k, b, o_T]])[0, 0]
             if b0 < 0.05:
                 dx = dx[:, 1:]
             assert dx.max() < x_tol, (k, b, dx.max())
+            worst_dx = max(worst_dx, dx.max())
             tight += dx.max() < 1e-4
             total += 1
-    assert tight >= 0.85 * total, (tight, total)
+    print('\n%s warm steps of config 2 against SLSQP: objective within %.1e (relative), coefficients within %.1e, %d of %d (step, agent) '
+          'pairs within 1e-4' % (who, worst_f, worst_dx, tight, total))
+    assert tight >= tight_share * total, (tight, total)
     # these are warm starts: a handful of iterations (a cold solve of this class at 1e-6 takes about sixty)
     assert np.mean(iters) < 15, iters
     return tight, total
@@ -70,7 +74,10 @@ def check_steps(solve_step, f_tol=1e-5, x_tol=2e-3):
 # as the complementarity is at the tolerance, a few barrier updates earlier: the objective then carries a gap of the order
 # (active rows) x mu, 1.7e-5 at most here, and the coefficients on a nearly flat face move with it: 2.6e-3 at most on the
 # HIP path, 6e-4 on the host build, in the same number of iterations: rounding decides where on the face a solve ends)
-FACTORS = [(0.0, 1e-5, 2e-3), (0.1, 3e-5, 4e-3)]
+# (round 5: thresholds tightened to twice what is achieved -- host build: objective 3.1e-6 / 1.8e-5, coefficients 5.9e-4 / 6.0e-4, 94 % of the
+# pairs within 1e-4; the HIP path ends some solves elsewhere on a flat face: its own bounds below)
+FACTORS = [(0.0, 1e-5, 1.2e-3), (0.1, 3e-5, 1.2e-3)]
+FACTORS_HIP = [(0.0, 1e-5, 2e-3), (0.1, 3e-5, 4e-3)]
 
 
 @pytest.mark.parametrize('factor,f_tol,x_tol', FACTORS)
@@ -80,11 +87,11 @@ def test_port_warm_steps_match_slsqp(factor, f_tol, x_tol):
     def solve_step(tpl, p, x0, lam):
         return port_binding.solve(tpl, p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32), warm_start=1,
                                   n_threads=8, tol=TOL, max_iter=500, warm_mu_factor=factor, warm_z_floor=0.1, warm_z_cap=0.0)
-    check_steps(solve_step, f_tol, x_tol)
+    check_steps(solve_step, f_tol, x_tol, 0.90, 'host build,')
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('factor,f_tol,x_tol', FACTORS)
+@pytest.mark.parametrize('factor,f_tol,x_tol', FACTORS_HIP)
 def test_hip_warm_steps_match_slsqp(factor, f_tol, x_tol):
     from omgtools.backend import BatchSolver
     solver = {}
@@ -94,7 +101,7 @@ def test_hip_warm_steps_match_slsqp(factor, f_tol, x_tol):
             solver['s'] = BatchSolver(tpl, len(p), options=dict(tol=TOL, max_iter=500, warm_start=1, warm_mu_factor=factor, warm_z_floor=0.1, warm_z_cap=0.0))
         return solver['s'].solve(p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32))
     try:
-        check_steps(solve_step, f_tol, x_tol)
+        check_steps(solve_step, f_tol, x_tol, 0.85, 'HIP,')
     finally:
         if 's' in solver:
             solver['s'].close()
