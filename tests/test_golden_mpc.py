@@ -3,8 +3,8 @@ tests/golden/generate_multistart.py): 8 agents of config 2, 12 steps with one kn
 -- parameters p_k (predicted state, time since the last knot), the shifted plan x0_k, the shifted multipliers lam_k --
 were dumped from a host run of the protocol; the NLP of every step was solved by scipy SLSQP from x0_k.  Here every
 step is solved again, warm-started from the dumped inputs the way `BatchP2P.step` does it, and must return SLSQP's
-solution: objective to 1e-5 relative, spline coefficients to 1e-4 for at least 85 % of the (step, agent) pairs and
-to 2e-3 for all -- but for the leading coefficient while the initial-condition rows no longer hold it (B_0(t0) < 0.05
+solution: objective to 1e-5 relative, spline coefficients to 1e-4 for at least 90 % of the (step, agent) pairs and
+to 1.2e-3 for all (round 5: twice what both tiers achieve, 6e-4 and 94 %) -- but for the leading coefficient while the initial-condition rows no longer hold it (B_0(t0) < 0.05
 just before a crossing: it floats on a flat face and only shapes the piece of the plan that was already travelled).
 
 CPU tier: host build of the kernel source; GPU tier: the HIP path through the C ABI."""
@@ -77,7 +77,7 @@ def check_steps(solve_step, f_tol=1e-5, x_tol=2e-3, tight_share=0.85, who=''):
 # (round 5: thresholds tightened to twice what is achieved -- host build: objective 3.1e-6 / 1.8e-5, coefficients 5.9e-4 / 6.0e-4, 94 % of the
 # pairs within 1e-4; the HIP path ends some solves elsewhere on a flat face: its own bounds below)
 FACTORS = [(0.0, 1e-5, 1.2e-3), (0.1, 3e-5, 1.2e-3)]
-FACTORS_HIP = [(0.0, 1e-5, 2e-3), (0.1, 3e-5, 4e-3)]
+FACTORS_HIP = [(0.0, 1e-5, 1.2e-3), (0.1, 4.5e-5, 1.2e-3)]      # (HIP achieves 5.9e-4 / 6.0e-4 like the host build; objective 3.1e-6 / 2.1e-5)
 
 
 @pytest.mark.parametrize('factor,f_tol,x_tol', FACTORS)
@@ -101,7 +101,7 @@ def test_hip_warm_steps_match_slsqp(factor, f_tol, x_tol):
             solver['s'] = BatchSolver(tpl, len(p), options=dict(tol=TOL, max_iter=500, warm_start=1, warm_mu_factor=factor, warm_z_floor=0.1, warm_z_cap=0.0))
         return solver['s'].solve(p, x0, lam_g0=lam, status0=np.zeros(len(p), dtype=np.int32))
     try:
-        check_steps(solve_step, f_tol, x_tol, 0.85, 'HIP,')
+        check_steps(solve_step, f_tol, x_tol, 0.90, 'HIP,')
     finally:
         if 's' in solver:
             solver['s'].close()
