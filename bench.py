@@ -350,8 +350,8 @@ def rollout_leg(mpc, x0_init, p_init, n_steps, warmup, dev):
 
 
 def stepwise_leg(problem, P, opts, n_steps, warmup, dev, n_streams):
-    """The headline protocol on the OTHER form of the per-step path (one handle when the headline runs two half-launches per
-    step, and the other way round): wall time between host syncs, solved agents counted per step by the solve kernels
+    """The headline protocol on the OTHER form of the per-step path (one handle when the headline runs sub-batch launches, and
+    two sub-batches otherwise): wall time between host syncs, solved agents counted per step by the solve kernels
     (`omgx_batch_set_stats` on every handle)."""
     from omgtools.batch import StreamedP2P, receding_horizon_batch
     B = P['p'].shape[0]
@@ -788,7 +788,7 @@ def main():
     solver.set_timing(False)
     # ---- receding-horizon steps: SURVEY.md 8d protocol (cold solve, then warm-started steps) ----
     # THE PER-STEP PRODUCT PATH (`receding_horizon_batch`): one handle, or -- for a batch of at least two rounds of resident
-    # workgroups, the headline's 1024 agents on 512 slots -- two stream-ordered half-launches per step (round 5; per agent the
+    # workgroups, the headline's 1024 agents on 512 slots -- three stream-ordered sub-batch launches per step (round 5; per agent the
     # same launches and bits as the single handle, tests/test_gpu_rollout.py).  `--streams 1` forces the single handle.
     rh = receding_horizon_batch(problem, P, device=dev, n_streams='auto' if args.streams == 0 else args.streams, options=opts)
     parts = rh.parts if isinstance(rh, StreamedP2P) else [rh]
@@ -843,7 +843,7 @@ def main():
     stats[:, 2] = np.max([sd.cpu().numpy()[:, 2] for sd in stats_d], axis=0)
     assert (stats[:, 3] == B).all()
     # launch intervals on the device clock (ms since ev_base): what the solve kernels occupied the chip for is the UNION of
-    # the intervals (two half-launches of one step, and the next step of one half, overlap)
+    # the intervals (the sub-batch launches of one step, and the next step of a sub-batch, overlap)
     spans = [[(ev_base.elapsed_time(a), ev_base.elapsed_time(b)) for a, b in row] for row in ev[W:]]
 
     def union_ms(iv):
@@ -888,8 +888,8 @@ def main():
                                   args.knot_intervals, args.obstacles, args.tol),
                    'agents_per_gpu': B, 'agents_total': n_total, 'n_var': tpl.n_var, 'n_con': tpl.n_con,
                    'launches_per_step': n_parts,
-                   'step_form': ('two stream-ordered half-launches per step (omgtools.batch.receding_horizon_batch: the batch is two '
-                                 'rounds of resident workgroups)' if n_parts > 1 else 'one launch per step'),
+                   'step_form': ('%d stream-ordered sub-batch launches per step (omgtools.batch.receding_horizon_batch: the batch is two '
+                                 'rounds of resident workgroups)' % n_parts if n_parts > 1 else 'one launch per step'),
                    'parallelism': 'agents sharded across ranks, no collective on the solve path'},
         'p50_batch_latency_ms': float(np.median(step_latency_ms)), 'max_batch_latency_ms': float(np.max(step_latency_ms)),
         'max_iters_in_a_step': int(stats[:, 2].max()), 'host_enqueue_ms_per_step': t_host / K * 1e3,
@@ -918,8 +918,8 @@ def main():
                                       'achieved': launches_iters * flops_per_iter / (sum(launches_ms) * 1e-3) / 1e12},
                      'note': 'algorithmic flops = sum(iters) x (n^3/3+2n^2), n=n_var (SURVEY 8d).  kernel_ms = chip time of the solve '
                              'kernels per timed step = UNION of the launch intervals (dispatch stamps of every launch, on the '
-                             'stream it runs on) / steps: with two half-launches per step the launches overlap each other and the '
-                             'next step of the other half, so the sum of the launch durations (launch_ms_mean x launches) exceeds '
+                             'stream it runs on) / steps: with sub-batch launches the launches of a step overlap each other and the '
+                             'next step of the other sub-batches, so the sum of the launch durations (launch_ms_mean x launches) exceeds '
                              'it; all_launches = every launch of this process (cold solves + warm-up + timed steps, the set '
                              'rocprofv3 --stats averages: its mean_ms is per launch; its `achieved` divides by the SUM of the '
                              'durations and is a lower bound when launches overlap).  traffic: from the committed PMC passes '

@@ -375,20 +375,21 @@ class StreamedP2P(object):
         import torch
         self.torch = torch
         B = P['p'].shape[0]
-        if n_streams < 1 or B % n_streams:
-            raise ValueError('%d agents do not split into %d equal sub-batches' % (B, n_streams))
-        n = B // n_streams
+        if n_streams < 1 or n_streams > B:
+            raise ValueError('%d agents do not split into %d sub-batches' % (B, n_streams))
+        from .distributed import shard_range
+        self.bounds = [shard_range(B, s, n_streams) for s in range(n_streams)]       # contiguous blocks, sizes differ by at most one
         self.dev = device if device is not None else torch.device('cuda', 0)
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(n_streams)]
         self.parts = []
         # (the caller's stream may still be writing what the sub-batches read, and the other way round at the end)
         ready = torch.cuda.current_stream(self.dev).record_event()
-        for s, st in enumerate(self.streams):
-            Ps = dict(P, p=P['p'][s * n:(s + 1) * n], x0=P['x0'][s * n:(s + 1) * n])
+        for (lo, hi), st in zip(self.bounds, self.streams):
+            Ps = dict(P, p=P['p'][lo:hi], x0=P['x0'][lo:hi])
             st.wait_event(ready)
             with torch.cuda.stream(st):
                 self.parts.append(BatchP2P(problem, Ps, ops='hip', device=self.dev, **kw))
-        self.B, self.n_sub = B, n
+        self.B = B
         self.kind = 'hip'
         self.tpl, self.problem = self.parts[0].tpl, problem
 
@@ -447,13 +448,12 @@ class StreamedP2P(object):
     def load(self, x=None, p=None):
         """x / p of the whole batch -> the sub-batches (device tensors [B, *]), ordered behind the caller's stream."""
         self.fork()
-        n = self.n_sub
-        for k, (m, st) in enumerate(zip(self.parts, self.streams)):
+        for (lo, hi), m, st in zip(self.bounds, self.parts, self.streams):
             with self.torch.cuda.stream(st):
                 if x is not None:
-                    m.x.copy_(x[k * n:(k + 1) * n])
+                    m.x.copy_(x[lo:hi])
                 if p is not None:
-                    m.p.copy_(p[k * n:(k + 1) * n])
+                    m.p.copy_(p[lo:hi])
 
     x = property(lambda self: self.gather('x'))
     p = property(lambda self: self.gather('p'))
@@ -470,20 +470,26 @@ class StreamedP2P(object):
             m.solver.close()
 
 
+# Sub-batches of the per-step product path.  Three: the HIP runtime maps streams onto four hardware queues, the caller's stream
+# takes one; a fourth sub-batch shares a queue with another one and serialises behind it (1.41 M solves/s against 2.16 M with
+# two and 2.20-2.26 M with three on the 1024-agent batch; five: 1.43 M, six: 1.11 M).
+PRODUCT_PATH_STREAMS = 3
+
+
 def receding_horizon_batch(problem, P, device=None, n_streams='auto', **kw):
     """The per-step product path for a batch of independent agents: a `BatchP2P`, or -- when the batch is at least two rounds
-    of resident workgroups (1024 agents of config 2 on 512 slots) -- the same batch as two stream-ordered half-launches
-    (`StreamedP2P`): a step of the whole batch is quantised in rounds of the resident workgroups and one straggler costs the
-    batch a whole extra round; with two halves on two streams the next step of one half fills the slots the
-    other half's straggler leaves idle.  Per agent the same launches, the same bits."""
+    of resident workgroups (1024 agents of config 2 on 512 slots) -- the same batch as `PRODUCT_PATH_STREAMS` stream-ordered
+    sub-batch launches per step (`StreamedP2P`): a step of the whole batch is quantised in rounds of the resident workgroups and
+    one straggler costs the batch a whole extra round; with the sub-batches on their own streams the next step
+    of one fills the slots the stragglers of the others leave idle.  Per agent the same launches, the same bits."""
     import torch
     dev = device if device is not None else torch.device('cuda', 0)
     B = P['p'].shape[0]
     if n_streams == 'auto' or n_streams <= 1:
         whole = BatchP2P(problem, P, ops='hip', device=dev, **kw)
         # (the launch grid of the handle = the workgroups the chip holds at once, capped at the batch)
-        if n_streams != 'auto' or B % 2 or B < 2 * whole.solver.workspace()['n_slabs']:
+        if n_streams != 'auto' or B < 2 * whole.solver.workspace()['n_slabs']:
             return whole
         whole.solver.close()
-        n_streams = 2
+        n_streams = PRODUCT_PATH_STREAMS
     return StreamedP2P(problem, P, n_streams=n_streams, device=dev, **kw)
