@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define OMGX_VERSION 6
+#define OMGX_VERSION 7
 #define OMGX_TERM_VARS 4      /* variables per term (version 3: three) */
 
 /* error codes */
@@ -101,6 +101,16 @@ typedef struct omgx_template {
   int32_t has_bounds;
   const double* lbg_def;            /* [n_con] */
   const double* ubg_def;            /* [n_con] */
+  /* (version 7) Lifted products and quotients: the LAST n_lift variables are auxiliary variables, the LAST n_lift rows their
+   * defining equalities (row n_con - n_lift + k: linear in variable n_var - n_lift + k, whose coefficient there may be a
+   * polynomial in other variables -- a quotient by a variable --, and otherwise a function of the caller's variables and of
+   * auxiliaries with smaller k only).  The front end writes a product of more than OMGX_TERM_VARS variable factors or a
+   * quotient by a variable expression this way (the vehicle models of `vehicles/bicycle.py:53`, `agv.py:50`, `trailer.py:28`,
+   * the free end time of `examples/p2p_dubins.py`).  The solver keeps these rows satisfied exactly: every trial point of its line
+   * search takes the auxiliaries from their defining rows (the Newton direction is the lifted system's, the iterates those of
+   * the caller's own problem).  0: none.  lift_row0: the first of the defining rows (a front end puts them last:
+   * n_con - n_lift). */
+  int32_t n_lift, lift_row0;
 } omgx_template;
 
 #define OMGX_BLOCK_VAR 0

@@ -183,7 +183,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   omgx::Work w;
     omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
                                d, kkt_doubles);
-  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_kkt_hbm(MODE), GEN> c; c.red = w.red;
+  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_root_lds(MODE), GEN> c; c.red = w.red;
 #ifdef OMGX_PROFILE
   __shared__ long long prof_lds[omgx::PH_COUNT];
   c.prof = prof_lds;
@@ -298,7 +298,7 @@ ipm_eval_kernel(omgx::Dims d, omgx::Tables T, int kkt_doubles, const double* __r
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
                                d, kkt_doubles);
-  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_kkt_hbm(MODE), GEN> c; c.red = w.red; c.prof = nullptr;
+  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_root_lds(MODE), GEN> c; c.red = w.red; c.prof = nullptr;
   const size_t stride = (size_t)d.n_con + 1 + d.nnz_j + kkt_doubles;
   for (int b = blockIdx.x; b < n_agents; b += gridDim.x) {
     double* o = out + (size_t)b * stride;
@@ -324,6 +324,7 @@ static ipm_eval_kernel_t ipm_eval_kernel_gen(int mode, int wave_ok) {
     case omgx::WS_JAC_HBM: return ipm_eval_kernel<omgx::WS_JAC_HBM, false, GEN>;
     case omgx::WS_JAC_ONLY: return ipm_eval_kernel<omgx::WS_JAC_ONLY, true, GEN>;
     case omgx::WS_JAC_HV: return ipm_eval_kernel<omgx::WS_JAC_HV, true, GEN>;
+    case omgx::WS_ROOT_HBM: return ipm_eval_kernel<omgx::WS_ROOT_HBM, false, true>;      // (one instance: the general one serves every template)
     default: return ipm_eval_kernel<omgx::WS_ROWS_HBM, false, GEN>;
   }
 #endif
@@ -348,6 +349,7 @@ static ipm_kernel_t ipm_kernel_gen(int mode, int wave_ok) {
     case omgx::WS_JAC_HBM: return ipm_solve_kernel<omgx::WS_JAC_HBM, false, GEN>;
     case omgx::WS_JAC_ONLY: return ipm_solve_kernel<omgx::WS_JAC_ONLY, true, GEN>;
     case omgx::WS_JAC_HV: return ipm_solve_kernel<omgx::WS_JAC_HV, true, GEN>;
+    case omgx::WS_ROOT_HBM: return ipm_solve_kernel<omgx::WS_ROOT_HBM, false, true>;
     default: return ipm_solve_kernel<omgx::WS_ROWS_HBM, false, GEN>;
   }
 #endif
@@ -615,7 +617,7 @@ ipm_rollout_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles, 
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
   omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles, d, kkt_doubles);
-  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_kkt_hbm(MODE), GEN> c; c.red = w.red;
+  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_root_lds(MODE), GEN> c; c.red = w.red;
   c.prof = nullptr;
   __shared__ int slot_lds;
   if (stagger > 0 && (__builtin_amdgcn_s_getreg(6148) & 1))
@@ -952,7 +954,10 @@ int pick_mode(const omgx::Dims& d, int kkt_doubles, size_t* lds_doubles, size_t*
     omgx::work_split(d, kkt_doubles, mode, lds_doubles, hbm_doubles);
     if (*lds_doubles * sizeof(double) <= (size_t)kLdsLimit) break;
   }
-  return mode <= omgx::WS_ROWS_HBM ? mode : omgx::WS_MODES;
+  if (mode <= omgx::WS_ROWS_HBM) return mode;
+  // the root block alone is too large for LDS: it stays in the slab (mode 6)
+  omgx::work_split(d, kkt_doubles, omgx::WS_ROOT_HBM, lds_doubles, hbm_doubles);
+  return *lds_doubles * sizeof(double) <= (size_t)kLdsLimit ? (int)omgx::WS_ROOT_HBM : (int)omgx::WS_MODES;
 }
 
 // The plan of a template for the workspace mode it gets: the spill modes store the leaf panels by columns
@@ -1020,6 +1025,7 @@ int check_template(const omgx_template* t) {
   if (!t || t->n_var <= 0 || t->n_par < 0 || t->n_con < 0 || t->n_terms < 0 || t->n_eq < 0 || t->n_root_vars < 0 ||
       !t->row_ptr || (t->n_terms > 0 && (!t->t_coef || !t->t_slot || !t->t_var)) || (t->n_eq > 0 && !t->eq_rows) ||
       (t->n_root_vars > 0 && !t->root_vars)) { g_err = "bad template"; return OMGX_E_INVALID; }
+  if (t->n_lift < 0 || (t->n_lift > 0 && (t->n_lift > t->n_var || t->lift_row0 < 0 || t->lift_row0 + t->n_lift > t->n_con))) { g_err = "bad template: lifted rows outside the template"; return OMGX_E_INVALID; }
   // the block table (optional): every entry inside its flat vector -- callers fill p / x0 and read x through these offsets
   // (`Point2Point::fillParameterDict / extractData`, export/point2point/Point2Point.cpp:263-294)
   if (t->n_blocks > 0) {
@@ -1172,6 +1178,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   UP(jv_ell, plan.jv_ell.size()); UP(jv_own, plan.jv_own.size()); UP(jv_glen, plan.jv_glen.size());
   UP(ja_ell, plan.ja_ell.size()); UP(ja_own, plan.ja_own.size()); UP(ja_glen, plan.ja_glen.size());
   UP(sl_list, plan.sl_list.size()); UP(sl_glen, plan.sl_glen.size());
+  UP(lift_rec, plan.lift_rec.size()); UP(lift_lev, plan.lift_lev.size());
   return OMGX_OK;
 }
 
@@ -1225,7 +1232,8 @@ int omgx_plan_describe(const omgx_template* tpl, omgx_plan_info* info, int32_t* 
 // (omgtools.backend.save_template) once per problem class and read by C/C++ callers -- the role the
 // generated nlp.so plays for the reference's C++ export (`export/export.py:236-262`, loaded in
 // `Point2Point.cpp:80-91`).  Layout: "OMGXTPL4", 16 int32 counts (the last three: block-table entries, the length of
-// their names, whether default bounds follow), then the arrays in struct order, the block table last ("OMGXTPL3" files -- three variables per term -- and "OMGXTPL2" files -- 13 counts, no table -- are still read).
+// their names, whether default bounds follow; "OMGXTPL5", written for templates with lifted auxiliaries: 18 counts, + n_lift and
+// lift_row0), then the arrays in struct order, the block table last ("OMGXTPL3" files -- three variables per term -- and "OMGXTPL2" files -- 13 counts, no table -- are still read).
 namespace {
 struct TplField { int kind; size_t count; const void* const* src; void** dst; };     // kind 0 int32, 1 double, 2 char
 
@@ -1252,10 +1260,12 @@ int omgx_template_write(const omgx_template* tpl, const char* path) {
   if (!path) { g_err = "null path"; return OMGX_E_INVALID; }
   FILE* fp = fopen(path, "wb");
   if (!fp) { g_err = std::string("cannot write ") + path; return OMGX_E_INVALID; }
-  const int32_t counts[16] = {tpl->n_var, tpl->n_par, tpl->n_con, tpl->n_atoms, tpl->n_slots, tpl->n_terms, tpl->n_prog,
+  const int32_t counts[18] = {tpl->n_var, tpl->n_par, tpl->n_con, tpl->n_atoms, tpl->n_slots, tpl->n_terms, tpl->n_prog,
                               tpl->n_knots, tpl->n_pp, tpl->n_mono, tpl->n_matom, tpl->n_eq, tpl->n_root_vars,
-                              tpl->n_blocks, tpl->block_names_len, tpl->has_bounds ? 1 : 0};
-  bool ok = fwrite("OMGXTPL4", 1, 8, fp) == 8 && fwrite(counts, sizeof(int32_t), 16, fp) == 16;
+                              tpl->n_blocks, tpl->block_names_len, tpl->has_bounds ? 1 : 0, tpl->n_lift, tpl->lift_row0};
+  // (a template without lifted auxiliaries is written as before: "OMGXTPL4", 16 counts)
+  const bool v5 = tpl->n_lift > 0;
+  bool ok = fwrite(v5 ? "OMGXTPL5" : "OMGXTPL4", 1, 8, fp) == 8 && fwrite(counts, sizeof(int32_t), v5 ? 18 : 16, fp) == (size_t)(v5 ? 18 : 16);
   TplField f[24];
   const size_t nf = tpl_fields(*tpl, nullptr, f);
   for (size_t i = 0; i < nf && ok; ++i) {
@@ -1281,20 +1291,21 @@ int omgx_template_read(const char* path, omgx_template** out) {
   FILE* fp = fopen(path, "rb");
   if (!fp) { g_err = std::string("cannot read ") + path; return OMGX_E_INVALID; }
   char magic[8];
-  int32_t c[16] = {0};
+  int32_t c[18] = {0};
   const bool head = fread(magic, 1, 8, fp) == 8;
-  const int file_version = !head ? 0 : (memcmp(magic, "OMGXTPL4", 8) == 0 ? 4 : (memcmp(magic, "OMGXTPL3", 8) == 0 ? 3 : (memcmp(magic, "OMGXTPL2", 8) == 0 ? 2 : 0)));
-  const int n_counts = file_version >= 3 ? 16 : (file_version == 2 ? 13 : 0);
+  const int file_version = !head ? 0 : (memcmp(magic, "OMGXTPL5", 8) == 0 ? 5 : (memcmp(magic, "OMGXTPL4", 8) == 0 ? 4 : (memcmp(magic, "OMGXTPL3", 8) == 0 ? 3 : (memcmp(magic, "OMGXTPL2", 8) == 0 ? 2 : 0))));
+  const int n_counts = file_version >= 5 ? 18 : (file_version >= 3 ? 16 : (file_version == 2 ? 13 : 0));
   const int file_tv = file_version >= 4 ? OMGX_TERM_VARS : 3;
   if (n_counts == 0 || fread(c, sizeof(int32_t), n_counts, fp) != (size_t)n_counts) {
     fclose(fp); g_err = std::string(path) + " is not an omgx template file"; return OMGX_E_INVALID;
   }
-  for (int i = 0; i < 16; ++i) if (c[i] < 0 || c[i] > (1 << 26)) { fclose(fp); g_err = "template file: bad counts"; return OMGX_E_INVALID; }
+  for (int i = 0; i < 18; ++i) if (c[i] < 0 || c[i] > (1 << 26)) { fclose(fp); g_err = "template file: bad counts"; return OMGX_E_INVALID; }
   omgx_template* t = (omgx_template*)calloc(1, sizeof(omgx_template));
   if (!t) { fclose(fp); g_err = "out of memory"; return OMGX_E_INVALID; }
   t->n_var = c[0]; t->n_par = c[1]; t->n_con = c[2]; t->n_atoms = c[3]; t->n_slots = c[4]; t->n_terms = c[5]; t->n_prog = c[6];
   t->n_knots = c[7]; t->n_pp = c[8]; t->n_mono = c[9]; t->n_matom = c[10]; t->n_eq = c[11]; t->n_root_vars = c[12];
   t->n_blocks = c[13]; t->block_names_len = c[14]; t->has_bounds = c[15];
+  t->n_lift = c[16]; t->lift_row0 = c[17];
   TplField f[24];
   const size_t nf = tpl_fields(*t, t, f, file_tv);
   bool ok = true;

@@ -53,6 +53,7 @@ struct Dims {
   int n_eqe;    // Jacobian entries of the equality rows
   int max_leaf, max_cpl;
   int col_doubles;   // scratch for the blocked LDL' (staging + panel buffers)
+  int col_small_noroot;   // col_small without the LDS copy of the root block (mode 6)
   int col_small;     // the same for the spill modes (left-looking leaf sweep only: inverse pivots + parked diagonal blocks per leaf): kept in LDS there
   int mono_packed;   // 1: every parameter monomial has <= 4 atoms, Tables::pm_rec / sl_ell hold MonoRec; 2: <= 8 atoms, MonoRec8; 0: CSR tables only
   int n_long;        // slots with more than OMGX_SLOT_CAP monomials (the first n_long entries of Tables::sl_list)
@@ -72,6 +73,7 @@ struct Dims {
   int n_cs_own;      // owner threads of the column sums J'w (chunks of the columns)
   int kg_side_dinv;  // 1: the side sums of the Gershgorin pass live in w.dinv, 0: in the side slots behind the KKT store
   int n_owner;       // owner bins in use (<= OMGX_NBIN, the stride of the record tables): the threads of the workgroup the plan was made for
+  int n_lift, lift_depth;   // auxiliary variables of lifted products / quotients (omgx_template::n_lift) and the length of their longest chain
 };
 
 // one parameter monomial coef * prod atoms[a_k] as a single 16-byte record (a_k = -1: unused): one
@@ -140,6 +142,9 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* sl_list;   // [n_slots] slots by decreasing monomial count
   const MonoRec* sl_ell;    // [sl_steps][n_slots] monomials of slot sl_list[i] (padding: coef 0)
   const int32_t* sl_glen;
+  // lifted auxiliaries (Dims::n_lift), level by level: lift_rec[k] = {ELL slot of the defining row, the auxiliary variable}; the records of
+  // level L (rows that read auxiliaries of the levels below only) are lift_lev[L] .. lift_lev[L + 1]
+  const int32_t* lift_rec; const int32_t* lift_lev;
   const int32_t* cs_ptr;    // [n_var + 1] column (position) -> its entries, row order
   const int32_t* cs_rec;    // [.][2] {Jacobian entry, row}
   const int32_t* obj_ent;   // [n_var] objective-row entry of the position (-1: none)
@@ -259,11 +264,15 @@ struct Work {
 // (compact) KKT store and every array the owner passes gather from in LDS.
 // Mode 5 (round 4) is mode 4 with the row values hv back in LDS, for templates that still fit half a CU then (config 2: 80,280 B):
 // hv is read by a dozen row passes per iteration, each a dependent global load per pass of the workgroup (+2 % solves/s).
-enum { WS_LDS = 0, WS_KKT_HBM = 1, WS_JAC_HBM = 2, WS_ROWS_HBM = 3, WS_JAC_ONLY = 4, WS_JAC_HV = 5, WS_MODES = 6 };
-OMGX_HD constexpr bool ws_kkt_hbm(int mode) { return mode >= WS_KKT_HBM && mode <= WS_ROWS_HBM; }
+// Mode 6 (round 5) is mode 3 with the root block left in the slab as well: templates whose root block (its variables + ALL
+// equality rows: the classes with lifted auxiliaries carry hundreds, include/omgx.h n_lift) does not fit LDS even alone
+// (Bicycle: order 439 = 773 KB).  Only the O(n_var) vectors, the descriptors and the panel buffers stay on chip.
+enum { WS_LDS = 0, WS_KKT_HBM = 1, WS_JAC_HBM = 2, WS_ROWS_HBM = 3, WS_JAC_ONLY = 4, WS_JAC_HV = 5, WS_ROOT_HBM = 6, WS_MODES = 7 };
+OMGX_HD constexpr bool ws_kkt_hbm(int mode) { return (mode >= WS_KKT_HBM && mode <= WS_ROWS_HBM) || mode == WS_ROOT_HBM; }
 OMGX_HD constexpr bool ws_jac_hbm(int mode) { return mode >= WS_JAC_HBM; }
-OMGX_HD constexpr bool ws_rows_hbm(int mode) { return mode == WS_ROWS_HBM; }
-OMGX_HD constexpr bool ws_hv_hbm(int mode) { return mode == WS_ROWS_HBM || mode == WS_JAC_ONLY; }
+OMGX_HD constexpr bool ws_rows_hbm(int mode) { return mode == WS_ROWS_HBM || mode == WS_ROOT_HBM; }
+OMGX_HD constexpr bool ws_hv_hbm(int mode) { return mode == WS_ROWS_HBM || mode == WS_JAC_ONLY || mode == WS_ROOT_HBM; }
+OMGX_HD constexpr bool ws_root_lds(int mode) { return ws_kkt_hbm(mode) && mode != WS_ROOT_HBM; }      // spill modes 1-3: the root block is copied to LDS for its factorisation
 
 OMGX_HD size_t root_doubles(const Dims& d) { return ((size_t)(d.nr + 1) * (d.nr + 2)) / 2; }
 
@@ -280,7 +289,7 @@ OMGX_HD void work_split(const Dims& d, int kkt_doubles, int mode, size_t* lds, s
   (ws_jac_hbm(mode) ? ng : nl) += d.nnz_j + 1;        // + one slot that stays 0.0 (padding records point at it)
   // (the spill modes keep the matrix descriptors and the small panel scratch of the leaf sweep in LDS: every row of
   // every block column reads them)
-  if (ws_kkt_hbm(mode)) { ng += (size_t)kkt_doubles; nl += d.col_small; } else nl += (size_t)kkt_doubles + d.col_doubles;
+  if (ws_kkt_hbm(mode)) { ng += (size_t)kkt_doubles; nl += ws_root_lds(mode) ? d.col_small : d.col_small_noroot; } else nl += (size_t)kkt_doubles + d.col_doubles;
   *lds = nl; *hbm = ng;
 }
 
@@ -313,11 +322,11 @@ OMGX_HD void work_carve_split(Work& w, double* lds, double* hbm, const Dims& d, 
   }
   if (ws_hv_hbm(MODE)) { w.hv = g; g += d.n_con; } else { w.hv = p; p += d.n_con; }
   if (ws_jac_hbm(MODE)) { w.jval = g; g += d.nnz_j + 1; } else { w.jval = p; p += d.nnz_j + 1; }
-  if (ws_kkt_hbm(MODE)) { w.kkt = g; g += kkt_doubles; w.col = p; p += d.col_small; }
+  if (ws_kkt_hbm(MODE)) { w.kkt = g; g += kkt_doubles; w.col = p; p += ws_root_lds(MODE) ? d.col_small : d.col_small_noroot; }
   else { w.kkt = p; p += kkt_doubles; w.col = p; p += d.col_doubles; }
   // spill modes: the root block is copied behind the root's panel buffer before the Schur updates -- over the leaf
   // sweep's scratch, which is dead by then (Dims::col_small covers both)
-  w.root = ws_kkt_hbm(MODE) ? w.col + (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + OMGX_PAN_LD * (d.nr + 1) : nullptr;
+  w.root = ws_root_lds(MODE) ? w.col + (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + OMGX_PAN_LD * (d.nr + 1) : nullptr;
 }
 
 OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
@@ -774,6 +783,30 @@ OMGX_FN double row_value_ell_t(const Tables& T, const Work& w, int i, int m, con
 template <class C>
 OMGX_FN double row_value_ell(const Dims& d, const Tables& T, const Work& w, int i, int m, const double* xv) {
   return row_value_ell_t<C::general>(T, w, i, m, xv);
+}
+
+// Lifted auxiliaries (omgx_template::n_lift: products of more than four variable factors, quotients by a variable) follow the
+// caller's variables: at xv every auxiliary takes the value its defining row gives it -- the row is linear in it: its values
+// with the auxiliary at 0 and at 1 --, level by level (a row reads auxiliaries of lower levels only; its owner is the only
+// thread that touches its auxiliary).  Applied to every trial point of the line search: the defining rows then hold exactly at
+// every iterate, the merit function is the one of the caller's own problem and no step is cut for what a product moves beyond
+// its linearisation (with the rows left to the Newton iteration the l1 penalty on 200 bilinear rows rejected every step
+// longer than 2e-3 on the Bicycle class of `vehicles/bicycle.py:53`).  Ends with a barrier when there is anything to do.
+template <class C>
+OMGX_FN void lift_project(const C& c, const Dims& d, const Tables& T, const Work& w, int m, double* xv) {
+  if (d.n_lift == 0) return;
+  for (int L = 0; L < d.lift_depth; ++L) {
+    const int k0 = T.lift_lev[L], k1 = T.lift_lev[L + 1];
+    OMGX_PFOR(kk, k1 - k0) {
+      const int32_t* q = T.lift_rec + 2 * (k0 + kk);
+      xv[q[1]] = 0.0;
+      const double g0 = row_value_ell<C>(d, T, w, q[0], m, xv);
+      xv[q[1]] = 1.0;
+      const double g1 = row_value_ell<C>(d, T, w, q[0], m, xv);
+      xv[q[1]] = -g0 / (g1 - g0);
+    }
+    c.sync();
+  }
 }
 
 // this thread's share of row r (terms strided over the workgroup); the caller sums the shares
@@ -2782,6 +2815,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       if (soc == 1) { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + (alpha * w.sol[q] + w.gbar[q]); } }
       else { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + alpha * w.sol[q]; } }
       c.sync();
+      if constexpr (C::general) lift_project(c, d, T, w, m, w.xt);
       tt = use_t ? c.uni(w.xt[n]) : 0.0;
       // row values at the trial point: one thread per row (long rows first), terms in table order
       double smin = 1e300, lnst = 0.0, rEt = 0.0;

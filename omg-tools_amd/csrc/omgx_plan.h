@@ -53,6 +53,7 @@ struct HostPlan {
   std::vector<int32_t> ja_own, jv_own, ja_glen, sl_list, sl_glen;
   std::vector<int32_t> rt_glen, jp_ell, jp_glen, cs_ell, cs_glen, cs_col, cs_own, jv_glen;
   std::vector<HItem> kh_rec, kg_rec;
+  std::vector<int32_t> lift_rec, lift_lev;
   std::string error;
 
   bool fail(const char* msg) { error = msg; return false; }
@@ -339,6 +340,7 @@ struct HostPlan {
       int small = 0;
       for (int l = 0; l < d.n_leaf; ++l) small += OMGX_PAN_SMALL(leaf_off[l + 1] - leaf_off[l]);
       // the root's panel buffer starts at the same offset, followed by the LDS copy of the root block (Work::root)
+      { const int rootpan = OMGX_PAN_LD * (d.nr + 1); d.col_small_noroot = (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + (small < rootpan ? rootpan : small); }
       { const int rootpart = OMGX_PAN_LD * (d.nr + 1) + (int)root_doubles(d); if (small < rootpart) small = rootpart; }
       d.col_small = (OMGX_BMAT_DOUBLES + OMGX_STAGE_LD) * (OMGX_MAX_LEAF + 1) + small;
     }
@@ -436,7 +438,7 @@ struct HostPlan {
     d.n_hess = (int)hrec.size();
     d.quartic = 0;
     for (int tt = 0; tt < d.n_terms; ++tt) if (t.t_var[OMGX_TV * tt + OMGX_TV - 1] >= 0) d.quartic = 1;
-    d.general = d.quartic;
+    d.general = d.quartic || t.n_lift > 0;      // (lifted auxiliaries: the general instance carries their projection)
     for (int k = 0; k < d.n_prog; ++k)
       if (t.prog[6 * k] == OP_COS || t.prog[6 * k] == OP_SIN || (t.prog[6 * k] == OP_BSPL && t.prog[6 * k + 3] > 5)) d.general = 1;
     // flat tables of the parameter stage
@@ -622,6 +624,46 @@ struct HostPlan {
         }
         T.jp_ell = jp_ell.data(); T.jp_glen = jp_glen.data();
         ell_stats("jp", m, (long)jr_ptr[m], jp_glen);
+      }
+      // lifted auxiliaries: the defining rows level by level (a row of level L reads auxiliaries of lower levels only)
+      {
+        d.n_lift = t.n_lift > 0 ? t.n_lift : 0;
+        d.lift_depth = 0;
+        lift_rec.assign(2 * (size_t)std::max(1, d.n_lift), 0);
+        lift_lev.assign(2, 0);
+        if (d.n_lift) {
+          const int v0 = d.n_var - d.n_lift, r0 = t.lift_row0;
+          if (v0 < 0 || r0 < 0 || r0 + d.n_lift > m) return fail("lifted rows outside the template");
+          std::vector<int> slot_of(m, 0), lev(d.n_lift, 0);
+          for (int i = 0; i < m; ++i) slot_of[row_perm[i]] = i;
+          for (int k = 0; k < d.n_lift; ++k) {
+            if (eq_index[r0 + k] < 0) return fail("the defining row of a lifted auxiliary is not an equality row");
+            int own = 0, lv = 0;
+            for (int tt = t.row_ptr[r0 + k]; tt < t.row_ptr[r0 + k + 1]; ++tt) {
+              int mine = 0;
+              for (int q = 0; q < OMGX_TV; ++q) {
+                const int v = t.t_var[OMGX_TV * tt + q];
+                if (v < v0) continue;
+                if (v == v0 + k) ++mine;
+                else if (v > v0 + k) return fail("a lifted row reads an auxiliary defined after it");
+                else lv = std::max(lv, lev[v - v0] + 1);
+              }
+              if (mine > 1) return fail("a lifted row is not linear in its auxiliary");
+              own += mine;
+            }
+            if (!own) return fail("a lifted row does not contain its auxiliary");
+            lev[k] = lv;
+            d.lift_depth = std::max(d.lift_depth, lv + 1);
+          }
+          lift_lev.assign(d.lift_depth + 1, 0);
+          int out = 0;
+          for (int L = 0; L < d.lift_depth; ++L) {
+            lift_lev[L] = out;
+            for (int k = 0; k < d.n_lift; ++k) if (lev[k] == L) { lift_rec[2 * out] = slot_of[r0 + k]; lift_rec[2 * out + 1] = v0 + k; ++out; }
+          }
+          lift_lev[d.lift_depth] = out;
+        }
+        T.lift_rec = lift_rec.data(); T.lift_lev = lift_lev.data();
       }
     }
     // (3) column sums J'w: entries of every column (position) in row order, objective entry apart

@@ -40,7 +40,8 @@ class CTemplate(C.Structure):
                [('n_eq', C.c_int32), ('eq_rows', _I32P), ('n_root_vars', C.c_int32), ('root_vars', _I32P)] + \
                [('n_blocks', C.c_int32), ('block_names_len', C.c_int32), ('block_names', C.c_char_p),
                 ('block_kind', _I32P), ('block_off', _I32P), ('block_rows', _I32P), ('block_cols', _I32P)] + \
-               [('has_bounds', C.c_int32), ('lbg_def', _F64P), ('ubg_def', _F64P)]
+               [('has_bounds', C.c_int32), ('lbg_def', _F64P), ('ubg_def', _F64P)] + \
+               [('n_lift', C.c_int32), ('lift_row0', C.c_int32)]
 
 
 class CPlanInfo(C.Structure):
@@ -150,6 +151,9 @@ def make_ctemplate(tpl, plan=None):
     ct.block_rows, ct.block_cols = i32(np.r_[rows, 0]), i32(np.r_[cols, 0])
     # default bounds of g (LBG_DEF / UBG_DEF of the reference's generated C++)
     ct.has_bounds, ct.lbg_def, ct.ubg_def = 1, f64(tpl.lb), f64(tpl.ub)
+    # lifted products / quotients (template.py `_append_lifted`): the last variables and rows
+    ct.n_lift = int(getattr(tpl, 'n_lift', 0))
+    ct.lift_row0 = int(getattr(tpl, 'lift_row0', tpl.n_con - ct.n_lift))
     return ct, keep
 
 
@@ -172,6 +176,21 @@ def save_template(tpl, path, lib=None):
     lib.omgx_template_write.argtypes = [C.POINTER(CTemplate), C.c_char_p]
     _check(lib, lib.omgx_template_write(C.byref(ct), os.fsencode(path)), 'omgx_template_write')
     return path
+
+
+def read_template_counts(path, lib=None):
+    """The counts of a template file as `omgx_template_read` returns them (the arrays stay in the library)."""
+    lib = lib or load_library()
+    out = C.POINTER(CTemplate)()
+    lib.omgx_template_read.argtypes = [C.c_char_p, C.POINTER(C.POINTER(CTemplate))]
+    _check(lib, lib.omgx_template_read(os.fsencode(path), C.byref(out)), 'omgx_template_read')
+    t = out.contents
+    counts = {k: int(getattr(t, k)) for k in ('n_var', 'n_par', 'n_con', 'n_atoms', 'n_slots', 'n_terms', 'n_eq', 'n_blocks',
+                                               'has_bounds', 'n_lift', 'lift_row0')}
+    lib.omgx_template_free.argtypes = [C.POINTER(CTemplate)]
+    lib.omgx_template_free.restype = None
+    lib.omgx_template_free(out)
+    return counts
 
 
 def describe_plan(tpl, lib=None):

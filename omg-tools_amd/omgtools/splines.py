@@ -496,3 +496,19 @@ def sample_splines(splines, time):
     is `omgx_batch_sample`."""
     time = np.asarray(time, dtype=float)
     return [matvec(s.basis.eval_basis(time), s.coeffs) for s in splines]
+
+
+def first_span_power_series(knots, degree):
+    """M [(degree + 1) x (degree + 1)]: B_i(u) = sum_k M[i, k] u^k on the first knot span of a clamped basis (the only functions that
+    do not vanish there are the first degree + 1), by interpolation at degree + 1 points of the span -- exact: they are polynomials
+    of that degree.  Used where a spline is evaluated at a point that depends on a variable (omgx_shim, free end time)."""
+    knots = np.asarray(knots, float)
+    basis = BSplineBasis(knots, degree)
+    inner = knots[knots > knots[0]]
+    width = float(inner[0] - knots[0])
+    u = knots[0] + width * (np.arange(degree + 1) + 0.5) / (degree + 1)
+    V = np.vander(u - knots[0], degree + 1, increasing=True)                 # V[j, k] = u_j^k
+    B = np.asarray(basis.eval_basis(u))[:, :degree + 1]                       # B[j, i] = B_i(u_j)
+    M = np.linalg.solve(V, B).T                                               # B_i(u) = sum_k M[i, k] (u - knots[0])^k
+    M[np.abs(M) < 1e-12 * np.abs(M).max()] = 0.0
+    return M

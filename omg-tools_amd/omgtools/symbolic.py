@@ -24,6 +24,7 @@ import numpy as np
 
 VAR, ATOM = 0, 1
 _ATOM_BASE = 1 << 30          # ids >= _ATOM_BASE are atoms, below are variables
+LIFT_CAP = 4                  # variable factors a template term carries (include/omgx.h OMGX_TERM_VARS); products beyond it are lifted
 
 
 def is_atom(sym):
@@ -170,9 +171,23 @@ class Poly(object):
             return Poly({k: c * other for k, c in self.terms.items()})
         if not isinstance(other, Poly):
             return NotImplemented
+        a, b = self, other
+        da, db = a.var_degree(), b.var_degree()
+        if da + db > LIFT_CAP and SymbolTable._stack:
+            # LIFTING (round 5): the product would have more variable factors than a template term carries (include/omgx.h
+            # OMGX_TERM_VARS = 4).  The factor of higher degree is replaced by an auxiliary variable `aux` with the equality row
+            # aux - factor = 0 (SymbolTable.lift: one auxiliary per distinct polynomial, e.g. per coefficient of a product
+            # spline), until the product fits: the NLP the solver sees is the lifted one -- same minimisers in the caller's
+            # variables -- with its auxiliaries and their rows appended behind the caller's x and g (template.py).
+            table = SymbolTable.current()
+            while da + db > LIFT_CAP and max(da, db) > 1:
+                if da >= db:
+                    a, da = table.lift(a), 1
+                else:
+                    b, db = table.lift(b), 1
         out = {}
-        for (v1, a1), c1 in self.terms.items():
-            for (v2, a2), c2 in other.terms.items():
+        for (v1, a1), c1 in a.terms.items():
+            for (v2, a2), c2 in b.terms.items():
                 key = (tuple(sorted(v1 + v2)), tuple(sorted(a1 + a2)))
                 out[key] = out.get(key, 0.0) + c1 * c2
         return Poly({k: c for k, c in out.items() if c != 0.0})
@@ -193,10 +208,11 @@ class Poly(object):
         other = Poly.lift(other)
         if other.is_constant():
             return self * (1.0 / other.constant_value())
-        if not (self.is_param_only() and other.is_param_only()):
-            raise TypeError('division is only defined between parameter-only '
-                            'polynomials (e.g. t/T)')
         table = SymbolTable.current()
+        if not (self.is_param_only() and other.is_param_only()):
+            # a quotient that involves variables (e.g. t / T with a free end time T): the auxiliary variable q with the
+            # equality row q * denominator - numerator = 0 (round 5, see __mul__)
+            return table.quotient(self, other)
         return Poly.symbol(table.new_div_atom(self, other))
 
     def __rtruediv__(self, other):
@@ -299,6 +315,8 @@ class SymbolTable(object):
         self.derived = []           # program entries
         self._bspl_cache = {}
         self._div_cache = {}
+        self.lifted = []            # auxiliary variables in creation order: (symbol, row polynomial that must vanish)
+        self._lift_cache = {}
 
     # context handling so Poly.__truediv__ can reach the active table
     def __enter__(self):
@@ -319,6 +337,26 @@ class SymbolTable(object):
         ids = list(range(self.n_var_syms, self.n_var_syms + n))
         self.n_var_syms += n
         return ids
+
+    def lift(self, poly):
+        """The auxiliary variable that stands for `poly` (one per distinct polynomial): Poly of degree 1."""
+        key = _exact_key(poly)
+        if key not in self._lift_cache:
+            sym = self.new_vars(1)[0]
+            self._lift_cache[key] = sym
+            self.lifted.append((sym, Poly.symbol(sym) + (-poly)))
+        return Poly.symbol(self._lift_cache[key])
+
+    def quotient(self, num, den):
+        """The auxiliary variable q = num / den, defined by the row q * den - num = 0."""
+        key = ('quot', _exact_key(num), _exact_key(den))
+        if key not in self._lift_cache:
+            sym = self.new_vars(1)[0]
+            self._lift_cache[key] = sym
+            with self:
+                row = Poly.symbol(sym) * Poly.lift(den) + (-Poly.lift(num))      # (may lift `den` first: its auxiliary then precedes q's row)
+            self.lifted.append((sym, row))
+        return Poly.symbol(self._lift_cache[key])
 
     def new_raw_atoms(self, n):
         ids = []

@@ -53,6 +53,8 @@ class NLPTemplate(object):
         objective = Poly()
         for child in father.children.values():
             objective = objective + child._objective
+        self.var_layout, self.con_layout = dict(self.var_layout), dict(self.con_layout)
+        self._append_lifted(father.table, var_index, rows, len(var_index))
         self._build(father.table, var_index, atom_index, rows, objective)
         # default values
         self.x_init = father_init_vector(father, '_variables', self.var_layout)
@@ -66,15 +68,33 @@ class NLPTemplate(object):
         reference's own construct code (its CasADi graphs evaluated on `Poly` values, omgx_shim) becomes
         a template."""
         self = cls()
-        self.var_layout = var_layout or {('x', 'x'): (0, len(var_syms), 1)}
+        self.var_layout = dict(var_layout or {('x', 'x'): (0, len(var_syms), 1)})
         self.par_layout = par_layout or {('p', 'p'): (0, len(par_syms), 1)}
-        self.con_layout = con_layout or {('g', 'g'): (0, len(rows), 1)}
+        self.con_layout = dict(con_layout or {('g', 'g'): (0, len(rows), 1)})
         self.lb, self.ub = np.asarray(lb, float).copy(), np.asarray(ub, float).copy()
         var_index = {int(sym): k for k, sym in enumerate(var_syms)}
         atom_index = {int(sym): k for k, sym in enumerate(par_syms)}
-        self._build(table, var_index, atom_index, list(rows), Poly.lift(objective))
+        rows = list(rows)
+        self._append_lifted(table, var_index, rows, len(var_syms))
+        self._build(table, var_index, atom_index, rows, Poly.lift(objective))
         self.x_init = np.zeros(self.n_var)
         return self
+
+    def _append_lifted(self, table, var_index, rows, n_user_var):
+        """Auxiliary variables of products / quotients that were lifted while the rows were formed (symbolic.py,
+        `Poly.__mul__`): a block ('lifted', 'aux') behind the caller's variables, their equality rows behind the caller's rows.
+        The caller's x / g offsets do not move; `lift_extend` / `lift_strip` take a caller's vectors to the template's and back."""
+        self.n_lift = len(table.lifted)
+        if not self.n_lift:
+            return
+        n_user_con = len(rows)
+        for k, (sym, row) in enumerate(table.lifted):
+            var_index[int(sym)] = n_user_var + k
+            rows.append(row)
+        self.var_layout[('lifted', 'aux')] = (n_user_var, self.n_lift, 1)
+        self.con_layout[('lifted', 'aux')] = (n_user_con, self.n_lift, 1)
+        self.lb = np.r_[self.lb, np.zeros(self.n_lift)]
+        self.ub = np.r_[self.ub, np.zeros(self.n_lift)]
 
     def _build(self, table, var_index, atom_index, rows, objective):
         self.n_var = sum(r * c for _, r, c in self.var_layout.values())
@@ -218,6 +238,45 @@ class NLPTemplate(object):
             total += v
         return total
 
+    def eval_slots_host(self, atoms):
+        return np.array([self._pp_value(pp, atoms) for pp in self.slot_pp]) if self.n_slots else np.zeros(0)
+
+    def eval_rows_host(self, x, atoms, rows, slots=None):
+        """Values of the given rows (indices; n_con = the objective) at x from the term lists."""
+        if slots is None:
+            slots = self.eval_slots_host(atoms)
+        out = np.zeros(len(rows))
+        xe = np.r_[np.asarray(x, float), 1.0]                 # (index -1 -> the factor 1)
+        for i, r in enumerate(rows):
+            t0, t1 = int(self.row_ptr[r]), int(self.row_ptr[r + 1])
+            c = self.t_coef[t0:t1] * np.where(self.t_slot[t0:t1] >= 0, slots[np.maximum(self.t_slot[t0:t1], 0)] if self.n_slots else 1.0, 1.0)
+            out[i] = np.sum(c * np.prod(xe[self.t_var[t0:t1]], axis=1))
+        return out
+
+    def lift_extend(self, x_user, p, lbg=None, ubg=None):
+        """A caller's x (and bounds) -> the template's: the auxiliary variables from their defining rows, in order (every row
+        is linear in its own auxiliary: value at 0 and at 1 give it), the bounds of those rows zero."""
+        n_lift = getattr(self, 'n_lift', 0)
+        if not n_lift:
+            return x_user, lbg, ubg
+        nv, nc = self.n_var - n_lift, self.n_con - n_lift
+        x = np.r_[np.asarray(x_user, float).reshape(-1)[:nv], np.zeros(n_lift)]
+        atoms = self.eval_atoms_host(np.asarray(p, float).reshape(-1))
+        slots = self.eval_slots_host(atoms)
+        for k in range(n_lift):
+            g0 = self.eval_rows_host(x, atoms, [nc + k], slots)[0]
+            x[nv + k] = 1.0
+            g1 = self.eval_rows_host(x, atoms, [nc + k], slots)[0]
+            x[nv + k] = -g0 / (g1 - g0)
+        ext = lambda b: None if b is None else np.r_[np.asarray(b, float).reshape(-1)[:nc], np.zeros(n_lift)]
+        return x, ext(lbg), ext(ubg)
+
+    def lift_strip(self, x, lam_g):
+        n_lift = getattr(self, 'n_lift', 0)
+        if not n_lift:
+            return x, lam_g
+        return np.asarray(x)[..., :self.n_var - n_lift], np.asarray(lam_g)[..., :self.n_con - n_lift]
+
     def eval_poly_host(self, poly, x, atoms):
         def value(sym):
             return atoms[self._atom(sym)] if is_atom(sym) else x[self._var(sym)]
@@ -244,7 +303,7 @@ class NLPTemplate(object):
 
 
     # ------------------------------------------------------------- files
-    _SCALARS = ('n_var', 'n_par', 'n_con', 'n_atoms', 'n_slots', 'n_terms')
+    _SCALARS = ('n_var', 'n_par', 'n_con', 'n_atoms', 'n_slots', 'n_terms', 'n_lift')
 
     def to_npz(self, path, **extra):
         """The template as one .npz (flat arrays, bounds, layouts): fixtures of problem classes whose front end is not in
@@ -255,7 +314,7 @@ class NLPTemplate(object):
             lay[which + '_names'] = np.array(['%s\t%s' % (label, name) for label, name, _, _, _ in table])
             lay[which + '_dims'] = np.array([[off, r, c] for _, _, off, r, c in table], dtype=np.int64).reshape(-1, 3)
         np.savez_compressed(path, lb=self.lb, ub=self.ub, x_init=getattr(self, 'x_init', np.zeros(self.n_var)),
-                            scalars=np.array([getattr(self, k) for k in self._SCALARS], dtype=np.int64),
+                            scalars=np.array([getattr(self, k, 0) for k in self._SCALARS], dtype=np.int64),
                             **self.flat_arrays(), **lay, **extra)
         return path
 
@@ -263,6 +322,7 @@ class NLPTemplate(object):
     def from_npz(cls, path):
         d = np.load(path)
         self = cls()
+        self.n_lift = 0                    # (files written before round 5 carry six scalars)
         for k, v in zip(cls._SCALARS, d['scalars']):
             setattr(self, k, int(v))
         for k in ('prog', 'knots', 'pp_ptr', 'pm_coef', 'pm_ptr', 'pm_atom', 'slot_pp', 'row_ptr', 't_coef', 't_slot',

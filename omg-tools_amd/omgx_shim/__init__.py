@@ -126,6 +126,26 @@ def patch_spline_extra(module):
             xv = x.eval(env).reshape(-1)[0]
             cv = cm.eval(env).reshape(-1)
             sym = _mod('symbolic')
+            if isinstance(xv, sym.Poly) and not xv.is_param_only():
+                # The evaluation point involves VARIABLES: t / T with a free end time T (`problems/point2point.py:269-369`: T is
+                # the variable, t the parameter -- 0 throughout a free-T run, the time axis resets with every update -- so the
+                # point is the lifted quotient q = t / T, symbolic.py).  Basis functions at a variable point are not atoms; on the
+                # FIRST knot span, where q lives, every one of them is a polynomial of the spline's degree in q: the value is
+                # Horner's scheme in q over combinations of the leading coefficients (products beyond four factors are lifted).
+                M = _mod('splines').first_span_power_series(knots, degree)          # B_i(u) = sum_k M[i, k] u^k for 0 <= u < first knot
+                C = []
+                for k in range(degree + 1):
+                    ck = 0.0
+                    for i in range(degree + 1):
+                        if M[i, k] != 0.0:
+                            ck = ck + cv[i] * float(M[i, k])
+                    C.append(ck)
+                acc = C[degree]
+                for k in range(degree - 1, -1, -1):
+                    acc = acc * xv + C[k]
+                out = np.empty((1, 1), dtype=object)
+                out[0, 0] = acc
+                return out
             if isinstance(xv, sym.Poly):
                 table = sym.SymbolTable.current()
                 B = [sym.Poly.symbol(i) for i in table.new_bspl_atoms(knots, degree, xv)]
@@ -219,9 +239,13 @@ class ShimSolver(object):
                 self._impl = solver_factory(self.template, options)
             else:
                 self._impl = _mod('backend').NlpSolver(self.template, options)     # raises without libomgx.so / a HIP device
-        res = self._impl(x0=x0, p=p, lbg=lbg, ubg=ubg)
+        # (a template with lifted products -- symbolic.py, `Poly.__mul__` -- carries auxiliary variables and rows behind the caller's:
+        # they are filled in from their defining rows here and cut off again below; a template without them passes through)
+        x0f, lbf, ubf = self.template.lift_extend(x0, p, lbg, ubg)
+        res = self._impl(x0=x0f, p=p, lbg=lbf, ubg=ubf)
         self._stats = self._impl.stats()
-        return {'x': np.asarray(res['x']), 'lam_g': np.asarray(res['lam_g'])}
+        x, lam = self.template.lift_strip(np.asarray(res['x']).reshape(-1), np.asarray(res['lam_g']).reshape(-1))
+        return {'x': np.asarray(x), 'lam_g': np.asarray(lam)}
 
     def stats(self):
         return dict(self._stats)

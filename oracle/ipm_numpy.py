@@ -559,6 +559,8 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         for bt in range(o['max_backtrack']):
             step = alpha * dxt + d_c if soc == 1 else alpha * dxt
             xt = x + step[:n]
+            if getattr(nlp, 'n_lift', 0):          # (omgx_core.h lift_project: the auxiliaries of lifted products follow the trial point)
+                xt = nlp.project_lifted(xt, c)
             tt = t + step[n]
             ft, ht, cEt = evaluate(xt)
             st = tt * v - ht

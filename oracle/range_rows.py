@@ -32,6 +32,8 @@ def expand_template(tpl):
     t2.ub = np.r_[tpl.ub, np.full(len(src), np.inf)]
     t2.con_layout = dict(tpl.con_layout)
     t2.con_layout[('range', 'lower_sides')] = (tpl.n_con, len(src), 1)
+    if getattr(tpl, 'n_lift', 0):
+        t2.lift_row0 = getattr(tpl, 'lift_row0', tpl.n_con - tpl.n_lift)      # (the defining rows of lifted auxiliaries keep their place)
     if hasattr(t2, 'plan'):
         t2.plan = None
     return t2, src, dup

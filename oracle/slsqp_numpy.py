@@ -24,3 +24,42 @@ def solve_slsqp(nlp, tpl, x0, p, maxiter=400, accept=(0,), viol_tol=1e-8):
     g = nlp.fg(out.x, c)[1]
     viol = max((g - tpl.ub)[ineq].max(), np.abs(g[eq] - tpl.lb[eq]).max(), (tpl.lb - g)[lo].max() if lo.any() else 0.0)
     return out.x, float(out.fun), bool(out.status in accept and viol < viol_tol)
+
+
+def solve_slsqp_reduced(nlp, tpl, x0_user, p, maxiter=400, accept=(0,), viol_tol=1e-8):
+    """SLSQP on the CALLER'S OWN problem of a template with lifted auxiliaries (template.py `_append_lifted`: products of more
+    than four variable factors, quotients by a variable): the unknowns are the caller's variables only; the auxiliaries are
+    functions of them -- their defining rows solved level by level (`NumpyNLP.project_lifted`) -- and the derivatives follow by
+    the implicit-function rule,  da/dx = -(dL/da)^-1 dL/dx  with L the defining rows.  The solver under test never sees this
+    form: it iterates on the lifted system.  Returns the full vector (auxiliaries included), the objective and the flag."""
+    nl = nlp.n_lift
+    nv, nc = nlp.n_var - nl, nlp.n_con - nl
+    c = nlp.term_coefs(p)
+    lb, ub = tpl.lb[:nc], tpl.ub[:nc]
+    memo = {}
+
+    def at(v):
+        key = v.tobytes()
+        if memo.get('key') != key:
+            xf = nlp.project_lifted(np.r_[v, np.zeros(nl)], c)
+            f, g = nlp.fg(xf, c)
+            J = nlp.jac(xf, c)
+            dadx = -np.linalg.solve(J[nc:nc + nl, nv:], J[nc:nc + nl, :nv])
+            R = J[:, :nv] + J[:, nv:] @ dadx
+            memo.update(key=key, x=xf, f=f, g=g[:nc], Jg=R[:nc], df=R[-1])
+        return memo
+    eq = lb == ub
+    ineq = np.isfinite(ub) & ~eq
+    lo = np.isfinite(lb) & ~eq
+    cons = [{'type': 'ineq', 'fun': lambda v: (ub - at(v)['g'])[ineq], 'jac': lambda v: -at(v)['Jg'][ineq]}]
+    if eq.any():
+        cons.append({'type': 'eq', 'fun': lambda v: at(v)['g'][eq] - lb[eq], 'jac': lambda v: at(v)['Jg'][eq]})
+    if lo.any():
+        cons.append({'type': 'ineq', 'fun': lambda v: (at(v)['g'] - lb)[lo], 'jac': lambda v: at(v)['Jg'][lo]})
+    out = minimize(lambda v: at(v)['f'], np.asarray(x0_user, float)[:nv], jac=lambda v: at(v)['df'], constraints=cons,
+                   method='SLSQP', options={'maxiter': maxiter, 'ftol': 1e-12})
+    m = at(out.x)
+    g = m['g']
+    viol = max((g - ub)[ineq].max() if ineq.any() else 0.0, np.abs(g[eq] - lb[eq]).max() if eq.any() else 0.0,
+               (lb - g)[lo].max() if lo.any() else 0.0)
+    return m['x'].copy(), float(out.fun), bool(out.status in accept and viol < viol_tol)

@@ -18,7 +18,15 @@ tests/golden/dubins_subst.npz (round 4): the same class with `options['substitut
 the integral of separate velocity splines, tied to the tangent-half-angle expressions by TWO-SIDED rows  -1e-3 <= x - int(v_til (1 -
 tg_ha^2)) <= 1e-3  (`basics/optilayer.py:634-666`) -- 118 range rows; what the library could not take before ABI 5.
 
-Run in the build container:  python tests/golden/generate_shim_fixtures.py"""
+tests/golden/bicycle_fixedT.npz, agv_fixedT.npz, dubins_freeT.npz, trailer_freeT.npz (round 5): the classes whose rows are products of
+more than four variable factors or quotients by a variable -- `vehicles/bicycle.py:53`, `vehicles/agv.py:50`, `vehicles/trailer.py:28`
+(the bodies of `examples/p2p_bicycle.py`, `p2p_agv.py`, `p2p_trailer.py`) and `examples/p2p_dubins.py` as shipped (free end time: the
+velocity divides by T).  `omgx_shim` writes such an expression with auxiliary variables (omgtools/symbolic.py `LIFT_CAP`, template.py
+`_append_lifted`): the template has the caller's variables and rows first and the auxiliaries / their defining rows behind them.
+xs carries the caller's variables extended by the auxiliaries, gs the REFERENCE's g at the caller's variables (defining rows: 0).
+x_slsqp: SLSQP on the caller's own problem (oracle/slsqp_numpy.py `solve_slsqp_reduced`) where it converges.
+
+Run in the build container:  python tests/golden/generate_shim_fixtures.py [dubins | dubins_subst | revolving_door | bicycle | agv | dubins_freeT | trailer]"""
 import os
 import subprocess
 import sys
@@ -32,10 +40,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 
-def make(case, out_name, subst='0'):
+def make(case, out_name, subst='0', freeT='0', slsqp=True):
     tmp = os.path.join(HERE, '_shim_tmp.npz')
-    env = dict(os.environ, SHIM_TEMPLATE=tmp, DUBINS_SUBST=subst, DUBINS_FREET='0', SHIM_NO_SIM='1' if subst == '1' else '0',
-               SHIM_DUMP=os.path.join(HERE, '_shim_dump.npz'))
+    lifted = out_name.split('_')[0] in ('bicycle', 'agv', 'trailer') or freeT == '1'
+    env = dict(os.environ, SHIM_TEMPLATE=tmp, DUBINS_SUBST=subst, DUBINS_FREET=freeT, FREET=freeT, KNOTS='5',
+               SHIM_NO_SIM='1' if (subst == '1' or lifted) else '0', SHIM_DUMP=os.path.join(HERE, '_shim_dump.npz'))
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'helpers', 'run_reference_on_shim.py'), case],
                        capture_output=True, text=True, env=env)
     print(r.stdout[-600:])
@@ -46,7 +55,12 @@ def make(case, out_name, subst='0'):
     tpl = NLPTemplate.from_npz(tmp)
     d = dict(np.load(tmp))
     nlp = NumpyNLP(tpl)
-    xs, fs, ok = solve_slsqp(nlp, tpl, d['x0'], d['p0'])
+    if getattr(tpl, 'n_lift', 0):
+        from oracle.slsqp_numpy import solve_slsqp_reduced
+        xs, fs, ok = (solve_slsqp_reduced(nlp, tpl, d['x0'], d['p0'], accept=(0, 8), viol_tol=1e-7) if slsqp
+                      else (np.zeros(tpl.n_var), float('nan'), False))
+    else:
+        xs, fs, ok = solve_slsqp(nlp, tpl, d['x0'], d['p0'])
     print('SLSQP f', fs, 'converged', ok)        # (slsqp_ok = 0: SLSQP gave up; the tests then rely on the KKT conditions)
     np.savez_compressed(os.path.join(HERE, out_name), x_slsqp=xs, f_slsqp=fs, slsqp_ok=int(ok), **d)
     os.remove(tmp)
@@ -61,3 +75,11 @@ if __name__ == '__main__':
         make('p2p_dubins', 'dubins_subst.npz', subst='1')
     if 'revolving_door' in which:
         make('revolving_door', 'revolving_door.npz')
+    if 'bicycle' in which:
+        make('p2p_bicycle', 'bicycle_fixedT.npz', slsqp=False)      # (SLSQP runs a denominator through zero on this class)
+    if 'agv' in which:
+        make('p2p_agv', 'agv_fixedT.npz')
+    if 'dubins_freeT' in which:
+        make('p2p_dubins', 'dubins_freeT.npz', freeT='1', slsqp=False)
+    if 'trailer' in which:
+        make('p2p_trailer', 'trailer_freeT.npz', freeT='1', slsqp=False)

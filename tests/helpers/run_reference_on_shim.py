@@ -76,6 +76,49 @@ elif which == 'p2p_dubins':
     problem = Point2point(vehicle, environment, freeT=os.environ.get('DUBINS_FREET', '0') == '1')
     vehicle.problem = problem
     target = [3., 3., 0.]
+elif which in ('p2p_trailer', 'p2p_bicycle', 'p2p_agv'):
+    # bodies of the reference's examples/p2p_trailer.py:24-45, p2p_bicycle.py:25-38, p2p_agv.py:25-37 (round 5): the models whose rows are
+    # products of spline expressions of degree 6 .. 10 in the coefficients -- lifted into auxiliary variables while the template
+    # is formed (omgtools/symbolic.py).  FREET=1: the free-end-time problem the example files build; default: fixed T.
+    freeT = os.environ.get('FREET', '0') == '1'
+    K = int(os.environ.get('KNOTS', '5'))
+    if which == 'p2p_trailer':
+        lead = Dubins(shapes=Circle(0.2), bounds={'vmax': 0.8, 'wmax': np.pi/3., 'wmin': -np.pi/3.})
+        lead.define_knots(knot_intervals=K)
+        lead.set_initial_conditions([0., 0., 0.])
+        lead.set_terminal_conditions([3.4, 3., 0.])
+        vehicle = Trailer(lead_veh=lead, shapes=Rectangle(0.2, 0.2), l_hitch=0.6, bounds={'tmax': np.pi/4., 'tmin': -np.pi/4.})
+        vehicle.define_knots(knot_intervals=K)
+        vehicle.set_initial_conditions(0.)
+        vehicle.set_terminal_conditions(0.)
+        environment = Environment(room={'shape': Square(5.), 'position': [1.5, 1.5]})
+        problem = Point2point(vehicle, environment, freeT=freeT)
+        problem.father.add(lead)
+        problem.vehicles.append(lead)
+        lead.to_simulate = False
+        target = None
+    elif which == 'p2p_bicycle':
+        vehicle = Bicycle(length=0.4, options={'plot_type': 'car', 'substitution': False})
+        vehicle.define_knots(knot_intervals=K)
+        vehicle.set_initial_conditions([0., 0., 0., 0.])
+        vehicle.set_terminal_conditions([3., 3., 0.])
+        environment = Environment(room={'shape': Square(5.), 'position': [1.5, 1.5]})
+        trajectories = {'velocity': {'time': [0.5], 'values': [[0.3, 0.0]]}}
+        environment.add_obstacle(Obstacle({'position': [1., 1.]}, shape=Circle(0.5), simulation={'trajectories': trajectories}))
+        problem = Point2point(vehicle, environment, freeT=freeT)
+        vehicle.problem = problem
+        target = [3., 3., 0.]
+    else:
+        vehicle = AGV(length=0.8, options={'plot_type': 'agv'})
+        vehicle.define_knots(knot_intervals=K)
+        vehicle.set_initial_conditions([0.8, -0.05, 0., 0.])
+        vehicle.set_terminal_conditions([2.45, -0.35, 0.])
+        environment = Environment(room={'shape': Rectangle(width=4, height=1), 'position': [2, 0.]})
+        rectangle = Rectangle(width=0.8, height=0.2)
+        environment.add_obstacle(Obstacle({'position': [1., -0.35]}, shape=rectangle))
+        environment.add_obstacle(Obstacle({'position': [3.4, -0.35]}, shape=rectangle))
+        problem = Point2point(vehicle, environment, freeT=freeT)
+        target = [2.45, -0.35, 0.]
 elif which == 'revolving_door':
     # body of the reference's examples/revolving_door.py:23-47: two rotating beams (`environment/obstacle.py:299-332`:
     # the hyperplane rows are multiplied by 1 + tg_ha^2 of the obstacle's orientation spline) between two standing ones
@@ -104,10 +147,13 @@ problem.reinitialize()
 father = problem.father
 x0 = np.asarray(father.get_variables().cat, float).reshape(-1).copy()
 p0 = np.asarray(father.set_parameters(0.).cat, float).reshape(-1).copy()
+import time as _time
+_t0 = _time.time()
 problem.solve(0., 0.1)
+out['first_solve_s'] = _time.time() - _t0
 tpl = problem.problem.template
-out.update(n_var=tpl.n_var, n_con=tpl.n_con, n_par=tpl.n_par, n_terms=int(tpl.n_terms),
-           first_status=problem.problem.stats()['return_status'])
+out.update(n_var=tpl.n_var, n_con=tpl.n_con, n_par=tpl.n_par, n_terms=int(tpl.n_terms), n_lift=int(getattr(tpl, 'n_lift', 0)),
+           first_status=problem.problem.stats()['return_status'], first_iters=int(problem.problem.stats().get('iter_count', -1)))
 # the template against the reference's own graphs, evaluated numerically at random points
 nlp_ref = problem.problem.nlp
 X, Pm = nlp_ref['x'].cat, nlp_ref['p'].cat
@@ -117,17 +163,22 @@ rng = np.random.default_rng(3)
 err = 0.0
 pts = []
 for k in range(3):
-    xv, pv = x0 + 0.1 * rng.standard_normal(tpl.n_var), p0.copy()
+    xv, pv = np.r_[x0, np.zeros(tpl.n_var - len(x0))] + 0.1 * rng.standard_normal(tpl.n_var), p0.copy()
     pv[tpl.entry_range('p2p0', 't', 'par')[0]] = 0.03 * (k + 1)          # time since the last knot: exercises t/T and B(t/T)
     for (label, name), (off, r_, c_) in tpl.par_layout.items():
         if name == 'theta':                                               # orientation of a rotating obstacle: cos / sin atoms
             pv[off] = rng.uniform(-3., 3.)
-    env = {X: xv.reshape(-1, 1), Pm: pv.reshape(-1, 1)}
+    n_lift = getattr(tpl, 'n_lift', 0)
+    xu = xv[:tpl.n_var - n_lift]
+    env = {X: xu.reshape(-1, 1), Pm: pv.reshape(-1, 1)}
     g_ref = np.asarray(nlp_ref['g'].cat.eval(env), float).reshape(-1)
     f_ref = float(np.asarray(casadi.MX.lift(nlp_ref['f']).eval(env), float).reshape(-1)[0])
+    xv = tpl.lift_extend(xu, pv)[0]                                         # (lifted products: the auxiliaries from their rows)
     f, g = nn.fg(xv, nn.term_coefs(pv))
-    pts.append((xv, pv, f, g))
-    err = max(err, np.abs(g - g_ref).max() / (1 + np.abs(g_ref).max()), abs(f - f_ref) / (1 + abs(f_ref)))
+    pts.append((xv, pv, f_ref, np.r_[g_ref, np.zeros(n_lift)]))      # (the values of the reference's graphs; the defining rows of lifted auxiliaries: 0)
+    gu = g[:tpl.n_con - n_lift]
+    err = max(err, np.abs(gu - g_ref).max() / (1 + np.abs(g_ref).max()), abs(f - f_ref) / (1 + abs(f_ref)),
+              np.abs(g[tpl.n_con - n_lift:]).max() if n_lift else 0.0)
 out['graph_vs_template'] = err
 np.savez(os.environ.get('SHIM_DUMP', '/tmp/shim_dump.npz'), lb=tpl.lb, ub=tpl.ub, x0=x0, p0=p0,
          row_ptr=tpl.row_ptr, xs=np.array([q[0] for q in pts]), ps=np.array([q[1] for q in pts]),
@@ -139,8 +190,24 @@ if os.environ.get('SHIM_TEMPLATE'):
                fs=np.array([q[2] for q in pts]), gs=np.array([q[3] for q in pts]))
 if os.environ.get('SHIM_NO_SIM') != '1':
     simulator = Simulator(problem)
-    simulator.run()
+    max_updates = int(os.environ.get('SHIM_MAX_UPDATES', '0'))
+    if max_updates:
+        # the loop of `Simulator.run` (execution/simulator.py:39-52), cut after a number of updates: status and iterations of each
+        simulator.deployer.reset()
+        updates = []
+        for k in range(max_updates):
+            _t0 = _time.time()
+            stop = simulator.update()
+            st = problem.problem.stats()
+            updates.append((st['return_status'], int(st.get('iter_count', -1))))
+            sys.stderr.write('update %d: %s, %d iterations, %.1f s\n' % (k, updates[-1][0], updates[-1][1], _time.time() - _t0)); sys.stderr.flush()
+            if stop:
+                break
+            simulator.update_timing()
+        out.update(update_status=[u[0] for u in updates], update_iters=[u[1] for u in updates])
+    else:
+        simulator.run()
     state = vehicle.signals['state'][:, -1]
-    out.update(final_error=float(np.abs(state - np.array(target)).max()), steps=len(problem.update_times),
+    out.update(final_error=float(np.abs(state[:len(target)] - np.array(target)).max()) if target is not None else None, steps=len(problem.update_times),
                statuses_ok=True)
 print('SHIM_RESULT ' + json.dumps(out))

@@ -1,0 +1,241 @@
+"""Products of more than four variable factors and quotients by a variable (the Bicycle / AGV / Trailer models of
+`vehicles/bicycle.py:53`, `vehicles/agv.py:50`, `vehicles/trailer.py:28`, the free end time of `examples/p2p_dubins.py` as shipped).
+
+Representation (omgtools/symbolic.py `LIFT_CAP`, template.py `_append_lifted`, include/omgx.h `n_lift`): the front end writes such an
+expression with auxiliary variables -- aux = the factor of higher degree, q * den = num -- whose defining equality rows sit behind
+the caller's rows.  The solver keeps those rows satisfied exactly: every trial point of its line search takes the auxiliaries
+from their rows (omgx_core.h `lift_project`), so its iterates are iterates of the caller's own problem.
+
+  CPU  the mechanism on a small NLP against scipy SLSQP on the UNLIFTED problem; the fixtures generated from the reference's own
+       construct code (tests/golden/generate_shim_fixtures.py: its modules executed on `omgx_shim`) reproduce the reference's f / g at
+       random points; host build of the solver from the reference's guess on the fixed-T Bicycle and AGV problems: optimality
+       conditions of the NLP evaluated by the numpy oracle, the objective against SLSQP on the caller's own problem (AGV), the same
+       iterates as the dense numpy statement of the solver; a template-file round trip.
+  GPU  the HIP path through the C ABI: derivative tables of the lifted template against the oracle, the solve against the host
+       build and the optimality conditions."""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+# ---- the mechanism on a small problem ------------------------------------------------------------------------------------------
+def _toy():
+    """min (x0 - 1)^2 + (x1 - 2)^2 + (x2 - 0.5)^2   s.t.  x0^2 x1^2 x2^2 <= 0.5 (six variable factors),  x0 / x2 >= 1.5 (a quotient by
+    a variable),  0.2 <= x2."""
+    from omgtools.symbolic import SymbolTable, Poly
+    from omgtools.template import NLPTemplate
+    table = SymbolTable()
+    with table:
+        syms = table.new_vars(3)
+        x = [Poly.symbol(s) for s in syms]
+        rows = [(x[0] * x[0] * x[1]) * (x[1] * x[2] * x[2]), x[0] / x[2], x[2]]
+        objective = (x[0] - 1.0) * (x[0] - 1.0) + (x[1] - 2.0) * (x[1] - 2.0) + (x[2] - 0.5) * (x[2] - 0.5)
+        tpl = NLPTemplate.from_polys(table, syms, [], rows, objective, lb=[-np.inf, 1.5, 0.2], ub=[0.5, np.inf, np.inf])
+    return tpl
+
+
+def test_lifting_builds_the_rows_and_the_solver_returns_the_minimum_of_the_unlifted_problem():
+    from scipy.optimize import minimize
+    from oracle import port_binding, ipm_numpy
+    from oracle.nlp_numpy import NumpyNLP
+    tpl = _toy()
+    assert tpl.n_lift == 2 and tpl.n_var == 5 and tpl.n_con == 5 and tpl.t_nv.max() <= 4
+    assert tpl.var_layout[('lifted', 'aux')] == (3, 2, 1) and tpl.con_layout[('lifted', 'aux')] == (3, 2, 1)
+    nlp = NumpyNLP(tpl)
+    assert list(nlp.lift_level) == [0, 0]
+    p = np.zeros(0)
+    c = nlp.term_coefs(p)
+    # the caller's vector extended: the auxiliaries from their rows; the lifted rows then hold and the caller's rows have the
+    # values of the original expressions
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        xu = rng.uniform(0.5, 2.0, size=3)
+        xf = tpl.lift_extend(xu, p)[0]
+        f, g = nlp.fg(xf, c)
+        assert np.abs(g[3:]).max() < 1e-14
+        assert abs(g[0] - (xu[0] * xu[1] * xu[2]) ** 2) < 1e-12 and abs(g[1] - xu[0] / xu[2]) < 1e-12
+        assert np.abs(nlp.project_lifted(np.r_[xu, 7.0, -3.0], c) - xf).max() < 1e-14
+    x0 = np.array([1.0, 1.0, 1.0])
+    ref = minimize(lambda v: (v[0] - 1) ** 2 + (v[1] - 2) ** 2 + (v[2] - 0.5) ** 2, x0, method='SLSQP', options={'ftol': 1e-14},
+                   constraints=[{'type': 'ineq', 'fun': lambda v: 0.5 - (v[0] * v[1] * v[2]) ** 2},
+                                {'type': 'ineq', 'fun': lambda v: v[0] / v[2] - 1.5}, {'type': 'ineq', 'fun': lambda v: v[2] - 0.2}])
+    assert ref.success
+    xf, lb, ub = tpl.lift_extend(x0, p, tpl.lb[:3], tpl.ub[:3])
+    res = port_binding.solve(tpl, p[None], xf[None], lb, ub, tol=1e-8, max_iter=200)
+    assert res['status'][0] == 0 and res['iters'][0] < 40
+    xs, lam = tpl.lift_strip(res['x'][0], res['lam_g'][0])
+    assert xs.shape == (3,) and lam.shape == (3,)
+    assert np.abs(xs - ref.x).max() < 1e-5, (xs, ref.x)
+    assert np.abs(nlp.fg(res['x'][0], c)[1][3:]).max() < 1e-12            # the defining rows hold exactly at the result
+    # iterate for iterate the dense numpy statement of the solver (same projection of the auxiliaries)
+    for iters in (2, 6):
+        a = port_binding.solve(tpl, p[None], xf[None], lb, ub, tol=1e-12, max_iter=iters)
+        b = ipm_numpy.solve(nlp, xf, p, lb, ub, opts={'tol': 1e-12, 'max_iter': iters})
+        assert a['iters'][0] == b['iters'] == iters
+        assert np.abs(a['x'][0] - b['x']).max() < 1e-8 * max(1.0, np.abs(b['x']).max()), iters
+
+
+def test_the_library_refuses_a_lifted_row_that_reads_a_later_auxiliary():
+    import omgtools.backend as be
+    tpl = _toy()
+    info = be.describe_plan(tpl)
+    assert info['n_eq'] == 2
+    bad = _toy()
+    # swap the two auxiliaries inside the term lists: the first defining row then reads the second auxiliary
+    tv = bad.t_var.copy()
+    tv[bad.t_var == 3], tv[bad.t_var == 4] = 4, 3
+    r0, r1 = int(bad.row_ptr[3]), int(bad.row_ptr[5])
+    keep = bad.t_var.copy()
+    keep[r0:r1] = tv[r0:r1]
+    bad.t_var = keep
+    with pytest.raises(Exception):
+        be.describe_plan(bad)
+
+
+# ---- the reference's classes -----------------------------------------------------------------------------------------------
+CLASSES = {'bicycle_fixedT': dict(shape=(293, 854, 25), n_lift=208, levels=3),
+           'agv_fixedT': dict(shape=(381, 2234, 52), n_lift=278, levels=3),
+           'dubins_freeT': dict(shape=(111, 394, 19), n_lift=76, levels=11),
+           'trailer_freeT': dict(shape=(168, 1896, 13), n_lift=127, levels=11)}
+
+
+def _load(name):
+    from omgtools.template import NLPTemplate
+    path = os.path.join(GOLDEN, name + '.npz')
+    tpl = NLPTemplate.from_npz(path)
+    d = np.load(path)
+    spec = CLASSES[name]
+    assert (tpl.n_var, tpl.n_con, tpl.n_par) == spec['shape'] and tpl.n_lift == spec['n_lift'] and tpl.t_nv.max() <= 4
+    return tpl, d
+
+
+@pytest.mark.parametrize('name', sorted(CLASSES))
+def test_lifted_templates_reproduce_the_reference_graphs(name):
+    """f and g of the reference's own CasADi graphs (evaluated by the shim on the closures the reference built) at three random
+    points against the template with the auxiliaries taken from their rows."""
+    from oracle.nlp_numpy import NumpyNLP
+    tpl, d = _load(name)
+    nlp = NumpyNLP(tpl)
+    assert int(nlp.lift_level.max()) + 1 == CLASSES[name]['levels']
+    nl = tpl.n_lift
+    for xv, pv, fs, gs in zip(d['xs'], d['ps'], d['fs'], d['gs']):
+        c = nlp.term_coefs(pv)
+        xf = nlp.project_lifted(np.r_[xv[:tpl.n_var - nl], np.zeros(nl)], c)
+        assert np.abs(xf - xv).max() < 1e-12 * (1 + np.abs(xv).max())       # (template.lift_extend wrote xv)
+        f, g = nlp.fg(xf, c)
+        assert abs(f - fs) < 1e-9 * (1 + abs(fs))
+        assert np.abs(g - gs).max() < 1e-9 * (1 + np.abs(gs).max())          # (the reference's rows; the defining rows: 0)
+
+
+def _extended(tpl, d):
+    nl = tpl.n_lift
+    return tpl.lift_extend(d['x0'], d['p0'], tpl.lb[:tpl.n_con - nl], tpl.ub[:tpl.n_con - nl])
+
+
+def _check_solution(name, tpl, d, res, tol):
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    nlp = NumpyNLP(tpl)
+    assert res['status'][0] == 0, res['status']
+    c = nlp.term_coefs(d['p0'])
+    f, g = nlp.fg(res['x'][0], c)
+    nl = tpl.n_lift
+    assert np.abs(g[tpl.n_con - nl:]).max() < 1e-11                          # the auxiliaries sit on their rows
+    assert (g - tpl.ub).max() < 10 * tol and (tpl.lb - g).max() < 10 * tol
+    assert_kkt(nlp, tpl, d['p0'], res['x'][0], res['lam_g'][0], 10 * tol, name)
+    if int(d['slsqp_ok']):
+        # SLSQP on the caller's own problem stops where no step improves its merit function any more (exit 8 on these classes):
+        # a feasible point of the same NLP; the interior-point path must do at least as well
+        assert f < float(d['f_slsqp']) + 1e-6, (f, float(d['f_slsqp']))
+    return f
+
+
+@pytest.mark.parametrize('name,max_iters', [('bicycle_fixedT', 120), ('agv_fixedT', 120)])
+def test_host_build_solves_the_lifted_classes_from_the_reference_guess(name, max_iters):
+    from oracle import port_binding, ipm_numpy
+    from oracle.nlp_numpy import NumpyNLP
+    tpl, d = _load(name)
+    x, lb, ub = _extended(tpl, d)
+    res = port_binding.solve(tpl, d['p0'][None], x[None], lb, ub, tol=1e-3, max_iter=500)
+    assert res['iters'][0] <= max_iters, res['iters']
+    _check_solution(name, tpl, d, res, 1e-3)
+    if name == 'bicycle_fixedT':
+        nlp = NumpyNLP(tpl)
+        a = port_binding.solve(tpl, d['p0'][None], x[None], lb, ub, tol=1e-12, max_iter=12)
+        b = ipm_numpy.solve(nlp, x, d['p0'], lb, ub, opts={'tol': 1e-12, 'max_iter': 12})
+        assert np.abs(a['x'][0] - b['x']).max() < 1e-7 * max(1.0, np.abs(b['x']).max())
+
+
+def test_template_file_round_trip_keeps_the_lifted_rows(tmp_path):
+    import omgtools.backend as be
+    tpl = _toy()
+    path = str(tmp_path / 'toy.omgx')
+    be.save_template(tpl, path)
+    with open(path, 'rb') as fh:
+        assert fh.read(8) == b'OMGXTPL5'
+    back = be.read_template_counts(path)
+    assert back['n_lift'] == 2 and back['lift_row0'] == 3 and back['n_var'] == 5 and back['n_con'] == 5
+    # a template without auxiliaries is written as before
+    from omgtools import workloads
+    problem, P = workloads.holonomic_p2p(2)
+    path4 = str(tmp_path / 'cfg2.omgx')
+    be.save_template(problem.father.template, path4)
+    with open(path4, 'rb') as fh:
+        assert fh.read(8) == b'OMGXTPL4'
+
+
+# ---- GPU -------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['bicycle_fixedT', 'agv_fixedT'])
+def test_lifted_classes_on_the_device(name):
+    import omgtools.backend as be
+    from oracle import port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    tpl, d = _load(name)
+    nlp = NumpyNLP(tpl)
+    x, lb, ub = _extended(tpl, d)
+    rng = np.random.default_rng(17)
+    B = 2
+    ps = np.repeat(d['p0'][None], B, axis=0)
+    xr = x[None] + rng.normal(scale=0.1, size=(B, tpl.n_var))
+    lam = rng.normal(size=(B, tpl.n_con))
+    solver = be.BatchSolver(tpl, B, options=dict(tol=1e-3, max_iter=500))
+    try:
+        got = solver.eval(ps, xr, lam)
+        res = solver.solve(ps, np.repeat(x[None], B, axis=0), lbg=lb, ubg=ub)
+    finally:
+        solver.close()
+    c = nlp.term_coefs(d['p0'])
+    for b in range(B):
+        f, g = nlp.fg(xr[b], c)
+        J, H = nlp.jac(xr[b], c), nlp.hess(xr[b], lam[b], c)
+        assert np.abs(got['g'][b] - g).max() < 1e-10 * max(1.0, np.abs(g).max())
+        assert np.abs(got['jac'][b] - J).max() < 1e-10 * max(1.0, np.abs(J).max())
+        assert np.abs(got['hess'][b] - H).max() < 1e-10 * max(1.0, np.abs(H).max())
+    assert np.array_equal(res['x'][0], res['x'][1])
+    f = _check_solution(name, tpl, d, res, 1e-3)
+    port = port_binding.solve(tpl, d['p0'][None], x[None], lb, ub, tol=1e-3, max_iter=500)
+    fp = nlp.fg(port['x'][0], c)[0]
+    print('\n%s: HIP %d iterations, host build %d; objectives %.6f / %.6f' % (name, res['iters'][0], port['iters'][0], f, fp))
+    assert abs(int(port['iters'][0]) - int(res['iters'][0])) <= 10
+    assert abs(f - fp) < 1e-3 * (1 + abs(f))
+
+
+@pytest.mark.gpu
+def test_toy_on_the_device_matches_the_host_build():
+    import omgtools.backend as be
+    from oracle import port_binding
+    tpl = _toy()
+    p = np.zeros((1, 0))
+    xf, lb, ub = tpl.lift_extend(np.array([1.0, 1.0, 1.0]), p[0], tpl.lb[:3], tpl.ub[:3])
+    solver = be.BatchSolver(tpl, 1, options=dict(tol=1e-8, max_iter=200))
+    try:
+        res = solver.solve(p, xf[None], lbg=lb, ubg=ub)
+    finally:
+        solver.close()
+    port = port_binding.solve(tpl, p, xf[None], lb, ub, tol=1e-8, max_iter=200)
+    assert res['status'][0] == 0 and res['iters'][0] == port['iters'][0]
+    assert np.abs(res['x'][0] - port['x'][0]).max() < 1e-9
