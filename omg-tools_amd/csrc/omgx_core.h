@@ -2200,6 +2200,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   if (c.tid() == 0) w.x[n] = 1.0;
   eval_params(c, d, T, w, p);
   OMGX_TOC(PH_S_PARAMS);
+  // lifted auxiliaries: whatever the caller handed in, the solve starts on their defining rows (eval_params ends with a
+  // barrier: the slots are there)
+  if constexpr (C::general) lift_project(c, d, T, w, m, w.x);
 
   // ---- row classification, gradient-based scaling, phase-I weights -----------
   // warm start only from a converged previous solve; otherwise a cold start from x0

@@ -275,6 +275,8 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
     sig = np.where(up, 1.0, -1.0)[iH]
     bnd = np.where(up, ub, lb)[iH]
     mE, mH = len(iE), len(iH)
+    if getattr(nlp, 'n_lift', 0):          # (omgx_core.h: the solve starts on the defining rows of the lifted auxiliaries)
+        x0 = nlp.project_lifted(x0, c)
     J0 = nlp.jac(np.array(x0, float), c)
     gmax = np.abs(J0[:nlp.n_con]).max(axis=1)
     rho = np.where(gmax > o['scale_gmax'], o['scale_gmax'] / np.maximum(gmax, 1e-300), 1.0) \

@@ -26,7 +26,7 @@ velocity divides by T).  `omgx_shim` writes such an expression with auxiliary va
 xs carries the caller's variables extended by the auxiliaries, gs the REFERENCE's g at the caller's variables (defining rows: 0).
 x_slsqp: SLSQP on the caller's own problem (oracle/slsqp_numpy.py `solve_slsqp_reduced`) where it converges.
 
-Run in the build container:  python tests/golden/generate_shim_fixtures.py [dubins | dubins_subst | revolving_door | bicycle | agv | dubins_freeT | trailer]"""
+Run in the build container:  python tests/golden/generate_shim_fixtures.py [dubins | dubins_subst | revolving_door | bicycle | agv | agv_loop | dubins_freeT | trailer]"""
 import os
 import subprocess
 import sys
@@ -67,6 +67,29 @@ def make(case, out_name, subst='0', freeT='0', slsqp=True):
     os.remove(env['SHIM_DUMP'])
 
 
+def make_loop(case, out_name, updates):
+    """The first `updates` updates of the reference's Simulator on `case` (execution/simulator.py:39-52, its own classes on the shim,
+    the host build of the solver behind them): parameters, initial guess (the reference's warm start: the shifted previous plan),
+    bounds and the result of every solve -- the device re-solves them as one batch (tests/test_lifted.py)."""
+    import glob
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    env = dict(os.environ, PORT_SOLVER_DUMP=tmp, SHIM_MAX_UPDATES=str(updates), FREET='0', KNOTS='5')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'helpers', 'run_reference_on_shim.py'), case],
+                       capture_output=True, text=True, env=env)
+    print(r.stdout[-400:])
+    assert 'SHIM_RESULT' in r.stdout, r.stderr[-3000:]
+    files = sorted(glob.glob(os.path.join(tmp, 'solve_*.npz')))
+    ds = [np.load(f) for f in files]
+    assert all(np.array_equal(d['lbg'], ds[0]['lbg']) and np.array_equal(d['ubg'], ds[0]['ubg']) for d in ds)
+    np.savez_compressed(os.path.join(HERE, out_name), p=np.array([d['p'] for d in ds]), x0=np.array([d['x0'] for d in ds]),
+                        x=np.array([d['x'] for d in ds]), lam_g=np.array([d['lam_g'] for d in ds]), lbg=ds[0]['lbg'], ubg=ds[0]['ubg'],
+                        status=np.array([int(d['status']) for d in ds]), iters=np.array([int(d['iters']) for d in ds]))
+    for f in files:
+        os.remove(f)
+    os.rmdir(tmp)
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['dubins', 'revolving_door']
     if 'dubins' in which:
@@ -79,6 +102,8 @@ if __name__ == '__main__':
         make('p2p_bicycle', 'bicycle_fixedT.npz', slsqp=False)      # (SLSQP runs a denominator through zero on this class)
     if 'agv' in which:
         make('p2p_agv', 'agv_fixedT.npz')
+    if 'agv_loop' in which:
+        make_loop('p2p_agv', 'agv_loop.npz', 12)
     if 'dubins_freeT' in which:
         make('p2p_dubins', 'dubins_freeT.npz', freeT='1', slsqp=False)
     if 'trailer' in which:

@@ -18,14 +18,15 @@ class PortNlpSolver(object):
         from oracle import port_binding
         from oracle.port_binding import _backend
         STATUS_STRINGS = _backend().STATUS_STRINGS
-        import os
-        if os.environ.get('PORT_SOLVER_DUMP'):            # (developer knob: the inputs of every solve, for a closer look at one of them)
-            self._n = getattr(self, '_n', -1) + 1
-            np.savez(os.path.join(os.environ['PORT_SOLVER_DUMP'], 'solve_%03d.npz' % self._n), p=np.asarray(p), x0=np.asarray(x0),
-                     lbg=np.asarray(lbg), ubg=np.asarray(ubg))
         res = port_binding.solve(self.template, np.asarray(p), np.asarray(x0), np.asarray(lbg), np.asarray(ubg),
                                  **self.options)
         self._stats = {'return_status': STATUS_STRINGS[int(res['status'][0])], 'iter_count': int(res['iters'][0])}
+        import os
+        if os.environ.get('PORT_SOLVER_DUMP'):            # (the inputs and the result of every solve: fixtures of closed loops, tests/golden/generate_shim_fixtures.py)
+            self._n = getattr(self, '_n', -1) + 1
+            np.savez(os.path.join(os.environ['PORT_SOLVER_DUMP'], 'solve_%03d.npz' % self._n), p=np.asarray(p), x0=np.asarray(x0),
+                     lbg=np.asarray(lbg), ubg=np.asarray(ubg), x=res['x'][0], lam_g=res['lam_g'][0], status=int(res['status'][0]),
+                     iters=int(res['iters'][0]))
         return {'x': res['x'][0], 'lam_g': res['lam_g'][0]}
 
     def stats(self):

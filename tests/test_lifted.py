@@ -70,6 +70,11 @@ def test_lifting_builds_the_rows_and_the_solver_returns_the_minimum_of_the_unlif
     assert xs.shape == (3,) and lam.shape == (3,)
     assert np.abs(xs - ref.x).max() < 1e-5, (xs, ref.x)
     assert np.abs(nlp.fg(res['x'][0], c)[1][3:]).max() < 1e-12            # the defining rows hold exactly at the result
+    # whatever a caller hands in for the auxiliaries, the solve starts on their rows: the same bits
+    junk = xf.copy()
+    junk[3:] = [7.0, -3.0]
+    again = port_binding.solve(tpl, p[None], junk[None], lb, ub, tol=1e-8, max_iter=200)
+    assert np.array_equal(again['x'], res['x']) and again['iters'][0] == res['iters'][0]
     # iterate for iterate the dense numpy statement of the solver (same projection of the auxiliaries)
     for iters in (2, 6):
         a = port_binding.solve(tpl, p[None], xf[None], lb, ub, tol=1e-12, max_iter=iters)
@@ -187,7 +192,62 @@ def test_template_file_round_trip_keeps_the_lifted_rows(tmp_path):
         assert fh.read(8) == b'OMGXTPL4'
 
 
+# ---- the AGV in closed loop ---------------------------------------------------------------------------------------------------
+# tests/golden/agv_loop.npz (generate_shim_fixtures.py `agv_loop`): the reference's Simulator (`execution/simulator.py:39-52`) on the body of
+# `examples/p2p_agv.py` with a fixed horizon, its own classes on the shim -- the solve before the loop and twelve updates, every one
+# from the reference's warm start (the shifted previous plan as x0, no multipliers: `problems/problem.py:57-60,113`), all thirteen
+# Solve_Succeeded on the host build (35-88 iterations).  Stored: p, x0, bounds and the result of every solve.
+def _loop():
+    d = np.load(os.path.join(GOLDEN, 'agv_loop.npz'))
+    tpl, _ = _load('agv_fixedT')
+    assert d['p'].shape == (13, tpl.n_par) and d['x0'].shape == (13, tpl.n_var) and (d['status'] == 0).all()
+    return tpl, d
+
+
+def test_host_build_reproduces_an_update_of_the_agv_loop():
+    from oracle import port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    tpl, d = _loop()
+    k = 7                                                                        # (the shortest solve of the loop)
+    res = port_binding.solve(tpl, d['p'][k][None], d['x0'][k][None], d['lbg'], d['ubg'], tol=1e-3, max_iter=500)
+    assert res['status'][0] == 0 and res['iters'][0] == d['iters'][k]
+    assert np.abs(res['x'][0] - d['x'][k]).max() < 1e-9
+    assert_kkt(NumpyNLP(tpl), tpl, d['p'][k], res['x'][0], res['lam_g'][0], 1e-2, ('agv loop', k))
+
+
 # ---- GPU -------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_the_agv_loop_as_one_batch_on_the_device():
+    """The thirteen solves of the closed loop as ONE batch through the C ABI (thirteen agents, each with the parameters and the
+    warm start of its update): every one succeeds, lands where the host build landed and satisfies the optimality conditions."""
+    import omgtools.backend as be
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    tpl, d = _loop()
+    nlp = NumpyNLP(tpl)
+    B = len(d['p'])
+    solver = be.BatchSolver(tpl, B, options=dict(tol=1e-3, max_iter=500))
+    try:
+        res = solver.solve(d['p'], d['x0'], lbg=d['lbg'], ubg=d['ubg'])
+        ms = solver.last_kernel_ms() if hasattr(solver, 'last_kernel_ms') else float('nan')
+    finally:
+        solver.close()
+    assert (res['status'] == 0).all(), res['status']
+    nv = tpl.n_var - tpl.n_lift
+    worst_x, worst_f = 0.0, 0.0
+    for k in range(B):
+        c = nlp.term_coefs(d['p'][k])
+        f, fh = nlp.fg(res['x'][k], c)[0], nlp.fg(d['x'][k], c)[0]
+        worst_f = max(worst_f, abs(f - fh) / (1 + abs(fh)))
+        worst_x = max(worst_x, np.abs(res['x'][k][:nv] - d['x'][k][:nv]).max())
+        assert_kkt(nlp, tpl, d['p'][k], res['x'][k], res['lam_g'][k], 1e-2, ('agv loop', k))
+    print('\nAGV loop on the device: iterations %s (host build %s); objective within %.1e, the caller\'s variables within %.1e of the host build'
+          % (res['iters'].tolist(), d['iters'].tolist(), worst_f, worst_x))
+    assert np.abs(res['iters'] - d['iters']).max() <= 10
+    assert worst_f < 1e-3 and worst_x < 1e-2
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ['bicycle_fixedT', 'agv_fixedT'])
 def test_lifted_classes_on_the_device(name):
@@ -234,8 +294,12 @@ def test_toy_on_the_device_matches_the_host_build():
     solver = be.BatchSolver(tpl, 1, options=dict(tol=1e-8, max_iter=200))
     try:
         res = solver.solve(p, xf[None], lbg=lb, ubg=ub)
+        junk = xf.copy()
+        junk[3:] = [7.0, -3.0]
+        again = solver.solve(p, junk[None], lbg=lb, ubg=ub)
     finally:
         solver.close()
     port = port_binding.solve(tpl, p, xf[None], lb, ub, tol=1e-8, max_iter=200)
     assert res['status'][0] == 0 and res['iters'][0] == port['iters'][0]
     assert np.abs(res['x'][0] - port['x'][0]).max() < 1e-9
+    assert np.array_equal(again['x'], res['x'])          # auxiliaries handed in off their rows: the same bits
