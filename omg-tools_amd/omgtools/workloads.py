@@ -242,8 +242,12 @@ def _fleet(name):
 
 def formation_holonomic(n_agents, rho=1.0):
     """Config 4 from its bundle: (problem view, updater view, father view, layout, {'p', 'x0', 'nbr'}).  (The room of
-    the x-update template grows with the fleet: one bundle per fleet size.)"""
+    the x-update template grows with the fleet: one bundle per fleet size; a fleet size without a committed bundle is built
+    by the front end -- `omgtools.scenarios`, the same numbers, tests/test_workload_bundles.py.)"""
     from .consensus import circular_neighbors
+    if not have('formation_holonomic_k10_%d' % n_agents):
+        from . import scenarios
+        return scenarios.formation_holonomic(n_agents, rho=rho)
     tpl, meta, problem, updater, lay = _fleet('formation_holonomic_k10_%d' % n_agents)
     P = fill_formation(tpl, lay, meta['obstacles'], n_agents, float(problem.options['horizon_time']), rho)
     P['nbr'] = circular_neighbors(n_agents)
@@ -252,6 +256,9 @@ def formation_holonomic(n_agents, rho=1.0):
 
 def rendezvous_holonomic(n_agents, seed=20240807 + 6, rho=2.0):
     from .consensus import circular_neighbors
+    if not have('rendezvous_holonomic_k10_%d' % n_agents):
+        from . import scenarios
+        return scenarios.rendezvous_holonomic(n_agents, seed=seed, rho=rho)
     tpl, meta, problem, updater, lay = _fleet('rendezvous_holonomic_k10_%d' % n_agents)
     P = fill_rendezvous(tpl, lay, meta['obstacles'], n_agents, seed, float(problem.options['horizon_time']), rho)
     P['nbr'] = circular_neighbors(n_agents)
