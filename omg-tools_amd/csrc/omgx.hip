@@ -324,7 +324,7 @@ static ipm_eval_kernel_t ipm_eval_kernel_gen(int mode, int wave_ok) {
     case omgx::WS_JAC_HBM: return ipm_eval_kernel<omgx::WS_JAC_HBM, false, GEN>;
     case omgx::WS_JAC_ONLY: return ipm_eval_kernel<omgx::WS_JAC_ONLY, true, GEN>;
     case omgx::WS_JAC_HV: return ipm_eval_kernel<omgx::WS_JAC_HV, true, GEN>;
-    case omgx::WS_ROOT_HBM: return ipm_eval_kernel<omgx::WS_ROOT_HBM, false, true>;      // (one instance: the general one serves every template)
+    case omgx::WS_ROOT_HBM: return ipm_eval_kernel<omgx::WS_ROOT_HBM, false, true>;      // (one instance: pick_mode hands mode 6 to general templates only)
     default: return ipm_eval_kernel<omgx::WS_ROWS_HBM, false, GEN>;
   }
 #endif
@@ -955,9 +955,10 @@ int pick_mode(const omgx::Dims& d, int kkt_doubles, size_t* lds_doubles, size_t*
     if (*lds_doubles * sizeof(double) <= (size_t)kLdsLimit) break;
   }
   if (mode <= omgx::WS_ROWS_HBM) return mode;
-  // the root block alone is too large for LDS: it stays in the slab (mode 6)
+  // the root block alone is too large for LDS: it stays in the slab (mode 6; compiled for the general instance only -- the
+  // templates that get here are the ones with lifted auxiliaries, hundreds of equality rows in the root)
   omgx::work_split(d, kkt_doubles, omgx::WS_ROOT_HBM, lds_doubles, hbm_doubles);
-  return *lds_doubles * sizeof(double) <= (size_t)kLdsLimit ? (int)omgx::WS_ROOT_HBM : (int)omgx::WS_MODES;
+  return (d.general && *lds_doubles * sizeof(double) <= (size_t)kLdsLimit) ? (int)omgx::WS_ROOT_HBM : (int)omgx::WS_MODES;
 }
 
 // The plan of a template for the workspace mode it gets: the spill modes store the leaf panels by columns
