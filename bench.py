@@ -317,6 +317,30 @@ def store_leg(mpc, problem, tpl, x0_init, p_init, n_steps, dev):
             'note': 'state / input / dinput / v_tot of every agent on 1001 samples, written by the solve kernel (A11 fused)'}
 
 
+def lifted_leg(n_agents):
+    """SURVEY 8(f)3 on the device: a class whose rows are products of more than four variable factors (the reference's AGV model,
+    `vehicles/agv.py:50`, written with lifted auxiliaries -- DESIGN.md 2 -- 381 variables / 2234 rows, workspace mode 6): the thirteen
+    solves of its closed loop tiled to a batch, cold solves from the reference's warm start.  One launch, timed by its own events."""
+    from omgtools.workloads import agv_loop
+    from omgtools.backend import BatchSolver
+    tpl, P = agv_loop(n_agents)
+    solver = BatchSolver(tpl, n_agents, options=dict(tol=1e-3, max_iter=500))
+    try:
+        solver.set_timing(True)
+        res = solver.solve(P['p'], P['x0'], lbg=P['lbg'], ubg=P['ubg'])
+        ms = solver.last_kernel_ms()
+        ws = solver.workspace()
+    finally:
+        solver.close()
+    its = np.asarray(res['iters'])
+    return {'class': 'AGV, fixed horizon (vehicles/agv.py:50): 381 variables (278 lifted auxiliaries), 2234 rows', 'agents': n_agents,
+            'solved_fraction': float((np.asarray(res['status']) == 0).mean()), 'mean_iters': float(its.mean()),
+            'same_iterations_as_host_build': bool(np.array_equal(its, P['iters_host'])), 'kernel_ms': ms,
+            'solves_per_s': n_agents / (ms * 1e-3), 'iterations_per_s': float(its.sum()) / (ms * 1e-3), 'workspace_mode': ws['mode'],
+            'lds_bytes_per_agent': ws['lds_bytes'],
+            'note': 'cold solves of the thirteen problems of the AGV closed loop, tiled; functional, not fast: the auxiliaries sit in a dense root of order 579 kept in the slab'}
+
+
 def rollout_leg(mpc, x0_init, p_init, n_steps, warmup, dev):
     """The same protocol -- cold solve, `warmup` steps, `n_steps` timed steps -- with the timed steps in ONE launch
     (`omgx_batch_rollout`): every agent runs its own predict / shift / solve loop without the barrier between the steps of
@@ -949,6 +973,10 @@ def main():
             out['rollout'] = rollout_leg(mpc, x0_init, p_init, args.steps, args.warmup, dev)
         except Exception as e:                            # (a second metric must never cost the headline line)
             out['rollout'] = {'error': repr(e)}
+        try:
+            out['lifted_class'] = lifted_leg(256)
+        except Exception as e:
+            out['lifted_class'] = {'error': repr(e)}
     if world == 1:
         # trajectory extraction (A11) against the HBM roofline, at the workload's batch and at 16x (the
         # 49 MB of one 1024-agent launch last ~10 us: launch-latency bound)

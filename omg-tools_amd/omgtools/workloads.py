@@ -265,6 +265,20 @@ def rendezvous_holonomic(n_agents, seed=20240807 + 6, rho=2.0):
     return problem, updater, problem.father, lay, P
 
 
+def agv_loop(n_agents):
+    """A class with lifted auxiliaries (template.py `_append_lifted`): the body of the reference's `examples/p2p_agv.py` with
+    a fixed horizon -- 381 variables (278 of them lifted), 2234 rows -- and the thirteen solves of its closed loop (the solve before the
+    loop and twelve updates of the reference's Simulator, each from the reference's warm start) tiled to `n_agents`:
+    (template, {'p', 'x0', 'lbg', 'ubg', 'iters_host'}).  The bundle is written from the fixtures the reference's own classes
+    produced on `omgx_shim` (tests/golden/generate_shim_fixtures.py; tests/test_workload_bundles.py compares them)."""
+    path = os.path.join(DATA_DIR, 'agv_fixedT_k5.npz')
+    tpl = NLPTemplate.from_npz(path)
+    d = np.load(path)
+    idx = np.arange(n_agents) % len(d['loop_p'])
+    return tpl, {'p': d['loop_p'][idx], 'x0': d['loop_x0'][idx], 'lbg': d['loop_lbg'], 'ubg': d['loop_ubg'],
+                 'iters_host': d['loop_iters'][idx]}
+
+
 def have(name):
     return os.path.exists(os.path.join(DATA_DIR, name + '.npz'))
 

@@ -86,3 +86,20 @@ def test_the_benchmark_path_imports_no_front_end_module():
             "bad = [m for m in %r if m in sys.modules]\n"
             "assert not bad, bad\n" % (os.path.join(ROOT, 'omg-tools_amd'), ROOT, FRONT_END))
     subprocess.check_call([sys.executable, '-c', code])
+
+
+def test_the_agv_bundle_is_the_fixture_of_the_reference_classes():
+    """`omgtools/data/agv_fixedT_k5.npz` (bench.py's `lifted_class` leg): the template and the closed-loop inputs the reference's own
+    AGV class produced on `omgx_shim` (tests/golden/agv_fixedT.npz, agv_loop.npz), array for array."""
+    from omgtools import workloads
+    from omgtools.template import NLPTemplate
+    gold = os.path.join(ROOT, 'tests', 'golden')
+    ref = NLPTemplate.from_npz(os.path.join(gold, 'agv_fixedT.npz'))
+    loop = np.load(os.path.join(gold, 'agv_loop.npz'))
+    tpl, P = workloads.agv_loop(26)
+    assert (tpl.n_var, tpl.n_con, tpl.n_par, tpl.n_lift) == (ref.n_var, ref.n_con, ref.n_par, ref.n_lift) == (381, 2234, 52, 278)
+    for k, v in ref.flat_arrays().items():
+        assert np.array_equal(np.asarray(v), np.asarray(tpl.flat_arrays()[k])), k
+    assert np.array_equal(tpl.lb, ref.lb) and np.array_equal(tpl.ub, ref.ub)
+    assert np.array_equal(P['p'][:13], loop['p']) and np.array_equal(P['p'][13:], loop['p'])
+    assert np.array_equal(P['x0'][:13], loop['x0']) and np.array_equal(P['lbg'], loop['lbg']) and np.array_equal(P['iters_host'][:13], loop['iters'])
