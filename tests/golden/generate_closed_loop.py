@@ -13,7 +13,7 @@ Per agent (64 seeded agents of the bench workload, `omgtools.workloads.holonomic
 Stored per step: the plan (all variables), its objective, the parameters the step was solved for, whether it crossed a knot.
 No number of the loop after step 0 comes from the product's algorithm; step 0 only takes its basin from it.
 
-Run from the repository root:  python tests/golden/generate_closed_loop.py [cfg2 | cfg3]   (1 min / about 10 min on 8 cores)"""
+Run from the repository root:  python tests/golden/generate_closed_loop.py [cfg2 | cfg3 | cfg5]   (1 min / about 10 min on 8 cores)"""
 import os
 import sys
 import time
@@ -26,7 +26,9 @@ sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
 sys.path.insert(0, ROOT)
 HERE = os.path.dirname(os.path.abspath(__file__))
 CONFIGS = {'cfg2': dict(workload='holonomic_p2p', agents=64, steps=25, chunk=2, slsqp=dict(maxiter=800)),
-           'cfg3': dict(workload='quadrotor_p2p', agents=8, steps=12, chunk=1, slsqp=dict(maxiter=1500, accept=(0, 8), viol_tol=1e-7))}
+           'cfg3': dict(workload='quadrotor_p2p', agents=8, steps=12, chunk=1, slsqp=dict(maxiter=1500, accept=(0, 8), viol_tol=1e-7)),
+           # (BASELINE config 5's class: Holonomic3D, K = 15, ten moving spheres -- 748 variables, 1812 rows; 8 agents x 18 updates, two crossings)
+           'cfg5': dict(workload='holonomic3d_p2p', agents=8, steps=18, chunk=1, slsqp=dict(maxiter=1500, accept=(0, 8), viol_tol=1e-7))}
 CFG = CONFIGS['cfg2']
 
 
