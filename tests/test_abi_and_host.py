@@ -226,3 +226,18 @@ def test_admm_table_keys_cover_the_full_period():
         assert min(abs(t_rel - q) for q in keys) < 1.5e-6
     with pytest.raises(ValueError):
         be.admm_table_keys(1.0, 0.1 * 2 ** 0.5)
+
+
+def test_sub_batch_sizes_follow_the_resident_workgroups():
+    """`omgtools.batch.split_bounds` (the per-step product path): contiguous, complete, sizes in quarters of the resident workgroups
+    with the larger sub-batches first; the even split when the number of slots is unknown or the batch is small."""
+    from omgtools.batch import split_bounds
+    sizes = lambda b: [hi - lo for lo, hi in b]
+    assert sizes(split_bounds(1024, 3, 512)) == [384, 384, 256]
+    assert sizes(split_bounds(1000, 3, 512)) == [384, 384, 232]
+    assert sizes(split_bounds(4096, 3, 512)) == [1408, 1408, 1280]
+    assert sizes(split_bounds(1024, 2, 512)) == [512, 512]
+    assert sizes(split_bounds(1024, 3)) == [342, 341, 341] and sizes(split_bounds(300, 3, 512)) == [100, 100, 100]
+    for B, n, slots in ((1024, 3, 512), (1000, 3, 512), (777, 4, 256), (5, 2, 512), (1500, 3, 512)):
+        b = split_bounds(B, n, slots)
+        assert b[0][0] == 0 and b[-1][1] == B and all(b[i][1] == b[i + 1][0] for i in range(n - 1)) and min(sizes(b)) >= 1

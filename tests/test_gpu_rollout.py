@@ -186,7 +186,7 @@ def test_back_to_back_rollouts_on_a_caller_stream():
 
 def test_the_per_step_product_path_picks_two_half_launches_for_two_rounds_of_workgroups():
     """`receding_horizon_batch`: one handle for a batch below two rounds of resident workgroups, three stream-ordered sub-batch
-    launches per step (342 + 341 + 341 agents) at 1024 agents (512 resident workgroups) -- with the plans of the single handle, bit
+    launches per step (384 + 384 + 256 agents: sizes in quarters of the resident workgroups, `split_bounds`) at 1024 agents (512 resident workgroups) -- with the plans of the single handle, bit
     for bit, also across the crossing."""
     import torch
     from omgtools import workloads
@@ -201,7 +201,7 @@ def test_the_per_step_product_path_picks_two_half_launches_for_two_rounds_of_wor
     problem, P = workloads.holonomic_p2p(n)
     rh = receding_horizon_batch(problem, P, device=dev, options=opts)
     assert isinstance(rh, StreamedP2P) and len(rh.parts) == PRODUCT_PATH_STREAMS == 3 and rh.B == n
-    assert [m.B for m in rh.parts] == [342, 341, 341]
+    assert [m.B for m in rh.parts] == [384, 384, 256]
     problem1, P1 = workloads.holonomic_p2p(n)
     one = receding_horizon_batch(problem1, P1, device=dev, n_streams=1, options=opts)
     assert isinstance(one, BatchP2P)
