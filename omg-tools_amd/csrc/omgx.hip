@@ -1173,7 +1173,7 @@ int build_batch(omgx_batch* b, const omgx_template* t) {
   UP(row_perm, plan.row_perm.size()); UP(cs_ptr, plan.cs_ptr.size()); UP(cs_rec, plan.cs_rec.size());
   UP(obj_ent, plan.obj_ent.size());
   UP(ka_rec, plan.ka_rec.size()); UP(kh_rec, plan.kh_rec.size()); UP(kg_rec, plan.kg_rec.size());
-  UP(ka_fix, plan.ka_fix.size()); UP(kg_fix, plan.kg_fix.size());
+  UP(ka_fix, plan.ka_fix.size()); UP(kg_fix, plan.kg_fix.size()); UP(kh_fix, plan.kh_fix.size());
   UP(rt_ell, plan.rt_ell.size()); UP(rt_glen, plan.rt_glen.size()); UP(jp_ell, plan.jp_ell.size()); UP(jp_glen, plan.jp_glen.size());
   UP(cs_ell, plan.cs_ell.size()); UP(cs_glen, plan.cs_glen.size()); UP(cs_col, plan.cs_col.size()); UP(cs_own, plan.cs_own.size());
   UP(jv_ell, plan.jv_ell.size()); UP(jv_own, plan.jv_own.size()); UP(jv_glen, plan.jv_glen.size());

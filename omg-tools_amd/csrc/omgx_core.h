@@ -69,6 +69,7 @@ struct Dims {
   int n_jv4, n_ja4;  // owners of the Jacobian item tables (four entries each): x-dependent entries, all entries
   int ka_len, kh_len, kg_len;   // records per owner bin (longest bin) of the pair / Hessian / Gershgorin passes
   int n_kafix, n_kgfix;         // targets whose run was cut (fix-up records)
+  int n_khfix;                  // the same for the Hessian items
   int side_off, dump_off;       // side slots / per-lane dump slots behind the KKT store
   int n_cs_own;      // owner threads of the column sums J'w (chunks of the columns)
   int kg_side_dinv;  // 1: the side sums of the Gershgorin pass live in w.dinv, 0: in the side slots behind the KKT store
@@ -154,6 +155,7 @@ struct Tables {   // read-only, shared by all agents (global memory)
   const int32_t* ka_rec;    // [ka_len][OMGX_NBIN][4] pair records {entry a, entry b, KKT address, row}
   const HItem* kh_rec;      // [kh_len][OMGX_NBIN] Hessian items (target = KKT address)
   const HItem* kg_rec;      // [kg_len][OMGX_NBIN] Gershgorin items (target = position, N + k = side slot k)
+  const int32_t* kh_fix;    // [n_khfix][3] the same for cut runs of Hessian items (after hess_bin)
   const int32_t* ka_fix;    // [n_kafix][3] {KKT address, first side slot, number of side slots}: address += the slots, in order
   const int32_t* kg_fix;    // [n_kgfix][3] the same for the Gershgorin sums (position)
 };
@@ -232,6 +234,7 @@ struct Opts {
 #define OMGX_SLOT_CAP    16      // monomials of a parameter slot one thread sums (setup); the rest of a longer slot: one wave
 #define OMGX_REC_BATCH   8       // records an owner loads at a time (all in flight together)
 #define OMGX_RUN_CAP     16      // longest run of records summed by one owner (longer runs are cut, see omgx_plan.h)
+#define OMGX_RUN_CAP_H   64      // the same for the Hessian items (only templates with lifted auxiliaries have such runs)
 #define OMGX_WAVE_ROWS   64      // register rows of a panel the wave-level routines take (lanes)
 #define OMGX_WAVE_COLS   40      // columns (registers per lane)
 
@@ -2163,6 +2166,20 @@ OMGX_FN void hess_bin(const Dims& d, const Tables& T, Work& w, int m, int bin, i
   hess_bin_t<C::general>(d, T, w, m, bin, dump);
 }
 
+// cut runs of Hessian items: the side slots are added to their entry, in order (after the owners' pass and a barrier;
+// ends with a barrier when there is anything to do)
+template <class C>
+OMGX_FN void hess_fix(const C& c, const Dims& d, const Tables& T, Work& w) {
+  if (d.n_khfix == 0) return;
+  OMGX_PFOR(i, d.n_khfix) {
+    const int32_t* f = T.kh_fix + 3 * i;
+    double a = w.kkt[f[0]];
+    for (int k = 0; k < f[2]; ++k) a += w.kkt[d.side_off + f[1] + k];
+    w.kkt[f[0]] = a;
+  }
+  c.sync();
+}
+
 // ---------------------------------------------------------------------------
 // the solve
 // ---------------------------------------------------------------------------
@@ -2595,6 +2612,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       kkt_rhs(c, d, T, w, t);
       tt_acc = use_t ? c.rsum(tt_acc) : 0.0;
       c.sync();
+      hess_fix(c, d, T, w);
       if (first_trial) {
         OMGX_PFOR(i, d.n_kgfix) {
           const int32_t* f = T.kg_fix + 3 * i;
@@ -3018,6 +3036,7 @@ OMGX_FN void ipm_eval(const C& c, const Dims& d, const Tables& T, Work& w, const
   c.sync();
   for (int bin = c.tid(); bin < d.n_owner; bin += c.nthr()) hess_bin<C>(d, T, w, m, bin, d.dump_off + (bin & 63));
   c.sync();
+  hess_fix(c, d, T, w);
 }
 
 }  // namespace omgx

@@ -46,7 +46,7 @@ struct HostPlan {
   // ---- owner-computes tables ----------------------------------------------------------------------
   std::vector<int32_t> je_ptr, jv_list, row_perm, cs_ptr, cs_rec, obj_ent;
   std::vector<JItem> je_item;
-  std::vector<int32_t> ka_rec, ka_fix, kg_fix;
+  std::vector<int32_t> ka_rec, ka_fix, kg_fix, kh_fix;
   std::vector<RowTerm> rt_ell;
   std::vector<JItem> jv_ell, ja_ell;
   std::vector<MonoRec> sl_ell;
@@ -780,6 +780,7 @@ struct HostPlan {
             }
           }
       }
+      const int n_side_pairs = n_side;      // (side slots of the pairs: consumed by their fix-up before the Hessian / Gershgorin passes run)
       // ---- Hessian items: one per (nonlinear term, variable pair), added to the store after the pairs
       struct HI { HItem it; int pa, pb; };
       std::vector<HI> his;
@@ -803,14 +804,19 @@ struct HostPlan {
         std::stable_sort(oh.begin(), oh.end(), [&](int x, int y) { return his[x].it.target < his[y].it.target; });
         std::vector<std::pair<int, std::vector<int>>> runs;
         for (int i : oh) { const int ad = his[i].it.target; if (runs.empty() || runs.back().first != ad) runs.push_back(std::make_pair(ad, std::vector<int>())); runs.back().second.push_back(i); }
-        // (no cutting here: at most a handful of terms meet in one Hessian entry; a cut run would need its own fix-up)
-        std::vector<Seg> segs;
-        for (auto& run : runs) { Seg g; g.target = run.first; g.items = run.second; segs.push_back(g); }
+        // (the benchmark classes: at most a handful of terms meet in one Hessian entry and nothing is cut.  Templates with
+        // lifted auxiliaries: thousands do -- an auxiliary that stands for a product spline meets every row it was substituted
+        // into --, one owner walked 14,520 records where the average has 1,500 (round 5): runs longer than OMGX_RUN_CAP_H are
+        // cut like the pairs' -- the first segment goes to the entry, the others to side slots (zero before the pass: the
+        // owners add to what they find), and kh_fix says which slots to add to which entry, in order)
+        std::vector<Seg> segs; cut(runs, segs, kh_fix, n_side, OMGX_RUN_CAP_H);
         std::vector<std::vector<std::pair<int, int>>> per; deal(segs, per);
         d.kh_len = ell_len(per);
         kh_rec.assign((size_t)OMGX_NBIN * std::max(1, d.kh_len), HItem{0.0, 0, -1, -1, -1, -1, 0});
         for (int bb = 0; bb < OMGX_NBIN; ++bb) for (size_t r = 0; r < per[bb].size(); ++r) {
-          HItem it = his[per[bb][r].first].it; it.target = per[bb][r].second;
+          HItem it = his[per[bb][r].first].it;
+          const int tg = per[bb][r].second;
+          it.target = tg <= -2 ? side0 + (-2 - tg) : tg;
           kh_rec[r * OMGX_NBIN + bb] = it;
         }
       }
@@ -851,12 +857,12 @@ struct HostPlan {
           cut(runs, sg, fx, ns, cap); deal(sg, pr);
           // (the side sums of this pass live in w.dinv [N] -- free between the dual residual and the factorisation -- or,
           // when they are more, in the side slots of the pairs, which the pair fix-up has consumed by then)
-          if (ns > d.N && ns > n_side) break;
+          if (ns > d.N && ns > n_side_pairs) break;      // (the slots behind them hold the cut runs of the Hessian items during that pass)
           if (per.empty() || ell_len(pr) < ell_len(per)) { segs = sg; kg_fix = fx; per = pr; n_side_g = ns; }
         }
         d.kg_side_dinv = n_side_g <= d.N ? 1 : 0;
         d.kg_len = ell_len(per);
-        if (getenv("OMGX_PLAN_DEBUG")) { size_t mx = 0; for (auto& v : per) mx = std::max(mx, v.size()); fprintf(stderr, "[plan] hessian items %zu, gershgorin records %zu (longest owner %zu), runs %zu, side slots %d (pairs %d), owners %d\n", his.size(), gis.size(), mx, runs.size(), n_side_g, n_side, owners); }
+        if (getenv("OMGX_PLAN_DEBUG")) { size_t mx = 0; for (auto& v : per) mx = std::max(mx, v.size()); fprintf(stderr, "[plan] hessian items %zu, gershgorin records %zu (longest owner %zu), runs %zu, side slots %d (pairs %d, with the Hessian's %d), owners %d\n", his.size(), gis.size(), mx, runs.size(), n_side_g, n_side_pairs, n_side, owners); }
         kg_rec.assign((size_t)OMGX_NBIN * std::max(1, d.kg_len), HItem{0.0, 0, -1, -1, -1, -1, 0});
         for (int bb = 0; bb < OMGX_NBIN; ++bb) for (size_t r = 0; r < per[bb].size(); ++r) {
           HItem it = gis[per[bb][r].first].it;
@@ -865,7 +871,8 @@ struct HostPlan {
           kg_rec[r * OMGX_NBIN + bb] = it;
         }
       }
-      d.n_kafix = (int)ka_fix.size() / 3; d.n_kgfix = (int)kg_fix.size() / 3;
+      d.n_kafix = (int)ka_fix.size() / 3; d.n_kgfix = (int)kg_fix.size() / 3; d.n_khfix = (int)kh_fix.size() / 3;
+      if (kh_fix.empty()) kh_fix.assign(3, 0);
       if (ka_fix.empty()) ka_fix.assign(3, 0);
       if (kg_fix.empty()) kg_fix.assign(3, 0);
       d.side_off = side0;
@@ -874,7 +881,7 @@ struct HostPlan {
                                                       //   whatever is not the end of a segment; distinct banks)
       d.dump_off = side0 + n_side;
       T.ka_rec = ka_rec.data(); T.kh_rec = kh_rec.data(); T.kg_rec = kg_rec.data();
-      T.ka_fix = ka_fix.data(); T.kg_fix = kg_fix.data();
+      T.ka_fix = ka_fix.data(); T.kg_fix = kg_fix.data(); T.kh_fix = kh_fix.data();
     }
     if (pair4.empty()) pair4.assign(4, 0);
     T.pair4 = pair4.data();
