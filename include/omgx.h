@@ -164,6 +164,13 @@ typedef struct omgx_options {
                            max_soc, the component replaced behind `basics/optilayer.py:60`); 0: plain backtracking.  Every template
                            class: the register-resident wave routines where the KKT panels fit them (omgx_plan_info.wave_path),
                            the blocked second solve elsewhere (spill modes included) */
+  int32_t hess_approx;         /* (version 7) 0 (default): the exact Lagrangian Hessian.  1: the Hessian without the curvature of the rows (objective
+                           Hessian + J' Sigma J), damped by a Levenberg-Marquardt weight that follows the accepted step length -- the
+                           analogue of 'ipopt.hessian_approximation': 'limited-memory', which the reference's own examples of the
+                           nonholonomic classes set (`examples/p2p_dubins.py:42`, `p2p_agv.py:43`); omgtools.backend maps that option
+                           onto it.  Linear convergence (hundreds of iterations), but phase I of these classes finishes:
+                           `examples/p2p_dubins.py` as shipped.  Honoured by templates on the general kernel instance (quartic terms,
+                           cos / sin atoms, lifted auxiliaries); ignored by the others */
 } omgx_options;
 
 typedef struct omgx_batch omgx_batch;

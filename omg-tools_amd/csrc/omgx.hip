@@ -1391,7 +1391,7 @@ int omgx_template_block(const omgx_template* tpl, int32_t kind, const char* name
 void omgx_default_options(omgx_options* o) {
   o->tol = 1e-3; o->max_iter = 300; o->mu_init = 0.1; o->kappa_push = 1.0;
   o->nu_init = 100.0; o->scale_gmax = 100.0; o->warm_start = 0; o->kappa_warm = 1e-3;
-  o->dw_leaf_ratio_cold = 1.0; o->warm_mu_factor = 1.0; o->warm_z_floor = 0.1; o->warm_z_cap = 0.01; o->max_soc = 1;
+  o->dw_leaf_ratio_cold = 1.0; o->warm_mu_factor = 1.0; o->warm_z_floor = 0.1; o->warm_z_cap = 0.01; o->max_soc = 1; o->hess_approx = 0;
 }
 
 int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device, omgx_batch** out) {
@@ -1406,7 +1406,7 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
   omgx_batch* b = new omgx_batch();
   b->device = device; b->n_agents = n_agents;
   omgx_options o; omgx_default_options(&o);
-  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm, o.dw_leaf_ratio_cold, 0, o.warm_mu_factor, o.warm_z_floor, o.warm_z_cap, o.max_soc};
+  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm, o.dw_leaf_ratio_cold, 0, o.warm_mu_factor, o.warm_z_floor, o.warm_z_cap, o.max_soc, o.hess_approx};
   ExpandedTemplate ex;
   const bool ranged = expand_range_rows(tpl, ex);
   b->n_con_user = tpl->n_con; b->n_range = ranged ? (int)ex.src.size() : 0;
@@ -1491,7 +1491,7 @@ int omgx_batch_set_options(omgx_batch* b, const omgx_options* o) {
   if (!b || !o || !(o->tol > 0) || o->max_iter < 0) { g_err = "bad options"; return OMGX_E_INVALID; }
   b->opts = {o->tol, o->max_iter, o->mu_init, o->kappa_push, o->nu_init, o->scale_gmax, o->warm_start, o->kappa_warm,
              o->dw_leaf_ratio_cold > 0 ? o->dw_leaf_ratio_cold : 1.0, 0, o->warm_mu_factor >= 0 ? o->warm_mu_factor : 0.0,
-             o->warm_z_floor >= 0 ? o->warm_z_floor : 0.0, o->warm_z_cap >= 0 ? o->warm_z_cap : 0.0, o->max_soc > 0 ? 1 : 0};
+             o->warm_z_floor >= 0 ? o->warm_z_floor : 0.0, o->warm_z_cap >= 0 ? o->warm_z_cap : 0.0, o->max_soc > 0 ? 1 : 0, o->hess_approx > 0 ? 1 : 0};
   return OMGX_OK;
 }
 

@@ -170,6 +170,7 @@ struct Opts {
   double warm_z_floor;         // warm starts: multipliers lifted to max(OMGX_WARM_ZMIN, min(warm_z_floor * tol, warm_z_cap * tol / slack))
   double warm_z_cap;           // (0: no cap)
   int max_soc;                 // 1: a rejected first trial of the line search is answered by a second-order correction (every template class: kkt_solve2_wave / kkt_solve2)
+  int hess_approx;             // 1: no constraint curvature in the Hessian, damping driven by the accepted step length (general instances; include/omgx.h)
 };
 
 // fixed constants of the iteration (same values in oracle/ipm_numpy.py DEFAULTS)
@@ -2328,6 +2329,14 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // a warm start also inherits the inertia correction the previous solve of this agent ended with
   // (first factorisation at that value instead of climbing 0, 1e-4, 1e-3, ... again)
   double dw_last = c.uni((warm && dw_prev > 0.0) ? dw_prev : 0.0), t_check = t;
+  // Round 5: `hess_approx` (the reference's examples of the nonholonomic classes ask IPOPT for a limited-memory Hessian,
+  // `examples/p2p_dubins.py:42`, `p2p_agv.py:43`: their authors did not trust the exact one there).  The analogue here: the
+  // Lagrangian Hessian WITHOUT the curvature of the rows (objective Hessian + J' Sigma J: positive semidefinite, no inertia
+  // trouble however large the multipliers of phase I), damped by `lm` -- a Levenberg-Marquardt weight driven by the accepted
+  // step length: x 4 after a step cut below a quarter, / 2 after a full one.  Linear convergence (hundreds of iterations), but
+  // phase I no longer drowns in an inertia correction of 1e6.  Compiled into the general instances only.
+  const bool gn = C::general ? (o.hess_approx != 0) : false;
+  double lm = 1.0;
   int dw_hold = dw_last > 0.0 ? 1 : 0, dw_backoff = 1;   // inertia-correction tracking (see the factorisation loop)
   // cold starts may damp the leaf (hyperplane) variables less and the root (trajectory) variables more
   // than dw (same product: the same bilinear negative curvature is covered); warm starts use dw on both
@@ -2517,7 +2526,8 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     OMGX_PFOR(q, N) w.xt[q] = 0.0;
     // weight of every row in the Lagrangian Hessian (multiplier x signed scale): one read per Hessian item instead of
     // three (w.ht -- 1/s during the residual phase -- is free until the line search)
-    OMGX_PFOR(r, m) w.ht[r] = (w.rtype[r] != ROW_FREE) ? w.z[r] * w.rho[r] : 0.0;
+    OMGX_PFOR(r, m) w.ht[r] = (w.rtype[r] != ROW_FREE && !gn) ? w.z[r] * w.rho[r] : 0.0;
+    if (gn && dw < lm) dw = lm;
     for (;;) {
       OMGX_PFOR(i, kkt_doubles) w.kkt[i] = 0.0;
       c.sync();
@@ -2630,7 +2640,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       // normal operation never pays the reduction) is taken back to it -- a knot-crossing step whose multipliers blew up for
       // one iteration climbed to 6e4 and then walked down by thirds for ten iterations with g_max = 0.3 all along.  Not after
       // a failed line search: that retry WANTS the heavier, steepest-descent-like direction.
-      if (first_trial && ls_fail == 0 && dw > OMGX_DW_CLAMP_FROM) {
+      if (first_trial && ls_fail == 0 && dw > OMGX_DW_CLAMP_FROM && !gn) {
         gcap = gersh_cap(c, N, T, w, reg_root, reg_leaf);
         if (dw > gcap) dw = gcap;
       }
@@ -2977,6 +2987,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
       }
       status = 4; break;
     }
+    if (gn) { if (alpha < 0.25) lm = fmin(lm * 4.0, 1e8); else if (alpha >= 1.0) lm = fmax(lm * 0.5, 1e-6); }
     ls_fail = 0;
     full_steps = (alpha >= 1.0 && alpha == a_p) ? full_steps + 1 : 0;      // (accepted at the first trial, not cut by the boundary)
     // ---- accept --------------------------------------------------------------------

@@ -57,7 +57,7 @@ class COptions(C.Structure):
     _fields_ = [('tol', C.c_double), ('max_iter', C.c_int32), ('mu_init', C.c_double),
                 ('kappa_push', C.c_double), ('nu_init', C.c_double), ('scale_gmax', C.c_double),
                 ('warm_start', C.c_int32), ('kappa_warm', C.c_double),
-                ('dw_leaf_ratio_cold', C.c_double), ('warm_mu_factor', C.c_double), ('warm_z_floor', C.c_double), ('warm_z_cap', C.c_double), ('max_soc', C.c_int32)]
+                ('dw_leaf_ratio_cold', C.c_double), ('warm_mu_factor', C.c_double), ('warm_z_floor', C.c_double), ('warm_z_cap', C.c_double), ('max_soc', C.c_int32), ('hess_approx', C.c_int32)]
 
 
 class CRolloutSpec(C.Structure):
@@ -72,7 +72,7 @@ class CRolloutSpec(C.Structure):
 
 DEFAULT_OPTIONS = dict(tol=1e-3, max_iter=300, mu_init=0.1, kappa_push=1.0,
                        nu_init=100.0, scale_gmax=100.0, warm_start=0, kappa_warm=1e-3,
-                       dw_leaf_ratio_cold=1.0, warm_mu_factor=1.0, warm_z_floor=0.1, warm_z_cap=0.01, max_soc=1)
+                       dw_leaf_ratio_cold=1.0, warm_mu_factor=1.0, warm_z_floor=0.1, warm_z_cap=0.01, max_soc=1, hess_approx=0)
 
 
 def make_options(**kw):
@@ -90,6 +90,10 @@ def options_from_problem(options):
         kw['tol'] = float(ipopt['ipopt.tol'])
     if 'ipopt.max_iter' in ipopt:
         kw['max_iter'] = int(ipopt['ipopt.max_iter'])
+    # (`examples/p2p_dubins.py:42`, `p2p_agv.py:43` ask IPOPT for a limited-memory Hessian on the nonholonomic classes: here the
+    # Hessian without the curvature of the rows, damped by the accepted step length -- include/omgx.h `hess_approx`)
+    if ipopt.get('ipopt.hessian_approximation') == 'limited-memory':
+        kw['hess_approx'] = 1
     kw.update(options.get('omgx', {}))
     return kw
 

@@ -314,6 +314,8 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
     dw_hold, dw_backoff = 0, 1
     status, it, nfact = 1, 0, 0
     ls_fail, full_steps = 0, 0
+    # (omgx_core.h `hess_approx`: no constraint curvature in the Hessian, a damping weight that follows the accepted step length)
+    gn, lm = bool(o.get('hess_approx', 0)), 1.0
     N = n + 1                      # (x, t)
     t_check = t
     # inertia correction acts on the variables that appear in a nonlinear term only: the rows
@@ -399,9 +401,10 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         lam[iH] = sig * z
         lam[iE] = y
         H = np.zeros((N, N))
-        H[:n, :n] = nlp.hess(x, lam * rho, c)
+        lam_h = np.zeros_like(lam) if gn else lam
+        H[:n, :n] = nlp.hess(x, lam_h * rho, c)
         # no variable is damped more than diagonal dominance of the Lagrangian Hessian needs
-        gersh = np.r_[nlp.hess_gershgorin(x, lam * rho, c), 0.0]
+        gersh = np.r_[nlp.hess_gershgorin(x, lam_h * rho, c), 0.0]
         Sig = z / s
         M = H + Jh.T @ (Sig[:, None] * Jh)
         if use_t:
@@ -421,6 +424,8 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         else:
             dw = dw_last * o['dw_dec']
             decreasing = True
+        if gn and dw < lm:
+            dw = lm
         tries = 0
         lv = np.asarray(getattr(nlp, 'leaf_vars', []), dtype=np.int64)
         # (warm starts only, like the kernel)
@@ -444,7 +449,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         # that value, and a correction carried over that exceeds it (> dw_clamp_from) is taken back to it; not after a failed
         # line search (that retry wants the heavier direction)
         gcap = 1.01 * (np.max(gersh[nl] / reg[nl]) if nl.any() else 0.0) + o['dw_first']
-        if ls_fail == 0 and dw > o.get('dw_clamp_from', 1.0):
+        if ls_fail == 0 and dw > o.get('dw_clamp_from', 1.0) and not gn:
             dw = min(dw, gcap)
 
         def escalated(v, floor_v):
@@ -600,6 +605,8 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                 continue
             status = 4
             break
+        if gn:
+            lm = min(lm * 4.0, 1e8) if alpha < 0.25 else (max(lm * 0.5, 1e-6) if alpha >= 1.0 else lm)
         ls_fail = 0
         full_steps = full_steps + 1 if (alpha >= 1.0 and alpha == a_p) else 0
         x, t, s, f, h, cE = xt, tt, st, ft, ht, cEt

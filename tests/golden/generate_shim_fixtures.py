@@ -26,7 +26,7 @@ velocity divides by T).  `omgx_shim` writes such an expression with auxiliary va
 xs carries the caller's variables extended by the auxiliaries, gs the REFERENCE's g at the caller's variables (defining rows: 0).
 x_slsqp: SLSQP on the caller's own problem (oracle/slsqp_numpy.py `solve_slsqp_reduced`) where it converges.
 
-Run in the build container:  python tests/golden/generate_shim_fixtures.py [dubins | dubins_subst | revolving_door | bicycle | agv | agv_loop | dubins_freeT | trailer]"""
+Run in the build container:  python tests/golden/generate_shim_fixtures.py [dubins | dubins_subst | revolving_door | bicycle | agv | agv_loop | dubins_freeT | dubins_shipped | trailer]"""
 import os
 import subprocess
 import sys
@@ -104,6 +104,10 @@ if __name__ == '__main__':
         make('p2p_agv', 'agv_fixedT.npz')
     if 'agv_loop' in which:
         make_loop('p2p_agv', 'agv_loop.npz', 12)
+    if 'dubins_shipped' in which:
+        # `examples/p2p_dubins.py` exactly as shipped: substituted velocity splines AND a free end time (the example asks IPOPT for a
+        # limited-memory Hessian: the solves of the tests set `hess_approx`)
+        make('p2p_dubins', 'dubins_shipped.npz', subst='1', freeT='1', slsqp=False)
     if 'dubins_freeT' in which:
         make('p2p_dubins', 'dubins_freeT.npz', freeT='1', slsqp=False)
     if 'trailer' in which:

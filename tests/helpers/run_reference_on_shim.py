@@ -74,6 +74,10 @@ elif which == 'p2p_dubins':
     environment.add_obstacle(Obstacle({'position': [1., 1.]}, shape=Circle(0.5),
                                       simulation={'trajectories': trajectories}))
     problem = Point2point(vehicle, environment, freeT=os.environ.get('DUBINS_FREET', '0') == '1')
+    if os.environ.get('DUBINS_FREET', '0') == '1':
+        # (examples/p2p_dubins.py:41-42: "extra solver settings which may improve performance"; max_iter: IPOPT's default, which the
+        # reference leaves in place -- this package's own default is 300)
+        problem.set_options({'solver_options': {'ipopt': {'ipopt.hessian_approximation': 'limited-memory', 'ipopt.max_iter': 3000}}})
     vehicle.problem = problem
     target = [3., 3., 0.]
 elif which in ('p2p_trailer', 'p2p_bicycle', 'p2p_agv'):

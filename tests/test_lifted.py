@@ -104,7 +104,9 @@ def test_the_library_refuses_a_lifted_row_that_reads_a_later_auxiliary():
 CLASSES = {'bicycle_fixedT': dict(shape=(293, 854, 25), n_lift=208, levels=3),
            'agv_fixedT': dict(shape=(381, 2234, 52), n_lift=278, levels=3),
            'dubins_freeT': dict(shape=(111, 394, 19), n_lift=76, levels=11),
-           'trailer_freeT': dict(shape=(168, 1896, 13), n_lift=127, levels=11)}
+           'trailer_freeT': dict(shape=(168, 1896, 13), n_lift=127, levels=11),
+           # `examples/p2p_dubins.py` exactly as shipped: substituted velocity splines (118 two-sided rows) AND a free end time
+           'dubins_shipped': dict(shape=(77, 362, 19), n_lift=16, levels=10)}
 
 
 def _load(name):
@@ -192,6 +194,49 @@ def test_template_file_round_trip_keeps_the_lifted_rows(tmp_path):
         assert fh.read(8) == b'OMGXTPL4'
 
 
+# ---- `examples/p2p_dubins.py` as shipped ---------------------------------------------------------------------------------------
+# The example asks IPOPT for a limited-memory Hessian (`examples/p2p_dubins.py:41-42`); `omgtools.backend.options_from_problem` maps
+# that onto `hess_approx` (include/omgx.h: the Hessian without the curvature of the rows, damped by the accepted step length).  With
+# the exact Hessian phase I of this problem drowns in an inertia correction of 4e6 and is given up at t = 0.25; with
+# the option the first solve of the reference's Simulator -- and its next six updates, HISTORY.md -- end in Solve_Succeeded.
+def test_the_reference_option_for_a_limited_memory_hessian_is_mapped():
+    import omgtools.backend as be
+    kw = be.options_from_problem({'solver': 'ipopt', 'solver_options': {'ipopt': {'ipopt.hessian_approximation': 'limited-memory',
+                                                                                  'ipopt.tol': 1e-4}}})
+    assert kw['hess_approx'] == 1 and kw['tol'] == 1e-4
+    assert 'hess_approx' not in be.options_from_problem({'solver': 'ipopt', 'solver_options': {'ipopt': {'ipopt.tol': 1e-3}}})
+    assert be.make_options().hess_approx == 0 and be.make_options(hess_approx=1).hess_approx == 1
+
+
+def _check_shipped(tpl, d, res, tol):
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt
+    nlp = NumpyNLP(tpl)
+    assert res['status'][0] == 0, res['status']
+    f, g = nlp.fg(res['x'][0], nlp.term_coefs(d['p0']))
+    nl = tpl.n_lift
+    assert np.abs(g[tpl.n_con - nl:]).max() < 1e-11
+    assert (g - tpl.ub).max() < 10 * tol and (tpl.lb - g).max() < 10 * tol       # (inside every tube of the substituted model)
+    assert_kkt(nlp, tpl, d['p0'], res['x'][0], res['lam_g'][0], 10 * tol, 'dubins_shipped')
+    T = res['x'][0][tpl.entry_range('p2p0', 'T', 'var')[0]]
+    assert 6.0 < T < 10.5 and abs(f - T) < 1e-9                                 # (the objective is the motion time)
+    return f
+
+
+def test_host_build_solves_the_dubins_example_as_shipped():
+    from oracle import port_binding
+    tpl, d = _load('dubins_shipped')
+    two_sided = np.isfinite(tpl.lb) & np.isfinite(tpl.ub) & (tpl.lb < tpl.ub)
+    assert two_sided.sum() == 118
+    x, lb, ub = _extended(tpl, d)
+    res = port_binding.solve(tpl, d['p0'][None], x[None], lb, ub, tol=1e-3, max_iter=3000, hess_approx=1)
+    assert res['iters'][0] < 1200, res['iters']
+    _check_shipped(tpl, d, res, 1e-3)
+    # the exact Hessian on the same problem: phase I is given up (the state of the art of this solver)
+    exact = port_binding.solve(tpl, d['p0'][None], x[None], lb, ub, tol=1e-3, max_iter=3000)
+    assert exact['status'][0] == 2
+
+
 # ---- the AGV in closed loop ---------------------------------------------------------------------------------------------------
 # tests/golden/agv_loop.npz (generate_shim_fixtures.py `agv_loop`): the reference's Simulator (`execution/simulator.py:39-52`) on the body of
 # `examples/p2p_agv.py` with a fixed horizon, its own classes on the shim -- the solve before the loop and twelve updates, every one
@@ -217,6 +262,25 @@ def test_host_build_reproduces_an_update_of_the_agv_loop():
 
 
 # ---- GPU -------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_the_dubins_example_as_shipped_on_the_device():
+    import omgtools.backend as be
+    from oracle import port_binding
+    tpl, d = _load('dubins_shipped')
+    x, lb, ub = _extended(tpl, d)
+    solver = be.BatchSolver(tpl, 2, options=dict(tol=1e-3, max_iter=3000, hess_approx=1))
+    try:
+        res = solver.solve(np.repeat(d['p0'][None], 2, axis=0), np.repeat(x[None], 2, axis=0), lbg=lb, ubg=ub)
+    finally:
+        solver.close()
+    assert np.array_equal(res['x'][0], res['x'][1])
+    f = _check_shipped(tpl, d, res, 1e-3)
+    port = port_binding.solve(tpl, d['p0'][None], x[None], lb, ub, tol=1e-3, max_iter=3000, hess_approx=1)
+    print('\ndubins as shipped: HIP %d iterations, host build %d; T = %.6f / %.6f' % (res['iters'][0], port['iters'][0], f,
+                                                                                    port['x'][0][tpl.entry_range('p2p0', 'T', 'var')[0]]))
+    assert abs(f - port['x'][0][tpl.entry_range('p2p0', 'T', 'var')[0]]) < 2e-2
+
+
 @pytest.mark.gpu
 def test_the_agv_loop_as_one_batch_on_the_device():
     """The thirteen solves of the closed loop as ONE batch through the C ABI (thirteen agents, each with the parameters and the
