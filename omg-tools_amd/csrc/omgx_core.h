@@ -2342,11 +2342,7 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   // than dw (same product: the same bilinear negative curvature is covered); warm starts use dw on both
     const double reg_leaf = warm ? 1.0 : o.dw_leaf_ratio_cold, reg_root = warm ? 1.0 : 1.0 / o.dw_leaf_ratio_cold;
   int it = 0, status = 1, ls_fail = 0, full_steps = 0;
-#ifdef OMGX_EXP_COLD_NU
-  const double nu_stall_max = OMGX_EXP_COLD_NU;
-#else
   const double nu_stall_max = warm ? OMGX_NU_MAX : 0.0;     // see the stall test in the loop
-#endif
   OMGX_TOC(PH_S_INIT);
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
   if (c.tid() == 0) c.prof[PH_SETUP] += c.prof[PH_S_DESC] + c.prof[PH_S_PARAMS] + c.prof[PH_S_JAC0] + c.prof[PH_S_CLASS] + c.prof[PH_S_INIT];

@@ -652,16 +652,40 @@ def save_admm_tables(path, layout, horizon_time, knot_time, update_time, sample_
     return path
 
 
+def second_attempt(solve, set_options, opts, enabled, p, x0, lbg, ubg):
+    """One solve of the single-agent solver object.  A solve that ends in Infeasible_Problem_Detected -- phase I given up -- is taken
+    once more from the same point with `hess_approx` (include/omgx.h: the Hessian without the curvature of the rows, damped by the
+    accepted step length; up to IPOPT's default of 3000 iterations): where IPOPT would enter its restoration phase.  Honoured by
+    templates on the general kernel instance; the others solve twice to the same end.  The iteration count reported is the sum."""
+    res = solve(p, x0, lbg, ubg)
+    if not enabled or int(res['status'][0]) != 2 or opts.get('hess_approx'):
+        return res
+    max_iter = int(opts.get('max_iter', DEFAULT_OPTIONS['max_iter']))
+    set_options(**dict(opts, hess_approx=1, max_iter=max(max_iter, 3000)))
+    try:
+        again = solve(p, x0, lbg, ubg)
+    finally:
+        set_options(**dict(opts, hess_approx=0, max_iter=max_iter))      # (set_options merges: the two keys are put back by name)
+    if int(again['status'][0]) == 0:
+        again['iters'] = again['iters'] + res['iters']
+        return again
+    return res
+
+
 class NlpSolver(object):
     """Single-agent solver object with the reference's `nlpsol` call shape."""
 
     def __init__(self, template, options):
         self.template = template
-        self.batch = BatchSolver(template, 1, options=options_from_problem(options))
+        self.opts = options_from_problem(options)
+        # (options['omgx']['hess_fallback'] = False switches the second attempt off)
+        self.fallback = bool(self.opts.pop('hess_fallback', True))
+        self.batch = BatchSolver(template, 1, options=self.opts)
         self._stats = {'return_status': 'Not_Solved', 'iter_count': 0}
 
     def __call__(self, x0=None, p=None, lbg=None, ubg=None, **kwargs):
-        res = self.batch.solve(np.asarray(p), np.asarray(x0), np.asarray(lbg), np.asarray(ubg))
+        res = second_attempt(self.batch.solve, self.batch.set_options, self.opts, self.fallback,
+                             np.asarray(p), np.asarray(x0), np.asarray(lbg), np.asarray(ubg))
         self._stats = {'return_status': STATUS_STRINGS[int(res['status'][0])],
                        'iter_count': int(res['iters'][0])}
         return {'x': res['x'][0], 'lam_g': res['lam_g'][0]}

@@ -18,8 +18,18 @@ class PortNlpSolver(object):
         from oracle import port_binding
         from oracle.port_binding import _backend
         STATUS_STRINGS = _backend().STATUS_STRINGS
-        res = port_binding.solve(self.template, np.asarray(p), np.asarray(x0), np.asarray(lbg), np.asarray(ubg),
-                                 **self.options)
+        # (the product's solver object takes a solve that gives up phase I once more with `hess_approx`: omgtools.backend.second_attempt)
+        state = dict(self.options)
+        fallback = bool(state.pop('hess_fallback', True))
+        base = dict(state)
+
+        def solve(p_, x_, lb_, ub_):
+            return port_binding.solve(self.template, p_, x_, lb_, ub_, **state)
+
+        def set_options(**kw):
+            state.clear()
+            state.update(kw)
+        res = _backend().second_attempt(solve, set_options, base, fallback, np.asarray(p), np.asarray(x0), np.asarray(lbg), np.asarray(ubg))
         self._stats = {'return_status': STATUS_STRINGS[int(res['status'][0])], 'iter_count': int(res['iters'][0])}
         import os
         if os.environ.get('PORT_SOLVER_DUMP'):            # (the inputs and the result of every solve: fixtures of closed loops, tests/golden/generate_shim_fixtures.py)

@@ -367,3 +367,41 @@ def test_toy_on_the_device_matches_the_host_build():
     assert res['status'][0] == 0 and res['iters'][0] == port['iters'][0]
     assert np.abs(res['x'][0] - port['x'][0]).max() < 1e-9
     assert np.array_equal(again['x'], res['x'])          # auxiliaries handed in off their rows: the same bits
+
+
+# ---- the solver object's second attempt ------------------------------------------------------------------------------------------
+def test_the_solver_object_takes_a_given_up_phase_one_again_with_the_convexified_hessian():
+    """`omgtools.backend.second_attempt` (the drop-in `nlpsol` object, B = 1): the unsubstituted free-end-time Dubins problem -- whose
+    terminal row has a vanishing gradient at the reference's guess -- ends in Infeasible_Problem_Detected with the exact Hessian and
+    in Solve_Succeeded at the second attempt; switched off, the first verdict stands.  (Host twin of the object: tests/port_solver.py.)"""
+    import port_solver
+    tpl, d = _load('dubins_freeT')
+    x, lb, ub = _extended(tpl, d)
+    options = {'solver': 'ipopt', 'solver_options': {'ipopt': {'ipopt.tol': 1e-3}}}
+    solver, _ = port_solver.create_nlp(tpl, options)
+    res = solver(x0=x, p=d['p0'], lbg=lb, ubg=ub)
+    st = solver.stats()
+    assert st['return_status'] == 'Solve_Succeeded' and 1000 < st['iter_count'] < 2500, st
+    _check_solution('dubins_freeT', tpl, dict(d, slsqp_ok=0), {'x': res['x'][None], 'lam_g': res['lam_g'][None], 'status': np.zeros(1, int)}, 1e-3)
+    off, _ = port_solver.create_nlp(tpl, dict(options, omgx={'hess_fallback': False}))
+    off(x0=x, p=d['p0'], lbg=lb, ubg=ub)
+    assert off.stats() == {'return_status': 'Infeasible_Problem_Detected', 'iter_count': 40}
+
+
+@pytest.mark.gpu
+def test_the_second_attempt_on_the_device():
+    import omgtools.backend as be
+    tpl, d = _load('dubins_freeT')
+    x, lb, ub = _extended(tpl, d)
+    solver = be.NlpSolver(tpl, {'solver': 'ipopt', 'solver_options': {'ipopt': {'ipopt.tol': 1e-3}}})
+    try:
+        res = solver(x0=x, p=d['p0'], lbg=lb, ubg=ub)
+        st = solver.stats()
+        assert st['return_status'] == 'Solve_Succeeded' and 1000 < st['iter_count'] < 2500, st
+        _check_solution('dubins_freeT', tpl, dict(d, slsqp_ok=0), {'x': np.asarray(res['x'])[None], 'lam_g': np.asarray(res['lam_g'])[None],
+                                                                   'status': np.zeros(1, int)}, 1e-3)
+        # the handle is back on the exact Hessian afterwards: the same call gives the same answer by the same route
+        again = solver(x0=x, p=d['p0'], lbg=lb, ubg=ub)
+        assert solver.stats() == st and np.array_equal(np.asarray(again['x']), np.asarray(res['x']))
+    finally:
+        solver.batch.close()
