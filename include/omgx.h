@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define OMGX_VERSION 7
+#define OMGX_VERSION 8
 #define OMGX_TERM_VARS 4      /* variables per term (version 3: three) */
 
 /* error codes */
@@ -295,6 +295,14 @@ int  omgx_batch_set_launch_events(omgx_batch* b, void* start_event, void* stop_e
  * a timed solve has run again; a launch that carried the caller's pair is not timed by the handle's. */
 int  omgx_batch_set_timing(omgx_batch* b, int32_t on);
 int  omgx_batch_last_kernel_ms(omgx_batch* b, double* ms);
+/* (version 8) What CasADi's `nlpsol` does at the head of every call behind `problems/problem.py:113` -- evaluate the constraint
+ * functions and their Jacobian at x0 -- and IPOPT's own start-up (gradient-based scaling `nlp_scaling_method`, initial slacks and
+ * multipliers) run as ONE launch for the whole batch ahead of the solve kernel (ipm_prepare_kernel: basis evaluation at t / T,
+ * coefficient slots, Jacobian and rows at x0, row classification and scaling, warm-start multipliers; many workgroups per CU) --
+ * on by default; omgx_batch_set_prepare(b, 0) makes every solve do its own setup inside the solve kernel again (the same
+ * statements: the same bits; `omgx_batch_rollout` always does).  With the setup kernel on, the begin stamp of the event pairs above
+ * is the setup kernel's and the end stamp the solve kernel's. */
+int  omgx_batch_set_prepare(omgx_batch* b, int32_t on);
 
 /* Warm-start shift  coeffs <- T * coeffs  for the masked agents
  * (reference `point2point.py:187-198`, `optilayer.py:470-490`,

@@ -178,7 +178,8 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  double* __restrict__ slabs, size_t slab_doubles, double* __restrict__ dw_state,
                  const int32_t* __restrict__ order, const StoreArgs* __restrict__ stp, int only_failed,
                  int* __restrict__ next_slot, const double* __restrict__ x0_alt, int n_alt, int32_t* __restrict__ attempts,
-                 unsigned long long* __restrict__ stats, int stagger, const CenterArgs* __restrict__ ctr) {
+                 unsigned long long* __restrict__ stats, int stagger, const CenterArgs* __restrict__ ctr,
+                 double* __restrict__ prep, size_t prep_doubles) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
     omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
@@ -190,6 +191,11 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
 #else
   c.prof = nullptr;
 #endif
+  // `prep` (round 6): the setup of every agent's solve -- parameter stage, Jacobian and rows at x0, classification, scaling, start
+  // values -- was done for the whole batch by ipm_prepare_kernel ahead of this launch; a solve then starts by loading its record.
+  // The matrix descriptors (the same for every agent) are written once per workgroup.
+  double* const jval_own = w.jval;
+  if (prep) { omgx::Kkt K0; K0.bind(d, T, w.kkt); omgx::kkt_describe(c, d, K0, w, true); }
   // mode 0: one workgroup per agent.  Spill modes: the grid is capped at the number of HBM
   // slabs and every workgroup walks over its agents.
   // `order` (optional) maps launch slots to agents: the host can put expected stragglers first so
@@ -228,9 +234,17 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
     int attempt = 0;
     for (;;) {
       const double* xs = attempt == 0 ? x0 + (size_t)b * d.n_var : x0_alt + ((size_t)(attempt - 1) * n_agents + b) * d.n_var;
-      r = omgx::ipm_solve(c, d, T, o, w, p + (size_t)b * d.n_par, xs,
-                          lbb, ubb, o.warm_start ? lam + (size_t)b * d.n_con : nullptr,
-                          o.warm_start ? status[b] : 0, kkt_doubles, o.warm_start ? dw_state[b] : 0.0);
+      omgx::Start st;
+      if (prep && attempt == 0) {
+        double* rec = prep + (size_t)b * prep_doubles;
+        if (omgx::ws_jac_hbm(MODE)) w.jval = rec + omgx::prep_layout(d).jval;      // (the scaled Jacobian stays where the setup kernel left it)
+        st = omgx::ipm_load_start<omgx::ws_jac_hbm(MODE)>(c, d, w, rec);
+      } else {
+        w.jval = jval_own;
+        st = omgx::ipm_setup(c, d, T, o, w, p + (size_t)b * d.n_par, xs, lbb, ubb, o.warm_start ? lam + (size_t)b * d.n_con : nullptr,
+                             o.warm_start ? status[b] : 0, kkt_doubles);
+      }
+      r = omgx::ipm_iterate(c, d, T, o, w, lbb, ubb, st, kkt_doubles, o.warm_start ? dw_state[b] : 0.0);
       __builtin_amdgcn_s_setprio(0);
       __syncthreads();
       if (r.status == 0 || o.warm_start || attempt >= n_alt) break;
@@ -286,6 +300,52 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   }
 }
 
+// Round 6: the setup of a batch of solves as a kernel of its own -- north_star's "basis evaluation on the sample grid and the
+// constraint Jacobian assembled with coalesced loads across a batch of agents".  One workgroup per agent, a few KB of LDS
+// (atoms, knots, slots, x) and half the registers of the solve kernel: four to eight workgroups per CU hide the table-load
+// latencies that the same statements pay in full at the head of the solve kernel, where two agents fill a CU (78 k of the
+// 339 k cycles of a warm-started solve, profiles/r05_phase_cycles_mpc.json).  Same device function (omgx::ipm_setup), same
+// thread count as the solve kernel (the fixed-order reductions depend on it): the same bits as the in-kernel setup.
+// Output: the agent's record (omgx::prep_layout) -- start point, slots, row arrays, scaled Jacobian, start scalars.
+__host__ __device__ inline size_t prepare_lds_doubles(const omgx::Dims& d) {
+  return (size_t)d.n_slots + d.n_atoms + d.n_knots + d.N + 64;
+}
+template <bool GEN>
+__global__ void __launch_bounds__(512, 4)      // (second argument: waves per SIMD the register allocation must leave room for -- 128 VGPRs)
+ipm_prepare_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, const double* __restrict__ p, const double* __restrict__ x0,
+                   const double* __restrict__ lb, const double* __restrict__ ub, int bounds_shared,
+                   const double* __restrict__ lam, const int32_t* __restrict__ status, int n_agents,
+                   double* __restrict__ prep, size_t prep_doubles, int only_failed) {
+  extern __shared__ __align__(16) double lds[];
+  const int b = blockIdx.x;
+  if (b >= n_agents) return;
+  if (only_failed && status[b] == 0) return;
+  const omgx::PrepLayout L = omgx::prep_layout(d);
+  double* rec = prep + (size_t)b * prep_doubles;
+  omgx::Work w;
+  {
+    double* q = lds;
+    w.slots = q; q += d.n_slots; w.atoms = q; q += d.n_atoms; w.knots = q; q += d.n_knots;
+    w.x = q; q += d.N; w.red = q; q += 64;
+    w.xt = nullptr; w.gbar = nullptr; w.sol = nullptr; w.dinv = nullptr; w.kkt = nullptr; w.col = nullptr; w.root = nullptr;
+    w.ht = nullptr; w.ds = nullptr;
+    w.hv = rec + L.hv; w.rho = rec + L.rho; w.vv = rec + L.vv; w.z = rec + L.z;
+    w.rtype = (int8_t*)(rec + L.rtype); w.jval = rec + L.jval;
+  }
+  omgx::CtxT<false, false, false, GEN, true> c; c.red = w.red; c.prof = nullptr;
+  const double* lbb = lb + (bounds_shared ? 0 : (size_t)b * d.n_con);
+  const double* ubb = ub + (bounds_shared ? 0 : (size_t)b * d.n_con);
+  const omgx::Start st = omgx::ipm_setup(c, d, T, o, w, p + (size_t)b * d.n_par, x0 + (size_t)b * d.n_var, lbb, ubb,
+                                         o.warm_start ? lam + (size_t)b * d.n_con : nullptr, o.warm_start ? status[b] : 0, 0);
+  __syncthreads();
+  for (int i = threadIdx.x; i < d.N; i += blockDim.x) rec[L.x + i] = w.x[i];
+  for (int i = threadIdx.x; i < d.n_slots; i += blockDim.x) rec[L.slots + i] = w.slots[i];
+  if (threadIdx.x == 0) {
+    rec[L.sc] = (double)st.status; rec[L.sc + 1] = (double)st.warm; rec[L.sc + 2] = (double)st.use_t;
+    rec[L.sc + 3] = st.mu; rec[L.sc + 4] = st.zt; rec[L.sc + 5] = st.f;
+  }
+}
+
 // Verification entry (omgx_batch_eval): one workgroup evaluates the tables of the solve at a caller's point and dumps the
 // raw arrays -- row values, objective, Jacobian entries, the KKT store holding the Lagrangian Hessian -- to `out`
 // [agent][n_con + 1 + nnz_j + kkt_doubles]; the host scatters them into dense matrices.
@@ -335,7 +395,8 @@ static ipm_eval_kernel_t ipm_eval_kernel_for(int mode, int wave_ok, int general)
 
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
-                             const int32_t*, const StoreArgs*, int, int*, const double*, int, int32_t*, unsigned long long*, int, const CenterArgs*);
+                             const int32_t*, const StoreArgs*, int, int*, const double*, int, int32_t*, unsigned long long*, int, const CenterArgs*,
+                             double*, size_t);
 // (GEN: the instance that carries the terms with four factors, the cos / sin atoms and the basis rows of any degree --
 // Dims::general; the other one is the kernel of the benchmark classes, free of that code)
 template <bool GEN>
@@ -860,6 +921,8 @@ struct omgx_batch {
   size_t slab_doubles = 0;
   double* d_slabs = nullptr;
   double* d_dw = nullptr;          // per-agent inertia correction carried between warm-started solves
+  // round 6: the setup of every solve as a kernel of its own ahead of the solve kernel (ipm_prepare_kernel): one record per agent
+  double* d_prep = nullptr; size_t prep_doubles = 0; size_t prep_lds = 0; bool prepare_on = false;
   int order_dw = 1;                // omgx_batch_order_by_iters: ties of the iteration count broken by the carried inertia correction (OMGX_ORDER_DW=0: developer switch)
   const int32_t* d_order = nullptr; // optional launch order (device pointer owned by the caller)
   const int32_t* pend_iters = nullptr; int32_t* pend_order = nullptr;   // omgx_batch_order_by_iters not launched yet
@@ -1463,7 +1526,31 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
     if ((rc = dalloc(b, (size_t)2, &b->d_next))) { omgx_batch_destroy(b); return rc; }
     if (hipMemset(b->d_next, 0, 2 * sizeof(int)) != hipSuccess) { g_err = "hipMemset failed"; omgx_batch_destroy(b); return OMGX_E_HIP; }
   }
+  {
+    // the setup kernel's records (omgx::prep_layout: ~43 KB per agent for config 2) and its LDS (atoms, knots, slots, x)
+    b->prep_doubles = (size_t)omgx::prep_layout(d).total;
+    b->prep_lds = prepare_lds_doubles(d) * sizeof(double);
+    const char* env = getenv("OMGX_PREPARE");       // developer switch: 0 = every solve does its own setup inside the solve kernel
+    b->prepare_on = !(env && env[0] == '0') && b->prep_lds <= (size_t)kLdsLimit;
+    if (b->prepare_on) {
+      if ((rc = dalloc(b, (size_t)n_agents * b->prep_doubles, &b->d_prep))) { omgx_batch_destroy(b); return rc; }
+      const void* pk = b->dims.general ? (const void*)ipm_prepare_kernel<true> : (const void*)ipm_prepare_kernel<false>;
+      static int prep_reserved[2] = {0, 0};
+      int& res = prep_reserved[b->dims.general ? 1 : 0];
+      if ((int)b->prep_lds > res) res = (int)b->prep_lds;
+      if (hipFuncSetAttribute(pk, hipFuncAttributeMaxDynamicSharedMemorySize, res) != hipSuccess) {
+        g_err = "cannot reserve dynamic LDS for ipm_prepare_kernel"; omgx_batch_destroy(b); return OMGX_E_HIP;
+      }
+    }
+  }
   *out = b;
+  return OMGX_OK;
+}
+
+int omgx_batch_set_prepare(omgx_batch* b, int32_t on) {
+  if (!b) return OMGX_E_INVALID;
+  if (on && !b->d_prep) { g_err = "this handle was created without the setup kernel's records (OMGX_PREPARE=0, or its LDS does not fit)"; return OMGX_E_INVALID; }
+  b->prepare_on = on != 0;
   return OMGX_OK;
 }
 
@@ -1604,13 +1691,27 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   b->timed = b->timing && !b->ext_ev0;
   b->ext_ev0 = b->ext_ev1 = nullptr;
   b->opts.prio_iter = b->prio_iter;
+  const bool prepared = b->prepare_on && b->d_prep;
+  if (prepared) {
+    // the setup of all B solves, many workgroups per CU; the begin stamp of the caller's / the handle's event pair rides on this
+    // launch, the end stamp on the solve kernel's: the pair brackets both
+    if (b->dims.general)
+      hipExtLaunchKernelGGL(ipm_prepare_kernel<true>, dim3(B), dim3(b->threads), (uint32_t)b->prep_lds, b->stream, e0, nullptr, 0u, d, b->dev, b->opts,
+                            kp, kx0, klb, kub, shared ? 1 : 0, (const double*)klam, (const int32_t*)kst, B, b->d_prep, b->prep_doubles, (flags & OMGX_ONLY_FAILED) ? 1 : 0);
+    else
+      hipExtLaunchKernelGGL(ipm_prepare_kernel<false>, dim3(B), dim3(b->threads), (uint32_t)b->prep_lds, b->stream, e0, nullptr, 0u, d, b->dev, b->opts,
+                            kp, kx0, klb, kub, shared ? 1 : 0, (const double*)klam, (const int32_t*)kst, B, b->d_prep, b->prep_doubles, (flags & OMGX_ONLY_FAILED) ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    e0 = nullptr;
+  }
   hipExtLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok, b->dims.general), dim3(b->n_slabs), dim3(b->threads), (uint32_t)b->lds_bytes, b->stream,
                         e0, e1, 0u, d, b->dev,
                         b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
                         b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, (const StoreArgs*)(b->store.out ? b->d_store : nullptr), (flags & OMGX_ONLY_FAILED) ? 1 : 0,
                         b->d_next, b->d_x0_alt, b->d_x0_alt ? b->n_alt : 0, b->d_attempts,
                         (unsigned long long*)(b->d_stats ? b->d_stats + 4 * (size_t)(b->stats_launch++ % b->stats_slots) : nullptr),
-                        b->stagger, (const CenterArgs*)(b->center_on ? b->d_center : nullptr));
+                        b->stagger, (const CenterArgs*)(b->center_on ? b->d_center : nullptr),
+                        prepared ? b->d_prep : (double*)nullptr, b->prep_doubles);
   HIPCHK(hipGetLastError());
   if (ranged)
     hipLaunchKernelGGL(range_contract_lam, dim3((B * nu + 255) / 256), dim3(256), 0, b->stream, (const double*)b->d_lam, lam_user_dev, B, nu, ni,

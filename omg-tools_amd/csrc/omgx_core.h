@@ -342,7 +342,7 @@ OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
 // ---------------------------------------------------------------------------
 #ifdef OMGX_HOST_PORT
 struct Ctx {
-  static constexpr bool wave_only = false, hbm = false, no_wave = false, root_lds = false, general = true;
+  static constexpr bool wave_only = false, hbm = false, no_wave = false, root_lds = false, general = true, prep = false;
   double* red;
   int tid() const { return 0; }
   int nthr() const { return 1; }
@@ -364,9 +364,12 @@ struct Ctx {
 // routines are not compiled into it
 // kGeneral: the instance for templates with Dims::general set (terms with four factors, cos / sin atoms, basis rows of
 // degree > 5): the other instance does not carry that code -- at the 256-register cap of this kernel it cost spills
-template <bool kHbm, bool kWaveOnly = false, bool kRootLds = false, bool kGeneral = false>
+// kPrep: the instance of the setup kernel (ipm_prepare_kernel): row arrays and Jacobian values in the agent's record in global
+// memory, no KKT store
+template <bool kHbm, bool kWaveOnly = false, bool kRootLds = false, bool kGeneral = false, bool kPrep = false>
 struct CtxT {
   static constexpr bool hbm = kHbm;
+  static constexpr bool prep = kPrep;
   static constexpr bool general = kGeneral;
   static constexpr bool root_lds = kRootLds;      // Work::root holds the root block from the Schur step on (spill modes)
   static constexpr bool wave_only = kWaveOnly;
@@ -472,7 +475,7 @@ enum { PH_JAC = 0, PH_RESID, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_STEP, PH_LINES
        PH_F_PARK, PH_F_SWEEP, PH_F_SCALE, PH_A_TCOL, PH_A_HESS, PH_P_LOAD, PH_P_DIV, PH_P_BSPL, PH_P_SLOTS, PH_COUNT };
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
 #define OMGX_TIC() long long tic_ = (c.sync(), clock64())
-#define OMGX_TOC(k) do { c.sync(); long long now_ = clock64(); if (c.tid() == 0) c.prof[k] += now_ - tic_; tic_ = now_; } while (0)
+#define OMGX_TOC(k) do { c.sync(); long long now_ = clock64(); if (c.tid() == 0 && c.prof) c.prof[k] += now_ - tic_; tic_ = now_; } while (0)
 #else
 #define OMGX_TIC() do {} while (0)
 #define OMGX_TOC(k) do {} while (0)
@@ -807,7 +810,10 @@ OMGX_FN void lift_project(const C& c, const Dims& d, const Tables& T, const Work
       const double g0 = row_value_ell<C>(d, T, w, q[0], m, xv);
       xv[q[1]] = 1.0;
       const double g1 = row_value_ell<C>(d, T, w, q[0], m, xv);
-      xv[q[1]] = -g0 / (g1 - g0);
+      // (a quotient row q den - num whose den is zero at this point has no value for its auxiliary: NaN -- the line search rejects
+      // such a trial point like any other that leaves the domain, the start of a solve is refused, ipm_solve)
+      const double den = g1 - g0;
+      xv[q[1]] = den != 0.0 ? -g0 / den : NAN;
     }
     c.sync();
   }
@@ -2199,28 +2205,45 @@ OMGX_FN double gersh_cap(const C& c, int N, const Tables& T, const Work& w, doub
   return c.uni(1.01 * c.rmax(g) + OMGX_DW_FIRST);
 }
 
+// What the setup of a solve hands to its iteration (beside the work arrays): status 1 = go on, 3 = invalid rows / start point
+struct Start { int status, warm, use_t; double mu, zt, f; };
+
+// Setup of one solve: parameter stage, Jacobian and row values at x0, row classification and gradient-based scaling, start
+// values of the multipliers and of the barrier parameter.  Runs either at the head of the solve kernel (ipm_solve) or -- for
+// a whole batch at once, many workgroups per CU -- as a kernel of its own ahead of it (ipm_prepare_kernel, omgx.hip; C::prep:
+// the row arrays and the Jacobian values then live in the agent's record in global memory, no KKT store, no descriptors):
+// the same statements in the same order either way, the same bits.
 template <class C>
-OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts& o, Work& w,
-                         const double* p, const double* x0, const double* lb, const double* ub,
-                         const double* lam0, int prev_status, int kkt_doubles, double dw_prev = 0.0) {
-  const int n = d.n_var, m = d.n_con, N = d.N;
-  Result res; res.status = 1; res.iters = 0; res.f = 0; res.mu = o.mu_init; res.t = 0; res.dw = 0;
-  Kkt K; K.bind(d, T, w.kkt);
+OMGX_FN Start ipm_setup(const C& c, const Dims& d, const Tables& T, const Opts& o, Work& w,
+                        const double* p, const double* x0, const double* lb, const double* ub,
+                        const double* lam0, int prev_status, int kkt_doubles) {
+  const int n = d.n_var, m = d.n_con;
+  Start res; res.status = 1; res.warm = 0; res.use_t = 0; res.mu = o.mu_init; res.zt = 0.0; res.f = 0.0;
   OMGX_TIC();
-  kkt_describe(c, d, K, w, false);      // (beside the parameter program of eval_params, whose barriers publish it)
+  if constexpr (!C::prep) {
+    Kkt K; K.bind(d, T, w.kkt);
+    kkt_describe(c, d, K, w, false);      // (beside the parameter program of eval_params, whose barriers publish it)
+  }
 
   // the per-agent inputs come from HBM (~1 us each if loaded where they are first needed): all of
   // them are requested here, so that their latencies overlap with each other and with the parameter
   // stage (p is loaded by eval_params; the multipliers wait in w.ds, which is free until the assembly)
   const bool warm_in = o.warm_start && prev_status == 0;
   OMGX_PFOR(i, n) w.x[i] = x0[i];
-  if (warm_in) { OMGX_PFOR(r, m) w.ds[r] = lam0[r]; }
+  if constexpr (!C::prep) { if (warm_in) { OMGX_PFOR(r, m) w.ds[r] = lam0[r]; } }
   if (c.tid() == 0) w.x[n] = 1.0;
   eval_params(c, d, T, w, p);
   OMGX_TOC(PH_S_PARAMS);
   // lifted auxiliaries: whatever the caller handed in, the solve starts on their defining rows (eval_params ends with a
   // barrier: the slots are there)
-  if constexpr (C::general) lift_project(c, d, T, w, m, w.x);
+  if constexpr (C::general) {
+    lift_project(c, d, T, w, m, w.x);
+    if (d.n_lift > 0) {      // an auxiliary without a value at the caller's point (division by a variable that is zero there): Invalid
+      double bad_aux = 0.0;
+      OMGX_PFOR(k, d.n_lift) if (!isfinite(w.x[n - d.n_lift + k])) bad_aux = 1.0;
+      if (c.rmax(bad_aux) > 0.0) { res.status = 3; return res; }
+    }
+  }
 
   // ---- row classification, gradient-based scaling, phase-I weights -----------
   // warm start only from a converged previous solve; otherwise a cold start from x0
@@ -2307,10 +2330,10 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
         // step runs into it: hundreds of iterations with step lengths of 1e-2 on a knot-crossing x-update; the floor keeps
         // such rows in the picture)
         const double s_r = row_slack(w, r, t);
-        w.z[r] = fmax(w.ds[r] / w.rho[r], fmax(OMGX_WARM_ZMIN, fmin(o.warm_z_floor * o.tol, o.warm_z_cap > 0.0 ? o.warm_z_cap * o.tol / s_r : 1e300)));
+        w.z[r] = fmax((C::prep ? lam0[r] : w.ds[r]) / w.rho[r], fmax(OMGX_WARM_ZMIN, fmin(o.warm_z_floor * o.tol, o.warm_z_cap > 0.0 ? o.warm_z_cap * o.tol / s_r : 1e300)));
         sz += s_r * w.z[r]; cnt0 += 1.0;
       } else if (ty == ROW_EQ) {
-        w.z[r] = w.ds[r] / w.rho[r];
+        w.z[r] = (C::prep ? lam0[r] : w.ds[r]) / w.rho[r];
       }
     }
     { double rv[2] = {sz, cnt0}; c.template reduce_ops<0, 0>(rv); sz = rv[0]; cnt0 = rv[1]; }
@@ -2326,6 +2349,74 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
     zt = c.uni(use_t ? fmax(mu / t, nu - rv[0]) : 0.0);
     f = rv[1];
   }
+  OMGX_TOC(PH_S_INIT);
+#if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
+  if (c.tid() == 0 && c.prof) c.prof[PH_SETUP] += c.prof[PH_S_DESC] + c.prof[PH_S_PARAMS] + c.prof[PH_S_JAC0] + c.prof[PH_S_CLASS] + c.prof[PH_S_INIT];
+#endif
+  res.warm = warm ? 1 : 0; res.use_t = use_t ? 1 : 0; res.mu = mu; res.zt = zt; res.f = f;
+  return res;
+}
+
+// Record of a prepared solve (one per agent, global memory; written by ipm_prepare_kernel, read by the solve kernel): offsets
+// in doubles.  sc: {status, warm, use_t, mu, zt, f, -, -}; x: [N] start point (lifted auxiliaries on their rows, x[n_var] = t);
+// the row arrays; rtype bytes; the scaled Jacobian values (+ the padding slot).
+struct PrepLayout { int sc, x, slots, hv, rho, vv, z, rtype, jval, total; };
+OMGX_HD PrepLayout prep_layout(const Dims& d) {
+  PrepLayout L; int o = 0;
+  L.sc = o; o += 8;
+  L.x = o; o += d.N;
+  L.slots = o; o += d.n_slots;
+  L.hv = o; o += d.n_con; L.rho = o; o += d.n_con; L.vv = o; o += d.n_con; L.z = o; o += d.n_con;
+  L.rtype = o; o += (d.n_con + 7) / 8;
+  o = (o + 1) & ~1;                       // (the Jacobian values 16-byte aligned)
+  L.jval = o; o += d.nnz_j + 1;
+  L.total = (o + 1) & ~1;
+  return L;
+}
+
+#ifndef OMGX_HOST_PORT
+// The solve kernel's side of a prepared solve: the record into the work arrays (every load independent of the others, all in
+// flight together -- one memory round trip where the in-kernel setup spends ~40 dependent ones).  JAC_GLOBAL: the Jacobian
+// values stay where the setup kernel wrote them (the caller points w.jval at the record); otherwise they are copied to LDS.
+template <bool JAC_GLOBAL, class C>
+OMGX_FN Start ipm_load_start(const C& c, const Dims& d, Work& w, const double* rec) {
+  const PrepLayout L = prep_layout(d);
+  OMGX_TIC();
+  Start st;
+  st.status = (int)rec[L.sc]; st.warm = (int)rec[L.sc + 1]; st.use_t = (int)rec[L.sc + 2];
+  st.mu = rec[L.sc + 3]; st.zt = rec[L.sc + 4]; st.f = rec[L.sc + 5];
+  OMGX_PFOR(i, d.N) w.x[i] = rec[L.x + i];
+  OMGX_PFOR(i, d.n_slots) w.slots[i] = rec[L.slots + i];
+  OMGX_PFOR(r, d.n_con) {
+    const double a = rec[L.hv + r], b = rec[L.rho + r], v = rec[L.vv + r], z = rec[L.z + r];
+    w.hv[r] = a; w.rho[r] = b; w.vv[r] = v; w.z[r] = z;
+  }
+  { double* rt = (double*)w.rtype; OMGX_PFOR(i, (d.n_con + 7) / 8) rt[i] = rec[L.rtype + i]; }
+  if constexpr (!JAC_GLOBAL) { OMGX_PFOR_U4(e, d.nnz_j + 1) w.jval[e] = rec[L.jval + e]; }
+  st.status = __builtin_amdgcn_readfirstlane(st.status); st.warm = __builtin_amdgcn_readfirstlane(st.warm);
+  st.use_t = __builtin_amdgcn_readfirstlane(st.use_t);
+  st.mu = c.uni(st.mu); st.zt = c.uni(st.zt); st.f = c.uni(st.f);
+  c.sync();
+  OMGX_TOC(PH_S_INIT);
+#if defined(OMGX_PROFILE)
+  if (c.tid() == 0 && c.prof) c.prof[PH_SETUP] += c.prof[PH_S_INIT];
+#endif
+  return st;
+}
+#endif
+
+// The iteration of a solve whose setup is done (the work arrays hold x, the slots, the scaled Jacobian, the row arrays and the
+// multipliers; `st` the scalars).
+template <class C>
+OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opts& o, Work& w,
+                           const double* lb, const double* ub, const Start& st, int kkt_doubles, double dw_prev = 0.0) {
+  const int n = d.n_var, m = d.n_con, N = d.N;
+  Result res; res.status = st.status == 3 ? 3 : 1; res.iters = 0; res.f = 0; res.mu = o.mu_init; res.t = 0; res.dw = 0;
+  if (st.status == 3) return res;
+  Kkt K; K.bind(d, T, w.kkt);
+  const bool warm = st.warm != 0, use_t = st.use_t != 0;
+  double mu = st.mu, nu = o.nu_init, zt = st.zt, f = st.f;
+  double t = use_t ? 1.0 : 0.0;
   // a warm start also inherits the inertia correction the previous solve of this agent ended with
   // (first factorisation at that value instead of climbing 0, 1e-4, 1e-3, ... again)
   double dw_last = c.uni((warm && dw_prev > 0.0) ? dw_prev : 0.0), t_check = t;
@@ -2340,13 +2431,9 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   int dw_hold = dw_last > 0.0 ? 1 : 0, dw_backoff = 1;   // inertia-correction tracking (see the factorisation loop)
   // cold starts may damp the leaf (hyperplane) variables less and the root (trajectory) variables more
   // than dw (same product: the same bilinear negative curvature is covered); warm starts use dw on both
-    const double reg_leaf = warm ? 1.0 : o.dw_leaf_ratio_cold, reg_root = warm ? 1.0 : 1.0 / o.dw_leaf_ratio_cold;
+  const double reg_leaf = warm ? 1.0 : o.dw_leaf_ratio_cold, reg_root = warm ? 1.0 : 1.0 / o.dw_leaf_ratio_cold;
   int it = 0, status = 1, ls_fail = 0, full_steps = 0;
   const double nu_stall_max = warm ? OMGX_NU_MAX : 0.0;     // see the stall test in the loop
-  OMGX_TOC(PH_S_INIT);
-#if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
-  if (c.tid() == 0) c.prof[PH_SETUP] += c.prof[PH_S_DESC] + c.prof[PH_S_PARAMS] + c.prof[PH_S_JAC0] + c.prof[PH_S_CLASS] + c.prof[PH_S_INIT];
-#endif
 
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
   long long resid_seen_ = 0;
@@ -3019,6 +3106,15 @@ OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts&
   res.status = status; res.iters = it > o.max_iter ? o.max_iter : it; res.f = f; res.mu = mu; res.t = t;
   res.dw = dw_last * reg_root;      // handed to the next (warm, symmetric) solve: the damping the root block had
   return res;
+}
+
+// One solve: setup, then the iteration (the head of the solve kernel when no prepared record is handed in; the host build).
+template <class C>
+OMGX_FN Result ipm_solve(const C& c, const Dims& d, const Tables& T, const Opts& o, Work& w,
+                         const double* p, const double* x0, const double* lb, const double* ub,
+                         const double* lam0, int prev_status, int kkt_doubles, double dw_prev = 0.0) {
+  const Start st = ipm_setup(c, d, T, o, w, p, x0, lb, ub, lam0, prev_status, kkt_doubles);
+  return ipm_iterate(c, d, T, o, w, lb, ub, st, kkt_doubles, dw_prev);
 }
 
 // Verification entry: what the tables of the solve evaluate at a given point, by the device code of

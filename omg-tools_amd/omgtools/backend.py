@@ -95,7 +95,20 @@ def options_from_problem(options):
     if ipopt.get('ipopt.hessian_approximation') == 'limited-memory':
         kw['hess_approx'] = 1
     kw.update(options.get('omgx', {}))
+    kw.pop('hess_fallback', None)      # (a switch of the drop-in solver object, `NlpSolver`: not a solver setting)
     return kw
+
+
+def template_is_general(tpl):
+    """True for templates the library runs on its general kernel instance (omgx_plan.h `general`: lifted auxiliaries, terms with four
+    variable factors, cos / sin atoms) -- the instances that honour `hess_approx`."""
+    if getattr(tpl, 'n_lift', 0):
+        return True
+    t_var = np.asarray(tpl.t_var).reshape(-1, 4) if np.asarray(tpl.t_var).ndim == 1 else np.asarray(tpl.t_var)
+    if t_var.shape[1] >= 4 and (t_var[:, 3] >= 0).any():
+        return True
+    prog = np.asarray(tpl.prog).reshape(-1, 6)
+    return bool(len(prog) and np.isin(prog[:, 0], (2, 3)).any())
 
 
 ROOT_HINT = ('splines_seg',)
@@ -479,6 +492,12 @@ class BatchSolver(object):
         self.lib.omgx_batch_set_timing.argtypes = [C.c_void_p, C.c_int32]
         _check(self.lib, self.lib.omgx_batch_set_timing(self._h, int(bool(on))), 'omgx_batch_set_timing')
 
+    def set_prepare(self, on):
+        """The setup of every solve as ONE launch for the whole batch ahead of the solve kernel (`omgx_batch_set_prepare`, ABI 8;
+        on by default): off = every solve does its own setup inside the solve kernel (the same statements, the same bits)."""
+        self.lib.omgx_batch_set_prepare.argtypes = [C.c_void_p, C.c_int32]
+        _check(self.lib, self.lib.omgx_batch_set_prepare(self._h, int(bool(on))), 'omgx_batch_set_prepare')
+
     def last_kernel_ms(self):
         ms = C.c_double()
         _check(self.lib, self.lib.omgx_batch_last_kernel_ms(self._h, C.byref(ms)),
@@ -661,7 +680,8 @@ def second_attempt(solve, set_options, opts, enabled, p, x0, lbg, ubg):
     if not enabled or int(res['status'][0]) != 2 or opts.get('hess_approx'):
         return res
     max_iter = int(opts.get('max_iter', DEFAULT_OPTIONS['max_iter']))
-    set_options(**dict(opts, hess_approx=1, max_iter=max(max_iter, 3000)))
+    # (the retry runs under the caller's own iteration limit when one was given; IPOPT's default of 3000 otherwise)
+    set_options(**dict(opts, hess_approx=1, max_iter=max_iter if 'max_iter' in opts else max(max_iter, 3000)))
     try:
         again = solve(p, x0, lbg, ubg)
     finally:
@@ -678,8 +698,9 @@ class NlpSolver(object):
     def __init__(self, template, options):
         self.template = template
         self.opts = options_from_problem(options)
-        # (options['omgx']['hess_fallback'] = False switches the second attempt off)
-        self.fallback = bool(self.opts.pop('hess_fallback', True))
+        # (options['omgx']['hess_fallback'] = False switches the second attempt off; templates off the general kernel instance
+        # ignore `hess_approx`: a second attempt would repeat the first solve to the same end)
+        self.fallback = bool(options.get('omgx', {}).get('hess_fallback', True)) and template_is_general(template)
         self.batch = BatchSolver(template, 1, options=self.opts)
         self._stats = {'return_status': 'Not_Solved', 'iter_count': 0}
 

@@ -1,3 +1,25 @@
+# This file is derived from OMG-tools (meco-group/omg-tools, `omgtools/problems/problem.py`, `omgtools/problems/point2point.py` (API surface, option keys, definition order)).
+#
+# OMG-tools -- Optimal Motion Generation-tools
+# Copyright (C) 2016 Ruben Van Parys & Tim Mercy, KU Leuven.
+# All rights reserved.
+#
+# OMG-tools is free software; you can redistribute it and/or
+# modify it under the terms of the GNU Lesser General Public
+# License as published by the Free Software Foundation; either
+# version 3 of the License, or (at your option) any later version.
+# This software is distributed in the hope that it will be useful,
+# but WITHOUT ANY WARRANTY; without even the implied warranty of
+# MERCHANTABILITY or FITNESS FOR A PARTICULAR PURPOSE. See the GNU
+# Lesser General Public License for more details.
+#
+# You should have received a copy of the GNU Lesser General Public
+# License along with this program; if not, write to the Free Software
+# Foundation, Inc., 51 Franklin Street, Fifth Floor, Boston, MA 02110-1301 USA
+#
+# Modifications: written anew for this repository on the same public classes, option names, definition order and messages
+# (they fix the flat x / p / g layouts of the drop-in boundary), on explicit polynomials (symbolic.py) instead of CasADi and
+# with the solver call replaced by the HIP path (backend.py).  Distributed under the same licence (COPYING.LESSER beside this file).
 """`Problem` and the point-to-point family (`Point2point` factory, `FixedTPoint2point`, `FreeEndPoint2point`,
 `FreeTPoint2point`): what one receding-horizon solve IS -- written for this package against the behaviour of the reference's
 `problems/problem.py` (options 54-74, init 85-91, solve 103-136, predict 138-163, reset_init_guess 165-181, simulate 187-192)

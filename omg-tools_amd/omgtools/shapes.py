@@ -1,3 +1,25 @@
+# This file is derived from OMG-tools (meco-group/omg-tools, `omgtools/basics/shape.py` (API surface, vertex order)).
+#
+# OMG-tools -- Optimal Motion Generation-tools
+# Copyright (C) 2016 Ruben Van Parys & Tim Mercy, KU Leuven.
+# All rights reserved.
+#
+# OMG-tools is free software; you can redistribute it and/or
+# modify it under the terms of the GNU Lesser General Public
+# License as published by the Free Software Foundation; either
+# version 3 of the License, or (at your option) any later version.
+# This software is distributed in the hope that it will be useful,
+# but WITHOUT ANY WARRANTY; without even the implied warranty of
+# MERCHANTABILITY or FITNESS FOR A PARTICULAR PURPOSE. See the GNU
+# Lesser General Public License for more details.
+#
+# You should have received a copy of the GNU Lesser General Public
+# License along with this program; if not, write to the Free Software
+# Foundation, Inc., 51 Franklin Street, Fifth Floor, Boston, MA 02110-1301 USA
+#
+# Modifications: written anew for this repository on the same public classes, option names, definition order and messages
+# (they fix the flat x / p / g layouts of the drop-in boundary), on explicit polynomials (symbolic.py) instead of CasADi and
+# with the solver call replaced by the HIP path (backend.py).  Distributed under the same licence (COPYING.LESSER beside this file).
 """Vehicle / obstacle / room shapes as PROBLEM DATA -- written for this package against the behaviour of the reference's
 `basics/shape.py` (Circle 49-68, Polyhedron 130-171, RegularPolyhedron 191-212, Rectangle 215-236, Square 239-243, Sphere
 282-336, Polyhedron3D 339-362, RegularPrisma 364-399, Cuboid 402-438, Cube 441-444, Plate 447-454): same class names and

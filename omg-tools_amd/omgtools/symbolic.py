@@ -317,6 +317,7 @@ class SymbolTable(object):
         self._div_cache = {}
         self.lifted = []            # auxiliary variables in creation order: (symbol, row polynomial that must vanish)
         self._lift_cache = {}
+        self.quotient_num = {}      # quotient auxiliary -> its numerator (omgx_shim checks what a variable evaluation point is)
 
     # context handling so Poly.__truediv__ can reach the active table
     def __enter__(self):
@@ -356,6 +357,7 @@ class SymbolTable(object):
             with self:
                 row = Poly.symbol(sym) * Poly.lift(den) + (-Poly.lift(num))      # (may lift `den` first: its auxiliary then precedes q's row)
             self.lifted.append((sym, row))
+            self.quotient_num[sym] = Poly.lift(num)
         return Poly.symbol(self._lift_cache[key])
 
     def new_raw_atoms(self, n):

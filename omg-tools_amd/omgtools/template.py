@@ -267,6 +267,9 @@ class NLPTemplate(object):
             g0 = self.eval_rows_host(x, atoms, [nc + k], slots)[0]
             x[nv + k] = 1.0
             g1 = self.eval_rows_host(x, atoms, [nc + k], slots)[0]
+            if not abs(g1 - g0) > 1e-300:
+                raise ValueError('lifted auxiliary %d: its defining row does not depend on it at this point (a quotient by a variable '
+                                 'that is zero at the initial guess): no admissible start' % k)
             x[nv + k] = -g0 / (g1 - g0)
         ext = lambda b: None if b is None else np.r_[np.asarray(b, float).reshape(-1)[:nc], np.zeros(n_lift)]
         return x, ext(lbg), ext(ubg)

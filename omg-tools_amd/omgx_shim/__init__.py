@@ -132,6 +132,18 @@ def patch_spline_extra(module):
                 # point is the lifted quotient q = t / T, symbolic.py).  Basis functions at a variable point are not atoms; on the
                 # FIRST knot span, where q lives, every one of them is a polynomial of the spline's degree in q: the value is
                 # Horner's scheme in q over combinations of the leading coefficients (products beyond four factors are lifted).
+                # Valid only while q stays on the first span [0, first interior knot): the series is in powers of (u - knots[0]) and
+                # Horner below runs in q itself, so the basis must start at 0; the one use in the reference is q = t / T with the
+                # parameter t = 0 (free end time) -- a numerator that is not a bare parameter would be a point somewhere else on
+                # the horizon, where this series is the wrong polynomial: refused rather than built silently.
+                if knots[0] != 0.0:
+                    raise NotImplementedError('evalspline at a variable point: the basis must start at 0 (knots[0] = %g)' % knots[0])
+                only = list(xv.terms.items())
+                q_sym = only[0][0][0][0] if len(only) == 1 and only[0][1] == 1.0 and len(only[0][0][0]) == 1 and not only[0][0][1] else None
+                num = sym.SymbolTable.current().quotient_num.get(q_sym)
+                if num is None or not num.is_param_only():
+                    raise NotImplementedError('evalspline at a variable point: only parameter / variable (t / T with t inside the first '
+                                              'knot span) is supported')
                 M = _mod('splines').first_span_power_series(knots, degree)          # B_i(u) = sum_k M[i, k] u^k for 0 <= u < first knot
                 C = []
                 for k in range(degree + 1):

@@ -12,6 +12,8 @@ class PortNlpSolver(object):
         options_from_problem = _backend().options_from_problem
         self.template = template
         self.options = options_from_problem(options)
+        # (the same switch as omgtools.backend.NlpSolver: off by option, and off for templates that ignore `hess_approx`)
+        self.fallback = bool(options.get('omgx', {}).get('hess_fallback', True)) and _backend().template_is_general(template)
         self._stats = {'return_status': 'Not_Solved', 'iter_count': 0}
 
     def __call__(self, x0=None, p=None, lbg=None, ubg=None, **kwargs):
@@ -20,7 +22,7 @@ class PortNlpSolver(object):
         STATUS_STRINGS = _backend().STATUS_STRINGS
         # (the product's solver object takes a solve that gives up phase I once more with `hess_approx`: omgtools.backend.second_attempt)
         state = dict(self.options)
-        fallback = bool(state.pop('hess_fallback', True))
+        fallback = self.fallback
         base = dict(state)
 
         def solve(p_, x_, lb_, ub_):
