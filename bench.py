@@ -396,11 +396,12 @@ def stepwise_leg(problem, P, opts, n_steps, warmup, dev, n_streams):
     wall = time.perf_counter() - t_0
     gc.enable()
     st = sum(sd.cpu().numpy() for sd in stats)
+    st[:, 2] = np.max([sd.cpu().numpy()[:, 2] for sd in stats], axis=0)
     for m in parts:
         m.solver.set_stats(None)
         m.solver.close()
     assert (st[:, 3] == B).all()
-    return {'solves_per_s': float(st[:, 0].sum()) / wall, 'ms_per_step': wall / n_steps * 1e3, 'steps': n_steps, 'warmup': warmup,
+    return {'solves_per_s': float(st[:, 0].sum()) / wall, 'max_iters_in_a_step': int(st[:, 2].max()), 'ms_per_step': wall / n_steps * 1e3, 'steps': n_steps, 'warmup': warmup,
             'solved_fraction': float(st[:, 0].sum()) / (n_steps * B), 'mean_iters': float(st[:, 1].sum()) / (n_steps * B),
             'launches_per_step': len(parts),
             'note': '%d sub-batch(es) of %d agents, per-step launches' % (len(parts), B // len(parts))}
@@ -498,6 +499,114 @@ def host_boundary_pipelined(problem, P, opts, n_steps, warmup, dev, engine='kern
                     + ({'kernel': 'omgx_batch_transfer kernels (no copy engine)', 'memcpy': 'hipMemcpyAsync (copy engine)',
                         'mapped': 'p lives in pinned host memory (written by the prediction kernel, read by the solve kernel over the host '
                                   'link: no transfer of its own), x / status / iters by one omgx_batch_transfer kernel'}[engine])}
+
+
+def closed_loop_parity(opts, dev):
+    """`parity_at_tol`: what the solver settings of this line mean for the plans -- the closed loop of the first 64 agents of the
+    workload (cold solve, 25 updates with two knot crossings, every update predicted from the product's OWN previous plan) against the
+    stored loop of an independent solver (scipy SLSQP in the loop, tests/golden/closed_loop_cfg2.npz; generator
+    tests/golden/generate_closed_loop.py), in the form of the reference's replay test (`export/tests/point2point/test.cpp:116-141`:
+    sampled state and input after every update), two-sided.  A fixture (data) and numpy, no oracle code; the same comparison as
+    tests/test_closed_loop.py (tools/closed_loop.py)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import closed_loop as cl
+    from omgtools.batch import BatchP2P
+    made = []
+
+    def make(problem, P, o):
+        made.append(BatchP2P(problem, P, ops='hip', device=dev, options=dict(o, **opts)))
+        return made[-1]
+    try:
+        worst, first, parted, med, capped = cl.run_loop(make, opts['tol'], 'cfg2')
+    finally:
+        for m in made:
+            m.solver.close()
+    return {'tol': opts['tol'], 'compl_inf_tol': opts.get('compl_inf_tol', 0.0), 'constr_viol_tol': opts.get('constr_viol_tol', 0.0),
+            'closed_loop_pos_m': float(worst[0]), 'closed_loop_vel_mps': float(worst[1]), 'closed_loop_rel': float(worst[2]),
+            'median_pos_m_at_end': med, 'after_cold_solve_pos_m': float(first[0]), 'parted_agents': len(parted), 'solves_at_iteration_cap': capped,
+            'agents': 64, 'updates': 25,
+            'reference': 'scipy SLSQP in the loop (tests/golden/closed_loop_cfg2.npz), sampled position / velocity of the first 0.2 s of '
+                         'every new plan, two-sided; rel = |a - b| / max(|a|, |b|, 0.1)'}
+
+
+def tolerance_leg(problem, P, opts, n_steps, warmup, dev):
+    """The headline protocol (per-step product path) at other solver settings, with the closed-loop figures of the same settings."""
+    from omgtools.batch import BatchP2P
+    out = stepwise_leg(problem, P, opts, n_steps, warmup, dev, 'auto')
+    out.pop('note', None)
+    # the same steps as ONE launch (omgx_batch_rollout): no barrier between the steps of different agents -- a straggler of a knot
+    # crossing then delays only itself, where the per-step path makes every agent of its sub-batch wait for it
+    mpc = BatchP2P(problem, P, ops='hip', device=dev, options=opts)
+    try:
+        ro = rollout_leg(mpc, mpc.x.clone(), mpc.p.clone(), n_steps, warmup, dev)
+        out['rollout'] = {k: ro[k] for k in ('solves_per_s', 'ms_per_step', 'solved_fraction', 'mean_iters')}
+    except Exception as e:
+        out['rollout'] = {'error': repr(e)}
+    finally:
+        mpc.solver.close()
+    out.update(parity=closed_loop_parity(opts, dev))
+    return out
+
+
+def sustained_leg(problem, P, opts, n_steps, dev, stop_tol=1e-3):
+    """The whole manoeuvre (round-5 review, item 4): the reference's loop runs until `stop_criterium` (`execution/simulator.py:39-62`,
+    `problems/point2point.py:98-102` -> `vehicles/holonomic.py:145-151`: |state - poseT| <= stop_tol and |input| <= stop_tol, stop_tol
+    = 1e-3, `vehicles/vehicle.py:72`) -- ~100 updates at T = 10 s -- where the headline times updates 4 - 23.  Here: cold solve, then
+    `n_steps` updates of every agent on the per-step product path without a host sync; the state the vehicle is in at every update
+    (the prediction written into p) is logged on the device and the criterion evaluated afterwards.  An agent counts as a solve
+    only while it is under way (the reference's loop ends at arrival; here it keeps solving -- cheap solves -- inside the timed region)."""
+    from omgtools.batch import StreamedP2P, receding_horizon_batch
+    B = P['p'].shape[0]
+    rh = receding_horizon_batch(problem, P, device=dev, n_streams='auto', options=opts)
+    parts = rh.parts if isinstance(rh, StreamedP2P) else [rh]
+    veh, tpl = problem.vehicles[0], problem.father.template
+    nd = veh.n_dim
+    o_pose = tpl.entry_range(veh.label, 'poseT', 'par')[0]
+    rh.solve_cold(bends=())
+    torch.cuda.synchronize()
+    stats = [torch.zeros((n_steps, 4), dtype=torch.int64, device=dev) for _ in parts]
+    logs = [torch.zeros((n_steps, m.B, 2 * nd), dtype=torch.float64, device=dev) for m in parts]
+    count = [0] * len(parts)
+
+    def hook(kp):
+        def log_state(m):                                   # (on the sub-batch's own stream, between the prediction and the solve)
+            k = count[kp]
+            logs[kp][k, :, :nd].copy_(m.p[:, m.o_state0:m.o_state0 + nd])
+            logs[kp][k, :, nd:].copy_(m.p[:, m.o_input0:m.o_input0 + nd])
+            count[kp] = k + 1
+        return log_state
+    hooks = [hook(k) for k in range(len(parts))]
+    for m, sd in zip(parts, stats):
+        m.solver.set_stats(sd)
+    quiet_host()
+    t_0 = time.perf_counter()
+    for _ in range(n_steps):
+        rh.step(before_solve=hooks if len(parts) > 1 else hooks[0])
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t_0
+    gc.enable()
+    st = sum(sd.cpu().numpy() for sd in stats).astype(float)
+    st[:, 2] = np.max([sd.cpu().numpy()[:, 2] for sd in stats], axis=0)
+    log = torch.cat(logs, dim=1).cpu().numpy()              # [n_steps, B, 2 nd]
+    pose = torch.cat([m.p[:, o_pose:o_pose + nd] for m in parts]).cpu().numpy()
+    for m in parts:
+        m.solver.set_stats(None)
+        m.solver.close()
+    there = (np.linalg.norm(log[:, :, :nd] - pose[None], axis=2) <= stop_tol) & (np.linalg.norm(log[:, :, nd:], axis=2) <= stop_tol)
+    arrived_at = np.where(there.any(axis=0), there.argmax(axis=0), n_steps)        # first update at which the criterion holds
+    under_way = (np.arange(n_steps)[:, None] < arrived_at[None, :]).sum(axis=1)    # agents the reference's loop would still be solving
+    win = 20
+    windows = [{'updates': '%d-%d' % (k, min(k + win, n_steps) - 1), 'mean_iters': float(st[k:k + win, 1].sum() / (B * len(st[k:k + win]))),
+                'max_iters': int(st[k:k + win, 2].max()), 'agents_under_way': int(under_way[k])} for k in range(0, n_steps, win)]
+    dist = np.linalg.norm(log[-1, :, :nd] - pose, axis=1)
+    return {'solves_per_s': float(under_way.sum()) / wall, 'all_agents_solves_per_s': float(st[:, 0].sum()) / wall,
+            'ms_per_update': wall / n_steps * 1e3, 'updates': n_steps, 'solved_fraction': float(st[:, 0].sum()) / (n_steps * B),
+            'mean_iters': float(st[:, 1].sum()) / (n_steps * B), 'max_iters': int(st[:, 2].max()),
+            'arrived_fraction': float((arrived_at < n_steps).mean()), 'updates_to_arrival_p50': float(np.median(arrived_at)),
+            'updates_to_arrival_max': int(arrived_at.max()), 'distance_to_goal_at_end_max_m': float(dist.max()),
+            'launches_per_update': len(parts), 'stop_tol': stop_tol, 'windows': windows,
+            'note': 'cold solve, then every update of the manoeuvre on the per-step product path; solves_per_s counts an agent only until it '
+                    'meets the reference\'s stop criterion (its later, trivial solves still run inside the timed region)'}
 
 
 def without_solver_objects(fn, *a, **kw):
@@ -738,8 +847,12 @@ def main():
                     help="p2p workload at N > 1: weak = --agents per GPU (default), strong = --agents in total, sharded over the ranks "
                          "(BASELINE's metric as worded: the 1024-agent batch at 1/2/4/8 GPU)")
     ap.add_argument('--streams', type=int, default=0,
-                    help='p2p: sub-batches of the per-step path on separate HIP streams (0 = automatic: two when the batch is at '
-                         'least two rounds of resident workgroups, else one)')
+                    help='p2p: sub-batches of the per-step path on separate HIP streams (0 = automatic: three -- '
+                         'omgtools.batch.PRODUCT_PATH_STREAMS -- when the batch is at least two rounds of resident workgroups, else one)')
+    ap.add_argument('--ipopt-defaults', action='store_true',
+                    help="also test IPOPT's absolute tolerances on the unscaled problem at their documented defaults (compl_inf_tol = "
+                         "constr_viol_tol = 1e-4, in force when the reference sets only ipopt.tol): omgx_options version 8")
+    ap.add_argument('--sustained-steps', type=int, default=120, help='updates of the whole-manoeuvre leg (`sustained`)')
     ap.add_argument('--workload', choices=['p2p', 'formation', 'rendezvous', 'quadrotor', 'holonomic3d'], default='p2p',
                     help="p2p = BASELINE.json configs[1] (headline); formation = configs[3], 512-agent ADMM")
     args = ap.parse_args()
@@ -776,6 +889,9 @@ def main():
     B = P['p'].shape[0]
     tpl = problem.father.template
     opts = dict(tol=args.tol, max_iter=300)
+    if args.ipopt_defaults:
+        from omgtools.backend import IPOPT_DEFAULT_TOLERANCES
+        opts.update(IPOPT_DEFAULT_TOLERANCES)
     # single-handle batch: the cold co-headline and the side legs (latency, fused store, rollout)
     mpc = BatchP2P(problem, P, ops='hip', device=dev, options=opts)
     solver = mpc.solver
@@ -915,6 +1031,7 @@ def main():
                    'step_form': ('%d stream-ordered sub-batch launches per step (omgtools.batch.receding_horizon_batch: the batch is two '
                                  'rounds of resident workgroups)' % n_parts if n_parts > 1 else 'one launch per step'),
                    'parallelism': 'agents sharded across ranks, no collective on the solve path'},
+        'tol': args.tol, 'compl_inf_tol': opts.get('compl_inf_tol', 0.0), 'constr_viol_tol': opts.get('constr_viol_tol', 0.0),
         'p50_batch_latency_ms': float(np.median(step_latency_ms)), 'max_batch_latency_ms': float(np.max(step_latency_ms)),
         'max_iters_in_a_step': int(stats[:, 2].max()), 'host_enqueue_ms_per_step': t_host / K * 1e3,
         'solved_fraction': n_ok / float(B), 'mean_iters': it_sum / float(n_meas * B),
@@ -954,7 +1071,29 @@ def main():
         rh.close()
     else:
         rh.solver.close()
+    if world == 1:
+        # the accuracy the solver settings of `value` buy: closed loop against an independent solver in the loop (64 agents, 25 updates)
+        try:
+            out['parity_at_tol'] = closed_loop_parity(opts, dev)
+            for k in ('closed_loop_pos_m', 'closed_loop_vel_mps', 'closed_loop_rel'):
+                out[k] = out['parity_at_tol'][k]
+        except Exception as e:
+            out['parity_at_tol'] = {'error': repr(e)}
     if world == 1 and not args.no_extras:
+        # the whole manoeuvre, and the accuracy / throughput curve over the solver settings (round-5 review, items 2 and 4)
+        try:
+            out['sustained'] = sustained_leg(problem, P, opts, args.sustained_steps, dev)
+        except Exception as e:
+            out['sustained'] = {'error': repr(e)}
+        from omgtools.backend import IPOPT_DEFAULT_TOLERANCES
+        curve = []
+        for label, o2 in (('tol 1e-3 + IPOPT default compl_inf_tol / constr_viol_tol 1e-4', dict(opts, tol=1e-3, **IPOPT_DEFAULT_TOLERANCES)),
+                          ('tol 1e-4', dict(opts, tol=1e-4)), ('tol 1e-5', dict(opts, tol=1e-5)), ('tol 1e-6', dict(opts, tol=1e-6))):
+            try:
+                curve.append(dict(tolerance_leg(problem, P, o2, args.steps, args.warmup, dev), settings=label))
+            except Exception as e:
+                curve.append({'settings': label, 'error': repr(e)})
+        out['tolerance_curve'] = curve
         out['latency_resident'] = latency_episodes(mpc, x0_init, p_init, 5, 40, host=False)
         out['latency_host_boundary'] = latency_episodes(mpc, x0_init, p_init, 5, 40, host=True)
         out['survey_8d_obstacle_rule'] = unedited_rule(args, dev, 20240807 + 2)

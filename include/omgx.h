@@ -171,6 +171,12 @@ typedef struct omgx_options {
                            onto it.  Linear convergence (hundreds of iterations), but phase I of these classes finishes:
                            `examples/p2p_dubins.py` as shipped.  Honoured by templates on the general kernel instance (quartic terms,
                            cos / sin atoms, lifted auxiliaries); ignored by the others */
+  double  compl_inf_tol;       /* (version 8) IPOPT's absolute tolerances on the unscaled problem, which stay at their documented defaults (1e-4
+                           each) when the reference sets only ipopt.tol = 1e-3 (`problems/problem.py:57`): a solve then ends when the scaled
+                           error is below tol AND the largest complementarity product |lam_i g_i| is below compl_inf_tol ... */
+  double  constr_viol_tol;     /* ... AND the largest unscaled violation of a row is below constr_viol_tol; the barrier parameter ends at
+                           min(tol, compl_inf_tol) / 10.  0 (default, rounds 1-5): neither is tested -- the scaled error alone decides.
+                           omgtools.backend maps 'ipopt.compl_inf_tol' / 'ipopt.constr_viol_tol' onto them when a caller sets them */
 } omgx_options;
 
 typedef struct omgx_batch omgx_batch;

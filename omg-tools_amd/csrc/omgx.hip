@@ -1454,7 +1454,7 @@ int omgx_template_block(const omgx_template* tpl, int32_t kind, const char* name
 void omgx_default_options(omgx_options* o) {
   o->tol = 1e-3; o->max_iter = 300; o->mu_init = 0.1; o->kappa_push = 1.0;
   o->nu_init = 100.0; o->scale_gmax = 100.0; o->warm_start = 0; o->kappa_warm = 1e-3;
-  o->dw_leaf_ratio_cold = 1.0; o->warm_mu_factor = 1.0; o->warm_z_floor = 0.1; o->warm_z_cap = 0.01; o->max_soc = 1; o->hess_approx = 0;
+  o->dw_leaf_ratio_cold = 1.0; o->warm_mu_factor = 1.0; o->warm_z_floor = 0.1; o->warm_z_cap = 0.01; o->max_soc = 1; o->hess_approx = 0; o->compl_inf_tol = 0.0; o->constr_viol_tol = 0.0;
 }
 
 int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device, omgx_batch** out) {
@@ -1469,7 +1469,7 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
   omgx_batch* b = new omgx_batch();
   b->device = device; b->n_agents = n_agents;
   omgx_options o; omgx_default_options(&o);
-  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm, o.dw_leaf_ratio_cold, 0, o.warm_mu_factor, o.warm_z_floor, o.warm_z_cap, o.max_soc, o.hess_approx};
+  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm, o.dw_leaf_ratio_cold, 0, o.warm_mu_factor, o.warm_z_floor, o.warm_z_cap, o.max_soc, o.hess_approx, o.compl_inf_tol, o.constr_viol_tol};
   ExpandedTemplate ex;
   const bool ranged = expand_range_rows(tpl, ex);
   b->n_con_user = tpl->n_con; b->n_range = ranged ? (int)ex.src.size() : 0;
@@ -1530,18 +1530,13 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
     // the setup kernel's records (omgx::prep_layout: ~43 KB per agent for config 2) and its LDS (atoms, knots, slots, x)
     b->prep_doubles = (size_t)omgx::prep_layout(d).total;
     b->prep_lds = prepare_lds_doubles(d) * sizeof(double);
-    const char* env = getenv("OMGX_PREPARE");       // developer switch: 0 = every solve does its own setup inside the solve kernel
-    b->prepare_on = !(env && env[0] == '0') && b->prep_lds <= (size_t)kLdsLimit;
-    if (b->prepare_on) {
-      if ((rc = dalloc(b, (size_t)n_agents * b->prep_doubles, &b->d_prep))) { omgx_batch_destroy(b); return rc; }
-      const void* pk = b->dims.general ? (const void*)ipm_prepare_kernel<true> : (const void*)ipm_prepare_kernel<false>;
-      static int prep_reserved[2] = {0, 0};
-      int& res = prep_reserved[b->dims.general ? 1 : 0];
-      if ((int)b->prep_lds > res) res = (int)b->prep_lds;
-      if (hipFuncSetAttribute(pk, hipFuncAttributeMaxDynamicSharedMemorySize, res) != hipSuccess) {
-        g_err = "cannot reserve dynamic LDS for ipm_prepare_kernel"; omgx_batch_destroy(b); return OMGX_E_HIP;
-      }
-    }
+    // OFF by default (omgx_batch_set_prepare / OMGX_PREPARE=1 switch it on).  Measured on the 1024-agent benchmark batch (round 6,
+    // profiles/r06_prepare_ab.txt): the solve kernel drops from 341 k to 277 k cycles per warm-started solve (its setup phase 77 k ->
+    // 6 k), but the setup kernel takes 64 us for the 1024 agents -- every workgroup walks the same chain of ~80 dependent table
+    // loads whatever the occupancy, and at the head of the solve kernel that chain already overlaps with the agent that shares
+    // the CU -- against 43 us saved: 1.73-1.74 M against 1.74-1.79 M solves/s with one launch per step.
+    const char* env = getenv("OMGX_PREPARE");
+    if (env && env[0] == '1') { const int rcp = omgx_batch_set_prepare(b, 1); if (rcp != OMGX_OK) { omgx_batch_destroy(b); return rcp; } }
   }
   *out = b;
   return OMGX_OK;
@@ -1549,8 +1544,19 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
 
 int omgx_batch_set_prepare(omgx_batch* b, int32_t on) {
   if (!b) return OMGX_E_INVALID;
-  if (on && !b->d_prep) { g_err = "this handle was created without the setup kernel's records (OMGX_PREPARE=0, or its LDS does not fit)"; return OMGX_E_INVALID; }
-  b->prepare_on = on != 0;
+  if (!on) { b->prepare_on = false; return OMGX_OK; }
+  if (b->prep_lds > (size_t)kLdsLimit) { g_err = "the setup kernel's LDS (atoms, knots, slots, x) does not fit one CU for this template"; return OMGX_E_INVALID; }
+  if (!b->d_prep) {      // the records: allocated when the kernel is first asked for
+    HIPCHK(hipSetDevice(b->device));
+    const int rc = dalloc(b, (size_t)b->n_agents * b->prep_doubles, &b->d_prep);
+    if (rc != OMGX_OK) return rc;
+    const void* pk = b->dims.general ? (const void*)ipm_prepare_kernel<true> : (const void*)ipm_prepare_kernel<false>;
+    static int prep_reserved[2] = {0, 0};
+    int& res = prep_reserved[b->dims.general ? 1 : 0];
+    if ((int)b->prep_lds > res) res = (int)b->prep_lds;
+    if (hipFuncSetAttribute(pk, hipFuncAttributeMaxDynamicSharedMemorySize, res) != hipSuccess) { g_err = "cannot reserve dynamic LDS for ipm_prepare_kernel"; return OMGX_E_HIP; }
+  }
+  b->prepare_on = true;
   return OMGX_OK;
 }
 
@@ -1578,7 +1584,8 @@ int omgx_batch_set_options(omgx_batch* b, const omgx_options* o) {
   if (!b || !o || !(o->tol > 0) || o->max_iter < 0) { g_err = "bad options"; return OMGX_E_INVALID; }
   b->opts = {o->tol, o->max_iter, o->mu_init, o->kappa_push, o->nu_init, o->scale_gmax, o->warm_start, o->kappa_warm,
              o->dw_leaf_ratio_cold > 0 ? o->dw_leaf_ratio_cold : 1.0, 0, o->warm_mu_factor >= 0 ? o->warm_mu_factor : 0.0,
-             o->warm_z_floor >= 0 ? o->warm_z_floor : 0.0, o->warm_z_cap >= 0 ? o->warm_z_cap : 0.0, o->max_soc > 0 ? 1 : 0, o->hess_approx > 0 ? 1 : 0};
+             o->warm_z_floor >= 0 ? o->warm_z_floor : 0.0, o->warm_z_cap >= 0 ? o->warm_z_cap : 0.0, o->max_soc > 0 ? 1 : 0, o->hess_approx > 0 ? 1 : 0,
+             o->compl_inf_tol > 0 ? o->compl_inf_tol : 0.0, o->constr_viol_tol > 0 ? o->constr_viol_tol : 0.0};
   return OMGX_OK;
 }
 

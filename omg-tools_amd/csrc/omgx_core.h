@@ -170,7 +170,10 @@ struct Opts {
   double warm_z_floor;         // warm starts: multipliers lifted to max(OMGX_WARM_ZMIN, min(warm_z_floor * tol, warm_z_cap * tol / slack))
   double warm_z_cap;           // (0: no cap)
   int max_soc;                 // 1: a rejected first trial of the line search is answered by a second-order correction (every template class: kkt_solve2_wave / kkt_solve2)
-  int hess_approx;             // 1: no constraint curvature in the Hessian, damping driven by the accepted step length (general instances; include/omgx.h)
+  int hess_approx;             // 1: no constraint curvature in the Hessian, damping driven by the accepted step length (general instances; include/omgx.h)  // (version 8) IPOPT's absolute tolerances on the UNSCALED problem beside `tol` (its documented defaults: compl_inf_tol = constr_viol_tol = 1e-4,
+  // which the reference leaves in force when it sets ipopt.tol = 1e-3, `problems/problem.py:57`); 0: not tested (rounds 1-5).  The barrier
+  // parameter ends at min(tol, compl_tol) / 10.
+  double compl_tol, viol_tol;
 };
 
 // fixed constants of the iteration (same values in oracle/ipm_numpy.py DEFAULTS)
@@ -2229,6 +2232,7 @@ OMGX_FN Start ipm_setup(const C& c, const Dims& d, const Tables& T, const Opts& 
   // them are requested here, so that their latencies overlap with each other and with the parameter
   // stage (p is loaded by eval_params; the multipliers wait in w.ds, which is free until the assembly)
   const bool warm_in = o.warm_start && prev_status == 0;
+  const double tol_c = (o.compl_tol > 0.0 && o.compl_tol < o.tol) ? o.compl_tol : o.tol;      // what the complementarity has to reach
   OMGX_PFOR(i, n) w.x[i] = x0[i];
   if constexpr (!C::prep) { if (warm_in) { OMGX_PFOR(r, m) w.ds[r] = lam0[r]; } }
   if (c.tid() == 0) w.x[n] = 1.0;
@@ -2330,14 +2334,14 @@ OMGX_FN Start ipm_setup(const C& c, const Dims& d, const Tables& T, const Opts& 
         // step runs into it: hundreds of iterations with step lengths of 1e-2 on a knot-crossing x-update; the floor keeps
         // such rows in the picture)
         const double s_r = row_slack(w, r, t);
-        w.z[r] = fmax((C::prep ? lam0[r] : w.ds[r]) / w.rho[r], fmax(OMGX_WARM_ZMIN, fmin(o.warm_z_floor * o.tol, o.warm_z_cap > 0.0 ? o.warm_z_cap * o.tol / s_r : 1e300)));
+        w.z[r] = fmax((C::prep ? lam0[r] : w.ds[r]) / w.rho[r], fmax(OMGX_WARM_ZMIN, fmin(o.warm_z_floor * tol_c, o.warm_z_cap > 0.0 ? o.warm_z_cap * tol_c / s_r : 1e300)));
         sz += s_r * w.z[r]; cnt0 += 1.0;
       } else if (ty == ROW_EQ) {
         w.z[r] = (C::prep ? lam0[r] : w.ds[r]) / w.rho[r];
       }
     }
     { double rv[2] = {sz, cnt0}; c.template reduce_ops<0, 0>(rv); sz = rv[0]; cnt0 = rv[1]; }
-    mu = c.uni(fmin(o.mu_init, fmax(o.tol / 10.0, o.warm_mu_factor * sz / fmax(1.0, cnt0))));
+    mu = c.uni(fmin(o.mu_init, fmax(tol_c / 10.0, o.warm_mu_factor * sz / fmax(1.0, cnt0))));
     // multiplier of t >= 0: dual feasible in t (nu - v'z - zt = 0) rather than on the central path,
     // so that the first Newton step in t is O(t) instead of O(nu t^2 / mu)
   }
@@ -2415,6 +2419,10 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
   if (st.status == 3) return res;
   Kkt K; K.bind(d, T, w.kkt);
   const bool warm = st.warm != 0, use_t = st.use_t != 0;
+  const double tol_c = (o.compl_tol > 0.0 && o.compl_tol < o.tol) ? o.compl_tol : o.tol;
+  const double mu_floor = tol_c / 10.0;
+  // (rows are tested scaled, `viol <= tol`; with viol_tol set also unscaled, folded into the same maximum: value / |rho| <= viol_tol)
+  const double viol_fold = o.viol_tol > 0.0 ? o.tol / o.viol_tol : 0.0;
   double mu = st.mu, nu = o.nu_init, zt = st.zt, f = st.f;
   double t = use_t ? 1.0 : 0.0;
   // a warm start also inherits the inertia correction the previous solve of this agent ended with
@@ -2505,12 +2513,13 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
     double viol = 0.0, zh = 0.0, rE_max = 0.0, rE_sum = 0.0, vz = 0.0, lam_sum = 0.0, cnt = 0.0;
     OMGX_PFOR(r, m) {
       const int ty = w.rtype[r];
+      const double vmul = viol_fold > 0.0 ? fmax(1.0, viol_fold / fabs(w.rho[r])) : 1.0;
       if (ty == ROW_UPPER || ty == ROW_LOWER) {
         cnt += 1.0; lam_sum += fabs(w.z[r]); vz += w.vv[r] * w.z[r];
-        viol = fmax(viol, w.hv[r]); zh = fmax(zh, fabs(w.z[r] * w.hv[r]));
+        viol = fmax(viol, w.hv[r] * vmul); zh = fmax(zh, fabs(w.z[r] * w.hv[r]));
       } else if (ty == ROW_EQ) {
         cnt += 1.0; lam_sum += fabs(w.z[r]); vz += w.vv[r] * w.z[r];
-        viol = fmax(viol, fabs(w.hv[r]));
+        viol = fmax(viol, fabs(w.hv[r]) * vmul);
         const double re = w.hv[r] - t * w.vv[r];
         rE_max = fmax(rE_max, fabs(re)); rE_sum += fabs(re);
       }
@@ -2524,7 +2533,7 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
     const double sd = c.uni(fmax(OMGX_S_MAX, lam_sum / fmax(1.0, cnt)) / OMGX_S_MAX);
     const double err0 = fmax(rd_max / sd, fmax(viol, zh / sd));
     res.f = f; res.mu = mu; res.t = t; res.iters = it;
-    if (err0 <= o.tol) { status = 0; break; }
+    if (err0 <= o.tol && (o.compl_tol <= 0.0 || zh <= o.compl_tol)) { status = 0; break; }
     if (it == o.max_iter) break;
     // barrier-problem error at a given mu.  Under a heavy inertia correction (concave rows with
     // multipliers ~ mu/s: the negative curvature itself scales with mu) the damped Newton method
@@ -2541,8 +2550,8 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
       if (use_t) comp = fmax(comp, fabs(t * zt - mu));
       const double rd_t = use_t ? (nu - vz - zt) : 0.0;
       const double emu = fmax(fmax(rd_max, fabs(rd_t)) / sd, fmax(rE_max, comp / sd));
-      if (mu > o.tol / 10.0 && emu <= keps * mu) {
-        mu = c.uni(fmax(o.tol / 10.0, fmin(OMGX_KAPPA_MU * mu, pow(mu, OMGX_THETA_MU))));
+      if (mu > mu_floor && emu <= keps * mu) {
+        mu = c.uni(fmax(mu_floor, fmin(OMGX_KAPPA_MU * mu, pow(mu, OMGX_THETA_MU))));
         continue;
       }
       if (use_t && zt < 0.1 * nu && t > o.tol && emu <= 100.0 * OMGX_KAPPA_EPS * mu) {
@@ -2551,6 +2560,12 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
         continue;
       }
       break;
+    }
+    // (version 8, constr_viol_tol: everything but the violation of the rows is converged and the barrier parameter sits on its
+    // floor -- what is left is t v_i, the shift phase I still holds: the penalty weight takes t down, a factor ten at a time)
+    if (use_t && viol_fold > 0.0 && !infeasible && mu <= mu_floor && nu < OMGX_NU_MAX && viol > o.tol &&
+        fmax(rd_max, zh) / sd <= o.tol && (o.compl_tol <= 0.0 || zh <= o.compl_tol)) {
+      nu = c.uni(nu * 10.0); zt = c.uni(zt + 0.9 * nu);
     }
     // stall test: phase I must shrink t by at least 10 % over OMGX_STALL_ITERS (20) iterations.
     // A warm-started solve (the previous solve of this agent converged, so a stall is likely
@@ -2925,8 +2940,10 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
     // (wave path: kkt_solve2_wave; every other template: kkt_solve2's blocked form -- round 4: the spill classes gain most,
     // 39 -> 33 cold iterations on the 3-D class, and a tube of quartic range rows 717 -> 149)
     int soc = (OMGX_SOC_COMPILED && o.max_soc > 0) ? 0 : 2;      // 0: not tried yet, 1: the trial under way is the corrected one, 2: done
+    int soc_rounds = 0;                                          // corrections computed for this step (at most OMGX_SOC_ROUNDS: IPOPT's max_soc is 4)
     for (int bt = 0; bt < OMGX_MAX_BACKTRACK; ++bt) {
-      if (soc == 1) { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + (alpha * w.sol[q] + w.gbar[q]); } }
+      if (soc == 1 && soc_rounds > 1) { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] += w.gbar[q]; } }      // (a further correction on top of the corrected trial)
+      else if (soc == 1) { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + (alpha * w.sol[q] + w.gbar[q]); } }
       else { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + alpha * w.sol[q]; } }
       c.sync();
       if constexpr (C::general) lift_project(c, d, T, w, m, w.xt);
@@ -2973,13 +2990,19 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
         // noise: such a step is taken as it is, like IPOPT's tiny-step rule; the error test decides about the rest)
         if (phi_noise || phit <= phi0 + OMGX_ETA * alpha * dphi || phit - phi0 <= 10.0 * 2.220446049250313e-16 * fabs(phi0)) { ok = 1; break; }
       }
-      if (soc == 1) {       // the corrected trial failed too: plain backtracking from here
+#ifndef OMGX_SOC_ROUNDS
+#define OMGX_SOC_ROUNDS 1
+#endif
+      // (the corrected trial failed too: one more correction from where it landed while its rows still violate -- a step along a
+      // curved row whose slack is tiny needs the correction to be exact to that slack --, else plain backtracking from here)
+      if (soc == 1 && soc_rounds < OMGX_SOC_ROUNDS && !(smin > 0.0)) soc = 0;
+      if (soc == 1) {
         soc = 2;
         alpha = c.uni(alpha * 0.5);
         c.sync(); continue;
       }
       if (soc == 0) {
-        soc = 1;
+        soc = 1; ++soc_rounds;
 #ifdef OMGX_COUNT_FACT
         ++omgx_dbg_cnt[9];
 #endif

@@ -57,7 +57,8 @@ class COptions(C.Structure):
     _fields_ = [('tol', C.c_double), ('max_iter', C.c_int32), ('mu_init', C.c_double),
                 ('kappa_push', C.c_double), ('nu_init', C.c_double), ('scale_gmax', C.c_double),
                 ('warm_start', C.c_int32), ('kappa_warm', C.c_double),
-                ('dw_leaf_ratio_cold', C.c_double), ('warm_mu_factor', C.c_double), ('warm_z_floor', C.c_double), ('warm_z_cap', C.c_double), ('max_soc', C.c_int32), ('hess_approx', C.c_int32)]
+                ('dw_leaf_ratio_cold', C.c_double), ('warm_mu_factor', C.c_double), ('warm_z_floor', C.c_double), ('warm_z_cap', C.c_double), ('max_soc', C.c_int32), ('hess_approx', C.c_int32),
+                ('compl_inf_tol', C.c_double), ('constr_viol_tol', C.c_double)]
 
 
 class CRolloutSpec(C.Structure):
@@ -72,7 +73,7 @@ class CRolloutSpec(C.Structure):
 
 DEFAULT_OPTIONS = dict(tol=1e-3, max_iter=300, mu_init=0.1, kappa_push=1.0,
                        nu_init=100.0, scale_gmax=100.0, warm_start=0, kappa_warm=1e-3,
-                       dw_leaf_ratio_cold=1.0, warm_mu_factor=1.0, warm_z_floor=0.1, warm_z_cap=0.01, max_soc=1, hess_approx=0)
+                       dw_leaf_ratio_cold=1.0, warm_mu_factor=1.0, warm_z_floor=0.1, warm_z_cap=0.01, max_soc=1, hess_approx=0, compl_inf_tol=0.0, constr_viol_tol=0.0)
 
 
 def make_options(**kw):
@@ -94,6 +95,11 @@ def options_from_problem(options):
     # Hessian without the curvature of the rows, damped by the accepted step length -- include/omgx.h `hess_approx`)
     if ipopt.get('ipopt.hessian_approximation') == 'limited-memory':
         kw['hess_approx'] = 1
+    # (IPOPT's absolute tolerances on the unscaled problem, when a caller sets them -- include/omgx.h; left alone, the scaled error
+    # `tol` alone decides, as in rounds 1-5: IPOPT_DEFAULT_TOLERANCES below is what IPOPT itself would keep in force)
+    for key, name in (('ipopt.compl_inf_tol', 'compl_inf_tol'), ('ipopt.constr_viol_tol', 'constr_viol_tol')):
+        if key in ipopt:
+            kw[name] = float(ipopt[key])
     kw.update(options.get('omgx', {}))
     kw.pop('hess_fallback', None)      # (a switch of the drop-in solver object, `NlpSolver`: not a solver setting)
     return kw
@@ -110,6 +116,10 @@ def template_is_general(tpl):
     prog = np.asarray(tpl.prog).reshape(-1, 6)
     return bool(len(prog) and np.isin(prog[:, 0], (2, 3)).any())
 
+
+# IPOPT's documented defaults of the two absolute tolerances: what `nlpsol('ipopt')` with the reference's options (ipopt.tol = 1e-3
+# only, `problems/problem.py:57`) tests beside the scaled error -- `dict(tol=1e-3, **IPOPT_DEFAULT_TOLERANCES)` is the like-for-like setting
+IPOPT_DEFAULT_TOLERANCES = dict(compl_inf_tol=1e-4, constr_viol_tol=1e-4)
 
 ROOT_HINT = ('splines_seg',)
 

@@ -300,13 +300,16 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
     z = mu / s
     zt = mu / t if use_t else 0.0
     y = np.zeros(mE)
+    # (omgx_options compl_inf_tol / constr_viol_tol, version 8: IPOPT's absolute tolerances on the unscaled problem; 0 = not tested)
+    compl_tol, viol_tol = float(o.get('compl_inf_tol', 0.0)), float(o.get('constr_viol_tol', 0.0))
+    tol_c = compl_tol if 0.0 < compl_tol < o['tol'] else o['tol']
     if z0 is not None:
         # primal-dual warm start: multipliers of the previous solve (unscaled lam_g),
         # barrier parameter from the average complementarity
         lam0 = np.asarray(z0, float) / rho
-        z = np.maximum(sig * lam0[iH], np.maximum(o['warm_zmin'], np.minimum(o['warm_z_floor'] * o['tol'], o['warm_z_cap'] * o['tol'] / s if o['warm_z_cap'] > 0 else np.inf)))
+        z = np.maximum(sig * lam0[iH], np.maximum(o['warm_zmin'], np.minimum(o['warm_z_floor'] * tol_c, o['warm_z_cap'] * tol_c / s if o['warm_z_cap'] > 0 else np.inf)))
         y = lam0[iE].copy()
-        mu = float(min(o['mu_init'], max(o['tol'] / 10., o['warm_mu_factor'] * (s * z).mean())))
+        mu = float(min(o['mu_init'], max(tol_c / 10., o['warm_mu_factor'] * (s * z).mean())))
     # multiplier of t >= 0: dual feasible in t (nu - v'z - c0'y - zt = 0) rather than on the central
     # path, so that the first Newton step in t is O(t) instead of O(nu t^2 / mu)
     zt = max(mu / t, nu - v @ z - cE0 @ y) if use_t else 0.0
@@ -350,6 +353,10 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         r_d[n] -= zt
         sd = max(o['s_max'], (np.abs(y).sum() + np.abs(z).sum()) / max(1, mE + mH)) / o['s_max']
         viol = max(np.maximum(h, 0).max() if mH else 0.0, np.abs(cE).max() if mE else 0.0)
+        if viol_tol > 0.0:      # the unscaled violation, folded into the same maximum (omgx_core.h `viol_fold`)
+            fold = o['tol'] / viol_tol
+            viol = max((np.maximum(h, 0) * np.maximum(1.0, fold / np.abs(rho[iH]))).max() if mH else 0.0,
+                       (np.abs(cE) * np.maximum(1.0, fold / np.abs(rho[iE]))).max() if mE else 0.0)
 
         def kkt_error(mu_):
             comp = np.abs(s * z - mu_).max() if mH else 0.0
@@ -357,14 +364,15 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                 comp = max(comp, abs(t * zt - mu_))
             return max(np.abs(r_d).max() / sd, np.abs(rE).max() if mE else 0.0, comp / sd)
 
-        err0 = max(np.abs(r_d[:n]).max() / sd, viol, (np.abs(z * h).max() / sd) if mH else 0.0)
+        zh_now = np.abs(z * h).max() if mH else 0.0
+        err0 = max(np.abs(r_d[:n]).max() / sd, viol, zh_now / sd)
         if trace is not None:
             trace.append(dict(it=it, f=f, mu=mu, err=err0, inf_pr=viol, inf_du=np.abs(r_d).max(),
                               dw=dw_last, nu=nu, t=t, zt=zt, imax=int(np.argmax(np.abs(r_d)))))
             if o.get('trace_full'):
                 trace[-1].update(r_d=r_d.copy(), y=y.copy(), z=z.copy(), s=s.copy(), x=x.copy(), iH=iH, iE=iE,
                                  Jh=Jh.copy(), Je=Je.copy())
-        if err0 <= o['tol']:
+        if err0 <= o['tol'] and (compl_tol <= 0.0 or zh_now <= compl_tol):
             status = 0
             break
         if it == o['max_iter']:
@@ -372,8 +380,8 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         while True:
             r_d[n] = (nu - v @ z - cE0 @ y - zt) if use_t else 0.0
             emu = kkt_error(mu)
-            if mu > o['tol'] / 10. and emu <= (o['kappa_eps_heavy'] if dw_last > o['dw_heavy'] else o['kappa_eps']) * mu:
-                mu = max(o['tol'] / 10., min(o['kappa_mu'] * mu, mu ** o['theta_mu']))
+            if mu > tol_c / 10. and emu <= (o['kappa_eps_heavy'] if dw_last > o['dw_heavy'] else o['kappa_eps']) * mu:
+                mu = max(tol_c / 10., min(o['kappa_mu'] * mu, mu ** o['theta_mu']))
                 continue
             if use_t and zt < 0.1 * nu and t > o['tol'] and emu <= o.get('esc_factor', 100) * o['kappa_eps'] * mu:
                 if nu >= o['nu_max']:
@@ -383,6 +391,11 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                 zt += 0.9 * nu
                 continue
             break
+        if use_t and viol_tol > 0.0 and status != 2 and mu <= tol_c / 10. and nu < o['nu_max'] and viol > o['tol'] and \
+                max(np.abs(r_d[:n]).max(), zh_now) / sd <= o['tol'] and (compl_tol <= 0.0 or zh_now <= compl_tol):
+            # (omgx_core.h: only the violation of the rows is left, i.e. the shift t v phase I still holds)
+            nu *= 10.0
+            zt += 0.9 * nu
         if use_t and it > 0 and it % o['stall_iters'] == 0:
             # phase I stalls: a warm-started solve raises the penalty weight first (local infeasibility
             # only at nu_max), a cold solve gives up at once

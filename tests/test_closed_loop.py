@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-N_TRAJ, FLOOR = 20, 1e-1
+FLOOR = 1e-1      # (tools/closed_loop.py FLOOR)
 
 # The NLP is non-convex: now and then two solvers leave a step in different local minima (one passes a disc on the other side, or
 # slides along a flat face of the L1 objective) and the two closed loops part for good.  Such agents are COUNTED (objective of
@@ -50,68 +50,20 @@ BOUNDS_CFG5 = {1e-3: (5.0e-2, 5.0e-2, 2.0e-1),
                1e-6: (1.5e-4, 6.0e-4, 6.0e-3)}
 
 
-def sampled(problem, tpl, x, p, spl, sample_time):
-    """state [B, n_spl, N_TRAJ] and input of the plans x [B, n_var] whose horizon clock stands at p[:, o_t]."""
-    veh = problem.vehicles[0]
-    T = float(problem.options['horizon_time'])
-    o_t = tpl.entry_range(problem.label, 't', 'par')[0]
-    L = len(veh.basis)
-    c = x[:, spl[0]:spl[1]].reshape(x.shape[0], -1, L)
-    dbasis, P1 = veh.basis.derivative(1)
-    st = np.zeros((x.shape[0], c.shape[1], N_TRAJ)); inp = np.zeros_like(st)
-    for b in range(x.shape[0]):
-        tau = (p[b, o_t] + sample_time * np.arange(N_TRAJ)) / T
-        E = np.asarray(veh.basis.eval_basis(tau))                 # [N_TRAJ, L]
-        Ed = np.asarray(dbasis.eval_basis(tau)) @ P1 / T
-        st[b], inp[b] = c[b] @ E.T, c[b] @ Ed.T
-    return st, inp
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+import closed_loop as cl          # tools/closed_loop.py: the comparison itself (shared with bench.py's `parity_at_tol`)
+
+
+def _objective(tpl):
+    from oracle.nlp_numpy import NumpyNLP
+    nlp = NumpyNLP(tpl)
+    return lambda x, p: nlp.fg(x, nlp.term_coefs(p))[0]
 
 
 def run_loop(make_mpc, tol, cfg='cfg2'):
-    from omgtools import workloads
-    from oracle.nlp_numpy import NumpyNLP
-    d = np.load(os.path.join(HERE, 'closed_loop_%s.npz' % cfg))
-    steps, n = d['x'].shape[0] - 1, d['x'].shape[1]
-    problem, P = {'cfg2': workloads.holonomic_p2p, 'cfg3': workloads.quadrotor_p2p, 'cfg5': workloads.holonomic3d_p2p}[cfg](n)
-    tpl = problem.father.template
-    nlp = NumpyNLP(tpl)
-    # (agents whose reference loop holds a step SLSQP did not finish -- 2 of the 8 Quadrotor agents: feasibility above 1e-7 at its
-    # 'positive directional derivative' exit -- are left out of the comparison, not out of the product's loop)
-    usable = d['ok'].all(axis=0)
-    assert np.array_equal(P['p'], d['p0']) and np.array_equal(P['x0'], d['x0']) and usable.sum() >= {'cfg2': n, 'cfg3': 6, 'cfg5': 6}[cfg]
-    assert (int(d['n_var']), int(d['n_con'])) == (tpl.n_var, tpl.n_con) and d['crossed'].sum() == {'cfg2': 2, 'cfg3': 3, 'cfg5': 2}[cfg]
-    spl, dt_s = d['spl'], float(d['sample_time'])
-    mpc = make_mpc(problem, P, dict(P.get('solver_options', {}), tol=tol, max_iter=300))
-    mpc.solve_cold(bends=())
-    assert (mpc.host('status') == 0).all()
-    parted = ~usable
-    parted_at = {}
-    capped = 0
-    e_state, e_input, e_rel = np.zeros((steps + 1, n)), np.zeros((steps + 1, n)), np.zeros((steps + 1, n))
-    for k in range(steps + 1):
-        if k > 0:
-            crossed = bool(mpc.step())
-            assert crossed == bool(d['crossed'][k]), k
-            # (tol 1e-6: the step before a knot crossing may crawl -- DESIGN.md 7, 0.04 % of the solves of the 1024-agent batch end
-            # at the iteration cap; such an agent keeps its last strictly feasible iterate and starts cold in the next step)
-            capped += int((mpc.host('status') != 0).sum())
-            assert capped <= (0 if tol >= 1e-3 else 2), (k, np.nonzero(mpc.host('status'))[0])
-        x, p = mpc.host('x'), mpc.host('p')
-        s_got, i_got = sampled(problem, tpl, x, p, spl, dt_s)
-        s_ref, i_ref = sampled(problem, tpl, d['x'][k], d['p'][k], spl, dt_s)
-        e_s, e_i = np.abs(s_got - s_ref), np.abs(i_got - i_ref)
-        e_state[k], e_input[k] = e_s.max(axis=(1, 2)), e_i.max(axis=(1, 2))
-        e_rel[k] = np.maximum((e_s / np.maximum(np.maximum(np.abs(s_got), np.abs(s_ref)), FLOOR)).max(axis=(1, 2)),
-                              (e_i / np.maximum(np.maximum(np.abs(i_got), np.abs(i_ref)), FLOOR)).max(axis=(1, 2)))
-        for b in np.nonzero(~parted)[0]:
-            f = nlp.fg(x[b], nlp.term_coefs(p[b]))[0]
-            if abs(f - d['f'][k, b]) > 2e-2 * (1 + abs(f)) or e_state[k, b] > 0.1:
-                parted[b] = True
-                parted_at[int(b)] = (k, float(f), float(d['f'][k, b]))
-    keep = ~parted
-    worst = np.array([e_state[:, keep].max(), e_input[:, keep].max(), e_rel[:, keep].max()])
-    first = np.array([e_state[0, keep].max(), e_input[0, keep].max(), e_rel[0, keep].max()])
-    return worst, first, parted_at, np.median(e_state[-1, keep])
+    worst, first, parted_at, med, _ = cl.run_loop(make_mpc, tol, cfg, objective=_objective, max_capped=0 if tol >= 1e-3 else 2)
+    return worst, first, parted_at, med
 
 
 def check(make_mpc, tol, who, cfg='cfg2'):

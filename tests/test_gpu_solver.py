@@ -127,3 +127,22 @@ def test_ragged_batch_and_masked_shift(cfg2_small):
                                                     x[:, lo:lo + rows * cols])
             assert np.abs(out - want).max() < 1e-12
         solver.close()
+
+
+def test_ipopt_absolute_tolerances_match_port(cfg2_small):
+    """omgx_options version 8 (`compl_inf_tol`, `constr_viol_tol`: IPOPT's absolute tolerances on the unscaled problem, at its
+    documented defaults): the HIP path takes the decisions of the host build -- same iteration counts -- and ends with
+    complementarity products below 1e-4; without the two options the iteration counts of the plain solve are unchanged."""
+    import omgtools.backend as be
+    from oracle import port_binding
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    for extra in ({}, be.IPOPT_DEFAULT_TOLERANCES):
+        opts = dict(tol=1e-3, max_iter=200, **extra)
+        solver = be.BatchSolver(tpl, 8, options=opts)
+        res = solver.solve(P['p'], P['x0'])
+        solver.close()
+        ref = port_binding.solve(tpl, P['p'], P['x0'], **opts)
+        assert np.array_equal(res['status'], ref['status']) and (res['status'] == 0).all()
+        assert np.abs(res['iters'] - ref['iters']).max() <= 1
+        assert np.abs(res['x'] - ref['x']).max() < 1e-6

@@ -88,3 +88,41 @@ def test_unsupported_and_free_bounds(cfg2_small):
     r = port_binding.solve(tpl, P['p'][:1], P['x0'][:1], lbg=lb, ubg=ub, tol=1e-3)
     assert r['status'][0] == 0
     assert np.all(r['lam_g'][0][100:235] == 0)
+
+
+def test_ipopt_absolute_tolerances(cfg2_small):
+    """omgx_options version 8: `compl_inf_tol` / `constr_viol_tol` -- IPOPT's absolute tolerances on the UNSCALED problem, which stay
+    at their documented defaults (1e-4 each) when the reference sets only ipopt.tol = 1e-3 (`problems/problem.py:57`).  With them
+    the solve ends only when the largest complementarity product |lam_i g_i| and the largest unscaled row violation are below
+    1e-4 as well (the barrier parameter then ends at min(tol, compl_inf_tol) / 10); host build == numpy statement in the iteration
+    counts; without them nothing changes (the iteration counts of the plain tol = 1e-3 solve)."""
+    from oracle import ipm_numpy, port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    import omgtools.backend as be
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    nlp = NumpyNLP(tpl)
+    n = 4
+    plain = port_binding.solve(tpl, P['p'][:n], P['x0'][:n], tol=1e-3, max_iter=200)
+    strict = port_binding.solve(tpl, P['p'][:n], P['x0'][:n], tol=1e-3, max_iter=200, **be.IPOPT_DEFAULT_TOLERANCES)
+    assert (plain['status'] == 0).all() and (strict['status'] == 0).all()
+    assert (strict['iters'] >= plain['iters']).all() and strict['iters'].sum() > plain['iters'].sum()
+    for b in range(n):
+        c = nlp.term_coefs(P['p'][b])
+        comp, viol = [], []
+        for res in (plain, strict):
+            g = nlp.fg(res['x'][b], c)[1]
+            lam = res['lam_g'][b]
+            side = np.where(np.isfinite(tpl.ub), g - tpl.ub, tpl.lb - g)
+            side = np.where(np.isfinite(tpl.ub) | np.isfinite(tpl.lb), side, 0.0)
+            comp.append(np.abs(lam * side).max())
+            viol.append(max(side.max(), 0.0))
+        assert comp[1] <= 1e-4 * (1 + 1e-9) and viol[1] <= 1e-4 * (1 + 1e-9), (comp, viol)
+        assert comp[0] > comp[1]                    # (the plain solve stops with products of ~1e-3 ...)
+        r = ipm_numpy.solve(nlp, P['x0'][b], P['p'][b], tpl.lb, tpl.ub, opts=dict(tol=1e-3, max_iter=200, **be.IPOPT_DEFAULT_TOLERANCES))
+        assert r['status'] == 0 and abs(r['iters'] - strict['iters'][b]) <= 1
+        assert abs(r['f'] - nlp.fg(strict['x'][b], c)[0]) < 1e-7
+    # the drop-in object forwards the reference's own option names
+    kw = be.options_from_problem({'solver': 'ipopt', 'solver_options': {'ipopt': {'ipopt.tol': 1e-3, 'ipopt.compl_inf_tol': 1e-4,
+                                                                                  'ipopt.constr_viol_tol': 2e-4}}})
+    assert kw == {'tol': 1e-3, 'compl_inf_tol': 1e-4, 'constr_viol_tol': 2e-4}
