@@ -195,7 +195,9 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   // values -- was done for the whole batch by ipm_prepare_kernel ahead of this launch; a solve then starts by loading its record.
   // The matrix descriptors (the same for every agent) are written once per workgroup.
   double* const jval_own = w.jval;
-  if (prep) { omgx::Kkt K0; K0.bind(d, T, w.kkt); omgx::kkt_describe(c, d, K0, w, true); }
+  // (the descriptors are rewritten per solve only where the fused trajectory store may use the space behind a small KKT store as scratch)
+  const bool describe_once = prep != nullptr || stp == nullptr;
+  if (describe_once) { omgx::Kkt K0; K0.bind(d, T, w.kkt); omgx::kkt_describe(c, d, K0, w, true); }
   // mode 0: one workgroup per agent.  Spill modes: the grid is capped at the number of HBM
   // slabs and every workgroup walks over its agents.
   // `order` (optional) maps launch slots to agents: the host can put expected stragglers first so
@@ -242,7 +244,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
       } else {
         w.jval = jval_own;
         st = omgx::ipm_setup(c, d, T, o, w, p + (size_t)b * d.n_par, xs, lbb, ubb, o.warm_start ? lam + (size_t)b * d.n_con : nullptr,
-                             o.warm_start ? status[b] : 0, kkt_doubles);
+                             o.warm_start ? status[b] : 0, kkt_doubles, !describe_once);
       }
       r = omgx::ipm_iterate(c, d, T, o, w, lbb, ubb, st, kkt_doubles, o.warm_start ? dw_state[b] : 0.0);
       __builtin_amdgcn_s_setprio(0);
@@ -285,6 +287,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
       sample_agent<double>(w.x + st.coeff_off, w.kkt, st.n_spl, st.degree, st.knots, st.n_knots, st.n_der, st.t0[b],
                            st.dt, st.inv_T, st.n_samp, 0, st.n_samp, st.out + (size_t)b * st.n_der * st.n_spl * st.n_samp,
                            st.v_tot ? st.v_tot + (size_t)b * st.n_samp : nullptr);
+      if (prep) { __syncthreads(); omgx::Kkt K0; K0.bind(d, T, w.kkt); omgx::kkt_describe(c, d, K0, w, true); }      // (the scratch may have reached the descriptors)
     }
 #ifdef OMGX_PROFILE
     __syncthreads();

@@ -2219,13 +2219,16 @@ struct Start { int status, warm, use_t; double mu, zt, f; };
 template <class C>
 OMGX_FN Start ipm_setup(const C& c, const Dims& d, const Tables& T, const Opts& o, Work& w,
                         const double* p, const double* x0, const double* lb, const double* ub,
-                        const double* lam0, int prev_status, int kkt_doubles) {
+                        const double* lam0, int prev_status, int kkt_doubles, bool describe = true) {
   const int n = d.n_var, m = d.n_con;
   Start res; res.status = 1; res.warm = 0; res.use_t = 0; res.mu = o.mu_init; res.zt = 0.0; res.f = 0.0;
   OMGX_TIC();
   if constexpr (!C::prep) {
-    Kkt K; K.bind(d, T, w.kkt);
-    kkt_describe(c, d, K, w, false);      // (beside the parameter program of eval_params, whose barriers publish it)
+    // (describe = false: the caller wrote the matrix descriptors -- the same for every agent -- once for its workgroup)
+    if (describe) {
+      Kkt K; K.bind(d, T, w.kkt);
+      kkt_describe(c, d, K, w, false);      // (beside the parameter program of eval_params, whose barriers publish it)
+    }
   }
 
   // the per-agent inputs come from HBM (~1 us each if loaded where they are first needed): all of
@@ -2264,7 +2267,7 @@ OMGX_FN Start ipm_setup(const C& c, const Dims& d, const Tables& T, const Opts& 
   // ... then one thread per row: classification, gradient-based scale, phase-I weight
   // (rows in the order of the ELL table of their Jacobian entries, eight entries in flight at a time: with the Jacobian
   // values in a slab -- two agents per CU -- a row that walks its entries one by one pays a memory round trip each)
-  double bad_local = 0.0;
+  double bad_local = 0.0, any_local = 0.0;
   OMGX_PFOR(ir, m) {
     const int r = T.row_perm[ir];
     const int Lr = T.jp_glen[ir >> 6];
@@ -2302,56 +2305,58 @@ OMGX_FN Start ipm_setup(const C& c, const Dims& d, const Tables& T, const Opts& 
     }
     else if (ty == ROW_EQ) v = h;
     w.vv[r] = v;
+    if (v != 0.0) any_local = 1.0;
   }
-  if (c.rmax(bad_local) > 0.0) { res.status = 3; return res; }
+  bool use_t;
+  {
+    double rv[2] = {bad_local, any_local};
+    c.template reduce_ops<1, 1>(rv);
+    if (rv[0] > 0.0) { res.status = 3; return res; }
+    use_t = rv[1] > 0.0;
+  }
   // the Jacobian the first iteration needs is this one with the rows scaled (the objective row as it is): one thread per
-  // entry, no second pass over the constraint terms at x0
+  // entry, no second pass over the constraint terms at x0.  (Round 6 measured the row owners writing their scaled entries inside the
+  // pass above instead: the scattered stores into the slab cost 3.4 k cycles more than this coalesced pass saves.)
   OMGX_PFOR_U4(e, d.nnz_j) {
     const int r = d.rp_packed ? (int)((uint32_t)T.je_rp[e] >> 16) : T.je_row[e];
     const double sc = (r < m) ? ((w.rtype[r] == ROW_FREE) ? 0.0 : w.rho[r]) : 1.0;
     w.jval[e] = jtmp[e] * sc;
   }
   OMGX_TOC(PH_S_CLASS);
-  double any_local = 0.0;
-  OMGX_PFOR(r, m) if (w.vv[r] != 0.0) any_local = 1.0;
-  const bool use_t = c.rmax(any_local) > 0.0;
   double mu = o.mu_init, nu = o.nu_init;
-  double t = use_t ? 1.0 : 0.0, zt = use_t ? mu / t : 0.0;
+  const double t = use_t ? 1.0 : 0.0;
+  double zt = 0.0, f;
   if (c.tid() == 0) w.x[n] = t;
-  OMGX_PFOR(r, m) {
-    const int ty = w.rtype[r];
-    w.z[r] = (ty == ROW_UPPER || ty == ROW_LOWER) ? mu / row_slack(w, r, t) : 0.0;
-  }
-  c.sync();
-  if (warm) {
-    // primal-dual warm start: multipliers of the previous solve (unscaled lam_g), barrier
-    // parameter from the average complementarity
-    double sz = 0.0, cnt0 = 0.0;
+  // start values of the multipliers -- cold: on the central path of mu_init; warm: the multipliers of the previous solve (unscaled
+  // lam_g), the barrier parameter from their average complementarity -- and, in the same pass, the sums the start scalars need
+  // (round 6: one pass and one reduction where there were three of each)
+  {
+    double sz = 0.0, cnt0 = 0.0, vz = 0.0;
     OMGX_PFOR(r, m) {
       const int ty = w.rtype[r];
+      double zr = 0.0;
       if (ty == ROW_UPPER || ty == ROW_LOWER) {
-        // (a row with a small slack AND a vanishing multiplier is invisible to the Newton system -- Sigma = z / s -- until the
-        // step runs into it: hundreds of iterations with step lengths of 1e-2 on a knot-crossing x-update; the floor keeps
-        // such rows in the picture)
         const double s_r = row_slack(w, r, t);
-        w.z[r] = fmax((C::prep ? lam0[r] : w.ds[r]) / w.rho[r], fmax(OMGX_WARM_ZMIN, fmin(o.warm_z_floor * tol_c, o.warm_z_cap > 0.0 ? o.warm_z_cap * tol_c / s_r : 1e300)));
-        sz += s_r * w.z[r]; cnt0 += 1.0;
-      } else if (ty == ROW_EQ) {
-        w.z[r] = (C::prep ? lam0[r] : w.ds[r]) / w.rho[r];
+        if (warm) {
+          // (a row with a small slack AND a vanishing multiplier is invisible to the Newton system -- Sigma = z / s -- until the
+          // step runs into it: hundreds of iterations with step lengths of 1e-2 on a knot-crossing x-update; the floor keeps
+          // such rows in the picture)
+          zr = fmax((C::prep ? lam0[r] : w.ds[r]) / w.rho[r], fmax(OMGX_WARM_ZMIN, fmin(o.warm_z_floor * tol_c, o.warm_z_cap > 0.0 ? o.warm_z_cap * tol_c / s_r : 1e300)));
+          sz += s_r * zr; cnt0 += 1.0;
+        } else zr = mu / s_r;
+      } else if (ty == ROW_EQ && warm) {
+        zr = (C::prep ? lam0[r] : w.ds[r]) / w.rho[r];
       }
+      w.z[r] = zr;
+      if (ty != ROW_FREE) vz += w.vv[r] * zr;
     }
-    { double rv[2] = {sz, cnt0}; c.template reduce_ops<0, 0>(rv); sz = rv[0]; cnt0 = rv[1]; }
-    mu = c.uni(fmin(o.mu_init, fmax(tol_c / 10.0, o.warm_mu_factor * sz / fmax(1.0, cnt0))));
+    double rv[4] = {sz, cnt0, vz, row_value_share(c, T, w, m, w.x)};
+    c.template reduce_ops<0, 0, 0, 0>(rv);
+    if (warm) mu = c.uni(fmin(o.mu_init, fmax(tol_c / 10.0, o.warm_mu_factor * rv[0] / fmax(1.0, rv[1]))));
     // multiplier of t >= 0: dual feasible in t (nu - v'z - zt = 0) rather than on the central path,
     // so that the first Newton step in t is O(t) instead of O(nu t^2 / mu)
-  }
-  double f;
-  {
-    double rv[2] = {0.0, row_value_share(c, T, w, m, w.x)};
-    OMGX_PFOR(r, m) if (w.rtype[r] != ROW_FREE) rv[0] += w.vv[r] * w.z[r];
-    c.template reduce_ops<0, 0>(rv);
-    zt = c.uni(use_t ? fmax(mu / t, nu - rv[0]) : 0.0);
-    f = rv[1];
+    zt = c.uni(use_t ? fmax(mu / t, nu - rv[2]) : 0.0);
+    f = rv[3];
   }
   OMGX_TOC(PH_S_INIT);
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
