@@ -158,7 +158,8 @@ typedef struct omgx_options {
                            complementarity and costs an ADMM x-update three iterations (formation bench: 4.3 instead of 1.2
                            per x-update); BatchP2P sets 0 -- its steps begin at tol / 10 whatever the complementarity
                            (warm_mu_factor 0.1), and the plain floor saves its crossing steps an iteration or two */
-  int32_t max_soc;             /* (version 5) 1 (default): a line search whose first trial is rejected offers the step once more with a
+  int32_t max_soc;             /* (version 5; version 8: a COUNT, at most 8, as IPOPT's max_soc -- further corrections while the corrected trial still
+                           leaves rows violated) 1 (default): a line search whose first trial is rejected offers the step once more with a
                            second-order correction -- one more solve with the factors of the iteration for the amount the rows
                            moved beyond their linearisation (the bilinear hyperplane rows) -- before it halves the step (IPOPT:
                            max_soc, the component replaced behind `basics/optilayer.py:60`); 0: plain backtracking.  Every template

@@ -1587,7 +1587,7 @@ int omgx_batch_set_options(omgx_batch* b, const omgx_options* o) {
   if (!b || !o || !(o->tol > 0) || o->max_iter < 0) { g_err = "bad options"; return OMGX_E_INVALID; }
   b->opts = {o->tol, o->max_iter, o->mu_init, o->kappa_push, o->nu_init, o->scale_gmax, o->warm_start, o->kappa_warm,
              o->dw_leaf_ratio_cold > 0 ? o->dw_leaf_ratio_cold : 1.0, 0, o->warm_mu_factor >= 0 ? o->warm_mu_factor : 0.0,
-             o->warm_z_floor >= 0 ? o->warm_z_floor : 0.0, o->warm_z_cap >= 0 ? o->warm_z_cap : 0.0, o->max_soc > 0 ? 1 : 0, o->hess_approx > 0 ? 1 : 0,
+             o->warm_z_floor >= 0 ? o->warm_z_floor : 0.0, o->warm_z_cap >= 0 ? o->warm_z_cap : 0.0, o->max_soc > 0 ? (o->max_soc > 8 ? 8 : o->max_soc) : 0, o->hess_approx > 0 ? 1 : 0,
              o->compl_inf_tol > 0 ? o->compl_inf_tol : 0.0, o->constr_viol_tol > 0 ? o->constr_viol_tol : 0.0};
   return OMGX_OK;
 }

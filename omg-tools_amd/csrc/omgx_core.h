@@ -169,7 +169,7 @@ struct Opts {
   double warm_mu_factor;       // warm starts: mu_0 = clamp(warm_mu_factor * mean(s z), tol / 10, mu_init)
   double warm_z_floor;         // warm starts: multipliers lifted to max(OMGX_WARM_ZMIN, min(warm_z_floor * tol, warm_z_cap * tol / slack))
   double warm_z_cap;           // (0: no cap)
-  int max_soc;                 // 1: a rejected first trial of the line search is answered by a second-order correction (every template class: kkt_solve2_wave / kkt_solve2)
+  int max_soc;                 // > 0: a rejected first trial of the line search is answered by up to max_soc second-order corrections (every template class: kkt_solve2_wave / kkt_solve2)
   int hess_approx;             // 1: no constraint curvature in the Hessian, damping driven by the accepted step length (general instances; include/omgx.h)  // (version 8) IPOPT's absolute tolerances on the UNSCALED problem beside `tol` (its documented defaults: compl_inf_tol = constr_viol_tol = 1e-4,
   // which the reference leaves in force when it sets ipopt.tol = 1e-3, `problems/problem.py:57`); 0: not tested (rounds 1-5).  The barrier
   // parameter ends at min(tol, compl_tol) / 10.
@@ -2945,7 +2945,7 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
     // (wave path: kkt_solve2_wave; every other template: kkt_solve2's blocked form -- round 4: the spill classes gain most,
     // 39 -> 33 cold iterations on the 3-D class, and a tube of quartic range rows 717 -> 149)
     int soc = (OMGX_SOC_COMPILED && o.max_soc > 0) ? 0 : 2;      // 0: not tried yet, 1: the trial under way is the corrected one, 2: done
-    int soc_rounds = 0;                                          // corrections computed for this step (at most OMGX_SOC_ROUNDS: IPOPT's max_soc is 4)
+    int soc_rounds = 0;                                          // corrections computed for this step (at most o.max_soc)
     for (int bt = 0; bt < OMGX_MAX_BACKTRACK; ++bt) {
       if (soc == 1 && soc_rounds > 1) { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] += w.gbar[q]; } }      // (a further correction on top of the corrected trial)
       else if (soc == 1) { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + (alpha * w.sol[q] + w.gbar[q]); } }
@@ -2995,12 +2995,10 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
         // noise: such a step is taken as it is, like IPOPT's tiny-step rule; the error test decides about the rest)
         if (phi_noise || phit <= phi0 + OMGX_ETA * alpha * dphi || phit - phi0 <= 10.0 * 2.220446049250313e-16 * fabs(phi0)) { ok = 1; break; }
       }
-#ifndef OMGX_SOC_ROUNDS
-#define OMGX_SOC_ROUNDS 1
-#endif
-      // (the corrected trial failed too: one more correction from where it landed while its rows still violate -- a step along a
-      // curved row whose slack is tiny needs the correction to be exact to that slack --, else plain backtracking from here)
-      if (soc == 1 && soc_rounds < OMGX_SOC_ROUNDS && !(smin > 0.0)) soc = 0;
+      // (round 6, max_soc > 1 -- IPOPT's max_soc is a count, default 4: the corrected trial failed too: one more correction from where
+      // it landed while its rows still violate -- a step along a curved row whose slack is tiny needs the correction to be exact to
+      // that slack --, else plain backtracking from here.  Holonomic3D cold solves: 36.3 -> 33.2 (2 rounds) -> 32.0 (4) iterations)
+      if (soc == 1 && soc_rounds < o.max_soc && !(smin > 0.0)) soc = 0;
       if (soc == 1) {
         soc = 2;
         alpha = c.uni(alpha * 0.5);

@@ -202,6 +202,9 @@ def fill_holonomic3d_p2p(tpl, veh_label, problem_label, obstacle_labels, L, n_ag
             _set(tpl, p, b, ol, 'rad', radii[l])
         _set(tpl, p, b, problem_label, 'T', horizon_time)
         straight_line(tpl, x0, b, veh_label, L, start, goal)
+    # (max_soc 4 -- IPOPT's default count -- was measured on this class in round 6: 36.3 -> 32.0 cold iterations on the host build, but on
+    # the device the further corrections cost more than the iterations they save -- a blocked second solve out of the slab each:
+    # 7.6 k -> 7.2 k cold solves/s at 8192 agents, 3.9 k -> 2.7 k at 1024: the default of one correction stays)
     return {'p': p, 'x0': x0, 'solver_options': {}}
 
 

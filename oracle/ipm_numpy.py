@@ -574,7 +574,9 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         # second-order correction (omgx_core.h, option max_soc; templates on the wave path like there): when the first
         # trial is rejected, one more solve with the factors of the iteration for what the rows moved beyond their
         # linearisation; the corrected step is offered once before the halving starts
-        soc = 0 if o['max_soc'] > 0 else 2
+        n_soc = int((opts or {}).get('max_soc', 1))          # (omgx_options max_soc: a count, default 1; DEFAULTS' entry belongs to solve_filter)
+        soc = 0 if n_soc > 0 else 2
+        soc_rounds = 0
         d_c = None
         for bt in range(o['max_backtrack']):
             step = alpha * dxt + d_c if soc == 1 else alpha * dxt
@@ -591,20 +593,24 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                 if phi_noise or phit <= phi0 + o['eta'] * alpha * dphi or phit - phi0 <= 10 * np.finfo(float).eps * abs(phi0):
                     ok = True
                     break
+            if soc == 1 and soc_rounds < n_soc and not (st - o.get('ftb_actual', 0.5) * (1.0 - tau) * s).min() > 0:
+                soc = 0                      # (omgx_core.h, max_soc > 1: one more correction from where the corrected trial landed)
             if soc == 1:
                 soc = 2
                 alpha *= 0.5
                 continue
             if soc == 0:
                 soc = 1
+                soc_rounds += 1
                 e = (s + alpha * ds) - st
                 eE = (cEt - tt * cE0) - (1.0 - alpha) * rE
                 rhs2 = np.r_[-(Jh.T @ (Sig * e)), -eE]
                 if not use_t:
                     rhs2[n] = 0.0
-                d_c = ldl_solve(L, d, rhs2)[:N]
+                d_new = ldl_solve(L, d, rhs2)[:N]
                 if not use_t:
-                    d_c[n] = 0.0
+                    d_new[n] = 0.0
+                d_c = d_new if d_c is None else d_c + d_new
                 continue
             alpha *= 0.5
         if trace is not None:
