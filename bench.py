@@ -130,7 +130,7 @@ def measured_traffic(n_agents):
     other batch sizes.  Counter unit KB; FETCH_SIZE doubled: on gfx950 rocprofv3 reports half the bytes of wide coalesced reads
     (MI355X_MICROARCH.md, HBM section) -- the table records are 16-byte-per-lane loads -- so this is an upper bound for the
     mixed access widths of this kernel; WRITE_SIZE as reported."""
-    for name in ('r05_pmc_hbm.json', 'r04_pmc_hbm.json'):
+    for name in ('r06_pmc_hbm.json', 'r05_pmc_hbm.json', 'r04_pmc_hbm.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if n_agents == 1024 and os.path.exists(path):
             d = json.load(open(path))
@@ -852,6 +852,7 @@ def main():
     ap.add_argument('--ipopt-defaults', action='store_true',
                     help="also test IPOPT's absolute tolerances on the unscaled problem at their documented defaults (compl_inf_tol = "
                          "constr_viol_tol = 1e-4, in force when the reference sets only ipopt.tol): omgx_options version 8")
+    ap.add_argument('--no-parity', action='store_true', help='skip the closed-loop parity leg (`parity_at_tol`: 26 launches of a 64-agent batch) -- profiling passes whose per-launch averages must cover the 1024-agent launches only')
     ap.add_argument('--sustained-steps', type=int, default=120, help='updates of the whole-manoeuvre leg (`sustained`)')
     ap.add_argument('--workload', choices=['p2p', 'formation', 'rendezvous', 'quadrotor', 'holonomic3d'], default='p2p',
                     help="p2p = BASELINE.json configs[1] (headline); formation = configs[3], 512-agent ADMM")
@@ -1071,7 +1072,7 @@ def main():
         rh.close()
     else:
         rh.solver.close()
-    if world == 1:
+    if world == 1 and not args.no_parity:
         # the accuracy the solver settings of `value` buy: closed loop against an independent solver in the loop (64 agents, 25 updates)
         try:
             out['parity_at_tol'] = closed_loop_parity(opts, dev)

@@ -1,15 +1,15 @@
 # One collection run of the evidence under profiles/ (round tag = $1, default r03).  Run on the GPU box:
 #   gpurun -- 'bash tools/run_profiles.sh r03'      then   python tools/profile_summary.py r03
 # The stats pass and every PMC pass are separate rocprofv3 runs (counters are never combined with trace domains).
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof
 R=$GRAFT_REPO_ROOT
 # the stats pass profiles the DEFAULT bench (two half-launches per step); the counter passes run one launch per step (--streams 1):
 # launches 0-4 of the process are then cold solves of the 1024-agent batch, the rest receding-horizon steps of all 1024 agents
-B1="python $R/bench.py --no-cpu --no-extras"
-B="python $R/bench.py --streams 1 --no-cpu --no-extras"
+B1="python $R/bench.py --no-cpu --no-extras --no-parity"
+B="python $R/bench.py --streams 1 --no-cpu --no-extras --no-parity"
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/stats -- $B1 > $R/gpurun_out/prof/bench_stats.json 2> $R/gpurun_out/prof/stats.err )
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof/fetch -- $B --steps 5 --warmup 1 > /dev/null 2> $R/gpurun_out/prof/fetch.err )
 ( cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof/write -- $B --steps 5 --warmup 1 > /dev/null 2> $R/gpurun_out/prof/write.err )
@@ -26,6 +26,7 @@ python bench.py --scaling strong --no-cpu --no-extras > gpurun_out/${TAG}_bench_
 python bench.py --agents 4096 --no-cpu --no-extras > gpurun_out/${TAG}_bench_n1_4096agents.json 2> gpurun_out/bench_4096.err
 python bench.py --agents 256 --no-cpu --no-extras > gpurun_out/${TAG}_bench_n1_256agents.json 2> gpurun_out/bench_256.err
 python bench.py --tol 1e-6 --no-cpu --no-extras > gpurun_out/${TAG}_bench_n1_tol1e-6.json 2> gpurun_out/bench_tol.err
+python bench.py --ipopt-defaults --no-cpu --no-extras > gpurun_out/${TAG}_bench_n1_ipopt_default_tolerances.json 2> gpurun_out/bench_ipd.err
 python bench.py --workload quadrotor --agents 4096 --steps 5 --warmup 2 > gpurun_out/${TAG}_bench_quadrotor_4096.json 2> gpurun_out/bench_quadrotor4096.err
 python bench.py --workload holonomic3d --agents 8192 --steps 3 --warmup 1 > gpurun_out/${TAG}_bench_holonomic3d_8192.json 2> gpurun_out/bench_h3d8192.err
 python bench.py --workload formation --steps 50 --warmup 5 > gpurun_out/${TAG}_bench_formation_n1.json 2> gpurun_out/bench_formation.err
