@@ -1498,6 +1498,9 @@ OMGX_FN int kkt_factor_wave(const C& c, const Dims& d, const Kkt& K, Work& w) {
     }
   }
   OMGX_TOC(PH_F_SCHUR);
+  // (Round 6 measured the root on the four waves of the workgroup -- root_ldl_4w, omgx_wave.h: the same bits, 30.2 k -> 22.1 k cycles alone
+  // on a CU -- and did not adopt it: inside the solve kernel f_root drops by 3.4 k only while the phases of the agent that shares the CU
+  // lose what the three parked waves used to leave it, 342 k -> 349 k cycles per solve: profiles/r06_micro_root_ldl.txt)
   int badr = 0;
   if (wave == 0) {
     const WPanel P = wpanel_root(Ms[d.n_leaf], d.n_root);

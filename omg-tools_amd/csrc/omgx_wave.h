@@ -168,6 +168,122 @@ __device__ __forceinline__ int wave_ldl(int off, const WPanel Pin) {
   return bad;
 }
 
+// Round 6: the packed root block by FOUR waves.  wave_ldl<40, 40, false> on one wave is a chain of 39 pivots at ~770 cycles each (two
+// v_readlane + one FMA per pair, 741 pairs, three waves parked: 35 k of the 76 k factorisation cycles of a solve).  Here the columns are
+// dealt round-robin to the waves (wave w holds columns w, w + 4, ...: NC / 4 registers per lane, lane i = row i as before); per pivot
+// the owner publishes its column and the reciprocal of its pivot in LDS (double-buffered: ONE workgroup barrier per pivot), every wave reads its
+// row's entry and the reciprocal, and the entries u_jk of its own columns as broadcast reads (all lanes one address: no v_readlane, no scalar-register traffic),
+// and updates its <= NC / 4 columns.  The arithmetic of every stored entry is that of wave_ldl -- a_ik <- fma(-(a_ij / d_j), u_kj, a_ik), the
+// pivots in the same order, the right-hand-side row as a lane vector updated with the same operands (kept by every wave) -- so the
+// factor is the SAME BITS.  All threads of the workgroup call it (waves beyond the fourth only take part in the barriers); `xoff`:
+// offset of 145 doubles of exchange buffer in the dynamic LDS; returns 1 (in every thread) if a pivot had the wrong sign -- nothing is
+// stored then -- and ends with a barrier (the factor is visible to the workgroup).
+// (W: this wave's index as a compile-time constant -- which columns it holds, whether it publishes the next one: nothing is decided at
+// run time but k < n; with the wave index in a register every pivot was a thicket of scalar branches, 730 cycles instead of 600 for the
+// un-pipelined form.  W = 4: a wave beyond the fourth, barriers only.)
+template <int NC, int W>
+__device__ __forceinline__ int root_ldl_4w_wave(int off, const WPanel P, int xoff) {
+  constexpr int NL = NC / 4;
+  constexpr int BS = 72;                               // a buffer: [0, 64) the column, [64] the reciprocal of its pivot
+  constexpr bool act = W < 4;
+  const double* A = omgx_lds + off;
+  double* Aw = omgx_lds + off;
+  double* X = omgx_lds + xoff;
+  const int lane = threadIdx.x & 63;
+  const int n = P.n;
+  const bool has_row = lane < n;                       // (the root has no carried register rows: nreg == n)
+  const int rl = has_row ? lane : 0;
+  const int ra = wsym<false>(P, rl);
+  double a[NL];
+#pragma unroll
+  for (int c = 0; c < NL; ++c) {                       // unconditional loads (all in flight), masked afterwards
+    const int j = 4 * c + (act ? W : 0);
+    const int jj = j > rl ? rl : j;
+    const double v = A[ra + jj];
+    a[c] = (has_row && j <= rl) ? v : 0.0;
+  }
+  const int v0a = wcarried<false>(P, P.vrow);
+  double yv0;
+  {
+    const double v0 = A[v0a + rl];
+    yv0 = (P.nvec > 0 && has_row) ? v0 : 0.0;
+  }
+  int bad = 0;
+  if (W == 0) {
+    X[lane] = a[0];
+    const double d0 = readlane_d(a[0], 0);
+    if (lane == 0) X[64] = rcp_pivot(d0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    if (k < n) {                                        // (wave-uniform; the only run-time decision)
+      const double* buf = X + (k & 1) * BS;
+      double* nxt = X + ((k + 1) & 1) * BS;
+      if (act) {
+        const bool pub = (k + 1 < NC) && (((k + 1) & 3) == W);      // (compile time) this wave owns column k + 1
+        const int c1 = pub ? (k + 1) >> 2 : 0;
+        const double colk = buf[lane], inv = buf[64], s1 = buf[pub ? k + 1 : 0], dk = buf[k];
+        const double li = colk * inv;
+        if (pub) {                                      // the next pivot's column first, published at once (with the reciprocal of its pivot)
+          a[c1] = fma(-li, s1, a[c1]);
+          nxt[lane] = a[c1];
+          const double d1 = readlane_d(a[c1], k + 1);
+          if (lane == 0) nxt[64] = rcp_pivot(d1);
+        }
+        const bool okp = (k < P.npos) ? (dk > 0.0) : (dk < 0.0);
+        bad |= okp ? 0 : 1;
+        {
+          int ln = lane;
+          asm volatile("" : "+v"(ln));
+          const double lm = ln > k ? li : 0.0;
+          const double y0k = readlane_d(yv0, k);
+          yv0 = fma(-lm, y0k, yv0);
+        }
+#pragma unroll
+        for (int c = k >> 2; c < NL; ++c) {
+          const int j = 4 * c + W;
+          if (j > k + 1) {                              // (compile time; column k + 1: done above by its owner)
+            const double s = buf[j];                    // u_jk: every lane reads the same address
+            a[c] = fma(-li, s, a[c]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (!bad && act) {
+    if (has_row) {
+#pragma unroll
+      for (int c = 0; c < NL; ++c) {
+        const int j = 4 * c + W;
+        if (j < n && j <= lane) Aw[ra + j] = a[c];
+      }
+    }
+    if (W == 0 && has_row && P.nvec > 0) Aw[v0a + lane] = yv0;
+  }
+  // (every wave saw the same pivots: `bad` is the same in all of them; waves beyond the fourth learn it through the buffer)
+  if (W == 0 && lane == 0) X[2 * BS] = bad ? 1.0 : 0.0;
+  __syncthreads();
+  const int bad_all = X[2 * BS] != 0.0 ? 1 : 0;
+  __syncthreads();
+  return bad_all;
+}
+
+template <int NC>
+__device__ __forceinline__ int root_ldl_4w(int off, const WPanel Pin, int xoff) {
+  static_assert(NC % 4 == 0, "columns are dealt to four waves");
+  const WPanel P = wpanel_uniform(Pin);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  switch (wv) {
+    case 0: return root_ldl_4w_wave<NC, 0>(off, P, xoff);
+    case 1: return root_ldl_4w_wave<NC, 1>(off, P, xoff);
+    case 2: return root_ldl_4w_wave<NC, 2>(off, P, xoff);
+    case 3: return root_ldl_4w_wave<NC, 3>(off, P, xoff);
+    default: return root_ldl_4w_wave<NC, 4>(off, P, xoff);
+  }
+}
+
 // inverse pivot of column `lane`, read back from the stored diagonal (after wave_ldl + wave_fence)
 template <bool BANDED>
 __device__ __forceinline__ double wave_dinv(const double* A, const WPanel P) {

@@ -22,8 +22,9 @@ __global__ __launch_bounds__(256) void k_root(const double* in, double* out, lon
     for (int i = threadIdx.x; i < total; i += blockDim.x) kkt[i] = in[i];
     __syncthreads();
     const long long t0 = clock64();
-    if (wave == 0) {
-      WPanel P; P.base = 0; P.ld = 0; P.n = n; P.nreg = n; P.nvec = 1; P.npos = npos; P.bw = n; P.vrow = n; P.band = -1; P.ldb = 0; P.wbase = 0;
+    WPanel P; P.base = 0; P.ld = 0; P.n = n; P.nreg = n; P.nvec = 1; P.npos = npos; P.bw = n; P.vrow = n; P.band = -1; P.ldb = 0; P.wbase = 0;
+    if (blocked == 2) bad_any |= root_ldl_4w<OMGX_WAVE_COLS>(0, P, soff);      // (round 6: all four waves)
+    else if (wave == 0) {
       bad_any |= blocked ? wave_ldl_packed16<OMGX_WAVE_COLS>(0, P, soff) : wave_ldl<OMGX_WAVE_COLS, OMGX_WAVE_COLS, false>(0, P);
       wave_fence();
     }
@@ -69,7 +70,8 @@ int main() {
     hipMemcpy(d_in, in.data(), total * 8, hipMemcpyHostToDevice);
     const size_t lds = (1024 + 256) * 8;
     hipFuncSetAttribute((const void*)k_root, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int blocked = 0; blocked < 2; ++blocked) {
+    std::vector<double> first;
+    for (int blocked = 0; blocked < 3; ++blocked) {
       for (int nb = 256; nb <= 512; nb += 256) {           // one / two workgroups per CU
         hipMemset(d_out, 0, total * 8);
         hipLaunchKernelGGL(k_root, dim3(nb), dim3(256), lds, 0, d_in, d_out, d_cyc, 16, n, npos, blocked);
@@ -83,15 +85,19 @@ int main() {
         for (int i = 0; i <= n; ++i) for (int k = 0; k < n && k <= i; ++k) {
           err = fmax(err, fabs(M[i * n + k] - out[i * (i + 1) / 2 + k])); mag = fmax(mag, fabs(M[i * n + k]));
         }
-        printf("n %2d (%2d positive pivots)  %-22s %d workgroup(s) per CU  %6.0f cycles  bad %lld  max |device - host| %.2e (max |entry| %.1f) %s (%s)\n",
-               n, npos, blocked ? "panels of 16 + MFMA" : "column by column", nb / 256, c / nb, bad, err, mag, err < 1e-11 ? "OK" : "MISMATCH", hipGetErrorString(hipGetLastError()));
+        if (blocked == 0) first = out;
+        bool same_bits = true;
+        for (int i = 0; i < total; ++i) same_bits = same_bits && out[i] == first[i];
+        printf("n %2d (%2d positive pivots)  %-22s %d workgroup(s) per CU  %6.0f cycles  bad %lld  max |device - host| %.2e (max |entry| %.1f) %s, same bits as column by column: %s (%s)\n",
+               n, npos, blocked == 2 ? "four waves through LDS" : (blocked ? "panels of 16 + MFMA" : "column by column"), nb / 256, c / nb, bad, err, mag, err < 1e-11 ? "OK" : "MISMATCH", same_bits ? "yes" : "no", hipGetErrorString(hipGetLastError()));
+        if (blocked == 2 && !same_bits) rc = 1;
         if (!(err < 1e-11) || bad) rc = 1;
       }
     }
     // a pivot of the wrong sign must be reported and nothing stored
     in[(npos - 1) * npos / 2 + npos - 1] = -3.0;
     hipMemcpy(d_in, in.data(), total * 8, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(k_root, dim3(1), dim3(256), lds, 0, d_in, d_out, d_cyc, 2, n, npos, 1);
+    hipLaunchKernelGGL(k_root, dim3(1), dim3(256), lds, 0, d_in, d_out, d_cyc, 2, n, npos, 2);
     hipDeviceSynchronize();
     std::vector<double> out(total); long long cyc[2];
     hipMemcpy(out.data(), d_out, total * 8, hipMemcpyDeviceToHost);
