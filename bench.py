@@ -25,6 +25,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'omg-tools_amd'))
 sys.path.insert(0, ROOT)
 
+# One process per GPU under a process group (the driver's launch for N > 1): RCCL's stream takes one of the HIP runtime's four hardware
+# queues; with eight the per-step product path keeps its overlap (omgtools.batch.product_path_streams).  Must be in the environment before
+# the runtime starts, i.e. before torch is imported.
+if int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('OMGX_FORCE_DIST') == '1':
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import numpy as np
 import torch
 

@@ -17,6 +17,8 @@ the tests' oracle port binding) runs the same protocol on host arrays instead: t
 parity tests and the CPU baseline of bench.py replay the loop.  This package itself never imports
 the oracle; the default `ops='hip'` is the only product path.
 """
+import os
+
 import numpy as np
 
 from .splines import shiftoverknot_T
@@ -500,6 +502,28 @@ class StreamedP2P(object):
 PRODUCT_PATH_STREAMS = 3
 
 
+def product_path_streams(process_group=None, hw_queues=None):
+    """Sub-batches of the per-step product path.  Three on a process of its own.  Round 6: under a `torch.distributed` process group
+    (the launch of a multi-GPU run: one process per GPU over RCCL) the communicator's stream takes one of the runtime's four hardware
+    queues as well and three sub-batches fall off the cliff that four do on a plain process -- measured with a group of one rank:
+    1.30-1.32 M solves/s against 2.15-2.17 M with two sub-batches (one launch per step 1.79 M); with eight hardware queues
+    (`GPU_MAX_HW_QUEUES=8`, which `bench.py` sets for such launches before the runtime starts) four sub-batches: 2.23-2.25 M."""
+    if process_group is None:
+        try:
+            import torch.distributed as dist
+            process_group = dist.is_available() and dist.is_initialized()
+        except Exception:
+            process_group = False
+    if not process_group:
+        return PRODUCT_PATH_STREAMS
+    if hw_queues is None:
+        try:
+            hw_queues = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+        except ValueError:
+            hw_queues = 4
+    return 4 if hw_queues >= 8 else 2
+
+
 def receding_horizon_batch(problem, P, device=None, n_streams='auto', **kw):
     """The per-step product path for a batch of independent agents: a `BatchP2P`, or -- when the batch is at least two rounds
     of resident workgroups (1024 agents of config 2 on 512 slots) -- the same batch as `PRODUCT_PATH_STREAMS` stream-ordered
@@ -516,5 +540,5 @@ def receding_horizon_batch(problem, P, device=None, n_streams='auto', **kw):
         if n_streams != 'auto' or B < 2 * slots:
             return whole
         whole.solver.close()
-        return StreamedP2P(problem, P, n_streams=PRODUCT_PATH_STREAMS, device=dev, slots=slots, **kw)
+        return StreamedP2P(problem, P, n_streams=product_path_streams(), device=dev, slots=slots, **kw)
     return StreamedP2P(problem, P, n_streams=n_streams, device=dev, **kw)

@@ -112,3 +112,15 @@ def test_pool_step_glue_in_c_equals_the_numpy_glue():
         assert np.abs(a.x - b.x).max() < 1e-8 and np.abs(a.p - b.p).max() < 1e-11
     assert crossings >= 1
     b.pool.close()
+
+
+def test_sub_batch_count_of_the_product_path_under_a_process_group():
+    """Round 6: under a torch.distributed process group RCCL's stream takes one of the HIP runtime's four hardware queues -- three
+    sub-batch streams then serialise (measured: 1.3 M instead of 2.2 M solves/s).  `product_path_streams` picks two there, four when
+    the process was started with eight hardware queues (`GPU_MAX_HW_QUEUES`, set by bench.py for distributed launches), three on a
+    process of its own."""
+    from omgtools.batch import product_path_streams, PRODUCT_PATH_STREAMS
+    assert product_path_streams(process_group=False) == PRODUCT_PATH_STREAMS == 3
+    assert product_path_streams(process_group=True, hw_queues=4) == 2
+    assert product_path_streams(process_group=True, hw_queues=8) == 4
+    assert product_path_streams() == 3                       # (no process group in this process)
