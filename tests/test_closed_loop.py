@@ -33,13 +33,13 @@ MAX_PARTED = 4
 # difference; 1e-6: 3.3e-4 m (median 2.7e-5 m), 1.7e-3 m/s, relative 8.6e-3; after the cold solve alone 7.7e-6 m / 7.5e-5 m/s.
 # The reference's own figure (relative 1e-4, one-sided, between two runs of the SAME solver at the SAME tolerance) is not what
 # a different solver at 1e-3 can meet against a converged one; these are the figures a user of the replacement gets.
-BOUNDS = {1e-3: (6.0e-2, 1.0e-1, 1.0),
+BOUNDS = {1e-3: (6.0e-2, 1.0e-1, 0.75),      # (round 6: the relative entry at 1.5 x what is achieved, 0.47 -- it was 1.0, no bound at all)
           1e-6: (1.0e-3, 4.0e-3, 2.0e-2)}
 # the Quadrotor class (closed_loop_cfg3.npz: 8 agents, 12 updates, three knot crossings, five moving circles; SLSQP's own accuracy on
 # this class is ~1e-4 on the coefficients: it stops with 'positive directional derivative' at a feasibility of 1e-7)
 # measured (host build): 1e-3: 5.4e-2 m (median at the end 2.0e-2), 0.18 m/s (the class flies at 1-2 m/s), relative 0.39;
 # 1e-6: 2.3e-4 m (median 6.5e-5), 1.2e-3 m/s, relative 2.3e-3; after the cold solve alone 1.6e-6 m
-BOUNDS_CFG3 = {1e-3: (1.2e-1, 4.0e-1, 1.0),
+BOUNDS_CFG3 = {1e-3: (1.2e-1, 4.0e-1, 0.6),     # (achieved 0.39)
                1e-6: (1.0e-3, 4.0e-3, 1.0e-2)}
 
 # the Holonomic3D class (closed_loop_cfg5.npz, round 5: BASELINE config 5's class -- K = 15, ten moving spheres, 748 variables / 1812 rows;
@@ -66,7 +66,7 @@ def run_loop(make_mpc, tol, cfg='cfg2'):
     return worst, first, parted_at, med
 
 
-def check(make_mpc, tol, who, cfg='cfg2'):
+def check(make_mpc, tol, who, cfg='cfg2', bounds=None):
     worst, first, parted_at, med = run_loop(make_mpc, tol, cfg)
     print('\n%s closed loop, %s, tol %g, against SLSQP in the loop: %d agents parted from the reference '
           'loop %s; the others: position %.2e m (median at the end %.1e), velocity %.2e m/s, two-sided relative %.2e (floor %.0e); after the cold '
@@ -74,9 +74,14 @@ def check(make_mpc, tol, who, cfg='cfg2'):
           % ((who, {'cfg2': '64 Holonomic agents x 25 updates (two crossings)', 'cfg3': '8 Quadrotor agents x 12 updates (three crossings)',
                'cfg5': '8 Holonomic3D agents x 18 updates (two crossings)'}[cfg],
               tol, len(parted_at), parted_at) + (worst[0], med, worst[1], worst[2], FLOOR) + tuple(first)))
-    b = {'cfg2': BOUNDS, 'cfg3': BOUNDS_CFG3, 'cfg5': BOUNDS_CFG5}[cfg][tol]
+    b = bounds if bounds is not None else {'cfg2': BOUNDS, 'cfg3': BOUNDS_CFG3, 'cfg5': BOUNDS_CFG5}[cfg][tol]
     assert len(parted_at) <= (MAX_PARTED if cfg == 'cfg2' else 1), parted_at
     assert worst[0] < b[0] and worst[1] < b[1] and worst[2] < b[2], (worst, b)
+
+
+# Round 6: IPOPT's absolute tolerances at their documented defaults beside tol = 1e-3 (omgx_options compl_inf_tol / constr_viol_tol, ABI 8:
+# what the reference's solver configuration actually tests, `problems/problem.py:57`) -- measured 9.6e-3 m / 2.3e-2 m/s / 0.156, no agent parted
+BOUNDS_IPOPT_DEFAULTS = (2.0e-2, 5.0e-2, 0.3)
 
 
 CASES = [('cfg2', 1e-3), ('cfg2', 1e-6), ('cfg3', 1e-3), ('cfg3', 1e-6), ('cfg5', 1e-3), ('cfg5', 1e-6)]
@@ -106,6 +111,39 @@ def test_hip_closed_loop_follows_slsqp_in_the_loop(cfg, tol):
         return mpcs[-1]
     try:
         check(make, tol, 'HIP', cfg)
+    finally:
+        for m in mpcs:
+            m.solver.close()
+
+
+def _with(make, extra):
+    return lambda problem, P, opts: make(problem, P, dict(opts, **extra))
+
+
+def test_port_closed_loop_at_ipopt_default_tolerances():
+    import omgtools.backend as be
+    from omgtools.batch import BatchP2P
+    from oracle import port_binding
+
+    def make(problem, P, opts):
+        m = BatchP2P(problem, P, ops=port_binding, options=opts)
+        m.n_threads = 8
+        return m
+    check(_with(make, be.IPOPT_DEFAULT_TOLERANCES), 1e-3, 'host build, IPOPT default absolute tolerances', 'cfg2', BOUNDS_IPOPT_DEFAULTS)
+
+
+@pytest.mark.gpu
+def test_hip_closed_loop_at_ipopt_default_tolerances():
+    import torch
+    import omgtools.backend as be
+    from omgtools.batch import BatchP2P
+    mpcs = []
+
+    def make(problem, P, opts):
+        mpcs.append(BatchP2P(problem, P, ops='hip', device=torch.device('cuda', 0), options=opts))
+        return mpcs[-1]
+    try:
+        check(_with(make, be.IPOPT_DEFAULT_TOLERANCES), 1e-3, 'HIP, IPOPT default absolute tolerances', 'cfg2', BOUNDS_IPOPT_DEFAULTS)
     finally:
         for m in mpcs:
             m.solver.close()
