@@ -357,6 +357,23 @@ class BatchP2P(object):
                 self.x[:, lo:lo + rows * cols] = (blk @ Tm.T).reshape(self.B, -1)
             self.lam = np.where(self.perm >= 0, self.lam[:, np.maximum(self.perm, 0)], 0.0)
 
+    # -- the reference's stop criterion ----------------------------------------------------------
+    def arrived(self, stop_tol=1e-3):
+        """Per agent: the reference's `stop_criterium` (`problems/point2point.py:98-102` -> `vehicles/holonomic.py:145-151`,
+        `holonomic3d.py`: |state - poseT| <= stop_tol and |input| <= stop_tol, Euclidean norms, `stop_tol` = 1e-3 by default,
+        `vehicles/vehicle.py:72`) on the state the last prediction wrote into p -- the state the vehicle is in at the time of
+        the current update.  Boolean tensor (device loop) / array (host loop); the reference's `Simulator.run` ends a vehicle's
+        loop at the first update for which this holds (`execution/simulator.py:39-62`).  Point-mass classes (state0 / input0 / poseT)."""
+        tpl, veh = self.tpl, self.veh
+        if (veh.label, 'poseT') not in tpl.par_layout or (veh.label, 'state0') not in tpl.par_layout:
+            raise NotImplementedError('arrived(): the class has no state0 / input0 / poseT parameters')
+        nd = self.n_dim
+        o_pose = tpl.entry_range(veh.label, 'poseT', 'par')[0]
+        st, inp, pose = (self.p[:, o:o + nd] for o in (self.o_state0, self.o_input0, o_pose))
+        if self.kind == 'hip':
+            return ((st - pose).norm(dim=1) <= stop_tol) & (inp.norm(dim=1) <= stop_tol)
+        return (np.linalg.norm(st - pose, axis=1) <= stop_tol) & (np.linalg.norm(inp, axis=1) <= stop_tol)
+
     # -- convenience -----------------------------------------------------------------------
     def host(self, name):
         a = getattr(self, name)

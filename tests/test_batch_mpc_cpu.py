@@ -124,3 +124,26 @@ def test_sub_batch_count_of_the_product_path_under_a_process_group():
     assert product_path_streams(process_group=True, hw_queues=4) == 2
     assert product_path_streams(process_group=True, hw_queues=8) == 4
     assert product_path_streams() == 3                       # (no process group in this process)
+
+
+def test_arrived_is_the_reference_stop_criterion():
+    """`BatchP2P.arrived` = `vehicles/holonomic.py:145-151` on the predicted state: nobody has arrived after the cold solve and a few
+    updates; an agent whose predicted state is put on its target pose at rest has."""
+    from omgtools import workloads
+    from omgtools.batch import BatchP2P
+    from oracle import port_binding
+    problem, P = workloads.holonomic_p2p(6)
+    m = BatchP2P(problem, P, ops=port_binding, options=dict(tol=1e-3, max_iter=300))
+    m.solve_cold()
+    for _ in range(3):
+        m.step()
+    assert not m.arrived().any()
+    tpl = m.tpl
+    o_pose = tpl.entry_range(m.veh.label, 'poseT', 'par')[0]
+    m.p[2, m.o_state0:m.o_state0 + 2] = m.p[2, o_pose:o_pose + 2] + np.array([6e-4, 0.0])
+    m.p[2, m.o_input0:m.o_input0 + 2] = np.array([0.0, -8e-4])
+    m.p[4, m.o_state0:m.o_state0 + 2] = m.p[4, o_pose:o_pose + 2]
+    m.p[4, m.o_input0:m.o_input0 + 2] = np.array([2e-3, 0.0])              # on the target but still moving
+    a = m.arrived()
+    assert a.tolist() == [False, False, True, False, False, False]
+    assert m.arrived(stop_tol=5e-4).sum() == 0

@@ -53,3 +53,31 @@ def test_mpc_replay_matches_port(cfg2_small):
             assert (gc_ - tpl.ub).max() < 1e-5 and (tpl.lb - gc_).max() < 1e-5
     assert crossings == 1
     gpu.solver.close()
+
+
+def test_arrived_on_the_device_is_the_reference_stop_criterion(cfg2_small):
+    """`BatchP2P.arrived` (device loop) against the statement of `vehicles/holonomic.py:145-151` on the downloaded parameters, along a run
+    long enough for the vehicles to reach their targets (T = 10 s, update time 0.1 s)."""
+    import torch
+    from omgtools import workloads
+    from omgtools.batch import BatchP2P
+    problem, P = workloads.holonomic_p2p(16)
+    m = BatchP2P(problem, P, ops='hip', device=torch.device('cuda', 0), options=dict(tol=1e-3, max_iter=300))
+    try:
+        m.solve_cold()
+        tpl = m.tpl
+        o_pose = tpl.entry_range(m.veh.label, 'poseT', 'par')[0]
+        seen = 0
+        for k in range(125):
+            m.step()
+            if k % 10 == 4 or k > 100:
+                p = m.host('p')
+                ref = (np.linalg.norm(p[:, m.o_state0:m.o_state0 + 2] - p[:, o_pose:o_pose + 2], axis=1) <= 1e-3) & \
+                      (np.linalg.norm(p[:, m.o_input0:m.o_input0 + 2], axis=1) <= 1e-3)
+                got = m.arrived().cpu().numpy()
+                assert np.array_equal(got, ref), k
+                seen = max(seen, int(got.sum()))
+        assert (m.host('status') == 0).all()
+        assert seen >= 12                                   # (the manoeuvre ends: most vehicles are on their targets at rest)
+    finally:
+        m.solver.close()
