@@ -32,3 +32,34 @@ def assert_kkt(nlp, tpl, p, x, lam, tol, who=''):
     assert comp < 3 * tol, (who, 'complementarity', comp)        # s z ~ mu <= kappa_eps * tol / 10 ... tol
     assert stat < 1.5 * tol, (who, 'stationarity', stat)
     return viol, sign, comp, stat
+
+
+def second_order_report(nlp, tpl, p, x, lam, lb=None, ub=None, mult_tol=1e-4, slack_tol=1e-2):
+    """Second-order NECESSARY condition at a KKT point, independent of any solver: the Lagrangian Hessian of the reference's NLP
+    (numpy restatement, the multipliers as returned) restricted to the tangent space of the active rows -- equality rows and
+    inequality rows with a multiplier above `mult_tol` and a slack below `slack_tol` -- has no negative eigenvalue.  Together with the
+    first-order conditions (`assert_kkt`) this excludes saddle points and maxima; the L1 objectives of these problems leave flat
+    directions (zero eigenvalues), so strict sufficiency is not to be had.  Returns (smallest eigenvalue, largest eigenvalue,
+    dimension of the tangent space, number of active rows)."""
+    lb = tpl.lb if lb is None else np.asarray(lb, float)
+    ub = tpl.ub if ub is None else np.asarray(ub, float)
+    c = nlp.term_coefs(p)
+    g = nlp.fg(x, c)[1]
+    J = nlp.jac(x, c)[:-1]
+    H = nlp.hess(x, lam, c)
+    eq = np.isfinite(lb) & (lb == ub)
+    up, lo = np.isfinite(ub) & ~eq, np.isfinite(lb) & ~eq
+    slack = np.where(up, ub - g, np.where(lo, g - lb, np.inf))
+    act = eq | ((np.abs(lam) > mult_tol) & (slack < slack_tol))
+    Ja = J[act]
+    if Ja.shape[0] == 0:
+        Z = np.eye(J.shape[1])
+    else:
+        _, S, Vt = np.linalg.svd(Ja, full_matrices=True)
+        rank = int((S > 1e-9 * S[0]).sum())
+        Z = Vt[rank:].T
+    if Z.shape[1] == 0:
+        return 0.0, 0.0, 0, int(act.sum())
+    Hr = Z.T @ H @ Z
+    ev = np.linalg.eigvalsh(0.5 * (Hr + Hr.T))
+    return float(ev.min()), float(ev.max()), int(Z.shape[1]), int(act.sum())

@@ -176,6 +176,27 @@ def test_host_build_solves_the_lifted_classes_from_the_reference_guess(name, max
         assert np.abs(a['x'][0] - b['x']).max() < 1e-7 * max(1.0, np.abs(b['x']).max())
 
 
+@pytest.mark.parametrize('name', ['bicycle_fixedT', 'agv_fixedT'])
+def test_second_order_condition_at_the_lifted_minima(name):
+    """Round 6: no second solver confirms the minima of the lifted classes (SLSQP and trust-constr wander off on these NLPs) -- a
+    solver-independent statement does: at the product's solution (host build, tol 1e-6) the first-order conditions hold AND the
+    Lagrangian Hessian of the reference's NLP, restricted to the tangent space of the active rows, has no negative eigenvalue
+    (`oracle.kkt_check.second_order_report`: numpy restatement of the NLP only).  Not a saddle point, not a maximum; the L1 objective
+    leaves flat directions, so the smallest eigenvalue is zero, not positive."""
+    from oracle import port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import assert_kkt, second_order_report
+    tpl, d = _load(name)
+    x, lb, ub = _extended(tpl, d)
+    res = port_binding.solve(tpl, d['p0'][None], x[None], lb, ub, tol=1e-6, max_iter=1200)
+    assert res['status'][0] == 0, res['status']
+    nlp = NumpyNLP(tpl)
+    assert_kkt(nlp, tpl, d['p0'], res['x'][0], res['lam_g'][0], 1e-5, name)
+    lo, hi, dim, n_act = second_order_report(nlp, tpl, d['p0'], res['x'][0], res['lam_g'][0], lb, ub)
+    print('\n%s: %d active rows, tangent space of dimension %d, reduced Lagrangian Hessian eigenvalues in [%.2e, %.2e]' % (name, n_act, dim, lo, hi))
+    assert dim > 0 and lo > -1e-8 * max(1.0, hi) - 1e-10, (lo, hi, dim, n_act)
+
+
 def test_template_file_round_trip_keeps_the_lifted_rows(tmp_path):
     import omgtools.backend as be
     tpl = _toy()
