@@ -126,3 +126,24 @@ def test_ipopt_absolute_tolerances(cfg2_small):
     kw = be.options_from_problem({'solver': 'ipopt', 'solver_options': {'ipopt': {'ipopt.tol': 1e-3, 'ipopt.compl_inf_tol': 1e-4,
                                                                                   'ipopt.constr_viol_tol': 2e-4}}})
     assert kw == {'tol': 1e-3, 'compl_inf_tol': 1e-4, 'constr_viol_tol': 2e-4}
+
+
+def test_second_order_condition_at_cfg2_solutions(cfg2_small):
+    """Solver-independent: at the host build's solutions of config 2 (tol 1e-6) the Lagrangian Hessian of the reference's NLP restricted to
+    the tangent space of the active rows has no negative eigenvalue (`oracle.kkt_check.second_order_report`) -- with the first-order
+    conditions of the test above: local minima, not saddle points."""
+    from oracle import port_binding
+    from oracle.nlp_numpy import NumpyNLP
+    from oracle.kkt_check import second_order_report
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    nlp = NumpyNLP(tpl)
+    res = port_binding.solve(tpl, P['p'][:6], P['x0'][:6], tol=1e-6, max_iter=300)
+    checked = 0
+    for b in range(6):
+        if res['status'][b] != 0:
+            continue
+        lo, hi, dim, n_act = second_order_report(nlp, tpl, P['p'][b], res['x'][b], res['lam_g'][b])
+        assert dim > 0 and lo > -1e-7 * max(1.0, hi), (b, lo, hi, dim, n_act)
+        checked += 1
+    assert checked >= 5
