@@ -2949,6 +2949,7 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
     // 39 -> 33 cold iterations on the 3-D class, and a tube of quartic range rows 717 -> 149)
     int soc = (OMGX_SOC_COMPILED && o.max_soc > 0) ? 0 : 2;      // 0: not tried yet, 1: the trial under way is the corrected one, 2: done
     int soc_rounds = 0;                                          // corrections computed for this step (at most o.max_soc)
+    const bool soc_levels = OMGX_SOC_COMPILED && o.max_soc > 0 && d.wave_ok && !gn;      // the correction at every step length a row rejects (below)
     for (int bt = 0; bt < OMGX_MAX_BACKTRACK; ++bt) {
       if (soc == 1 && soc_rounds > 1) { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] += w.gbar[q]; } }      // (a further correction on top of the corrected trial)
       else if (soc == 1) { OMGX_PFOR(q, N) { const int v = T.order[q]; w.xt[v] = w.x[v] + (alpha * w.sol[q] + w.gbar[q]); } }
@@ -3004,6 +3005,14 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
       if (soc == 1 && soc_rounds < o.max_soc && !(smin > 0.0)) soc = 0;
       if (soc == 1) {
         soc = 2;
+        // Round 6: the correction is offered again at the shorter step when it was a ROW, not the merit function, that rejected the
+        // trial.  A hyperplane normal glued to its norm constraint (slack 6e-8) has to move 2e-2 along the sphere: the linear model
+        // loses 3.4e-4 at the full step, one correction leaves 5e-5 -- but at a quarter of the step the loss is 2e-5 and ITS correction
+        // leaves less than the slack.  With the correction at the first trial only, that solve took ninety iterations at alpha = 2^-8
+        // (knot-crossing step at IPOPT's tolerances: slowest agent 112 -> 16 iterations, tol 1e-4: 83 -> 20; nothing got slower)
+        // (templates on the wave path -- the second solve is a substitution in registers there; the spill classes pay a blocked solve out of
+        // their slab per correction and keep the first-trial rule, as does the damped-Hessian mode whose weight follows the accepted step)
+        if (soc_levels && !(smin > 0.0)) { soc = 0; soc_rounds = 0; }
         alpha = c.uni(alpha * 0.5);
         c.sync(); continue;
       }
@@ -3061,6 +3070,7 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
         c.sync();
         continue;
       }
+      if (soc == 2 && soc_levels && !(smin > 0.0)) { soc = 0; soc_rounds = 0; }      // (see above: a row rejected this step length too)
       alpha = c.uni(alpha * 0.5);
       c.sync();
     }

@@ -577,6 +577,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         n_soc = int((opts or {}).get('max_soc', 1))          # (omgx_options max_soc: a count, default 1; DEFAULTS' entry belongs to solve_filter)
         soc = 0 if n_soc > 0 else 2
         soc_rounds = 0
+        soc_levels = n_soc > 0 and bool(getattr(nlp, 'wave_ok', False)) and not gn      # (omgx_core.h: templates on the wave path)
         d_c = None
         for bt in range(o['max_backtrack']):
             step = alpha * dxt + d_c if soc == 1 else alpha * dxt
@@ -593,10 +594,13 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                 if phi_noise or phit <= phi0 + o['eta'] * alpha * dphi or phit - phi0 <= 10 * np.finfo(float).eps * abs(phi0):
                     ok = True
                     break
-            if soc == 1 and soc_rounds < n_soc and not (st - o.get('ftb_actual', 0.5) * (1.0 - tau) * s).min() > 0:
+            row_rejected = not ((st - o.get('ftb_actual', 0.5) * (1.0 - tau) * s).min() > 0)
+            if soc == 1 and soc_rounds < n_soc and row_rejected:
                 soc = 0                      # (omgx_core.h, max_soc > 1: one more correction from where the corrected trial landed)
             if soc == 1:
                 soc = 2
+                if row_rejected and soc_levels:             # (omgx_core.h, round 6: the correction is offered again at the shorter step when a row rejected this one)
+                    soc, soc_rounds, d_c = 0, 0, None
                 alpha *= 0.5
                 continue
             if soc == 0:
@@ -612,6 +616,8 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                     d_new[n] = 0.0
                 d_c = d_new if d_c is None else d_c + d_new
                 continue
+            if soc == 2 and soc_levels and row_rejected:
+                soc, soc_rounds, d_c = 0, 0, None
             alpha *= 0.5
         if trace is not None:
             trace[-1].update(alpha=alpha, a_p=a_p, a_d=a_d, ok=ok, tries=tries, bt=bt, dphi=dphi)
