@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define OMGX_VERSION 8
+#define OMGX_VERSION 9
 #define OMGX_TERM_VARS 4      /* variables per term (version 3: three) */
 
 /* error codes */
@@ -306,10 +306,24 @@ int  omgx_batch_last_kernel_ms(omgx_batch* b, double* ms);
  * functions and their Jacobian at x0 -- and IPOPT's own start-up (gradient-based scaling `nlp_scaling_method`, initial slacks and
  * multipliers) run as ONE launch for the whole batch ahead of the solve kernel (ipm_prepare_kernel: basis evaluation at t / T,
  * coefficient slots, Jacobian and rows at x0, row classification and scaling, warm-start multipliers; many workgroups per CU) --
- * on by default; omgx_batch_set_prepare(b, 0) makes every solve do its own setup inside the solve kernel again (the same
- * statements: the same bits; `omgx_batch_rollout` always does).  With the setup kernel on, the begin stamp of the event pairs above
- * is the setup kernel's and the end stamp the solve kernel's. */
+ * OFF by default (measured on the 1024-agent benchmark batch, profiles/r06_prepare_ab.txt: the solve kernel loses 64 k cycles per
+ * warm solve, the setup kernel costs more than that saves); omgx_batch_set_prepare(b, 1) / OMGX_PREPARE=1 switch it on.  The same
+ * statements either way: the same bits (`omgx_batch_rollout` always does its setup in the kernel).  With the setup kernel on, the begin
+ * stamp of the event pairs above is the setup kernel's and the end stamp the solve kernel's. */
 int  omgx_batch_set_prepare(omgx_batch* b, int32_t on);
+/* (version 9) The reference's stop criterion inside the solve launch.  `Simulator.run` ends a vehicle's loop at the first update
+ * for which `problem.stop_criterium` holds (`execution/simulator.py:39-62`; `problems/point2point.py:98-102` ->
+ * `vehicles/holonomic.py:145-151`: |state0 - poseT| <= stop_tol and |input0| <= stop_tol, Euclidean norms, stop_tol = 1e-3 by
+ * default, `vehicles/vehicle.py:72`); in a batch the vehicles arrive at different updates.  under_way [n_agents] int32 on the
+ * device, owned by the caller, 1 = the agent's loop is running: every solve launch after this call tests the criterion on the
+ * agent's parameter vector p (offsets o_state0, o_input0, o_poseT of n_dim entries each -- the state the prediction wrote, the
+ * target) before it solves an agent with under_way = 1; if it holds the flag is cleared for good.  An agent whose flag is 0 is not
+ * solved: x <- x0 (it keeps its plan), lam_g and status stay as they are, iters = 0, the launch statistics and the fused
+ * trajectory store skip it.  The agents under way are solved exactly as without the rule (same bits).  under_way = NULL switches
+ * the rule off.  While the rule is on every solve does its own setup (omgx_batch_set_prepare is ignored); omgx_batch_rollout
+ * does not apply it. */
+int  omgx_batch_set_stop(omgx_batch* b, int32_t o_state0, int32_t o_input0, int32_t o_poseT, int32_t n_dim, double stop_tol,
+                         int32_t* under_way);
 
 /* Warm-start shift  coeffs <- T * coeffs  for the masked agents
  * (reference `point2point.py:187-198`, `optilayer.py:470-490`,

@@ -63,6 +63,13 @@ struct CenterArgs {
   const int32_t* pub_inv;     // [B] slot of the agent's row in x_send (-1: not published); nullptr: nothing published
   double* x_send;
 };
+// The reference's stop criterion inside the solve launch (omgx_batch_set_stop): parameter offsets of the state, the input and
+// the target of the vehicle, its dimension, the tolerance; under_way [B] (device, owned by the caller): 1 while the agent's loop runs
+struct StopArgs {
+  int o_state, o_input, o_pose, n_dim;
+  double tol;
+  int32_t* under_way;
+};
 struct StoreArgs {
   double* out;            // [B, n_der, n_spl, n_samp]
   double* v_tot;          // [B, n_samp] or nullptr (needs n_der >= 2)
@@ -179,7 +186,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  const int32_t* __restrict__ order, const StoreArgs* __restrict__ stp, int only_failed,
                  int* __restrict__ next_slot, const double* __restrict__ x0_alt, int n_alt, int32_t* __restrict__ attempts,
                  unsigned long long* __restrict__ stats, int stagger, const CenterArgs* __restrict__ ctr,
-                 double* __restrict__ prep, size_t prep_doubles) {
+                 double* __restrict__ prep, size_t prep_doubles, const StopArgs* __restrict__ stop) {
   extern __shared__ __align__(16) double lds[];
   omgx::Work w;
     omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
@@ -222,6 +229,19 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
     }
     // restart pass (OMGX_ONLY_FAILED): agents that are solved already keep x, lam_g, status, iters
     if (only_failed && status[b] == 0) continue;
+    // stop rule (omgx_batch_set_stop): a vehicle whose loop has ended -- the criterion held at this or an earlier update -- is not
+    // solved again: it keeps its plan (x <- x0), its multipliers and its status; iters = 0.  Every thread evaluates the same
+    // numbers from the same loads (a thread that reads the flag after thread 0 cleared it takes the same branch).
+    if (stop) {
+      const StopArgs sa = *stop;
+      bool go = sa.under_way[b] != 0;
+      if (go && omgx::stop_criterium(p + (size_t)b * d.n_par, sa.o_state, sa.o_input, sa.o_pose, sa.n_dim, sa.tol)) go = false;
+      if (!go) {
+        for (int i = threadIdx.x; i < d.n_var; i += blockDim.x) x[(size_t)b * d.n_var + i] = x0[(size_t)b * d.n_var + i];
+        if (threadIdx.x == 0) { sa.under_way[b] = 0; iters[b] = 0; }
+        continue;
+      }
+    }
 #ifdef OMGX_PROFILE
     if (threadIdx.x < omgx::PH_COUNT) prof_lds[threadIdx.x] = 0;
     __syncthreads();
@@ -399,7 +419,7 @@ static ipm_eval_kernel_t ipm_eval_kernel_for(int mode, int wave_ok, int general)
 typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const double*, const double*, const double*,
                              const double*, int, double*, double*, int32_t*, int32_t*, int, long long*, double*, size_t, double*,
                              const int32_t*, const StoreArgs*, int, int*, const double*, int, int32_t*, unsigned long long*, int, const CenterArgs*,
-                             double*, size_t);
+                             double*, size_t, const StopArgs*);
 // (GEN: the instance that carries the terms with four factors, the cos / sin atoms and the basis rows of any degree --
 // Dims::general; the other one is the kernel of the benchmark classes, free of that code)
 template <bool GEN>
@@ -940,6 +960,8 @@ struct omgx_batch {
   StoreArgs* d_store = nullptr;     // its copy in device memory (what the kernel reads)
   RolloutArgs* d_rollout = nullptr; RolloutStep* d_ro_steps = nullptr; int ro_steps_cap = 0; int32_t* d_ro_perm = nullptr;      // omgx_batch_rollout
   std::vector<int32_t> ro_perm_host;
+  StopArgs* d_stop = nullptr;       // omgx_batch_set_stop: device copy of the arguments
+  bool stop_on = false;
   CenterArgs* d_center = nullptr;   // omgx_batch_set_center: device copy of the arguments (nullptr: off); the slot map behind it
   int32_t* d_pub_inv = nullptr;
   bool center_on = false;
@@ -1563,12 +1585,30 @@ int omgx_batch_set_prepare(omgx_batch* b, int32_t on) {
   return OMGX_OK;
 }
 
+int omgx_batch_set_stop(omgx_batch* b, int32_t o_state0, int32_t o_input0, int32_t o_poseT, int32_t n_dim, double stop_tol, int32_t* under_way) {
+  if (!b) { g_err = "bad argument"; return OMGX_E_INVALID; }
+  if (!under_way) { b->stop_on = false; return OMGX_OK; }
+  b->stop_on = false;      // (a failed registration leaves the rule OFF)
+  const int np = b->dims.n_par;
+  if (n_dim <= 0 || o_state0 < 0 || o_input0 < 0 || o_poseT < 0 || o_state0 + n_dim > np || o_input0 + n_dim > np || o_poseT + n_dim > np ||
+      !(stop_tol >= 0.0)) { g_err = "stop rule: parameter offsets out of range or a negative tolerance"; return OMGX_E_INVALID; }
+  HIPCHK(hipSetDevice(b->device));
+  if (!b->d_stop) HIPCHK(hipMalloc((void**)&b->d_stop, sizeof(StopArgs)));
+  StopArgs sa;
+  sa.o_state = o_state0; sa.o_input = o_input0; sa.o_pose = o_poseT; sa.n_dim = n_dim; sa.tol = stop_tol; sa.under_way = under_way;
+  HIPCHK(hipMemcpyAsync(b->d_stop, &sa, sizeof(StopArgs), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  b->stop_on = true;
+  return OMGX_OK;
+}
+
 void omgx_batch_destroy(omgx_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (void* p : b->allocs) (void)hipFree(p);
   if (b->d_store) (void)hipFree(b->d_store);
   if (b->d_center) (void)hipFree(b->d_center);
+  if (b->d_stop) (void)hipFree(b->d_stop);
   if (b->d_rollout) (void)hipFree(b->d_rollout);
   if (b->d_ro_steps) (void)hipFree(b->d_ro_steps);
   if (b->d_ro_perm) (void)hipFree(b->d_ro_perm);
@@ -1701,7 +1741,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
   b->timed = b->timing && !b->ext_ev0;
   b->ext_ev0 = b->ext_ev1 = nullptr;
   b->opts.prio_iter = b->prio_iter;
-  const bool prepared = b->prepare_on && b->d_prep;
+  const bool prepared = b->prepare_on && b->d_prep && !b->stop_on;      // (the stop rule is the solve kernel's: it does its own setup then)
   if (prepared) {
     // the setup of all B solves, many workgroups per CU; the begin stamp of the caller's / the handle's event pair rides on this
     // launch, the end stamp on the solve kernel's: the pair brackets both
@@ -1721,7 +1761,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
                         b->d_next, b->d_x0_alt, b->d_x0_alt ? b->n_alt : 0, b->d_attempts,
                         (unsigned long long*)(b->d_stats ? b->d_stats + 4 * (size_t)(b->stats_launch++ % b->stats_slots) : nullptr),
                         b->stagger, (const CenterArgs*)(b->center_on ? b->d_center : nullptr),
-                        prepared ? b->d_prep : (double*)nullptr, b->prep_doubles);
+                        prepared ? b->d_prep : (double*)nullptr, b->prep_doubles, (const StopArgs*)(b->stop_on ? b->d_stop : nullptr));
   HIPCHK(hipGetLastError());
   if (ranged)
     hipLaunchKernelGGL(range_contract_lam, dim3((B * nu + 255) / 256), dim3(256), 0, b->stream, (const double*)b->d_lam, lam_user_dev, B, nu, ni,

@@ -2198,6 +2198,18 @@ OMGX_FN void hess_fix(const C& c, const Dims& d, const Tables& T, Work& w) {
 // ---------------------------------------------------------------------------
 struct Result { int status, iters; double f, mu, t, dw; };
 
+// The reference's stop criterion of the point-mass classes on an agent's parameter vector (`problems/point2point.py:98-102` ->
+// `vehicles/holonomic.py:145-151`, `holonomic3d.py`: |state0 - poseT| <= tol and |input0| <= tol, Euclidean norms): what ends a
+// vehicle's loop in `execution/simulator.py:39-62`.  One statement for the solve kernel's stop rule and the host build's.
+OMGX_HD bool stop_criterium(const double* p, int o_state, int o_input, int o_pose, int n_dim, double tol) {
+  double e2 = 0.0, u2 = 0.0;
+  for (int k = 0; k < n_dim; ++k) {
+    const double e = p[o_state + k] - p[o_pose + k], u = p[o_input + k];
+    e2 += e * e; u2 += u * u;
+  }
+  return sqrt(e2) <= tol && sqrt(u2) <= tol;
+}
+
 // The inertia correction at which every nonlinear variable gets at least its Gershgorin row sum g_q (w.xt, position order) under
 // the cap min(dw f_q, g_q + 0.03 dw): max_q g_q / f_q, with a margin of 1 % and the smallest correction on top
 template <class C>

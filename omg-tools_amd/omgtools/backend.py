@@ -504,9 +504,21 @@ class BatchSolver(object):
 
     def set_prepare(self, on):
         """The setup of every solve as ONE launch for the whole batch ahead of the solve kernel (`omgx_batch_set_prepare`, ABI 8;
-        on by default): off = every solve does its own setup inside the solve kernel (the same statements, the same bits)."""
+        off by default -- measured slower on the benchmark batch): off = every solve does its own setup inside the solve kernel
+        (the same statements, the same bits)."""
         self.lib.omgx_batch_set_prepare.argtypes = [C.c_void_p, C.c_int32]
         _check(self.lib, self.lib.omgx_batch_set_prepare(self._h, int(bool(on))), 'omgx_batch_set_prepare')
+
+    def set_stop(self, o_state0=0, o_input0=0, o_poseT=0, n_dim=0, stop_tol=1e-3, under_way=None):
+        """The reference's stop criterion inside the solve launch (include/omgx.h omgx_batch_set_stop, ABI 9): under_way [B] int32
+        device tensor (kept alive by the caller too), 1 = the agent's loop is running; None switches the rule off."""
+        self.lib.omgx_batch_set_stop.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p]
+        if under_way is not None and (under_way.dim() != 1 or under_way.shape[0] != self.n_agents or not under_way.is_contiguous()
+                                      or under_way.element_size() != 4 or under_way.is_floating_point()):
+            raise ValueError('under_way must be a contiguous [n_agents] int32 device tensor')
+        _check(self.lib, self.lib.omgx_batch_set_stop(self._h, int(o_state0), int(o_input0), int(o_poseT), int(n_dim), float(stop_tol),
+                                                       under_way.data_ptr() if under_way is not None else None), 'omgx_batch_set_stop')
+        self._under_way_keep = under_way
 
     def last_kernel_ms(self):
         ms = C.c_double()

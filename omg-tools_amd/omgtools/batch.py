@@ -117,6 +117,7 @@ class BatchP2P(object):
         self.shift_mats = np.concatenate(mats)
         self._shift_dense = [(e, m.reshape(e[1], e[1])) for e, m in zip(ents, mats)]
         self.time = 0.0
+        self.under_way, self.stop_tol = None, 1e-3        # (stop_at_arrival)
         # (warm_mu_factor 0.1: a step starts at the barrier parameter the previous solve of the agent ended with, tol / 10,
         # unless the shifted point is far off that central path -- a tenth of its average complementarity then: at tol 1e-3
         # the same iterates as factor 0, at 1e-6 0.03 % instead of 0.4 % of the steps end at the iteration cap)
@@ -179,15 +180,31 @@ class BatchP2P(object):
                                      self.status, self.iters, bounds_shared=True)
             self.x, self.x_new = self.x_new, self.x
         elif self.pool is not None:
+            if self.under_way is not None:
+                raise NotImplementedError('stop_at_arrival: not with a host pool (its workers run the step glue themselves)')
             if not warm:
                 self.lam[:] = 0.
             self.pool.solve(self.p, self.x, self.lam, self.status, self.iters, self.dw, step=step_desc,
                             **dict(self.opts, warm_start=int(warm), max_iter=self.max_iter_step if warm else self.max_iter_cold, **extra))
         else:
+            kw = dict(self.opts, max_iter=self.max_iter_step if warm else self.max_iter_cold, **extra)
+            if self.under_way is not None:
+                # the stop rule as the solve kernel applies it: the criterion on p ends an agent's loop for good; the agents
+                # under way are solved as a batch of their own (independent problems: the same results), the others keep
+                # their plan, their multipliers and their status, iters = 0
+                self.under_way &= ~self.arrived(self.stop_tol)
+                idx = np.flatnonzero(self.under_way)
+                self.iters = np.zeros(self.B, dtype=np.int32)
+                if len(idx):
+                    dw = self.dw[idx].copy()
+                    r = self.port.solve(self.tpl, self.p[idx], self.x[idx], lam_g0=self.lam[idx] if warm else None,
+                                        status0=self.status[idx] if warm else None, warm_start=int(warm),
+                                        n_threads=self.n_threads, dw_state=dw, **kw)
+                    self.x[idx], self.lam[idx], self.status[idx], self.iters[idx], self.dw[idx] = r['x'], r['lam_g'], r['status'], r['iters'], dw
+                return
             r = self.port.solve(self.tpl, self.p, self.x, lam_g0=self.lam if warm else None,
                                 status0=self.status if warm else None, warm_start=int(warm),
-                                n_threads=self.n_threads, dw_state=self.dw,
-                                **dict(self.opts, max_iter=self.max_iter_step if warm else self.max_iter_cold, **extra))
+                                n_threads=self.n_threads, dw_state=self.dw, **kw)
             self.x, self.lam, self.status, self.iters = r['x'], r['lam_g'], r['status'], r['iters']
 
     def solve_cold(self, bends=(1.0, -1.0, 2.5, -2.5), fused=True):
@@ -374,6 +391,28 @@ class BatchP2P(object):
             return ((st - pose).norm(dim=1) <= stop_tol) & (inp.norm(dim=1) <= stop_tol)
         return (np.linalg.norm(st - pose, axis=1) <= stop_tol) & (np.linalg.norm(inp, axis=1) <= stop_tol)
 
+    def stop_at_arrival(self, stop_tol=1e-3, on=True):
+        """End every agent's loop where the reference's does: from now on an agent for which `arrived(stop_tol)` holds at an update
+        is not solved at that update or any later one (`execution/simulator.py:39-62` leaves its `while` loop; a fleet's
+        vehicles arrive at different updates) -- it keeps its plan, its multipliers and its status, `iters` reads 0.  Device loop:
+        the rule is the solve kernel's (`omgx_batch_set_stop`, no launch of its own); `under_way` [B] (int32 tensor / bool array)
+        holds who is still running.  The agents under way are solved exactly as without the rule.  `rollout` does not apply it."""
+        if not on:
+            self.under_way = None
+            if self.kind == 'hip':
+                self.solver.set_stop(under_way=None)
+            return
+        tpl, veh = self.tpl, self.veh
+        if (veh.label, 'poseT') not in tpl.par_layout or (veh.label, 'state0') not in tpl.par_layout:
+            raise NotImplementedError('stop_at_arrival(): the class has no state0 / input0 / poseT parameters')
+        self.stop_tol = float(stop_tol)
+        if self.kind == 'hip':
+            self.under_way = self.torch.ones(self.B, dtype=self.torch.int32, device=self.dev)
+            self.solver.set_stop(self.o_state0, self.o_input0, tpl.entry_range(veh.label, 'poseT', 'par')[0], self.n_dim, self.stop_tol,
+                                 self.under_way)
+        else:
+            self.under_way = np.ones(self.B, dtype=bool)
+
     # -- convenience -----------------------------------------------------------------------
     def host(self, name):
         a = getattr(self, name)
@@ -405,6 +444,30 @@ def split_bounds(B, n_streams, slots=None):
     return out
 
 
+_SUB_BATCH_STREAMS = {}
+
+
+def sub_batch_streams(dev, n):
+    """The HIP streams the sub-batches of a device run on: HIGH-PRIORITY streams, created once per device, shared by every
+    `StreamedP2P` on it and put to use (an event record) right away.  The HIP runtime maps streams onto `GPU_MAX_HW_QUEUES`
+    (four) hardware queues per priority level when they are first used -- a new queue while the level has fewer than four, else
+    the least-used one -- so whether three default-priority streams got three queues depended on what the process had created
+    before (the null stream, every library handle's own stream, a process group's): measured on the benchmark batch, round 6
+    (`profiles/r06_stream_placement.txt`), 1.2 M instead of 2.2 M solves/s when a library handle was created ahead of the first
+    `StreamedP2P`, or when a second `StreamedP2P` followed the first in a process -- two sub-batches on one queue run their
+    launches one after the other.  Nothing else in a process uses the high-priority level: its first three streams get a
+    queue each, whatever came before (2.15-2.20 M in all four creation orders tried, with and without a process group)."""
+    import torch
+    key = (dev.type, dev.index or 0)
+    have = _SUB_BATCH_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        st = torch.cuda.Stream(device=dev, priority=int(os.environ.get('OMGX_STREAM_PRIORITY', '-1')))
+        if not os.environ.get('OMGX_NO_STREAM_TOUCH'):      # (developer knob: the order-dependent behaviour of rounds 5 / 6)
+            torch.cuda.Event().record(st)
+        have.append(st)
+    return have[:n]
+
+
 class StreamedP2P(object):
     """The batch as `n_streams` sub-batches, each a `BatchP2P` with its own library handle on its own HIP stream.  The problems of
     a point-to-point batch are independent, so nothing orders the steps of one sub-batch against those of another: while one waits
@@ -423,7 +486,8 @@ class StreamedP2P(object):
             raise ValueError('%d agents do not split into %d sub-batches' % (B, n_streams))
         self.bounds = split_bounds(B, n_streams, slots)
         self.dev = device if device is not None else torch.device('cuda', 0)
-        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(n_streams)]
+        self.streams = sub_batch_streams(self.dev, n_streams) if not os.environ.get('OMGX_NO_STREAM_TOUCH') else \
+            [torch.cuda.Stream(device=self.dev) for _ in range(n_streams)]
         self.parts = []
         # (the caller's stream may still be writing what the sub-batches read, and the other way round at the end)
         ready = torch.cuda.current_stream(self.dev).record_event()
@@ -458,6 +522,16 @@ class StreamedP2P(object):
             with self.torch.cuda.stream(st):
                 out.append(part.step(events=ev, before_solve=hk))
         return any(out)
+
+    def stop_at_arrival(self, stop_tol=1e-3, on=True):
+        for m in self.parts:
+            m.stop_at_arrival(stop_tol, on)
+
+    @property
+    def under_way(self):
+        if self.parts[0].under_way is None:
+            return None
+        return self.gather('under_way')
 
     @property
     def time(self):
@@ -513,32 +587,20 @@ class StreamedP2P(object):
             m.solver.close()
 
 
-# Sub-batches of the per-step product path.  Three: the HIP runtime maps streams onto four hardware queues, the caller's stream
-# takes one; a fourth sub-batch shares a queue with another one and serialises behind it (1.41 M solves/s against 2.16 M with
-# two and 2.20-2.26 M with three on the 1024-agent batch; five: 1.43 M, six: 1.11 M).
+# Sub-batches of the per-step product path: three, on streams with a hardware queue each (`sub_batch_streams`).  Measured on the
+# 1024-agent batch with the streams in their own (high-priority) queue pool, round 6: two 2.09 M, three 2.20-2.25 M, four
+# 2.22-2.25 M (p50 step latency 0.75 / 0.66-0.91 / 0.97-1.01 ms), five 1.42 M solves/s -- the pool has four queues, a fifth stream
+# shares one and its launches queue behind another sub-batch's.
 PRODUCT_PATH_STREAMS = 3
 
 
 def product_path_streams(process_group=None, hw_queues=None):
-    """Sub-batches of the per-step product path.  Three on a process of its own.  Round 6: under a `torch.distributed` process group
-    (the launch of a multi-GPU run: one process per GPU over RCCL) the communicator's stream takes one of the runtime's four hardware
-    queues as well and three sub-batches fall off the cliff that four do on a plain process -- measured with a group of one rank:
-    1.30-1.32 M solves/s against 2.15-2.17 M with two sub-batches (one launch per step 1.79 M); with eight hardware queues
-    (`GPU_MAX_HW_QUEUES=8`, which `bench.py` sets for such launches before the runtime starts) four sub-batches: 2.23-2.25 M."""
-    if process_group is None:
-        try:
-            import torch.distributed as dist
-            process_group = dist.is_available() and dist.is_initialized()
-        except Exception:
-            process_group = False
-    if not process_group:
-        return PRODUCT_PATH_STREAMS
-    if hw_queues is None:
-        try:
-            hw_queues = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
-        except ValueError:
-            hw_queues = 4
-    return 4 if hw_queues >= 8 else 2
+    """Sub-batches of the per-step product path: `PRODUCT_PATH_STREAMS`.  (While the sub-batch streams came from the runtime's
+    common pool of four hardware queues the count depended on what else the process had created -- a `torch.distributed` process
+    group's stream, a library handle ahead of the first `StreamedP2P` -- and this function picked two or four under a process
+    group; with the streams in a queue pool of their own, `sub_batch_streams`, three is measured the same with and without a group
+    and with four or eight hardware queues: 2.20 M in each case.  The arguments are kept for callers of that version.)"""
+    return PRODUCT_PATH_STREAMS
 
 
 def receding_horizon_batch(problem, P, device=None, n_streams='auto', **kw):

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.omgx_version.restype = ctypes.c_int
-    assert lib.omgx_version() == 8
+    assert lib.omgx_version() == 9
     lib.omgx_status_string.restype = ctypes.c_char_p
     assert lib.omgx_status_string(0) == b'Solve_Succeeded'
 

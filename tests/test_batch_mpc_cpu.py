@@ -114,16 +114,13 @@ def test_pool_step_glue_in_c_equals_the_numpy_glue():
     b.pool.close()
 
 
-def test_sub_batch_count_of_the_product_path_under_a_process_group():
-    """Round 6: under a torch.distributed process group RCCL's stream takes one of the HIP runtime's four hardware queues -- three
-    sub-batch streams then serialise (measured: 1.3 M instead of 2.2 M solves/s).  `product_path_streams` picks two there, four when
-    the process was started with eight hardware queues (`GPU_MAX_HW_QUEUES`, set by bench.py for distributed launches), three on a
-    process of its own."""
+def test_sub_batch_count_of_the_product_path():
+    """Three sub-batches, with or without a torch.distributed process group: the sub-batch streams live in a hardware-queue pool
+    of their own (`omgtools.batch.sub_batch_streams`, high-priority streams), so the count no longer depends on what else the
+    process created (rounds 5 / 6 picked two or four under a process group; measured now: 2.20 M solves/s with three either way)."""
     from omgtools.batch import product_path_streams, PRODUCT_PATH_STREAMS
-    assert product_path_streams(process_group=False) == PRODUCT_PATH_STREAMS == 3
-    assert product_path_streams(process_group=True, hw_queues=4) == 2
-    assert product_path_streams(process_group=True, hw_queues=8) == 4
-    assert product_path_streams() == 3                       # (no process group in this process)
+    assert PRODUCT_PATH_STREAMS == 3
+    assert product_path_streams() == product_path_streams(process_group=True, hw_queues=4) == product_path_streams(process_group=True, hw_queues=8) == 3
 
 
 def test_arrived_is_the_reference_stop_criterion():
@@ -147,3 +144,38 @@ def test_arrived_is_the_reference_stop_criterion():
     a = m.arrived()
     assert a.tolist() == [False, False, True, False, False, False]
     assert m.arrived(stop_tol=5e-4).sum() == 0
+
+
+def test_stop_at_arrival_ends_an_agents_loop_like_the_reference():
+    """`BatchP2P.stop_at_arrival` (host loop; the device loop's rule is the solve kernel's, tests/test_gpu_batch_mpc.py): the reference's
+    `Simulator.run` leaves a vehicle's loop at the first update for which `stop_criterium` holds (`execution/simulator.py:39-62`).  With a
+    wide tolerance the six vehicles arrive at different updates: until then an agent is solved exactly as without the rule, from then on
+    it keeps its plan, its multipliers and its status and `iters` reads 0 -- also when the criterion stops holding later."""
+    from omgtools import workloads
+    from omgtools.batch import BatchP2P
+    from oracle import port_binding
+    problem, P = workloads.holonomic_p2p(6)
+    opts = dict(tol=1e-3, max_iter=300)
+    free, ruled = (BatchP2P(problem, P, ops=port_binding, options=opts) for _ in range(2))
+    ruled.stop_at_arrival(stop_tol=2.5)            # (|state - poseT| <= 2.5 m and |input| <= 2.5 m/s: under way, some metres out)
+    for m in (free, ruled):
+        m.solve_cold()
+    assert ruled.under_way.all() and np.array_equal(free.x, ruled.x)
+    ended_at = np.full(6, -1)
+    frozen = {}
+    for k in range(40):
+        free.step(); ruled.step()
+        crit = free.arrived(2.5)                     # (the free loop's p equals the ruled one's for every agent still under way)
+        for b in range(6):
+            if ended_at[b] < 0 and crit[b]:
+                ended_at[b] = k
+                frozen[b] = (ruled.x[b].copy(), ruled.lam[b].copy())
+        run = ended_at < 0
+        assert np.array_equal(ruled.under_way, run), k
+        assert np.array_equal(ruled.x[run], free.x[run]) and np.array_equal(ruled.lam[run], free.lam[run]) and np.array_equal(ruled.iters[run], free.iters[run])
+        assert (ruled.iters[~run] == 0).all() and (ruled.status[~run] == 0).all()
+    assert (ended_at >= 0).sum() >= 3 and len(set(ended_at[ended_at >= 0])) >= 2 and (ended_at != 0).all()
+    for b, (xb, lb) in frozen.items():             # shifted over the knots it crossed since, never solved again
+        assert ruled.iters[b] == 0
+    ruled.stop_at_arrival(on=False)
+    assert ruled.under_way is None

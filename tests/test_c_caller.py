@@ -43,7 +43,7 @@ def test_c_program_links_and_reads_the_template(exe, case):
     out = subprocess.check_output([exe, path, 'plan']).decode().split()
     got = dict(zip(out[0::2], out[1::2]))
     plan = be.describe_plan(tpl)
-    assert int(got['version']) == 8
+    assert int(got['version']) == 9
     assert (int(got['n_var']), int(got['n_con']), int(got['n_par'])) == (tpl.n_var, tpl.n_con, tpl.n_par)
     assert (int(got['n_leaf']), int(got['n_root']), int(got['nnz_j'])) == (plan['n_leaf'], plan['n_root'], plan['nnz_j'])
     assert int(got['lds_bytes']) == plan['lds_bytes']

@@ -81,3 +81,64 @@ def test_arrived_on_the_device_is_the_reference_stop_criterion(cfg2_small):
         assert seen >= 12                                   # (the manoeuvre ends: most vehicles are on their targets at rest)
     finally:
         m.solver.close()
+
+
+def test_stop_rule_of_the_solve_kernel_ends_loops_like_the_reference():
+    """`omgx_batch_set_stop` (ABI 9) through `BatchP2P.stop_at_arrival`: the solve kernel tests the reference's stop criterion
+    (`vehicles/holonomic.py:145-151` on the state the prediction wrote) before it solves an agent and never solves it again once it
+    held (`execution/simulator.py:39-62`).  Against a loop without the rule: the agents under way get the same bits, the flags clear
+    at the update at which `arrived()` first holds, an agent whose loop has ended keeps its plan (x <- x0 in the double-buffered loop),
+    multipliers and status, `iters` 0, and the launch statistics count only the agents that were solved.  Also through the
+    three-stream product path."""
+    import torch
+    from omgtools import workloads
+    from omgtools.batch import BatchP2P, receding_horizon_batch
+    B = 24
+    problem, P = workloads.holonomic_p2p(B)
+    dev = torch.device('cuda', 0)
+    opts = dict(tol=1e-3, max_iter=300)
+    free = BatchP2P(problem, P, ops='hip', device=dev, options=opts)
+    ruled = BatchP2P(problem, P, ops='hip', device=dev, options=opts)
+    try:
+        ruled.stop_at_arrival(stop_tol=2.5)
+        stats = torch.zeros((60, 4), dtype=torch.int64, device=dev)
+        for m in (free, ruled):
+            m.solve_cold(bends=())
+        assert np.array_equal(free.host('x'), ruled.host('x')) and ruled.host('under_way').all()
+        ruled.solver.set_stats(stats)
+        ended = np.zeros(B, dtype=bool)
+        firsts = []
+        for k in range(40):
+            x_prev, lam_prev = ruled.host('x'), ruled.host('lam')
+            crossed = free.step()
+            assert ruled.step() == crossed
+            now = free.arrived(2.5).cpu().numpy() & ~ended
+            firsts += [k] * int(now.sum())
+            ended |= now
+            run = ~ended
+            assert np.array_equal(ruled.host('under_way') != 0, run), k
+            for name in ('x', 'lam', 'iters', 'status'):
+                assert np.array_equal(ruled.host(name)[run], free.host(name)[run]), (k, name)
+            assert (ruled.host('iters')[ended] == 0).all() and (ruled.host('status')[ended] == 0).all()
+            if not crossed and ended.any():       # (a crossing shifts the kept plan and moves its multipliers by index like everyone's)
+                assert np.array_equal(ruled.host('x')[ended & ~now], x_prev[ended & ~now])
+                assert np.array_equal(ruled.host('lam')[ended], lam_prev[ended])
+            assert int(stats[k, 3].item()) == int(run.sum()) and int(stats[k, 0].item()) == int(run.sum())
+        assert ended.sum() >= B // 2 and len(set(firsts)) >= 3 and min(firsts) > 0
+        ruled.solver.set_stats(None)
+    finally:
+        free.solver.close(); ruled.solver.close()
+    # the product path: three sub-batches on their own streams, the rule in each
+    a = receding_horizon_batch(problem, P, device=dev, n_streams=3, options=opts)
+    b = BatchP2P(problem, P, ops='hip', device=dev, options=opts)
+    try:
+        for m in (a, b):
+            m.stop_at_arrival(stop_tol=2.5)
+            m.solve_cold(bends=())
+        for _ in range(30):
+            a.step(); b.step()
+        ua = a.under_way.cpu().numpy()
+        assert np.array_equal(ua, b.host('under_way')) and 0 < ua.sum() < B
+        assert np.array_equal(a.x.cpu().numpy(), b.host('x')) and np.array_equal(a.iters.cpu().numpy(), b.host('iters'))
+    finally:
+        a.close(); b.solver.close()
