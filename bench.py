@@ -872,6 +872,7 @@ def main():
     ap.add_argument('--ipopt-defaults', action='store_true',
                     help="also test IPOPT's absolute tolerances on the unscaled problem at their documented defaults (compl_inf_tol = "
                          "constr_viol_tol = 1e-4, in force when the reference sets only ipopt.tol): omgx_options version 8")
+    ap.add_argument('--refine', type=int, default=None, help='p2p: omgx_options.refine (default: the library default, 1); 0 switches the refinement of regularised steps off (A/B runs)')
     ap.add_argument('--no-parity', action='store_true', help='skip the closed-loop parity leg (`parity_at_tol`: 26 launches of a 64-agent batch) -- profiling passes whose per-launch averages must cover the 1024-agent launches only')
     ap.add_argument('--sustained-steps', type=int, default=120, help='updates of the whole-manoeuvre leg (`sustained`)')
     ap.add_argument('--workload', choices=['p2p', 'formation', 'rendezvous', 'quadrotor', 'holonomic3d'], default='p2p',
@@ -913,6 +914,8 @@ def main():
     if args.ipopt_defaults:
         from omgtools.backend import IPOPT_DEFAULT_TOLERANCES
         opts.update(IPOPT_DEFAULT_TOLERANCES)
+    if args.refine is not None:
+        opts['refine'] = args.refine
     # single-handle batch: the cold co-headline and the side legs (latency, fused store, rollout)
     mpc = BatchP2P(problem, P, ops='hip', device=dev, options=opts)
     solver = mpc.solver

@@ -178,6 +178,17 @@ typedef struct omgx_options {
   double  constr_viol_tol;     /* ... AND the largest unscaled violation of a row is below constr_viol_tol; the barrier parameter ends at
                            min(tol, compl_inf_tol) / 10.  0 (default, rounds 1-5): neither is tested -- the scaled error alone decides.
                            omgtools.backend maps 'ipopt.compl_inf_tol' / 'ipopt.constr_viol_tol' onto them when a caller sets them */
+  int32_t refine;              /* (version 9) 1: iterative refinement of a regularised Newton step (default 0).  When the Lagrangian Hessian needs an
+                           inertia correction D the factors are those of K + D and the step s1 is a proximal step; (K + D) s2 = D s1 adds the
+                           next term of the series towards the step of K itself -- one more solve with the factors of the iteration (IPOPT refines
+                           its steps against the unperturbed system too: `min_refinement_steps`).  Taken from the second iteration of a solve
+                           on, when the term is no longer than the step, not after an iteration that accepted less than a tenth of its step,
+                           in cold solves once phase I is over, and only if the first trial of the line search accepts the refined step as it
+                           stands (else the plain step takes the whole line search).  Templates on the wave path with the exact Hessian and no
+                           lifted auxiliaries; ignored by the others and by omgx_batch_rollout (kernel instances of their own carry it: the default
+                           instance stays free of its registers).  Measured: fewer iterations on every protocol of the
+                           host build (tol 1e-6: 9.5 -> 6.9 per warm solve, a third of the unsolved steps), on the device +22 % / +52 % at
+                           tol 1e-4 / 1e-6 but -3 % at the headline's 1e-3, where nine of ten solves end after one iteration: off by default */
 } omgx_options;
 
 typedef struct omgx_batch omgx_batch;

@@ -175,7 +175,7 @@ __device__ void sample_agent(const double* coeffs, double* scratch, int n_spl, i
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-template <int MODE, bool WAVE_ONLY, bool GEN>
+template <int MODE, bool WAVE_ONLY, bool GEN, bool REFINE = false>
 __global__ void __launch_bounds__(512)
 ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
                  const double* __restrict__ p, const double* __restrict__ x0,
@@ -191,7 +191,7 @@ ipm_solve_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles,
   omgx::Work w;
     omgx::work_carve_split<MODE>(w, lds, MODE == omgx::WS_LDS ? nullptr : slabs + (size_t)blockIdx.x * slab_doubles,
                                d, kkt_doubles);
-  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_root_lds(MODE), GEN> c; c.red = w.red;
+  omgx::CtxT<omgx::ws_kkt_hbm(MODE), WAVE_ONLY, omgx::ws_root_lds(MODE), GEN, false, REFINE> c; c.red = w.red;
 #ifdef OMGX_PROFILE
   __shared__ long long prof_lds[omgx::PH_COUNT];
   c.prof = prof_lds;
@@ -423,7 +423,16 @@ typedef void (*ipm_kernel_t)(omgx::Dims, omgx::Tables, omgx::Opts, int, const do
 // (GEN: the instance that carries the terms with four factors, the cos / sin atoms and the basis rows of any degree --
 // Dims::general; the other one is the kernel of the benchmark classes, free of that code)
 template <bool GEN>
-static ipm_kernel_t ipm_kernel_gen(int mode, int wave_ok) {
+static ipm_kernel_t ipm_kernel_gen(int mode, int wave_ok, int refine = 0) {
+  // (the refinement of regularised steps -- omgx_options.refine -- has instances of its own: templates on the wave path, not general)
+  if (refine && wave_ok && !GEN) {
+    switch (mode) {
+      case omgx::WS_LDS: return ipm_solve_kernel<omgx::WS_LDS, true, false, true>;
+      case omgx::WS_JAC_ONLY: return ipm_solve_kernel<omgx::WS_JAC_ONLY, true, false, true>;
+      case omgx::WS_JAC_HV: return ipm_solve_kernel<omgx::WS_JAC_HV, true, false, true>;
+      default: break;
+    }
+  }
 #ifdef OMGX_ONLY_HEADLINE      // developer builds (register counts of one instance in a third of the compile time): only the kernel of the benchmark class
   return ipm_solve_kernel<omgx::WS_JAC_HV, true, false>;
 #else
@@ -438,8 +447,8 @@ static ipm_kernel_t ipm_kernel_gen(int mode, int wave_ok) {
   }
 #endif
 }
-static ipm_kernel_t ipm_kernel_for(int mode, int wave_ok, int general) {
-  return general ? ipm_kernel_gen<true>(mode, wave_ok) : ipm_kernel_gen<false>(mode, wave_ok);
+static ipm_kernel_t ipm_kernel_for(int mode, int wave_ok, int general, int refine = 0) {
+  return general ? ipm_kernel_gen<true>(mode, wave_ok) : ipm_kernel_gen<false>(mode, wave_ok, refine);
 }
 
 template <typename OutT>
@@ -1479,7 +1488,7 @@ int omgx_template_block(const omgx_template* tpl, int32_t kind, const char* name
 void omgx_default_options(omgx_options* o) {
   o->tol = 1e-3; o->max_iter = 300; o->mu_init = 0.1; o->kappa_push = 1.0;
   o->nu_init = 100.0; o->scale_gmax = 100.0; o->warm_start = 0; o->kappa_warm = 1e-3;
-  o->dw_leaf_ratio_cold = 1.0; o->warm_mu_factor = 1.0; o->warm_z_floor = 0.1; o->warm_z_cap = 0.01; o->max_soc = 1; o->hess_approx = 0; o->compl_inf_tol = 0.0; o->constr_viol_tol = 0.0;
+  o->dw_leaf_ratio_cold = 1.0; o->warm_mu_factor = 1.0; o->warm_z_floor = 0.1; o->warm_z_cap = 0.01; o->max_soc = 1; o->hess_approx = 0; o->compl_inf_tol = 0.0; o->constr_viol_tol = 0.0; o->refine = 0;
 }
 
 int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device, omgx_batch** out) {
@@ -1494,7 +1503,7 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
   omgx_batch* b = new omgx_batch();
   b->device = device; b->n_agents = n_agents;
   omgx_options o; omgx_default_options(&o);
-  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm, o.dw_leaf_ratio_cold, 0, o.warm_mu_factor, o.warm_z_floor, o.warm_z_cap, o.max_soc, o.hess_approx, o.compl_inf_tol, o.constr_viol_tol};
+  b->opts = {o.tol, o.max_iter, o.mu_init, o.kappa_push, o.nu_init, o.scale_gmax, o.warm_start, o.kappa_warm, o.dw_leaf_ratio_cold, 0, o.warm_mu_factor, o.warm_z_floor, o.warm_z_cap, o.max_soc, o.hess_approx, o.compl_inf_tol, o.constr_viol_tol, o.refine};
   ExpandedTemplate ex;
   const bool ranged = expand_range_rows(tpl, ex);
   b->n_con_user = tpl->n_con; b->n_range = ranged ? (int)ex.src.size() : 0;
@@ -1528,6 +1537,11 @@ int omgx_batch_create(const omgx_template* tpl, int32_t n_agents, int32_t device
   if ((int)b->lds_bytes > reserved) reserved = (int)b->lds_bytes;
   if (hipFuncSetAttribute((const void*)ipm_kernel_for(b->ws_mode, b->dims.wave_ok, b->dims.general), hipFuncAttributeMaxDynamicSharedMemorySize,
                           reserved) != hipSuccess) {
+    g_err = "cannot reserve dynamic LDS for ipm_solve_kernel"; omgx_batch_destroy(b); return OMGX_E_HIP;
+  }
+  if (ipm_kernel_for(b->ws_mode, b->dims.wave_ok, b->dims.general, 1) != ipm_kernel_for(b->ws_mode, b->dims.wave_ok, b->dims.general) &&
+      hipFuncSetAttribute((const void*)ipm_kernel_for(b->ws_mode, b->dims.wave_ok, b->dims.general, 1), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          reserved) != hipSuccess) {      // (the instance with the refinement of regularised steps, omgx_options.refine)
     g_err = "cannot reserve dynamic LDS for ipm_solve_kernel"; omgx_batch_destroy(b); return OMGX_E_HIP;
   }
   if (ipm_rollout_t rk = rollout_kernel_for(b->ws_mode, b->dims.wave_ok, b->dims.general)) {
@@ -1628,7 +1642,7 @@ int omgx_batch_set_options(omgx_batch* b, const omgx_options* o) {
   b->opts = {o->tol, o->max_iter, o->mu_init, o->kappa_push, o->nu_init, o->scale_gmax, o->warm_start, o->kappa_warm,
              o->dw_leaf_ratio_cold > 0 ? o->dw_leaf_ratio_cold : 1.0, 0, o->warm_mu_factor >= 0 ? o->warm_mu_factor : 0.0,
              o->warm_z_floor >= 0 ? o->warm_z_floor : 0.0, o->warm_z_cap >= 0 ? o->warm_z_cap : 0.0, o->max_soc > 0 ? (o->max_soc > 8 ? 8 : o->max_soc) : 0, o->hess_approx > 0 ? 1 : 0,
-             o->compl_inf_tol > 0 ? o->compl_inf_tol : 0.0, o->constr_viol_tol > 0 ? o->constr_viol_tol : 0.0};
+             o->compl_inf_tol > 0 ? o->compl_inf_tol : 0.0, o->constr_viol_tol > 0 ? o->constr_viol_tol : 0.0, o->refine > 0 ? 1 : 0};
   return OMGX_OK;
 }
 
@@ -1754,7 +1768,7 @@ int omgx_batch_solve(omgx_batch* b, const double* p, const double* x0, const dou
     HIPCHK(hipGetLastError());
     e0 = nullptr;
   }
-  hipExtLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok, b->dims.general), dim3(b->n_slabs), dim3(b->threads), (uint32_t)b->lds_bytes, b->stream,
+  hipExtLaunchKernelGGL(ipm_kernel_for(b->ws_mode, b->dims.wave_ok, b->dims.general, b->opts.refine), dim3(b->n_slabs), dim3(b->threads), (uint32_t)b->lds_bytes, b->stream,
                         e0, e1, 0u, d, b->dev,
                         b->opts, b->kkt_doubles, kp, kx0, klb, kub, shared ? 1 : 0, kx, klam, kst, kit, B, b->d_prof,
                         b->d_slabs, b->slab_doubles, b->d_dw, b->d_order, (const StoreArgs*)(b->store.out ? b->d_store : nullptr), (flags & OMGX_ONLY_FAILED) ? 1 : 0,
@@ -2172,7 +2186,7 @@ int omgx_batch_rollout(omgx_batch* b, const omgx_rollout_spec* sp, double* p, do
   if (sp->cross_options) {
     const omgx_options& co = *sp->cross_options;
     a.o_cross.kappa_warm = co.kappa_warm; a.o_cross.warm_mu_factor = co.warm_mu_factor; a.o_cross.warm_z_floor = co.warm_z_floor;
-    a.o_cross.warm_z_cap = co.warm_z_cap; a.o_cross.max_iter = co.max_iter; a.o_cross.tol = co.tol; a.o_cross.max_soc = co.max_soc;
+    a.o_cross.warm_z_cap = co.warm_z_cap; a.o_cross.max_iter = co.max_iter; a.o_cross.tol = co.tol; a.o_cross.max_soc = co.max_soc; a.o_cross.refine = co.refine > 0 ? 1 : 0;
   }
   // per-step statistics: the slots the next n_steps single launches would have taken (omgx_batch_set_stats)
   a.stats = nullptr;

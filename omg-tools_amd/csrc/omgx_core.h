@@ -174,6 +174,7 @@ struct Opts {
   // which the reference leaves in force when it sets ipopt.tol = 1e-3, `problems/problem.py:57`); 0: not tested (rounds 1-5).  The barrier
   // parameter ends at min(tol, compl_tol) / 10.
   double compl_tol, viol_tol;
+  int refine;                  // (version 9) 1: iterative refinement of a regularised Newton step, from the second iteration of a solve on (default 0)
 };
 
 // fixed constants of the iteration (same values in oracle/ipm_numpy.py DEFAULTS)
@@ -345,7 +346,7 @@ OMGX_HD void work_carve(Work& w, double* base, const Dims& d, int kkt_doubles) {
 // ---------------------------------------------------------------------------
 #ifdef OMGX_HOST_PORT
 struct Ctx {
-  static constexpr bool wave_only = false, hbm = false, no_wave = false, root_lds = false, general = true, prep = false;
+  static constexpr bool wave_only = false, hbm = false, no_wave = false, root_lds = false, general = true, prep = false, refine = true;
   double* red;
   int tid() const { return 0; }
   int nthr() const { return 1; }
@@ -369,10 +370,13 @@ struct Ctx {
 // degree > 5): the other instance does not carry that code -- at the 256-register cap of this kernel it cost spills
 // kPrep: the instance of the setup kernel (ipm_prepare_kernel): row arrays and Jacobian values in the agent's record in global
 // memory, no KKT store
-template <bool kHbm, bool kWaveOnly = false, bool kRootLds = false, bool kGeneral = false, bool kPrep = false>
+// kRefine: the instance that carries the refinement of regularised steps (Opts::refine): its second solve and its second pass through
+// the step phase cost the instance without them 2.5 % of its cycles per solve through register pressure alone (345.8 k against 337 k)
+template <bool kHbm, bool kWaveOnly = false, bool kRootLds = false, bool kGeneral = false, bool kPrep = false, bool kRefine = false>
 struct CtxT {
   static constexpr bool hbm = kHbm;
   static constexpr bool prep = kPrep;
+  static constexpr bool refine = kRefine;
   static constexpr bool general = kGeneral;
   static constexpr bool root_lds = kRootLds;      // Work::root holds the root block from the Schur step on (spill modes)
   static constexpr bool wave_only = kWaveOnly;
@@ -1593,7 +1597,7 @@ OMGX_FN void kkt_solve_wave(const C& c, const Dims& d, const Kkt& K, Work& w, do
 // leaf order (fixed order of the sums), substitutes the root forwards and backwards; the leaves finish as in
 // kkt_solve_wave.  out [N]: the solution in position order (the equality multipliers of this solve are dropped).
 template <class C>
-OMGX_FN void kkt_solve2_wave(const C& c, const Dims& d, const Kkt& K, Work& w, double* out) {
+OMGX_FN void kkt_solve2_wave(const C& c, const Dims& d, const Kkt& K, Work& w, double* out, bool with_y = false) {
   const BMat* Ms = (const BMat*)w.col;
   const int lane = c.lane(), wave = c.wave(), nw = c.nwaves();
   const int koff = (int)(w.kkt - omgx_lds);
@@ -1657,7 +1661,7 @@ OMGX_FN void kkt_solve2_wave(const C& c, const Dims& d, const Kkt& K, Work& w, d
     const int j = lane < P.n ? lane : 0;
     const double y = wave_fwd_r<false>(koff, P, dl, w.kkt[wcarried<false>(P, P.n) + j]);
     const double x = wave_bwd_r<false>(koff, P, dl, y * dl);
-    if (lane < d.n_root) out[d.root_off + lane] = x;
+    if (lane < (with_y ? P.n : d.n_root)) out[d.root_off + lane] = x;      // (with_y: the equality multipliers behind the N positions)
   }
   c.sync();
   double* xg = xg0 + wave * 64;
@@ -2032,10 +2036,10 @@ static thread_local std::vector<double> omgx_sol2;       // output of a second s
 // over the storage its blocked routines leave (leaf panels U = L D with inverse pivots aside, root L with the pivots
 // on the diagonal).
 template <class C>
-OMGX_FN void kkt_solve2(const C& c, const Dims& d, const Kkt& K, Work& w, double* out) {
+OMGX_FN void kkt_solve2(const C& c, const Dims& d, const Kkt& K, Work& w, double* out, bool with_y = false) {
 #ifndef OMGX_HOST_PORT
   if constexpr (C::wave_only) {
-    kkt_solve2_wave(c, d, K, w, out);
+    kkt_solve2_wave(c, d, K, w, out, with_y);
   } else {
     // Blocked storage (templates off the wave path, spill modes included): leaf right-hand sides from their carried rows into
     // `out` (LDS), a wave per leaf substitutes forwards, the leaves subtract W Delta^-1 y from the root's right-hand side one
@@ -2136,7 +2140,7 @@ OMGX_FN void kkt_solve2(const C& c, const Dims& d, const Kkt& K, Work& w, double
   }
   omgx_sol2.resize((size_t)d.N + d.n_eq);
   kkt_solve(c, d, K, w, omgx_sol2.data());
-  for (int q = 0; q < d.N; ++q) out[q] = omgx_sol2[q];
+  for (int q = 0; q < d.N + (with_y ? d.n_eq : 0); ++q) out[q] = omgx_sol2[q];
 #endif
 }
 
@@ -2461,6 +2465,7 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
   // than dw (same product: the same bilinear negative curvature is covered); warm starts use dw on both
   const double reg_leaf = warm ? 1.0 : o.dw_leaf_ratio_cold, reg_root = warm ? 1.0 : 1.0 / o.dw_leaf_ratio_cold;
   int it = 0, status = 1, ls_fail = 0, full_steps = 0;
+  double alpha_prev = 1.0;      // step length the previous iteration accepted
   const double nu_stall_max = warm ? OMGX_NU_MAX : 0.0;     // see the stall test in the loop
 
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
@@ -2638,6 +2643,7 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
     // trajectory coefficient whose bilinear rows are all inactive (multipliers ~ mu / s) is then
     // practically undamped even while dw covers the active hyperplane rows elsewhere.
     int first_trial = 1;
+    double dw_leaf_used = 0.0, dw_root_used = 0.0;      // the inertia correction the factors of this iteration carry (leaf / root variables)
     double gcap = -1.0;      // the Gershgorin guarantee of this iteration (computed when first needed)
     // (side sums of cut runs: w.dinv -- the dual residual has been read, the factorisation has not started -- or the pairs' side slots)
     double* const gside = d.kg_side_dinv ? w.dinv : w.kkt + d.side_off;
@@ -2793,7 +2799,7 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
         fprintf(stderr, "      factorisation: dw %.3e decreasing %d -> bad %d   (largest Gershgorin sum %.3e at x[%d])\n", dw, decreasing, bad, gmx, qg >= 0 ? T.order[qg] : -1); }
 #endif
       first_trial = 0;
-      if (!bad) { if (decreasing) dw_backoff = 1; break; }
+      if (!bad) { if (decreasing) dw_backoff = 1; dw_leaf_used = dw_root_used = dw; break; }
       if (bad == 2 && d.wave_ok && warm) {
         // The leaves are positive definite at this dw and their Schur complements are in the root, which alone
         // has the wrong inertia: raise the inertia correction of the root variables only (with positive definite
@@ -2845,6 +2851,7 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
         }
         if (failed) break;
         if (leave_root) { dw = c.uni(gcap); decreasing = 0; c.sync(); continue; }      // (full reassembly at the guarantee)
+        dw_leaf_used = dw; dw_root_used = dwr;
         dw = dwr;                    // what the next iteration starts from
         break;
       }
@@ -2865,13 +2872,85 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
 
     // ---- Newton step -------------------------------------------------------------
     kkt_solve(c, d, K, w, w.sol);
+    bool refined = false;      // w.sol carries refinement terms (their sum parked in the store's right-hand-side slots)
+    // Iterative refinement of a regularised step (o.refine, off by default; round 6).  With an inertia correction D the factors are
+    // those of K + D and the step s1 = -(K + D)^-1 r is a proximal step: in the directions the Lagrangian Hessian leaves nearly flat
+    // -- hyperplanes sliding along an inactive face, the LP-like directions of the L1 objective -- it covers lambda / (lambda + delta)
+    // of the way, and the dual residual it leaves, D s1, is the regularisation term itself (1.1-1.6e-3 against tol 1e-3 on a typical
+    // warm step: why the slowest agent of a step needs three iterations).  Since K s1 = -r - D s1, the step of the unregularised
+    // system is s1 + s2 + ... with (K + D) s_{k+1} = D s_k; ONE term is added -- one more solve with the factors of the iteration
+    // (kkt_solve2 with the equality multipliers), no Hessian product; both s1 and s1 + s2 are descent directions of the regularised
+    // model (s2' g = -g' M^-1 D M^-1 g <= 0).  More terms were measured: stragglers move around, nothing gained.  Rules, each from a
+    // measured failure:  the term is taken only if it is no longer than the step (where K is indefinite along the step the series
+    // grows);  from the second iteration of a solve on (nine of ten warm solves end after one iteration and pay nothing);  not after
+    // an iteration that accepted less than a tenth of its step (there the line search holds the solve back and a longer direction is
+    // cut further: a formation x-update in a phase-I crawl, 212 iterations, ran into the cap with refined steps);  in cold solves only
+    // once phase I is over (`examples/revolving_door.py` from the reference's guess: Infeasible_Detected after 20 iterations with
+    // refined phase-I steps, 46 iterations without);  no lifted auxiliaries (trial points projected onto defining rows: a toy
+    // problem ended in Numerical_Failure);  wave-path templates with the exact Hessian (a second solve of the spill classes runs out
+    // of their slab);  and the refined step stands only if the FIRST trial of the line search accepts it as it is -- else the plain
+    // step takes over with its own boundary rule and line search (the pass loop below; the term waits in the store's right-hand-side
+    // slots).  Host build, three fresh seeds x (cold + 110 updates of 1024 agents): cold 21.6 -> 20.8 iterations, warm 1.208 -> 1.192,
+    // slowest agent per update summed 562 -> 447, solves with more than five iterations 501 -> 308, nothing unsolved either way; tight
+    // tolerances gain most (tol 1e-6: 9.5 -> 6.9 iterations per warm solve, unsolved steps 24 -> 7 of 46 k).  On the device the second
+    // solve and the repeated step phase cost more than the saved iterations give back where solves are short: headline 2.26 -> 2.19 M
+    // solves/s at tol 1e-3, +22 % / +52 % at 1e-4 / 1e-6 (profiles/r06_refine_ab.txt).  Hence an option.  The term lives in w.ht
+    // (free between the factorisation and the line search).
+#ifndef OMGX_REFINE_ALPHA
+#define OMGX_REFINE_ALPHA 0.1      // the refinement is skipped after an iteration whose accepted step length was below this
+#endif
+#ifndef OMGX_REFINE_PHASE2_ONLY
+#define OMGX_REFINE_PHASE2_ONLY 0
+#endif
+#ifndef OMGX_REFINE_TMAX
+#define OMGX_REFINE_TMAX 1e-4     // cold solves: no refinement while phase I is under way (t above this)
+#endif
+    if constexpr (C::refine)
+    if (o.refine > 0 && it >= 1 && alpha_prev >= OMGX_REFINE_ALPHA && ((warm && !OMGX_REFINE_PHASE2_ONLY) || !use_t || t <= OMGX_REFINE_TMAX) && d.wave_ok && d.n_lift == 0 && !gn && dw_leaf_used > 0.0) {
+      const BMat* Ms2 = (const BMat*)w.col;
+      const int rb2 = Ms2[d.n_leaf].pad_;
+      double n1 = 0.0;
+      OMGX_PFOR(q, N) {
+        const double wq = T.reg_w[q];
+        const double dq = q >= d.root_off ? dw_root_used : dw_leaf_used;
+        double add = dq * (wq == 1.0 ? reg_root : (wq == -1.0 ? reg_leaf : wq));
+        if (wq == 1.0 || wq == -1.0) add = fmin(add, w.xt[q] + OMGX_DW_CAP_FLOOR * dq);      // (the assembly's statement)
+        w.kkt[kkt_rhs_slot<C>(d, Ms2, q)] = add * w.sol[q];
+        n1 = fmax(n1, fabs(w.sol[q]));
+      }
+      OMGX_PFOR(k, d.n_eq) w.kkt[rb2 + tri(d.nr, d.n_root + k)] = 0.0;
+      c.sync();
+      kkt_solve2(c, d, K, w, w.ht, true);
+      double n2 = 0.0;
+      OMGX_PFOR(q, N) n2 = fmax(n2, fabs(w.ht[q]));
+      double rv2[2] = {n1, n2};
+      c.template reduce_ops<1, 1>(rv2);
+      if (rv2[1] <= rv2[0]) {
+        // (the term also waits in the right-hand-side slots of the store -- free until a second-order correction solves again --
+        // in case the first trial of the line search sends the iteration back to the plain step, below)
+        OMGX_PFOR(q, N) { w.sol[q] += w.ht[q]; w.kkt[kkt_rhs_slot<C>(d, Ms2, q)] = w.ht[q]; }
+        OMGX_PFOR(k, d.n_eq) { w.sol[N + k] += w.ht[N + k]; w.kkt[rb2 + tri(d.nr, d.n_root + k)] = w.ht[N + k]; }
+        refined = true;
+      }
+#if defined(OMGX_HOST_PORT) && defined(OMGX_TRACE)
+      fprintf(stderr, "      refinement: |s1| %.3e |s2| %.3e -> %s\n", rv2[0], rv2[1], refined ? "taken" : "not taken");
+#endif
+      c.sync();
+    }
     OMGX_TOC(PH_SOLVE);
     if (!use_t && c.tid() == 0) w.sol[N - 1] = 0.0;
     c.sync();
-    const double dt = c.uni(w.sol[N - 1]);
-    // (the primal boundary step is collected up to OMGX_EXPAND_MAX: a heavily regularised step may be lengthened, below)
-    double ap_l = OMGX_EXPAND_MAX, ad_l = 1.0, ymax = 0.0, gdx = 0.0, ysum = 0.0;
+    // (what the update below and the traces read of the step and its line search; two passes at most: a refined step whose first
+    // trial is not accepted gives way to the plain step of the same factors, and the pass runs again as if there had been no refinement)
+    double dt = 0.0, gdx = 0.0, a_p = 0.0, a_d = 0.0, dzt = 0.0, phi0 = 0.0, dphi = 0.0, alpha = 0.0, ft = f, tt = t;
+    int ok = 0;
     const double tau = c.uni(fmax(OMGX_TAU_MIN, 1.0 - mu));
+    for (;;) {
+    bool back_to_plain = false;
+    dt = c.uni(w.sol[N - 1]);
+    // (the primal boundary step is collected up to OMGX_EXPAND_MAX: a heavily regularised step may be lengthened, below)
+    double ap_l = OMGX_EXPAND_MAX, ad_l = 1.0, ymax = 0.0, ysum = 0.0;
+    gdx = 0.0;
     OMGX_PFOR(ir, m) {
       const int r = T.row_perm[ir];
       const int ty = w.rtype[r];
@@ -2904,13 +2983,12 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
     OMGX_PFOR(q, N) gdx += w.gbar[q] * w.sol[q];
     double lns = 0.0;
     OMGX_PFOR(r, m) if (w.rtype[r] == ROW_UPPER || w.rtype[r] == ROW_LOWER) lns += log(row_slack(w, r, t));
-    double a_p, a_d;
     {
       double rv[6] = {ap_l, ad_l, ymax, gdx, lns, ysum};
       c.template reduce_ops<2, 2, 1, 0, 0, 0>(rv);
       a_p = rv[0]; a_d = rv[1]; ymax = rv[2]; gdx = rv[3]; lns = rv[4]; ysum = rv[5];
     }
-    double dzt = 0.0;
+    dzt = 0.0;
     if (use_t) {
       dzt = c.uni(mu / t - zt - (zt / t) * dt);
       if (dt < 0.0) a_p = fmin(a_p, -tau * t / dt);
@@ -2927,8 +3005,8 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
     // against a predicted decrease of 1e-11, every trial is an ascent step and the solve ends in Numerical_Failure (seen on
     // the quartic free-end-time problem and on 1e-6 formation x-updates).
     const double floorE = c.uni(delta_c * ysum);
-    const double phi0 = c.uni(f + nu * t - mu * lns - (use_t ? mu * log(t) : 0.0) + nuE * fmax(0.0, rE_sum - floorE));
-    const double dphi = c.uni(gdx - nuE * fmax(0.0, rE_sum - floorE));
+    phi0 = c.uni(f + nu * t - mu * lns - (use_t ? mu * log(t) : 0.0) + nuE * fmax(0.0, rE_sum - floorE));
+    dphi = c.uni(gdx - nuE * fmax(0.0, rE_sum - floorE));
 
     OMGX_TOC(PH_STEP);
     // ---- Armijo backtracking on the barrier function, iterate stays strictly feasible ----
@@ -2947,7 +3025,7 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
       while (2.0 * ex <= a_bnd && 2.0 * ex <= OMGX_EXPAND_MAX) ex *= 2.0;
       a_p = c.uni(fmin(a_bnd, ex));
     }
-    double alpha = a_p, ft = f, tt = t; int ok = 0;
+    alpha = a_p; ft = f; tt = t; ok = 0;
     // Second-order correction (o.max_soc; templates on the wave path): when the first trial is rejected, the rows have
     // moved by e = (s + alpha ds) - s(x + alpha dx) more than their linearisation said (the bilinear hyperplane rows: a term
     // of second order in the step, which is what cuts a step along an active face to a few per cent).  One more solve
@@ -3010,6 +3088,23 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
         // resolve -- its value is a sum of ~n_con terms of size 1 -- and the Armijo test then compares rounding
         // noise: such a step is taken as it is, like IPOPT's tiny-step rule; the error test decides about the rest)
         if (phi_noise || phit <= phi0 + OMGX_ETA * alpha * dphi || phit - phi0 <= 10.0 * 2.220446049250313e-16 * fabs(phi0)) { ok = 1; break; }
+      }
+      if constexpr (C::refine)
+      if (refined && bt == 0) {
+        // the refined step is taken only where its first trial is accepted as it stands; else the plain step of the same factors,
+        // with its own boundary rule, directional derivative and line search (the term comes back out of the right-hand-side slots)
+        const BMat* Ms2 = (const BMat*)w.col;
+        const int rb2 = Ms2[d.n_leaf].pad_;
+        c.sync();
+        OMGX_PFOR(q, N) w.sol[q] -= w.kkt[kkt_rhs_slot<C>(d, Ms2, q)];
+        OMGX_PFOR(k, d.n_eq) w.sol[N + k] -= w.kkt[rb2 + tri(d.nr, d.n_root + k)];
+        if (!use_t && c.tid() == 0) w.sol[N - 1] = 0.0;
+        c.sync();
+        refined = false; back_to_plain = true;
+#if defined(OMGX_HOST_PORT) && defined(OMGX_TRACE)
+        fprintf(stderr, "      refined step rejected at its first trial (alpha %.3e smin %.3e): back to the plain step\n", alpha, smin);
+#endif
+        break;
       }
       // (round 6, max_soc > 1 -- IPOPT's max_soc is a count, default 4: the corrected trial failed too: one more correction from where
       // it landed while its rows still violate -- a step along a curved row whose slack is tiny needs the correction to be exact to
@@ -3086,6 +3181,8 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
       alpha = c.uni(alpha * 0.5);
       c.sync();
     }
+    if (!back_to_plain) break;
+    }
     OMGX_TOC(PH_L_ROWS);
 #if defined(OMGX_PROFILE) && !defined(OMGX_HOST_PORT)
     if (c.tid() == 0) c.prof[PH_LINESEARCH] = c.prof[PH_L_TERMS] + c.prof[PH_L_ROWS];
@@ -3124,6 +3221,7 @@ OMGX_FN Result ipm_iterate(const C& c, const Dims& d, const Tables& T, const Opt
     if (gn) { if (alpha < 0.25) lm = fmin(lm * 4.0, 1e8); else if (alpha >= 1.0) lm = fmax(lm * 0.5, 1e-6); }
     ls_fail = 0;
     full_steps = (alpha >= 1.0 && alpha == a_p) ? full_steps + 1 : 0;      // (accepted at the first trial, not cut by the boundary)
+    alpha_prev = alpha;
     // ---- accept --------------------------------------------------------------------
     c.sync();
     OMGX_PFOR(q, N) w.x[q] = w.xt[q];

@@ -345,10 +345,11 @@ class FormationMPC(object):
     def step(self):
         lay, ops = self.lay, self.ops
         t_prev, t_now = self.time, self.time + self.update_time
-        rel_prev = np.round(t_prev, 6) % self.knot_time
+        from .splines import since_knot
+        rel_prev = since_knot(t_prev, self.knot_time)
         tau = (rel_prev + self.update_time) / self.T
         crossed = int(np.round(t_prev / self.knot_time, 6)) < int(np.round(t_now / self.knot_time, 6))
-        t_rel = float(np.round(t_now, 6) % self.knot_time)
+        t_rel = since_knot(t_now, self.knot_time)
         ops.predict(self.o_spl, self.n_spl, self.basis, tau, 1.0 / self.T, [lay.p_state0, lay.p_input0], lay.p_t, t_rel)
         dt = self.update_time
         for ox, ov, oa, nd in self.obst:        # x <- x + v dt + a dt^2 / 2, v <- v + a dt (`environment/obstacle.py:246-264`)

@@ -58,7 +58,7 @@ class COptions(C.Structure):
                 ('kappa_push', C.c_double), ('nu_init', C.c_double), ('scale_gmax', C.c_double),
                 ('warm_start', C.c_int32), ('kappa_warm', C.c_double),
                 ('dw_leaf_ratio_cold', C.c_double), ('warm_mu_factor', C.c_double), ('warm_z_floor', C.c_double), ('warm_z_cap', C.c_double), ('max_soc', C.c_int32), ('hess_approx', C.c_int32),
-                ('compl_inf_tol', C.c_double), ('constr_viol_tol', C.c_double)]
+                ('compl_inf_tol', C.c_double), ('constr_viol_tol', C.c_double), ('refine', C.c_int32)]
 
 
 class CRolloutSpec(C.Structure):
@@ -73,7 +73,7 @@ class CRolloutSpec(C.Structure):
 
 DEFAULT_OPTIONS = dict(tol=1e-3, max_iter=300, mu_init=0.1, kappa_push=1.0,
                        nu_init=100.0, scale_gmax=100.0, warm_start=0, kappa_warm=1e-3,
-                       dw_leaf_ratio_cold=1.0, warm_mu_factor=1.0, warm_z_floor=0.1, warm_z_cap=0.01, max_soc=1, hess_approx=0, compl_inf_tol=0.0, constr_viol_tol=0.0)
+                       dw_leaf_ratio_cold=1.0, warm_mu_factor=1.0, warm_z_floor=0.1, warm_z_cap=0.01, max_soc=1, hess_approx=0, compl_inf_tol=0.0, constr_viol_tol=0.0, refine=0)
 
 
 def make_options(**kw):

@@ -21,7 +21,7 @@ import os
 
 import numpy as np
 
-from .splines import shiftoverknot_T
+from .splines import shiftoverknot_T, since_knot
 
 
 # solver options of a knot-crossing step (BatchP2P `cross_options`)
@@ -271,11 +271,11 @@ class BatchP2P(object):
         B, L, nd = self.B, self.L, self.n_dim
         t_prev = self.time
         t_now = t_prev + self.update_time
-        rel_prev = np.round(t_prev, 6) % self.knot_time
+        rel_prev = since_knot(t_prev, self.knot_time)
         # (1) ideal prediction on the current plan, (2) horizon bookkeeping
         tau = (rel_prev + self.update_time) / self.T
         crossed = int(np.round(t_prev / self.knot_time, 6)) < int(np.round(t_now / self.knot_time, 6))
-        t_rel = float(np.round(t_now, 6) % self.knot_time)
+        t_rel = since_knot(t_now, self.knot_time)
         if self.kind == 'host' and self.pool is not None:
             self.time = t_now
             self._solve(True, step_desc=self._pool_step(tau, t_rel, crossed), extra=self.cross_options if crossed else None)
@@ -319,10 +319,10 @@ class BatchP2P(object):
         t = self.time
         for _ in range(int(n_steps)):                      # (the clock of `step`, statement for statement)
             t_prev, t_now = t, t + self.update_time
-            rel_prev = np.round(t_prev, 6) % self.knot_time
+            rel_prev = since_knot(t_prev, self.knot_time)
             tau.append((rel_prev + self.update_time) / self.T)
             crossed.append(int(np.round(t_prev / self.knot_time, 6)) < int(np.round(t_now / self.knot_time, 6)))
-            t_rel.append(float(np.round(t_now, 6) % self.knot_time))
+            t_rel.append(since_knot(t_now, self.knot_time))
             t = t_now
         self.solver.set_options(warm_start=1, max_iter=self.max_iter_step, **self._base_extra)
         if self.straggler_first:

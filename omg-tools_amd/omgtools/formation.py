@@ -48,7 +48,7 @@ import numpy as np
 
 from .opti import OptiChild, OptiFather
 from .problems import FixedTPoint2point
-from .splines import shift_knot1_fwd, shiftfirstknot_T, shiftoverknot_T
+from .splines import shift_knot1_fwd, shiftfirstknot_T, shiftoverknot_T, since_knot
 from .consensus import (coupling_matrix, zupdate_matrices, FormationLayout, circular_neighbors, reverse_slots,      # noqa: F401
                         shift_tables)
 from .symbolic import Poly
@@ -295,13 +295,13 @@ class FormationPoint2point(object):
         t0 = time.time()
         # knot crossing: shift the warm start of x and the whole consensus state (`admm.py:477-491`)
         crossing = int(np.round(self._time_prev / self.knot_time, 6)) < int(np.round(current_time / self.knot_time, 6))
-        t_rel = float(np.round(current_time, 6) % self.knot_time)
+        t_rel = since_knot(current_time, self.knot_time)
         if self._device_prediction(current_time, update_time, crossing):
             # Nobody disturbs the vehicles (`ideal_prediction`, `vehicles/vehicle.py:323-326`): the initial conditions of this
             # update are the current plan `update_time` ahead -- one launch on the resident plan (`FormationMPC.step`) instead
             # of packing every vehicle's parameter vector on the host.  What the fleet shares (obstacle motion, T) comes from
             # ONE sub-problem's parameters and is written to all rows; rel_pos_c, poseT and rho do not change between updates.
-            rel_prev = np.round(self._time_prev, 6) % self.knot_time
+            rel_prev = since_knot(self._time_prev, self.knot_time)
             tau = (rel_prev + (current_time - self._time_prev)) / float(self.options['horizon_time'])
             veh = self.vehicles[0]
             self.ops.predict(self._o_plan, veh.n_spl, veh.basis, tau, 1.0 / float(self.options['horizon_time']),
@@ -351,7 +351,7 @@ class FormationPoint2point(object):
 
     def simulate(self, current_time, simulation_time, sample_time):
         horizon_time = self.options['horizon_time']
-        rel = np.round(current_time - self.start_time, 6) % self.knot_time
+        rel = since_knot(current_time - self.start_time, self.knot_time)
         simulation_time = min(simulation_time, horizon_time - rel)
         for vehicle in self.vehicles:
             vehicle.simulate(simulation_time, sample_time)

@@ -43,7 +43,7 @@ import numpy as np
 from .opti import OptiChild, OptiFather, inf
 from .plotting import PlotLayer
 from .vehicles import get_fleet_vehicles
-from .splines import definite_integral, evalspline, shiftoverknot_T
+from .splines import definite_integral, evalspline, shiftoverknot_T, since_knot
 
 _NESTED_OPTIONS = ('solver_options', 'codegen')
 
@@ -308,7 +308,7 @@ class FixedTPoint2point(Point2pointProblem):
 
     def _since_knot(self, elapsed):
         """t: seconds since the last knot the plan passed (or the time the user pinned with `set_init_time`)."""
-        return np.round(elapsed, 6) % self.knot_time if self.init_time is None else self.init_time
+        return since_knot(elapsed, self.knot_time) if self.init_time is None else self.init_time
 
     def set_parameters(self, current_time):
         return {self: {'t': self._since_knot(current_time), 'T': self.options['horizon_time']}}
@@ -348,7 +348,7 @@ class FixedTPoint2point(Point2pointProblem):
     def compute_partial_objective(self, current_time, update_time):
         """What the part of the plan that is executed now costs (summed up over the run as `self.objective`)."""
         T = self.options['horizon_time']
-        a = (np.round(current_time - self.start_time, 6) % self.knot_time) / T
+        a = since_knot(current_time - self.start_time, self.knot_time) / T
         b = a + update_time / T
         self.objective += sum(T * definite_integral(g, a, b) for g in self._slacks())
 

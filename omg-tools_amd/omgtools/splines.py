@@ -370,6 +370,20 @@ def extrapolate_T(basis, t_extra):
     return T
 
 
+def since_knot(t, knot_time):
+    """Seconds since the last knot of the receding horizon at time t: the reference's statement `np.round(t, 6) % knot_time`
+    (`problems/point2point.py:177`, the parameter `t`), repaired where it contradicts the reference's own crossing test
+    `int(np.round(t / knot_time, 6))` (`point2point.py:190-193`).  When t is a whole number of knot intervals whose product rounds
+    above t -- T = 10 s, 11 intervals: `knot_time = (int(T * 1000) / 11) / 1000` (`point2point.py:134`) is 0.9090909090909092, one ulp
+    above 10 / 11, and 11 of them exceed t = 10.0 -- the remainder comes out one interval short of zero (0.909...) while the
+    crossing test has just moved the horizon on: the initial-condition rows are then evaluated 0.909 s
+    into a plan that begins NOW, every vehicle re-plans from a start that violates them, and the next update jumps back.  The
+    reference's IPOPT absorbs it; measured here (1024 agents of config 2, update 99 = t 10.0): the slowest agent 62 iterations,
+    six for the update after.  A remainder within 1e-9 of a whole interval is the knot itself: 0."""
+    rel = float(np.round(t, 6) % knot_time)
+    return 0.0 if knot_time - rel < 1e-9 else rel
+
+
 def shiftoverknot_T(basis):
     """Warm-start matrix when the horizon start passes the first interior knot:
     the new coefficients describe s(tau + delta) on the same (uniform) knot

@@ -317,6 +317,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
     dw_hold, dw_backoff = 0, 1
     status, it, nfact = 1, 0, 0
     ls_fail, full_steps = 0, 0
+    alpha_prev = 1.0
     # (omgx_core.h `hess_approx`: no constraint curvature in the Hessian, a damping weight that follows the accepted step length)
     gn, lm = bool(o.get('hess_approx', 0)), 1.0
     N = n + 1                      # (x, t)
@@ -468,8 +469,10 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
         def escalated(v, floor_v):
             nxt = o['dw_first'] if v == 0.0 else v * o['dw_inc']
             return gcap if (ls_fail == 0 and v < gcap and nxt > gcap) else nxt
+        dw_used = np.zeros(N)          # the inertia correction the factors carry (per variable, before weights and caps)
         while True:
-            K, L, d, ok = factor(np.full(N, dw))
+            dw_used = np.full(N, dw)
+            K, L, d, ok = factor(dw_used)
             nfact += 1
             if ok:
                 if decreasing:
@@ -503,7 +506,8 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
                     if dwr > o['dw_max']:
                         status = 4
                         break
-                    K, L, d, ok = factor(np.where(is_root, dwr, dw))
+                    dw_used = np.where(is_root, dwr, dw)
+                    K, L, d, ok = factor(dw_used)
                     nfact += 1
                     if ok:
                         break
@@ -539,86 +543,109 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             res_ = rhs - K @ sol
             res_[N:] -= delta_c * sol[N:]
             sol += ldl_solve(L, d, res_)
-        dxt, y_new = sol[:N], sol[N:]
-        if not use_t:
-            dxt[n] = 0.0
-        ds = -Jh @ dxt
-        dz = mu / s - z - Sig * ds
-        dt = dxt[n]
-        dzt = (mu / t - zt - (zt / t) * dt) if use_t else 0.0
-        tau = max(o['tau_min'], 1.0 - mu)
-        a_p = ftb(s, ds, tau, o['expand_max'])            # (the boundary step up to expand_max: omgx_core.h OMGX_EXPAND_MAX)
-        a_d = ftb(z, dz, tau)
-        if use_t:
-            if dt < 0:
-                a_p = min(a_p, -tau * t / dt)
-            if dzt < 0:
-                a_d = min(a_d, -tau * zt / dzt)
-        thE = np.abs(rE).sum()
-        nuE = 2.0 * max(1.0, np.abs(y_new).max() if mE else 0.0)
-        # (quasi-definite system: the linearised equality residual after the full step is delta_c * y_new; the merit
-        # function counts the equality residual only above that floor -- omgx_core.h)
-        floorE = delta_c * (np.abs(y_new).sum() if mE else 0.0)
-        phi0 = f + nu * t - mu * np.log(s).sum() - (mu * np.log(t) if use_t else 0.0) + nuE * max(0.0, thE - floorE)
-        dphi = g_bar @ dxt - nuE * max(0.0, thE - floorE)
-        # a step of the regularised system may be offered longer (omgx_core.h: the crawl of the proximal iteration)
-        a_bnd = a_p
-        a_p = min(a_bnd, 1.0)
-        phi_noise = abs(a_p * dphi) <= o.get('phi_noise', 1e-10) * (1.0 + abs(phi0))      # (omgx_core.h OMGX_PHI_NOISE)
-        if not phi_noise and dw_last > o['expand_dw'] and full_steps >= o['expand_from']:
-            ex = 1.0
-            while 2.0 * ex <= a_bnd and 2.0 * ex <= o['expand_max']:
-                ex *= 2.0
-            a_p = min(a_bnd, ex)
-        alpha, ok = a_p, False
-        # second-order correction (omgx_core.h, option max_soc; templates on the wave path like there): when the first
-        # trial is rejected, one more solve with the factors of the iteration for what the rows moved beyond their
-        # linearisation; the corrected step is offered once before the halving starts
-        n_soc = int((opts or {}).get('max_soc', 1))          # (omgx_options max_soc: a count, default 1; DEFAULTS' entry belongs to solve_filter)
-        soc = 0 if n_soc > 0 else 2
-        soc_rounds = 0
-        soc_levels = n_soc > 0 and bool(getattr(nlp, 'wave_ok', False)) and not gn      # (omgx_core.h: templates on the wave path)
-        d_c = None
-        for bt in range(o['max_backtrack']):
-            step = alpha * dxt + d_c if soc == 1 else alpha * dxt
-            xt = x + step[:n]
-            if getattr(nlp, 'n_lift', 0):          # (omgx_core.h lift_project: the auxiliaries of lifted products follow the trial point)
-                xt = nlp.project_lifted(xt, c)
-            tt = t + step[n]
-            ft, ht, cEt = evaluate(xt)
-            st = tt * v - ht
-            # (omgx_core.h OMGX_FTB_ACTUAL: every row really keeps half of what the linear fraction-to-boundary rule leaves it)
-            if (st - o.get('ftb_actual', 0.5) * (1.0 - tau) * s).min() > 0 and (not use_t or tt > 0):
-                phit = ft + nu * tt - mu * np.log(st).sum() - (mu * np.log(tt) if use_t else 0.0) \
-                    + nuE * max(0.0, np.abs(cEt - tt * cE0).sum() - floorE)
-                if phi_noise or phit <= phi0 + o['eta'] * alpha * dphi or phit - phi0 <= 10 * np.finfo(float).eps * abs(phi0):
-                    ok = True
+        # iterative refinement of a regularised step (omgx_core.h, option refine: version 9): with D the inertia correction the
+        # factors carry, K s1 = -r - D s1, so s1 + s2 with (K + D) s2 = D s1 is one term closer to the step of the unregularised
+        # system; taken when the term is no longer than the step, from the second iteration of a solve on, not after an iteration
+        # that accepted less than a tenth of its step, in cold solves only once phase I is over; templates on the wave path with
+        # the exact Hessian.  A refined step stands only if its first trial is accepted: else the plain step takes the whole
+        # line search (the pass loop below), like there
+        refine_on = int((opts or {}).get('refine', 0)) > 0      # (omgx_options refine: off by default)
+        term = None
+        if refine_on and it >= 1 and alpha_prev >= 0.1 and (z0 is not None or not use_t or t <= 1e-4) and \
+                bool(getattr(nlp, 'wave_ok', False)) and not getattr(nlp, 'n_lift', 0) and not gn and (dw_used[lv].max() if len(lv) else dw_used.max()) > 0.0:
+            cand = ldl_solve(L, d, np.r_[shift(dw_used) * sol[:N], np.zeros(mE)])
+            if np.abs(cand[:N]).max() <= np.abs(sol[:N]).max():
+                term = cand
+                sol = sol + term
+        while True:          # (two passes at most: a refined step whose first trial is not accepted gives way to the plain step)
+            back_to_plain = False
+            dxt, y_new = sol[:N], sol[N:]
+            if not use_t:
+                dxt[n] = 0.0
+            ds = -Jh @ dxt
+            dz = mu / s - z - Sig * ds
+            dt = dxt[n]
+            dzt = (mu / t - zt - (zt / t) * dt) if use_t else 0.0
+            tau = max(o['tau_min'], 1.0 - mu)
+            a_p = ftb(s, ds, tau, o['expand_max'])            # (the boundary step up to expand_max: omgx_core.h OMGX_EXPAND_MAX)
+            a_d = ftb(z, dz, tau)
+            if use_t:
+                if dt < 0:
+                    a_p = min(a_p, -tau * t / dt)
+                if dzt < 0:
+                    a_d = min(a_d, -tau * zt / dzt)
+            thE = np.abs(rE).sum()
+            nuE = 2.0 * max(1.0, np.abs(y_new).max() if mE else 0.0)
+            # (quasi-definite system: the linearised equality residual after the full step is delta_c * y_new; the merit
+            # function counts the equality residual only above that floor -- omgx_core.h)
+            floorE = delta_c * (np.abs(y_new).sum() if mE else 0.0)
+            phi0 = f + nu * t - mu * np.log(s).sum() - (mu * np.log(t) if use_t else 0.0) + nuE * max(0.0, thE - floorE)
+            dphi = g_bar @ dxt - nuE * max(0.0, thE - floorE)
+            # a step of the regularised system may be offered longer (omgx_core.h: the crawl of the proximal iteration)
+            a_bnd = a_p
+            a_p = min(a_bnd, 1.0)
+            phi_noise = abs(a_p * dphi) <= o.get('phi_noise', 1e-10) * (1.0 + abs(phi0))      # (omgx_core.h OMGX_PHI_NOISE)
+            if not phi_noise and dw_last > o['expand_dw'] and full_steps >= o['expand_from']:
+                ex = 1.0
+                while 2.0 * ex <= a_bnd and 2.0 * ex <= o['expand_max']:
+                    ex *= 2.0
+                a_p = min(a_bnd, ex)
+            alpha, ok = a_p, False
+            # second-order correction (omgx_core.h, option max_soc; templates on the wave path like there): when the first
+            # trial is rejected, one more solve with the factors of the iteration for what the rows moved beyond their
+            # linearisation; the corrected step is offered once before the halving starts
+            n_soc = int((opts or {}).get('max_soc', 1))          # (omgx_options max_soc: a count, default 1; DEFAULTS' entry belongs to solve_filter)
+            soc = 0 if n_soc > 0 else 2
+            soc_rounds = 0
+            soc_levels = n_soc > 0 and bool(getattr(nlp, 'wave_ok', False)) and not gn      # (omgx_core.h: templates on the wave path)
+            d_c = None
+            for bt in range(o['max_backtrack']):
+                step = alpha * dxt + d_c if soc == 1 else alpha * dxt
+                xt = x + step[:n]
+                if getattr(nlp, 'n_lift', 0):          # (omgx_core.h lift_project: the auxiliaries of lifted products follow the trial point)
+                    xt = nlp.project_lifted(xt, c)
+                tt = t + step[n]
+                ft, ht, cEt = evaluate(xt)
+                st = tt * v - ht
+                # (omgx_core.h OMGX_FTB_ACTUAL: every row really keeps half of what the linear fraction-to-boundary rule leaves it)
+                if (st - o.get('ftb_actual', 0.5) * (1.0 - tau) * s).min() > 0 and (not use_t or tt > 0):
+                    phit = ft + nu * tt - mu * np.log(st).sum() - (mu * np.log(tt) if use_t else 0.0) \
+                        + nuE * max(0.0, np.abs(cEt - tt * cE0).sum() - floorE)
+                    if phi_noise or phit <= phi0 + o['eta'] * alpha * dphi or phit - phi0 <= 10 * np.finfo(float).eps * abs(phi0):
+                        ok = True
+                        break
+                if term is not None and bt == 0:      # (omgx_core.h: the refined step stands only if its first trial is accepted)
+                    sol = sol - term
+                    term = None
+                    back_to_plain = True
                     break
-            row_rejected = not ((st - o.get('ftb_actual', 0.5) * (1.0 - tau) * s).min() > 0)
-            if soc == 1 and soc_rounds < n_soc and row_rejected:
-                soc = 0                      # (omgx_core.h, max_soc > 1: one more correction from where the corrected trial landed)
-            if soc == 1:
-                soc = 2
-                if row_rejected and soc_levels:             # (omgx_core.h, round 6: the correction is offered again at the shorter step when a row rejected this one)
+                row_rejected = not ((st - o.get('ftb_actual', 0.5) * (1.0 - tau) * s).min() > 0)
+                if soc == 1 and soc_rounds < n_soc and row_rejected:
+                    soc = 0                      # (omgx_core.h, max_soc > 1: one more correction from where the corrected trial landed)
+                if soc == 1:
+                    soc = 2
+                    if row_rejected and soc_levels:             # (omgx_core.h, round 6: the correction is offered again at the shorter step when a row rejected this one)
+                        soc, soc_rounds, d_c = 0, 0, None
+                    alpha *= 0.5
+                    continue
+                if soc == 0:
+                    soc = 1
+                    soc_rounds += 1
+                    e = (s + alpha * ds) - st
+                    eE = (cEt - tt * cE0) - (1.0 - alpha) * rE
+                    rhs2 = np.r_[-(Jh.T @ (Sig * e)), -eE]
+                    if not use_t:
+                        rhs2[n] = 0.0
+                    d_new = ldl_solve(L, d, rhs2)[:N]
+                    if not use_t:
+                        d_new[n] = 0.0
+                    d_c = d_new if d_c is None else d_c + d_new
+                    continue
+                if soc == 2 and soc_levels and row_rejected:
                     soc, soc_rounds, d_c = 0, 0, None
                 alpha *= 0.5
-                continue
-            if soc == 0:
-                soc = 1
-                soc_rounds += 1
-                e = (s + alpha * ds) - st
-                eE = (cEt - tt * cE0) - (1.0 - alpha) * rE
-                rhs2 = np.r_[-(Jh.T @ (Sig * e)), -eE]
-                if not use_t:
-                    rhs2[n] = 0.0
-                d_new = ldl_solve(L, d, rhs2)[:N]
-                if not use_t:
-                    d_new[n] = 0.0
-                d_c = d_new if d_c is None else d_c + d_new
-                continue
-            if soc == 2 and soc_levels and row_rejected:
-                soc, soc_rounds, d_c = 0, 0, None
-            alpha *= 0.5
+            if not back_to_plain:
+                break
         if trace is not None:
             trace[-1].update(alpha=alpha, a_p=a_p, a_d=a_d, ok=ok, tries=tries, bt=bt, dphi=dphi)
         if not ok:
@@ -634,6 +661,7 @@ def solve(nlp, x0, p, lb, ub, opts=None, z0=None, trace=None):
             lm = min(lm * 4.0, 1e8) if alpha < 0.25 else (max(lm * 0.5, 1e-6) if alpha >= 1.0 else lm)
         ls_fail = 0
         full_steps = full_steps + 1 if (alpha >= 1.0 and alpha == a_p) else 0
+        alpha_prev = alpha
         x, t, s, f, h, cE = xt, tt, st, ft, ht, cEt
         if z0 is not None:
             # component-wise dual step: every multiplier takes its full Newton step, clipped at the

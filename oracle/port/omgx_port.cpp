@@ -41,6 +41,7 @@ extern "C" int omgx_port_solve_mt(const omgx_template* tpl, const omgx_options* 
   o.prio_iter = 0; o.warm_mu_factor = opt->warm_mu_factor >= 0 ? opt->warm_mu_factor : 0.0;
   o.warm_z_floor = opt->warm_z_floor >= 0 ? opt->warm_z_floor : 0.0; o.warm_z_cap = opt->warm_z_cap >= 0 ? opt->warm_z_cap : 0.0; o.max_soc = opt->max_soc > 0 ? (opt->max_soc > 8 ? 8 : opt->max_soc) : 0; o.hess_approx = opt->hess_approx > 0 ? 1 : 0;
   o.compl_tol = opt->compl_inf_tol > 0 ? opt->compl_inf_tol : 0.0; o.viol_tol = opt->constr_viol_tol > 0 ? opt->constr_viol_tol : 0.0;
+  o.refine = opt->refine > 0 ? 1 : 0;
   const omgx::Dims& d = plan.dims;
   std::atomic<int> next(0);
   auto worker = [&]() {
@@ -169,6 +170,7 @@ extern "C" int omgx_port_pool_solve(void* h, const omgx_options* opt, int32_t n_
   o.prio_iter = 0; o.warm_mu_factor = opt->warm_mu_factor >= 0 ? opt->warm_mu_factor : 0.0;
   o.warm_z_floor = opt->warm_z_floor >= 0 ? opt->warm_z_floor : 0.0; o.warm_z_cap = opt->warm_z_cap >= 0 ? opt->warm_z_cap : 0.0; o.max_soc = opt->max_soc > 0 ? (opt->max_soc > 8 ? 8 : opt->max_soc) : 0; o.hess_approx = opt->hess_approx > 0 ? 1 : 0;
   o.compl_tol = opt->compl_inf_tol > 0 ? opt->compl_inf_tol : 0.0; o.viol_tol = opt->constr_viol_tol > 0 ? opt->constr_viol_tol : 0.0;
+  o.refine = opt->refine > 0 ? 1 : 0;
   std::atomic<int> next(0);
   pp->run([&](int tid) {
     double* buf = pp->bufs[tid].data();

@@ -179,3 +179,33 @@ def test_stop_at_arrival_ends_an_agents_loop_like_the_reference():
         assert ruled.iters[b] == 0
     ruled.stop_at_arrival(on=False)
     assert ruled.under_way is None
+
+
+def test_the_knot_clock_is_consistent_where_the_reference_statement_is_not():
+    """`omgtools.splines.since_knot`: the reference's `np.round(t, 6) % knot_time` (`problems/point2point.py:177`) everywhere but
+    where it contradicts the reference's own crossing test (`point2point.py:190-193`): T = 10 s, 11 knot intervals, t = 10.0 -- the
+    crossing test counts the 11th knot, the remainder reads 0.909 s.  The receding-horizon loop crosses that instant with consistent
+    initial conditions: no agent needs more than a handful of iterations there (62 with the verbatim statement)."""
+    from omgtools.splines import since_knot
+    kt = (int(10.0 * 1000.) / 11) / 1000.                                     # (`point2point.py:134`: 0.9090909090909092, one ulp above 10 / 11)
+    assert abs(float(np.round(10.0, 6) % kt) - kt) < 1e-12                  # the reference statement at t = 10.0: one interval off
+    assert int(np.round(9.9 / kt, 6)) < int(np.round(10.0 / kt, 6))         # ... while its crossing test shifts the plan
+    assert since_knot(10.0, kt) == 0.0 and since_knot(20.0, kt) == 0.0
+    for t in (0.0, 0.1, 0.5, 0.9, 1.0, 4.5, 9.9, 10.1, 17.3):                 # elsewhere: the reference's statement, bit for bit
+        assert since_knot(t, kt) == float(np.round(t, 6) % kt)
+    assert since_knot(1.0, 0.5) == 0.0 and since_knot(0.75, 0.5) == 0.25
+    from omgtools import workloads
+    from omgtools.batch import BatchP2P
+    from oracle import port_binding
+    problem, P = workloads.holonomic_p2p(1024)
+    sel = np.array([159, 35, 0, 1])                                           # (159: the 62-iteration agent of the verbatim clock)
+    m = BatchP2P(problem, dict(P, p=P['p'][sel], x0=P['x0'][sel]), ops=port_binding, options=dict(tol=1e-3, max_iter=300))
+    m.solve_cold(bends=())
+    m.time = 9.0                                                              # (the clock only: ten updates up to and across t = 10.0)
+    worst = 0
+    for k in range(12):
+        crossed = m.step()
+        if abs(m.time - 10.0) < 1e-9:
+            assert crossed and m.p[0, m.o_t] == 0.0
+        worst = max(worst, int(m.iters.max()))
+    assert (m.status == 0).all() and worst <= 12

@@ -146,3 +146,36 @@ def test_ipopt_absolute_tolerances_match_port(cfg2_small):
         assert np.array_equal(res['status'], ref['status']) and (res['status'] == 0).all()
         assert np.abs(res['iters'] - ref['iters']).max() <= 1
         assert np.abs(res['x'] - ref['x']).max() < 1e-6
+
+
+def test_refined_steps_match_port(cfg2_small):
+    """omgx_options version 9, `refine` = 1: iterative refinement of regularised Newton steps (one more solve with the factors of the
+    iteration, `kkt_solve2_wave` with the equality multipliers; the fall-back to the plain step when the first trial of the line search
+    does not accept the refined one).  The HIP path takes the decisions of the host build -- cold solves and warm-started re-solves at
+    moved parameters, tolerances 1e-3 and 1e-6 -- and needs fewer iterations than without the option at the tight tolerance; off (the
+    default) nothing changes."""
+    import omgtools.backend as be
+    from oracle import port_binding
+    problem, P = cfg2_small
+    tpl = problem.father.template
+    o_t = tpl.entry_range(problem.label, 't', 'par')[0]
+    p2 = P['p'].copy()
+    p2[:, o_t] += 0.1
+    total = {}
+    for tol in (1e-3, 1e-6):
+        for refine in (0, 1):
+            opts = dict(tol=tol, max_iter=300, refine=refine)
+            solver = be.BatchSolver(tpl, 8, options=opts)
+            res = solver.solve(P['p'], P['x0'])
+            ref = port_binding.solve(tpl, P['p'], P['x0'], **opts)
+            solver.close()
+            solver = be.BatchSolver(tpl, 8, options=dict(opts, warm_start=1))      # (a fresh handle: no inertia correction carried over, like the port call)
+            warm = solver.solve(p2, ref['x'], lam_g0=ref['lam_g'], status0=ref['status'])      # (both warm solves from the same point)
+            solver.close()
+            refw = port_binding.solve(tpl, p2, ref['x'], lam_g0=ref['lam_g'], status0=ref['status'], warm_start=1, **opts)
+            for got, want in ((res, ref), (warm, refw)):
+                assert np.array_equal(got['status'], want['status']) and (got['status'] == 0).all()
+                assert np.abs(got['iters'] - want['iters']).max() <= (1 if tol == 1e-3 else 3)
+                assert np.abs(got['x'] - want['x']).max() < (1e-6 if tol == 1e-3 else 2e-3)
+            total[(tol, refine)] = int(res['iters'].sum() + warm['iters'].sum())
+    assert total[(1e-6, 1)] < total[(1e-6, 0)]

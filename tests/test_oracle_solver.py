@@ -22,6 +22,20 @@ def test_port_matches_numpy_iteration_for_iteration(cfg2_small):
         assert r['iters'] == ref['iters'][b] == 24
         assert np.abs(r['x'] - ref['x'][b]).max() < 1e-9
         assert np.abs(r['lam_g'] - ref['lam_g'][b]).max() < 1e-9 * (1 + np.abs(r['lam_g']).max())
+    # round 6, omgx_options.refine = 1 (iterative refinement of regularised steps, with its fall-back to the plain step when the
+    # first trial does not accept the refined one): the same agreement over the 22 iterations all four need with it (the first of
+    # them then converges after 23 instead of 26)
+    ref = port_binding.solve(tpl, P['p'][:4], P['x0'][:4], tol=1e-6, max_iter=22, refine=1)
+    plain = port_binding.solve(tpl, P['p'][:4], P['x0'][:4], tol=1e-6, max_iter=22)
+    assert np.abs(ref['x'] - plain['x']).max() > 1e-6                      # (the option does something)
+    for b in range(4):
+        r = ipm_numpy.solve(nlp, P['x0'][b], P['p'][b], tpl.lb, tpl.ub, opts={'tol': 1e-6, 'max_iter': 22, 'refine': 1})
+        assert r['iters'] == ref['iters'][b] == 22
+        assert np.abs(r['x'] - ref['x'][b]).max() < 1e-9
+        assert np.abs(r['lam_g'] - ref['lam_g'][b]).max() < 1e-9 * (1 + np.abs(r['lam_g']).max())
+    full = port_binding.solve(tpl, P['p'][:4], P['x0'][:4], tol=1e-6, max_iter=150, refine=1)
+    base = port_binding.solve(tpl, P['p'][:4], P['x0'][:4], tol=1e-6, max_iter=150)
+    assert (full['status'] == 0).all() and full['iters'].sum() < base['iters'].sum()
     # ... and they stop at the same point (rounding differences grow in the last iterations, where the
     # barrier parameter is ~1e-7: the count may differ by a few)
     ref = port_binding.solve(tpl, P['p'][:4], P['x0'][:4], tol=3e-6, max_iter=150)
