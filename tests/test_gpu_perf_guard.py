@@ -82,3 +82,66 @@ def test_consensus_protocol_iteration_counts(kind):
     assert int((status == 0).sum().item()) == N
     _check(kind + '_x_update_mean_iters', float(stats[:, 1].sum()) / max(1, int(stats[:, 3].sum())))
     solver.close()
+
+
+def test_whole_manoeuvre_with_the_stop_rule():
+    """bench.py's `sustained` leg as a guard: cold solve, then 120 updates of the 1024-agent batch on the three-stream product path with
+    the stop rule of the solve kernel on (`omgx_batch_set_stop`: a vehicle's loop ends where the reference's `Simulator.run` ends it).
+    Every solve converges, every vehicle arrives, the solves the kernels count and the mean iterations are the committed ones, and the
+    update at t = T = 10.0 -- where the reference's knot clock contradicts itself, `omgtools.splines.since_knot` -- is an ordinary
+    crossing (slowest agent 62 iterations with the verbatim clock)."""
+    import torch
+    from omgtools import workloads
+    from omgtools.batch import receding_horizon_batch, StreamedP2P
+    dev = torch.device('cuda', 0)
+    problem, P = workloads.holonomic_p2p(1024)
+    rh = receding_horizon_batch(problem, P, device=dev, n_streams='auto', options=dict(tol=1e-3, max_iter=300))
+    assert isinstance(rh, StreamedP2P) and len(rh.parts) == 3
+    try:
+        rh.solve_cold(bends=())
+        rh.stop_at_arrival(1e-3)
+        n = 120
+        stats = [torch.zeros((n, 4), dtype=torch.int64, device=dev) for _ in rh.parts]
+        for m, sd in zip(rh.parts, stats):
+            m.solver.set_stats(sd)
+        for _ in range(n):
+            rh.step()
+        rh.synchronize()
+        st = sum(sd.cpu().numpy() for sd in stats).astype(float)
+        worst = np.max([sd.cpu().numpy()[:, 2] for sd in stats], axis=0)
+        for m in rh.parts:
+            m.solver.set_stats(None)
+        assert (st[:, 0] == st[:, 3]).all()                                   # every solve converged
+        assert st[0, 3] == 1024 and st[-1, 3] == 0 and (np.diff(st[:, 3]) <= 0).all()      # loops end, none starts again
+        assert int(rh.under_way.sum().item()) == 0
+        _check('p2p_manoeuvre_solves', st[:, 3].sum())
+        _check('p2p_manoeuvre_mean_iters', st[:, 1].sum() / st[:, 3].sum())
+        assert worst.max() <= 60 and worst[99] <= 4                          # (update 99: t = 10.0)
+    finally:
+        rh.close()
+
+
+def test_sub_batch_streams_are_shared_and_have_a_queue_level_of_their_own():
+    """`omgtools.batch.sub_batch_streams`: the sub-batches of every `StreamedP2P` of a device run on the same high-priority streams (the HIP
+    runtime maps streams onto four hardware queues per priority level at first use; on the default level two sub-batches could share
+    a queue depending on what the process had created before: 1.2 M instead of 2.2 M solves/s, profiles/r06_stream_placement.txt)."""
+    import torch
+    from omgtools import workloads
+    from omgtools.batch import StreamedP2P, sub_batch_streams
+    dev = torch.device('cuda', 0)
+    s3 = sub_batch_streams(dev, 3)
+    assert len(s3) == 3 and len({s.cuda_stream for s in s3}) == 3 and all(s.priority < 0 for s in s3)
+    assert [s.cuda_stream for s in sub_batch_streams(dev, 2)] == [s.cuda_stream for s in s3[:2]]
+    problem, P = workloads.holonomic_p2p(12)
+    a = StreamedP2P(problem, P, n_streams=3, device=dev, options=dict(tol=1e-3, max_iter=300))
+    b = StreamedP2P(problem, P, n_streams=2, device=dev, options=dict(tol=1e-3, max_iter=300))
+    try:
+        assert [s.cuda_stream for s in a.streams] == [s.cuda_stream for s in s3]
+        assert [s.cuda_stream for s in b.streams] == [s.cuda_stream for s in s3[:2]]
+        for m in (a, b):                                  # (two instances on the same streams: each a correct loop of its own)
+            m.solve_cold(bends=())
+        for _ in range(3):
+            a.step(); b.step()
+        assert np.array_equal(a.x.cpu().numpy(), b.x.cpu().numpy()) and (a.status.cpu().numpy() == 0).all()
+    finally:
+        a.close(); b.close()
