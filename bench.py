@@ -629,6 +629,35 @@ def sustained_leg(problem, P, opts, n_steps, dev, stop_tol=1e-3, stop_rule=True)
                      'solves_per_s counts an agent only until the logged states meet the reference\'s stop criterion')}
 
 
+def manoeuvre_rollout(problem, P, opts, n_steps, dev, stop_tol=1e-3):
+    """The whole manoeuvre as ONE launch (`omgx_batch_rollout` with the stop rule on): every agent runs its own loop -- prediction,
+    knot-crossing shift, warm-started solve -- until its state meets the reference's stop criterion, at most `n_steps` updates, without
+    the barrier between the updates of different agents.  For simulation / evaluation runs with ideal prediction (what `Simulator.run`
+    does for one vehicle); the same bits per agent as the per-step loop (tests/test_gpu_rollout.py)."""
+    from omgtools.batch import BatchP2P
+    m = BatchP2P(problem, P, ops='hip', device=dev, options=opts)
+    try:
+        m.solve_cold(bends=())
+        m.stop_at_arrival(stop_tol)
+        stats = torch.zeros((n_steps, 4), dtype=torch.int64, device=dev)
+        m.solver.set_stats(stats)
+        torch.cuda.synchronize()
+        quiet_host()
+        t_0 = time.perf_counter()
+        m.rollout(n_steps)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t_0
+        gc.enable()
+        m.solver.set_stats(None)
+        st = stats.cpu().numpy().astype(float)
+        return {'solves_per_s': float(st[:, 3].sum()) / wall, 'solves': int(st[:, 3].sum()), 'ms': wall * 1e3, 'solved_fraction': float(st[:, 0].sum()) / max(1.0, st[:, 3].sum()),
+                'mean_iters': float(st[:, 1].sum()) / max(1.0, st[:, 3].sum()), 'max_iters': int(st[:, 2].max()),
+                'agents_under_way_at_the_end': int(m.under_way.sum().item()),
+                'note': 'one launch for the whole manoeuvre: every agent loops until its state meets the stop criterion'}
+    finally:
+        m.solver.close()
+
+
 def without_solver_objects(fn, *a, **kw):
     """A front-end builder called for its template only (`Point2point.init` would create a solver object of its own)."""
     import omgtools.backend as be
@@ -1107,6 +1136,7 @@ def main():
         # the whole manoeuvre, and the accuracy / throughput curve over the solver settings (round-5 review, items 2 and 4)
         try:
             out['sustained'] = sustained_leg(problem, P, opts, args.sustained_steps, dev)
+            out['sustained']['as_one_rollout'] = manoeuvre_rollout(problem, P, opts, args.sustained_steps, dev)
             every = sustained_leg(problem, P, opts, args.sustained_steps, dev, stop_rule=False)
             out['sustained']['every_agent_solved_at_every_update'] = {k: every[k] for k in ('solves_per_s', 'ms_per_update', 'mean_iters', 'max_iters', 'solves', 'note')}
         except Exception as e:

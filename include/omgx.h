@@ -331,8 +331,9 @@ int  omgx_batch_set_prepare(omgx_batch* b, int32_t on);
  * target) before it solves an agent with under_way = 1; if it holds the flag is cleared for good.  An agent whose flag is 0 is not
  * solved: x <- x0 (it keeps its plan), lam_g and status stay as they are, iters = 0, the launch statistics and the fused
  * trajectory store skip it.  The agents under way are solved exactly as without the rule (same bits).  under_way = NULL switches
- * the rule off.  While the rule is on every solve does its own setup (omgx_batch_set_prepare is ignored); omgx_batch_rollout
- * does not apply it. */
+ * the rule off.  While the rule is on every solve does its own setup (omgx_batch_set_prepare is ignored).  omgx_batch_rollout applies
+ * the rule at the same place of a step (after prediction, obstacle motion and knot-crossing shift): the agent's loop inside the call
+ * ends there -- x, p, lam_g, status stay as they are at that step, the remaining steps log iters 0. */
 int  omgx_batch_set_stop(omgx_batch* b, int32_t o_state0, int32_t o_input0, int32_t o_poseT, int32_t n_dim, double stop_tol,
                          int32_t* under_way);
 

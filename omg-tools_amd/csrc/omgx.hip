@@ -697,6 +697,7 @@ struct RolloutArgs {
   omgx::Opts o_cross;
   unsigned long long* stats;            // [K][4] {solved, sum of iterations, max, agents} or nullptr
   int32_t* iters_log; int32_t* status_log;     // [K][n_agents] or nullptr
+  StopArgs stop; int stop_on;           // omgx_batch_set_stop: an agent's loop ends at the step its state meets the criterion
 };
 
 template <int MODE, bool WAVE_ONLY, bool GEN>
@@ -770,6 +771,25 @@ ipm_rollout_kernel(omgx::Dims d, omgx::Tables T, omgx::Opts o, int kkt_doubles, 
         __syncthreads();
         for (int i = threadIdx.x; i < d.n_con; i += blockDim.x) { const int s = rop->lam_perm[i]; lamb[i] = s >= 0 ? w.kkt[s] : 0.0; }
         __syncthreads();
+      }
+      // stop rule (omgx_batch_set_stop), where the solve kernel of the per-step path tests it -- after the glue of the step: the
+      // vehicle has arrived, its loop ends here (`execution/simulator.py:39-62`): plan, multipliers and status stay as they are,
+      // the remaining steps of the call log iters 0
+      if (rop->stop_on) {
+        const StopArgs sa = rop->stop;
+        bool go = sa.under_way[b] != 0;
+        if (go && omgx::stop_criterium(pb, sa.o_state, sa.o_input, sa.o_pose, sa.n_dim, sa.tol)) go = false;
+        __syncthreads();
+        if (!go) {
+          if (threadIdx.x == 0) {
+            sa.under_way[b] = 0; iters[b] = 0;
+            for (int k2 = k; k2 < K; ++k2) {
+              if (rop->iters_log) rop->iters_log[(size_t)k2 * n_agents + b] = 0;
+              if (rop->status_log) rop->status_log[(size_t)k2 * n_agents + b] = status[b];
+            }
+          }
+          break;
+        }
       }
       // (4) warm-started solve, results back to the agent's rows
       const omgx::Result r = omgx::ipm_solve(c, d, T, st.crossed ? rop->o_cross : o, w, pb, xb, lbb, ubb, o.warm_start ? lamb : nullptr,
@@ -970,6 +990,7 @@ struct omgx_batch {
   RolloutArgs* d_rollout = nullptr; RolloutStep* d_ro_steps = nullptr; int ro_steps_cap = 0; int32_t* d_ro_perm = nullptr;      // omgx_batch_rollout
   std::vector<int32_t> ro_perm_host;
   StopArgs* d_stop = nullptr;       // omgx_batch_set_stop: device copy of the arguments
+  StopArgs stop_host = {};          // (and the host copy: omgx_batch_rollout hands it to its kernel inside RolloutArgs)
   bool stop_on = false;
   CenterArgs* d_center = nullptr;   // omgx_batch_set_center: device copy of the arguments (nullptr: off); the slot map behind it
   int32_t* d_pub_inv = nullptr;
@@ -1612,6 +1633,7 @@ int omgx_batch_set_stop(omgx_batch* b, int32_t o_state0, int32_t o_input0, int32
   sa.o_state = o_state0; sa.o_input = o_input0; sa.o_pose = o_poseT; sa.n_dim = n_dim; sa.tol = stop_tol; sa.under_way = under_way;
   HIPCHK(hipMemcpyAsync(b->d_stop, &sa, sizeof(StopArgs), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
+  b->stop_host = sa;
   b->stop_on = true;
   return OMGX_OK;
 }
@@ -2189,6 +2211,7 @@ int omgx_batch_rollout(omgx_batch* b, const omgx_rollout_spec* sp, double* p, do
     a.o_cross.warm_z_cap = co.warm_z_cap; a.o_cross.max_iter = co.max_iter; a.o_cross.tol = co.tol; a.o_cross.max_soc = co.max_soc; a.o_cross.refine = co.refine > 0 ? 1 : 0;
   }
   // per-step statistics: the slots the next n_steps single launches would have taken (omgx_batch_set_stats)
+  a.stop_on = b->stop_on ? 1 : 0; a.stop = b->stop_host;
   a.stats = nullptr;
   if (b->d_stats) {
     if (sp->n_steps > b->stats_slots - (int)(b->stats_launch % b->stats_slots)) { g_err = "rollout: the stats array has fewer free slots than steps"; return OMGX_E_INVALID; }

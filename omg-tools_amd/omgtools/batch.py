@@ -396,7 +396,8 @@ class BatchP2P(object):
         is not solved at that update or any later one (`execution/simulator.py:39-62` leaves its `while` loop; a fleet's
         vehicles arrive at different updates) -- it keeps its plan, its multipliers and its status, `iters` reads 0.  Device loop:
         the rule is the solve kernel's (`omgx_batch_set_stop`, no launch of its own); `under_way` [B] (int32 tensor / bool array)
-        holds who is still running.  The agents under way are solved exactly as without the rule.  `rollout` does not apply it."""
+        holds who is still running.  The agents under way are solved exactly as without the rule.  `rollout` applies it too: an agent's
+        loop inside the launch ends at the step its state meets the criterion (its plan stays as it is at that step)."""
         if not on:
             self.under_way = None
             if self.kind == 'hip':

@@ -212,3 +212,49 @@ def test_the_per_step_product_path_picks_two_half_launches_for_two_rounds_of_wor
         assert torch.equal(getattr(rh, name), getattr(one, name)), name       # (the properties join the streams)
     assert abs(rh.time - one.time) < 1e-12
     rh.close(); one.solver.close()
+
+
+def test_rollout_applies_the_stop_rule_like_the_stepwise_loop():
+    """`omgx_batch_rollout` with `omgx_batch_set_stop` on (`BatchP2P.stop_at_arrival`): inside the one launch an agent's loop ends at the
+    step its state meets the reference's stop criterion -- the step at which the solve kernel of the stepwise loop stops solving it.
+    Same flags, the same iteration counts step by step (0 from the stop on), the same bits for the agents still under way at the end;
+    an agent that stopped keeps the plan it had at that step (the stepwise loop goes on shifting it at later knot crossings)."""
+    import torch
+    from omgtools import workloads
+    from omgtools.batch import BatchP2P
+    B, K = 24, 40
+    problem, P = workloads.holonomic_p2p(B)
+    dev = torch.device('cuda', 0)
+    opts = dict(tol=1e-3, max_iter=300)
+    step, roll = (BatchP2P(problem, P, ops='hip', device=dev, options=opts) for _ in range(2))
+    try:
+        for m in (step, roll):
+            m.stop_at_arrival(stop_tol=2.5)
+            m.solve_cold(bends=())
+        it_hist = np.zeros((K, B), dtype=np.int32)
+        x_at_stop = {}
+        was = np.ones(B, dtype=bool)
+        for k in range(K):
+            step.step()
+            it_hist[k] = step.host('iters')
+            now = step.host('under_way') != 0
+            for b in np.flatnonzero(was & ~now):
+                x_at_stop[int(b)] = step.host('x')[b].copy()
+            was = now
+        iters_log = torch.zeros((K, B), dtype=torch.int32, device=dev)
+        status_log = torch.full((K, B), -1, dtype=torch.int32, device=dev)
+        stats = torch.zeros((K, 4), dtype=torch.int64, device=dev)
+        roll.solver.set_stats(stats)
+        roll.rollout(K, iters_log=iters_log, status_log=status_log)
+        torch.cuda.synchronize()
+        roll.solver.set_stats(None)
+        under = roll.host('under_way') != 0
+        assert np.array_equal(under, was) and 0 < under.sum() < B and len(x_at_stop) == int((~under).sum())
+        assert np.array_equal(iters_log.cpu().numpy(), it_hist) and (status_log.cpu().numpy() == 0).all()
+        assert np.array_equal(stats[:, 3].cpu().numpy(), (it_hist > 0).sum(axis=1)) and np.array_equal(stats[:, 1].cpu().numpy(), it_hist.sum(axis=1))
+        for name in ('x', 'lam', 'p'):
+            assert np.array_equal(roll.host(name)[under], step.host(name)[under]), name
+        for b, xb in x_at_stop.items():
+            assert np.array_equal(roll.host('x')[b], xb), b
+    finally:
+        step.solver.close(); roll.solver.close()
